@@ -1,0 +1,153 @@
+/*
+ * rslo_hip.h -- C ABI of librslo_hip.so, the MI355X (gfx950) implementation of the
+ * RSLO two-frame LiDAR-odometry hot path.
+ *
+ * Boundary rules
+ *   - extern "C", plain device pointers + sizes, no torch types.  Every pointer is a
+ *     DEVICE pointer unless the parameter name starts with h_.
+ *   - The caller owns every buffer (inputs, outputs, workspaces).  Nothing is allocated
+ *     or freed inside the library; *_ws_bytes() functions size the workspaces.
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing
+ *     synchronises.  Data-dependent counts are written to device ints the caller reads.
+ *   - Return value: 0 on success, a negative RSLO_E* code otherwise; rslo_last_error()
+ *     gives the text (thread-local).
+ *   - Coordinates are int32 (b, z, y, x); features are row-major fp32 [rows, channels];
+ *     sparse-conv weights are [K = kz*ky*kx, Cin, Cout] (a view of spconv's
+ *     [kz,ky,kx,Cin,Cout]); a neighbour table nbr[rows*K] holds the contributing row of
+ *     the other side for kernel offset k, or -1.
+ *
+ * Each entry point cites the reference interface it replaces (paths relative to the
+ * DecaYale/RSLO tree).  The spconv_plus / apex / kornia sources are not part of that tree
+ * (Dockerfile:55-61,93-97; freeze.yml:212); for those the call site is cited.
+ */
+#ifndef RSLO_HIP_H_
+#define RSLO_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define RSLO_API __attribute__((visibility("default")))
+#else
+#define RSLO_API
+#endif
+
+#define RSLO_OK 0
+#define RSLO_EINVAL (-1)   /* bad argument / unsupported shape                         */
+#define RSLO_ELAUNCH (-2)  /* hipLaunch / runtime error                                */
+#define RSLO_ERANGE (-3)   /* linear voxel index does not fit the 32-bit key space     */
+#define RSLO_EWS (-4)      /* workspace too small                                      */
+
+RSLO_API int rslo_abi_version(void);
+RSLO_API const char *rslo_last_error(void);
+
+/* ------------------------------------------------------------------------------------
+ * a1  Voxelization.  Replaces spconv.utils.VoxelGenerator.generate
+ *     (rslo/builder/voxel_builder.py:36-54,83-94; called rslo/data/preprocess.py:493).
+ * points [P,F] fp32 (x,y,z first).  First-come voxel numbering in point order, at most
+ * T points per voxel kept in point order, processing stops at the first point that would
+ * open voxel number max_voxels, coordinates stored (z,y,x).
+ * Outputs are sized for max_voxels; rows >= *d_nvox are zero.
+ * ------------------------------------------------------------------------------------ */
+RSLO_API size_t rslo_voxelize_ws_bytes(int64_t P);
+RSLO_API int rslo_voxelize(const float *points, int64_t P, int F, const float *h_range6,
+                  const float *h_vsize3, const int32_t *h_grid_xyz, int T, int max_voxels,
+                  void *ws, size_t ws_bytes, float *voxels /*[max_voxels,T,F]*/,
+                  int32_t *coords /*[max_voxels,3] zyx*/, int32_t *num_points /*[max_voxels]*/,
+                  int32_t *d_nvox /*[1]*/, void *stream);
+
+/* a4  SimpleVoxel_XYZINormalC.forward (rslo/models/voxel_encoder.py:258-280):
+ *     per-voxel mean of the F features, channels 4:7 divided by (norm + 1e-12). */
+RSLO_API int rslo_vfe_mean(const float *voxels /*[M,T,F]*/, const int32_t *num_points /*[M]*/, int64_t M,
+                  int T, int F, float *out /*[M,F]*/, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * a5  Site index + rulebooks.  Replace the implicit indice-pair builds behind
+ *     spconv.SparseConvTensor / SubMConv3d / SparseConv3d / SparseInverseConv3d
+ *     (rslo/models/middle.py:119-213,223-225).
+ * The site index is an open-addressing hash: keys[cap] (uint32 linear index, 0xFFFFFFFF =
+ * empty), vals[cap] (row).  cap = rslo_hash_capacity(n) (power of two >= 2n).
+ * ------------------------------------------------------------------------------------ */
+RSLO_API int64_t rslo_hash_capacity(int64_t n);
+RSLO_API int rslo_hash_build(const int32_t *coords /*[N,4]*/, int64_t N, int B, const int32_t *h_dims3,
+                    uint32_t *keys, int32_t *vals, int64_t cap, void *stream);
+/* SubM: output set == input set in the given order; nbr[o][k] = row at coords[o]+(k-ks/2). */
+RSLO_API int rslo_rulebook_subm(const int32_t *coords, int64_t N, int B, const int32_t *h_dims3,
+                       const int32_t *h_ks3, const uint32_t *keys, const int32_t *vals, int64_t cap,
+                       int32_t *nbr /*[N,K]*/, void *stream);
+/* Strided conv, step 1: mark the output sites (in = out*stride - pad + k) in a bitmap over
+ * the output volume and rank them; *d_count receives the number of output sites M.
+ * words = rslo_conv_bitmap_words(B, out_dims).  scan_ws: rslo_scan_ws_bytes(words). */
+RSLO_API int64_t rslo_conv_bitmap_words(int B, const int32_t *h_out_dims3);
+RSLO_API size_t rslo_scan_ws_bytes(int64_t n);
+RSLO_API int rslo_conv_out_count(const int32_t *coords_in, int64_t N, int B, const int32_t *h_ks3,
+                        const int32_t *h_stride3, const int32_t *h_pad3, const int32_t *h_out_dims3,
+                        uint32_t *bitmap /*[words]*/, int32_t *word_prefix /*[words]*/, int64_t words,
+                        void *scan_ws, size_t scan_ws_bytes, int32_t *d_count /*[1]*/, void *stream);
+/* step 2: emit the M output coordinates in ascending linear-index order. */
+RSLO_API int rslo_conv_out_coords(const uint32_t *bitmap, const int32_t *word_prefix, int64_t words, int B,
+                         const int32_t *h_out_dims3, int32_t *out_coords /*[M,4]*/, int64_t M,
+                         void *stream);
+/* step 3: nbr[o][k] = input row at out*stride - pad + k (probe of the INPUT site index). */
+RSLO_API int rslo_rulebook_conv(const int32_t *coords_out, int64_t M, int B, const int32_t *h_in_dims3,
+                       const int32_t *h_ks3, const int32_t *h_stride3, const int32_t *h_pad3,
+                       const uint32_t *in_keys, const int32_t *in_vals, int64_t in_cap,
+                       int32_t *nbr /*[M,K]*/, void *stream);
+/* step 4: nbrT[i][k] = output row o with o*stride - pad + k == in (probe of the OUTPUT index);
+ * the table the dgrad and SparseInverseConv3d use. */
+RSLO_API int rslo_rulebook_conv_T(const int32_t *coords_in, int64_t N, int B, const int32_t *h_out_dims3,
+                         const int32_t *h_ks3, const int32_t *h_stride3, const int32_t *h_pad3,
+                         const uint32_t *out_keys, const int32_t *out_vals, int64_t out_cap,
+                         int32_t *nbrT /*[N,K]*/, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * a6/a7  Sparse convolution arithmetic (spconv SubMConv3d / SparseConv3d /
+ *        SparseInverseConv3d forward + backward; call sites middle.py:119-213).
+ * fwd : out[o] = act( bias + sum_k in[nbr[o][k]] . W[kk] ),  kk = flip_k ? K-1-k : k
+ *       act = LeakyReLU(slope) fused when slope != 1 (middle.py:99-101,123...).
+ * dgrad: din[i] = sum_k dout[nbrT[i][k]] . W[kk]^T   (for SubM pass nbr and flip_k=1)
+ * wgrad: dW[k]  = sum_o in[nbr[o][k]]^T dout[o]      (deterministic two-stage reduce)
+ * Supported channel counts: 1..64 on both sides.
+ * ------------------------------------------------------------------------------------ */
+RSLO_API int rslo_spconv_fwd(const float *in, int cin, const float *W, const float *bias, const int32_t *nbr,
+                    int64_t n_out, int K, int cout, int flip_k, float act_slope, float *out,
+                    void *stream);
+RSLO_API int rslo_spconv_dgrad(const float *dout, int cout, const float *W, const int32_t *nbrT, int64_t n_in,
+                      int K, int cin, int flip_k, float *din, void *stream);
+RSLO_API size_t rslo_spconv_wgrad_ws_bytes(int64_t n_out, int K, int cin, int cout);
+RSLO_API int rslo_spconv_wgrad(const float *in, int cin, const float *dout, int cout, const int32_t *nbr,
+                      int64_t n_out, int K, void *ws, size_t ws_bytes, float *dW /*[K,cin,cout]*/,
+                      float *dbias /*[cout] or NULL*/, void *stream);
+/* LeakyReLU backward from the saved OUTPUT (sign-preserving): g = dout * (y > 0 ? 1 : slope). */
+RSLO_API int rslo_leaky_bwd(const float *y, const float *dout, int64_t n, float slope, float *g, void *stream);
+
+/* a8  SparseConvTensor.dense() + view (middle.py:240-243): [M,C] rows -> [B,C,D,H,W]
+ *     (zero-filled here) and its backward gather. */
+RSLO_API int rslo_dense_scatter(const float *feat, const int32_t *coords, int64_t M, int C, int B,
+                       const int32_t *h_dims3, float *out, void *stream);
+RSLO_API int rslo_dense_gather(const float *dense, const int32_t *coords, int64_t M, int C, int B,
+                      const int32_t *h_dims3, float *dfeat, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * a17  Chamfer nearest neighbour.  Replaces cd.forward_cuda_one_direction /
+ *      cd.backward_cuda_one_direction (thirdparty/chamfer_distance/chamfer_distance.cpp:62-76,
+ *      94-113; kernels chamfer_distance.cu:6-137,177-206).  Arithmetic follows the CPU
+ *      nnsearch (chamfer_distance.cpp:116-144): fp32 products and sums without contraction,
+ *      strict '<' so the lowest index wins ties -- bit-exact dist and idx vs that path.
+ * ------------------------------------------------------------------------------------ */
+RSLO_API size_t rslo_chamfer_ws_bytes(int B, int N, int M);
+RSLO_API int rslo_chamfer_nn(const float *xyz1 /*[B,N,3]*/, const float *xyz2 /*[B,M,3]*/, int B, int N, int M,
+                    float *dist /*[B,N]*/, int32_t *idx /*[B,N]*/, void *ws, size_t ws_bytes,
+                    void *stream);
+RSLO_API int rslo_chamfer_grad(const float *xyz1, const float *xyz2, int B, int N, int M,
+                      const float *graddist1, const int32_t *idx1, float *gradxyz1 /*[B,N,3]*/,
+                      float *gradxyz2 /*[B,M,3]*/, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RSLO_HIP_H_ */

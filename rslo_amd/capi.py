@@ -1,0 +1,289 @@
+"""ctypes binding of librslo_hip.so (include/rslo_hip.h) for torch tensors on a ROCm device.
+
+This is the only place where Python meets the C ABI.  Tensors are passed as raw device
+pointers plus sizes; work is enqueued on torch's current HIP stream.  There is NO fallback:
+if the library is missing or a call fails, an exception is raised.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librslo_hip.so")
+_lib = None
+
+_I3 = C.c_int32 * 3
+_F3 = C.c_float * 3
+_F6 = C.c_float * 6
+
+# name -> (restype, argtypes); checked against include/rslo_hip.h by tests/test_cabi.py
+_vp, _i, _i64, _sz, _f = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_float
+SIGNATURES = {
+    "rslo_abi_version": (C.c_int, []),
+    "rslo_last_error": (C.c_char_p, []),
+    "rslo_voxelize_ws_bytes": (_sz, [_i64]),
+    "rslo_voxelize": (C.c_int, [_vp, _i64, _i, _vp, _vp, _vp, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
+    "rslo_vfe_mean": (C.c_int, [_vp, _vp, _i64, _i, _i, _vp, _vp]),
+    "rslo_hash_capacity": (_i64, [_i64]),
+    "rslo_hash_build": (C.c_int, [_vp, _i64, _i, _vp, _vp, _vp, _i64, _vp]),
+    "rslo_rulebook_subm": (C.c_int, [_vp, _i64, _i, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "rslo_conv_bitmap_words": (_i64, [_i, _vp]),
+    "rslo_scan_ws_bytes": (_sz, [_i64]),
+    "rslo_conv_out_count": (C.c_int, [_vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _sz, _vp, _vp]),
+    "rslo_conv_out_coords": (C.c_int, [_vp, _vp, _i64, _i, _vp, _vp, _i64, _vp]),
+    "rslo_rulebook_conv": (C.c_int, [_vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "rslo_rulebook_conv_T": (C.c_int, [_vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "rslo_spconv_fwd": (C.c_int, [_vp, _i, _vp, _vp, _vp, _i64, _i, _i, _i, _f, _vp, _vp]),
+    "rslo_spconv_dgrad": (C.c_int, [_vp, _i, _vp, _vp, _i64, _i, _i, _i, _vp, _vp]),
+    "rslo_spconv_wgrad_ws_bytes": (_sz, [_i64, _i, _i, _i]),
+    "rslo_spconv_wgrad": (C.c_int, [_vp, _i, _vp, _i, _vp, _i64, _i, _vp, _sz, _vp, _vp, _vp]),
+    "rslo_leaky_bwd": (C.c_int, [_vp, _vp, _i64, _f, _vp, _vp]),
+    "rslo_dense_scatter": (C.c_int, [_vp, _vp, _i64, _i, _i, _vp, _vp, _vp]),
+    "rslo_dense_gather": (C.c_int, [_vp, _vp, _i64, _i, _i, _vp, _vp, _vp]),
+    "rslo_chamfer_ws_bytes": (_sz, [_i, _i, _i]),
+    "rslo_chamfer_nn": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "rslo_chamfer_grad": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+}
+
+
+class RsloHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load librslo_hip.so; raise (never fall back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RsloHipError(
+                "librslo_hip.so not found at %s -- build it with `python -m rslo_amd.build` "
+                "(there is no CPU fallback for the RSLO hot path)" % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def _chk(rc, name):
+    if rc != 0:
+        raise RsloHipError("%s failed (%d): %s" % (name, rc, lib().rslo_last_error().decode()))
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t, dtype=None, name="tensor"):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RsloHipError("%s must live on the GPU (the RSLO hot path has no CPU fallback)" % name)
+    if dtype is not None and t.dtype != dtype:
+        raise RsloHipError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise RsloHipError("%s must be contiguous" % name)
+    return C.c_void_p(t.data_ptr())
+
+
+def _i3(x):
+    return _I3(*[int(v) for v in x])
+
+
+def _ws(nbytes, device):
+    return torch.empty((max(int(nbytes), 16),), dtype=torch.uint8, device=device)
+
+
+# --------------------------------------------------------------------------------------
+# voxelization / VFE
+# --------------------------------------------------------------------------------------
+def voxelize(points, pc_range, voxel_size, grid_xyz, max_points, max_voxels):
+    """points [P,F] f32 cuda -> (voxels [max_voxels,T,F], coords [max_voxels,3] zyx, num [max_voxels],
+    d_nvox [1] int32 on device).  Rows >= nvox are zero; the caller slices after reading nvox."""
+    P, F = points.shape
+    dev = points.device
+    voxels = torch.empty((max_voxels, max_points, F), dtype=torch.float32, device=dev)
+    coords = torch.empty((max_voxels, 3), dtype=torch.int32, device=dev)
+    num = torch.empty((max_voxels,), dtype=torch.int32, device=dev)
+    nvox = torch.empty((1,), dtype=torch.int32, device=dev)
+    wsb = lib().rslo_voxelize_ws_bytes(P)
+    ws = _ws(wsb, dev)
+    r = _F6(*[float(v) for v in pc_range])
+    v = _F3(*[float(x) for x in voxel_size])
+    g = _i3(grid_xyz)
+    _chk(lib().rslo_voxelize(_ptr(points, torch.float32, "points"), P, F, r, v, g, int(max_points),
+                             int(max_voxels), _ptr(ws), wsb, _ptr(voxels), _ptr(coords), _ptr(num),
+                             _ptr(nvox), _stream()), "rslo_voxelize")
+    return voxels, coords, num, nvox
+
+
+def vfe_mean(voxels, num_points):
+    M, T, F = voxels.shape
+    out = torch.empty((M, F), dtype=torch.float32, device=voxels.device)
+    _chk(lib().rslo_vfe_mean(_ptr(voxels, torch.float32, "voxels"), _ptr(num_points, torch.int32, "num_points"),
+                             M, T, F, _ptr(out), _stream()), "rslo_vfe_mean")
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# site index + rulebooks
+# --------------------------------------------------------------------------------------
+class SiteIndex:
+    """Hash over the active sites of one level: coords [N,4] int32 (b,z,y,x)."""
+
+    def __init__(self, coords, batch, dims):
+        self.coords = coords
+        self.batch = int(batch)
+        self.dims = [int(d) for d in dims]
+        N = coords.shape[0]
+        self.cap = int(lib().rslo_hash_capacity(N))
+        self.keys = torch.empty((self.cap,), dtype=torch.int32, device=coords.device)
+        self.vals = torch.empty((self.cap,), dtype=torch.int32, device=coords.device)
+        _chk(lib().rslo_hash_build(_ptr(coords, torch.int32, "coords"), N, self.batch, _i3(self.dims),
+                                   _ptr(self.keys), _ptr(self.vals), self.cap, _stream()), "rslo_hash_build")
+
+
+def rulebook_subm(index, ks):
+    N = index.coords.shape[0]
+    K = int(ks[0] * ks[1] * ks[2])
+    nbr = torch.empty((N, K), dtype=torch.int32, device=index.coords.device)
+    _chk(lib().rslo_rulebook_subm(_ptr(index.coords), N, index.batch, _i3(index.dims), _i3(ks),
+                                  _ptr(index.keys), _ptr(index.vals), index.cap, _ptr(nbr), _stream()),
+         "rslo_rulebook_subm")
+    return nbr
+
+
+def conv_out_dims(in_dims, ks, stride, pad):
+    return [(int(d) + 2 * int(p) - int(k)) // int(s) + 1 for d, k, s, p in zip(in_dims, ks, stride, pad)]
+
+
+def rulebook_conv(index, ks, stride, pad):
+    """Strided conv rulebook.  Returns (out_index: SiteIndex, nbr [M,K], nbrT [N,K]).
+    One device->host read (the output count) is unavoidable: it sizes the output tensors."""
+    dev = index.coords.device
+    N = index.coords.shape[0]
+    K = int(ks[0] * ks[1] * ks[2])
+    od = conv_out_dims(index.dims, ks, stride, pad)
+    words = int(lib().rslo_conv_bitmap_words(index.batch, _i3(od)))
+    bitmap = torch.empty((words,), dtype=torch.int32, device=dev)
+    prefix = torch.empty((words,), dtype=torch.int32, device=dev)
+    swb = lib().rslo_scan_ws_bytes(words)
+    sws = _ws(swb, dev)
+    cnt = torch.empty((1,), dtype=torch.int32, device=dev)
+    _chk(lib().rslo_conv_out_count(_ptr(index.coords), N, index.batch, _i3(ks), _i3(stride), _i3(pad),
+                                   _i3(od), _ptr(bitmap), _ptr(prefix), words, _ptr(sws), swb, _ptr(cnt),
+                                   _stream()), "rslo_conv_out_count")
+    M = int(cnt.item())
+    out_coords = torch.empty((M, 4), dtype=torch.int32, device=dev)
+    _chk(lib().rslo_conv_out_coords(_ptr(bitmap), _ptr(prefix), words, index.batch, _i3(od),
+                                    _ptr(out_coords), M, _stream()), "rslo_conv_out_coords")
+    out_index = SiteIndex(out_coords, index.batch, od)
+    nbr = torch.empty((M, K), dtype=torch.int32, device=dev)
+    _chk(lib().rslo_rulebook_conv(_ptr(out_coords), M, index.batch, _i3(index.dims), _i3(ks), _i3(stride),
+                                  _i3(pad), _ptr(index.keys), _ptr(index.vals), index.cap, _ptr(nbr),
+                                  _stream()), "rslo_rulebook_conv")
+    nbrT = torch.empty((N, K), dtype=torch.int32, device=dev)
+    _chk(lib().rslo_rulebook_conv_T(_ptr(index.coords), N, index.batch, _i3(od), _i3(ks), _i3(stride),
+                                    _i3(pad), _ptr(out_index.keys), _ptr(out_index.vals), out_index.cap,
+                                    _ptr(nbrT), _stream()), "rslo_rulebook_conv_T")
+    return out_index, nbr, nbrT
+
+
+# --------------------------------------------------------------------------------------
+# sparse conv arithmetic
+# --------------------------------------------------------------------------------------
+def spconv_fwd(x, W, bias, nbr, flip_k=False, act_slope=1.0):
+    """x [Nin,Cin], W [K,Cin,Cout], nbr [Nout,K] -> [Nout,Cout]."""
+    n_out, K = nbr.shape
+    Kw, cin, cout = W.shape
+    if Kw != K or x.shape[1] != cin:
+        raise RsloHipError("spconv_fwd: shape mismatch x%s W%s nbr%s" % (tuple(x.shape), tuple(W.shape), tuple(nbr.shape)))
+    out = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
+    _chk(lib().rslo_spconv_fwd(_ptr(x, torch.float32, "x"), cin, _ptr(W, torch.float32, "W"),
+                               _ptr(bias, torch.float32, "bias"), _ptr(nbr, torch.int32, "nbr"), n_out, K, cout,
+                               int(flip_k), float(act_slope), _ptr(out), _stream()), "rslo_spconv_fwd")
+    return out
+
+
+def spconv_dgrad(dout, W, nbrT, flip_k=False):
+    """dout [Nout,Cout], W [K,Cin,Cout], nbrT [Nin,K] -> din [Nin,Cin]."""
+    n_in, K = nbrT.shape
+    Kw, cin, cout = W.shape
+    if Kw != K or dout.shape[1] != cout:
+        raise RsloHipError("spconv_dgrad: shape mismatch")
+    din = torch.empty((n_in, cin), dtype=torch.float32, device=dout.device)
+    _chk(lib().rslo_spconv_dgrad(_ptr(dout, torch.float32, "dout"), cout, _ptr(W, torch.float32, "W"),
+                                 _ptr(nbrT, torch.int32, "nbrT"), n_in, K, cin, int(flip_k), _ptr(din),
+                                 _stream()), "rslo_spconv_dgrad")
+    return din
+
+
+def spconv_wgrad(x, dout, nbr, cin, cout, with_bias=True):
+    n_out, K = nbr.shape
+    dev = x.device
+    dW = torch.empty((K, cin, cout), dtype=torch.float32, device=dev)
+    db = torch.empty((cout,), dtype=torch.float32, device=dev) if with_bias else None
+    wsb = lib().rslo_spconv_wgrad_ws_bytes(n_out, K, cin, cout)
+    ws = _ws(wsb, dev)
+    _chk(lib().rslo_spconv_wgrad(_ptr(x, torch.float32, "x"), cin, _ptr(dout, torch.float32, "dout"), cout,
+                                 _ptr(nbr, torch.int32, "nbr"), n_out, K, _ptr(ws), wsb, _ptr(dW), _ptr(db),
+                                 _stream()), "rslo_spconv_wgrad")
+    return dW, db
+
+
+def leaky_bwd(y, dout, slope):
+    g = torch.empty_like(dout)
+    _chk(lib().rslo_leaky_bwd(_ptr(y, torch.float32, "y"), _ptr(dout, torch.float32, "dout"), y.numel(),
+                              float(slope), _ptr(g), _stream()), "rslo_leaky_bwd")
+    return g
+
+
+def dense_scatter(feat, coords, batch, dims):
+    M, Cc = feat.shape
+    out = torch.empty((batch, Cc, dims[0], dims[1], dims[2]), dtype=torch.float32, device=feat.device)
+    _chk(lib().rslo_dense_scatter(_ptr(feat, torch.float32, "feat"), _ptr(coords, torch.int32, "coords"), M, Cc,
+                                  int(batch), _i3(dims), _ptr(out), _stream()), "rslo_dense_scatter")
+    return out
+
+
+def dense_gather(dense, coords, C_, batch, dims):
+    M = coords.shape[0]
+    out = torch.empty((M, C_), dtype=torch.float32, device=dense.device)
+    _chk(lib().rslo_dense_gather(_ptr(dense, torch.float32, "dense"), _ptr(coords, torch.int32, "coords"), M, C_,
+                                 int(batch), _i3(dims), _ptr(out), _stream()), "rslo_dense_gather")
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# chamfer
+# --------------------------------------------------------------------------------------
+def chamfer_nn(xyz1, xyz2, dist=None, idx=None):
+    B, N, _ = xyz1.shape
+    M = xyz2.shape[1]
+    dev = xyz1.device
+    if dist is None:
+        dist = torch.empty((B, N), dtype=torch.float32, device=dev)
+    if idx is None:
+        idx = torch.empty((B, N), dtype=torch.int32, device=dev)
+    wsb = lib().rslo_chamfer_ws_bytes(B, N, M)
+    ws = _ws(wsb, dev)
+    _chk(lib().rslo_chamfer_nn(_ptr(xyz1, torch.float32, "xyz1"), _ptr(xyz2, torch.float32, "xyz2"), B, N, M,
+                               _ptr(dist, torch.float32, "dist"), _ptr(idx, torch.int32, "idx"), _ptr(ws), wsb,
+                               _stream()), "rslo_chamfer_nn")
+    return dist, idx
+
+
+def chamfer_grad(xyz1, xyz2, graddist1, idx1, g1=None, g2=None):
+    B, N, _ = xyz1.shape
+    M = xyz2.shape[1]
+    if g1 is None:
+        g1 = torch.empty_like(xyz1)
+    if g2 is None:
+        g2 = torch.empty_like(xyz2)
+    _chk(lib().rslo_chamfer_grad(_ptr(xyz1, torch.float32, "xyz1"), _ptr(xyz2, torch.float32, "xyz2"), B, N, M,
+                                 _ptr(graddist1, torch.float32, "graddist1"), _ptr(idx1, torch.int32, "idx1"),
+                                 _ptr(g1), _ptr(g2), _stream()), "rslo_chamfer_grad")
+    return g1, g2

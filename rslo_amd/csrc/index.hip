@@ -1,0 +1,624 @@
+// Site index (hash), rulebook builders, voxelizer, VFE mean and dense scatter for gfx950.
+// All kernels are HBM/L2-bound integer work: one thread per (site, kernel-offset) with the
+// offset fastest so table writes are coalesced; the hash tables (<= a few MB) live in L2.
+#include <stdarg.h>
+
+#include "rslo_common.h"
+
+// ---------------------------------------------------------------------------------------
+// error text
+// ---------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+extern "C" void rslo_set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char *rslo_last_error(void) { return g_err; }
+extern "C" int rslo_abi_version(void) { return 1; }
+
+// ---------------------------------------------------------------------------------------
+// exclusive scan of int32 values (or popcounts of uint32 words), 1024 elements per block
+// ---------------------------------------------------------------------------------------
+#define SCAN_BLOCK 256
+#define SCAN_ITEMS 4
+#define SCAN_TILE (SCAN_BLOCK * SCAN_ITEMS)
+
+template <bool POPC>
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_block(const uint32_t *__restrict__ in,
+                                                           int32_t *__restrict__ out,
+                                                           int32_t *__restrict__ sums, int64_t n) {
+  __shared__ int32_t wsum[SCAN_BLOCK / 64];
+  const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+  int32_t v[SCAN_ITEMS];
+  int32_t tsum = 0;
+#pragma unroll
+  for (int j = 0; j < SCAN_ITEMS; ++j) {
+    uint32_t x = (base + j < n) ? in[base + j] : 0u;
+    v[j] = POPC ? __popc(x) : (int32_t)x;
+    tsum += v[j];
+  }
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  int32_t inc = tsum;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    int32_t t = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += t;
+  }
+  if (lane == 63) wsum[wid] = inc;
+  __syncthreads();
+  int32_t woff = 0;
+  for (int w = 0; w < wid; ++w) woff += wsum[w];
+  int32_t run = woff + inc - tsum;
+#pragma unroll
+  for (int j = 0; j < SCAN_ITEMS; ++j) {
+    if (base + j < n) out[base + j] = run;
+    run += v[j];
+  }
+  if (threadIdx.x == SCAN_BLOCK - 1) sums[blockIdx.x] = woff + inc;
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_sums(int32_t *__restrict__ sums, int64_t nb,
+                                                          int32_t *__restrict__ total) {
+  __shared__ int32_t wsum[SCAN_BLOCK / 64];
+  __shared__ int32_t carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  for (int64_t b0 = 0; b0 < nb; b0 += SCAN_BLOCK) {
+    int64_t i = b0 + threadIdx.x;
+    int32_t v = (i < nb) ? sums[i] : 0;
+    int32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      int32_t t = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += t;
+    }
+    if (lane == 63) wsum[wid] = inc;
+    __syncthreads();
+    int32_t woff = carry_s;
+    for (int w = 0; w < wid; ++w) woff += wsum[w];
+    if (i < nb) sums[i] = woff + inc - v;
+    __syncthreads();
+    if (threadIdx.x == SCAN_BLOCK - 1) carry_s = woff + inc;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && total) *total = carry_s;
+}
+
+__global__ void k_scan_add(int32_t *__restrict__ out, const int32_t *__restrict__ sums, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] += sums[i / SCAN_TILE];
+}
+
+extern "C" size_t rslo_scan_ws_bytes(int64_t n) {
+  return (size_t)(rslo_cdiv(n > 0 ? n : 1, SCAN_TILE) + 4) * sizeof(int32_t);
+}
+
+// in: n uint32 (flags or bitmap words), out: n exclusive prefix, total -> *d_total
+template <bool POPC>
+static int scan_exclusive(const uint32_t *in, int32_t *out, int64_t n, void *ws, size_t ws_bytes,
+                          int32_t *d_total, hipStream_t st) {
+  if (ws_bytes < rslo_scan_ws_bytes(n)) {
+    rslo_set_error("scan workspace too small");
+    return RSLO_EWS;
+  }
+  int32_t *sums = (int32_t *)ws;
+  int64_t nb = rslo_cdiv(n > 0 ? n : 1, SCAN_TILE);
+  hipLaunchKernelGGL(k_scan_block<POPC>, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, st, in, out, sums, n);
+  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_BLOCK), 0, st, sums, nb, d_total);
+  if (n > 0)
+    hipLaunchKernelGGL(k_scan_add, dim3((unsigned)rslo_cdiv(n, 256)), dim3(256), 0, st, out, sums, n);
+  RSLO_CHECK_LAUNCH("scan");
+  return RSLO_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// hash build
+// ---------------------------------------------------------------------------------------
+extern "C" int64_t rslo_hash_capacity(int64_t n) {
+  int64_t c = 1024;
+  while (c < 2 * n) c <<= 1;
+  return c;
+}
+
+__global__ void k_hash_insert(const int32_t *__restrict__ coords, int64_t N, Dims3 s,
+                              uint32_t *__restrict__ keys, int32_t *__restrict__ vals, uint32_t mask,
+                              int shift) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int4 c = reinterpret_cast<const int4 *>(coords)[i];
+  const uint32_t key = rslo_lin(c.x, c.y, c.z, c.w, s);
+  uint32_t p = rslo_hslot(key, shift);
+  while (true) {
+    uint32_t prev = atomicCAS(&keys[p], RSLO_EMPTY_KEY, key);
+    if (prev == RSLO_EMPTY_KEY || prev == key) {
+      vals[p] = (int32_t)i;
+      return;
+    }
+    p = (p + 1) & mask;
+  }
+}
+
+static int check_volume(int B, const int32_t *d) {
+  double v = (double)B * d[0] * d[1] * d[2];
+  if (v >= 4294967295.0) {
+    rslo_set_error("volume %g does not fit the 32-bit key space", v);
+    return RSLO_ERANGE;
+  }
+  return RSLO_OK;
+}
+
+extern "C" int rslo_hash_build(const int32_t *coords, int64_t N, int B, const int32_t *d,
+                               uint32_t *keys, int32_t *vals, int64_t cap, void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  RSLO_CHECK_ARG(cap >= 2 * N && (cap & (cap - 1)) == 0, "hash_build: cap must be a power of two >= 2N");
+  if (int rc = check_volume(B, d)) return rc;
+  RSLO_HIP(hipMemsetAsync(keys, 0xFF, (size_t)cap * sizeof(uint32_t), st));
+  if (N == 0) return RSLO_OK;
+  const int shift = 32 - rslo_log2_i64(cap);
+  hipLaunchKernelGGL(k_hash_insert, dim3((unsigned)rslo_cdiv(N, 256)), dim3(256), 0, st, coords, N,
+                     Dims3{d[0], d[1], d[2]}, keys, vals, (uint32_t)(cap - 1), shift);
+  RSLO_CHECK_LAUNCH("hash_insert");
+  return RSLO_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// SubM rulebook: one thread per (row, offset)
+// ---------------------------------------------------------------------------------------
+__global__ void k_rulebook_subm(const int32_t *__restrict__ coords, int64_t N, Dims3 s, Int3 ks,
+                                const uint32_t *__restrict__ keys, const int32_t *__restrict__ vals,
+                                uint32_t mask, int shift, int32_t *__restrict__ nbr) {
+  const int K = ks.a * ks.b * ks.c;
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= N * K) return;
+  const int64_t o = t / K;
+  int k = (int)(t - o * K);
+  const int kx = k % ks.c;
+  k /= ks.c;
+  const int ky = k % ks.b;
+  const int kz = k / ks.b;
+  const int4 c = reinterpret_cast<const int4 *>(coords)[o];
+  const int z = c.y + kz - ks.a / 2, y = c.z + ky - ks.b / 2, x = c.w + kx - ks.c / 2;
+  int32_t r = -1;
+  if (z >= 0 && z < s.d && y >= 0 && y < s.h && x >= 0 && x < s.w)
+    r = rslo_hfind(keys, vals, mask, shift, rslo_lin(c.x, z, y, x, s));
+  nbr[t] = r;
+}
+
+extern "C" int rslo_rulebook_subm(const int32_t *coords, int64_t N, int B, const int32_t *d,
+                                  const int32_t *ks, const uint32_t *keys, const int32_t *vals,
+                                  int64_t cap, int32_t *nbr, void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (int rc = check_volume(B, d)) return rc;
+  if (N == 0) return RSLO_OK;
+  const int K = ks[0] * ks[1] * ks[2];
+  const int shift = 32 - rslo_log2_i64(cap);
+  hipLaunchKernelGGL(k_rulebook_subm, dim3((unsigned)rslo_cdiv(N * K, 256)), dim3(256), 0, st, coords, N,
+                     Dims3{d[0], d[1], d[2]}, Int3{ks[0], ks[1], ks[2]}, keys, vals,
+                     (uint32_t)(cap - 1), shift, nbr);
+  RSLO_CHECK_LAUNCH("rulebook_subm");
+  return RSLO_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// strided conv: output set through a bitmap over the output volume (gives the ascending
+// linear order without a sort), then the two neighbour tables by hash probes.
+// ---------------------------------------------------------------------------------------
+extern "C" int64_t rslo_conv_bitmap_words(int B, const int32_t *od) {
+  int64_t vol = (int64_t)B * od[0] * od[1] * od[2];
+  return (vol + 31) / 32;
+}
+
+__global__ void k_conv_mark(const int32_t *__restrict__ coords, int64_t N, Int3 ks, Int3 st, Int3 pd,
+                            Dims3 od, uint32_t *__restrict__ bitmap) {
+  const int K = ks.a * ks.b * ks.c;
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= N * K) return;
+  const int64_t i = t / K;
+  int k = (int)(t - i * K);
+  const int kx = k % ks.c;
+  k /= ks.c;
+  const int ky = k % ks.b;
+  const int kz = k / ks.b;
+  const int4 c = reinterpret_cast<const int4 *>(coords)[i];
+  const int tz = c.y + pd.a - kz, ty = c.z + pd.b - ky, tx = c.w + pd.c - kx;
+  if (tz < 0 || ty < 0 || tx < 0) return;
+  if (tz % st.a || ty % st.b || tx % st.c) return;
+  const int z = tz / st.a, y = ty / st.b, x = tx / st.c;
+  if (z >= od.d || y >= od.h || x >= od.w) return;
+  const uint32_t lin = rslo_lin(c.x, z, y, x, od);
+  atomicOr(&bitmap[lin >> 5], 1u << (lin & 31));
+}
+
+extern "C" int rslo_conv_out_count(const int32_t *coords_in, int64_t N, int B, const int32_t *ks,
+                                   const int32_t *stride, const int32_t *pad, const int32_t *od,
+                                   uint32_t *bitmap, int32_t *word_prefix, int64_t words, void *scan_ws,
+                                   size_t scan_ws_bytes, int32_t *d_count, void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (int rc = check_volume(B, od)) return rc;
+  RSLO_CHECK_ARG(words == rslo_conv_bitmap_words(B, od), "conv_out_count: wrong bitmap size");
+  RSLO_HIP(hipMemsetAsync(bitmap, 0, (size_t)words * sizeof(uint32_t), st));
+  const int K = ks[0] * ks[1] * ks[2];
+  if (N > 0) {
+    hipLaunchKernelGGL(k_conv_mark, dim3((unsigned)rslo_cdiv(N * K, 256)), dim3(256), 0, st, coords_in, N,
+                       Int3{ks[0], ks[1], ks[2]}, Int3{stride[0], stride[1], stride[2]},
+                       Int3{pad[0], pad[1], pad[2]}, Dims3{od[0], od[1], od[2]}, bitmap);
+    RSLO_CHECK_LAUNCH("conv_mark");
+  }
+  return scan_exclusive<true>(bitmap, word_prefix, words, scan_ws, scan_ws_bytes, d_count, st);
+}
+
+__global__ void k_conv_emit(const uint32_t *__restrict__ bitmap, const int32_t *__restrict__ prefix,
+                            int64_t words, Dims3 od, int32_t *__restrict__ out_coords, int64_t M) {
+  int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= words) return;
+  uint32_t bits = bitmap[w];
+  if (!bits) return;
+  int32_t r = prefix[w];
+  while (bits) {
+    const int b = __ffs(bits) - 1;
+    bits &= bits - 1;
+    uint32_t lin = (uint32_t)(w * 32 + b);
+    const int x = lin % od.w;
+    lin /= od.w;
+    const int y = lin % od.h;
+    lin /= od.h;
+    const int z = lin % od.d;
+    const int bb = lin / od.d;
+    if (r < M) reinterpret_cast<int4 *>(out_coords)[r] = make_int4(bb, z, y, x);
+    ++r;
+  }
+}
+
+extern "C" int rslo_conv_out_coords(const uint32_t *bitmap, const int32_t *word_prefix, int64_t words,
+                                    int B, const int32_t *od, int32_t *out_coords, int64_t M,
+                                    void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  (void)B;
+  if (M == 0 || words == 0) return RSLO_OK;
+  hipLaunchKernelGGL(k_conv_emit, dim3((unsigned)rslo_cdiv(words, 256)), dim3(256), 0, st, bitmap,
+                     word_prefix, words, Dims3{od[0], od[1], od[2]}, out_coords, M);
+  RSLO_CHECK_LAUNCH("conv_emit");
+  return RSLO_OK;
+}
+
+__global__ void k_rulebook_conv(const int32_t *__restrict__ coords_out, int64_t M, Dims3 id, Int3 ks,
+                                Int3 st, Int3 pd, const uint32_t *__restrict__ keys,
+                                const int32_t *__restrict__ vals, uint32_t mask, int shift,
+                                int32_t *__restrict__ nbr) {
+  const int K = ks.a * ks.b * ks.c;
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= M * K) return;
+  const int64_t o = t / K;
+  int k = (int)(t - o * K);
+  const int kx = k % ks.c;
+  k /= ks.c;
+  const int ky = k % ks.b;
+  const int kz = k / ks.b;
+  const int4 c = reinterpret_cast<const int4 *>(coords_out)[o];
+  const int z = c.y * st.a - pd.a + kz, y = c.z * st.b - pd.b + ky, x = c.w * st.c - pd.c + kx;
+  int32_t r = -1;
+  if (z >= 0 && z < id.d && y >= 0 && y < id.h && x >= 0 && x < id.w)
+    r = rslo_hfind(keys, vals, mask, shift, rslo_lin(c.x, z, y, x, id));
+  nbr[t] = r;
+}
+
+extern "C" int rslo_rulebook_conv(const int32_t *coords_out, int64_t M, int B, const int32_t *id,
+                                  const int32_t *ks, const int32_t *stride, const int32_t *pad,
+                                  const uint32_t *in_keys, const int32_t *in_vals, int64_t in_cap,
+                                  int32_t *nbr, void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (int rc = check_volume(B, id)) return rc;
+  if (M == 0) return RSLO_OK;
+  const int K = ks[0] * ks[1] * ks[2];
+  const int shift = 32 - rslo_log2_i64(in_cap);
+  hipLaunchKernelGGL(k_rulebook_conv, dim3((unsigned)rslo_cdiv(M * K, 256)), dim3(256), 0, st, coords_out,
+                     M, Dims3{id[0], id[1], id[2]}, Int3{ks[0], ks[1], ks[2]},
+                     Int3{stride[0], stride[1], stride[2]}, Int3{pad[0], pad[1], pad[2]}, in_keys,
+                     in_vals, (uint32_t)(in_cap - 1), shift, nbr);
+  RSLO_CHECK_LAUNCH("rulebook_conv");
+  return RSLO_OK;
+}
+
+__global__ void k_rulebook_conv_T(const int32_t *__restrict__ coords_in, int64_t N, Dims3 od, Int3 ks,
+                                  Int3 st, Int3 pd, const uint32_t *__restrict__ keys,
+                                  const int32_t *__restrict__ vals, uint32_t mask, int shift,
+                                  int32_t *__restrict__ nbrT) {
+  const int K = ks.a * ks.b * ks.c;
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= N * K) return;
+  const int64_t i = t / K;
+  int k = (int)(t - i * K);
+  const int kx = k % ks.c;
+  k /= ks.c;
+  const int ky = k % ks.b;
+  const int kz = k / ks.b;
+  const int4 c = reinterpret_cast<const int4 *>(coords_in)[i];
+  const int tz = c.y + pd.a - kz, ty = c.z + pd.b - ky, tx = c.w + pd.c - kx;
+  int32_t r = -1;
+  if (tz >= 0 && ty >= 0 && tx >= 0 && tz % st.a == 0 && ty % st.b == 0 && tx % st.c == 0) {
+    const int z = tz / st.a, y = ty / st.b, x = tx / st.c;
+    if (z < od.d && y < od.h && x < od.w)
+      r = rslo_hfind(keys, vals, mask, shift, rslo_lin(c.x, z, y, x, od));
+  }
+  nbrT[t] = r;
+}
+
+extern "C" int rslo_rulebook_conv_T(const int32_t *coords_in, int64_t N, int B, const int32_t *od,
+                                    const int32_t *ks, const int32_t *stride, const int32_t *pad,
+                                    const uint32_t *out_keys, const int32_t *out_vals, int64_t out_cap,
+                                    int32_t *nbrT, void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (int rc = check_volume(B, od)) return rc;
+  if (N == 0) return RSLO_OK;
+  const int K = ks[0] * ks[1] * ks[2];
+  const int shift = 32 - rslo_log2_i64(out_cap);
+  hipLaunchKernelGGL(k_rulebook_conv_T, dim3((unsigned)rslo_cdiv(N * K, 256)), dim3(256), 0, st, coords_in,
+                     N, Dims3{od[0], od[1], od[2]}, Int3{ks[0], ks[1], ks[2]},
+                     Int3{stride[0], stride[1], stride[2]}, Int3{pad[0], pad[1], pad[2]}, out_keys,
+                     out_vals, (uint32_t)(out_cap - 1), shift, nbrT);
+  RSLO_CHECK_LAUNCH("rulebook_conv_T");
+  return RSLO_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// voxelizer.  Point i -> voxel key; hash slot keeps the smallest point index (first-come
+// order) and a linked list of its points.  Voxel id = exclusive scan over "is first point"
+// flags (= rank of the first index), rank of a point inside its voxel = number of list
+// members with a smaller index.  Everything is order-independent, hence deterministic.
+// ---------------------------------------------------------------------------------------
+struct VoxWs {
+  uint32_t *keys;
+  int32_t *first, *head, *vid, *next, *slot, *pos, *cutoff;
+  uint32_t *flags;
+  void *scan_ws;
+  size_t scan_bytes;
+  int64_t cap;
+};
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static size_t vox_ws_layout(int64_t P, void *base, VoxWs *w) {
+  const int64_t cap = rslo_hash_capacity(P);
+  size_t off = 0;
+  char *b = (char *)base;
+  auto take = [&](size_t bytes) {
+    void *p = b ? (void *)(b + off) : nullptr;
+    off += align256(bytes);
+    return p;
+  };
+  void *keys = take(cap * 4), *first = take(cap * 4), *head = take(cap * 4), *vid = take(cap * 4);
+  void *next = take((size_t)P * 4), *slot = take((size_t)P * 4), *pos = take((size_t)P * 4),
+       *flags = take((size_t)P * 4);
+  void *cutoff = take(256);
+  size_t sb = rslo_scan_ws_bytes(P);
+  void *sws = take(sb);
+  if (w) {
+    w->keys = (uint32_t *)keys; w->first = (int32_t *)first; w->head = (int32_t *)head;
+    w->vid = (int32_t *)vid; w->next = (int32_t *)next; w->slot = (int32_t *)slot;
+    w->pos = (int32_t *)pos; w->flags = (uint32_t *)flags; w->cutoff = (int32_t *)cutoff;
+    w->scan_ws = sws; w->scan_bytes = sb; w->cap = cap;
+  }
+  return off;
+}
+
+extern "C" size_t rslo_voxelize_ws_bytes(int64_t P) { return vox_ws_layout(P > 0 ? P : 1, nullptr, nullptr); }
+
+struct VoxGeom {
+  float lo[3], vs[3];
+  int g[3];
+};
+
+__device__ __forceinline__ bool vox_coord(const float *__restrict__ p, const VoxGeom &G, int c[3]) {
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const float q = __fdiv_rn(__fsub_rn(p[j], G.lo[j]), G.vs[j]);
+    const float fl = floorf(q);
+    if (!(fl >= 0.0f) || !(fl < (float)G.g[j])) return false;
+    c[j] = (int)fl;
+  }
+  return true;
+}
+
+__global__ void k_vox_insert(const float *__restrict__ pts, int64_t P, int F, VoxGeom G,
+                             uint32_t *__restrict__ keys, int32_t *__restrict__ first,
+                             int32_t *__restrict__ head, int32_t *__restrict__ next,
+                             int32_t *__restrict__ slot, uint32_t mask, int shift) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  int c[3];
+  if (!vox_coord(pts + i * F, G, c)) {
+    slot[i] = -1;
+    return;
+  }
+  const uint32_t key = ((uint32_t)c[2] * G.g[1] + c[1]) * G.g[0] + c[0];
+  uint32_t s = rslo_hslot(key, shift);
+  while (true) {
+    uint32_t prev = atomicCAS(&keys[s], RSLO_EMPTY_KEY, key);
+    if (prev == RSLO_EMPTY_KEY || prev == key) break;
+    s = (s + 1) & mask;
+  }
+  atomicMin(&first[s], (int32_t)i);
+  next[i] = atomicExch(&head[s], (int32_t)i);
+  slot[i] = (int32_t)s;
+}
+
+__global__ void k_vox_flags(const int32_t *__restrict__ slot, const int32_t *__restrict__ first, int64_t P,
+                            uint32_t *__restrict__ flags) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  const int32_t s = slot[i];
+  flags[i] = (s >= 0 && first[s] == (int32_t)i) ? 1u : 0u;
+}
+
+__global__ void k_vox_assign(const uint32_t *__restrict__ keys, const int32_t *__restrict__ slot,
+                             const uint32_t *__restrict__ flags, const int32_t *__restrict__ pos, int64_t P,
+                             VoxGeom G, int max_voxels, int32_t *__restrict__ vid,
+                             int32_t *__restrict__ coords, int32_t *__restrict__ cutoff,
+                             int32_t *__restrict__ d_nvox) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  if (i == P - 1) {
+    const int32_t tot = pos[i] + (int32_t)flags[i];
+    *d_nvox = tot < max_voxels ? tot : max_voxels;
+  }
+  if (!flags[i]) return;
+  const int32_t s = slot[i];
+  const int32_t v = pos[i];
+  vid[s] = v;
+  if (v < max_voxels) {
+    uint32_t key = keys[s];
+    const int x = key % G.g[0];
+    key /= G.g[0];
+    const int y = key % G.g[1];
+    const int z = key / G.g[1];
+    coords[v * 3 + 0] = z;
+    coords[v * 3 + 1] = y;
+    coords[v * 3 + 2] = x;
+  } else if (v == max_voxels) {
+    *cutoff = (int32_t)i;  // the reference loop `break`s here
+  }
+}
+
+__global__ void k_vox_fill(const float *__restrict__ pts, int64_t P, int F, int T,
+                           const int32_t *__restrict__ slot, const int32_t *__restrict__ head,
+                           const int32_t *__restrict__ next, const int32_t *__restrict__ vid,
+                           const int32_t *__restrict__ cutoff, float *__restrict__ voxels,
+                           int32_t *__restrict__ num_points) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  const int32_t s = slot[i];
+  if (s < 0 || i >= (int64_t)*cutoff) return;
+  int rank = 0;
+  for (int32_t j = head[s]; j >= 0; j = next[j]) rank += (j < (int32_t)i);
+  if (rank >= T) return;
+  const int32_t v = vid[s];
+  float *dst = voxels + ((int64_t)v * T + rank) * F;
+  const float *src = pts + i * F;
+  for (int f = 0; f < F; ++f) dst[f] = src[f];
+  atomicAdd(&num_points[v], 1);
+}
+
+extern "C" int rslo_voxelize(const float *points, int64_t P, int F, const float *range6,
+                             const float *vsize3, const int32_t *grid_xyz, int T, int max_voxels,
+                             void *ws, size_t ws_bytes, float *voxels, int32_t *coords,
+                             int32_t *num_points, int32_t *d_nvox, void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  RSLO_CHECK_ARG(F >= 3 && T >= 1 && max_voxels >= 1, "voxelize: bad F/T/max_voxels");
+  RSLO_CHECK_ARG(P < (int64_t)2000000000, "voxelize: too many points");
+  {
+    int32_t d[3] = {grid_xyz[2], grid_xyz[1], grid_xyz[0]};
+    if (int rc = check_volume(1, d)) return rc;
+  }
+  RSLO_HIP(hipMemsetAsync(voxels, 0, (size_t)max_voxels * T * F * sizeof(float), st));
+  RSLO_HIP(hipMemsetAsync(num_points, 0, (size_t)max_voxels * sizeof(int32_t), st));
+  RSLO_HIP(hipMemsetAsync(coords, 0, (size_t)max_voxels * 3 * sizeof(int32_t), st));
+  RSLO_HIP(hipMemsetAsync(d_nvox, 0, sizeof(int32_t), st));
+  if (P == 0) return RSLO_OK;
+  if (ws_bytes < rslo_voxelize_ws_bytes(P)) {
+    rslo_set_error("voxelize: workspace too small (%zu < %zu)", ws_bytes, rslo_voxelize_ws_bytes(P));
+    return RSLO_EWS;
+  }
+  VoxWs w;
+  vox_ws_layout(P, ws, &w);
+  VoxGeom G;
+  for (int j = 0; j < 3; ++j) {
+    G.lo[j] = range6[j];
+    G.vs[j] = vsize3[j];
+    G.g[j] = grid_xyz[j];
+  }
+  RSLO_HIP(hipMemsetAsync(w.keys, 0xFF, (size_t)w.cap * 4, st));
+  RSLO_HIP(hipMemsetAsync(w.head, 0xFF, (size_t)w.cap * 4, st));
+  RSLO_HIP(hipMemsetAsync(w.first, 0x7F, (size_t)w.cap * 4, st));
+  RSLO_HIP(hipMemsetAsync(w.cutoff, 0x7F, sizeof(int32_t), st));
+  const unsigned nb = (unsigned)rslo_cdiv(P, 256);
+  const int shift = 32 - rslo_log2_i64(w.cap);
+  hipLaunchKernelGGL(k_vox_insert, dim3(nb), dim3(256), 0, st, points, P, F, G, w.keys, w.first, w.head,
+                     w.next, w.slot, (uint32_t)(w.cap - 1), shift);
+  hipLaunchKernelGGL(k_vox_flags, dim3(nb), dim3(256), 0, st, w.slot, w.first, P, w.flags);
+  RSLO_CHECK_LAUNCH("vox_insert");
+  if (int rc = scan_exclusive<false>(w.flags, w.pos, P, w.scan_ws, w.scan_bytes, nullptr, st)) return rc;
+  hipLaunchKernelGGL(k_vox_assign, dim3(nb), dim3(256), 0, st, w.keys, w.slot, w.flags, w.pos, P, G,
+                     max_voxels, w.vid, coords, w.cutoff, d_nvox);
+  hipLaunchKernelGGL(k_vox_fill, dim3(nb), dim3(256), 0, st, points, P, F, T, w.slot, w.head, w.next,
+                     w.vid, w.cutoff, voxels, num_points);
+  RSLO_CHECK_LAUNCH("vox_fill");
+  return RSLO_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// VFE mean (a4)
+// ---------------------------------------------------------------------------------------
+__global__ void k_vfe_mean(const float *__restrict__ voxels, const int32_t *__restrict__ num, int64_t M,
+                           int T, int F, float *__restrict__ out) {
+  int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= M) return;
+  const float inv_n = (float)num[v];
+  float m[16];
+  for (int f = 0; f < F; ++f) {
+    float s = 0.f;
+    for (int t = 0; t < T; ++t) s = __fadd_rn(s, voxels[((int64_t)v * T + t) * F + f]);
+    m[f] = __fdiv_rn(s, inv_n);
+  }
+  if (F >= 7) {
+    const float n2 = __fadd_rn(__fadd_rn(__fmul_rn(m[4], m[4]), __fmul_rn(m[5], m[5])), __fmul_rn(m[6], m[6]));
+    const float d = __fadd_rn(__fsqrt_rn(n2), 1e-12f);
+    m[4] = __fdiv_rn(m[4], d);
+    m[5] = __fdiv_rn(m[5], d);
+    m[6] = __fdiv_rn(m[6], d);
+  }
+  for (int f = 0; f < F; ++f) out[v * F + f] = m[f];
+}
+
+extern "C" int rslo_vfe_mean(const float *voxels, const int32_t *num_points, int64_t M, int T, int F,
+                             float *out, void *stream) {
+  RSLO_CHECK_ARG(F <= 16, "vfe_mean: F > 16 unsupported");
+  if (M == 0) return RSLO_OK;
+  hipLaunchKernelGGL(k_vfe_mean, dim3((unsigned)rslo_cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, voxels,
+                     num_points, M, T, F, out);
+  RSLO_CHECK_LAUNCH("vfe_mean");
+  return RSLO_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// dense scatter / gather (a8)
+// ---------------------------------------------------------------------------------------
+template <bool GATHER>
+__global__ void k_dense(float *__restrict__ feat, const int32_t *__restrict__ coords, int64_t M, int C,
+                        Dims3 s, float *__restrict__ dense) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= M * C) return;
+  const int64_t r = t % M;
+  const int ch = (int)(t / M);
+  const int4 c = reinterpret_cast<const int4 *>(coords)[r];
+  const int64_t vol = (int64_t)s.d * s.h * s.w;
+  const int64_t off = ((int64_t)c.x * C + ch) * vol + ((int64_t)c.y * s.h + c.z) * s.w + c.w;
+  if (GATHER)
+    feat[r * C + ch] = dense[off];
+  else
+    dense[off] = feat[r * C + ch];
+}
+
+extern "C" int rslo_dense_scatter(const float *feat, const int32_t *coords, int64_t M, int C, int B,
+                                  const int32_t *d, float *out, void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  RSLO_HIP(hipMemsetAsync(out, 0, (size_t)B * C * d[0] * d[1] * d[2] * sizeof(float), st));
+  if (M == 0) return RSLO_OK;
+  hipLaunchKernelGGL(k_dense<false>, dim3((unsigned)rslo_cdiv(M * C, 256)), dim3(256), 0, st,
+                     const_cast<float *>(feat), coords, M, C, Dims3{d[0], d[1], d[2]}, out);
+  RSLO_CHECK_LAUNCH("dense_scatter");
+  return RSLO_OK;
+}
+
+extern "C" int rslo_dense_gather(const float *dense, const int32_t *coords, int64_t M, int C, int B,
+                                 const int32_t *d, float *dfeat, void *stream) {
+  (void)B;
+  if (M == 0) return RSLO_OK;
+  hipLaunchKernelGGL(k_dense<true>, dim3((unsigned)rslo_cdiv(M * C, 256)), dim3(256), 0,
+                     (hipStream_t)stream, dfeat, coords, M, C, Dims3{d[0], d[1], d[2]},
+                     const_cast<float *>(dense));
+  RSLO_CHECK_LAUNCH("dense_gather");
+  return RSLO_OK;
+}

@@ -1,0 +1,395 @@
+// Sparse 3-D convolution arithmetic for gfx950: output-stationary implicit GEMM.
+//
+// A workgroup (4 wave64) owns a tile of 64*RB output rows, each wave 16*RB of them.  For every
+// kernel offset k the wave gathers the neighbour rows named by the table straight into MFMA
+// A-fragments (16-byte loads, four lanes cover one 64-byte row segment), W_k is staged once
+// per workgroup in LDS and read as B-fragments, and v_mfma_f32_16x16x4_f32 accumulates the
+// [16 x Cout] result in registers across all K offsets: one coalesced-ish store per output
+// row, no atomics, no scatter.  Offsets for which none of the wave's 16 rows has a neighbour
+// are skipped (about half of them on LiDAR data), so the MFMA work follows the rulebook
+// density.  Bias and LeakyReLU are fused into the epilogue.
+//
+// K-slab trick: lane (i = lane&15, g = lane>>4) loads the float4 in[row_i][16j + 4g .. +3];
+// slab (j,t) feeds element t of it as A[i][g], so the slab's k index g stands for input
+// channel 16j+4g+t, and the B fragment is read from LDS at that same channel.  The
+// contraction order differs from a plain loop only by a permutation of the channel sum.
+#include "rslo_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define SPC_THREADS 256
+#define SPC_WAVES 4
+#define SPC_MAXK 27
+
+template <int CIN_T>
+struct AFrag {
+  float v[CIN_T >= 16 ? CIN_T / 4 : 2];
+};
+
+// Loads the A fragments of one neighbour row.  cin is the true channel count.
+template <int CIN_T>
+__device__ __forceinline__ void load_a(const float *__restrict__ in, int32_t r, int cin, int g,
+                                       AFrag<CIN_T> &a) {
+  if constexpr (CIN_T >= 16) {
+#pragma unroll
+    for (int j = 0; j < CIN_T / 16; ++j) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r >= 0) v = *reinterpret_cast<const float4 *>(in + (int64_t)r * cin + 16 * j + 4 * g);
+      a.v[4 * j + 0] = v.x;
+      a.v[4 * j + 1] = v.y;
+      a.v[4 * j + 2] = v.z;
+      a.v[4 * j + 3] = v.w;
+    }
+  } else {  // CIN_T == 8: channels 4s+g, guarded
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int c = 4 * s + g;
+      a.v[s] = (r >= 0 && c < cin) ? in[(int64_t)r * cin + c] : 0.f;
+    }
+  }
+}
+
+// LDS channel row of slab `s` for lane group g
+template <int CIN_T>
+__device__ __forceinline__ int slab_channel(int s, int g) {
+  if constexpr (CIN_T >= 16)
+    return 16 * (s >> 2) + 4 * g + (s & 3);
+  else
+    return 4 * s + g;
+}
+
+// out[o] = act(bias + sum_k in[nbr[o][k]] . B_k),  B_k[ci][co] = TRANS ? W[kk][co][ci] : W[kk][ci][co]
+template <int CIN_T, int COUT_T, int RB, bool TRANS>
+__global__ __launch_bounds__(SPC_THREADS) void k_spconv(const float *__restrict__ in, int cin,
+                                                        const float *__restrict__ W,
+                                                        const float *__restrict__ bias,
+                                                        const int32_t *__restrict__ nbr, int64_t n_out,
+                                                        int K, int cout, int flip_k, float slope,
+                                                        float *__restrict__ out) {
+  constexpr int LDW = COUT_T + 4;
+  constexpr int NSLAB = CIN_T / 4;
+  constexpr int NB = COUT_T / 16;
+  constexpr int TILE = 64 * RB;
+  __shared__ __attribute__((aligned(16))) float Wl[2][CIN_T * LDW];
+  __shared__ int32_t nbl[TILE * SPC_MAXK];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int64_t row0 = (int64_t)blockIdx.x * TILE;
+
+  // neighbour rows of the tile: one contiguous slab of the table
+  {
+    const int64_t lim = (n_out - row0) * K;
+    for (int e = tid; e < TILE * K; e += SPC_THREADS) nbl[e] = (e < lim) ? nbr[row0 * K + e] : -1;
+  }
+
+  auto stage = [&](int k, int buf) {
+    const int kk = flip_k ? (K - 1 - k) : k;
+    const float *wk = W + (int64_t)kk * cin * cout;
+    for (int e = tid; e < CIN_T * COUT_T; e += SPC_THREADS) {
+      const int ci = e / COUT_T, co = e - ci * COUT_T;
+      float v = 0.f;
+      if (ci < cin && co < cout) v = TRANS ? wk[co * cin + ci] : wk[ci * cout + co];
+      Wl[buf][ci * LDW + co] = v;
+    }
+  };
+
+  f32x4 acc[RB][NB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[rb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  stage(0, 0);
+  __syncthreads();
+
+  for (int k = 0; k < K; ++k) {
+    const int buf = k & 1;
+    if (k + 1 < K) stage(k + 1, buf ^ 1);  // other buffer: readers of it finished before the last barrier
+    int32_t r[RB];
+    bool any = false;
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      r[rb] = nbl[((wid * RB + rb) * 16 + li) * K + k];
+      any |= (__ballot(r[rb] >= 0) != 0ull);
+    }
+    if (any) {
+      AFrag<CIN_T> a[RB];
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) load_a<CIN_T>(in, r[rb], cin, g, a[rb]);
+      const float *wl = Wl[buf];
+#pragma unroll
+      for (int s = 0; s < NSLAB; ++s) {
+        const int ch = slab_channel<CIN_T>(s, g);
+        float b[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) b[nb] = wl[ch * LDW + nb * 16 + li];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+            acc[rb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rb].v[s], b[nb], acc[rb][nb], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  // epilogue: D[row = 4g + j][col = li] per 16x16 block
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const int col = nb * 16 + li;
+      if (col >= cout) continue;
+      const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t row = row0 + (wid * RB + rb) * 16 + 4 * g + j;
+        if (row < n_out) {
+          float v = acc[rb][nb][j] + bv;
+          v = v > 0.f ? v : v * slope;
+          out[row * cout + col] = v;
+        }
+      }
+    }
+  }
+}
+
+static int pad_cin(int c) { return c <= 8 ? 8 : (c <= 16 ? 16 : (c <= 32 ? 32 : 64)); }
+static int pad_cout(int c) { return c <= 16 ? 16 : (c <= 32 ? 32 : 64); }
+
+template <bool TRANS>
+static int launch_spconv(const float *in, int cin, const float *W, const float *bias, const int32_t *nbr,
+                         int64_t n_out, int K, int cout, int flip_k, float slope, float *out,
+                         hipStream_t st) {
+  RSLO_CHECK_ARG(cin >= 1 && cin <= 64 && cout >= 1 && cout <= 64, "spconv: channels must be in 1..64");
+  RSLO_CHECK_ARG(K >= 1 && K <= SPC_MAXK, "spconv: K must be in 1..27");
+  RSLO_CHECK_ARG(cin <= 8 || cin % 4 == 0, "spconv: cin > 8 must be a multiple of 4");
+  if (n_out == 0) return RSLO_OK;
+  const int ci = pad_cin(cin), co = pad_cout(cout);
+  RSLO_CHECK_ARG(ci == 8 || ci == cin, "spconv: cin must be <=8, 16, 32 or 64");
+  // one 16-row block per wave while the launch would not fill the chip, two otherwise
+  const bool rb2 = (n_out >= 256 * 128 * 2) && co >= 32;
+#define SPC_CASE(CI, CO)                                                                             \
+  if (ci == CI && co == CO) {                                                                        \
+    if (rb2)                                                                                         \
+      hipLaunchKernelGGL((k_spconv<CI, CO, 2, TRANS>), dim3((unsigned)rslo_cdiv(n_out, 128)),        \
+                         dim3(SPC_THREADS), 0, st, in, cin, W, bias, nbr, n_out, K, cout, flip_k,    \
+                         slope, out);                                                                \
+    else                                                                                             \
+      hipLaunchKernelGGL((k_spconv<CI, CO, 1, TRANS>), dim3((unsigned)rslo_cdiv(n_out, 64)),         \
+                         dim3(SPC_THREADS), 0, st, in, cin, W, bias, nbr, n_out, K, cout, flip_k,    \
+                         slope, out);                                                                \
+  }
+  SPC_CASE(8, 16) SPC_CASE(8, 32) SPC_CASE(8, 64)
+  SPC_CASE(16, 16) SPC_CASE(16, 32) SPC_CASE(16, 64)
+  SPC_CASE(32, 16) SPC_CASE(32, 32) SPC_CASE(32, 64)
+  SPC_CASE(64, 16) SPC_CASE(64, 32) SPC_CASE(64, 64)
+#undef SPC_CASE
+  RSLO_CHECK_LAUNCH("spconv");
+  return RSLO_OK;
+}
+
+extern "C" int rslo_spconv_fwd(const float *in, int cin, const float *W, const float *bias,
+                               const int32_t *nbr, int64_t n_out, int K, int cout, int flip_k,
+                               float act_slope, float *out, void *stream) {
+  return launch_spconv<false>(in, cin, W, bias, nbr, n_out, K, cout, flip_k, act_slope, out,
+                              (hipStream_t)stream);
+}
+
+// din[i][a] = sum_k sum_b dout[nbrT[i][k]][b] W[kk][a][b]: the same kernel with the roles of the
+// channel counts swapped and W_k read transposed.
+extern "C" int rslo_spconv_dgrad(const float *dout, int cout, const float *W, const int32_t *nbrT,
+                                 int64_t n_in, int K, int cin, int flip_k, float *din, void *stream) {
+  RSLO_CHECK_ARG(cout <= 8 || cout % 4 == 0, "spconv_dgrad: cout > 8 must be a multiple of 4");
+  return launch_spconv<true>(dout, cout, W, nullptr, nbrT, n_in, K, cin, flip_k, 1.0f, din,
+                             (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------
+// wgrad: dW[k] = sum_o in[nbr[o][k]]^T dout[o].  Grid (chunk, k): the workgroup compacts the
+// valid (in,out) pairs of its row chunk for offset k (ballot + prefix, deterministic), then
+// the four waves take 4-pair groups round-robin and accumulate Cin x Cout in MFMA registers
+// (A = in^T: lane (ci, g) reads in[pair g][ci]; B = dout: lane (g, co)).  Wave partials are
+// summed through LDS and written to ws[chunk][k]; a second kernel reduces the chunks in a
+// fixed order -- no atomics, bit-reproducible.
+// ---------------------------------------------------------------------------------------
+#define WG_CHUNK 2048
+
+template <int CIN_T, int COUT_T>
+__global__ __launch_bounds__(SPC_THREADS) void k_wgrad(const float *__restrict__ in, int cin,
+                                                       const float *__restrict__ dout, int cout,
+                                                       const int32_t *__restrict__ nbr, int64_t n_out, int K,
+                                                       float *__restrict__ ws, float *__restrict__ ws_bias) {
+  constexpr int CB = CIN_T / 16, NB = COUT_T / 16;
+  __shared__ int32_t p_in[WG_CHUNK], p_out[WG_CHUNK];
+  __shared__ int32_t wcnt[SPC_WAVES];
+  __shared__ int32_t base_s;
+  __shared__ __attribute__((aligned(16))) float red[CIN_T * COUT_T];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int k = blockIdx.y;
+  const int64_t o0 = (int64_t)blockIdx.x * WG_CHUNK;
+  const int64_t o1 = (o0 + WG_CHUNK < n_out) ? o0 + WG_CHUNK : n_out;
+
+  if (tid == 0) base_s = 0;
+  __syncthreads();
+  for (int64_t ob = o0; ob < o1; ob += SPC_THREADS) {
+    const int64_t o = ob + tid;
+    const int32_t r = (o < o1) ? nbr[o * K + k] : -1;
+    const unsigned long long m = __ballot(r >= 0);
+    if (lane == 0) wcnt[wid] = __popcll(m);
+    __syncthreads();
+    int off = base_s;
+    for (int w = 0; w < wid; ++w) off += wcnt[w];
+    if (r >= 0) {
+      const int p = off + __popcll(m & ((1ull << lane) - 1ull));
+      p_in[p] = r;
+      p_out[p] = (int32_t)(o - 0);
+    }
+    __syncthreads();
+    if (tid == 0) base_s += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    __syncthreads();
+  }
+  const int np = base_s;
+
+  f32x4 acc[CB][NB];
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[cb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int q = wid * 4; q < np; q += SPC_WAVES * 4) {
+    const int p = q + g;
+    const bool ok = p < np;
+    const int32_t ri = ok ? p_in[p] : 0;
+    const int64_t ro = ok ? (int64_t)p_out[p] : 0;
+    float a[CB], b[NB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+      const int c = cb * 16 + li;
+      a[cb] = (ok && c < cin) ? in[(int64_t)ri * cin + c] : 0.f;
+    }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const int c = nb * 16 + li;
+      b[nb] = (ok && c < cout) ? dout[ro * cout + c] : 0.f;
+    }
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+        acc[cb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cb], b[nb], acc[cb][nb], 0, 0, 0);
+  }
+
+  // fixed-order reduction of the 4 wave partials through LDS
+  for (int w = 0; w < SPC_WAVES; ++w) {
+    if (wid == w) {
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int ci = cb * 16 + 4 * g + j, co = nb * 16 + li;
+            float v = acc[cb][nb][j];
+            if (w) v += red[ci * COUT_T + co];
+            red[ci * COUT_T + co] = v;
+          }
+    }
+    __syncthreads();
+  }
+  float *dst = ws + ((int64_t)blockIdx.x * K + k) * cin * cout;
+  for (int e = tid; e < cin * cout; e += SPC_THREADS) {
+    const int ci = e / cout, co = e - ci * cout;
+    dst[e] = red[ci * COUT_T + co];
+  }
+  if (k == 0 && ws_bias) {  // bias gradient partial: column sums of dout over the chunk
+    __syncthreads();
+    const int c = tid & 63, part = tid >> 6;
+    float s = 0.f;
+    if (c < cout)
+      for (int64_t o = o0 + part; o < o1; o += 4) s += dout[o * cout + c];
+    red[tid] = s;
+    __syncthreads();
+    if (part == 0 && c < cout)
+      ws_bias[(int64_t)blockIdx.x * cout + c] = (red[c] + red[64 + c]) + (red[128 + c] + red[192 + c]);
+  }
+}
+
+__global__ void k_wgrad_reduce(const float *__restrict__ ws, int nchunk, int64_t n, float *__restrict__ dW) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  float s = 0.f;
+  for (int c = 0; c < nchunk; ++c) s += ws[(int64_t)c * n + e];
+  dW[e] = s;
+}
+
+static int wgrad_chunks(int64_t n_out) { return (int)rslo_cdiv(n_out > 0 ? n_out : 1, WG_CHUNK); }
+
+extern "C" size_t rslo_spconv_wgrad_ws_bytes(int64_t n_out, int K, int cin, int cout) {
+  return (size_t)wgrad_chunks(n_out) * ((size_t)K * cin * cout + cout) * sizeof(float);
+}
+
+extern "C" int rslo_spconv_wgrad(const float *in, int cin, const float *dout, int cout,
+                                 const int32_t *nbr, int64_t n_out, int K, void *ws, size_t ws_bytes,
+                                 float *dW, float *dbias, void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  RSLO_CHECK_ARG(cin >= 1 && cin <= 64 && cout >= 1 && cout <= 64, "wgrad: channels must be in 1..64");
+  RSLO_CHECK_ARG(K >= 1 && K <= SPC_MAXK, "wgrad: K must be in 1..27");
+  const int64_t nW = (int64_t)K * cin * cout;
+  if (n_out == 0) {
+    RSLO_HIP(hipMemsetAsync(dW, 0, nW * sizeof(float), st));
+    if (dbias) RSLO_HIP(hipMemsetAsync(dbias, 0, cout * sizeof(float), st));
+    return RSLO_OK;
+  }
+  if (ws_bytes < rslo_spconv_wgrad_ws_bytes(n_out, K, cin, cout)) {
+    rslo_set_error("wgrad: workspace too small");
+    return RSLO_EWS;
+  }
+  const int nch = wgrad_chunks(n_out);
+  const int ci = cin <= 16 ? 16 : (cin <= 32 ? 32 : 64), co = pad_cout(cout);
+  dim3 grid((unsigned)nch, (unsigned)K);
+  float *ws_bias = (float *)ws + (int64_t)nch * nW;
+#define WG_CASE(CI, CO)                                                                               \
+  if (ci == CI && co == CO)                                                                           \
+    hipLaunchKernelGGL((k_wgrad<CI, CO>), grid, dim3(SPC_THREADS), 0, st, in, cin, dout, cout, nbr,   \
+                       n_out, K, (float *)ws, dbias ? ws_bias : nullptr);
+  WG_CASE(16, 16) WG_CASE(16, 32) WG_CASE(16, 64)
+  WG_CASE(32, 16) WG_CASE(32, 32) WG_CASE(32, 64)
+  WG_CASE(64, 16) WG_CASE(64, 32) WG_CASE(64, 64)
+#undef WG_CASE
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)rslo_cdiv(nW, 256)), dim3(256), 0, st,
+                     (const float *)ws, nch, nW, dW);
+  if (dbias)
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(1), dim3(256), 0, st, (const float *)ws_bias, nch,
+                       (int64_t)cout, dbias);
+  RSLO_CHECK_LAUNCH("wgrad");
+  return RSLO_OK;
+}
+
+__global__ void k_leaky_bwd(const float *__restrict__ y, const float *__restrict__ dout, int64_t n,
+                            float slope, float *__restrict__ g) {
+  int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i + 3 < n) {
+    const float4 yv = *reinterpret_cast<const float4 *>(y + i);
+    float4 d = *reinterpret_cast<const float4 *>(dout + i);
+    d.x = yv.x > 0.f ? d.x : d.x * slope;
+    d.y = yv.y > 0.f ? d.y : d.y * slope;
+    d.z = yv.z > 0.f ? d.z : d.z * slope;
+    d.w = yv.w > 0.f ? d.w : d.w * slope;
+    *reinterpret_cast<float4 *>(g + i) = d;
+  } else {
+    for (; i < n; ++i) g[i] = y[i] > 0.f ? dout[i] : dout[i] * slope;
+  }
+}
+
+extern "C" int rslo_leaky_bwd(const float *y, const float *dout, int64_t n, float slope, float *g,
+                              void *stream) {
+  if (n == 0) return RSLO_OK;
+  hipLaunchKernelGGL(k_leaky_bwd, dim3((unsigned)rslo_cdiv(rslo_cdiv(n, 4), 256)), dim3(256), 0,
+                     (hipStream_t)stream, y, dout, n, slope, g);
+  RSLO_CHECK_LAUNCH("leaky_bwd");
+  return RSLO_OK;
+}

@@ -1,0 +1,230 @@
+"""Pins the CPU oracle (oracle/rslo_oracle.c) -- no GPU needed.
+
+  * chamfer NN   : bit-exact vs oracle/_ref (the reference's chamfer_distance.cpp compiled from
+                   /root/reference) when that build is present, vs committed golden vectors, and
+                   vs torch.cdist.
+  * sparse conv  : no reference source exists (spconv_plus is not in the tree).  Arbiter = dense
+                   F.conv3d / conv_transpose3d on the densified tensor sampled at the active sites
+                   ("known-answer material" (i)).
+  * voxelizer    : hand-made known-answer clouds (first-come ids, T truncation, max_voxels break).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import oracle as O
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def rand_sites(rng, batch, dims, n):
+    vol = batch * dims[0] * dims[1] * dims[2]
+    lin = rng.choice(vol, size=min(n, vol), replace=False)
+    rng.shuffle(lin)
+    x = lin % dims[2]; r = lin // dims[2]
+    y = r % dims[1]; r //= dims[1]
+    z = r % dims[0]; b = r // dims[0]
+    return np.stack([b, z, y, x], 1).astype(np.int32)
+
+
+def densify(feat, coords, batch, dims):
+    return torch.from_numpy(O.dense(feat, coords, batch, dims))
+
+
+# ------------------------------------------------------------------------------- voxelizer
+def test_voxelize_known_answer():
+    rng_ = [0, 0, 0, 4, 4, 2]
+    vs = [1.0, 1.0, 1.0]
+    pts = np.array([
+        [0.5, 0.5, 0.5, 1],   # voxel A (0,0,0)  -> id 0
+        [3.5, 0.5, 0.5, 2],   # voxel B (x=3)    -> id 1
+        [0.6, 0.4, 0.5, 3],   # A again
+        [9.0, 0.5, 0.5, 4],   # out of range
+        [0.5, 2.5, 1.5, 5],   # voxel C (z=1,y=2,x=0) -> id 2
+        [0.1, 0.9, 0.9, 6],   # A third point (dropped, T=2)
+        [3.9, 0.1, 0.1, 7],   # B again
+        [-0.01, 0.5, 0.5, 8],  # just below range
+    ], np.float32)
+    v, c, n = O.voxelize(pts, rng_, vs, max_points=2, max_voxels=10)
+    assert c.tolist() == [[0, 0, 0], [0, 0, 3], [1, 2, 0]]
+    assert n.tolist() == [2, 2, 1]
+    assert v[0, :, 3].tolist() == [1, 3] and v[1, :, 3].tolist() == [2, 7] and v[2, :, 3].tolist() == [5, 0]
+
+
+def test_voxelize_max_voxels_breaks():
+    pts = np.array([[0.5, 0.5, 0.5], [1.5, 0.5, 0.5], [2.5, 0.5, 0.5], [0.6, 0.5, 0.5]], np.float32)
+    v, c, n = O.voxelize(pts, [0, 0, 0, 4, 4, 2], [1, 1, 1], max_points=5, max_voxels=2)
+    # the third point would open voxel #2 -> the loop stops; the 4th point (voxel 0) is never seen
+    assert len(c) == 2 and n.tolist() == [1, 1]
+
+
+def test_voxelize_empty_and_grid_size():
+    v, c, n = O.voxelize(np.zeros((0, 7), np.float32), [0, 0, 0, 4, 4, 2], [1, 1, 1], 5, 8)
+    assert v.shape == (0, 5, 7) and c.shape == (0, 3)
+    assert O.grid_size([-70.4, -38.4, -3, 70.4, 38.4, 5], [0.1, 0.1, 0.2]).tolist() == [1408, 768, 40]
+
+
+# ------------------------------------------------------------------------------- rulebooks
+def test_subm_rulebook_known_answer():
+    coords = np.array([[0, 1, 1, 1], [0, 1, 1, 2], [0, 0, 0, 0], [1, 1, 1, 1]], np.int32)
+    nbr = O.rulebook_subm(coords, 2, [3, 3, 3])
+    assert nbr[0, 13] == 0 and nbr[1, 13] == 1 and nbr[3, 13] == 3
+    assert nbr[0, 14] == 1            # +x neighbour of row 0 is row 1
+    assert nbr[1, 12] == 0            # -x neighbour of row 1 is row 0
+    assert nbr[0, 0] == 2             # (-1,-1,-1) of (1,1,1) is (0,0,0)
+    assert nbr[2, 26] == 0
+    assert (nbr[3] >= 0).sum() == 1   # other batch: only itself
+    # symmetry used by the SubM dgrad: pair (i -> o via k) <=> (o -> i via K-1-k)
+    for o in range(4):
+        for k in range(27):
+            i = nbr[o, k]
+            if i >= 0:
+                assert nbr[i, 26 - k] == o
+
+
+def test_conv_rulebook_order_and_tables():
+    rng = np.random.default_rng(0)
+    dims = [9, 12, 10]
+    coords = rand_sites(rng, 2, dims, 150)
+    oc, od, nbr, nbrT = O.rulebook_conv(coords, 2, dims, [3, 3, 3], [2, 2, 2], [1, 1, 1])
+    assert od == [5, 6, 5]
+    lin = ((oc[:, 0] * od[0] + oc[:, 1]) * od[1] + oc[:, 2]) * od[2] + oc[:, 3]
+    assert (np.diff(lin) > 0).all(), "outputs must be in ascending linear order"
+    # nbr / nbrT are transposes of each other
+    pairs_a = {(int(nbr[o, k]), o, k) for o in range(len(oc)) for k in range(27) if nbr[o, k] >= 0}
+    pairs_b = {(i, int(nbrT[i, k]), k) for i in range(len(coords)) for k in range(27) if nbrT[i, k] >= 0}
+    assert pairs_a == pairs_b and len(pairs_a) > 0
+    # geometry of every pair: in = out*stride - pad + k
+    for (i, o, k) in list(pairs_a)[:200]:
+        kz, ky, kx = k // 9, (k // 3) % 3, k % 3
+        assert coords[i, 0] == oc[o, 0]
+        assert (coords[i, 1:] == oc[o, 1:] * 2 - 1 + np.array([kz, ky, kx])).all()
+    # spconv-style export
+    pairs, num = O.pairs_from_nbrT(nbrT)
+    assert num.sum() == len(pairs_a)
+    for k in range(27):
+        assert (np.diff(pairs[k, 0, :num[k]]) > 0).all()
+
+
+# ----------------------------------------------------------------- sparse conv vs dense conv
+@pytest.mark.parametrize("cin,cout", [(7, 16), (16, 7), (32, 64)])
+def test_subm_conv_equals_dense_conv3d(cin, cout):
+    rng = np.random.default_rng(1)
+    dims, B = [6, 9, 8], 2
+    coords = rand_sites(rng, B, dims, 120)
+    x = rng.normal(size=(len(coords), cin)).astype(np.float32)
+    W = (rng.normal(size=(27, cin, cout)) * 0.2).astype(np.float32)
+    b = rng.normal(size=(cout,)).astype(np.float32)
+    nbr = O.rulebook_subm(coords, B, dims)
+    y = O.spconv_fwd(x, W, b, nbr)
+    xd = densify(x, coords, B, dims)
+    wt = torch.from_numpy(W).reshape(3, 3, 3, cin, cout).permute(4, 3, 0, 1, 2).contiguous()
+    yd = F.conv3d(xd.double(), wt.double(), torch.from_numpy(b).double(), padding=1)
+    ys = yd[coords[:, 0], :, coords[:, 1], coords[:, 2], coords[:, 3]].float().numpy()
+    np.testing.assert_allclose(y, ys, rtol=1e-5, atol=1e-5)
+
+
+def test_strided_and_inverse_conv_equal_dense():
+    rng = np.random.default_rng(2)
+    dims, B, cin, cout = [9, 10, 12], 2, 16, 32
+    ks, st, pd = [3, 3, 3], [2, 2, 2], [0, 1, 1]
+    coords = rand_sites(rng, B, dims, 200)
+    x = rng.normal(size=(len(coords), cin)).astype(np.float32)
+    W = (rng.normal(size=(27, cin, cout)) * 0.2).astype(np.float32)
+    oc, od, nbr, nbrT = O.rulebook_conv(coords, B, dims, ks, st, pd)
+    y = O.spconv_fwd(x, W, None, nbr)
+    xd = densify(x, coords, B, dims).double()
+    wt = torch.from_numpy(W).reshape(3, 3, 3, cin, cout).permute(4, 3, 0, 1, 2).contiguous().double()
+    yd = F.conv3d(xd, wt, None, stride=st, padding=pd)
+    assert list(yd.shape[2:]) == od
+    # active outputs = where the occupancy conv is positive
+    occ = F.conv3d((xd.abs().sum(1, keepdim=True) > 0).double(), torch.ones(1, 1, 3, 3, 3).double(),
+                   stride=st, padding=pd)
+    assert int((occ > 0).sum()) == len(oc)
+    ys = yd[oc[:, 0], :, oc[:, 1], oc[:, 2], oc[:, 3]].float().numpy()
+    np.testing.assert_allclose(y, ys, rtol=1e-5, atol=1e-5)
+    # inverse conv (SparseInverseConv3d): conv_transpose3d sampled at the saved input sites
+    Wi = (rng.normal(size=(27, cout, 8)) * 0.2).astype(np.float32)
+    z = O.spconv_fwd(y, Wi, None, nbrT)
+    ydn = densify(y, oc, B, od).double()
+    wti = torch.from_numpy(Wi).reshape(3, 3, 3, cout, 8).permute(3, 4, 0, 1, 2).contiguous().double()
+    out_pad = [dims[i] - ((od[i] - 1) * st[i] - 2 * pd[i] + 3) for i in range(3)]
+    zd = F.conv_transpose3d(ydn, wti, None, stride=st, padding=pd, output_padding=out_pad)
+    zs = zd[coords[:, 0], :, coords[:, 1], coords[:, 2], coords[:, 3]].float().numpy()
+    np.testing.assert_allclose(z, zs, rtol=1e-5, atol=1e-5)
+
+
+def test_backward_matches_autograd_of_dense_conv():
+    rng = np.random.default_rng(3)
+    dims, B, cin, cout = [5, 7, 6], 1, 16, 16
+    coords = rand_sites(rng, B, dims, 70)
+    x = rng.normal(size=(len(coords), cin)).astype(np.float32)
+    W = (rng.normal(size=(27, cin, cout)) * 0.2).astype(np.float32)
+    gy = rng.normal(size=(len(coords), cout)).astype(np.float32)
+    nbr = O.rulebook_subm(coords, B, dims)
+    xd = densify(x, coords, B, dims).double().requires_grad_(True)
+    wt = torch.from_numpy(W).reshape(3, 3, 3, cin, cout).permute(4, 3, 0, 1, 2).contiguous().double().requires_grad_(True)
+    yd = F.conv3d(xd, wt, None, padding=1)
+    ys = yd[coords[:, 0], :, coords[:, 1], coords[:, 2], coords[:, 3]]
+    (ys * torch.from_numpy(gy).double()).sum().backward()
+    gx_ref = xd.grad[coords[:, 0], :, coords[:, 1], coords[:, 2], coords[:, 3]].float().numpy()
+    gw_ref = wt.grad.permute(2, 3, 4, 1, 0).reshape(27, cin, cout).float().numpy()
+    # SubM: nbrT[i][k] = nbr[i][K-1-k]
+    nbrT = nbr[:, ::-1].copy()
+    gx = O.spconv_dgrad(gy, W, nbrT)
+    gw, gb = O.spconv_wgrad(x, gy, nbr, cin, cout)
+    np.testing.assert_allclose(gx, gx_ref, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(gw, gw_ref, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(gb, gy.sum(0), rtol=1e-5, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------- chamfer
+def _ref_module():
+    from oracle import build_ref
+    return build_ref.load()
+
+
+def test_chamfer_matches_reference_build_bitexact():
+    ref = _ref_module()
+    if ref is None:
+        pytest.skip("oracle/_ref not built (reference tree absent and no prebuilt file)")
+    rng = np.random.default_rng(5)
+    for (b, n, m) in [(1, 700, 500), (2, 333, 1025), (1, 1, 1)]:
+        a = rng.normal(size=(b, n, 3)).astype(np.float32) * 10
+        c = rng.normal(size=(b, m, 3)).astype(np.float32) * 10
+        c[:, : min(m, 5)] = a[:, : min(m, 5)][:, :, :]  # exact hits / ties
+        ta, tc = torch.from_numpy(a), torch.from_numpy(c)
+        d1, d2 = torch.zeros(b, n), torch.zeros(b, m)
+        i1, i2 = torch.zeros(b, n, dtype=torch.int32), torch.zeros(b, m, dtype=torch.int32)
+        ref.forward(ta, tc, d1, d2, i1, i2)
+        d, i = O.chamfer_nn(a, c)
+        assert (i == i1.numpy()).all() and (d == d1.numpy()).all()
+        # backward (direction 1 only): feed zero grad for direction 2
+        gd = rng.normal(size=(b, n)).astype(np.float32)
+        g1, g2 = torch.zeros(b, n, 3), torch.zeros(b, m, 3)
+        ref.backward(ta, tc, g1, g2, torch.from_numpy(gd), torch.zeros(b, m), i1, i2)
+        o1, o2 = O.chamfer_grad(a, c, gd, i)
+        np.testing.assert_allclose(o1, g1.numpy(), rtol=0, atol=0)
+        np.testing.assert_allclose(o2, g2.numpy(), rtol=1e-6, atol=1e-6)
+
+
+def test_chamfer_golden_vectors():
+    f = os.path.join(GOLD, "chamfer_ref.npz")
+    g = np.load(f)
+    d, i = O.chamfer_nn(g["xyz1"], g["xyz2"])
+    assert (i == g["idx1"]).all() and (d == g["dist1"]).all()
+
+
+def test_chamfer_vs_cdist_and_tie_break():
+    rng = np.random.default_rng(6)
+    a = rng.normal(size=(1, 400, 3)).astype(np.float32)
+    c = rng.normal(size=(1, 300, 3)).astype(np.float32)
+    d, i = O.chamfer_nn(a, c)
+    ref = torch.cdist(torch.from_numpy(a).double(), torch.from_numpy(c).double()).argmin(-1).numpy()
+    assert (i == ref).mean() > 0.999
+    c2 = np.repeat(c[:, :10], 3, axis=1)  # duplicated targets: lowest index must win
+    d2, i2 = O.chamfer_nn(a, c2)
+    assert (i2 % 3 == 0).all()
