@@ -1,0 +1,245 @@
+"""GPU parity: every HIP entry point (through the C ABI) against the CPU oracle on the same inputs.
+
+Bar: bit-exact for integer/index work (voxel ids, coordinates, neighbour tables, chamfer idx) and for
+the chamfer distances; fp32 tolerance (stated per test) for the convolution arithmetic.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle as O
+from rslo_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def dev(x, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(x))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def rand_sites(rng, batch, dims, n):
+    vol = batch * dims[0] * dims[1] * dims[2]
+    lin = rng.choice(vol, size=min(n, vol), replace=False)
+    x = lin % dims[2]; r = lin // dims[2]
+    y = r % dims[1]; r //= dims[1]
+    z = r % dims[0]; b = r // dims[0]
+    return np.stack([b, z, y, x], 1).astype(np.int32)
+
+
+# ------------------------------------------------------------------------------- voxelizer
+def _vox_both(hip, pts, rng_, vs, T, maxv):
+    g = O.grid_size(rng_, vs)
+    v, c, n, nv = hip.voxelize(dev(pts), rng_, vs, g, T, maxv)
+    M = int(nv.item())
+    ov, oc, on = O.voxelize(pts, rng_, vs, T, maxv)
+    assert M == len(oc)
+    assert (c[:M].cpu().numpy() == oc).all()
+    assert (n[:M].cpu().numpy() == on).all()
+    assert (v[:M].cpu().numpy() == ov).all()
+    assert float(v[M:].abs().sum()) == 0.0 and int(n[M:].sum()) == 0
+    return v[:M], c[:M], n[:M]
+
+
+def test_voxelize_small_cases(hip):
+    rng = np.random.default_rng(0)
+    pts = (rng.random((5000, 7)) * np.array([10, 8, 4, 1, 1, 1, 1]) - np.array([1, 1, 0.5, 0, 0, 0, 0])).astype(np.float32)
+    _vox_both(hip, pts, [0, 0, 0, 8, 6, 3], [0.5, 0.5, 0.5], 3, 10000)   # T truncation, out-of-range points
+    _vox_both(hip, pts, [0, 0, 0, 8, 6, 3], [0.5, 0.5, 0.5], 5, 100)     # max_voxels break
+    _vox_both(hip, pts[:1], [0, 0, 0, 8, 6, 3], [0.5, 0.5, 0.5], 5, 100)
+    _vox_both(hip, pts[:0], [0, 0, 0, 8, 6, 3], [0.5, 0.5, 0.5], 5, 100)  # empty cloud
+
+
+def test_voxelize_kitti_shaped_scan_and_vfe(hip):
+    pts = S.scan()
+    v, c, n = _vox_both(hip, pts, S.PC_RANGE, S.VOXEL_SIZE, S.MAX_POINTS_PER_VOXEL, S.MAX_VOXELS)
+    assert len(c) > 30000
+    f = hip.vfe_mean(v, n).cpu().numpy()
+    np.testing.assert_allclose(f, O.vfe_mean(v.cpu().numpy(), n.cpu().numpy()), rtol=2e-6, atol=2e-6)
+    # cap hit: 20000 voxels
+    _vox_both(hip, pts, S.PC_RANGE, S.VOXEL_SIZE, S.MAX_POINTS_PER_VOXEL, 20000)
+
+
+# ------------------------------------------------------------------------------- rulebooks
+def _encoder_levels(hip, coords, batch, dims):
+    """Runs the rulebook chain of SpMiddleFHDWithCov2_3 on both sides; yields per-level data."""
+    specs = [([3, 3, 3], [2, 2, 2], [1, 1, 1]), ([3, 3, 3], [2, 2, 2], [1, 1, 1]),
+             ([3, 3, 3], [2, 2, 2], [0, 1, 1]), ([3, 1, 1], [2, 1, 1], [0, 0, 0])]
+    idx = hip.SiteIndex(dev(coords), batch, dims)
+    oc = coords
+    od = list(dims)
+    for li, (ks, st, pd) in enumerate(specs):
+        if li < 4:
+            nbr = hip.rulebook_subm(idx, [3, 3, 3]).cpu().numpy()
+            assert (nbr == O.rulebook_subm(oc, batch, od)).all(), "subm table level %d" % li
+        oidx, nb, nbT = hip.rulebook_conv(idx, ks, st, pd)
+        oc2, od2, onb, onbT = O.rulebook_conv(oc, batch, od, ks, st, pd)
+        assert oidx.dims == od2
+        assert (oidx.coords.cpu().numpy() == oc2).all(), "out coords level %d" % li
+        assert (nb.cpu().numpy() == onb).all() and (nbT.cpu().numpy() == onbT).all()
+        idx, oc, od = oidx, oc2, od2
+    return oc, od
+
+
+def test_rulebooks_bitexact_random_sites(hip):
+    rng = np.random.default_rng(1)
+    dims = [17, 40, 36]
+    coords = rand_sites(rng, 3, dims, 3000)
+    _encoder_levels(hip, coords, 3, dims)
+
+
+def test_rulebooks_bitexact_kitti_scan_batch2(hip):
+    cs = []
+    for b, seed in enumerate((0, 1)):
+        _, c, _ = O.voxelize(S.scan(scan_seed=seed), S.PC_RANGE, S.VOXEL_SIZE, 10, 40000)
+        cs.append(np.concatenate([np.full((len(c), 1), b, np.int32), c], 1))
+    coords = np.concatenate(cs, 0)
+    oc, od = _encoder_levels(hip, coords, 2, [41, 768, 1408])
+    assert od == [2, 96, 176]
+
+
+def test_rulebook_empty_input(hip):
+    idx = hip.SiteIndex(torch.zeros((0, 4), dtype=torch.int32, device="cuda"), 1, [5, 8, 8])
+    assert hip.rulebook_subm(idx, [3, 3, 3]).shape == (0, 27)
+    oidx, nb, nbT = hip.rulebook_conv(idx, [3, 3, 3], [2, 2, 2], [1, 1, 1])
+    assert oidx.coords.shape == (0, 4) and nb.shape == (0, 27) and nbT.shape == (0, 27)
+
+
+# ------------------------------------------------------------------------------- conv arithmetic
+CONV_TOL = dict(rtol=2e-5, atol=2e-5)   # fp32 MFMA accumulation vs the oracle's double accumulation
+
+CHANNELS = [(7, 16), (16, 16), (16, 32), (32, 32), (32, 64), (64, 64), (64, 32), (32, 16), (16, 7)]
+
+
+@pytest.mark.parametrize("cin,cout", CHANNELS)
+def test_subm_conv_fwd_bwd(hip, cin, cout):
+    rng = np.random.default_rng(10 + cin + cout)
+    dims, B = [9, 30, 28], 2
+    coords = rand_sites(rng, B, dims, 2500)   # ~16 % occupancy: every offset occurs
+    x = rng.normal(size=(len(coords), cin)).astype(np.float32)
+    W = (rng.normal(size=(27, cin, cout)) / np.sqrt(cin * 4)).astype(np.float32)
+    b = rng.normal(size=(cout,)).astype(np.float32)
+    gy = rng.normal(size=(len(coords), cout)).astype(np.float32)
+    nbr = O.rulebook_subm(coords, B, dims)
+    dn = dev(nbr)
+    y = hip.spconv_fwd(dev(x), dev(W), dev(b), dn, act_slope=0.01).cpu().numpy()
+    yo = O.spconv_fwd(x, W, b, nbr)
+    yo = np.where(yo > 0, yo, yo * np.float32(0.01))
+    np.testing.assert_allclose(y, yo, **CONV_TOL)
+    y2 = hip.spconv_fwd(dev(x), dev(W), None, dn).cpu().numpy()
+    np.testing.assert_allclose(y2, O.spconv_fwd(x, W, None, nbr), **CONV_TOL)
+    gx = hip.spconv_dgrad(dev(gy), dev(W), dn, flip_k=True).cpu().numpy()
+    np.testing.assert_allclose(gx, O.spconv_dgrad(gy, W, nbr[:, ::-1].copy()), **CONV_TOL)
+    gw, gb = hip.spconv_wgrad(dev(x), dev(gy), dn, cin, cout)
+    ow, ob = O.spconv_wgrad(x, gy, nbr, cin, cout)
+    np.testing.assert_allclose(gw.cpu().numpy(), ow, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(gb.cpu().numpy(), ob, rtol=1e-4, atol=1e-4)
+
+
+def test_strided_and_inverse_conv(hip):
+    rng = np.random.default_rng(3)
+    dims, B, cin, cout = [11, 24, 26], 2, 32, 64
+    ks, st, pd = [3, 3, 3], [2, 2, 2], [0, 1, 1]
+    coords = rand_sites(rng, B, dims, 2000)
+    x = rng.normal(size=(len(coords), cin)).astype(np.float32)
+    W = (rng.normal(size=(27, cin, cout)) * 0.1).astype(np.float32)
+    oc, od, nbr, nbrT = O.rulebook_conv(coords, B, dims, ks, st, pd)
+    y = hip.spconv_fwd(dev(x), dev(W), None, dev(nbr)).cpu().numpy()
+    yo = O.spconv_fwd(x, W, None, nbr)
+    np.testing.assert_allclose(y, yo, **CONV_TOL)
+    gy = rng.normal(size=yo.shape).astype(np.float32)
+    gx = hip.spconv_dgrad(dev(gy), dev(W), dev(nbrT)).cpu().numpy()
+    np.testing.assert_allclose(gx, O.spconv_dgrad(gy, W, nbrT), **CONV_TOL)
+    gw, _ = hip.spconv_wgrad(dev(x), dev(gy), dev(nbr), cin, cout, with_bias=False)
+    np.testing.assert_allclose(gw.cpu().numpy(), O.spconv_wgrad(x, gy, nbr, cin, cout)[0], rtol=1e-4, atol=1e-4)
+    # inverse conv: forward over the transposed table with its own weight [K, cout, c2]
+    Wi = (rng.normal(size=(27, cout, 32)) * 0.1).astype(np.float32)
+    z = hip.spconv_fwd(dev(yo), dev(Wi), None, dev(nbrT)).cpu().numpy()
+    np.testing.assert_allclose(z, O.spconv_fwd(yo, Wi, None, nbrT), **CONV_TOL)
+
+
+def test_conv_ragged_sizes_and_empty(hip):
+    rng = np.random.default_rng(4)
+    for n in (1, 15, 63, 64, 65, 129):
+        dims = [4, 8, 8]
+        coords = rand_sites(rng, 1, dims, n)
+        x = rng.normal(size=(len(coords), 16)).astype(np.float32)
+        W = (rng.normal(size=(27, 16, 16)) * 0.1).astype(np.float32)
+        nbr = O.rulebook_subm(coords, 1, dims)
+        y = hip.spconv_fwd(dev(x), dev(W), None, dev(nbr)).cpu().numpy()
+        np.testing.assert_allclose(y, O.spconv_fwd(x, W, None, nbr), **CONV_TOL)
+    e = hip.spconv_fwd(torch.zeros((0, 16), device="cuda"), dev(W), None,
+                       torch.zeros((0, 27), dtype=torch.int32, device="cuda"))
+    assert e.shape == (0, 16)
+
+
+def test_conv_linearity_at_full_size(hip):
+    """Size-independent property at the BASELINE scan size: conv(a*x1 + x2) == a*conv(x1) + conv(x2)."""
+    _, c, _ = O.voxelize(S.scan(), S.PC_RANGE, S.VOXEL_SIZE, 10, 40000)
+    coords = np.concatenate([np.zeros((len(c), 1), np.int32), c], 1)
+    idx = hip.SiteIndex(dev(coords), 1, [41, 768, 1408])
+    nbr = hip.rulebook_subm(idx, [3, 3, 3])
+    g = torch.Generator(device="cuda").manual_seed(0)
+    x1 = torch.randn((len(c), 16), device="cuda", generator=g)
+    x2 = torch.randn((len(c), 16), device="cuda", generator=g)
+    W = torch.randn((27, 16, 16), device="cuda", generator=g) * 0.1
+    lhs = hip.spconv_fwd((2.5 * x1 + x2).contiguous(), W, None, nbr)
+    rhs = 2.5 * hip.spconv_fwd(x1, W, None, nbr) + hip.spconv_fwd(x2, W, None, nbr)
+    assert float((lhs - rhs).abs().max()) < 1e-4
+    # and against the oracle on the full-size table
+    yo = O.spconv_fwd(x1.cpu().numpy(), W.cpu().numpy(), None, nbr.cpu().numpy())
+    np.testing.assert_allclose(hip.spconv_fwd(x1, W, None, nbr).cpu().numpy(), yo, **CONV_TOL)
+
+
+def test_dense_scatter_gather(hip):
+    rng = np.random.default_rng(5)
+    dims, B, Cc = [2, 12, 10], 3, 64
+    coords = rand_sites(rng, B, dims, 200)
+    f = rng.normal(size=(len(coords), Cc)).astype(np.float32)
+    d = hip.dense_scatter(dev(f), dev(coords), B, dims)
+    assert (d.cpu().numpy() == O.dense(f, coords, B, dims)).all()
+    back = hip.dense_gather(d, dev(coords), Cc, B, dims)
+    assert (back.cpu().numpy() == f).all()
+
+
+def test_leaky_bwd(hip):
+    y = torch.randn(1001, device="cuda")
+    g = torch.randn(1001, device="cuda")
+    out = hip.leaky_bwd(y, g, 0.01)
+    assert torch.equal(out, torch.where(y > 0, g, g * 0.01))
+
+
+# ------------------------------------------------------------------------------- chamfer
+def test_chamfer_golden_and_oracle_bitexact(hip):
+    g = np.load(os.path.join(GOLD, "chamfer_ref.npz"))
+    d, i = hip.chamfer_nn(dev(g["xyz1"]), dev(g["xyz2"]))
+    assert (i.cpu().numpy() == g["idx1"]).all() and (d.cpu().numpy() == g["dist1"]).all()
+    g1, g2 = hip.chamfer_grad(dev(g["xyz1"]), dev(g["xyz2"]), dev(g["graddist1"]), i)
+    np.testing.assert_allclose(g1.cpu().numpy(), g["gradxyz1"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(g2.cpu().numpy(), g["gradxyz2"], rtol=1e-5, atol=1e-5)
+    rng = np.random.default_rng(7)
+    for (b, n, m) in [(1, 1, 1), (1, 5, 3000), (3, 1025, 777), (1, 4097, 4096)]:
+        a = (rng.normal(size=(b, n, 3)) * 10).astype(np.float32)
+        c = (rng.normal(size=(b, m, 3)) * 10).astype(np.float32)
+        d, i = hip.chamfer_nn(dev(a), dev(c))
+        od, oi = O.chamfer_nn(a, c)
+        assert (i.cpu().numpy() == oi).all() and (d.cpu().numpy() == od).all()
+
+
+def test_chamfer_full_size_properties(hip):
+    """At the BASELINE size (~31k x 31k): self-query gives idx == arange and dist == 0; a sampled
+    subset agrees bit-exactly with the oracle."""
+    v, c, n = O.voxelize(S.scan(), S.PC_RANGE, S.VOXEL_SIZE, 10, 40000)
+    p = O.vfe_mean(v, n)[:, :3][None].copy()
+    t = dev(p)
+    d, i = hip.chamfer_nn(t, t)
+    assert torch.equal(i[0].long(), torch.arange(p.shape[1], device="cuda")) and float(d.abs().max()) == 0.0
+    q = (p[:, ::37] + np.float32(0.05)).copy()
+    d, i = hip.chamfer_nn(dev(q), t)
+    od, oi = O.chamfer_nn(q, p)
+    assert (i.cpu().numpy() == oi).all() and (d.cpu().numpy() == od).all()
