@@ -1,0 +1,224 @@
+"""Losses of the RSLO hot path (reference: rslo/core/losses.py:56-113,144-197,301-507).
+
+`AdaptiveWeightedL2Loss`: L2 with a learnable log-variance.
+`Aleat5_1ChamferL2NormalWeightedALLSVDLoss`: the self-supervised consistency loss -- nearest-neighbour
+association (chamfer), 97th-percentile ROI, covariance-weighted (Mahalanobis) point residual with a
+log-det regulariser, and a detached weighted-Kabsch ICP refinement that produces the pseudo-targets.
+
+MI355X form: all frame pairs are processed as one batch with static shapes -- the ROI is a 0/1 weight
+instead of a boolean gather (no dynamic shapes, no host sync), the 3x3 inverse/determinant are closed
+form, the Kabsch step is batched and branch-free.  Values equal the reference's per-pair loop up to fp32
+summation order.  The association runs on the hand-written chamfer kernel (thirdparty.chamfer_distance).
+"""
+from abc import ABCMeta, abstractmethod
+
+import apex.amp as amp
+import kornia
+import torch
+from torch import nn
+
+from rslo.layers.svd import SVDHead, kabsch_rotation
+
+
+class Loss(nn.Module):
+    """Abstract base class for loss functions."""
+    __metaclass__ = ABCMeta
+
+    def __init__(self, loss_weight=1):
+        super().__init__()
+        self._loss_weight = loss_weight
+
+    def forward(self, prediction_tensor, target_tensor, ignore_nan_targets=False, scope=None, **params):
+        if ignore_nan_targets:
+            target_tensor = torch.where(torch.isnan(target_tensor), prediction_tensor, target_tensor)
+        ret = self._compute_loss(prediction_tensor, target_tensor, **params)
+        if isinstance(ret, (list, tuple)):
+            return [self._loss_weight * ret[0]] + list(ret[1:])
+        return self._loss_weight * ret
+
+    @abstractmethod
+    @amp.float_function
+    def _compute_loss(self, prediction_tensor, target_tensor, **params):
+        pass
+
+
+def _adaptive_reduce(loss_b, alpha, focal_gamma):
+    """exp(-a) * sum_b fw_b loss_b + a with fw = normalised (exp(-a) loss)^gamma (losses.py:190-196)."""
+    fw = (torch.exp(-alpha) * loss_b) ** focal_gamma
+    fw = fw / (torch.sum(fw) + 1e-12)
+    return (fw * (torch.exp(-alpha) * loss_b)).sum() + alpha
+
+
+class AdaptiveWeightedL2Loss(Loss):
+    def __init__(self, init_alpha, learn_alpha=True, loss_weight=1, focal_gamma=0, balance_scale=1):
+        super().__init__(loss_weight)
+        self.learn_alpha = learn_alpha
+        self.alpha = nn.Parameter(torch.Tensor([init_alpha]), requires_grad=learn_alpha)
+        self.focal_gamma = focal_gamma
+
+    def _compute_loss(self, prediction_tensor, target_tensor, mask=None, alpha=None, focal_gamma=None):
+        if focal_gamma is None:
+            focal_gamma = self.focal_gamma
+        mask = torch.ones_like(target_tensor) if mask is None else mask.expand_as(target_tensor)
+        diff = prediction_tensor - target_tensor
+        dims = list(range(1, prediction_tensor.dim()))
+        loss_b = torch.sum(diff * diff * mask, dim=dims) / (torch.sum(mask, dim=dims) + 1e-12)
+        return _adaptive_reduce(loss_b, self.alpha, focal_gamma)
+
+
+def span_cov2(cov_param):
+    """7 covariance parameters -> (Sigma [..,3,3], eigenvectors V): cumulative eigenvalues
+    l1 = p0, l2 = l1 + p1, l3 = l2 + p2; V = R(quat p3..6 / (|.| + 1e-9)) with the channels read as
+    (x, y, z, w) -- no roll (losses.py:348-363)."""
+    shp = cov_param.shape[:-1]
+    p = cov_param.reshape(-1, 7)
+    l1 = p[:, 0]
+    l2 = l1 + p[:, 1]
+    l3 = l2 + p[:, 2]
+    lam = torch.stack([l1, l2, l3], -1)
+    q = p[:, 3:] / (torch.norm(p[:, 3:], dim=-1, keepdim=True) + 1e-9)
+    V = kornia.quaternion_to_rotation_matrix(q)
+    sigma = (V * lam[:, None, :]) @ V.transpose(-1, -2)
+    return sigma.reshape(*shp, 3, 3), V.reshape(*shp, 3, 3)
+
+
+def sym3_inverse_det(S):
+    """Closed-form inverse and determinant of a batch of 3x3 matrices (adjugate / det); replaces the
+    reference's torch.inverse / torch.det over ~30k matrices (losses.py:424,435)."""
+    a, b, c = S[..., 0, 0], S[..., 0, 1], S[..., 0, 2]
+    d, e, f = S[..., 1, 0], S[..., 1, 1], S[..., 1, 2]
+    g, h, i = S[..., 2, 0], S[..., 2, 1], S[..., 2, 2]
+    A, B, C_ = e * i - f * h, -(d * i - f * g), d * h - e * g
+    det = a * A + b * B + c * C_
+    adj = torch.stack([torch.stack([A, -(b * i - c * h), b * f - c * e], -1),
+                       torch.stack([B, a * i - c * g, -(a * f - c * d)], -1),
+                       torch.stack([C_, -(a * h - b * g), a * e - b * d], -1)], -2)
+    return adj / det[..., None, None], det
+
+
+def points_roi(dist, penalize_ratio):
+    """dist [B,N] -> bool mask dist < max(kth(dist, 1 + int(N * ratio)), 1.0) (losses.py:326-334)."""
+    N = dist.shape[-1]
+    k = 1 + int(N * penalize_ratio)
+    m, _ = torch.kthvalue(dist, min(k, N), dim=-1, keepdim=True)
+    m = torch.max(m, torch.ones_like(m))
+    return dist < m
+
+
+def gather_rows(x, idx):
+    """x [B,M,...], idx [B,N] long -> [B,N,...]."""
+    tail = x.shape[2:]
+    flat = x.reshape(x.shape[0], x.shape[1], -1)
+    out = torch.gather(flat, 1, idx[..., None].expand(-1, -1, flat.shape[-1]))
+    return out.reshape(x.shape[0], idx.shape[1], *tail)
+
+
+def masked_kabsch(src, tgt, w, mask):
+    """SVDHead (rslo/layers/svd.py:14-64) over the rows selected by `mask`, without gathering them:
+    unweighted centroids over the selection, H = sum mask*w (src-c_s)(tgt-c_t)^T.  src,tgt [B,N,3];
+    w, mask [B,N].  Returns the INVERSE motion (R^T, -R^T t) like SVDHead."""
+    m = mask.to(src.dtype)
+    cnt = m.sum(-1, keepdim=True).clamp_min(1.0)
+    cs = (src * m[..., None]).sum(1) / cnt
+    ct = (tgt * m[..., None]).sum(1) / cnt
+    sc = (src - cs[:, None]) * (m * w)[..., None]
+    H = sc.transpose(1, 2) @ (tgt - ct[:, None])
+    R = kabsch_rotation(H)
+    t = -(R @ cs[..., None]) + ct[..., None]
+    Rt = R.transpose(-1, -2).contiguous()
+    return Rt, -(Rt @ t).squeeze(-1)
+
+
+class ChamferL2Loss(Loss):
+    def __init__(self, *args, **kwargs):
+        raise NotImplementedError("ChamferL2Loss is not configured on the RSLO hot path")
+
+
+class Aleat5_1ChamferL2NormalWeightedALLSVDLoss(Loss):
+    def __init__(self, init_alpha=0, learn_alpha=False, loss_weight=1, focal_gamma=0, n_samples=-1,
+                 penalize_ratio=0.95, sample_block_size=(0.1, 1, 1), norm=True, pred_downsample_ratio=1,
+                 reg_weight=0.001, sph_weight=1):
+        super().__init__(loss_weight=loss_weight)
+        from thirdparty.chamfer_distance.chamfer_distance import OneDirectionChamferDistanceWithIdx
+        self.learn_alpha = learn_alpha
+        self.alpha = nn.Parameter(torch.Tensor([init_alpha]), requires_grad=learn_alpha)
+        self.focal_gamma = focal_gamma
+        self.n_samples = n_samples
+        self.penalize_ratio = penalize_ratio
+        self.sample_block_size = sample_block_size
+        self.cd = OneDirectionChamferDistanceWithIdx()
+        self.norm = norm
+        self.svd = SVDHead()
+        if pred_downsample_ratio < 1:
+            raise NotImplementedError("pred_downsample_ratio < 1 is not configured on the RSLO hot path")
+        self.pred_downsample_ratio = pred_downsample_ratio
+        self.reg_weight = reg_weight
+        self.sph_weight = sph_weight
+
+    def _points_roi(self, dist, penalize_ratio=0.95, dist_threshold=None):
+        if dist_threshold is not None:
+            return dist < dist_threshold
+        return points_roi(dist, penalize_ratio)
+
+    def _associate(self, xyz_pred, target, normal_pred):
+        with torch.no_grad():
+            dist, idx = self.cd(xyz_pred.detach(), target.detach())
+            idx = idx.long()
+            roi = points_roi(dist, self.penalize_ratio)
+        assoc = gather_rows(target, idx)
+        w = nn.functional.cosine_similarity(normal_pred, (assoc - xyz_pred).detach(), dim=-1).abs()
+        return idx, roi, assoc, w
+
+    def _compute_loss(self, xyz_pred, xyz_target, cov_pred, cov_target, R_pred, t_pred, normal_pred,
+                      normal_target, mask=None, alpha=None, focal_gamma=None, icp_iter=1):
+        """xyz_pred [B,N,3], xyz_target [B,M,3], cov_* [B,.,7], R_pred [B,3,3] -> (loss, res_R, res_T)."""
+        assert mask is None, "per-point masks are not used by the configured loss (voxel_odom_net.py:706)"
+        loss_b, res_r, res_t = self.pair_losses(xyz_pred, xyz_target, cov_pred, cov_target, R_pred, t_pred,
+                                                normal_pred, normal_target, icp_iter=icp_iter)
+        return self.reduce(loss_b, focal_gamma), res_r, res_t
+
+    def reduce(self, loss_b, focal_gamma=None):
+        """mean over pairs, then exp(-alpha) * loss + alpha (losses.py:496-506)."""
+        if focal_gamma is None:
+            focal_gamma = self.focal_gamma
+        loss = loss_b.sum() / loss_b.shape[0]
+        fw = (torch.exp(-self.alpha) * loss) ** focal_gamma
+        fw = fw / (torch.sum(fw) + 1e-12)
+        return (fw * (torch.exp(-self.alpha) * loss)).sum() + self.alpha
+
+    def pair_losses(self, xyz_pred, xyz_target, cov_pred, cov_target, R_pred, t_pred, normal_pred,
+                    normal_target, icp_iter=1):
+        """Per-pair residual loss [B] and the ICP refinement (res_R [B,3,3], res_T [B,3])."""
+        sig1, _ = span_cov2(cov_pred)
+        sig2, _ = span_cov2(cov_target)
+
+        idx, roi, xyz_assoc, weight = self._associate(xyz_pred, xyz_target, normal_pred)
+        sig2_assoc = gather_rows(sig2, idx)
+        diff_vec = xyz_pred - xyz_assoc
+        Rd = R_pred.detach()[:, None]
+        sigma = sig1 + Rd @ sig2_assoc @ Rd.transpose(-1, -2)
+        sigma_inv, det = sym3_inverse_det(sigma)
+        sq = (diff_vec.unsqueeze(-2) @ sigma_inv @ diff_vec.unsqueeze(-1)).reshape(diff_vec.shape[:2])
+        m = roi.to(sq.dtype)
+        cnt = m.sum(-1)
+        zero = torch.zeros_like(sq)
+        loss_b = torch.where(roi, sq, zero).sum(-1) / cnt \
+            + self.reg_weight * torch.where(roi, 0.5 * torch.log(det), zero).sum(-1) / cnt
+
+        # detached ICP refinement (losses.py:449-488)
+        with torch.no_grad():
+            B = xyz_pred.shape[0]
+            src = xyz_pred.detach()
+            tgt0 = xyz_target.detach()
+            res_r = torch.eye(3, device=src.device, dtype=src.dtype).expand(B, 3, 3).contiguous()
+            res_t = torch.zeros(B, 3, device=src.device, dtype=src.dtype)
+            assoc, w, sel = xyz_assoc.detach(), weight.detach(), roi
+            for it in range(icp_iter):
+                R, t = masked_kabsch(src, assoc, w * w, sel)
+                res_r = R @ res_r
+                res_t = (R @ res_t[..., None]).squeeze(-1) + t
+                if it < icp_iter - 1:
+                    moved = tgt0 @ res_r.transpose(-1, -2) + res_t[:, None]
+                    _, sel, assoc, w = self._associate(src, moved, normal_pred.detach())
+
+        return loss_b, res_r, res_t

@@ -1,0 +1,51 @@
+"""BasicBlock of the BEV encoder (reference: rslo/models/custom_resnet_spc.py:224-298): two 3x3
+(mask-)convs with BN, residual add where masks are averaged, ReLU."""
+import torch
+import torch.nn as nn
+
+from rslo.layers.SparseConv import SPC_LeakyReLU, SPC_ReLU
+
+
+def conv1x1(in_planes, out_planes, stride=1, Conv2d=None, groups=1):
+    return Conv2d(in_planes, out_planes, kernel_size=1, stride=stride, padding=0, bias=False, groups=groups)
+
+
+def conv3x3(in_planes, out_planes, stride=1, Conv2d=None, groups=1):
+    return Conv2d(in_planes, out_planes, kernel_size=3, stride=stride, padding=1, bias=False, groups=groups)
+
+
+def SPC_add(a, b):
+    if isinstance(a, (list, tuple)):
+        return [a[0] + b[0], ((a[1] + b[1]) / 2).float()]
+    return a + b
+
+
+def SPC_cat(a, b):
+    if isinstance(a, (list, tuple)):
+        return [torch.cat([a[0], b[0]], dim=1), ((a[1] + b[1]) / 2).float()]
+    return torch.cat([a, b], dim=1)
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, lrelu=False, BN=None, Conv2d=None, groups=1,
+                 use_se=False, use_sa=False):
+        super().__init__()
+        assert not use_se and not use_sa, "SE / spatial attention are off in the shipped config"
+        self.BatchNorm2d = BN if BN is not None else nn.BatchNorm2d
+        self.Conv2d = Conv2d if Conv2d is not None else nn.Conv2d
+        self.conv1 = conv3x3(inplanes, planes, stride, Conv2d=self.Conv2d, groups=groups)
+        self.bn1 = self.BatchNorm2d(planes)
+        self.relu = SPC_LeakyReLU(0.1, True) if lrelu else SPC_ReLU(inplace=True)
+        self.conv2 = conv3x3(planes, planes, Conv2d=self.Conv2d, groups=groups)
+        self.bn2 = self.BatchNorm2d(planes)
+        self.downsample = downsample
+        self.stride = stride
+        self.use_se = self.use_sa = False
+
+    def forward(self, x):
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.bn2(self.conv2(out))
+        residual = x if self.downsample is None else self.downsample(x)
+        return self.relu(SPC_add(out, residual))

@@ -1,0 +1,103 @@
+"""Sparse 3-D Geometric-Unit encoder with the covariance branch
+(reference: rslo/models/middle.py:36-245; layer table SURVEY.md App-A.1).
+
+  middle_conv       subm0 x2 -> conv3d2 (s2) -> subm1 x2 -> conv3d3 (s2)                     -> ret0
+  middle_conv_tail  subm2 x3 -> conv3d4 (s2, pad (0,1,1)) -> subm3 x3 -> conv3d5 ((3,1,1)/(2,1,1)) -> BEV
+  middle_cov_deconv inv(conv3d3) BN -> dsubm3 BN -> inv(conv3d2) BN -> dsubm2 x2 BN -> dsubm1 -> 7 params
+
+Differences from the reference that do not change results: any batch_size is accepted (the reference
+asserts 1; BatchNorm1d statistics stay per frame, see spconv.SparseSequential); the ELU on the
+eigenvalue channels is out of place (the in-place write at middle.py:237 breaks autograd in torch 2).
+"""
+import numpy as np
+import spconv
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from torchplus.nn import Empty
+from torchplus.tools import change_default_args
+
+REGISTERED_MIDDLE_CLASSES = {}
+
+
+def register_middle(cls, name=None):
+    name = cls.__name__ if name is None else name
+    assert name not in REGISTERED_MIDDLE_CLASSES, f"exist class: {REGISTERED_MIDDLE_CLASSES}"
+    REGISTERED_MIDDLE_CLASSES[name] = cls
+    return cls
+
+
+def get_middle_class(name):
+    assert name in REGISTERED_MIDDLE_CLASSES, f"available class: {REGISTERED_MIDDLE_CLASSES}"
+    return REGISTERED_MIDDLE_CLASSES[name]
+
+
+@register_middle
+class SpMiddleFHDWithCov2_3(nn.Module):
+    def __init__(self, output_shape, use_GN=False, sync_bn=False, bn_type="None", use_leakyReLU=False,
+                 relu_type="ReLU", num_input_features=128, num_filters_down1=[64], num_filters_down2=[64, 64],
+                 name="SpMiddleFHDWithConf"):
+        super().__init__()
+        assert bn_type in ["None", "BN", "SyncBN", "SemiGlobalSyncBN", "MaskSyncBN"]
+        assert relu_type in ["", "ReLU", "LeakyReLU", "PReLU"]
+        self.name = name
+        if bn_type == "None":
+            BatchNorm1d = Empty
+        elif bn_type == "BN":
+            BatchNorm1d = change_default_args(eps=1e-3, momentum=0.01)(nn.BatchNorm1d)
+        else:
+            raise NotImplementedError("encoder bn_type %r is outside the shipped configuration" % bn_type)
+        SpConv3d = change_default_args(bias=True)(spconv.SparseConv3d)
+        SubMConv3d = change_default_args(bias=True)(spconv.SubMConv3d)
+        InvConv3d = change_default_args(bias=True)(spconv.SparseInverseConv3d)
+        if use_leakyReLU or relu_type == "LeakyReLU":
+            self.relu = nn.LeakyReLU
+        elif relu_type == "ReLU":
+            self.relu = nn.ReLU
+        else:
+            raise NotImplementedError("relu_type %r" % relu_type)
+        act = self.relu
+
+        self.sparse_shape = np.array(output_shape[1:4]) + [1, 0, 0]
+        self.voxel_output_shape = output_shape
+        c = num_input_features
+        self.middle_conv = spconv.SparseSequential(
+            SubMConv3d(c, 16, 3, indice_key="subm0"), BatchNorm1d(16), act(),
+            SubMConv3d(16, 16, 3, indice_key="subm0"), BatchNorm1d(16), act(),
+            SpConv3d(16, 32, 3, 2, padding=1, indice_key="conv3d2"), BatchNorm1d(32), act(),
+            SubMConv3d(32, 32, 3, indice_key="subm1"), BatchNorm1d(32), act(),
+            SubMConv3d(32, 32, 3, indice_key="subm1"), BatchNorm1d(32), act(),
+            SpConv3d(32, 64, 3, 2, padding=1, indice_key="conv3d3"), BatchNorm1d(64), act(),
+        )
+        self.middle_conv_tail = spconv.SparseSequential(
+            SubMConv3d(64, 64, 3, indice_key="subm2"), BatchNorm1d(64), act(),
+            SubMConv3d(64, 64, 3, indice_key="subm2"), BatchNorm1d(64), act(),
+            SubMConv3d(64, 64, 3, indice_key="subm2"), BatchNorm1d(64), act(),
+            SpConv3d(64, 64, 3, 2, padding=[0, 1, 1], indice_key="conv3d4"), BatchNorm1d(64), act(),
+            SubMConv3d(64, 64, 3, indice_key="subm3"), BatchNorm1d(64), act(),
+            SubMConv3d(64, 64, 3, indice_key="subm3"), BatchNorm1d(64), act(),
+            SubMConv3d(64, 64, 3, indice_key="subm3"), BatchNorm1d(64), act(),
+            SpConv3d(64, 64, (3, 1, 1), (2, 1, 1), indice_key="conv3d5"), BatchNorm1d(64), act(),
+        )
+        self.middle_cov_deconv = spconv.SparseSequential(
+            InvConv3d(64, 32, 3, indice_key="conv3d3"), nn.BatchNorm1d(32), act(),
+            SubMConv3d(32, 32, 3, indice_key="dsubm3"), nn.BatchNorm1d(32), act(),
+            InvConv3d(32, 16, 3, indice_key="conv3d2"), nn.BatchNorm1d(16), act(),
+            SubMConv3d(16, 16, 3, indice_key="dsubm2"), nn.BatchNorm1d(16), act(),
+            SubMConv3d(16, 16, 3, indice_key="dsubm2"), nn.BatchNorm1d(16), act(),
+            SubMConv3d(16, 7, 3, indice_key="dsubm1"),
+        )
+        self.max_batch_size = 6
+
+    def forward(self, voxel_features, coors, batch_size):
+        coors = coors.int()
+        x = spconv.SparseConvTensor(voxel_features, coors, self.sparse_shape, batch_size)
+        ret0 = self.middle_conv(x)
+        ret = self.middle_conv_tail(ret0)
+        cov = self.middle_cov_deconv(ret0).features
+        # eigenvalue increments > 0 (middle.py:237), out of place
+        cov = torch.cat([F.elu(cov[:, :3]) + 1 + 1e-6, cov[:, 3:]], dim=1)
+        dense = ret.dense()
+        N, Cc, D, H, W = dense.shape
+        return dense.view(N, Cc * D, H, W), cov

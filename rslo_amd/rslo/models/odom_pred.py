@@ -1,0 +1,161 @@
+"""BEV odometry head: per-unit transformation maps, confidences and the ego-motion vote
+(reference: rslo/models/odom_pred.py:45-435; call stack SURVEY.md 3.3.1).
+
+xs = [bev_0, bev_1(, bev_2)] each [B,128,96,176] -> all (i<j) pairs -> encoder-decoder -> per-cell
+local (t, q) map -> local->global transform -> confidence-weighted mean = the pair's pose.
+"""
+import apex
+import apex.amp as amp
+import torch
+from torch import nn
+
+import rslo.models.custom_resnet_spc as resnet
+from rslo.data.dataset import from_pointwise_local_transformation_tch
+from rslo.layers.confidence import ConfidenceModule
+from rslo.layers.MaskConv import MaskConv
+from rslo.models.odom_pred_base import OdomPredEncDecBase, conf_trunk
+from rslo.utils.pose_utils import rotate_vec_by_q
+from torchplus.nn import Empty
+
+REGISTERED_ODOM_PRED_CLASSES = {}
+
+
+def register_odom_pred(cls, name=None):
+    name = cls.__name__ if name is None else name
+    assert name not in REGISTERED_ODOM_PRED_CLASSES, f"exist class: {REGISTERED_ODOM_PRED_CLASSES}"
+    REGISTERED_ODOM_PRED_CLASSES[name] = cls
+    return cls
+
+
+def get_odom_class(name):
+    assert name in REGISTERED_ODOM_PRED_CLASSES, f"available class: {REGISTERED_ODOM_PRED_CLASSES}"
+    return REGISTERED_ODOM_PRED_CLASSES[name]
+
+
+class UNOdomPredEncDecSVDTempMaskBase(OdomPredEncDecBase):
+    def __init__(self, use_svd=True, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.use_svd = use_svd
+        if use_svd:
+            raise NotImplementedError("use_svd=True vote is a 'next' row (SURVEY.md 8f-4)")
+        nuf = list(kwargs.get("num_upsample_filters"))
+        conf_type = kwargs.get("conf_type")
+        motion, tconf, qconf = [], [], []
+        if self.pred_pyramid_motion:
+            for c in nuf:
+                motion.append(nn.Sequential(
+                    nn.Conv2d(c, c // 2, kernel_size=3, stride=1, padding=1), self.BatchNorm2d(c // 2), self.ReLU(),
+                    nn.Conv2d(c // 2, 64, kernel_size=3, stride=1, padding=1), self.BatchNorm2d(64), self.ReLU(),
+                    nn.Conv2d(64, 7, 1, stride=1)))
+                tconf.append(ConfidenceModule(conf_trunk(c, self.BatchNorm2d, self.ReLU), conf_type=conf_type))
+                qconf.append(ConfidenceModule(conf_trunk(c, self.BatchNorm2d, self.ReLU), conf_type=conf_type))
+        self.pyramid_motion_blocks = nn.ModuleList(motion)
+        self.q_map_conf = ConfidenceModule(conf_trunk(nuf[-1], self.BatchNorm2d, self.ReLU), conf_type=conf_type)
+        self.t_map_conf = ConfidenceModule(conf_trunk(nuf[-1], self.BatchNorm2d, self.ReLU), conf_type=conf_type)
+        self.pyramid_tconf_blocks = nn.ModuleList(tconf)   # present in checkpoints, never called
+        self.pyramid_qconf_blocks = nn.ModuleList(qconf)
+        self.hier_weight_gen = nn.AvgPool2d(3, 2, padding=1)
+
+    @amp.float_function
+    def forward(self, xs, tq_map_gt=None, local_spatial_features=None, **kwargs):
+        if not isinstance(xs, list):
+            xs = [xs]
+        if self._cycle_constraint:
+            xs = self.create_cycle_constraint_data(xs)
+        with torch.no_grad():   # occupancy of the FIRST frame of each pair only (odom_pred.py:165-168)
+            input_mask_bool = xs[0].sum(dim=1, keepdim=True) != 0
+            input_mask = input_mask_bool.to(dtype=xs[0].dtype)
+
+        x = torch.cat(xs, dim=1)
+        ups = []
+        for blk, skip in zip(self.blocks, self.skip_blocks):
+            x = blk(x)
+            ups.append(skip(x[0]))
+        x = x[0]
+
+        py_masks = []
+        if self.pred_pyramid_motion:
+            m = input_mask
+            for i in range(len(self.deblocks) - 1):
+                m = self.mask_gen_pools[-(i + 1)](m)
+                py_masks.append(m)
+            py_masks.reverse()
+
+        py_preds = []
+        for i, deblock in enumerate(self.deblocks):
+            x = deblock(torch.cat([x, ups[-(i + 1)]], dim=1))
+            if self.pred_pyramid_motion and i < len(self.deblocks) - 1:
+                p = self.pyramid_motion_blocks[i](x)
+                py_preds.append([p * (py_masks[i] > 0).to(dtype=p.dtype), py_masks[i]])
+        x_tail = x
+
+        tq_map = self.tq_map_conv(x)
+        tq_map = torch.cat([tq_map[:, :3], tq_map[:, 3:] / torch.norm(tq_map[:, 3:], dim=1, keepdim=True)], dim=1)
+
+        if not self.dense_predict:
+            raise NotImplementedError("the fc (non-dense) head is outside the RSLO hot path")
+        t_conf = self.t_map_conf(x_tail, extra_mask=input_mask)
+        r_conf = self.q_map_conf(x_tail, extra_mask=input_mask)
+        tq_map_g, odom = self.vote(tq_map, t_conf, r_conf)
+        odoms = [odom]
+
+        with torch.no_grad():   # temperature-20 confidences on detached features -> loss masks
+            temp_tq_conf = torch.cat([self.t_map_conf(x_tail.detach(), extra_mask=input_mask, temperature=20),
+                                      self.q_map_conf(x_tail.detach(), extra_mask=input_mask, temperature=20)], 1)
+        pyramid_motion = py_preds + [[tq_map * input_mask, input_mask * temp_tq_conf]]
+        for p in range(2, len(pyramid_motion) + 1):
+            pyramid_motion[-p][1] = pyramid_motion[-p][1] * self.hier_weight_gen(pyramid_motion[-(p - 1)][1])
+
+        translations, rotations = [], []
+        for o in odoms:
+            t, r = o[:, :3], o[:, 3:]
+            if self.odom_format == "r(x+t)":
+                t = rotate_vec_by_q(t, r)
+            r = r / (torch.norm(r, dim=1, keepdim=True) + 1e-12)
+            translations.append(t)
+            rotations.append(r)
+        return {"translation_preds": translations, "rotation_preds": rotations, "tq_map_g": tq_map_g * input_mask,
+                "pyramid_motion": pyramid_motion, "transformed_inputs": None, "t_conf": t_conf, "r_conf": r_conf}
+
+    def vote(self, tq_map, t_conf, r_conf):
+        """Ego-motion voting (odom_pred.py:347-357): confidence-weighted mean of the global maps."""
+        tq_map_g = from_pointwise_local_transformation_tch(tq_map, self.point_cloud_range)
+        t = (tq_map_g[:, :3] * t_conf).sum(dim=(2, 3)) / (t_conf.sum(dim=(2, 3)) + 1e-12)
+        q = (tq_map_g[:, 3:] * r_conf).sum(dim=(2, 3)) / (r_conf.sum(dim=(2, 3)) + 1e-12)
+        return tq_map_g, torch.cat([t, q], dim=-1)
+
+    def aggregate_tq(self, tq_maps, selected_masks, t_confs, r_confs):
+        assert len(tq_maps) == len(selected_masks) == len(t_confs) == len(r_confs)
+        return [self.vote(m, tc, rc)[1] for m, tc, rc in zip(tq_maps, t_confs, r_confs)]
+
+
+def conv1x1(in_planes, out_planes, stride=1, Conv2d=None, groups=1):
+    Conv2d = nn.Conv2d if Conv2d is None else Conv2d
+    return Conv2d(in_planes, out_planes, kernel_size=1, stride=stride, bias=False, groups=groups)
+
+
+@register_odom_pred
+class UNRResNetOdomPredEncDecSVDTempMask(UNOdomPredEncDecSVDTempMaskBase):
+    def __init__(self, *args, **kw):
+        self.inplanes = -1
+        super().__init__(*args, **kw)
+        for m in self.modules():   # odom_pred.py:379-387
+            if isinstance(m, nn.Conv2d) and m.weight.requires_grad:
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d, apex.parallel.SyncBatchNorm)):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    def _make_layer(self, inplanes, planes, num_blocks, stride=1, first_groups=1, use_norm=True):
+        block = resnet.BasicBlock
+        conv2d = MaskConv
+        BatchNorm2d = self.BatchNorm2d if use_norm else Empty
+        downsample = None
+        if stride != 1 or inplanes != planes * block.expansion:
+            downsample = nn.Sequential(conv1x1(inplanes, planes * block.expansion, stride, Conv2d=conv2d,
+                                               groups=first_groups), BatchNorm2d(planes * block.expansion))
+        layers = [block(inplanes, planes, stride, downsample, BN=BatchNorm2d, Conv2d=conv2d, groups=first_groups)]
+        self.inplanes = planes * block.expansion
+        for _ in range(1, num_blocks):
+            layers.append(block(self.inplanes, planes, BN=BatchNorm2d, Conv2d=conv2d))
+        return nn.Sequential(*layers), self.inplanes

@@ -1,0 +1,423 @@
+"""UnVoxelOdomNetICP3: the network + self-supervised loss of the RSLO hot path
+(reference: rslo/models/voxel_odom_net.py:47-816; call stacks SURVEY.md 3.3 / 3.4).
+
+Same constructor kwargs, attribute names, state-dict keys and forward(example) -> dict contract as the
+reference class, so second_builder / train_hdf5.py / evaluate.py can drive it unchanged.
+
+MI355X re-design inside that contract:
+  * all frames of all samples go through the sparse encoder as ONE batched SparseConvTensor (batch index
+    = t * B + b): one rulebook chain and ~20 conv launches per step instead of per frame;
+  * the loss is batched over frame pairs with static shapes (rslo/core/losses.py);
+  * global_step is mirrored on the host (no .cpu() sync per query); the logging extras of the training
+    forward stay on the GPU unless `cpu_extras` is True (the reference copies ~10 tensors to the host every
+    step, voxel_odom_net.py:519-539).
+"""
+import contextlib
+import time
+
+import apex.amp as amp
+import kornia
+import numpy as np
+import torch
+import torchplus
+from torch import nn
+from torch.nn import functional as F
+
+from rslo.data.dataset import generate_pointwise_local_transformation_tch
+from rslo.models import middle, odom_pred, voxel_encoder
+
+REGISTERED_NETWORK_CLASSES = {}
+
+
+def register_voxelnet(cls, name=None):
+    name = cls.__name__ if name is None else name
+    assert name not in REGISTERED_NETWORK_CLASSES, f"exist class: {REGISTERED_NETWORK_CLASSES}"
+    REGISTERED_NETWORK_CLASSES[name] = cls
+    return cls
+
+
+def get_voxelnet_class(name):
+    assert name in REGISTERED_NETWORK_CLASSES, f"available class: {REGISTERED_NETWORK_CLASSES}"
+    return REGISTERED_NETWORK_CLASSES[name]
+
+
+def create_cycle_constraint_data(xs, cat_dim=1):
+    """All (i < j) pairs of a list of [B, ...] tensors -> [x_i...], [x_j...] each [B*npairs, ...]."""
+    assert len(xs) >= 2
+    shape = xs[0].shape
+    x1, x2 = [], []
+    for i in range(len(xs)):
+        for j in range(i + 1, len(xs)):
+            x1.append(xs[i])
+            x2.append(xs[j])
+    return [torch.stack(x1, dim=cat_dim).reshape(-1, *shape[1:]), torch.stack(x2, dim=cat_dim).reshape(-1, *shape[1:])]
+
+
+def _detach_tree(x):
+    if isinstance(x, torch.Tensor):
+        return x.detach()
+    if isinstance(x, (list, tuple)):
+        return [_detach_tree(v) for v in x]
+    if isinstance(x, dict):
+        return {k: _detach_tree(v) for k, v in x.items()}
+    return x
+
+
+def _cpu_tree(x):
+    if isinstance(x, torch.Tensor):
+        return x.detach().cpu()
+    if isinstance(x, (list, tuple)):
+        return [_cpu_tree(v) for v in x]
+    if isinstance(x, dict):
+        return {k: _cpu_tree(v) for k, v in x.items()}
+    return x
+
+
+@register_voxelnet
+class UnVoxelOdomNetICP3(nn.Module):
+    def __init__(self, output_shape, pc_range=None, num_input_features=4, vfe_class_name="VoxelFeatureExtractor",
+                 vfe_num_filters=[32, 128], with_distance=False, middle_class_name="SparseMiddleExtractor",
+                 middle_num_input_features=-1, middle_num_filters_d1=[64], middle_num_filters_d2=[64, 64],
+                 middle_use_leakyReLU=False, middle_bn_type="BN", middle_relu_type="ReLU",
+                 odom_class_name="ResNetOdomPred", odom_num_input_features=-1, odom_layer_nums=[3, 5, 5],
+                 odom_layer_strides=[2, 2, 2], odom_num_filters=[128, 128, 256], odom_upsample_strides=[1, 2, 4],
+                 odom_num_upsample_filters=[256, 256, 256], odom_pooling_type="avg_pool", odom_pooling_size=1,
+                 odom_cycle_constraint=False, odom_conv_type="official", odom_format="rx+t",
+                 odom_pred_pyramid_motion=False, odom_use_deep_supervision=False, odom_dense_predict=False,
+                 odom_use_loss_mask=True, odom_use_dynamic_mask=False, odom_use_corr=False, odom_dropout=0.2,
+                 odom_bn_type="BN", odom_conf_type="linear", odom_use_SPGN=False, odom_use_leakyReLU=False,
+                 odom_first_conv_groups=1, odom_use_se=False, odom_use_sa=False, vfe_use_norm=True,
+                 odom_enc_use_norm=True, odom_use_svd=False, odom_dropout_input=False, odom_cubic_pred_height=5,
+                 freeze_bn=False, freeze_bn_affine=False, freeze_bn_start_step=1e20, sync_bn=False, use_GN=False,
+                 encode_background_as_zeros=True, rotation_loss=None, translation_loss=None,
+                 pyramid_rotation_loss=None, pyramid_translation_loss=None, consistency_loss=None,
+                 measure_time=False, voxel_generator=None, pyloss_exp_w_base=0.5, testing=False, icp_iter=2,
+                 name="voxel_odom_net", **kwargs):
+        super().__init__()
+        self.name = name
+        self.testing = testing
+        self._encode_background_as_zeros = encode_background_as_zeros
+        self._num_input_features = num_input_features
+        self.voxel_generator = voxel_generator
+        self._rotation_loss = rotation_loss
+        self._translation_loss = translation_loss
+        self._pyramid_rotation_loss = pyramid_rotation_loss
+        self._pyramid_translation_loss = pyramid_translation_loss
+        self._consistency_loss = consistency_loss
+        self._conf_reg_loss = nn.MSELoss
+        assert pyloss_exp_w_base > 0
+        self._pyloss_exp_w_base = pyloss_exp_w_base
+        assert icp_iter > 0, "The parameter of icp_iter should be larger than 0."
+        self.icp_iter = icp_iter
+        self.measure_time = measure_time
+        self.cpu_extras = False
+
+        self.voxel_feature_extractor = voxel_encoder.get_vfe_class(vfe_class_name)(
+            num_input_features, vfe_use_norm, num_filters=vfe_num_filters, with_distance=with_distance,
+            voxel_size=self.voxel_generator.voxel_size, pc_range=self.voxel_generator.point_cloud_range)
+        self.middle_feature_extractor = middle.get_middle_class(middle_class_name)(
+            output_shape, bn_type=middle_bn_type, use_GN=use_GN, sync_bn=sync_bn,
+            use_leakyReLU=middle_use_leakyReLU, relu_type=middle_relu_type,
+            num_input_features=middle_num_input_features, num_filters_down1=middle_num_filters_d1,
+            num_filters_down2=middle_num_filters_d2)
+        self.middle_feature_extractor_name = middle_class_name
+        self.odom_predictor = odom_pred.get_odom_class(odom_class_name)(
+            bn_type=odom_bn_type, enc_use_norm=odom_enc_use_norm, conv_type=odom_conv_type,
+            layer_nums=odom_layer_nums, layer_strides=odom_layer_strides, num_filters=odom_num_filters,
+            upsample_strides=odom_upsample_strides, num_upsample_filters=odom_num_upsample_filters,
+            num_input_features=odom_num_input_features * 2, pooling_type=odom_pooling_type,
+            pooling_size=odom_pooling_size, encode_background_as_zeros=True, use_groupnorm=use_GN, num_groups=32,
+            dropout=odom_dropout, cycle_constraint=odom_cycle_constraint,
+            pred_pyramid_motion=odom_pred_pyramid_motion, use_deep_supervision=odom_use_deep_supervision,
+            use_loss_mask=odom_use_loss_mask, use_dynamic_mask=odom_use_dynamic_mask, odom_format=odom_format,
+            point_cloud_range=pc_range, dense_predict=odom_dense_predict, use_correlation=odom_use_corr,
+            conf_type=odom_conf_type, use_SPGN=odom_use_SPGN, use_leakyReLU=odom_use_leakyReLU,
+            dropout_input=odom_dropout_input, first_conv_groups=odom_first_conv_groups, use_se=odom_use_se,
+            use_sa=odom_use_sa, use_svd=odom_use_svd, cubic_pred_height=odom_cubic_pred_height,
+            freeze_bn=freeze_bn, freeze_bn_affine=freeze_bn_affine, sync_bn=sync_bn, name="odomPred")
+
+        self.freeze_bn = freeze_bn
+        self.freeze_bn_affine = freeze_bn_affine
+        self.freeze_bn_start_step = freeze_bn_start_step
+        self.register_buffer("global_step", torch.LongTensor(1).zero_())
+        self._step_cache = (None, 0)
+        self.warm_flag = False
+        self._time_dict, self._time_total_dict, self._time_count_dict = {}, {}, {}
+
+    # ------------------------------------------------------------------ bookkeeping (driver-facing)
+    def train(self, mode=True):
+        super().train(mode)
+        if self.freeze_bn and self.get_global_step() >= self.freeze_bn_start_step:
+            for m in self.modules():
+                if isinstance(m, nn.modules.batchnorm._BatchNorm):
+                    m.eval()
+                    if self.freeze_bn_affine:
+                        for p in (m.weight, m.bias):
+                            if p is not None:
+                                p.requires_grad = False
+        return self
+
+    def update_global_step(self):
+        self.global_step += 1
+
+    def get_global_step(self):
+        ver, val = self._step_cache
+        if ver != self.global_step._version:
+            val = int(self.global_step.item())
+            self._step_cache = (self.global_step._version, val)
+        return val
+
+    def clear_global_step(self):
+        self.global_step.zero_()
+
+    def clear_metrics(self):
+        pass
+
+    def start_timer(self, *names):
+        if not self.measure_time:
+            return
+        torch.cuda.synchronize()
+        for name in names:
+            self._time_dict[name] = time.time()
+
+    def end_timer(self, name):
+        if not self.measure_time or name not in self._time_dict:
+            return
+        torch.cuda.synchronize()
+        dt = time.time() - self._time_dict[name]
+        self._time_count_dict[name] = self._time_count_dict.get(name, 0) + 1
+        self._time_total_dict[name] = self._time_total_dict.get(name, 0.0) + dt
+
+    def clear_timer(self):
+        self._time_count_dict.clear()
+        self._time_dict.clear()
+        self._time_total_dict.clear()
+
+    @contextlib.contextmanager
+    def profiler(self):
+        old = self.measure_time
+        self.measure_time = True
+        yield
+        self.measure_time = old
+
+    def get_avg_time_dict(self):
+        return {k: v / max(1, self._time_count_dict[k]) for k, v in self._time_total_dict.items()}
+
+    # ------------------------------------------------------------------ forward
+    def network_forward(self, voxels, num_points, coors, batch_size, example):
+        assert len(voxels) == len(num_points) == len(coors), "The lengths should be same."
+        T = len(voxels)
+        self.start_timer("voxel_feature_extractor")
+        voxel_features = [self.voxel_feature_extractor(voxels[t], num_points[t], coors[t]) for t in range(T)]
+        self.end_timer("voxel_feature_extractor")
+
+        self.start_timer("middle forward")
+        # one batched encoder pass: frame t of sample b gets batch index t * B + b
+        merged = []
+        for t in range(T):
+            c = coors[t].int()
+            if t:
+                c = c.clone()
+                c[:, 0] += t * batch_size
+            merged.append(c)
+        bev, cov = self.middle_feature_extractor(torch.cat(voxel_features, 0), torch.cat(merged, 0), T * batch_size)
+        spatial_features = list(bev.split(batch_size, dim=0))
+        middle_conf_preds = list(cov.split([f.shape[0] for f in voxel_features], dim=0))
+        self.end_timer("middle forward")
+
+        preds_dict = self.odom_predictor(spatial_features, tq_map_gt=example.get("tq_maps", [None])[0])
+        with torch.no_grad():
+            preds_dict["feature_mask"] = (torch.cat(spatial_features, dim=1).sum(dim=1, keepdim=True) != 0).float()
+            disp = [f.mean(dim=1, keepdim=True) for f in spatial_features]
+            preds_dict["middle_feature"] = [(d - d.min()) / (d.max() - d.min() + 1e-12) for d in disp]
+        preds_dict["middle_conf_preds"] = middle_conf_preds
+        preds_dict["voxel_features"] = voxel_features
+        preds_dict["voxel_coords"] = coors
+        preds_dict["normal_preds"] = []
+        return preds_dict
+
+    def forward(self, example):
+        voxels, num_points, coors = example["voxels"], example["num_points"], example["coordinates"]
+        if len(num_points[0].shape) == 2:   # padded multi-gpu layout: [B, maxN, ...] + num_voxels
+            vb, nb, cb = [], [], []
+            for t in range(len(voxels)):
+                nv = example["num_voxels"][t].cpu().numpy().reshape(-1)
+                vb.append(torch.cat([voxels[t][i, :n] for i, n in enumerate(nv)], 0))
+                nb.append(torch.cat([num_points[t][i, :n] for i, n in enumerate(nv)], 0))
+                cb.append(torch.cat([coors[t][i, :n] for i, n in enumerate(nv)], 0))
+            voxels, num_points, coors = vb, nb, cb
+        batch_size_dev = example["num_voxels"][0].shape[0]
+        preds_dict = self.network_forward(voxels, num_points, coors, batch_size_dev, example=example)
+
+        if self.training:
+            ret = self.loss(example, preds_dict)
+            extras = {
+                "middle_feature": preds_dict["middle_feature"], "feature_mask": preds_dict["feature_mask"],
+                "t_conf": preds_dict.pop("t_conf", None), "r_conf": preds_dict.pop("r_conf", None),
+                "pyramid_motion": preds_dict.pop("pyramid_motion", None),
+                "dynamic_sigma": preds_dict.pop("dynamic_sigma", -1),
+                "transformed_inputs": preds_dict.pop("transformed_inputs", None),
+                "tq_map_g": preds_dict.pop("tq_map_g", None), "local_motion": preds_dict.pop("local_motion", None),
+                "down_masks": preds_dict.pop("down_masks", None),
+                "middle_conf_preds": list(preds_dict["middle_conf_preds"]),
+            }
+            ret.update(_cpu_tree(extras) if self.cpu_extras else _detach_tree(extras))
+            return ret
+
+        t_pred, r_pred = preds_dict["translation_preds"], preds_dict["rotation_preds"]
+        if isinstance(t_pred, (list, tuple)):
+            t_pred = t_pred[-1]
+        if isinstance(r_pred, (list, tuple)):
+            r_pred = r_pred[-1]
+        out = {"translation_preds": t_pred.detach(), "rotation_preds": r_pred.detach()}
+        if self.testing:
+            out["middle_conf_preds"] = _detach_tree(list(preds_dict["middle_conf_preds"]))
+            out["voxel_features"] = _detach_tree(preds_dict["voxel_features"])
+            out["normal_preds"] = preds_dict["normal_preds"]
+            out["tq_map_g"] = preds_dict["tq_map_g"].detach()
+            out["pyramid_motion"] = _detach_tree(preds_dict["pyramid_motion"])
+            out["t_conf"] = preds_dict["t_conf"].detach()
+            out["r_conf"] = preds_dict["r_conf"].detach()
+            out["normal_gt"] = example.get("normal_gt", None)
+        return out
+
+    # ------------------------------------------------------------------ loss
+    def gen_tq_maps(self, odometries, spatial_size, pc_range, cubic_tq_map=False):
+        if len(spatial_size) == 2:
+            spatial_size = [1] + list(spatial_size)
+        grid_size = np.array(list(spatial_size[::-1]))
+        pc_range = np.asarray(pc_range)
+        voxel_size = (pc_range[3:] - pc_range[0:3]) / grid_size
+        ssize = grid_size if cubic_tq_map else grid_size[:2]
+        origin_loc = ((0 - pc_range[0]) / (pc_range[3] - pc_range[0]) * grid_size[0],
+                      (pc_range[4] - 0) / (pc_range[4] - pc_range[1]) * grid_size[1],
+                      (0 - pc_range[2]) / (pc_range[5] - pc_range[2]) * grid_size[2])
+        maps = [generate_pointwise_local_transformation_tch(tq, spatial_size=ssize, origin_loc=origin_loc,
+                                                            voxel_size=voxel_size, inv_trans_factor=-1)
+                for tq in odometries]
+        return [torch.stack(maps, dim=0)]
+
+    @amp.float_function
+    def loss(self, example, preds_dict):
+        T_preds, R_preds = preds_dict["translation_preds"], preds_dict["rotation_preds"]
+        if not isinstance(T_preds, (list, tuple)):
+            T_preds = [T_preds]
+        if not isinstance(R_preds, (list, tuple)):
+            R_preds = [R_preds]
+        self.start_timer("create_loss forward")
+        t_loss, r_loss, py_T, py_R, C_loss = self.create_loss(
+            preds_dict, example, self._translation_loss, self._rotation_loss,
+            pyramid_rotation_loss=self._pyramid_rotation_loss,
+            pyramid_translation_loss=self._pyramid_translation_loss, consistency_loss=self._consistency_loss)
+        pyramid_loss = torch.zeros([1], dtype=T_preds[0].dtype, device=T_preds[0].device)
+        n = len(py_T)
+        for i, (tl, rl) in enumerate(zip(py_T, py_R)):
+            pyramid_loss = pyramid_loss + self._pyloss_exp_w_base ** (n - i) * (tl + rl)
+        loss = t_loss + r_loss + pyramid_loss + C_loss
+        self.end_timer("create_loss forward")
+        return {"loss": loss, "translation_loss": t_loss.detach(), "rotation_loss": r_loss.detach(),
+                "pyramid_loss": pyramid_loss.detach(), "C_loss": C_loss.detach(),
+                "translation_preds": T_preds[0].detach(), "rotation_preds": R_preds[0].detach()}
+
+    @amp.float_function
+    def create_loss(self, preds_dict, example, translation_loss, rotation_loss, pyramid_translation_loss=None,
+                    pyramid_rotation_loss=None, pyramid_preds=None, consistency_loss=None):
+        translation_preds, rotation_preds = preds_dict["translation_preds"], preds_dict["rotation_preds"]
+        if not isinstance(translation_preds, (list, tuple)):
+            translation_preds = [translation_preds]
+        if not isinstance(rotation_preds, (list, tuple)):
+            rotation_preds = [rotation_preds]
+        dtype, device = translation_preds[0].dtype, translation_preds[0].device
+        pyramid_preds = preds_dict["pyramid_motion"]
+        example["icp_odometry"] = example["icp_odometry"].view(-1, 7)
+        translation_targets = example["icp_odometry"][:, :3]
+        rotation_targets = example["icp_odometry"][:, 3:]
+        step = self.get_global_step()
+
+        if translation_loss._loss_weight == 0:
+            self.warm_flag = True
+        if self.warm_flag:
+            warm_weight = 1.0 / (0.001 * step + 1) if step < 1500 else 0
+            translation_loss._loss_weight = warm_weight
+            rotation_loss._loss_weight = warm_weight
+        else:
+            warm_weight = 0
+
+        C_loss = torch.zeros([1], dtype=dtype, device=device)
+        res_r = res_t = None
+        if consistency_loss is not None:
+            if len(preds_dict["middle_conf_preds"]) == 0:
+                raise NotImplementedError("hier_points supervision without a covariance head (SURVEY.md 8f-4)")
+            feats = preds_dict["voxel_features"]
+            cols = [0, 1, 2, 4, 5, 6] if feats[0].shape[1] > 6 else [0, 1, 2, 3, 4, 5]
+            B = example["num_voxels"][0].shape[0]
+            # rows of sample b inside frame t (frames hold the samples back to back)
+            if B == 1:
+                counts = [[f.shape[0]] for f in feats]
+            else:
+                counts = [[int(v) for v in example["num_voxels"][t].reshape(-1).tolist()] for t in range(len(feats))]
+            per_sample = []
+            for b in range(B):
+                offs = [sum(counts[t][:b]) for t in range(len(feats))]
+                # the reference truncates every frame of a sample to the shortest one (voxel_odom_net.py:646-651)
+                min_len = min(counts[t][b] for t in range(len(feats)))
+                points = [feats[t][offs[t]:offs[t] + min_len][:, cols][None] for t in range(len(feats))]
+                confs = [preds_dict["middle_conf_preds"][t][offs[t]:offs[t] + min_len][None] for t in range(len(feats))]
+                per_sample.append(create_cycle_constraint_data(points, 1) + create_cycle_constraint_data(confs, 1))
+            npairs = per_sample[0][0].shape[0]
+
+            weights = [0.01, 0.01, 0.05, 0.1, 1]
+            for R_pred, T_pred, weight in zip(rotation_preds, translation_preds, weights[-len(translation_preds):]):
+                if R_pred.shape[-1] == 9:
+                    R_pred = R_pred.reshape(-1, 3, 3)
+                else:
+                    R_pred = kornia.quaternion_to_rotation_matrix(torchplus.roll(R_pred, shift=-1, dim=-1))
+                if step <= 1500:   # warm-up: the consistency loss sees the identity pose
+                    R_pred = torch.eye(3, device=device, dtype=dtype).expand(R_pred.shape[0], 3, 3).contiguous()
+                    T_pred = torch.zeros_like(T_pred)
+                icp_iter = self.icp_iter if step > 1500 else 5
+                pair_losses, rs, ts = [], [], []
+                for b, (pts1, pts2, cov1, cov2) in enumerate(per_sample):   # pairs of sample b: rows b*npairs..
+                    Rb, Tb = R_pred[b * npairs:(b + 1) * npairs], T_pred[b * npairs:(b + 1) * npairs]
+                    p2_moved = pts2[:, :, :3] @ Rb.transpose(-1, -2) + Tb[:, None]
+                    n2_moved = pts2[:, :, 3:] @ Rb.detach().transpose(-1, -2)
+                    lb, rr, tt = consistency_loss.pair_losses(
+                        pts1[:, :, :3], p2_moved, cov_pred=cov1, cov_target=cov2, R_pred=Rb, t_pred=Tb,
+                        normal_pred=pts1[:, :, 3:].detach(), normal_target=n2_moved.detach(), icp_iter=icp_iter)
+                    pair_losses.append(lb)
+                    rs.append(rr)
+                    ts.append(tt)
+                l = consistency_loss._loss_weight * consistency_loss.reduce(torch.cat(pair_losses))
+                res_r, res_t = torch.cat(rs), torch.cat(ts)
+                C_loss = C_loss + (1 - warm_weight) * weight * l
+
+        if res_r is not None and res_t is not None:
+            rotation_targets = kornia.rotation_matrix_to_quaternion((res_r @ R_pred.detach()).contiguous())
+            rotation_targets = torchplus.roll(rotation_targets, 1, dim=-1)
+            rotation_targets = rotation_targets * torch.sign(rotation_targets[:, 0:1])
+            translation_targets = (res_r @ T_pred[..., None].detach() + res_t[..., None]).squeeze(-1)
+
+        if len(pyramid_preds) > 0:
+            example["tq_maps"] = self.gen_tq_maps(
+                torch.cat([translation_targets, rotation_targets], dim=-1).reshape(-1, 7),
+                spatial_size=pyramid_preds[-1][0].shape[2:], pc_range=self.odom_predictor.point_cloud_range,
+                cubic_tq_map=self.odom_predictor._cubic_pred_height > 0)
+        pyramid_targets = list(example["tq_maps"])
+
+        T_loss = sum(translation_loss(p, translation_targets) for p in translation_preds)
+        R_loss = sum(rotation_loss(p, rotation_targets) for p in rotation_preds)
+        if pyramid_translation_loss is None or pyramid_rotation_loss is None:
+            return T_loss, R_loss
+
+        pyramid_T_losses, pyramid_R_losses = [], []
+        for pp in pyramid_preds:
+            pred, pred_mask = (pp[0], pp[1]) if isinstance(pp, (tuple, list)) else (pp, None)
+            T_p, R_p = pred[:, :3], pred[:, 3:]
+            T_tgt, R_tgt = pyramid_targets[0][:, :3], pyramid_targets[0][:, 3:]
+            if T_tgt.shape != T_p.shape:
+                T_tgt = F.interpolate(T_tgt, size=T_p[0, 0].shape, mode="nearest")
+            if R_tgt.shape != R_p.shape:
+                R_tgt = F.interpolate(R_tgt, size=T_p[0, 0].shape, mode="nearest")
+            pyramid_T_losses.append(pyramid_translation_loss(T_p, T_tgt, mask=pred_mask[:, :1]))
+            pyramid_R_losses.append(pyramid_rotation_loss(R_p, R_tgt, mask=pred_mask[:, -1:]))
+        return T_loss, R_loss, pyramid_T_losses, pyramid_R_losses, C_loss

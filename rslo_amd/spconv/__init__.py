@@ -1,0 +1,332 @@
+"""spconv operator API used by the RSLO hot path, implemented on librslo_hip.so.
+
+Mirrors the subset of spconv-1.x that rslo/models/middle.py:80-97,119-213,224,240 touches:
+SparseConvTensor, SubMConv3d, SparseConv3d, SparseInverseConv3d, SparseSequential (+ utils.VoxelGenerator).
+Same constructor arguments, parameter names/shapes (weight [kz,ky,kx,Cin,Cout], bias [Cout]) and
+indice_key sharing rules, so reference checkpoints load and the reference modules run unchanged.
+
+MI355X design (not spconv's gather -> GEMM -> scatter-add per offset):
+  * a level's active sites are indexed by a device hash (capi.SiteIndex);
+  * a rulebook is a dense neighbour table [rows, K] (int32, -1 = no neighbour) plus its transpose;
+    strided-conv outputs are numbered by ascending linear index via a bitmap rank (no sort);
+  * convolution is ONE output-stationary implicit-GEMM launch per layer (MFMA fp32), with bias and
+    a following LeakyReLU/ReLU fused into the epilogue by SparseSequential;
+  * SubM tables are cached on the site index, so `dsubm*` keys on a level that already ran `subm*`
+    reuse the table instead of rebuilding it.
+There is no CPU path: tensors must be on the GPU and the HIP library must be present.
+"""
+import math
+
+import torch
+from torch import nn
+
+from rslo_amd import capi
+
+from . import utils  # noqa: F401
+
+__all__ = ["SparseConvTensor", "SparseModule", "SparseSequential", "SubMConv3d", "SparseConv3d",
+           "SparseInverseConv3d", "utils"]
+
+
+def _triple(v):
+    if isinstance(v, (list, tuple)):
+        assert len(v) == 3
+        return [int(x) for x in v]
+    return [int(v)] * 3
+
+
+class Rulebook:
+    """Neighbour tables of one indice_key."""
+
+    def __init__(self, kind, nbr, nbrT, in_index, out_index, ks, stride, pad):
+        self.kind = kind            # "subm" | "conv"
+        self.nbr = nbr              # [n_out, K]: input row per (out, k)
+        self.nbrT = nbrT            # [n_in, K]:  output row per (in, k)   (None for subm: symmetric)
+        self.in_index = in_index
+        self.out_index = out_index
+        self.ks, self.stride, self.pad = ks, stride, pad
+
+    def indice_pairs(self):
+        """spconv-1.x view of the table: (indice_pairs [K,2,P] padded with -1, indice_num [K]);
+        pairs of offset k in ascending input row.  For parity checks / introspection only."""
+        t = self.nbrT if self.nbrT is not None else torch.flip(self.nbr, dims=[1])
+        N, K = t.shape
+        num = (t >= 0).sum(0).to(torch.int32)
+        cap = max(int(num.max().item()) if N else 0, 1)
+        pairs = torch.full((K, 2, cap), -1, dtype=torch.int32, device=t.device)
+        for k in range(K):
+            rows = torch.nonzero(t[:, k] >= 0).flatten()
+            pairs[k, 0, : rows.numel()] = rows.to(torch.int32)
+            pairs[k, 1, : rows.numel()] = t[rows, k]
+        return pairs, num
+
+
+class SparseConvTensor:
+    def __init__(self, features, indices, spatial_shape, batch_size, grid=None, index=None):
+        self.features = features
+        self.indices = indices
+        self.spatial_shape = [int(s) for s in spatial_shape]
+        self.batch_size = int(batch_size)
+        self.indice_dict = {}
+        self.grid = grid
+        self._index = index
+
+    @property
+    def spatial_size(self):
+        return int(torch.tensor(self.spatial_shape).prod())
+
+    def find_indice_pair(self, key):
+        if key is None:
+            return None
+        return self.indice_dict.get(key)
+
+    def site_index(self):
+        if self._index is None:
+            idx = self.indices
+            if idx.dtype != torch.int32:
+                idx = idx.int()
+            self._index = capi.SiteIndex(idx.contiguous(), self.batch_size, self.spatial_shape)
+            self._index.subm_cache = {}
+        return self._index
+
+    def batch_offsets(self):
+        """Row range of every batch element (rows are grouped by batch index on every level:
+        level 0 is a concatenation, strided outputs are in ascending linear order).  One host read,
+        cached on the site index."""
+        index = self.site_index()
+        offs = getattr(index, "batch_offs", None)
+        if offs is None:
+            b = index.coords[:, 0].contiguous()
+            probe = torch.arange(self.batch_size + 1, dtype=b.dtype, device=b.device)
+            offs = torch.searchsorted(b, probe).tolist()
+            index.batch_offs = offs
+        return offs
+
+    def dense(self, channels_first=True):
+        out = _DenseFn.apply(self.features, self.site_index().coords, self.batch_size, tuple(self.spatial_shape))
+        if not channels_first:
+            out = out.permute(0, 2, 3, 4, 1).contiguous()
+        return out
+
+    def _like(self, features, indices=None, spatial_shape=None, index=None):
+        t = SparseConvTensor(features, self.indices if indices is None else indices,
+                             self.spatial_shape if spatial_shape is None else spatial_shape, self.batch_size,
+                             self.grid, index if index is not None else (self._index if indices is None else None))
+        t.indice_dict = self.indice_dict
+        return t
+
+
+class _DenseFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, coords, batch, dims):
+        ctx.save_for_backward(coords)
+        ctx.meta = (feat.shape[1], batch, dims)
+        return capi.dense_scatter(feat.contiguous(), coords, batch, dims)
+
+    @staticmethod
+    def backward(ctx, g):
+        (coords,) = ctx.saved_tensors
+        C_, batch, dims = ctx.meta
+        return capi.dense_gather(g.contiguous(), coords, C_, batch, dims), None, None, None
+
+
+class _SparseConvFn(torch.autograd.Function):
+    """y = act(bias + sum_k x[nbr[:,k]] @ W[k]) and its dgrad/wgrad, all through the C ABI."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, nbr, nbrT, subm, slope):
+        K = nbr.shape[1]
+        cin, cout = weight.shape[-2], weight.shape[-1]
+        W3 = weight.reshape(K, cin, cout)
+        x = x.contiguous()
+        y = capi.spconv_fwd(x, W3, bias, nbr, flip_k=False, act_slope=slope)
+        ctx.save_for_backward(x, weight, y if slope != 1.0 else None, nbr, nbrT)
+        ctx.meta = (subm, slope, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, y, nbr, nbrT = ctx.saved_tensors
+        subm, slope, has_bias = ctx.meta
+        K = nbr.shape[1]
+        cin, cout = weight.shape[-2], weight.shape[-1]
+        W3 = weight.reshape(K, cin, cout)
+        g = gy.contiguous()
+        if slope != 1.0:
+            g = capi.leaky_bwd(y, g, slope)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            if subm:      # pair (i -> o via k)  <=>  (o -> i via K-1-k)
+                gx = capi.spconv_dgrad(g, W3, nbr, flip_k=True)
+            else:
+                gx = capi.spconv_dgrad(g, W3, nbrT, flip_k=False)
+        if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+            gw, gb = capi.spconv_wgrad(x, g, nbr, cin, cout, with_bias=has_bias)
+            gw = gw.reshape(weight.shape)
+        return gx, gw, gb, None, None, None, None
+
+
+class SparseModule(nn.Module):
+    """Marker base class: modules that consume / produce SparseConvTensor."""
+
+
+class SparseConvolution(SparseModule):
+    def __init__(self, ndim, in_channels, out_channels, kernel_size=3, stride=1, padding=0, dilation=1,
+                 groups=1, bias=True, subm=False, output_padding=0, transposed=False, inverse=False,
+                 indice_key=None, fused_bn=False):
+        super().__init__()
+        assert ndim == 3 and groups == 1 and not transposed and not fused_bn
+        self.ndim = ndim
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size = _triple(kernel_size)
+        self.stride = _triple(stride)
+        self.padding = _triple(padding)
+        self.dilation = _triple(dilation)
+        assert self.dilation == [1, 1, 1], "dilation is not used by the RSLO hot path"
+        self.subm, self.inverse = subm, inverse
+        self.indice_key = indice_key
+        self.weight = nn.Parameter(torch.empty(*self.kernel_size, in_channels, out_channels))
+        if bias:
+            self.bias = nn.Parameter(torch.empty(out_channels))
+        else:
+            self.register_parameter("bias", None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            fan_in, _ = nn.init._calculate_fan_in_and_fan_out(self.weight)
+            bound = 1 / math.sqrt(fan_in)
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def extra_repr(self):
+        return "%d, %d, kernel_size=%s, stride=%s, padding=%s, subm=%s, inverse=%s, indice_key=%s" % (
+            self.in_channels, self.out_channels, self.kernel_size, self.stride, self.padding, self.subm,
+            self.inverse, self.indice_key)
+
+    # -- rulebook --------------------------------------------------------------------------
+    def _rulebook(self, x):
+        rb = x.find_indice_pair(self.indice_key)
+        if self.inverse:
+            assert rb is not None and rb.kind == "conv", "inverse conv needs the rulebook of its forward twin"
+            return rb
+        if rb is not None:
+            return rb
+        index = x.site_index()
+        if self.subm:
+            key = tuple(self.kernel_size)
+            nbr = index.subm_cache.get(key)
+            if nbr is None:
+                nbr = capi.rulebook_subm(index, self.kernel_size)
+                index.subm_cache[key] = nbr
+            rb = Rulebook("subm", nbr, None, index, index, self.kernel_size, [1, 1, 1], None)
+        else:
+            out_index, nbr, nbrT = capi.rulebook_conv(index, self.kernel_size, self.stride, self.padding)
+            out_index.subm_cache = {}
+            rb = Rulebook("conv", nbr, nbrT, index, out_index, self.kernel_size, self.stride, self.padding)
+        if self.indice_key is not None:
+            x.indice_dict[self.indice_key] = rb
+        return rb
+
+    def forward(self, x, act_slope=1.0):
+        assert isinstance(x, SparseConvTensor)
+        rb = self._rulebook(x)
+        if self.inverse:      # output sites = the saved INPUT sites of the forward twin, same order
+            y = _SparseConvFn.apply(x.features, self.weight, self.bias, rb.nbrT, rb.nbr, False, act_slope)
+            return x._like(y, rb.in_index.coords, rb.in_index.dims, rb.in_index)
+        if self.subm:
+            y = _SparseConvFn.apply(x.features, self.weight, self.bias, rb.nbr, None, True, act_slope)
+            return x._like(y)
+        y = _SparseConvFn.apply(x.features, self.weight, self.bias, rb.nbr, rb.nbrT, False, act_slope)
+        return x._like(y, rb.out_index.coords, rb.out_index.dims, rb.out_index)
+
+
+class SubMConv3d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
+                 bias=True, indice_key=None):
+        super().__init__(3, in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias,
+                         subm=True, indice_key=indice_key)
+
+
+class SparseConv3d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
+                 bias=True, indice_key=None):
+        super().__init__(3, in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias,
+                         indice_key=indice_key)
+
+
+class SparseInverseConv3d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, indice_key, bias=True):
+        super().__init__(3, in_channels, out_channels, kernel_size, bias=bias, inverse=True,
+                         indice_key=indice_key)
+
+
+def _act_slope(m):
+    """Slope of an activation SparseSequential can fuse into the preceding conv, else None."""
+    if type(m) is nn.LeakyReLU:
+        return float(m.negative_slope)
+    if type(m) is nn.ReLU:
+        return 0.0
+    return None
+
+
+def _is_identity(m):
+    return type(m).__name__ == "Empty" or isinstance(m, nn.Identity)
+
+
+class SparseSequential(SparseModule):
+    """nn.Sequential over sparse and dense modules: dense modules see `.features`
+    (middle.py:181 mixes raw nn.BatchNorm1d into the chain).  conv -> [identity] -> (Leaky)ReLU
+    runs as ONE fused launch."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        if len(args) == 1 and isinstance(args[0], dict):
+            for k, m in args[0].items():
+                self.add_module(k, m)
+        else:
+            for i, m in enumerate(args):
+                self.add_module(str(i), m)
+        for name, m in kwargs.items():
+            self.add_module(name, m)
+
+    def __getitem__(self, idx):
+        return list(self._modules.values())[idx]
+
+    def __len__(self):
+        return len(self._modules)
+
+    def add(self, module, name=None):
+        self.add_module(str(len(self._modules)) if name is None else name, module)
+
+    def forward(self, x):
+        mods = list(self._modules.values())
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, SparseConvolution):
+                j = i + 1
+                while j < len(mods) and _is_identity(mods[j]):
+                    j += 1
+                slope = _act_slope(mods[j]) if j < len(mods) else None
+                if slope is not None:
+                    x = m(x, act_slope=slope)
+                    i = j + 1
+                    continue
+                x = m(x)
+            elif isinstance(m, SparseModule):
+                x = m(x)
+            elif isinstance(x, SparseConvTensor):
+                if isinstance(m, nn.modules.batchnorm._BatchNorm) and m.training and x.batch_size > 1:
+                    # the reference runs the encoder one frame at a time (middle.py:221), so batch
+                    # statistics are per frame: normalise each batch segment on its own, in frame order
+                    offs = x.batch_offsets()
+                    parts = [m(x.features[offs[b]:offs[b + 1]]) for b in range(x.batch_size)
+                             if offs[b + 1] > offs[b]]
+                    x = x._like(torch.cat(parts, 0))
+                elif x.features.shape[0] > 0 or not isinstance(m, nn.modules.batchnorm._BatchNorm):
+                    x = x._like(m(x.features))
+            else:
+                x = m(x)
+            i += 1
+        return x
