@@ -1,0 +1,277 @@
+#!/usr/bin/env python
+"""bench.py -- frame-pairs/s of the RSLO two-frame odometry hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W           (N = 1: single process)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (one rank per GPU, RCCL)
+
+Workload (BASELINE.json configs[2], "C3"): full forward + backward of UnVoxelOdomNetICP3 on synthetic
+KITTI-shaped frame pairs (2 x ~131k points each), batch 4 frame pairs per GPU, fp32, random-init
+weights of the shipped architecture.  One step = voxelize the 8 resident point clouds -> VFE -> batched sparse
+GU encoder (+ covariance branch) -> BEV head + ego-motion vote -> consistency loss (chamfer NN, covariance
+residual, ICP) -> backward -> Adam step.  Raw points are resident in HBM before the timed region.
+N > 1: pure data parallel (each rank its own frame pairs, weak scaling), DDP gradient all-reduce over RCCL.
+
+Prints ONE JSON line (rank 0).  `roofline` describes the dominant hand-written kernel (the sparse-conv
+implicit GEMM): algorithmic bytes (SURVEY.md 8d formula) / HIP-event time per launch, measured live in the
+timed region.  `cpu_baseline` is the same path on the host cores over the oracle backend, on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E ~8 TB/s (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=4, help="frame pairs per GPU (C3: 4)")
+    ap.add_argument("--rings", type=int, default=64, help="64 = KITTI-shaped ~131k points; 128 = dense scan")
+    ap.add_argument("--no-optim", action="store_true", help="time forward+backward only")
+    ap.add_argument("--no-voxelize", action="store_true", help="voxelize once outside the timed region")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP events (roofline=null)")
+    ap.add_argument("--kernel-report", default="", help="write the per-kernel roofline table to this JSON file")
+    return ap.parse_args()
+
+
+# --------------------------------------------------------------------------------------------- kernel events
+class ConvProbe:
+    """Wraps the sparse-conv C-ABI calls with HIP events on the launching stream and records the
+    algorithmic bytes / flops of every launch (P*Cin*s + Nout*Cout*s + 8P + K*Cin*Cout*s)."""
+
+    def __init__(self, capi):
+        self.capi = capi
+        self.records = []
+        self.enabled = False
+        self.keep_tables = False
+        self._orig = {}
+
+    @staticmethod
+    def kernel_name(cin_op, cout_op, n_out, trans):
+        ci = 8 if cin_op <= 8 else (16 if cin_op <= 16 else (32 if cin_op <= 32 else 64))
+        co = 16 if cout_op <= 16 else (32 if cout_op <= 32 else 64)
+        rb = 2 if (n_out >= 256 * 128 * 2 and co >= 32) else 1
+        return "k_spconv<%d, %d, %d, %s>" % (ci, co, rb, "true" if trans else "false")
+
+    def install(self):
+        capi = self.capi
+        self._orig = {"spconv_fwd": capi.spconv_fwd, "spconv_dgrad": capi.spconv_dgrad}
+        probe = self
+
+        def timed(fn, name_fn):
+            def wrapper(*a, **k):
+                if not probe.enabled:
+                    return fn(*a, **k)
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                out = fn(*a, **k)
+                e1.record()
+                probe.records.append((name_fn(*a, **k), e0, e1))
+                return out
+            return wrapper
+
+        def fwd_meta(x, W, bias, nbr, flip_k=False, act_slope=1.0):
+            K, cin, cout = W.shape
+            return ("fwd", cin, cout, K, nbr.shape[0], nbr if probe.keep_tables else None,
+                    probe.kernel_name(cin, cout, nbr.shape[0], False))
+
+        def dgrad_meta(dout, W, nbrT, flip_k=False):
+            K, cin, cout = W.shape
+            return ("dgrad", cout, cin, K, nbrT.shape[0], nbrT if probe.keep_tables else None,
+                    probe.kernel_name(cout, cin, nbrT.shape[0], True))
+
+        capi.spconv_fwd = timed(self._orig["spconv_fwd"], fwd_meta)
+        capi.spconv_dgrad = timed(self._orig["spconv_dgrad"], dgrad_meta)
+
+    def uninstall(self):
+        for k, f in self._orig.items():
+            setattr(self.capi, k, f)
+
+    def summarize(self, steps):
+        """-> (per-kernel dict, dominant kernel roofline dict).  Needs the LAST step recorded with
+        keep_tables so pair counts can be read; launches are identical every step (fixed inputs)."""
+        torch.cuda.synchronize()
+        per_step = len(self.records) // max(steps, 1)
+        last = self.records[-per_step:]
+        pairs = [int((m[5] >= 0).sum().item()) for (m, _, _) in last]
+        groups = {}
+        for i, (m, e0, e1) in enumerate(self.records):
+            kind, cin, cout, K, n_out, _, name = m
+            P = pairs[i % per_step]
+            byts = P * cin * 4 + n_out * cout * 4 + 8 * P + K * cin * cout * 4
+            flops = 2 * P * cin * cout
+            g = groups.setdefault(name, {"launches": 0, "ms": 0.0, "bytes": 0, "flops": 0})
+            g["launches"] += 1
+            g["ms"] += e0.elapsed_time(e1)
+            g["bytes"] += byts
+            g["flops"] += flops
+        for g in groups.values():
+            g["avg_us"] = 1e3 * g["ms"] / g["launches"]
+            g["GBps"] = g["bytes"] / (g["ms"] * 1e-3) / 1e9
+            g["TFLOPs"] = g["flops"] / (g["ms"] * 1e-3) / 1e12
+        name = max(groups, key=lambda n: groups[n]["ms"])
+        g = groups[name]
+        roof = {"bound": "hbm", "kernel": name, "achieved": round(g["GBps"], 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(g["GBps"] / HBM_PEAK_GBS, 4), "traffic": None,
+                "avg_launch_us": round(g["avg_us"], 2), "launches_per_step": g["launches"] // max(steps, 1),
+                "algorithmic_bytes_per_launch": int(g["bytes"] // g["launches"]),
+                "tflops": round(g["TFLOPs"], 2)}
+        tot_ms = sum(x["ms"] for x in groups.values())
+        tot_b = sum(x["bytes"] for x in groups.values())
+        roof["all_spconv_fwd_dgrad"] = {"ms_per_step": round(tot_ms / max(steps, 1), 3),
+                                        "GBps": round(tot_b / (tot_ms * 1e-3) / 1e9, 1)}
+        return groups, roof
+
+
+# --------------------------------------------------------------------------------------------- cpu baseline
+def cpu_baseline(args):
+    """The same host modules over the oracle backend on the host cores: 1 frame pair, forward + backward
+    (bounded sample: ~10-30 s of CPU work)."""
+    from oracle import cpu_backend
+    from rslo_amd import workload
+    torch.manual_seed(7)
+    threads = torch.get_num_threads()
+    with cpu_backend.patched():
+        net, _ = workload.build_network(device="cpu")
+        net.train()
+        net.global_step.fill_(2000)
+        clouds = workload.kitti_pairs(1, n_el=args.rings)
+        t0 = time.time()
+        ex = workload.make_example(net, clouds, device="cpu")
+        ret = net(ex)
+        ret["loss"].backward()
+        dt = time.time() - t0
+    return {"value": round(1.0 / dt, 4), "unit": "frame-pairs/s", "cores": int(threads), "kind": "port",
+            "sample": "1 frame pair (2 x %d-ring synthetic scans), voxelize+forward+backward, bs=1, "
+                      "oracle C/OpenMP sparse ops + torch-CPU dense head; %.1f s" % (args.rings, dt)}
+
+
+# --------------------------------------------------------------------------------------------- main
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist_on = world > 1
+    if dist_on:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if dist_on else 0)
+
+    import rslo_amd  # noqa: F401
+    from rslo_amd import capi, workload
+    capi.lib()   # fail loudly if the HIP library is missing
+
+    torch.manual_seed(7)
+    net, _ = workload.build_network(device=dev)
+    net.train()
+    net.global_step.fill_(2000)          # past the warm-up: predicted pose in the loss, icp_iter = 2
+    model = net
+    if dist_on:
+        model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[local_rank], find_unused_parameters=True,
+                                                          bucket_cap_mb=48)
+    params = [p for p in net.parameters() if p.requires_grad]
+    opt = torch.optim.Adam(params, lr=8e-5, betas=(0.9, 0.99), fused=True)
+
+    clouds = workload.kitti_pairs(args.batch, n_el=args.rings, start=rank * args.batch)
+    clouds = [[torch.from_numpy(c).to(dev) for c in pair] for pair in clouds]
+    fixed_example = workload.make_example(net, clouds, device=dev) if args.no_voxelize else None
+
+    def step():
+        ex = fixed_example if fixed_example is not None else workload.make_example(net, clouds, device=dev)
+        if fixed_example is not None:
+            ex = dict(ex)
+        opt.zero_grad(set_to_none=True)
+        ret = model(ex)
+        ret["loss"].mean().backward()
+        if not args.no_optim:
+            torch.nn.utils.clip_grad_norm_(params, 10.0)
+            opt.step()
+        return ret
+
+    probe = ConvProbe(capi)
+    use_probe = (not args.no_kernel_events) and rank == 0
+    if use_probe:
+        probe.install()
+
+    for _ in range(args.warmup):
+        step()
+
+    def barrier():
+        if dist_on:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    probe.enabled = use_probe
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        if use_probe and i == args.steps - 1:
+            probe.keep_tables = True
+        ret = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    probe.enabled = False
+    if dist_on:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    loss_val = float(ret["loss"].detach().mean().item())
+    if rank == 0:
+        roof = None
+        if use_probe and probe.records:
+            groups, roof = probe.summarize(args.steps)
+            if args.kernel_report:
+                with open(args.kernel_report, "w") as f:
+                    json.dump({k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()}
+                               for k, v in groups.items()}, f, indent=1)
+            probe.uninstall()
+        n_points = int(np.mean([c.shape[0] for pair in clouds for c in pair]))
+        line = {
+            "metric": "frame-pairs/sec fwd+bwd (synthetic KITTI-shaped ~%dk-pt scans)" % (n_points // 1000),
+            "value": round(args.batch * world * args.steps / elapsed, 3),
+            "unit": "frame-pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C3: full fwd+bwd (voxelize + GU encoder + BEV head/vote + chamfer/ICP loss"
+                                   "%s), bs=%d frame pairs/GPU, fp32, %d-ring scans (~%d pts/frame), dp%d"
+                                   % ("" if args.no_optim else " + Adam step", args.batch, args.rings, n_points, world),
+                       "frame_pairs_per_gpu": args.batch, "points_per_frame": n_points,
+                       "voxelize_in_step": not args.no_voxelize, "optimizer_in_step": not args.no_optim,
+                       "final_loss": round(loss_val, 4)},
+            "roofline": roof,
+            "cpu_baseline": None,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(args)
+            except Exception as e:   # the baseline is informational; never lose the measurement over it
+                line["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(line), flush=True)
+    if dist_on:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

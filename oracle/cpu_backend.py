@@ -1,0 +1,126 @@
+"""CPU stand-in for rslo_amd.capi built on the oracle -- TEST INFRASTRUCTURE ONLY.
+
+`with cpu_backend.patched():` swaps the entry points of `rslo_amd.capi` for oracle-backed versions that
+accept CPU tensors, so the *same* host modules (spconv mirror, encoder, loss) can be run on the CPU as the
+reference-semantics path: the checker for the GPU parity tests and the "port" CPU baseline of bench.py.
+The product never imports this module and has no switch that could route to it.
+"""
+import contextlib
+
+import numpy as np
+import torch
+
+import oracle as O
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+class SiteIndex:
+    def __init__(self, coords, batch, dims):
+        self.coords = coords.contiguous()
+        self.batch = int(batch)
+        self.dims = [int(d) for d in dims]
+        self.cap = 0
+        self.keys = self.vals = None
+
+
+def voxelize(points, pc_range, voxel_size, grid_xyz, max_points, max_voxels):
+    v, c, n = O.voxelize(_np(points), pc_range, voxel_size, max_points, max_voxels)
+    M = len(c)
+    F = points.shape[1]
+    vox = torch.zeros((max_voxels, max_points, F))
+    coords = torch.zeros((max_voxels, 3), dtype=torch.int32)
+    num = torch.zeros((max_voxels,), dtype=torch.int32)
+    vox[:M], coords[:M], num[:M] = torch.from_numpy(v), torch.from_numpy(c), torch.from_numpy(n)
+    return vox, coords, num, torch.tensor([M], dtype=torch.int32)
+
+
+def vfe_mean(voxels, num_points):
+    return torch.from_numpy(O.vfe_mean(_np(voxels), _np(num_points)))
+
+
+def rulebook_subm(index, ks):
+    return torch.from_numpy(O.rulebook_subm(_np(index.coords), index.batch, index.dims, ks))
+
+
+def conv_out_dims(in_dims, ks, stride, pad):
+    return O.conv_out_dims(in_dims, ks, stride, pad)
+
+
+def rulebook_conv(index, ks, stride, pad):
+    oc, od, nbr, nbrT = O.rulebook_conv(_np(index.coords), index.batch, index.dims, ks, stride, pad)
+    return SiteIndex(torch.from_numpy(oc), index.batch, od), torch.from_numpy(nbr), torch.from_numpy(nbrT)
+
+
+def spconv_fwd(x, W, bias, nbr, flip_k=False, act_slope=1.0):
+    Wn = _np(W)
+    if flip_k:
+        Wn = Wn[::-1].copy()
+    y = O.spconv_fwd(_np(x), Wn, None if bias is None else _np(bias), _np(nbr))
+    if act_slope != 1.0:
+        y = np.where(y > 0, y, y * np.float32(act_slope)).astype(np.float32)
+    return torch.from_numpy(y)
+
+
+def spconv_dgrad(dout, W, nbrT, flip_k=False):
+    Wn = _np(W)
+    if flip_k:
+        Wn = Wn[::-1].copy()
+    return torch.from_numpy(O.spconv_dgrad(_np(dout), Wn, _np(nbrT)))
+
+
+def spconv_wgrad(x, dout, nbr, cin, cout, with_bias=True):
+    dW, db = O.spconv_wgrad(_np(x), _np(dout), _np(nbr), cin, cout)
+    return torch.from_numpy(dW), (torch.from_numpy(db) if with_bias else None)
+
+
+def leaky_bwd(y, dout, slope):
+    return torch.where(y > 0, dout, dout * slope)
+
+
+def dense_scatter(feat, coords, batch, dims):
+    return torch.from_numpy(O.dense(_np(feat), _np(coords), batch, list(dims)))
+
+
+def dense_gather(dense, coords, C_, batch, dims):
+    c = coords.long()
+    return dense[c[:, 0], :, c[:, 1], c[:, 2], c[:, 3]].contiguous()
+
+
+def chamfer_nn(xyz1, xyz2, dist=None, idx=None):
+    d, i = O.chamfer_nn(_np(xyz1), _np(xyz2))
+    d, i = torch.from_numpy(d), torch.from_numpy(i)
+    if dist is not None:
+        dist.copy_(d)
+        idx.copy_(i)
+        return dist, idx
+    return d, i
+
+
+def chamfer_grad(xyz1, xyz2, graddist1, idx1, g1=None, g2=None):
+    a, b = O.chamfer_grad(_np(xyz1), _np(xyz2), _np(graddist1), _np(idx1))
+    a, b = torch.from_numpy(a), torch.from_numpy(b)
+    if g1 is not None:
+        g1.copy_(a)
+        g2.copy_(b)
+        return g1, g2
+    return a, b
+
+
+_NAMES = ["SiteIndex", "voxelize", "vfe_mean", "rulebook_subm", "conv_out_dims", "rulebook_conv", "spconv_fwd",
+          "spconv_dgrad", "spconv_wgrad", "leaky_bwd", "dense_scatter", "dense_gather", "chamfer_nn", "chamfer_grad"]
+
+
+@contextlib.contextmanager
+def patched():
+    from rslo_amd import capi
+    saved = {n: getattr(capi, n) for n in _NAMES}
+    try:
+        for n in _NAMES:
+            setattr(capi, n, globals()[n])
+        yield
+    finally:
+        for n, f in saved.items():
+            setattr(capi, n, f)

@@ -1,0 +1,55 @@
+"""Synthetic workloads for bench.py / smoke() / the parity tests: KITTI-shaped frame pairs turned into the
+`example` dict the reference's collate + example_convert_to_torch produce (train_hdf5.py:44-89,
+rslo/data/preprocess.py:46-134), with the voxelization done by the network's own voxel generator."""
+import numpy as np
+import torch
+
+from rslo_amd import synthetic
+
+
+def build_network(testing=False, device="cuda"):
+    import rslo_amd  # noqa: F401
+    from rslo.builder import second_builder, voxel_builder
+    from rslo.utils import config_text
+    cfg = config_text.shipped_config()
+    m = cfg.model.second
+    vg = voxel_builder.build(m.voxel_generator)
+    net = second_builder.build(m, vg, testing=testing)
+    return net.to(device), cfg
+
+
+def make_example(net, clouds_per_sample, max_voxels=synthetic.MAX_VOXELS, device="cuda"):
+    """clouds_per_sample: list (batch) of lists (frames) of [P,7] float32 arrays.
+    Returns the example dict: per frame t, the B samples' voxels concatenated with the batch index
+    prepended to the coordinates (merge_second_batch, preprocess.py:75-89)."""
+    B, T = len(clouds_per_sample), len(clouds_per_sample[0])
+    ex = {"voxels": [], "num_points": [], "coordinates": [], "num_voxels": []}
+    for t in range(T):
+        vs, ns, cs, nv = [], [], [], []
+        for b in range(B):
+            pts = clouds_per_sample[b][t]
+            if isinstance(pts, np.ndarray):
+                pts = torch.from_numpy(pts)
+            r = net.voxel_generator.generate(pts.to(device), max_voxels)
+            v, c, n = r["voxels"], r["coordinates"], r["num_points_per_voxel"]
+            vs.append(v)
+            ns.append(n)
+            cs.append(torch.cat([torch.full((c.shape[0], 1), b, dtype=torch.int32, device=c.device), c], 1))
+            nv.append(v.shape[0])
+        ex["voxels"].append(torch.cat(vs, 0))
+        ex["num_points"].append(torch.cat(ns, 0))
+        ex["coordinates"].append(torch.cat(cs, 0))
+        ex["num_voxels"].append(torch.tensor(nv, dtype=torch.int64).reshape(B, 1))
+    npairs = T * (T - 1) // 2
+    ex["icp_odometry"] = torch.zeros(B * npairs, 7, device=device)
+    ex["tq_maps"] = [torch.zeros(B * npairs, 7, 96, 176, device=device)]
+    return ex
+
+
+def kitti_pairs(batch, n_el=64, start=0):
+    """`batch` synthetic frame pairs (2 frames each) -> clouds_per_sample."""
+    out = []
+    for b in range(batch):
+        p0, p1, _ = synthetic.frame_pair(start + b, n_el=n_el)
+        out.append([p0, p1])
+    return out

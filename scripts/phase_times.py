@@ -1,0 +1,50 @@
+"""Where does a C3 step go?  Sync-bracketed phase timings (diagnostic, not the benchmark)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import rslo_amd
+from rslo_amd import workload, capi
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+torch.manual_seed(7)
+net, _ = workload.build_network()
+net.train(); net.global_step.fill_(2000)
+params = [p for p in net.parameters() if p.requires_grad]
+opt = torch.optim.Adam(params, lr=8e-5, fused=True)
+clouds = [[torch.from_numpy(c).cuda() for c in pair] for pair in workload.kitti_pairs(B)]
+
+def sync():
+    torch.cuda.synchronize(); return time.perf_counter()
+
+acc = {}
+def add(k, dt): acc[k] = acc.get(k, 0.0) + dt
+
+# wrap C-ABI calls with sync timers to attribute time inside forward/backward
+names = ["voxelize", "vfe_mean", "rulebook_subm", "rulebook_conv", "spconv_fwd", "spconv_dgrad", "spconv_wgrad",
+         "leaky_bwd", "dense_scatter", "dense_gather", "chamfer_nn"]
+orig = {n: getattr(capi, n) for n in names}
+orig["SiteIndex"] = capi.SiteIndex
+def wrap(n, f):
+    def w(*a, **k):
+        t0 = sync(); r = f(*a, **k); add("capi." + n, sync() - t0); return r
+    return w
+DETAIL = os.environ.get("DETAIL", "1") == "1"
+if DETAIL:
+    for n in names: setattr(capi, n, wrap(n, orig[n]))
+
+for it in range(6):
+    if it == 2: acc.clear()
+    t0 = sync()
+    ex = workload.make_example(net, clouds); t1 = sync(); add("make_example(voxelize)", t1 - t0)
+    opt.zero_grad(set_to_none=True)
+    voxels, num_points, coors = ex["voxels"], ex["num_points"], ex["coordinates"]
+    Bdev = ex["num_voxels"][0].shape[0]
+    t1 = sync()
+    preds = net.network_forward(voxels, num_points, coors, Bdev, example=ex); t2 = sync(); add("network_forward", t2 - t1)
+    ret = net.loss(ex, preds); t3 = sync(); add("loss_forward", t3 - t2)
+    ret["loss"].mean().backward(); t4 = sync(); add("backward", t4 - t3)
+    torch.nn.utils.clip_grad_norm_(params, 10.0); opt.step(); t5 = sync(); add("clip+adam", t5 - t4)
+    add("TOTAL", t5 - t0)
+n = 4
+for k, v in sorted(acc.items(), key=lambda kv: -kv[1]):
+    print("%-28s %8.2f ms/step" % (k, 1e3 * v / n))

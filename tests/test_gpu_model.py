@@ -1,0 +1,173 @@
+"""GPU parity of the assembled path: host mirror + HIP kernels vs (a) golden vectors from the real reference
+and (b) the same modules run on the CPU over the oracle backend (oracle/cpu_backend.py).
+
+Tolerances: poses 1e-4 relative (the north star's bar), losses 5e-4 relative, features/gradients fp32-level.
+"""
+import copy
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import rslo_amd  # noqa: F401
+from oracle import cpu_backend
+from rslo_amd import synthetic, workload
+
+from test_golden_host import (check_closs, check_create_loss, check_head, load_small_head, make_closs)
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def pieces():
+    return np.load(os.path.join(GOLD, "ref_pieces.npz"))
+
+
+def test_consistency_loss_gpu_matches_reference(hip, pieces):
+    closs = make_closs().cuda()          # real HIP chamfer inside
+    check_closs(pieces, closs, "cuda")
+
+
+def test_bev_head_gpu_matches_reference(hip):
+    head, g = load_small_head()
+    check_head(head, g, "cuda")
+
+
+def test_create_loss_gpu_matches_reference(hip, pieces):
+    check_create_loss(pieces, "cuda", None)
+
+
+def reduced_pair(seed=0, rings=16):
+    """A cheap KITTI-shaped pair: every (64/rings)-th ring of the synthetic scan (~8k voxels/frame)."""
+    p0, p1, motion = synthetic.frame_pair(seed)
+    rings_id0 = np.arange(len(p0)) * 64 // len(p0)
+    rings_id1 = np.arange(len(p1)) * 64 // len(p1)
+    step = 64 // rings
+    return p0[rings_id0 % step == 0], p1[rings_id1 % step == 0], motion
+
+
+def clone_to_cpu(net):
+    net_cpu = copy.deepcopy(net).cpu()
+    return net_cpu
+
+
+def example_to_cpu(ex):
+    out = {}
+    for k, v in ex.items():
+        if isinstance(v, list):
+            out[k] = [x.cpu() if isinstance(x, torch.Tensor) else x for x in v]
+        elif isinstance(v, torch.Tensor):
+            out[k] = v.cpu()
+        else:
+            out[k] = v
+    return out
+
+
+def rel(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def test_encoder_fwd_bwd_matches_cpu_oracle(hip):
+    torch.manual_seed(7)
+    net, _ = workload.build_network()
+    net.train()
+    p0, p1, _ = reduced_pair(0)
+    ex = workload.make_example(net, [[p0, p1]])
+    feats = [net.voxel_feature_extractor(ex["voxels"][t], ex["num_points"][t]) for t in range(2)]
+    coords = torch.cat([ex["coordinates"][0], ex["coordinates"][1] + torch.tensor([1, 0, 0, 0], dtype=torch.int32, device="cuda")], 0)
+    x = torch.cat(feats, 0)
+    enc = net.middle_feature_extractor
+    bev, cov = enc(x, coords, 2)
+    g_bev, g_cov = torch.randn_like(bev), torch.randn_like(cov)
+    (bev * g_bev).sum().add((cov * g_cov).sum()).backward()
+
+    enc_cpu = copy.deepcopy(enc).cpu()
+    enc_cpu.zero_grad()
+    with cpu_backend.patched():
+        bev_c, cov_c = enc_cpu(x.cpu(), coords.cpu(), 2)
+        ((bev_c * g_bev.cpu()).sum() + (cov_c * g_cov.cpu()).sum()).backward()
+    assert bev.shape == (2, 128, 96, 176)
+    assert rel(bev, bev_c) < 2e-5 and rel(cov, cov_c) < 2e-5
+    # weight gradients: 20 chained fp32 layers vs the oracle's double accumulation, plus LeakyReLU masks that can
+    # flip for |y| ~ 1e-7 -- a few 1e-3 of the largest entry on the earliest layers
+    for (n, p), (_, pc) in zip(enc.named_parameters(), enc_cpu.named_parameters()):
+        assert rel(p.grad, pc.grad) < 5e-3, n
+
+
+def test_full_network_fwd_bwd_matches_cpu_oracle(hip):
+    torch.manual_seed(7)
+    net, _ = workload.build_network()
+    net.train()
+    net.global_step.fill_(2000)
+    p0, p1, _ = reduced_pair(1)
+    ex = workload.make_example(net, [[p0, p1]])
+    net_cpu = clone_to_cpu(net)
+    ret = net(ex)
+    ret["loss"].backward()
+    with cpu_backend.patched():
+        ret_c = net_cpu(example_to_cpu(ex))
+        ret_c["loss"].backward()
+    # pose output within 1e-4 relative of the CPU reference-semantics path (north star)
+    assert rel(ret["translation_preds"], ret_c["translation_preds"]) < 1e-4
+    assert rel(ret["rotation_preds"], ret_c["rotation_preds"]) < 1e-4
+    # loss terms hang off the ICP pseudo-targets (amplified fp32 differences): 2e-3 relative
+    for k in ("loss", "translation_loss", "rotation_loss", "pyramid_loss", "C_loss"):
+        assert rel(ret[k], ret_c[k]) < 2e-3, k
+    checked = 0
+    for (n, p), (_, pc) in zip(net.named_parameters(), net_cpu.named_parameters()):
+        if pc.grad is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
+            continue
+        assert p.grad is not None, n
+        assert rel(p.grad, pc.grad) < 2e-2, n
+        checked += 1
+    assert checked >= 200   # 213 of 290 parameter tensors receive gradients
+
+
+def test_eval_forward_batched_equals_per_sample(hip):
+    """bs > 1 is an extension of the reference (middle.py:221 asserts bs == 1): the batched result must equal
+    the per-sample results.  Eval mode (BN uses running statistics), fresh BN buffers."""
+    torch.manual_seed(3)
+    net, _ = workload.build_network()
+    net.eval()
+    a = reduced_pair(2)
+    b = reduced_pair(3)
+    with torch.no_grad():
+        both = net(workload.make_example(net, [[a[0], a[1]], [b[0], b[1]]]))
+        one_a = net(workload.make_example(net, [[a[0], a[1]]]))
+        one_b = net(workload.make_example(net, [[b[0], b[1]]]))
+    t = torch.cat([one_a["translation_preds"], one_b["translation_preds"]])
+    r = torch.cat([one_a["rotation_preds"], one_b["rotation_preds"]])
+    assert both["translation_preds"].shape == (2, 3) and both["rotation_preds"].shape == (2, 4)
+    assert rel(both["translation_preds"], t) < 1e-4 and rel(both["rotation_preds"], r) < 1e-4
+
+
+def test_spconv_api_indice_pairs_view(hip):
+    """The spconv-1.x `indice_pairs` view of our tables equals the oracle's export (bit-exact indices)."""
+    import oracle as O
+    import spconv
+    rng = np.random.default_rng(0)
+    dims = [9, 20, 18]
+    lin = rng.choice(2 * 9 * 20 * 18, size=1200, replace=False)
+    x_ = lin % 18; r = lin // 18
+    y_ = r % 20; r //= 20
+    z_ = r % 9; b_ = r // 9
+    coords = np.stack([b_, z_, y_, x_], 1).astype(np.int32)
+    coords = coords[np.argsort(coords[:, 0], kind="stable")]
+    feats = torch.randn(len(coords), 16, device="cuda")
+    t = spconv.SparseConvTensor(feats, torch.from_numpy(coords).cuda(), dims, 2)
+    conv = spconv.SparseConv3d(16, 32, 3, 2, padding=1, indice_key="c").cuda()
+    sub = spconv.SubMConv3d(16, 16, 3, indice_key="s").cuda()
+    y = conv(sub(t))
+    oc, od, nbr, nbrT = O.rulebook_conv(coords, 2, dims, [3, 3, 3], [2, 2, 2], [1, 1, 1])
+    assert y.spatial_shape == od and (y.indices.cpu().numpy() == oc).all()
+    pairs, num = t.indice_dict["c"].indice_pairs()
+    opairs, onum = O.pairs_from_nbrT(nbrT)
+    assert (num.cpu().numpy() == onum).all() and (pairs.cpu().numpy() == opairs).all()
+    spairs, snum = t.indice_dict["s"].indice_pairs()
+    osub = O.rulebook_subm(coords, 2, dims)
+    op2, on2 = O.pairs_from_nbrT(osub[:, ::-1].copy())
+    assert (snum.cpu().numpy() == on2).all() and (spairs.cpu().numpy() == op2).all()
