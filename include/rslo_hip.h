@@ -147,6 +147,41 @@ RSLO_API int rslo_chamfer_grad(const float *xyz1, const float *xyz2, int B, int 
                       const float *graddist1, const int32_t *idx1, float *gradxyz1 /*[B,N,3]*/,
                       float *gradxyz2 /*[B,M,3]*/, void *stream);
 
+/* ------------------------------------------------------------------------------------
+ * a18-a20  Consistency loss (rslo/core/losses.py:337-507, Aleat5_1ChamferL2NormalWeightedALLSVDLoss).
+ * All arrays are per frame pair b in [0,B): p1 [B,N,3] source voxel means, n1 [B,N,3] their normals,
+ * tgt [B,M,3] posed target means, cov1 [B,N,7] / cov2 [B,M,7] covariance parameters
+ * (3 eigenvalue increments + quaternion read as x,y,z,w -- losses.py:348-363), idx/dist [B,N] the
+ * chamfer association, thr [B] = max(kth(dist), 1) (losses.py:326-334), Rd [B,9] the detached pose.
+ *
+ * cov_residual_fwd: loss[b] = mean_roi(d^T sigma^-1 d) + reg * mean_roi(0.5 log det sigma),
+ *                   sigma = S1 + Rd S2[idx] Rd^T, d = p1 - tgt[idx], roi = dist < thr (losses.py:396-435;
+ *                   closed-form 3x3 inverse/det instead of torch.inverse/torch.det over ~30k matrices).
+ * cov_residual_bwd: gradients of sum_b gloss[b]*loss[b] w.r.t. tgt, cov1, cov2 (and p1 if gp1 != NULL).
+ * icp_step        : one SVDHead refinement (rslo/layers/svd.py:14-64 called from losses.py:451-465):
+ *                   weighted Kabsch over the ROI with w = cos(n1, tgt[idx]-p1)^2, unweighted centroids,
+ *                   reflection fix, returns the inverse motion and composes res_r = R res_r,
+ *                   res_t = R res_t + t in place.  No host round trip (the reference branches on det(R)).
+ * transform_points: out = R x + t per pair (losses.py:471-473).
+ * ------------------------------------------------------------------------------------ */
+RSLO_API size_t rslo_cov_residual_ws_bytes(int B, int N);
+RSLO_API int rslo_cov_residual_fwd(const float *p1, const float *tgt, const float *cov1, const float *cov2,
+                          const int32_t *idx, const float *dist, const float *thr, const float *Rd, int B, int N,
+                          int M, float reg_weight, void *ws, size_t ws_bytes, float *loss /*[B]*/,
+                          float *cnt /*[B]*/, void *stream);
+RSLO_API int rslo_cov_residual_bwd(const float *p1, const float *tgt, const float *cov1, const float *cov2,
+                          const int32_t *idx, const float *dist, const float *thr, const float *Rd,
+                          const float *gloss /*[B]*/, const float *cnt /*[B]*/, int B, int N, int M,
+                          float reg_weight, float *gp1 /*[B,N,3] or NULL*/, float *gtgt /*[B,M,3]*/,
+                          float *gcov1 /*[B,N,7]*/, float *gcov2 /*[B,M,7]*/, void *stream);
+RSLO_API size_t rslo_icp_ws_bytes(int B, int N);
+RSLO_API int rslo_icp_step(const float *p1, const float *n1, const float *tgt, const int32_t *idx, const float *dist,
+                  const float *thr, int B, int N, int M, void *ws, size_t ws_bytes, float *res_r /*[B,9] in/out*/,
+                  float *res_t /*[B,3] in/out*/, float *step_R /*[B,9] or NULL*/, float *step_t /*[B,3] or NULL*/,
+                  void *stream);
+RSLO_API int rslo_transform_points(const float *x, const float *R, const float *t, int B, int M, float *out,
+                          void *stream);
+
 #ifdef __cplusplus
 }
 #endif

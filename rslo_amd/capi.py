@@ -44,6 +44,12 @@ SIGNATURES = {
     "rslo_chamfer_ws_bytes": (_sz, [_i, _i, _i]),
     "rslo_chamfer_nn": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "rslo_chamfer_grad": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "rslo_cov_residual_ws_bytes": (_sz, [_i, _i]),
+    "rslo_cov_residual_fwd": (C.c_int, [_vp] * 8 + [_i, _i, _i, _f, _vp, _sz, _vp, _vp, _vp]),
+    "rslo_cov_residual_bwd": (C.c_int, [_vp] * 10 + [_i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
+    "rslo_icp_ws_bytes": (_sz, [_i, _i]),
+    "rslo_icp_step": (C.c_int, [_vp] * 6 + [_i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
+    "rslo_transform_points": (C.c_int, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
 }
 
 
@@ -287,3 +293,62 @@ def chamfer_grad(xyz1, xyz2, graddist1, idx1, g1=None, g2=None):
                                  _ptr(graddist1, torch.float32, "graddist1"), _ptr(idx1, torch.int32, "idx1"),
                                  _ptr(g1), _ptr(g2), _stream()), "rslo_chamfer_grad")
     return g1, g2
+
+
+# --------------------------------------------------------------------------------------
+# consistency loss
+# --------------------------------------------------------------------------------------
+def cov_residual_fwd(p1, tgt, cov1, cov2, idx, dist, thr, Rd, reg_weight):
+    """-> loss [B], cnt [B] (see include/rslo_hip.h)."""
+    B, N, _ = p1.shape
+    M = tgt.shape[1]
+    dev = p1.device
+    loss = torch.empty((B,), dtype=torch.float32, device=dev)
+    cnt = torch.empty((B,), dtype=torch.float32, device=dev)
+    wsb = lib().rslo_cov_residual_ws_bytes(B, N)
+    ws = _ws(wsb, dev)
+    _chk(lib().rslo_cov_residual_fwd(_ptr(p1, torch.float32, "p1"), _ptr(tgt, torch.float32, "tgt"),
+                                     _ptr(cov1, torch.float32, "cov1"), _ptr(cov2, torch.float32, "cov2"),
+                                     _ptr(idx, torch.int32, "idx"), _ptr(dist, torch.float32, "dist"),
+                                     _ptr(thr, torch.float32, "thr"), _ptr(Rd, torch.float32, "Rd"), B, N, M,
+                                     float(reg_weight), _ptr(ws), wsb, _ptr(loss), _ptr(cnt), _stream()),
+         "rslo_cov_residual_fwd")
+    return loss, cnt
+
+
+def cov_residual_bwd(p1, tgt, cov1, cov2, idx, dist, thr, Rd, gloss, cnt, reg_weight, need_gp1=False):
+    B, N, _ = p1.shape
+    M = tgt.shape[1]
+    gp1 = torch.empty_like(p1) if need_gp1 else None
+    gtgt = torch.empty_like(tgt)
+    gcov1 = torch.empty_like(cov1)
+    gcov2 = torch.empty_like(cov2)
+    _chk(lib().rslo_cov_residual_bwd(_ptr(p1, torch.float32, "p1"), _ptr(tgt, torch.float32, "tgt"),
+                                     _ptr(cov1, torch.float32, "cov1"), _ptr(cov2, torch.float32, "cov2"),
+                                     _ptr(idx, torch.int32, "idx"), _ptr(dist, torch.float32, "dist"),
+                                     _ptr(thr, torch.float32, "thr"), _ptr(Rd, torch.float32, "Rd"),
+                                     _ptr(gloss, torch.float32, "gloss"), _ptr(cnt, torch.float32, "cnt"), B, N, M,
+                                     float(reg_weight), _ptr(gp1), _ptr(gtgt), _ptr(gcov1), _ptr(gcov2), _stream()),
+         "rslo_cov_residual_bwd")
+    return gp1, gtgt, gcov1, gcov2
+
+
+def icp_step(p1, n1, tgt, idx, dist, thr, res_r, res_t):
+    """One Kabsch refinement over the ROI; composes res_r [B,3,3] / res_t [B,3] IN PLACE."""
+    B, N, _ = p1.shape
+    M = tgt.shape[1]
+    wsb = lib().rslo_icp_ws_bytes(B, N)
+    ws = _ws(wsb, p1.device)
+    _chk(lib().rslo_icp_step(_ptr(p1, torch.float32, "p1"), _ptr(n1, torch.float32, "n1"),
+                             _ptr(tgt, torch.float32, "tgt"), _ptr(idx, torch.int32, "idx"),
+                             _ptr(dist, torch.float32, "dist"), _ptr(thr, torch.float32, "thr"), B, N, M, _ptr(ws), wsb,
+                             _ptr(res_r, torch.float32, "res_r"), _ptr(res_t, torch.float32, "res_t"), None, None,
+                             _stream()), "rslo_icp_step")
+
+
+def transform_points(x, R, t):
+    B, M, _ = x.shape
+    out = torch.empty_like(x)
+    _chk(lib().rslo_transform_points(_ptr(x, torch.float32, "x"), _ptr(R, torch.float32, "R"),
+                                     _ptr(t, torch.float32, "t"), B, M, _ptr(out), _stream()), "rslo_transform_points")
+    return out

@@ -1,0 +1,501 @@
+// Fused kernels of the self-supervised consistency loss for gfx950.
+//
+//  * covariance-weighted residual, forward and backward: one thread per correspondence rebuilds both
+//    3x3 covariances from their 7 parameters (cumulative eigenvalues + quaternion), gathers the partner by
+//    the chamfer index, forms sigma = S1 + R S2 R^T, its closed-form inverse / determinant and the
+//    Mahalanobis + log-det terms; block partial sums in double, deterministic second-stage reduce.
+//    The backward recomputes instead of storing and scatter-adds the partner gradients with atomics
+//    (the reference's own CUDA backward uses atomicAdd too, chamfer_distance.cu:177-206).
+//  * ICP step: weighted-Kabsch moments of the ROI in double (one pass, raw moments), then a single
+//    thread does the 3x3 Jacobi SVD, the reflection fix and composes the running (R, t) -- no host
+//    round trip for torch.svd / det (rslo/layers/svd.py:36-46).
+// All of it is latency/HBM-bound elementwise work on < 3 MB per pair.
+#include "rslo_common.h"
+
+#define LS_THREADS 256
+
+struct Cov7 {
+  float lam[3];
+  float qn;      // |q|
+  float qh[4];   // q / (|q| + 1e-9)
+  float qhn;     // max(|qh|, 1e-12)
+  float qt[4];   // qh / qhn  (x, y, z, w)
+  float V[9];    // rotation matrix of qt, row-major
+};
+
+__device__ __forceinline__ void cov_build(const float *__restrict__ p, Cov7 &c, float S[9]) {
+  c.lam[0] = p[0];
+  c.lam[1] = c.lam[0] + p[1];
+  c.lam[2] = c.lam[1] + p[2];
+  const float n = sqrtf(p[3] * p[3] + p[4] * p[4] + p[5] * p[5] + p[6] * p[6]);
+  c.qn = n;
+  const float inv = 1.0f / (n + 1e-9f);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) c.qh[k] = p[3 + k] * inv;
+  float hn = sqrtf(c.qh[0] * c.qh[0] + c.qh[1] * c.qh[1] + c.qh[2] * c.qh[2] + c.qh[3] * c.qh[3]);
+  hn = fmaxf(hn, 1e-12f);
+  c.qhn = hn;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) c.qt[k] = c.qh[k] / hn;
+  const float x = c.qt[0], y = c.qt[1], z = c.qt[2], w = c.qt[3];
+  const float tx = 2.f * x, ty = 2.f * y, tz = 2.f * z;
+  const float twx = tx * w, twy = ty * w, twz = tz * w;
+  const float txx = tx * x, txy = ty * x, txz = tz * x;
+  const float tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  float *V = c.V;
+  V[0] = 1.f - (tyy + tzz); V[1] = txy - twz;         V[2] = txz + twy;
+  V[3] = txy + twz;         V[4] = 1.f - (txx + tzz); V[5] = tyz - twx;
+  V[6] = txz - twy;         V[7] = tyz + twx;         V[8] = 1.f - (txx + tyy);
+  // S = V diag(lam) V^T
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+      S[a * 3 + b] = V[a * 3 + 0] * c.lam[0] * V[b * 3 + 0] + V[a * 3 + 1] * c.lam[1] * V[b * 3 + 1] +
+                     V[a * 3 + 2] * c.lam[2] * V[b * 3 + 2];
+}
+
+// gradient of the 7 parameters given G = dL/dS (symmetric)
+__device__ __forceinline__ void cov_backward(const float *__restrict__ p, const Cov7 &c, const float G[9],
+                                             float g[7]) {
+  const float *V = c.V;
+  float GV[9];   // G V
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) GV[a * 3 + k] = G[a * 3 + 0] * V[0 * 3 + k] + G[a * 3 + 1] * V[1 * 3 + k] + G[a * 3 + 2] * V[2 * 3 + k];
+  float dl[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) dl[k] = V[0 * 3 + k] * GV[0 * 3 + k] + V[1 * 3 + k] * GV[1 * 3 + k] + V[2 * 3 + k] * GV[2 * 3 + k];
+  g[0] = dl[0] + dl[1] + dl[2];
+  g[1] = dl[1] + dl[2];
+  g[2] = dl[2];
+  float dV[9];   // 2 G V diag(lam)
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) dV[a * 3 + k] = 2.f * c.lam[k] * GV[a * 3 + k];
+  const float x = c.qt[0], y = c.qt[1], z = c.qt[2], w = c.qt[3];
+  float dq[4];
+  dq[0] = dV[1] * 2 * y + dV[2] * 2 * z + dV[3] * 2 * y - dV[4] * 4 * x - dV[5] * 2 * w + dV[6] * 2 * z + dV[7] * 2 * w - dV[8] * 4 * x;
+  dq[1] = -dV[0] * 4 * y + dV[1] * 2 * x + dV[2] * 2 * w + dV[3] * 2 * x + dV[5] * 2 * z - dV[6] * 2 * w + dV[7] * 2 * z - dV[8] * 4 * y;
+  dq[2] = -dV[0] * 4 * z - dV[1] * 2 * w + dV[2] * 2 * x + dV[3] * 2 * w - dV[4] * 4 * z + dV[5] * 2 * y + dV[6] * 2 * x + dV[7] * 2 * y;
+  dq[3] = -dV[1] * 2 * z + dV[2] * 2 * y + dV[3] * 2 * z - dV[5] * 2 * x - dV[6] * 2 * y + dV[7] * 2 * x;
+  // qt = qh / max(|qh|, eps)
+  float dot = c.qt[0] * dq[0] + c.qt[1] * dq[1] + c.qt[2] * dq[2] + c.qt[3] * dq[3];
+  float dh[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) dh[k] = (dq[k] - c.qt[k] * dot) / c.qhn;
+  // qh = q / (|q| + 1e-9)
+  const float n = c.qn, ne = n + 1e-9f;
+  float qd = p[3] * dh[0] + p[4] * dh[1] + p[5] * dh[2] + p[6] * dh[3];
+  const float coef = (n > 0.f) ? qd / (n * ne * ne) : 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) g[3 + k] = dh[k] / ne - p[3 + k] * coef;
+}
+
+__device__ __forceinline__ float inv3(const float S[9], float I[9]) {
+  const float a = S[0], b = S[1], c = S[2], d = S[3], e = S[4], f = S[5], g = S[6], h = S[7], i = S[8];
+  const float A = e * i - f * h, B = -(d * i - f * g), C = d * h - e * g;
+  const float det = a * A + b * B + c * C;
+  const float r = 1.0f / det;
+  I[0] = A * r;  I[1] = -(b * i - c * h) * r;  I[2] = (b * f - c * e) * r;
+  I[3] = B * r;  I[4] = (a * i - c * g) * r;   I[5] = -(a * f - c * d) * r;
+  I[6] = C * r;  I[7] = -(a * h - b * g) * r;  I[8] = (a * e - b * d) * r;
+  return det;
+}
+
+// sigma = S1 + R S2 R^T
+__device__ __forceinline__ void sigma_of(const float S1[9], const float S2[9], const float R[9], float sg[9]) {
+  float RS[9];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) RS[a * 3 + b] = R[a * 3 + 0] * S2[0 * 3 + b] + R[a * 3 + 1] * S2[1 * 3 + b] + R[a * 3 + 2] * S2[2 * 3 + b];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+      sg[a * 3 + b] = S1[a * 3 + b] + RS[a * 3 + 0] * R[b * 3 + 0] + RS[a * 3 + 1] * R[b * 3 + 1] + RS[a * 3 + 2] * R[b * 3 + 2];
+}
+
+__device__ __forceinline__ double block_sum(double v, double *sh) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d, 64);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[wid] = v;
+  __syncthreads();
+  double s = 0.0;
+  if (threadIdx.x == 0)
+    for (int w = 0; w < LS_THREADS / 64; ++w) s += sh[w];
+  return s;   // valid on thread 0
+}
+
+// ---------------------------------------------------------------------------------------
+// residual forward: partial[b][block][3] = sum roi*sq, sum roi*0.5*log det, sum roi
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(LS_THREADS) void k_resid_fwd(const float *__restrict__ p1, const float *__restrict__ tgt,
+                                                          const float *__restrict__ cov1, const float *__restrict__ cov2,
+                                                          const int32_t *__restrict__ idx, const float *__restrict__ dist,
+                                                          const float *__restrict__ thr, const float *__restrict__ Rd,
+                                                          int N, int M, double *__restrict__ partial) {
+  __shared__ double sh[LS_THREADS / 64];
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * LS_THREADS + threadIdx.x;
+  double sq = 0.0, ld = 0.0, cnt = 0.0;
+  if (i < N && dist[(int64_t)b * N + i] < thr[b]) {
+    const int j = idx[(int64_t)b * N + i];
+    const float *a = p1 + ((int64_t)b * N + i) * 3, *t = tgt + ((int64_t)b * M + j) * 3;
+    float R[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R[k] = Rd[b * 9 + k];
+    Cov7 c1, c2;
+    float S1[9], S2[9], sg[9], I[9];
+    cov_build(cov1 + ((int64_t)b * N + i) * 7, c1, S1);
+    cov_build(cov2 + ((int64_t)b * M + j) * 7, c2, S2);
+    sigma_of(S1, S2, R, sg);
+    const float det = inv3(sg, I);
+    const float d0 = a[0] - t[0], d1 = a[1] - t[1], d2 = a[2] - t[2];
+    const float v0 = I[0] * d0 + I[1] * d1 + I[2] * d2, v1 = I[3] * d0 + I[4] * d1 + I[5] * d2,
+                v2 = I[6] * d0 + I[7] * d1 + I[8] * d2;
+    sq = (double)(d0 * v0 + d1 * v1 + d2 * v2);
+    ld = (double)(0.5f * logf(det));
+    cnt = 1.0;
+  }
+  const double s0 = block_sum(sq, sh), s1 = block_sum(ld, sh), s2 = block_sum(cnt, sh);
+  if (threadIdx.x == 0) {
+    double *o = partial + ((int64_t)b * gridDim.x + blockIdx.x) * 3;
+    o[0] = s0; o[1] = s1; o[2] = s2;
+  }
+}
+
+__global__ void k_resid_finish(const double *__restrict__ partial, int nblk, float reg, float *__restrict__ loss,
+                               float *__restrict__ cnt_out) {
+  const int b = blockIdx.x;
+  if (threadIdx.x != 0) return;
+  double s0 = 0, s1 = 0, s2 = 0;
+  for (int k = 0; k < nblk; ++k) {
+    const double *o = partial + ((int64_t)b * nblk + k) * 3;
+    s0 += o[0]; s1 += o[1]; s2 += o[2];
+  }
+  loss[b] = (float)(s0 / s2 + (double)reg * (s1 / s2));
+  cnt_out[b] = (float)s2;
+}
+
+extern "C" size_t rslo_cov_residual_ws_bytes(int B, int N) {
+  return (size_t)(B > 0 ? B : 1) * (size_t)rslo_cdiv(N > 0 ? N : 1, LS_THREADS) * 3 * sizeof(double);
+}
+
+extern "C" int rslo_cov_residual_fwd(const float *p1, const float *tgt, const float *cov1, const float *cov2,
+                                              const int32_t *idx, const float *dist, const float *thr,
+                                              const float *Rd, int B, int N, int M, float reg_weight, void *ws,
+                                              size_t ws_bytes, float *loss, float *cnt, void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (B == 0) return RSLO_OK;
+  RSLO_CHECK_ARG(N >= 1 && M >= 1, "cov_residual_fwd: empty clouds");
+  if (ws_bytes < rslo_cov_residual_ws_bytes(B, N)) {
+    rslo_set_error("cov_residual_fwd: workspace too small");
+    return RSLO_EWS;
+  }
+  const int nblk = (int)rslo_cdiv(N, LS_THREADS);
+  hipLaunchKernelGGL(k_resid_fwd, dim3(nblk, B), dim3(LS_THREADS), 0, st, p1, tgt, cov1, cov2, idx, dist, thr, Rd, N,
+                     M, (double *)ws);
+  hipLaunchKernelGGL(k_resid_finish, dim3(B), dim3(64), 0, st, (const double *)ws, nblk, reg_weight, loss, cnt);
+  RSLO_CHECK_LAUNCH("cov_residual_fwd");
+  return RSLO_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// residual backward: gloss[b] -> gtgt (scatter), gcov1 (direct), gcov2 (scatter)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(LS_THREADS) void k_resid_bwd(const float *__restrict__ p1, const float *__restrict__ tgt,
+                                                          const float *__restrict__ cov1, const float *__restrict__ cov2,
+                                                          const int32_t *__restrict__ idx, const float *__restrict__ dist,
+                                                          const float *__restrict__ thr, const float *__restrict__ Rd,
+                                                          const float *__restrict__ gloss, const float *__restrict__ cnt,
+                                                          int N, int M, float reg, float *__restrict__ gp1,
+                                                          float *__restrict__ gtgt, float *__restrict__ gcov1,
+                                                          float *__restrict__ gcov2) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * LS_THREADS + threadIdx.x;
+  if (i >= N) return;
+  float *g1 = gcov1 + ((int64_t)b * N + i) * 7;
+  if (!(dist[(int64_t)b * N + i] < thr[b])) {
+#pragma unroll
+    for (int k = 0; k < 7; ++k) g1[k] = 0.f;
+    if (gp1) {
+      gp1[((int64_t)b * N + i) * 3 + 0] = 0.f;
+      gp1[((int64_t)b * N + i) * 3 + 1] = 0.f;
+      gp1[((int64_t)b * N + i) * 3 + 2] = 0.f;
+    }
+    return;
+  }
+  const float wgt = gloss[b] / cnt[b];
+  const int j = idx[(int64_t)b * N + i];
+  const float *a = p1 + ((int64_t)b * N + i) * 3, *t = tgt + ((int64_t)b * M + j) * 3;
+  const float *pc1 = cov1 + ((int64_t)b * N + i) * 7, *pc2 = cov2 + ((int64_t)b * M + j) * 7;
+  float R[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) R[k] = Rd[b * 9 + k];
+  Cov7 c1, c2;
+  float S1[9], S2[9], sg[9], I[9];
+  cov_build(pc1, c1, S1);
+  cov_build(pc2, c2, S2);
+  sigma_of(S1, S2, R, sg);
+  inv3(sg, I);
+  const float d0 = a[0] - t[0], d1 = a[1] - t[1], d2 = a[2] - t[2];
+  float v[3] = {I[0] * d0 + I[1] * d1 + I[2] * d2, I[3] * d0 + I[4] * d1 + I[5] * d2,
+                I[6] * d0 + I[7] * d1 + I[8] * d2};
+  // sigma^-1 is symmetric up to rounding: use the symmetrised inverse for the log-det term
+  float G[9];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      G[r * 3 + c] = wgt * (-v[r] * v[c] + reg * 0.25f * (I[r * 3 + c] + I[c * 3 + r]));
+  // d(sq)/dd = (sigma^-1 + sigma^-T) d
+  const float u0 = I[0] * d0 + I[3] * d1 + I[6] * d2, u1 = I[1] * d0 + I[4] * d1 + I[7] * d2,
+              u2 = I[2] * d0 + I[5] * d1 + I[8] * d2;
+  const float gd[3] = {wgt * (v[0] + u0), wgt * (v[1] + u1), wgt * (v[2] + u2)};
+  if (gp1) {
+    gp1[((int64_t)b * N + i) * 3 + 0] = gd[0];
+    gp1[((int64_t)b * N + i) * 3 + 1] = gd[1];
+    gp1[((int64_t)b * N + i) * 3 + 2] = gd[2];
+  }
+  float *gt = gtgt + ((int64_t)b * M + j) * 3;
+  atomicAdd(gt + 0, -gd[0]);
+  atomicAdd(gt + 1, -gd[1]);
+  atomicAdd(gt + 2, -gd[2]);
+  float g7[7];
+  cov_backward(pc1, c1, G, g7);
+#pragma unroll
+  for (int k = 0; k < 7; ++k) g1[k] = g7[k];
+  // G2 = R^T G R
+  float RtG[9], G2[9];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) RtG[r * 3 + c] = R[0 * 3 + r] * G[0 * 3 + c] + R[1 * 3 + r] * G[1 * 3 + c] + R[2 * 3 + r] * G[2 * 3 + c];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) G2[r * 3 + c] = RtG[r * 3 + 0] * R[0 * 3 + c] + RtG[r * 3 + 1] * R[1 * 3 + c] + RtG[r * 3 + 2] * R[2 * 3 + c];
+  cov_backward(pc2, c2, G2, g7);
+  float *g2 = gcov2 + ((int64_t)b * M + j) * 7;
+#pragma unroll
+  for (int k = 0; k < 7; ++k) atomicAdd(g2 + k, g7[k]);
+}
+
+extern "C" int rslo_cov_residual_bwd(const float *p1, const float *tgt, const float *cov1, const float *cov2,
+                                              const int32_t *idx, const float *dist, const float *thr,
+                                              const float *Rd, const float *gloss, const float *cnt, int B, int N,
+                                              int M, float reg_weight, float *gp1 /*or NULL*/, float *gtgt,
+                                              float *gcov1, float *gcov2, void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (B == 0) return RSLO_OK;
+  RSLO_HIP(hipMemsetAsync(gtgt, 0, (size_t)B * M * 3 * sizeof(float), st));
+  RSLO_HIP(hipMemsetAsync(gcov2, 0, (size_t)B * M * 7 * sizeof(float), st));
+  hipLaunchKernelGGL(k_resid_bwd, dim3((unsigned)rslo_cdiv(N, LS_THREADS), B), dim3(LS_THREADS), 0, st, p1, tgt, cov1,
+                     cov2, idx, dist, thr, Rd, gloss, cnt, N, M, reg_weight, gp1, gtgt, gcov1, gcov2);
+  RSLO_CHECK_LAUNCH("cov_residual_bwd");
+  return RSLO_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// ICP step (rslo/core/losses.py:449-488 + rslo/layers/svd.py:14-64)
+// moments (23 doubles): m, m*s[3], m*t[3], mw, mw*s[3], mw*t[3], mw*s(x)t[9]
+// with m = roi (dist < thr), w = cos(n1, assoc - p1)^2, s = p1, t = tgt[idx]
+// ---------------------------------------------------------------------------------------
+#define ICP_NM 23
+
+__global__ __launch_bounds__(LS_THREADS) void k_icp_moments(const float *__restrict__ p1, const float *__restrict__ n1,
+                                                            const float *__restrict__ tgt, const int32_t *__restrict__ idx,
+                                                            const float *__restrict__ dist, const float *__restrict__ thr,
+                                                            int N, int M, double *__restrict__ partial) {
+  __shared__ double sh[LS_THREADS / 64];
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * LS_THREADS + threadIdx.x;
+  double mo[ICP_NM];
+#pragma unroll
+  for (int k = 0; k < ICP_NM; ++k) mo[k] = 0.0;
+  if (i < N && dist[(int64_t)b * N + i] < thr[b]) {
+    const int j = idx[(int64_t)b * N + i];
+    const float *s = p1 + ((int64_t)b * N + i) * 3, *t = tgt + ((int64_t)b * M + j) * 3;
+    const float *n = n1 + ((int64_t)b * N + i) * 3;
+    const float e0 = t[0] - s[0], e1 = t[1] - s[1], e2 = t[2] - s[2];
+    const float dot = n[0] * e0 + n[1] * e1 + n[2] * e2;
+    const float nn = n[0] * n[0] + n[1] * n[1] + n[2] * n[2], ee = e0 * e0 + e1 * e1 + e2 * e2;
+    // torch.nn.functional.cosine_similarity: x.y / (max(|x|, eps) * max(|y|, eps)), eps = 1e-8
+    const float c = dot / (fmaxf(sqrtf(nn), 1e-8f) * fmaxf(sqrtf(ee), 1e-8f));
+    const double w = (double)(fabsf(c) * fabsf(c));
+    mo[0] = 1.0;
+    mo[7] = w;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      mo[1 + a] = s[a];
+      mo[4 + a] = t[a];
+      mo[8 + a] = w * s[a];
+      mo[11 + a] = w * t[a];
+#pragma unroll
+      for (int c2 = 0; c2 < 3; ++c2) mo[14 + a * 3 + c2] = w * (double)s[a] * (double)t[c2];
+    }
+  }
+  double *o = partial + ((int64_t)b * gridDim.x + blockIdx.x) * ICP_NM;
+#pragma unroll
+  for (int k = 0; k < ICP_NM; ++k) {
+    const double sres = block_sum(mo[k], sh);
+    if (threadIdx.x == 0) o[k] = sres;
+  }
+}
+
+__device__ void svd3_jacobi(const double H[9], double U[9], double S[3], double V[9]) {
+  double A[9];
+  for (int k = 0; k < 9; ++k) { A[k] = H[k]; V[k] = (k % 4 == 0) ? 1.0 : 0.0; }
+  for (int sweep = 0; sweep < 30; ++sweep) {
+    double off = 0.0;
+    for (int p = 0; p < 2; ++p)
+      for (int q = p + 1; q < 3; ++q) {
+        double al = 0, be = 0, ga = 0;
+        for (int k = 0; k < 3; ++k) { al += A[k * 3 + p] * A[k * 3 + p]; be += A[k * 3 + q] * A[k * 3 + q]; ga += A[k * 3 + p] * A[k * 3 + q]; }
+        off = fmax(off, fabs(ga) / (sqrt(al * be) + 1e-300));
+        if (fabs(ga) <= 1e-300 || fabs(ga) <= 1e-17 * sqrt(al * be)) continue;
+        const double zeta = (be - al) / (2.0 * ga);
+        const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+        for (int k = 0; k < 3; ++k) {
+          const double ap = A[k * 3 + p], aq = A[k * 3 + q];
+          A[k * 3 + p] = c * ap - s * aq;
+          A[k * 3 + q] = s * ap + c * aq;
+          const double vp = V[k * 3 + p], vq = V[k * 3 + q];
+          V[k * 3 + p] = c * vp - s * vq;
+          V[k * 3 + q] = s * vp + c * vq;
+        }
+      }
+    if (off < 1e-15) break;
+  }
+  for (int k = 0; k < 3; ++k) S[k] = sqrt(A[0 * 3 + k] * A[0 * 3 + k] + A[1 * 3 + k] * A[1 * 3 + k] + A[2 * 3 + k] * A[2 * 3 + k]);
+  // sort descending (columns of A and V)
+  for (int a = 0; a < 2; ++a)
+    for (int b2 = a + 1; b2 < 3; ++b2)
+      if (S[b2] > S[a]) {
+        const double ts = S[a]; S[a] = S[b2]; S[b2] = ts;
+        for (int k = 0; k < 3; ++k) {
+          double tmp = A[k * 3 + a]; A[k * 3 + a] = A[k * 3 + b2]; A[k * 3 + b2] = tmp;
+          tmp = V[k * 3 + a]; V[k * 3 + a] = V[k * 3 + b2]; V[k * 3 + b2] = tmp;
+        }
+      }
+  const double tiny = 1e-14 * (S[0] > 0 ? S[0] : 1.0);
+  for (int k = 0; k < 3; ++k) {
+    if (S[k] > tiny) {
+      for (int r = 0; r < 3; ++r) U[r * 3 + k] = A[r * 3 + k] / S[k];
+    } else if (k == 2) {   // complete to a right-handed frame; the reflection fix below decides the sign
+      U[0 * 3 + 2] = U[1 * 3 + 0] * U[2 * 3 + 1] - U[2 * 3 + 0] * U[1 * 3 + 1];
+      U[1 * 3 + 2] = U[2 * 3 + 0] * U[0 * 3 + 1] - U[0 * 3 + 0] * U[2 * 3 + 1];
+      U[2 * 3 + 2] = U[0 * 3 + 0] * U[1 * 3 + 1] - U[1 * 3 + 0] * U[0 * 3 + 1];
+    } else {
+      for (int r = 0; r < 3; ++r) U[r * 3 + k] = (r == k) ? 1.0 : 0.0;
+    }
+  }
+}
+
+__device__ double det3(const double M[9]) {
+  return M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) + M[2] * (M[3] * M[7] - M[4] * M[6]);
+}
+
+// One thread per pair: reduce partials, Kabsch, compose res_r/res_t in place.
+__global__ void k_icp_solve(const double *__restrict__ partial, int nblk, float *__restrict__ res_r,
+                            float *__restrict__ res_t, float *__restrict__ step_R, float *__restrict__ step_t) {
+  const int b = blockIdx.x;
+  __shared__ double mo[ICP_NM];
+  if (threadIdx.x < ICP_NM) {
+    double s = 0.0;
+    for (int k = 0; k < nblk; ++k) s += partial[((int64_t)b * nblk + k) * ICP_NM + threadIdx.x];
+    mo[threadIdx.x] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  const double cnt = mo[0] > 1.0 ? mo[0] : 1.0;
+  double cs[3], ct[3];
+  for (int a = 0; a < 3; ++a) { cs[a] = mo[1 + a] / cnt; ct[a] = mo[4 + a] / cnt; }
+  double H[9];   // sum mw (s - cs)(t - ct)^T
+  for (int a = 0; a < 3; ++a)
+    for (int c = 0; c < 3; ++c)
+      H[a * 3 + c] = mo[14 + a * 3 + c] - mo[8 + a] * ct[c] - cs[a] * mo[11 + c] + mo[7] * cs[a] * ct[c];
+  double U[9], S[3], V[9];
+  svd3_jacobi(H, U, S, V);
+  double VUt[9];
+  for (int a = 0; a < 3; ++a)
+    for (int c = 0; c < 3; ++c) VUt[a * 3 + c] = V[a * 3 + 0] * U[c * 3 + 0] + V[a * 3 + 1] * U[c * 3 + 1] + V[a * 3 + 2] * U[c * 3 + 2];
+  double R[9];
+  if (det3(VUt) < 0.0) {
+    for (int a = 0; a < 3; ++a)
+      for (int c = 0; c < 3; ++c) R[a * 3 + c] = V[a * 3 + 0] * U[c * 3 + 0] + V[a * 3 + 1] * U[c * 3 + 1] - V[a * 3 + 2] * U[c * 3 + 2];
+  } else {
+    for (int k = 0; k < 9; ++k) R[k] = VUt[k];
+  }
+  // t = -R cs + ct ; return the inverse motion (R^T, -R^T t)
+  double t[3], Ri[9], ti[3];
+  for (int a = 0; a < 3; ++a) t[a] = -(R[a * 3 + 0] * cs[0] + R[a * 3 + 1] * cs[1] + R[a * 3 + 2] * cs[2]) + ct[a];
+  for (int a = 0; a < 3; ++a)
+    for (int c = 0; c < 3; ++c) Ri[a * 3 + c] = R[c * 3 + a];
+  for (int a = 0; a < 3; ++a) ti[a] = -(Ri[a * 3 + 0] * t[0] + Ri[a * 3 + 1] * t[1] + Ri[a * 3 + 2] * t[2]);
+  if (step_R)
+    for (int k = 0; k < 9; ++k) step_R[b * 9 + k] = (float)Ri[k];
+  if (step_t)
+    for (int a = 0; a < 3; ++a) step_t[b * 3 + a] = (float)ti[a];
+  // res_r = Ri res_r ; res_t = Ri res_t + ti
+  double rr[9], rt[3];
+  for (int k = 0; k < 9; ++k) rr[k] = res_r[b * 9 + k];
+  for (int a = 0; a < 3; ++a) rt[a] = res_t[b * 3 + a];
+  for (int a = 0; a < 3; ++a) {
+    for (int c = 0; c < 3; ++c)
+      res_r[b * 9 + a * 3 + c] = (float)(Ri[a * 3 + 0] * rr[0 * 3 + c] + Ri[a * 3 + 1] * rr[1 * 3 + c] + Ri[a * 3 + 2] * rr[2 * 3 + c]);
+    res_t[b * 3 + a] = (float)(Ri[a * 3 + 0] * rt[0] + Ri[a * 3 + 1] * rt[1] + Ri[a * 3 + 2] * rt[2] + ti[a]);
+  }
+}
+
+extern "C" size_t rslo_icp_ws_bytes(int B, int N) {
+  return (size_t)(B > 0 ? B : 1) * (size_t)rslo_cdiv(N > 0 ? N : 1, LS_THREADS) * ICP_NM * sizeof(double);
+}
+
+extern "C" int rslo_icp_step(const float *p1, const float *n1, const float *tgt, const int32_t *idx,
+                                      const float *dist, const float *thr, int B, int N, int M, void *ws,
+                                      size_t ws_bytes, float *res_r /*[B,9] in/out*/, float *res_t /*[B,3] in/out*/,
+                                      float *step_R /*[B,9] or NULL*/, float *step_t /*[B,3] or NULL*/, void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (B == 0) return RSLO_OK;
+  RSLO_CHECK_ARG(N >= 1 && M >= 1, "icp_step: empty clouds");
+  if (ws_bytes < rslo_icp_ws_bytes(B, N)) {
+    rslo_set_error("icp_step: workspace too small");
+    return RSLO_EWS;
+  }
+  const int nblk = (int)rslo_cdiv(N, LS_THREADS);
+  hipLaunchKernelGGL(k_icp_moments, dim3(nblk, B), dim3(LS_THREADS), 0, st, p1, n1, tgt, idx, dist, thr, N, M,
+                     (double *)ws);
+  hipLaunchKernelGGL(k_icp_solve, dim3(B), dim3(64), 0, st, (const double *)ws, nblk, res_r, res_t, step_R, step_t);
+  RSLO_CHECK_LAUNCH("icp_step");
+  return RSLO_OK;
+}
+
+// out[b][j] = R[b] x[b][j] + t[b]
+__global__ void k_transform(const float *__restrict__ x, const float *__restrict__ R, const float *__restrict__ t, int M,
+                            float *__restrict__ out) {
+  const int b = blockIdx.y;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= M) return;
+  const float *p = x + ((int64_t)b * M + j) * 3;
+  const float *r = R + b * 9;
+  float *o = out + ((int64_t)b * M + j) * 3;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) o[a] = r[a * 3 + 0] * p[0] + r[a * 3 + 1] * p[1] + r[a * 3 + 2] * p[2] + t[b * 3 + a];
+}
+
+extern "C" int rslo_transform_points(const float *x, const float *R, const float *t, int B, int M, float *out,
+                                              void *stream) {
+  if (B == 0 || M == 0) return RSLO_OK;
+  hipLaunchKernelGGL(k_transform, dim3((unsigned)rslo_cdiv(M, 256), B), dim3(256), 0, (hipStream_t)stream, x, R, t, M,
+                     out);
+  RSLO_CHECK_LAUNCH("transform_points");
+  return RSLO_OK;
+}

@@ -18,6 +18,7 @@ import torch
 from torch import nn
 
 from rslo.layers.svd import SVDHead, kabsch_rotation
+from rslo_amd import capi
 
 
 class Loss(nn.Module):
@@ -96,13 +97,37 @@ def sym3_inverse_det(S):
     return adj / det[..., None, None], det
 
 
-def points_roi(dist, penalize_ratio):
-    """dist [B,N] -> bool mask dist < max(kth(dist, 1 + int(N * ratio)), 1.0) (losses.py:326-334)."""
+def roi_threshold(dist, penalize_ratio):
+    """dist [B,N] -> [B,1] threshold max(kth(dist, 1 + int(N * ratio)), 1.0) in squared metres
+    (losses.py:326-334; the reference's `len(dist - 1)` is just N)."""
     N = dist.shape[-1]
     k = 1 + int(N * penalize_ratio)
     m, _ = torch.kthvalue(dist, min(k, N), dim=-1, keepdim=True)
-    m = torch.max(m, torch.ones_like(m))
-    return dist < m
+    return torch.max(m, torch.ones_like(m))
+
+
+def points_roi(dist, penalize_ratio):
+    return dist < roi_threshold(dist, penalize_ratio)
+
+
+class _CovResidualFn(torch.autograd.Function):
+    """Fused covariance-weighted residual (rslo_cov_residual_fwd / _bwd): per-pair loss [B]."""
+
+    @staticmethod
+    def forward(ctx, p1, tgt, cov1, cov2, idx, dist, thr, Rd, reg):
+        p1, tgt, cov1, cov2 = p1.contiguous(), tgt.contiguous(), cov1.contiguous(), cov2.contiguous()
+        Rd = Rd.contiguous()
+        loss, cnt = capi.cov_residual_fwd(p1, tgt, cov1, cov2, idx, dist, thr, Rd, reg)
+        ctx.save_for_backward(p1, tgt, cov1, cov2, idx, dist, thr, Rd, cnt)
+        ctx.reg = reg
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        p1, tgt, cov1, cov2, idx, dist, thr, Rd, cnt = ctx.saved_tensors
+        gp1, gtgt, gcov1, gcov2 = capi.cov_residual_bwd(p1, tgt, cov1, cov2, idx, dist, thr, Rd, g.contiguous(), cnt,
+                                                        ctx.reg, need_gp1=ctx.needs_input_grad[0])
+        return gp1, gtgt, gcov1, gcov2, None, None, None, None, None
 
 
 def gather_rows(x, idx):
@@ -154,6 +179,7 @@ class Aleat5_1ChamferL2NormalWeightedALLSVDLoss(Loss):
         self.pred_downsample_ratio = pred_downsample_ratio
         self.reg_weight = reg_weight
         self.sph_weight = sph_weight
+        self.use_fused = True
 
     def _points_roi(self, dist, penalize_ratio=0.95, dist_threshold=None):
         if dist_threshold is not None:
@@ -188,7 +214,36 @@ class Aleat5_1ChamferL2NormalWeightedALLSVDLoss(Loss):
 
     def pair_losses(self, xyz_pred, xyz_target, cov_pred, cov_target, R_pred, t_pred, normal_pred,
                     normal_target, icp_iter=1):
-        """Per-pair residual loss [B] and the ICP refinement (res_R [B,3,3], res_T [B,3])."""
+        """Per-pair residual loss [B] and the ICP refinement (res_R [B,3,3], res_T [B,3]).
+        GPU tensors take the fused HIP kernels; the plain-torch formulation below is the same math op by op
+        (it is what the golden vectors of the reference pin, and what the fused kernels are tested against)."""
+        if xyz_pred.is_cuda and self.use_fused:
+            return self.pair_losses_fused(xyz_pred, xyz_target, cov_pred, cov_target, R_pred, normal_pred, icp_iter)
+        return self.pair_losses_torch(xyz_pred, xyz_target, cov_pred, cov_target, R_pred, t_pred, normal_pred,
+                                      normal_target, icp_iter)
+
+    def pair_losses_fused(self, xyz_pred, xyz_target, cov_pred, cov_target, R_pred, normal_pred, icp_iter=1):
+        p1 = xyz_pred.detach().contiguous().float()
+        n1 = normal_pred.detach().contiguous().float()
+        tgt0 = xyz_target.detach().contiguous().float()
+        dist, idx = capi.chamfer_nn(p1, tgt0)
+        thr = roi_threshold(dist, self.penalize_ratio).reshape(-1).contiguous()
+        loss_b = _CovResidualFn.apply(xyz_pred, xyz_target, cov_pred, cov_target, idx, dist, thr,
+                                      R_pred.detach(), float(self.reg_weight))
+        B = p1.shape[0]
+        res_r = torch.eye(3, device=p1.device, dtype=torch.float32).repeat(B, 1, 1)
+        res_t = torch.zeros(B, 3, device=p1.device, dtype=torch.float32)
+        cur = tgt0
+        for it in range(icp_iter):
+            capi.icp_step(p1, n1, cur, idx, dist, thr, res_r, res_t)
+            if it < icp_iter - 1:
+                cur = capi.transform_points(tgt0, res_r, res_t)
+                dist, idx = capi.chamfer_nn(p1, cur)
+                thr = roi_threshold(dist, self.penalize_ratio).reshape(-1).contiguous()
+        return loss_b, res_r, res_t
+
+    def pair_losses_torch(self, xyz_pred, xyz_target, cov_pred, cov_target, R_pred, t_pred, normal_pred,
+                          normal_target, icp_iter=1):
         sig1, _ = span_cov2(cov_pred)
         sig2, _ = span_cov2(cov_target)
 

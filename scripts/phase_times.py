@@ -6,9 +6,13 @@ import rslo_amd
 from rslo_amd import workload, capi
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+if os.environ.get("BENCHMARK", "0") == "1":
+    torch.backends.cudnn.benchmark = True
 torch.manual_seed(7)
 net, _ = workload.build_network()
 net.train(); net.global_step.fill_(2000)
+if os.environ.get("CL", "0") == "1":
+    net.odom_predictor.to(memory_format=torch.channels_last)
 params = [p for p in net.parameters() if p.requires_grad]
 opt = torch.optim.Adam(params, lr=8e-5, fused=True)
 clouds = [[torch.from_numpy(c).cuda() for c in pair] for pair in workload.kitti_pairs(B)]
@@ -32,8 +36,8 @@ DETAIL = os.environ.get("DETAIL", "1") == "1"
 if DETAIL:
     for n in names: setattr(capi, n, wrap(n, orig[n]))
 
-for it in range(6):
-    if it == 2: acc.clear()
+for it in range(8):
+    if it == 4: acc.clear()
     t0 = sync()
     ex = workload.make_example(net, clouds); t1 = sync(); add("make_example(voxelize)", t1 - t0)
     opt.zero_grad(set_to_none=True)

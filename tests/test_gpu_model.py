@@ -30,6 +30,46 @@ def test_consistency_loss_gpu_matches_reference(hip, pieces):
     check_closs(pieces, closs, "cuda")
 
 
+def test_fused_loss_kernels_match_torch_formulation(hip, pieces):
+    """rslo_cov_residual_fwd/bwd + rslo_icp_step vs the op-by-op torch formulation on the same GPU inputs."""
+    from test_golden_host import run_closs
+    res = {}
+    for fused in (True, False):
+        closs = make_closs().cuda()
+        closs.use_fused = fused
+        l, rr, tt, leaves = run_closs(pieces, closs, "cuda", 2)
+        l.backward()
+        res[fused] = (l.detach(), rr, tt, [t.grad.clone() for t in leaves])
+    a, b = res[True], res[False]
+    assert float((a[0] - b[0]).abs() / b[0].abs()) < 1e-5
+    assert float((a[1] - b[1]).abs().max()) < 1e-5 and float((a[2] - b[2]).abs().max()) < 2e-5
+    for ga, gb, name in zip(a[3], b[3], ("cov1", "cov2", "q", "T")):
+        assert float((ga - gb).abs().max()) <= 1e-4 * float(gb.abs().max()) + 1e-8, name
+
+
+def test_icp_step_recovers_known_motion(hip):
+    """SVDHead known answer: a cloud and its rigidly moved copy -> the inverse motion."""
+    import kornia
+    g = torch.Generator(device="cuda").manual_seed(0)
+    N = 5000
+    p = torch.randn(2, N, 3, device="cuda", generator=g) * torch.tensor([20.0, 10.0, 2.0], device="cuda")
+    n = torch.nn.functional.normalize(torch.randn(2, N, 3, device="cuda", generator=g), dim=-1)
+    R = kornia.quaternion_to_rotation_matrix(torch.tensor([[0.01, -0.02, 0.03, 1.0], [0.0, 0.0, -0.05, 1.0]], device="cuda"))
+    t = torch.tensor([[0.7, 0.1, -0.05], [-0.4, 0.3, 0.02]], device="cuda")
+    tgt = (p @ R.transpose(1, 2) + t[:, None]).contiguous()
+    idx = torch.arange(N, dtype=torch.int32, device="cuda").repeat(2, 1).contiguous()
+    dist = torch.zeros(2, N, device="cuda")
+    thr = torch.ones(2, device="cuda")
+    res_r = torch.eye(3, device="cuda").repeat(2, 1, 1)
+    res_t = torch.zeros(2, 3, device="cuda")
+    hip.icp_step(p.contiguous(), n.contiguous(), tgt, idx, dist, thr, res_r, res_t)
+    # returns the map target -> source: R^T, -R^T t
+    assert float((res_r - R.transpose(1, 2)).abs().max()) < 1e-5
+    assert float((res_t + (R.transpose(1, 2) @ t[..., None]).squeeze(-1)).abs().max()) < 1e-4
+    moved = hip.transform_points(tgt, res_r, res_t)
+    assert float((moved - p).abs().max()) < 1e-3
+
+
 def test_bev_head_gpu_matches_reference(hip):
     head, g = load_small_head()
     check_head(head, g, "cuda")
@@ -65,6 +105,19 @@ def example_to_cpu(ex):
     return out
 
 
+def bias_before_bn(net):
+    """Names of conv biases that feed straight into a BatchNorm: their gradient is analytically zero (BN removes the
+    mean), so both sides hold pure rounding noise and cannot be compared."""
+    names = set()
+    for mname, m in net.named_modules():
+        kids = list(m.named_children())
+        for (n0, c0), (n1, c1) in zip(kids, kids[1:]):
+            if isinstance(c1, torch.nn.modules.batchnorm._BatchNorm) and getattr(c0, "bias", None) is not None \
+                    and not isinstance(c0, torch.nn.modules.batchnorm._BatchNorm):
+                names.add((mname + "." if mname else "") + n0 + ".bias")
+    return names
+
+
 def rel(a, b):
     a, b = a.detach().cpu().double(), b.detach().cpu().double()
     return float((a - b).abs().max() / (b.abs().max() + 1e-12))
@@ -93,8 +146,11 @@ def test_encoder_fwd_bwd_matches_cpu_oracle(hip):
     assert rel(bev, bev_c) < 2e-5 and rel(cov, cov_c) < 2e-5
     # weight gradients: 20 chained fp32 layers vs the oracle's double accumulation, plus LeakyReLU masks that can
     # flip for |y| ~ 1e-7 -- a few 1e-3 of the largest entry on the earliest layers
+    skip = bias_before_bn(enc)
+    assert len(skip) == 5
     for (n, p), (_, pc) in zip(enc.named_parameters(), enc_cpu.named_parameters()):
-        assert rel(p.grad, pc.grad) < 5e-3, n
+        if n not in skip:
+            assert rel(p.grad, pc.grad) < 5e-3, n
 
 
 def test_full_network_fwd_bwd_matches_cpu_oracle(hip):
@@ -102,6 +158,12 @@ def test_full_network_fwd_bwd_matches_cpu_oracle(hip):
     net, _ = workload.build_network()
     net.train()
     net.global_step.fill_(2000)
+    # A random-init head votes a garbage pose (several metres, arbitrary rotation); ICP from there is chaotic and
+    # amplifies fp32 noise.  Put the per-unit head near a plausible motion, as a trained network would be.
+    with torch.no_grad():
+        last = net.odom_predictor.tq_map_conv[6]
+        last.weight.mul_(0.01)
+        last.bias.copy_(torch.tensor([0.8, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0]))
     p0, p1, _ = reduced_pair(1)
     ex = workload.make_example(net, [[p0, p1]])
     net_cpu = clone_to_cpu(net)
@@ -117,14 +179,17 @@ def test_full_network_fwd_bwd_matches_cpu_oracle(hip):
     for k in ("loss", "translation_loss", "rotation_loss", "pyramid_loss", "C_loss"):
         assert rel(ret[k], ret_c[k]) < 2e-3, k
     checked = 0
+    skip = bias_before_bn(net)
     for (n, p), (_, pc) in zip(net.named_parameters(), net_cpu.named_parameters()):
+        if n in skip:
+            continue
         if pc.grad is None:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
             continue
         assert p.grad is not None, n
         assert rel(p.grad, pc.grad) < 2e-2, n
         checked += 1
-    assert checked >= 200   # 213 of 290 parameter tensors receive gradients
+    assert checked >= 170   # 213 of 290 parameter tensors receive gradients
 
 
 def test_eval_forward_batched_equals_per_sample(hip):
