@@ -13,6 +13,8 @@
 // slab (j,t) feeds element t of it as A[i][g], so the slab's k index g stands for input
 // channel 16j+4g+t, and the B fragment is read from LDS at that same channel.  The
 // contraction order differs from a plain loop only by a permutation of the channel sum.
+#include <stdlib.h>
+
 #include "rslo_common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -20,6 +22,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define SPC_THREADS 256
 #define SPC_WAVES 4
 #define SPC_MAXK 27
+
+// XCD-aware tile order (MI355X: 8 XCDs, block b runs on XCD b % 8, each XCD has its own 4 MB L2).  Consecutive
+// row tiles gather overlapping neighbour rows, so give every XCD one contiguous chunk of tiles: launch
+// 8 * ceil(n/8) blocks, block b works on tile (b % 8) * ceil(n/8) + b / 8 (tiles >= n are idle).  A wrong
+// guess about placement only costs speed.
+__device__ __forceinline__ int64_t xcd_tile(int64_t n_tiles) {
+  static const int NX = 8;
+  const int64_t chunk = (n_tiles + NX - 1) / NX;
+  return (int64_t)(blockIdx.x % NX) * chunk + blockIdx.x / NX;
+}
+static inline unsigned xcd_grid(int64_t n_tiles) { return (unsigned)(8 * ((n_tiles + 7) / 8)); }
 
 template <int CIN_T>
 struct AFrag {
@@ -75,7 +88,10 @@ __global__ __launch_bounds__(SPC_THREADS) void k_spconv(const float *__restrict_
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int li = lane & 15, g = lane >> 4;
-  const int64_t row0 = (int64_t)blockIdx.x * TILE;
+  const int64_t n_tiles = (n_out + TILE - 1) / TILE;
+  const int64_t tile_id = xcd_tile(n_tiles);
+  if (tile_id >= n_tiles) return;
+  const int64_t row0 = tile_id * TILE;
 
   // neighbour rows of the tile: one contiguous slab of the table
   {
@@ -155,6 +171,283 @@ __global__ __launch_bounds__(SPC_THREADS) void k_spconv(const float *__restrict_
   }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// v2: barrier-free, wave-granular variant.  A wave owns 16*RBW output rows x 16*NBW output channels and
+// walks the K offsets on its own: the tile's neighbour rows sit in a wave-private LDS slab, the A fragments
+// are gathered with 16-byte loads as above, and the B fragments (W_k[:, 16*NBW columns]) come straight from
+// global memory (the weight tensor is <= 442 KB and lives in L2/L1) -- no W staging, no __syncthreads in the
+// offset loop, no lock-step between waves; offsets are skipped per 16-row block.  The NB/NBW waves that share
+// a row tile sit in the same workgroup, so their identical gathers hit the CU's L1.
+// ---------------------------------------------------------------------------------------
+template <int CIN_T, int COUT_T, int RBW, int NBW, bool TRANS>
+__global__ __launch_bounds__(SPC_THREADS) void k_spconv_v2(const float *__restrict__ in, int cin,
+                                                           const float *__restrict__ W,
+                                                           const float *__restrict__ bias,
+                                                           const int32_t *__restrict__ nbr, int64_t n_out,
+                                                           int K, int cout, int flip_k, float slope,
+                                                           float *__restrict__ out) {
+  constexpr int NSLAB = CIN_T / 4;
+  constexpr int NB = COUT_T / 16;
+  constexpr int CG = NB / NBW;            // column groups (waves) per row tile
+  constexpr int ROWS = 16 * RBW;
+  __shared__ int32_t nbl[SPC_WAVES][ROWS * SPC_MAXK];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int64_t n_blocks = (((n_out + ROWS - 1) / ROWS) * CG + SPC_WAVES - 1) / SPC_WAVES;
+  const int64_t vb = xcd_tile(n_blocks);
+  const int64_t task = (vb < n_blocks ? vb : (int64_t)1 << 40) * SPC_WAVES + wid;
+  const int64_t tile = task / CG;
+  const int cg = (int)(task - tile * CG);
+  const int64_t row0 = tile * ROWS;
+  const bool active = row0 < n_out;
+
+  if (active) {
+    const int64_t lim = (n_out - row0) * K;
+    for (int e = lane; e < ROWS * K; e += 64) nbl[wid][e] = (e < lim) ? nbr[row0 * K + e] : -1;
+  }
+  __syncthreads();
+  if (!active) return;
+
+  f32x4 acc[RBW][NBW];
+#pragma unroll
+  for (int rb = 0; rb < RBW; ++rb)
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb) acc[rb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int k = 0; k < K; ++k) {
+    int32_t r[RBW];
+    bool on[RBW];
+    bool any = false;
+#pragma unroll
+    for (int rb = 0; rb < RBW; ++rb) {
+      r[rb] = nbl[wid][(rb * 16 + li) * K + k];
+      on[rb] = (__ballot(r[rb] >= 0) != 0ull);
+      any |= on[rb];
+    }
+    if (!any) continue;
+    const int kk = flip_k ? (K - 1 - k) : k;
+    const float *wk = W + (int64_t)kk * cin * cout;
+    float b[NSLAB][NBW];
+    if constexpr (TRANS && CIN_T >= 16) {
+      // B[ci][co] = wk[co * cin + ci]: contiguous along ci -> one float4 per (j, nb) covers slabs 4j..4j+3
+#pragma unroll
+      for (int nb = 0; nb < NBW; ++nb) {
+        const int co = (cg * NBW + nb) * 16 + li;
+#pragma unroll
+        for (int j = 0; j < CIN_T / 16; ++j) {
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (co < cout) v = *reinterpret_cast<const float4 *>(wk + (int64_t)co * cin + 16 * j + 4 * g);
+          b[4 * j + 0][nb] = v.x;
+          b[4 * j + 1][nb] = v.y;
+          b[4 * j + 2][nb] = v.z;
+          b[4 * j + 3][nb] = v.w;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < NSLAB; ++s) {
+        const int ch = slab_channel<CIN_T>(s, g);
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) {
+          const int co = (cg * NBW + nb) * 16 + li;
+          float v = 0.f;
+          if (ch < cin && co < cout) v = TRANS ? wk[(int64_t)co * cin + ch] : wk[(int64_t)ch * cout + co];
+          b[s][nb] = v;
+        }
+      }
+    }
+#pragma unroll
+    for (int rb = 0; rb < RBW; ++rb) {
+      if (!on[rb]) continue;
+      AFrag<CIN_T> a;
+      load_a<CIN_T>(in, r[rb], cin, g, a);
+#pragma unroll
+      for (int s = 0; s < NSLAB; ++s)
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb)
+          acc[rb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[s], b[s][nb], acc[rb][nb], 0, 0, 0);
+    }
+  }
+
+#pragma unroll
+  for (int rb = 0; rb < RBW; ++rb) {
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb) {
+      const int col = (cg * NBW + nb) * 16 + li;
+      if (col >= cout) continue;
+      const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t row = row0 + rb * 16 + 4 * g + j;
+        if (row < n_out) {
+          float v = acc[rb][nb][j] + bv;
+          v = v > 0.f ? v : v * slope;
+          out[row * cout + col] = v;
+        }
+      }
+    }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------
+// v3: the production kernel for channel counts that are multiples of 16.
+//   * wave-granular: a wave owns 16*RBW output rows x all COUT_T channels and walks ONLY its active kernel
+//     offsets (a 27-bit mask built once from the wave-private LDS copy of its neighbour rows), so the offset
+//     loop has no data-dependent branch around the MFMAs and the accumulators stay in AGPRs;
+//   * every operand load is 16 bytes: A rows by plain float4 gathers (lanes without a neighbour read row 0 and
+//     zero the fragment; the b128 buffer-load builtin with its free bounds check mis-selects to a dword load on
+//     this toolchain), B straight from the L2-resident weight tensor using two index
+//     permutations: K-slab (j,t) <-> input channel 16j+4g+t, and column li of block nb <-> output channel
+//     NB*li+nb, which makes both the forward (contiguous along Cout) and the transposed (contiguous along
+//     Cin) weight reads float4 and turns the epilogue into one 16-byte store per lane and row;
+//   * MFMA order is slab-major so consecutive MFMAs hit different accumulators (16x16x4 f32 needs >= 2).
+// ---------------------------------------------------------------------------------------
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <int N>
+struct VecF {
+  float v[N];
+};
+
+template <int NB>
+__device__ __forceinline__ VecF<NB> load_vec(const float *p) {
+  VecF<NB> r;
+  if constexpr (NB == 4) {
+    const float4 t = *reinterpret_cast<const float4 *>(p);
+    r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
+  } else if constexpr (NB == 2) {
+    const float2 t = *reinterpret_cast<const float2 *>(p);
+    r.v[0] = t.x; r.v[1] = t.y;
+  } else {
+    r.v[0] = *p;
+  }
+  return r;
+}
+
+template <int CIN_T, int COUT_T, int RBW, bool TRANS>
+__global__ __launch_bounds__(SPC_THREADS) void k_spconv_v3(const float *__restrict__ in,
+                                                           const float *__restrict__ W,
+                                                           const float *__restrict__ bias,
+                                                           const int32_t *__restrict__ nbr, int64_t n_out,
+                                                           int K, int flip_k, float slope,
+                                                           float *__restrict__ out) {
+  constexpr int NJ = CIN_T / 16;
+  constexpr int NB = COUT_T / 16;
+  constexpr int ROWS = 16 * RBW;
+  __shared__ int32_t nbl[SPC_WAVES][ROWS * SPC_MAXK];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int64_t n_tiles = (n_out + ROWS - 1) / ROWS;
+  const int64_t n_blocks = (n_tiles + SPC_WAVES - 1) / SPC_WAVES;
+  const int64_t vb = xcd_tile(n_blocks);
+  const int64_t tile = vb * SPC_WAVES + wid;
+  const bool active = vb < n_blocks && tile < n_tiles;
+  const int64_t row0 = tile * ROWS;
+
+  if (active) {
+    const int64_t lim = (n_out - row0) * K;
+    for (int e = lane; e < ROWS * K; e += 64) nbl[wid][e] = (e < lim) ? nbr[row0 * K + e] : -1;
+  }
+  __syncthreads();
+  if (!active) return;
+
+  // active-offset mask of this wave
+  unsigned mask = 0;
+  for (int k = 0; k < K; ++k) {
+    bool any = false;
+#pragma unroll
+    for (int rb = 0; rb < RBW; ++rb) any |= nbl[wid][(rb * 16 + li) * K + k] >= 0;
+    if (__ballot(any) != 0ull) mask |= 1u << k;
+  }
+  mask = __builtin_amdgcn_readfirstlane(mask);
+
+  f32x4 acc[RBW][NB];
+#pragma unroll
+  for (int rb = 0; rb < RBW; ++rb)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[rb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  while (mask) {
+    const int k = __builtin_ctz(mask);
+    mask &= mask - 1;
+    const int kk = flip_k ? (K - 1 - k) : k;
+    const float *wk = W + (int64_t)kk * CIN_T * COUT_T;
+    const float *ap[RBW];
+    bool ok[RBW];
+#pragma unroll
+    for (int rb = 0; rb < RBW; ++rb) {
+      const int32_t r = nbl[wid][(rb * 16 + li) * K + k];
+      ok[rb] = r >= 0;                      // "no neighbour": read row 0 and zero the fragment
+      ap[rb] = in + (int64_t)(ok[rb] ? r : 0) * CIN_T + 4 * g;
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      // A: channels 16j+4g .. +3 of the neighbour rows
+      float a[RBW][4];
+#pragma unroll
+      for (int rb = 0; rb < RBW; ++rb) {
+        const float4 t = *reinterpret_cast<const float4 *>(ap[rb] + 16 * j);
+        a[rb][0] = ok[rb] ? t.x : 0.f;
+        a[rb][1] = ok[rb] ? t.y : 0.f;
+        a[rb][2] = ok[rb] ? t.z : 0.f;
+        a[rb][3] = ok[rb] ? t.w : 0.f;
+      }
+      // B[slab t][nb]: input channel 16j+4g+t, output channel NB*li+nb
+      float b[4][NB];
+      if constexpr (TRANS) {   // wk[co * CIN_T + ci]: float4 along ci (= along t)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          const float4 v = *reinterpret_cast<const float4 *>(wk + (NB * li + nb) * CIN_T + 16 * j + 4 * g);
+          b[0][nb] = v.x; b[1][nb] = v.y; b[2][nb] = v.z; b[3][nb] = v.w;
+        }
+      } else {                 // wk[ci * COUT_T + co]: NB contiguous floats along co (= along nb)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const VecF<NB> v = load_vec<NB>(wk + (16 * j + 4 * g + t) * COUT_T + NB * li);
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) b[t][nb] = v.v[nb];
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int rb = 0; rb < RBW; ++rb)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+            acc[rb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rb][t], b[t][nb], acc[rb][nb], 0, 0, 0);
+    }
+  }
+
+  // epilogue: lane (g, li) holds rows 4g+j, output channels NB*li .. NB*li+NB-1
+  VecF<NB> bv;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) bv.v[nb] = bias ? bias[NB * li + nb] : 0.f;
+#pragma unroll
+  for (int rb = 0; rb < RBW; ++rb)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t row = row0 + rb * 16 + 4 * g + j;
+      if (row >= n_out) continue;
+      float o[NB];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        float v = acc[rb][nb][j] + bv.v[nb];
+        o[nb] = v > 0.f ? v : v * slope;
+      }
+      float *dst = out + row * COUT_T + NB * li;
+      if constexpr (NB == 4)
+        *reinterpret_cast<float4 *>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+      else if constexpr (NB == 2)
+        *reinterpret_cast<float2 *>(dst) = make_float2(o[0], o[1]);
+      else
+        dst[0] = o[0];
+    }
+}
+
 static int pad_cin(int c) { return c <= 8 ? 8 : (c <= 16 ? 16 : (c <= 32 ? 32 : 64)); }
 static int pad_cout(int c) { return c <= 16 ? 16 : (c <= 32 ? 32 : 64); }
 
@@ -168,16 +461,69 @@ static int launch_spconv(const float *in, int cin, const float *W, const float *
   if (n_out == 0) return RSLO_OK;
   const int ci = pad_cin(cin), co = pad_cout(cout);
   RSLO_CHECK_ARG(ci == 8 || ci == cin, "spconv: cin must be <=8, 16, 32 or 64");
+  static const int variant = getenv("RSLO_SPCONV_V") ? atoi(getenv("RSLO_SPCONV_V")) : 0;
+  if ((variant == 0 || variant >= 100) && ci == cin && co == cout && cin % 16 == 0 && cout % 16 == 0) {
+    // v3 (variant 100 + RBW forces the row blocking; default: 2 row blocks when the launch still fills the chip)
+    int rbw = variant >= 100 ? variant - 100 : ((n_out >= 256 * 32 * 8) ? 2 : 1);
+#define SPC3_CASE(CI, CO)                                                                                  \
+    if (ci == CI && co == CO) {                                                                            \
+      if (rbw == 2)                                                                                        \
+        hipLaunchKernelGGL((k_spconv_v3<CI, CO, 2, TRANS>), dim3(xcd_grid(rslo_cdiv(rslo_cdiv(n_out, 32), 4))), \
+                           dim3(SPC_THREADS), 0, st, in, W, bias, nbr, n_out, K, flip_k, slope, out);      \
+      else                                                                                                 \
+        hipLaunchKernelGGL((k_spconv_v3<CI, CO, 1, TRANS>), dim3(xcd_grid(rslo_cdiv(rslo_cdiv(n_out, 16), 4))), \
+                           dim3(SPC_THREADS), 0, st, in, W, bias, nbr, n_out, K, flip_k, slope, out);      \
+    }
+    SPC3_CASE(16, 16) SPC3_CASE(16, 32) SPC3_CASE(16, 64)
+    SPC3_CASE(32, 16) SPC3_CASE(32, 32) SPC3_CASE(32, 64)
+    SPC3_CASE(64, 16) SPC3_CASE(64, 32) SPC3_CASE(64, 64)
+#undef SPC3_CASE
+    RSLO_CHECK_LAUNCH("spconv_v3");
+    return RSLO_OK;
+  }
+  if (variant >= 1 && variant < 100) {
+    // v2: variant digits = RBW*10 + NBW (e.g. 41 = 4 row blocks x 1 col block per wave)
+    const int rbw = variant / 10, nbw = variant % 10;
+#define SPC2_LAUNCH(CI, CO, RBW, NBW)                                                                     \
+    {                                                                                                   \
+      constexpr int CG = (CO / 16) / NBW;                                                               \
+      const int64_t tasks = rslo_cdiv(n_out, 16 * RBW) * CG;                                            \
+      hipLaunchKernelGGL((k_spconv_v2<CI, CO, RBW, NBW, TRANS>), dim3(xcd_grid(rslo_cdiv(tasks, 4))),   \
+                         dim3(SPC_THREADS), 0, st, in, cin, W, bias, nbr, n_out, K, cout, flip_k, slope, \
+                         out);                                                                          \
+    }
+#define SPC2_CASE(CI, CO)                                                                               \
+    if (ci == CI && co == CO) {                                                                         \
+      constexpr int NBALL = CO / 16;                                                                    \
+      const int nb_eff = nbw > NBALL ? NBALL : nbw;                                                     \
+      if (rbw == 4 && nb_eff == 1) SPC2_LAUNCH(CI, CO, 4, 1)                                            \
+      else if (rbw == 2 && nb_eff == 1) SPC2_LAUNCH(CI, CO, 2, 1)                                       \
+      else if (rbw == 2 && nb_eff == 2) SPC2_LAUNCH(CI, CO, 2, (NBALL >= 2 ? 2 : 1))                    \
+      else if (rbw == 4 && nb_eff == 2) SPC2_LAUNCH(CI, CO, 4, (NBALL >= 2 ? 2 : 1))                    \
+      else if (rbw == 1 && nb_eff == 2) SPC2_LAUNCH(CI, CO, 1, (NBALL >= 2 ? 2 : 1))                    \
+      else if (rbw == 1 && nb_eff >= 4) SPC2_LAUNCH(CI, CO, 1, NBALL)                                   \
+      else if (rbw == 2 && nb_eff >= 4) SPC2_LAUNCH(CI, CO, 2, NBALL)                                   \
+      else SPC2_LAUNCH(CI, CO, 1, 1)                                                                    \
+    }
+    SPC2_CASE(8, 16) SPC2_CASE(8, 32) SPC2_CASE(8, 64)
+    SPC2_CASE(16, 16) SPC2_CASE(16, 32) SPC2_CASE(16, 64)
+    SPC2_CASE(32, 16) SPC2_CASE(32, 32) SPC2_CASE(32, 64)
+    SPC2_CASE(64, 16) SPC2_CASE(64, 32) SPC2_CASE(64, 64)
+#undef SPC2_CASE
+#undef SPC2_LAUNCH
+    RSLO_CHECK_LAUNCH("spconv_v2");
+    return RSLO_OK;
+  }
   // one 16-row block per wave while the launch would not fill the chip, two otherwise
   const bool rb2 = (n_out >= 256 * 128 * 2) && co >= 32;
 #define SPC_CASE(CI, CO)                                                                             \
   if (ci == CI && co == CO) {                                                                        \
     if (rb2)                                                                                         \
-      hipLaunchKernelGGL((k_spconv<CI, CO, 2, TRANS>), dim3((unsigned)rslo_cdiv(n_out, 128)),        \
+      hipLaunchKernelGGL((k_spconv<CI, CO, 2, TRANS>), dim3(xcd_grid(rslo_cdiv(n_out, 128))),        \
                          dim3(SPC_THREADS), 0, st, in, cin, W, bias, nbr, n_out, K, cout, flip_k,    \
                          slope, out);                                                                \
     else                                                                                             \
-      hipLaunchKernelGGL((k_spconv<CI, CO, 1, TRANS>), dim3((unsigned)rslo_cdiv(n_out, 64)),         \
+      hipLaunchKernelGGL((k_spconv<CI, CO, 1, TRANS>), dim3(xcd_grid(rslo_cdiv(n_out, 64))),         \
                          dim3(SPC_THREADS), 0, st, in, cin, W, bias, nbr, n_out, K, cout, flip_k,    \
                          slope, out);                                                                \
   }
