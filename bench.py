@@ -28,6 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E ~8 TB/s (MI355X_MICROARCH.md)
+MFMA_F32_PEAK_TF = 157.3   # dense fp32-input MFMA peak = the fp32 vector peak (MI355X_MICROARCH.md)
 
 
 def parse():
@@ -59,10 +60,14 @@ class ConvProbe:
 
     @staticmethod
     def kernel_name(cin_op, cout_op, n_out, trans):
+        """The template instantiation rslo_spconv_fwd/dgrad dispatches to (rslo_amd/csrc/spconv.hip)."""
+        t = "true" if trans else "false"
+        if cin_op % 16 == 0 and cout_op % 16 == 0:
+            return "k_spconv_v3<%d, %d, %d, %s>" % (cin_op, cout_op, 2 if n_out >= 256 * 32 * 8 else 1, t)
         ci = 8 if cin_op <= 8 else (16 if cin_op <= 16 else (32 if cin_op <= 32 else 64))
         co = 16 if cout_op <= 16 else (32 if cout_op <= 32 else 64)
         rb = 2 if (n_out >= 256 * 128 * 2 and co >= 32) else 1
-        return "k_spconv<%d, %d, %d, %s>" % (ci, co, rb, "true" if trans else "false")
+        return "k_spconv<%d, %d, %d, %s>" % (ci, co, rb, t)
 
     def install(self):
         capi = self.capi
@@ -123,11 +128,19 @@ class ConvProbe:
             g["TFLOPs"] = g["flops"] / (g["ms"] * 1e-3) / 1e12
         name = max(groups, key=lambda n: groups[n]["ms"])
         g = groups[name]
-        roof = {"bound": "hbm", "kernel": name, "achieved": round(g["GBps"], 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(g["GBps"] / HBM_PEAK_GBS, 4), "traffic": None,
-                "avg_launch_us": round(g["avg_us"], 2), "launches_per_step": g["launches"] // max(steps, 1),
-                "algorithmic_bytes_per_launch": int(g["bytes"] // g["launches"]),
-                "tflops": round(g["TFLOPs"], 2)}
+        # which roof bounds it: arithmetic intensity vs the fp32 ridge (157.3 TF / 8 TB/s = 19.7 flop/B)
+        ai = g["flops"] / g["bytes"]
+        if ai >= MFMA_F32_PEAK_TF * 1e3 / HBM_PEAK_GBS:
+            roof = {"bound": "mfma", "kernel": name, "achieved": round(g["TFLOPs"], 2), "peak": MFMA_F32_PEAK_TF,
+                    "unit": "TFLOP/s", "frac": round(g["TFLOPs"] / MFMA_F32_PEAK_TF, 4), "traffic": None}
+        else:
+            roof = {"bound": "hbm", "kernel": name, "achieved": round(g["GBps"], 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(g["GBps"] / HBM_PEAK_GBS, 4), "traffic": None}
+        roof.update({"arithmetic_intensity_flop_per_byte": round(ai, 2), "algorithmic_GBps": round(g["GBps"], 1),
+                     "hbm_frac": round(g["GBps"] / HBM_PEAK_GBS, 4), "algorithmic_TFLOPs": round(g["TFLOPs"], 2),
+                     "avg_launch_us": round(g["avg_us"], 2), "launches_per_step": g["launches"] // max(steps, 1),
+                     "algorithmic_bytes_per_launch": int(g["bytes"] // g["launches"]),
+                     "algorithmic_flops_per_launch": int(g["flops"] // g["launches"])})
         tot_ms = sum(x["ms"] for x in groups.values())
         tot_b = sum(x["bytes"] for x in groups.values())
         roof["all_spconv_fwd_dgrad"] = {"ms_per_step": round(tot_ms / max(steps, 1), 3),

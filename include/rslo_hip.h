@@ -122,6 +122,19 @@ RSLO_API size_t rslo_spconv_wgrad_ws_bytes(int64_t n_out, int K, int cin, int co
 RSLO_API int rslo_spconv_wgrad(const float *in, int cin, const float *dout, int cout, const int32_t *nbr,
                       int64_t n_out, int K, void *ws, size_t ws_bytes, float *dW /*[K,cin,cout]*/,
                       float *dbias /*[cout] or NULL*/, void *stream);
+/* Pair-list view of a neighbour table (the spconv-1.x rulebook layout): pairs of offset k are contiguous in
+ * [koff[k], koff[k+1]) in ascending output row; pairs_in/out need room for n_rows*K entries (upper bound),
+ * koff [K+1] lives on the device.  Built once per indice_key; feeds the weight-gradient kernel. */
+RSLO_API size_t rslo_rulebook_pairs_ws_bytes(int64_t n_rows, int K);
+RSLO_API int rslo_rulebook_pairs(const int32_t *nbr, int64_t n_rows, int K, void *ws, size_t ws_bytes,
+                        int32_t *pairs_in, int32_t *pairs_out, int32_t *koff /*[K+1]*/, void *stream);
+/* wgrad over pair lists: dW[k] = sum_{p in [koff[k],koff[k+1])} in[pairs_in[p]]^T dout[pairs_out[p]];
+ * dbias = column sums of dout (all n_out rows).  Deterministic (fixed-order two-stage reduction). */
+RSLO_API size_t rslo_spconv_wgrad_pairs_ws_bytes(int64_t n_out, int K, int cin, int cout);
+RSLO_API int rslo_spconv_wgrad_pairs(const float *in, int cin, const float *dout, int cout, const int32_t *pairs_in,
+                            const int32_t *pairs_out, const int32_t *koff, int64_t n_out, int K, void *ws,
+                            size_t ws_bytes, float *dW /*[K,cin,cout]*/, float *dbias /*[cout] or NULL*/,
+                            void *stream);
 /* LeakyReLU backward from the saved OUTPUT (sign-preserving): g = dout * (y > 0 ? 1 : slope). */
 RSLO_API int rslo_leaky_bwd(const float *y, const float *dout, int64_t n, float slope, float *g, void *stream);
 

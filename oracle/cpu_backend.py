@@ -76,6 +76,31 @@ def spconv_wgrad(x, dout, nbr, cin, cout, with_bias=True):
     return torch.from_numpy(dW), (torch.from_numpy(db) if with_bias else None)
 
 
+def rulebook_pairs(nbr):
+    t = _np(nbr)
+    n, K = t.shape
+    pin, pout, koff = [], [], [0]
+    for k in range(K):
+        rows = np.nonzero(t[:, k] >= 0)[0]
+        pin.append(t[rows, k])
+        pout.append(rows.astype(np.int32))
+        koff.append(koff[-1] + len(rows))
+    return (torch.from_numpy(np.concatenate(pin).astype(np.int32)), torch.from_numpy(np.concatenate(pout).astype(np.int32)),
+            torch.tensor(koff, dtype=torch.int32))
+
+
+def spconv_wgrad_pairs(x, dout, pairs, n_out, K, cin, cout, with_bias=True):
+    pin, pout, koff = (_np(p) for p in pairs)
+    xd, gd = _np(x).astype(np.float64), _np(dout).astype(np.float64)
+    dW = np.zeros((K, cin, cout), np.float64)
+    for k in range(K):
+        a, b = int(koff[k]), int(koff[k + 1])
+        if b > a:
+            dW[k] = xd[pin[a:b]].T @ gd[pout[a:b]]
+    db = torch.from_numpy(gd.sum(0).astype(np.float32)) if with_bias else None
+    return torch.from_numpy(dW.astype(np.float32)), db
+
+
 def leaky_bwd(y, dout, slope):
     return torch.where(y > 0, dout, dout * slope)
 
@@ -110,7 +135,7 @@ def chamfer_grad(xyz1, xyz2, graddist1, idx1, g1=None, g2=None):
 
 
 _NAMES = ["SiteIndex", "voxelize", "vfe_mean", "rulebook_subm", "conv_out_dims", "rulebook_conv", "spconv_fwd",
-          "spconv_dgrad", "spconv_wgrad", "leaky_bwd", "dense_scatter", "dense_gather", "chamfer_nn", "chamfer_grad"]
+          "spconv_dgrad", "spconv_wgrad", "rulebook_pairs", "spconv_wgrad_pairs", "leaky_bwd", "dense_scatter", "dense_gather", "chamfer_nn", "chamfer_grad"]
 
 
 @contextlib.contextmanager

@@ -38,6 +38,10 @@ SIGNATURES = {
     "rslo_spconv_dgrad": (C.c_int, [_vp, _i, _vp, _vp, _i64, _i, _i, _i, _vp, _vp]),
     "rslo_spconv_wgrad_ws_bytes": (_sz, [_i64, _i, _i, _i]),
     "rslo_spconv_wgrad": (C.c_int, [_vp, _i, _vp, _i, _vp, _i64, _i, _vp, _sz, _vp, _vp, _vp]),
+    "rslo_rulebook_pairs_ws_bytes": (_sz, [_i64, _i]),
+    "rslo_rulebook_pairs": (C.c_int, [_vp, _i64, _i, _vp, _sz, _vp, _vp, _vp, _vp]),
+    "rslo_spconv_wgrad_pairs_ws_bytes": (_sz, [_i64, _i, _i, _i]),
+    "rslo_spconv_wgrad_pairs": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i64, _i, _vp, _sz, _vp, _vp, _vp]),
     "rslo_leaky_bwd": (C.c_int, [_vp, _vp, _i64, _f, _vp, _vp]),
     "rslo_dense_scatter": (C.c_int, [_vp, _vp, _i64, _i, _i, _vp, _vp, _vp]),
     "rslo_dense_gather": (C.c_int, [_vp, _vp, _i64, _i, _i, _vp, _vp, _vp]),
@@ -237,6 +241,36 @@ def spconv_wgrad(x, dout, nbr, cin, cout, with_bias=True):
     _chk(lib().rslo_spconv_wgrad(_ptr(x, torch.float32, "x"), cin, _ptr(dout, torch.float32, "dout"), cout,
                                  _ptr(nbr, torch.int32, "nbr"), n_out, K, _ptr(ws), wsb, _ptr(dW), _ptr(db),
                                  _stream()), "rslo_spconv_wgrad")
+    return dW, db
+
+
+def rulebook_pairs(nbr):
+    """nbr [rows,K] -> (pairs_in [rows*K cap], pairs_out [rows*K cap], koff [K+1] on device)."""
+    n, K = nbr.shape
+    dev = nbr.device
+    cap = max(n * K, 1)
+    pin = torch.empty((cap,), dtype=torch.int32, device=dev)
+    pout = torch.empty((cap,), dtype=torch.int32, device=dev)
+    koff = torch.empty((K + 1,), dtype=torch.int32, device=dev)
+    wsb = lib().rslo_rulebook_pairs_ws_bytes(n, K)
+    ws = _ws(wsb, dev)
+    _chk(lib().rslo_rulebook_pairs(_ptr(nbr, torch.int32, "nbr"), n, K, _ptr(ws), wsb, _ptr(pin), _ptr(pout),
+                                   _ptr(koff), _stream()), "rslo_rulebook_pairs")
+    return pin, pout, koff
+
+
+def spconv_wgrad_pairs(x, dout, pairs, n_out, K, cin, cout, with_bias=True):
+    """pairs = (pairs_in, pairs_out, koff) over rows of x (in) and dout (out)."""
+    pin, pout, koff = pairs
+    dev = x.device
+    dW = torch.empty((K, cin, cout), dtype=torch.float32, device=dev)
+    db = torch.empty((cout,), dtype=torch.float32, device=dev) if with_bias else None
+    wsb = lib().rslo_spconv_wgrad_pairs_ws_bytes(n_out, K, cin, cout)
+    ws = _ws(wsb, dev)
+    _chk(lib().rslo_spconv_wgrad_pairs(_ptr(x, torch.float32, "x"), cin, _ptr(dout, torch.float32, "dout"), cout,
+                                       _ptr(pin, torch.int32, "pairs_in"), _ptr(pout, torch.int32, "pairs_out"),
+                                       _ptr(koff, torch.int32, "koff"), n_out, K, _ptr(ws), wsb, _ptr(dW), _ptr(db),
+                                       _stream()), "rslo_spconv_wgrad_pairs")
     return dW, db
 
 

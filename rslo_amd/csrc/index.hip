@@ -622,3 +622,59 @@ extern "C" int rslo_dense_gather(const float *dense, const int32_t *coords, int6
   RSLO_CHECK_LAUNCH("dense_gather");
   return RSLO_OK;
 }
+
+// ---------------------------------------------------------------------------------------
+// neighbour table -> spconv-style pair lists (for the weight-gradient kernels)
+// ---------------------------------------------------------------------------------------
+__global__ void k_pair_flags(const int32_t *__restrict__ nbr, int64_t N, int K, uint32_t *__restrict__ flags) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= N * K) return;
+  const int64_t o = t / K;
+  const int k = (int)(t - o * K);
+  flags[(int64_t)k * N + o] = nbr[t] >= 0 ? 1u : 0u;
+}
+
+__global__ void k_pair_emit(const int32_t *__restrict__ nbr, const int32_t *__restrict__ pos, int64_t N, int K,
+                            int32_t total_unused, int32_t *__restrict__ pin, int32_t *__restrict__ pout,
+                            int32_t *__restrict__ koff, const int32_t *__restrict__ d_total) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= N * K) return;
+  const int64_t o = t / K;
+  const int k = (int)(t - o * K);
+  const int64_t f = (int64_t)k * N + o;
+  if (o == 0) koff[k] = pos[f];
+  if (t == 0) koff[K] = *d_total;
+  const int32_t r = nbr[t];
+  if (r >= 0) {
+    const int32_t p = pos[f];
+    pin[p] = r;
+    pout[p] = (int32_t)o;
+  }
+}
+
+extern "C" int rslo_rulebook_pairs(const int32_t *nbr, int64_t n_rows, int K, void *ws, size_t ws_bytes,
+                                   int32_t *pairs_in, int32_t *pairs_out, int32_t *koff, void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (n_rows == 0) {
+    RSLO_HIP(hipMemsetAsync(koff, 0, (size_t)(K + 1) * sizeof(int32_t), st));
+    return RSLO_OK;
+  }
+  const int64_t n = n_rows * K;
+  RSLO_CHECK_ARG(n < (int64_t)2000000000, "rulebook_pairs: table too large");
+  const size_t need = (size_t)n * 8 + rslo_scan_ws_bytes(n) + 512;
+  if (ws_bytes < need) {
+    rslo_set_error("rulebook_pairs: workspace too small");
+    return RSLO_EWS;
+  }
+  uint32_t *flags = (uint32_t *)ws;
+  int32_t *pos = (int32_t *)ws + n;
+  int32_t *d_total = (int32_t *)((char *)ws + (size_t)n * 8);
+  void *sws = (char *)ws + (size_t)n * 8 + 256;
+  const unsigned nb = (unsigned)rslo_cdiv(n, 256);
+  hipLaunchKernelGGL(k_pair_flags, dim3(nb), dim3(256), 0, st, nbr, n_rows, K, flags);
+  if (int rc = scan_exclusive<false>(flags, pos, n, sws, ws_bytes - (size_t)n * 8 - 256, d_total, st)) return rc;
+  hipLaunchKernelGGL(k_pair_emit, dim3(nb), dim3(256), 0, st, nbr, pos, n_rows, K, 0, pairs_in, pairs_out, koff,
+                     d_total);
+  RSLO_CHECK_LAUNCH("rulebook_pairs");
+  return RSLO_OK;
+}

@@ -715,6 +715,212 @@ extern "C" int rslo_spconv_wgrad(const float *in, int cin, const float *dout, in
   return RSLO_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------
+// wgrad v2 on explicit pair lists.  rslo_rulebook_pairs() turns a neighbour table into the spconv-style
+// rulebook once per indice_key (pairs of offset k contiguous, ascending output row; koff[K+1] on the device),
+// so the gradient kernels do no compaction.  Grid (pair chunk, offset): the 4 waves of a workgroup split a
+// chunk of WG2_CHUNK pairs; lane (li, g) loads CB contiguous input channels of pair g and NB contiguous output
+// channels (16-byte loads for 64 channels, the same column-permutation trick as the forward kernel) and
+// v_mfma_f32_16x16x4_f32 accumulates dW[ci = CB*i + cb][co = NB*li + nb] with the pair index as the
+// contraction dimension.  Wave partials are summed through LDS in a fixed order, chunk partials by a second
+// kernel in chunk order: deterministic, no atomics.
+// ---------------------------------------------------------------------------------------
+#define WG2_CHUNK 2048
+
+template <int CIN_T, int COUT_T, bool EXACT>
+__global__ __launch_bounds__(SPC_THREADS) void k_wgrad2(const float *__restrict__ in, int cin,
+                                                        const float *__restrict__ dout, int cout,
+                                                        const int32_t *__restrict__ pin,
+                                                        const int32_t *__restrict__ pout,
+                                                        const int32_t *__restrict__ koff, int K,
+                                                        float *__restrict__ ws) {
+  constexpr int CB = CIN_T / 16, NB = COUT_T / 16;
+  __shared__ __attribute__((aligned(16))) float red[CIN_T * COUT_T];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int k = blockIdx.y;
+  const int pk0 = koff[k], pk1 = koff[k + 1];
+  const int p0 = pk0 + (int)blockIdx.x * WG2_CHUNK;
+  if (p0 >= pk1) return;
+  const int p1 = (p0 + WG2_CHUNK < pk1) ? p0 + WG2_CHUNK : pk1;
+
+  f32x4 acc[CB][NB];
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[cb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int w0 = p0 + wid * (WG2_CHUNK / SPC_WAVES);
+  const int w1 = (w0 + WG2_CHUNK / SPC_WAVES < p1) ? w0 + WG2_CHUNK / SPC_WAVES : p1;
+  constexpr int UN = (CB * NB >= 8) ? 4 : 8;     // pair groups whose gathers are in flight together
+  for (int q = w0; q < w1; q += 64) {
+    // one coalesced index load per lane for 64 pairs, handed to the (li, g) fragment lanes by cross-lane reads
+    const int myp = q + lane;
+    const int32_t my_i = (myp < w1) ? pin[myp] : -1;
+    const int32_t my_o = (myp < w1) ? pout[myp] : 0;
+#pragma unroll
+    for (int h = 0; h < 16 / UN; ++h) {
+      if (q + h * UN * 4 >= w1) break;
+      float a[UN][CB], b[UN][NB];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int src = (h * UN + u) * 4 + g;
+        const int32_t ri = __shfl(my_i, src, 64);
+        const int32_t ro = __shfl(my_o, src, 64);
+        const bool ok = ri >= 0;
+        if constexpr (EXACT) {
+          const VecF<CB> va = load_vec<CB>(in + (int64_t)(ok ? ri : 0) * CIN_T + CB * li);
+          const VecF<NB> vb = load_vec<NB>(dout + (int64_t)ro * COUT_T + NB * li);
+#pragma unroll
+          for (int cb = 0; cb < CB; ++cb) a[u][cb] = ok ? va.v[cb] : 0.f;
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) b[u][nb] = vb.v[nb];
+        } else {
+#pragma unroll
+          for (int cb = 0; cb < CB; ++cb) {
+            const int c = CB * li + cb;
+            a[u][cb] = (ok && c < cin) ? in[(int64_t)ri * cin + c] : 0.f;
+          }
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) {
+            const int c = NB * li + nb;
+            b[u][nb] = (c < cout) ? dout[(int64_t)ro * cout + c] : 0.f;
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u)
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+            acc[cb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][cb], b[u][nb], acc[cb][nb], 0, 0, 0);
+    }
+  }
+
+  for (int w = 0; w < SPC_WAVES; ++w) {
+    if (wid == w) {
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int ci = CB * (4 * g + j) + cb, co = NB * li + nb;
+            float v = acc[cb][nb][j];
+            if (w) v += red[ci * COUT_T + co];
+            red[ci * COUT_T + co] = v;
+          }
+    }
+    __syncthreads();
+  }
+  float *dst = ws + ((int64_t)blockIdx.x * K + k) * cin * cout;
+  for (int e = tid; e < cin * cout; e += SPC_THREADS) {
+    const int ci = e / cout, co = e - ci * cout;
+    dst[e] = red[ci * COUT_T + co];
+  }
+}
+
+__global__ void k_wgrad2_reduce(const float *__restrict__ ws, const int32_t *__restrict__ koff, int K, int cc,
+                                float *__restrict__ dW) {
+  const int k = blockIdx.y;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= cc) return;
+  const int n = koff[k + 1] - koff[k];
+  const int nch = (n + WG2_CHUNK - 1) / WG2_CHUNK;
+  float s = 0.f;
+  for (int c = 0; c < nch; ++c) s += ws[((int64_t)c * K + k) * cc + e];
+  dW[(int64_t)k * cc + e] = s;
+}
+
+// column sums of x [rows, cols] -> partial[block][cols]; one block per CS_ROWS rows, consecutive threads read
+// consecutive floats (whole rows), 256 / cols_pad row-parts per block reduced through LDS in a fixed order
+#define CS_ROWS 512
+__global__ __launch_bounds__(256) void k_colsum_partial(const float *__restrict__ x, int64_t rows, int cols,
+                                                        int cols_pad, float *__restrict__ partial) {
+  __shared__ float red[256];
+  const int c = threadIdx.x % cols_pad, part = threadIdx.x / cols_pad, nparts = 256 / cols_pad;
+  const int64_t r0 = (int64_t)blockIdx.x * CS_ROWS, r1 = (r0 + CS_ROWS < rows) ? r0 + CS_ROWS : rows;
+  float s = 0.f;
+  if (c < cols)
+    for (int64_t r = r0 + part; r < r1; r += nparts) s += x[r * cols + c];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (part == 0 && c < cols) {
+    float t = 0.f;
+    for (int p = 0; p < nparts; ++p) t += red[p * cols_pad + c];
+    partial[(int64_t)blockIdx.x * cols + c] = t;
+  }
+}
+
+extern "C" size_t rslo_rulebook_pairs_ws_bytes(int64_t n_rows, int K) {
+  const int64_t n = (n_rows > 0 ? n_rows : 1) * K;
+  return (size_t)n * 8 + rslo_scan_ws_bytes(n) + 512;
+}
+
+extern "C" size_t rslo_spconv_wgrad_pairs_ws_bytes(int64_t n_out, int K, int cin, int cout) {
+  const int64_t nch = rslo_cdiv(n_out > 0 ? n_out : 1, WG2_CHUNK);
+  const int64_t ncs = rslo_cdiv(n_out > 0 ? n_out : 1, CS_ROWS);
+  return ((size_t)nch * (size_t)K * cin * cout + (size_t)(ncs + ncs / CS_ROWS + 8) * cout) * sizeof(float);
+}
+
+extern "C" int rslo_spconv_wgrad_pairs(const float *in, int cin, const float *dout, int cout,
+                                       const int32_t *pairs_in, const int32_t *pairs_out, const int32_t *koff,
+                                       int64_t n_out, int K, void *ws, size_t ws_bytes, float *dW, float *dbias,
+                                       void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  RSLO_CHECK_ARG(cin >= 1 && cin <= 64 && cout >= 1 && cout <= 64, "wgrad: channels must be in 1..64");
+  RSLO_CHECK_ARG(K >= 1 && K <= SPC_MAXK, "wgrad: K must be in 1..27");
+  const int64_t nW = (int64_t)K * cin * cout;
+  if (n_out == 0) {
+    RSLO_HIP(hipMemsetAsync(dW, 0, nW * sizeof(float), st));
+    if (dbias) RSLO_HIP(hipMemsetAsync(dbias, 0, cout * sizeof(float), st));
+    return RSLO_OK;
+  }
+  if (ws_bytes < rslo_spconv_wgrad_pairs_ws_bytes(n_out, K, cin, cout)) {
+    rslo_set_error("wgrad_pairs: workspace too small");
+    return RSLO_EWS;
+  }
+  const int nch = (int)rslo_cdiv(n_out, WG2_CHUNK);   // P_k <= n_out: upper bound on chunks per offset
+  const int ci = cin <= 16 ? 16 : (cin <= 32 ? 32 : 64), co = pad_cout(cout);
+  const bool exact = (ci == cin && co == cout);
+  dim3 grid((unsigned)nch, (unsigned)K);
+#define WG2_CASE(CI, CO)                                                                                  \
+  if (ci == CI && co == CO) {                                                                             \
+    if (exact)                                                                                            \
+      hipLaunchKernelGGL((k_wgrad2<CI, CO, true>), grid, dim3(SPC_THREADS), 0, st, in, cin, dout, cout,   \
+                         pairs_in, pairs_out, koff, K, (float *)ws);                                      \
+    else                                                                                                  \
+      hipLaunchKernelGGL((k_wgrad2<CI, CO, false>), grid, dim3(SPC_THREADS), 0, st, in, cin, dout, cout,  \
+                         pairs_in, pairs_out, koff, K, (float *)ws);                                      \
+  }
+  WG2_CASE(16, 16) WG2_CASE(16, 32) WG2_CASE(16, 64)
+  WG2_CASE(32, 16) WG2_CASE(32, 32) WG2_CASE(32, 64)
+  WG2_CASE(64, 16) WG2_CASE(64, 32) WG2_CASE(64, 64)
+#undef WG2_CASE
+  const int cc = cin * cout;
+  hipLaunchKernelGGL(k_wgrad2_reduce, dim3((unsigned)rslo_cdiv(cc, 256), (unsigned)K), dim3(256), 0, st,
+                     (const float *)ws, koff, K, cc, dW);
+  if (dbias) {
+    // tree of column sums: n_out rows -> ceil(/512) partial rows -> ... -> 1 row (written straight to dbias)
+    float *wsb = (float *)ws + (int64_t)nch * nW;
+    const float *src = dout;
+    int64_t rows = n_out;
+    while (true) {
+      const int64_t nblk = rslo_cdiv(rows, CS_ROWS);
+      float *dst = (nblk == 1) ? dbias : wsb;
+      hipLaunchKernelGGL(k_colsum_partial, dim3((unsigned)nblk), dim3(256), 0, st, src, rows, cout, co, dst);
+      if (nblk == 1) break;
+      src = dst;
+      rows = nblk;
+      wsb += nblk * cout;
+    }
+  }
+  RSLO_CHECK_LAUNCH("wgrad_pairs");
+  return RSLO_OK;
+}
+
 __global__ void k_leaky_bwd(const float *__restrict__ y, const float *__restrict__ dout, int64_t n,
                             float slope, float *__restrict__ g) {
   int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;

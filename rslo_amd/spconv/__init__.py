@@ -45,6 +45,13 @@ class Rulebook:
         self.in_index = in_index
         self.out_index = out_index
         self.ks, self.stride, self.pad = ks, stride, pad
+        self._pairs = None
+
+    def pairs(self):
+        """(pairs_in, pairs_out, koff): the table as spconv-style pair lists, built once per rulebook."""
+        if self._pairs is None:
+            self._pairs = capi.rulebook_pairs(self.nbr)
+        return self._pairs
 
     def indice_pairs(self):
         """spconv-1.x view of the table: (indice_pairs [K,2,P] padded with -1, indice_num [K]);
@@ -134,7 +141,8 @@ class _SparseConvFn(torch.autograd.Function):
     """y = act(bias + sum_k x[nbr[:,k]] @ W[k]) and its dgrad/wgrad, all through the C ABI."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, nbr, nbrT, subm, slope):
+    def forward(ctx, x, weight, bias, nbr, nbrT, subm, slope, rb=None, inverse=False):
+        ctx.rb, ctx.inverse = rb, inverse
         K = nbr.shape[1]
         cin, cout = weight.shape[-2], weight.shape[-1]
         W3 = weight.reshape(K, cin, cout)
@@ -161,9 +169,15 @@ class _SparseConvFn(torch.autograd.Function):
             else:
                 gx = capi.spconv_dgrad(g, W3, nbrT, flip_k=False)
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
-            gw, gb = capi.spconv_wgrad(x, g, nbr, cin, cout, with_bias=has_bias)
+            if ctx.rb is not None:
+                pin, pout, koff = ctx.rb.pairs()
+                # an inverse conv runs over the same pairs with the roles of the two sides swapped
+                pairs = (pout, pin, koff) if ctx.inverse else (pin, pout, koff)
+                gw, gb = capi.spconv_wgrad_pairs(x, g, pairs, g.shape[0], K, cin, cout, with_bias=has_bias)
+            else:
+                gw, gb = capi.spconv_wgrad(x, g, nbr, cin, cout, with_bias=has_bias)
             gw = gw.reshape(weight.shape)
-        return gx, gw, gb, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None, None
 
 
 class SparseModule(nn.Module):
@@ -215,11 +229,11 @@ class SparseConvolution(SparseModule):
         index = x.site_index()
         if self.subm:
             key = tuple(self.kernel_size)
-            nbr = index.subm_cache.get(key)
-            if nbr is None:
+            rb = index.subm_cache.get(key)
+            if rb is None:
                 nbr = capi.rulebook_subm(index, self.kernel_size)
-                index.subm_cache[key] = nbr
-            rb = Rulebook("subm", nbr, None, index, index, self.kernel_size, [1, 1, 1], None)
+                rb = Rulebook("subm", nbr, None, index, index, self.kernel_size, [1, 1, 1], None)
+                index.subm_cache[key] = rb
         else:
             out_index, nbr, nbrT = capi.rulebook_conv(index, self.kernel_size, self.stride, self.padding)
             out_index.subm_cache = {}
@@ -232,12 +246,12 @@ class SparseConvolution(SparseModule):
         assert isinstance(x, SparseConvTensor)
         rb = self._rulebook(x)
         if self.inverse:      # output sites = the saved INPUT sites of the forward twin, same order
-            y = _SparseConvFn.apply(x.features, self.weight, self.bias, rb.nbrT, rb.nbr, False, act_slope)
+            y = _SparseConvFn.apply(x.features, self.weight, self.bias, rb.nbrT, rb.nbr, False, act_slope, rb, True)
             return x._like(y, rb.in_index.coords, rb.in_index.dims, rb.in_index)
         if self.subm:
-            y = _SparseConvFn.apply(x.features, self.weight, self.bias, rb.nbr, None, True, act_slope)
+            y = _SparseConvFn.apply(x.features, self.weight, self.bias, rb.nbr, None, True, act_slope, rb, False)
             return x._like(y)
-        y = _SparseConvFn.apply(x.features, self.weight, self.bias, rb.nbr, rb.nbrT, False, act_slope)
+        y = _SparseConvFn.apply(x.features, self.weight, self.bias, rb.nbr, rb.nbrT, False, act_slope, rb, False)
         return x._like(y, rb.out_index.coords, rb.out_index.dims, rb.out_index)
 
 

@@ -73,10 +73,17 @@ for ci, ((nbr, nbrT), (a, b)) in enumerate(zip(convs, [(16, 32), (32, 64), (64, 
 for li, ((ix, nbr), (ci, co)) in enumerate(zip(levels, chans)):
     if ONLY and "wgrad" not in ONLY: continue
     n = nbr.shape[0]; x = rn(n, ci); gy = rn(n, co)
-    capi.spconv_wgrad(x, gy, nbr, ci, co); torch.cuda.synchronize()
+    pairs = capi.rulebook_pairs(nbr)
+    ref, _ = capi.spconv_wgrad(x, gy, nbr, ci, co)
+    got, gb = capi.spconv_wgrad_pairs(x, gy, pairs, n, 27, ci, co); torch.cuda.synchronize()
+    print("   wgrad pairs vs table maxrel=%.1e  bias maxrel=%.1e" % (float((got - ref).abs().max() / ref.abs().max()), float((gb - gy.sum(0)).abs().max() / gy.sum(0).abs().max())))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(REPS): capi.spconv_wgrad(x, gy, nbr, ci, co)
+    for _ in range(REPS): capi.rulebook_pairs(nbr)
+    e1.record(); torch.cuda.synchronize(); print("   rulebook_pairs %.1f us" % (1e3 * e0.elapsed_time(e1) / REPS))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(REPS): capi.spconv_wgrad_pairs(x, gy, pairs, n, 27, ci, co)
     e1.record(); torch.cuda.synchronize()
     P = int((nbr >= 0).sum()); us = 1e3 * e0.elapsed_time(e1) / REPS
     byts = P * (ci + co) * 4 + 8 * P + 27 * ci * co * 4

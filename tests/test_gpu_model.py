@@ -187,6 +187,9 @@ def test_full_network_fwd_bwd_matches_cpu_oracle(hip):
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
             continue
         assert p.grad is not None, n
+        if float(pc.grad.abs().max()) < 1e-6:     # analytically zero (e.g. the softmax-shift bias of a confidence head)
+            assert float(p.grad.abs().max()) < 1e-5, n
+            continue
         # sparse encoder + loss parameters: 2e-2; the dense head runs through MIOpen on one side and the CPU
         # conv on the other over ~30 chained fp32 layers on a random-init net (ReLU masks flip): 5e-2
         assert rel(p.grad, pc.grad) < (5e-2 if n.startswith("odom_predictor.") else 2e-2), n
