@@ -138,6 +138,22 @@ RSLO_API int rslo_spconv_wgrad_pairs(const float *in, int cin, const float *dout
 /* LeakyReLU backward from the saved OUTPUT (sign-preserving): g = dout * (y > 0 ? 1 : slope). */
 RSLO_API int rslo_leaky_bwd(const float *y, const float *dout, int64_t n, float slope, float *g, void *stream);
 
+/* a7  Per-frame BatchNorm1d (+ fused LeakyReLU) of the covariance branch (nn.BatchNorm1d at
+ *     rslo/models/middle.py:181-198; the reference feeds one frame per call, so statistics are per frame).
+ * Rows are grouped by frame: seg_off [S+1] (device).  Training-mode semantics of S consecutive module calls:
+ * biased variance for normalisation, running estimates updated in segment order with the unbiased variance.
+ * y = act(gamma * (x - mean_s) * invstd_s + beta); save_mean / save_invstd [S,C] feed the backward. */
+RSLO_API size_t rslo_segbn_ws_bytes(int S, int64_t max_seg_len, int C);
+RSLO_API int rslo_segbn_fwd(const float *x, int C, const int32_t *seg_off, int S, int64_t max_seg_len,
+                   const float *gamma, const float *beta, float *running_mean /*or NULL*/,
+                   float *running_var /*or NULL*/, float momentum, float eps, float act_slope, void *ws,
+                   size_t ws_bytes, float *y, float *save_mean, float *save_invstd, void *stream);
+/* ws_bytes >= rslo_segbn_ws_bytes(...) + 2*S*C*4 */
+RSLO_API int rslo_segbn_bwd(const float *x, const float *y, const float *gy, int C, const int32_t *seg_off, int S,
+                   int64_t max_seg_len, const float *gamma, const float *save_mean, const float *save_invstd,
+                   float act_slope, void *ws, size_t ws_bytes, float *gx, float *dgamma, float *dbeta,
+                   void *stream);
+
 /* a8  SparseConvTensor.dense() + view (middle.py:240-243): [M,C] rows -> [B,C,D,H,W]
  *     (zero-filled here) and its backward gather. */
 RSLO_API int rslo_dense_scatter(const float *feat, const int32_t *coords, int64_t M, int C, int B,

@@ -43,6 +43,9 @@ SIGNATURES = {
     "rslo_spconv_wgrad_pairs_ws_bytes": (_sz, [_i64, _i, _i, _i]),
     "rslo_spconv_wgrad_pairs": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i64, _i, _vp, _sz, _vp, _vp, _vp]),
     "rslo_leaky_bwd": (C.c_int, [_vp, _vp, _i64, _f, _vp, _vp]),
+    "rslo_segbn_ws_bytes": (_sz, [_i, _i64, _i]),
+    "rslo_segbn_fwd": (C.c_int, [_vp, _i, _vp, _i, _i64, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _sz, _vp, _vp, _vp, _vp]),
+    "rslo_segbn_bwd": (C.c_int, [_vp, _vp, _vp, _i, _vp, _i, _i64, _vp, _vp, _vp, _f, _vp, _sz, _vp, _vp, _vp, _vp]),
     "rslo_dense_scatter": (C.c_int, [_vp, _vp, _i64, _i, _i, _vp, _vp, _vp]),
     "rslo_dense_gather": (C.c_int, [_vp, _vp, _i64, _i, _i, _vp, _vp, _vp]),
     "rslo_chamfer_ws_bytes": (_sz, [_i, _i, _i]),
@@ -279,6 +282,39 @@ def leaky_bwd(y, dout, slope):
     _chk(lib().rslo_leaky_bwd(_ptr(y, torch.float32, "y"), _ptr(dout, torch.float32, "dout"), y.numel(),
                               float(slope), _ptr(g), _stream()), "rslo_leaky_bwd")
     return g
+
+
+def segbn_fwd(x, seg_off, S, max_len, gamma, beta, running_mean, running_var, momentum, eps, act_slope):
+    """-> (y, save_mean [S,C], save_invstd [S,C]); running stats updated in place, segment after segment."""
+    n, Cc = x.shape
+    dev = x.device
+    y = torch.empty_like(x)
+    mean = torch.empty((S, Cc), dtype=torch.float32, device=dev)
+    invstd = torch.empty((S, Cc), dtype=torch.float32, device=dev)
+    wsb = lib().rslo_segbn_ws_bytes(S, max_len, Cc)
+    ws = _ws(wsb, dev)
+    _chk(lib().rslo_segbn_fwd(_ptr(x, torch.float32, "x"), Cc, _ptr(seg_off, torch.int32, "seg_off"), S, max_len,
+                              _ptr(gamma, torch.float32, "gamma"), _ptr(beta, torch.float32, "beta"),
+                              _ptr(running_mean, torch.float32, "running_mean"),
+                              _ptr(running_var, torch.float32, "running_var"), float(momentum), float(eps),
+                              float(act_slope), _ptr(ws), wsb, _ptr(y), _ptr(mean), _ptr(invstd), _stream()),
+         "rslo_segbn_fwd")
+    return y, mean, invstd
+
+
+def segbn_bwd(x, y, gy, seg_off, S, max_len, gamma, mean, invstd, act_slope):
+    n, Cc = x.shape
+    dev = x.device
+    gx = torch.empty_like(x)
+    dgamma = torch.empty((Cc,), dtype=torch.float32, device=dev)
+    dbeta = torch.empty((Cc,), dtype=torch.float32, device=dev)
+    wsb = lib().rslo_segbn_ws_bytes(S, max_len, Cc) + 2 * S * Cc * 4
+    ws = _ws(wsb, dev)
+    _chk(lib().rslo_segbn_bwd(_ptr(x, torch.float32, "x"), _ptr(y, torch.float32, "y"), _ptr(gy, torch.float32, "gy"),
+                              Cc, _ptr(seg_off, torch.int32, "seg_off"), S, max_len,
+                              _ptr(gamma, torch.float32, "gamma"), _ptr(mean), _ptr(invstd), float(act_slope),
+                              _ptr(ws), wsb, _ptr(gx), _ptr(dgamma), _ptr(dbeta), _stream()), "rslo_segbn_bwd")
+    return gx, dgamma, dbeta
 
 
 def dense_scatter(feat, coords, batch, dims):

@@ -180,6 +180,42 @@ class _SparseConvFn(torch.autograd.Function):
         return gx, gw, gb, None, None, None, None, None, None
 
 
+class _SegBNActFn(torch.autograd.Function):
+    """Per-frame BatchNorm1d (training statistics) + LeakyReLU through rslo_segbn_fwd / _bwd."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, bn, seg_off, S, max_len, slope):
+        x = x.contiguous()
+        y, mean, invstd = capi.segbn_fwd(x, seg_off, S, max_len, gamma, beta, bn.running_mean, bn.running_var,
+                                         bn.momentum, bn.eps, slope)
+        ctx.save_for_backward(x, y, gamma, mean, invstd, seg_off)
+        ctx.meta = (S, max_len, slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, y, gamma, mean, invstd, seg_off = ctx.saved_tensors
+        S, max_len, slope = ctx.meta
+        gx, dgamma, dbeta = capi.segbn_bwd(x, y, gy.contiguous(), seg_off, S, max_len, gamma, mean, invstd, slope)
+        return gx, dgamma, dbeta, None, None, None, None, None
+
+
+def _segmented_bn_act(x, bn, slope):
+    """Training-mode nn.BatchNorm1d over each frame of the batched tensor, fused with the activation."""
+    index = x.site_index()
+    offs = x.batch_offsets()
+    dev_off = getattr(index, "batch_offs_dev", None)
+    if dev_off is None:
+        dev_off = torch.tensor(offs, dtype=torch.int32, device=x.features.device)
+        index.batch_offs_dev = dev_off
+    S = x.batch_size
+    max_len = max(offs[b + 1] - offs[b] for b in range(S))
+    y = _SegBNActFn.apply(x.features, bn.weight, bn.bias, bn, dev_off, S, max_len, slope)
+    if bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(sum(1 for b in range(S) if offs[b + 1] > offs[b]))
+    return x._like(y)
+
+
 class SparseModule(nn.Module):
     """Marker base class: modules that consume / produce SparseConvTensor."""
 
@@ -331,6 +367,14 @@ class SparseSequential(SparseModule):
             elif isinstance(m, SparseModule):
                 x = m(x)
             elif isinstance(x, SparseConvTensor):
+                fusable_bn = (type(m) is nn.BatchNorm1d and m.training and m.affine and m.track_running_stats
+                              and m.momentum is not None and x.features.is_cuda and x.features.shape[0] > 0)
+                if fusable_bn:
+                    j = i + 1
+                    slope = _act_slope(mods[j]) if j < len(mods) else None
+                    x = _segmented_bn_act(x, m, 1.0 if slope is None else slope)
+                    i = j + 1 if slope is not None else j
+                    continue
                 if isinstance(m, nn.modules.batchnorm._BatchNorm) and m.training and x.batch_size > 1:
                     # the reference runs the encoder one frame at a time (middle.py:221), so batch
                     # statistics are per frame: normalise each batch segment on its own, in frame order

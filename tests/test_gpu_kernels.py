@@ -139,6 +139,18 @@ def test_subm_conv_fwd_bwd(hip, cin, cout):
     ow, ob = O.spconv_wgrad(x, gy, nbr, cin, cout)
     np.testing.assert_allclose(gw.cpu().numpy(), ow, rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(gb.cpu().numpy(), ob, rtol=1e-4, atol=1e-4)
+    # pair-list rulebook (spconv layout, ascending output row per offset): bit-exact, and the wgrad over it
+    pin, pout, koff = hip.rulebook_pairs(dn)
+    P = int(koff[-1].item())
+    assert P == int((nbr >= 0).sum())
+    ko = koff.cpu().numpy()
+    for k in (0, 13, 26):
+        rows = np.nonzero(nbr[:, k] >= 0)[0]
+        assert (pout[ko[k]:ko[k + 1]].cpu().numpy() == rows).all()
+        assert (pin[ko[k]:ko[k + 1]].cpu().numpy() == nbr[rows, k]).all()
+    gw2, gb2 = hip.spconv_wgrad_pairs(dev(x), dev(gy), (pin, pout, koff), len(coords), 27, cin, cout)
+    np.testing.assert_allclose(gw2.cpu().numpy(), ow, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(gb2.cpu().numpy(), ob, rtol=1e-4, atol=1e-4)
 
 
 def test_strided_and_inverse_conv(hip):
@@ -243,3 +255,31 @@ def test_chamfer_full_size_properties(hip):
     d, i = hip.chamfer_nn(dev(q), t)
     od, oi = O.chamfer_nn(q, p)
     assert (i.cpu().numpy() == oi).all() and (d.cpu().numpy() == od).all()
+
+
+def test_segmented_batchnorm_matches_torch_per_frame(hip):
+    """rslo_segbn_fwd/bwd == nn.BatchNorm1d applied frame by frame (+ LeakyReLU), incl. running statistics."""
+    torch.manual_seed(0)
+    offs = [0, 700, 700, 1900, 2500]          # one empty frame
+    S, Cc = 4, 32
+    x = torch.randn(offs[-1], Cc, device="cuda") * 2 + 0.5
+    gy = torch.randn(offs[-1], Cc, device="cuda")
+    bn = torch.nn.BatchNorm1d(Cc).cuda().train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+    ref_bn = torch.nn.BatchNorm1d(Cc).cuda().train()
+    ref_bn.load_state_dict(bn.state_dict())
+    xr = x.clone().requires_grad_(True)
+    parts = [torch.nn.functional.leaky_relu(ref_bn(xr[offs[b]:offs[b + 1]]), 0.01) for b in range(S) if offs[b + 1] > offs[b]]
+    yr = torch.cat(parts, 0)
+    (yr * gy).sum().backward()
+    seg = torch.tensor(offs, dtype=torch.int32, device="cuda")
+    y, mean, invstd = hip.segbn_fwd(x, seg, S, 1200, bn.weight.detach(), bn.bias.detach(), bn.running_mean,
+                                    bn.running_var, bn.momentum, bn.eps, 0.01)
+    assert float((y - yr).abs().max()) < 2e-5
+    assert float((bn.running_mean - ref_bn.running_mean).abs().max()) < 1e-6
+    assert float((bn.running_var - ref_bn.running_var).abs().max()) < 1e-5
+    gx, dg, db = hip.segbn_bwd(x, y, gy, seg, S, 1200, bn.weight.detach(), mean, invstd, 0.01)
+    assert float((gx - xr.grad).abs().max()) < 2e-5
+    assert float((dg - ref_bn.weight.grad).abs().max()) < 2e-4 and float((db - ref_bn.bias.grad).abs().max()) < 2e-4
