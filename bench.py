@@ -141,6 +141,16 @@ class ConvProbe:
                      "avg_launch_us": round(g["avg_us"], 2), "launches_per_step": g["launches"] // max(steps, 1),
                      "algorithmic_bytes_per_launch": int(g["bytes"] // g["launches"]),
                      "algorithmic_flops_per_launch": int(g["flops"] // g["launches"])})
+        # HBM-side bytes per launch from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md), collected
+        # with rocprofv3 on this same command (scripts/pmc_bench_traffic.sh) and committed under profiles/
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_bench.json")) as f:
+                tr = json.load(f)
+            if name in tr.get("kernels", {}):
+                roof["traffic"] = int(tr["kernels"][name]["hbm_bytes_per_launch"])
+                roof["traffic_source"] = "profiles/r01_pmc_traffic_bench.json"
+        except (OSError, ValueError, KeyError):
+            pass
         tot_ms = sum(x["ms"] for x in groups.values())
         tot_b = sum(x["bytes"] for x in groups.values())
         roof["all_spconv_fwd_dgrad"] = {"ms_per_step": round(tot_ms / max(steps, 1), 3),
@@ -177,13 +187,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist_on = world > 1
+    dist_on = world > 1 or os.environ.get("RSLO_BENCH_FORCE_DIST", "0") == "1"   # (the latter: DDP smoke test at N=1)
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if dist_on else 0)
@@ -198,8 +211,11 @@ def main():
     net.global_step.fill_(2000)          # past the warm-up: predicted pose in the loss, icp_iter = 2
     model = net
     if dist_on:
-        model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[local_rank], find_unused_parameters=True,
-                                                          bucket_cap_mb=48)
+        # Data parallel without the DDP wrapper: identical initial weights (broadcast), and after backward ONE flat
+        # 48 MB all-reduce of the gradients over RCCL (rslo.utils.distributed_utils.average_gradients).  torch DDP with
+        # find_unused_parameters=True (77 of 290 tensors never get a gradient) costs ~8 ms of host time per step here.
+        from rslo.utils.distributed_utils import average_gradients, broadcast_params
+        broadcast_params(net, 0)
     params = [p for p in net.parameters() if p.requires_grad]
     opt = torch.optim.Adam(params, lr=8e-5, betas=(0.9, 0.99), fused=True)
 
@@ -214,6 +230,8 @@ def main():
         opt.zero_grad(set_to_none=True)
         ret = model(ex)
         ret["loss"].mean().backward()
+        if dist_on:
+            average_gradients(net)
         if not args.no_optim:
             torch.nn.utils.clip_grad_norm_(params, 10.0)
             opt.step()

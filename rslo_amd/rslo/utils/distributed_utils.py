@@ -24,14 +24,11 @@ def average_gradients(model, bucket=True):
             dist.all_reduce(p.grad.data)
             p.grad.data.div_(world)
         return
-    flat = torch.cat([p.grad.reshape(-1) for p in params])
+    grads = [p.grad for p in params]
+    flat = torch.cat([g.reshape(-1) for g in grads])
     dist.all_reduce(flat)
     flat.div_(world)
-    off = 0
-    for p in params:
-        n = p.grad.numel()
-        p.grad.copy_(flat[off:off + n].view_as(p.grad))
-        off += n
+    torch._foreach_copy_(grads, [c.view_as(g) for c, g in zip(flat.split([g.numel() for g in grads]), grads)])
 
 
 def broadcast_params(model, src=0):
