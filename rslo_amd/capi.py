@@ -87,7 +87,11 @@ def _chk(rc, name):
 
 
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # raw hipStream_t of torch's current stream (fast path; falls back to the public API)
+    try:
+        return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
+    except AttributeError:
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 def _ptr(t, dtype=None, name="tensor"):

@@ -209,7 +209,8 @@ extern "C" int rslo_cov_residual_fwd(const float *p1, const float *tgt, const fl
 // ---------------------------------------------------------------------------------------
 // residual backward: gloss[b] -> gtgt (scatter), gcov1 (direct), gcov2 (scatter)
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(LS_THREADS) void k_resid_bwd(const float *__restrict__ p1, const float *__restrict__ tgt,
+#define RB_THREADS 64
+__global__ __launch_bounds__(RB_THREADS) void k_resid_bwd(const float *__restrict__ p1, const float *__restrict__ tgt,
                                                           const float *__restrict__ cov1, const float *__restrict__ cov2,
                                                           const int32_t *__restrict__ idx, const float *__restrict__ dist,
                                                           const float *__restrict__ thr, const float *__restrict__ Rd,
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(LS_THREADS) void k_resid_bwd(const float *__restric
                                                           float *__restrict__ gtgt, float *__restrict__ gcov1,
                                                           float *__restrict__ gcov2) {
   const int b = blockIdx.y;
-  const int i = blockIdx.x * LS_THREADS + threadIdx.x;
+  const int i = blockIdx.x * RB_THREADS + threadIdx.x;
   if (i >= N) return;
   float *g1 = gcov1 + ((int64_t)b * N + i) * 7;
   if (!(dist[(int64_t)b * N + i] < thr[b])) {
@@ -296,7 +297,7 @@ extern "C" int rslo_cov_residual_bwd(const float *p1, const float *tgt, const fl
   if (B == 0) return RSLO_OK;
   RSLO_HIP(hipMemsetAsync(gtgt, 0, (size_t)B * M * 3 * sizeof(float), st));
   RSLO_HIP(hipMemsetAsync(gcov2, 0, (size_t)B * M * 7 * sizeof(float), st));
-  hipLaunchKernelGGL(k_resid_bwd, dim3((unsigned)rslo_cdiv(N, LS_THREADS), B), dim3(LS_THREADS), 0, st, p1, tgt, cov1,
+  hipLaunchKernelGGL(k_resid_bwd, dim3((unsigned)rslo_cdiv(N, RB_THREADS), B), dim3(RB_THREADS), 0, st, p1, tgt, cov1,
                      cov2, idx, dist, thr, Rd, gloss, cnt, N, M, reg_weight, gp1, gtgt, gcov1, gcov2);
   RSLO_CHECK_LAUNCH("cov_residual_bwd");
   return RSLO_OK;

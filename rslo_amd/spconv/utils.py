@@ -48,6 +48,15 @@ class VoxelGenerator:
             return vox.cpu().numpy(), coords.cpu().numpy(), num.cpu().numpy()
         return vox, coords, num
 
+    def generate_many(self, clouds, max_voxels=None):
+        """Voxelize several CUDA clouds with ONE host read of the voxel counts (generate() syncs per cloud).
+        Returns a list of (voxels, coordinates, num_points_per_voxel)."""
+        maxv = int(max_voxels or self._max_voxels)
+        outs = [capi.voxelize(p.contiguous().float(), self._point_cloud_range, self._voxel_size, self._grid_size,
+                              self._max_num_points, maxv) for p in clouds]
+        counts = torch.cat([o[3] for o in outs]).tolist()
+        return [(o[0][:m], o[1][:m], o[2][:m]) for o, m in zip(outs, counts)]
+
     @property
     def voxel_size(self):
         return self._voxel_size

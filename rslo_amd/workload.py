@@ -24,14 +24,24 @@ def make_example(net, clouds_per_sample, max_voxels=synthetic.MAX_VOXELS, device
     prepended to the coordinates (merge_second_batch, preprocess.py:75-89)."""
     B, T = len(clouds_per_sample), len(clouds_per_sample[0])
     ex = {"voxels": [], "num_points": [], "coordinates": [], "num_voxels": []}
+    flat = []
     for t in range(T):
-        vs, ns, cs, nv = [], [], [], []
         for b in range(B):
             pts = clouds_per_sample[b][t]
             if isinstance(pts, np.ndarray):
                 pts = torch.from_numpy(pts)
-            r = net.voxel_generator.generate(pts.to(device), max_voxels)
-            v, c, n = r["voxels"], r["coordinates"], r["num_points_per_voxel"]
+            flat.append(pts.to(device))
+    if hasattr(net.voxel_generator, "generate_many") and flat[0].is_cuda:
+        results = net.voxel_generator.generate_many(flat, max_voxels)      # one host read for all clouds
+    else:
+        results = []
+        for pts in flat:
+            r = net.voxel_generator.generate(pts, max_voxels)
+            results.append((r["voxels"], r["coordinates"], r["num_points_per_voxel"]))
+    for t in range(T):
+        vs, ns, cs, nv = [], [], [], []
+        for b in range(B):
+            v, c, n = results[t * B + b]
             vs.append(v)
             ns.append(n)
             cs.append(torch.cat([torch.full((c.shape[0], 1), b, dtype=torch.int32, device=c.device), c], 1))
