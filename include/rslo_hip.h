@@ -172,6 +172,11 @@ RSLO_API size_t rslo_chamfer_ws_bytes(int B, int N, int M);
 RSLO_API int rslo_chamfer_nn(const float *xyz1 /*[B,N,3]*/, const float *xyz2 /*[B,M,3]*/, int B, int N, int M,
                     float *dist /*[B,N]*/, int32_t *idx /*[B,N]*/, void *ws, size_t ws_bytes,
                     void *stream);
+/* Ragged batch: pair b uses only its first ncnt[b] queries and mcnt[b] targets of the padded [B,N,3]/[B,M,3]
+ * arrays (device int32 [B]; NULL = all).  Padding queries get dist = +inf, idx = 0. */
+RSLO_API int rslo_chamfer_nn_ragged(const float *xyz1, const float *xyz2, int B, int N, int M, const int32_t *ncnt,
+                           const int32_t *mcnt, float *dist, int32_t *idx, void *ws, size_t ws_bytes,
+                           void *stream);
 RSLO_API int rslo_chamfer_grad(const float *xyz1, const float *xyz2, int B, int N, int M,
                       const float *graddist1, const int32_t *idx1, float *gradxyz1 /*[B,N,3]*/,
                       float *gradxyz2 /*[B,M,3]*/, void *stream);

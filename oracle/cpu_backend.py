@@ -114,8 +114,19 @@ def dense_gather(dense, coords, C_, batch, dims):
     return dense[c[:, 0], :, c[:, 1], c[:, 2], c[:, 3]].contiguous()
 
 
-def chamfer_nn(xyz1, xyz2, dist=None, idx=None):
-    d, i = O.chamfer_nn(_np(xyz1), _np(xyz2))
+def chamfer_nn(xyz1, xyz2, dist=None, idx=None, ncnt=None, mcnt=None):
+    if ncnt is None and mcnt is None:
+        d, i = O.chamfer_nn(_np(xyz1), _np(xyz2))
+    else:       # ragged batch: pair by pair on the valid prefixes, padding rows get +inf / 0
+        a, b = _np(xyz1), _np(xyz2)
+        B, N, _ = a.shape
+        d = np.full((B, N), np.inf, np.float32)
+        i = np.zeros((B, N), np.int32)
+        for k in range(B):
+            n = int(ncnt[k]) if ncnt is not None else N
+            m = int(mcnt[k]) if mcnt is not None else b.shape[1]
+            dk, ik = O.chamfer_nn(a[k:k + 1, :n], b[k:k + 1, :m])
+            d[k, :n], i[k, :n] = dk[0], ik[0]
     d, i = torch.from_numpy(d), torch.from_numpy(i)
     if dist is not None:
         dist.copy_(d)

@@ -33,12 +33,14 @@ __device__ __forceinline__ f32x2 dist2(f32x2 tx, f32x2 ty, f32x2 tz, float qx, f
 // same expression gives the same bits, so this is exactly "lowest index wins ties".
 __global__ __launch_bounds__(CH_THREADS) void k_chamfer_part(const float *__restrict__ xyz1,
                                                              const float *__restrict__ xyz2, int N, int M,
-                                                             int seg_len, int S, float *__restrict__ pdist,
+                                                             int seg_len, int S, const int32_t *__restrict__ mcnt,
+                                                             float *__restrict__ pdist,
                                                              int32_t *__restrict__ pidx) {
   __shared__ f32x2 tx[CH_TILE / 2], ty[CH_TILE / 2], tz[CH_TILE / 2];
   const int b = blockIdx.z, s = blockIdx.y;
+  const int Mb = mcnt ? mcnt[b] : M;          // ragged batch: only the first Mb targets of pair b exist
   const int m0 = s * seg_len;
-  const int m1 = (m0 + seg_len < M) ? m0 + seg_len : M;
+  const int m1 = (m0 + seg_len < Mb) ? m0 + seg_len : Mb;
   const float *q = xyz1 + (int64_t)b * N * 3;
   const float *t = xyz2 + (int64_t)b * M * 3;
   const int q0 = blockIdx.x * (CH_THREADS * CH_QPT) + threadIdx.x;
@@ -117,10 +119,16 @@ __global__ __launch_bounds__(CH_THREADS) void k_chamfer_part(const float *__rest
 }
 
 __global__ void k_chamfer_merge(const float *__restrict__ pdist, const int32_t *__restrict__ pidx, int N, int S,
-                                float *__restrict__ dist, int32_t *__restrict__ idx) {
+                                const int32_t *__restrict__ ncnt, float *__restrict__ dist,
+                                int32_t *__restrict__ idx) {
   const int b = blockIdx.y;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
+  if (ncnt && i >= ncnt[b]) {   // padding row of a ragged batch: never inside any ROI
+    dist[(int64_t)b * N + i] = __builtin_inff();
+    idx[(int64_t)b * N + i] = 0;
+    return;
+  }
   float best = pdist[((int64_t)b * S) * N + i];
   int besti = pidx[((int64_t)b * S) * N + i];
   for (int s = 1; s < S; ++s) {
@@ -149,8 +157,18 @@ extern "C" size_t rslo_chamfer_ws_bytes(int B, int N, int M) {
   return (size_t)chamfer_segments(B, N, M) * (size_t)(B > 0 ? B : 1) * (size_t)(N > 0 ? N : 1) * 8;
 }
 
+extern "C" int rslo_chamfer_nn_ragged(const float *xyz1, const float *xyz2, int B, int N, int M,
+                                      const int32_t *ncnt, const int32_t *mcnt, float *dist, int32_t *idx,
+                                      void *ws, size_t ws_bytes, void *stream);
+
 extern "C" int rslo_chamfer_nn(const float *xyz1, const float *xyz2, int B, int N, int M, float *dist,
                                int32_t *idx, void *ws, size_t ws_bytes, void *stream) {
+  return rslo_chamfer_nn_ragged(xyz1, xyz2, B, N, M, nullptr, nullptr, dist, idx, ws, ws_bytes, stream);
+}
+
+extern "C" int rslo_chamfer_nn_ragged(const float *xyz1, const float *xyz2, int B, int N, int M,
+                                      const int32_t *ncnt, const int32_t *mcnt, float *dist, int32_t *idx,
+                                      void *ws, size_t ws_bytes, void *stream) {
   hipStream_t st = (hipStream_t)stream;
   RSLO_CHECK_ARG(B >= 0 && N >= 0 && M >= 1, "chamfer_nn: need M >= 1");
   if (B == 0 || N == 0) return RSLO_OK;
@@ -163,10 +181,10 @@ extern "C" int rslo_chamfer_nn(const float *xyz1, const float *xyz2, int B, int 
   float *pdist = (float *)ws;
   int32_t *pidx = (int32_t *)(pdist + (int64_t)S * B * N);
   dim3 grid((unsigned)rslo_cdiv(N, CH_THREADS * CH_QPT), (unsigned)S, (unsigned)B);
-  hipLaunchKernelGGL(k_chamfer_part, grid, dim3(CH_THREADS), 0, st, xyz1, xyz2, N, M, seg_len, S, pdist,
+  hipLaunchKernelGGL(k_chamfer_part, grid, dim3(CH_THREADS), 0, st, xyz1, xyz2, N, M, seg_len, S, mcnt, pdist,
                      pidx);
   hipLaunchKernelGGL(k_chamfer_merge, dim3((unsigned)rslo_cdiv(N, 256), (unsigned)B), dim3(256), 0, st, pdist,
-                     pidx, N, S, dist, idx);
+                     pidx, N, S, ncnt, dist, idx);
   RSLO_CHECK_LAUNCH("chamfer_nn");
   return RSLO_OK;
 }

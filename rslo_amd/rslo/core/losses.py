@@ -106,6 +106,16 @@ def roi_threshold(dist, penalize_ratio):
     return torch.max(m, torch.ones_like(m))
 
 
+def roi_threshold_ragged(dist, counts, penalize_ratio):
+    """Same threshold for a padded batch: row b holds counts[b] valid distances followed by +inf padding, and
+    k_b = 1 + int(counts[b] * ratio) differs per row -> one sort instead of per-row kthvalue calls."""
+    k = 1 + (counts.double() * penalize_ratio).long()
+    k = torch.minimum(k, counts.long()).clamp_min(1)
+    srt, _ = torch.sort(dist, dim=-1)
+    m = srt.gather(1, (k - 1)[:, None])
+    return torch.max(m, torch.ones_like(m))
+
+
 def points_roi(dist, penalize_ratio):
     return dist < roi_threshold(dist, penalize_ratio)
 
@@ -213,21 +223,36 @@ class Aleat5_1ChamferL2NormalWeightedALLSVDLoss(Loss):
         return (fw * (torch.exp(-self.alpha) * loss)).sum() + self.alpha
 
     def pair_losses(self, xyz_pred, xyz_target, cov_pred, cov_target, R_pred, t_pred, normal_pred,
-                    normal_target, icp_iter=1):
+                    normal_target, icp_iter=1, counts=None, counts_host=None):
         """Per-pair residual loss [B] and the ICP refinement (res_R [B,3,3], res_T [B,3]).
         GPU tensors take the fused HIP kernels; the plain-torch formulation below is the same math op by op
-        (it is what the golden vectors of the reference pin, and what the fused kernels are tested against)."""
+        (it is what the golden vectors of the reference pin, and what the fused kernels are tested against).
+        counts (int32 [B] on the device) / counts_host: pairs of different length zero-padded to one batch --
+        pair b uses its first counts[b] points on both sides."""
         if xyz_pred.is_cuda and self.use_fused:
-            return self.pair_losses_fused(xyz_pred, xyz_target, cov_pred, cov_target, R_pred, normal_pred, icp_iter)
-        return self.pair_losses_torch(xyz_pred, xyz_target, cov_pred, cov_target, R_pred, t_pred, normal_pred,
-                                      normal_target, icp_iter)
+            return self.pair_losses_fused(xyz_pred, xyz_target, cov_pred, cov_target, R_pred, normal_pred, icp_iter,
+                                          counts)
+        if counts_host is None:
+            return self.pair_losses_torch(xyz_pred, xyz_target, cov_pred, cov_target, R_pred, t_pred, normal_pred,
+                                          normal_target, icp_iter)
+        outs = [self.pair_losses_torch(xyz_pred[b:b + 1, :n], xyz_target[b:b + 1, :n], cov_pred[b:b + 1, :n],
+                                       cov_target[b:b + 1, :n], R_pred[b:b + 1], t_pred[b:b + 1],
+                                       normal_pred[b:b + 1, :n], normal_target[b:b + 1, :n], icp_iter)
+                for b, n in enumerate(counts_host)]
+        return torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs]), torch.cat([o[2] for o in outs])
 
-    def pair_losses_fused(self, xyz_pred, xyz_target, cov_pred, cov_target, R_pred, normal_pred, icp_iter=1):
+    def _thr(self, dist, counts):
+        if counts is None:
+            return roi_threshold(dist, self.penalize_ratio).reshape(-1).contiguous()
+        return roi_threshold_ragged(dist, counts, self.penalize_ratio).reshape(-1).contiguous()
+
+    def pair_losses_fused(self, xyz_pred, xyz_target, cov_pred, cov_target, R_pred, normal_pred, icp_iter=1,
+                          counts=None):
         p1 = xyz_pred.detach().contiguous().float()
         n1 = normal_pred.detach().contiguous().float()
         tgt0 = xyz_target.detach().contiguous().float()
-        dist, idx = capi.chamfer_nn(p1, tgt0)
-        thr = roi_threshold(dist, self.penalize_ratio).reshape(-1).contiguous()
+        dist, idx = capi.chamfer_nn(p1, tgt0, ncnt=counts, mcnt=counts)
+        thr = self._thr(dist, counts)
         loss_b = _CovResidualFn.apply(xyz_pred, xyz_target, cov_pred, cov_target, idx, dist, thr,
                                       R_pred.detach(), float(self.reg_weight))
         B = p1.shape[0]
@@ -238,8 +263,8 @@ class Aleat5_1ChamferL2NormalWeightedALLSVDLoss(Loss):
             capi.icp_step(p1, n1, cur, idx, dist, thr, res_r, res_t)
             if it < icp_iter - 1:
                 cur = capi.transform_points(tgt0, res_r, res_t)
-                dist, idx = capi.chamfer_nn(p1, cur)
-                thr = roi_threshold(dist, self.penalize_ratio).reshape(-1).contiguous()
+                dist, idx = capi.chamfer_nn(p1, cur, ncnt=counts, mcnt=counts)
+                thr = self._thr(dist, counts)
         return loss_b, res_r, res_t
 
     def pair_losses_torch(self, xyz_pred, xyz_target, cov_pred, cov_target, R_pred, t_pred, normal_pred,

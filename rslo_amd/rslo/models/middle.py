@@ -93,6 +93,11 @@ class SpMiddleFHDWithCov2_3(nn.Module):
     def forward(self, voxel_features, coors, batch_size):
         coors = coors.int()
         x = spconv.SparseConvTensor(voxel_features, coors, self.sparse_shape, batch_size)
+        # all rulebooks first (they depend on coordinates only): the 4 host reads of output-site counts happen
+        # before any convolution is queued, then the ~20 conv launches run without a sync in between
+        p0 = self.middle_conv.plan(x)
+        self.middle_conv_tail.plan(p0)
+        self.middle_cov_deconv.plan(p0)
         ret0 = self.middle_conv(x)
         ret = self.middle_conv_tail(ret0)
         cov = self.middle_cov_deconv(ret0).features

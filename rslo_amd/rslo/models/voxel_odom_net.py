@@ -356,7 +356,7 @@ class UnVoxelOdomNetICP3(nn.Module):
                 counts = [[f.shape[0]] for f in feats]
             else:
                 counts = [[int(v) for v in example["num_voxels"][t].reshape(-1).tolist()] for t in range(len(feats))]
-            per_sample = []
+            per_sample, lens = [], []
             for b in range(B):
                 offs = [sum(counts[t][:b]) for t in range(len(feats))]
                 # the reference truncates every frame of a sample to the shortest one (voxel_odom_net.py:646-651)
@@ -364,7 +364,18 @@ class UnVoxelOdomNetICP3(nn.Module):
                 points = [feats[t][offs[t]:offs[t] + min_len][:, cols][None] for t in range(len(feats))]
                 confs = [preds_dict["middle_conf_preds"][t][offs[t]:offs[t] + min_len][None] for t in range(len(feats))]
                 per_sample.append(create_cycle_constraint_data(points, 1) + create_cycle_constraint_data(confs, 1))
+                lens.append(min_len)
             npairs = per_sample[0][0].shape[0]
+            # all pairs of all samples as ONE zero-padded batch [B * npairs, Lmax, .] + per-pair valid counts
+            if B == 1:
+                pts1, pts2, cov1, cov2 = per_sample[0]
+                cnt_dev = cnt_host = None
+            else:
+                Lmax = max(lens)
+                padded = [[F.pad(x, (0, 0, 0, Lmax - n)) for x in ps] for ps, n in zip(per_sample, lens)]
+                pts1, pts2, cov1, cov2 = (torch.cat([p[k] for p in padded], 0) for k in range(4))
+                cnt_host = [n for n in lens for _ in range(npairs)]
+                cnt_dev = torch.tensor(cnt_host, dtype=torch.int32, device=device)
 
             weights = [0.01, 0.01, 0.05, 0.1, 1]
             for R_pred, T_pred, weight in zip(rotation_preds, translation_preds, weights[-len(translation_preds):]):
@@ -376,19 +387,13 @@ class UnVoxelOdomNetICP3(nn.Module):
                     R_pred = torch.eye(3, device=device, dtype=dtype).expand(R_pred.shape[0], 3, 3).contiguous()
                     T_pred = torch.zeros_like(T_pred)
                 icp_iter = self.icp_iter if step > 1500 else 5
-                pair_losses, rs, ts = [], [], []
-                for b, (pts1, pts2, cov1, cov2) in enumerate(per_sample):   # pairs of sample b: rows b*npairs..
-                    Rb, Tb = R_pred[b * npairs:(b + 1) * npairs], T_pred[b * npairs:(b + 1) * npairs]
-                    p2_moved = pts2[:, :, :3] @ Rb.transpose(-1, -2) + Tb[:, None]
-                    n2_moved = pts2[:, :, 3:] @ Rb.detach().transpose(-1, -2)
-                    lb, rr, tt = consistency_loss.pair_losses(
-                        pts1[:, :, :3], p2_moved, cov_pred=cov1, cov_target=cov2, R_pred=Rb, t_pred=Tb,
-                        normal_pred=pts1[:, :, 3:].detach(), normal_target=n2_moved.detach(), icp_iter=icp_iter)
-                    pair_losses.append(lb)
-                    rs.append(rr)
-                    ts.append(tt)
-                l = consistency_loss._loss_weight * consistency_loss.reduce(torch.cat(pair_losses))
-                res_r, res_t = torch.cat(rs), torch.cat(ts)
+                p2_moved = pts2[:, :, :3] @ R_pred.transpose(-1, -2) + T_pred[:, None]
+                n2_moved = pts2[:, :, 3:] @ R_pred.detach().transpose(-1, -2)
+                lb, res_r, res_t = consistency_loss.pair_losses(
+                    pts1[:, :, :3], p2_moved, cov_pred=cov1, cov_target=cov2, R_pred=R_pred, t_pred=T_pred,
+                    normal_pred=pts1[:, :, 3:].detach(), normal_target=n2_moved.detach(), icp_iter=icp_iter,
+                    counts=cnt_dev, counts_host=cnt_host)
+                l = consistency_loss._loss_weight * consistency_loss.reduce(lb)
                 C_loss = C_loss + (1 - warm_weight) * weight * l
 
         if res_r is not None and res_t is not None:

@@ -278,6 +278,18 @@ class SparseConvolution(SparseModule):
             x.indice_dict[self.indice_key] = rb
         return rb
 
+    def plan(self, x):
+        """Build (or look up) this layer's rulebook and return the output site set WITHOUT touching features.
+        Rulebooks depend only on coordinates; planning a whole encoder up front puts the few host reads of
+        strided-conv output counts before any convolution is enqueued, so the conv launches that follow run
+        back to back on the GPU."""
+        rb = self._rulebook(x)
+        if self.inverse:
+            return x._like(None, rb.in_index.coords, rb.in_index.dims, rb.in_index)
+        if self.subm:
+            return x._like(None)
+        return x._like(None, rb.out_index.coords, rb.out_index.dims, rb.out_index)
+
     def forward(self, x, act_slope=1.0):
         assert isinstance(x, SparseConvTensor)
         rb = self._rulebook(x)
@@ -348,6 +360,13 @@ class SparseSequential(SparseModule):
 
     def add(self, module, name=None):
         self.add_module(str(len(self._modules)) if name is None else name, module)
+
+    def plan(self, x):
+        """Propagate only the site sets through the chain (see SparseConvolution.plan)."""
+        for m in self._modules.values():
+            if isinstance(m, (SparseConvolution, SparseSequential)):
+                x = m.plan(x)
+        return x
 
     def forward(self, x):
         mods = list(self._modules.values())

@@ -241,3 +241,27 @@ def test_spconv_api_indice_pairs_view(hip):
     osub = O.rulebook_subm(coords, 2, dims)
     op2, on2 = O.pairs_from_nbrT(osub[:, ::-1].copy())
     assert (snum.cpu().numpy() == on2).all() and (spairs.cpu().numpy() == op2).all()
+
+
+def test_training_batched_loss_equals_per_sample(hip):
+    """bs 2 training step: the padded ragged loss batch must give the per-sample consistency / ICP results.
+    BN layers are put in eval mode so that the only coupling between samples would be a batching error."""
+    torch.manual_seed(5)
+    net, _ = workload.build_network()
+    net.train()
+    for m in net.modules():
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            m.eval()
+    net.global_step.fill_(2000)
+    with torch.no_grad():
+        last = net.odom_predictor.tq_map_conv[6]
+        last.weight.mul_(0.01)
+        last.bias.copy_(torch.tensor([0.8, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0]))
+    a, b = reduced_pair(4), reduced_pair(5, rings=32)      # different sizes -> ragged batch
+    both = net(workload.make_example(net, [[a[0], a[1]], [b[0], b[1]]]))
+    ra = net(workload.make_example(net, [[a[0], a[1]]]))
+    rb = net(workload.make_example(net, [[b[0], b[1]]]))
+    # C_loss = exp(-alpha) * mean over pairs + alpha with alpha = 0
+    assert rel(both["C_loss"], (ra["C_loss"] + rb["C_loss"]) / 2) < 1e-4
+    assert rel(both["translation_preds"], torch.cat([ra["translation_preds"], rb["translation_preds"]])) < 1e-4
+    assert rel(both["translation_loss"], (ra["translation_loss"] + rb["translation_loss"]) / 2) < 1e-3
