@@ -283,3 +283,27 @@ def test_segmented_batchnorm_matches_torch_per_frame(hip):
     gx, dg, db = hip.segbn_bwd(x, y, gy, seg, S, 1200, bn.weight.detach(), mean, invstd, 0.01)
     assert float((gx - xr.grad).abs().max()) < 2e-5
     assert float((dg - ref_bn.weight.grad).abs().max()) < 2e-4 and float((db - ref_bn.bias.grad).abs().max()) < 2e-4
+
+
+def test_c5_dense_scan_geometry(hip):
+    """BASELINE config C5 geometry: 128-ring scan (~263k points), 0.1 m cubic voxels, sparse shape [81,768,1408],
+    max_voxels 2^18.  Voxel ids and the level-0/1 rulebooks are bit-exact vs the oracle; one conv agrees."""
+    pts = S.scan(n_el=128)
+    assert len(pts) > 260000
+    v, c, n = _vox_both(hip, pts, S.PC_RANGE, S.VOXEL_SIZE_DENSE, S.MAX_POINTS_PER_VOXEL, 1 << 18)
+    assert len(c) > 50000
+    coords = np.concatenate([np.zeros((len(c), 1), np.int32), c.cpu().numpy()], 1)
+    dims = [81, 768, 1408]
+    idx = hip.SiteIndex(dev(coords), 1, dims)
+    nbr = hip.rulebook_subm(idx, [3, 3, 3])
+    onbr = O.rulebook_subm(coords, 1, dims)
+    assert (nbr.cpu().numpy() == onbr).all()
+    oidx, nb, nbT = hip.rulebook_conv(idx, [3, 3, 3], [2, 2, 2], [1, 1, 1])
+    oc, od, onb, onbT = O.rulebook_conv(coords, 1, dims, [3, 3, 3], [2, 2, 2], [1, 1, 1])
+    assert od == [41, 384, 704] and (oidx.coords.cpu().numpy() == oc).all()
+    assert (nb.cpu().numpy() == onb).all() and (nbT.cpu().numpy() == onbT).all()
+    g = torch.Generator(device="cuda").manual_seed(0)
+    x = torch.randn((len(c), 16), device="cuda", generator=g)
+    W = torch.randn((27, 16, 32), device="cuda", generator=g) * 0.1
+    y = hip.spconv_fwd(x, W, None, nb)
+    np.testing.assert_allclose(y.cpu().numpy(), O.spconv_fwd(x.cpu().numpy(), W.cpu().numpy(), None, onb), **CONV_TOL)
