@@ -11,7 +11,7 @@ from torch import nn
 
 import rslo.models.custom_resnet_spc as resnet
 from rslo.data.dataset import from_pointwise_local_transformation_tch
-from rslo.layers.confidence import ConfidenceModule
+from rslo.layers.confidence import ConfidenceModule, masked_spatial_softmax
 from rslo.layers.MaskConv import MaskConv
 from rslo.models.odom_pred_base import OdomPredEncDecBase, conf_trunk
 from rslo.utils.pose_utils import rotate_vec_by_q
@@ -94,14 +94,20 @@ class UNOdomPredEncDecSVDTempMaskBase(OdomPredEncDecBase):
 
         if not self.dense_predict:
             raise NotImplementedError("the fc (non-dense) head is outside the RSLO hot path")
-        t_conf = self.t_map_conf(x_tail, extra_mask=input_mask)
-        r_conf = self.q_map_conf(x_tail, extra_mask=input_mask)
+        # The reference evaluates both confidence heads twice on the same features (T = 1 with gradient, T = 20 on
+        # x.detach(), odom_pred.py:242-243,257-258).  The logits of the second pass are identical, so they are reused;
+        # its only other effect -- a second running-statistics update of the trunk's BatchNorms with the same batch
+        # statistics -- is replayed algebraically.
+        bn_before = self._snapshot_bn((self.t_map_conf, self.q_map_conf))
+        t_conf, t_logit = self.t_map_conf(x_tail, extra_mask=input_mask, return_logit=True)
+        r_conf, r_logit = self.q_map_conf(x_tail, extra_mask=input_mask, return_logit=True)
         tq_map_g, odom = self.vote(tq_map, t_conf, r_conf)
         odoms = [odom]
 
-        with torch.no_grad():   # temperature-20 confidences on detached features -> loss masks
-            temp_tq_conf = torch.cat([self.t_map_conf(x_tail.detach(), extra_mask=input_mask, temperature=20),
-                                      self.q_map_conf(x_tail.detach(), extra_mask=input_mask, temperature=20)], 1)
+        with torch.no_grad():   # temperature-20 confidences -> loss masks
+            temp_tq_conf = torch.cat([masked_spatial_softmax(t_logit.detach(), input_mask, 20),
+                                      masked_spatial_softmax(r_logit.detach(), input_mask, 20)], 1)
+            self._replay_bn_update(bn_before)
         pyramid_motion = py_preds + [[tq_map * input_mask, input_mask * temp_tq_conf]]
         for p in range(2, len(pyramid_motion) + 1):
             pyramid_motion[-p][1] = pyramid_motion[-p][1] * self.hier_weight_gen(pyramid_motion[-(p - 1)][1])
@@ -116,6 +122,30 @@ class UNOdomPredEncDecSVDTempMaskBase(OdomPredEncDecBase):
             rotations.append(r)
         return {"translation_preds": translations, "rotation_preds": rotations, "tq_map_g": tq_map_g * input_mask,
                 "pyramid_motion": pyramid_motion, "transformed_inputs": None, "t_conf": t_conf, "r_conf": r_conf}
+
+    def _snapshot_bn(self, modules):
+        """Running statistics of the training-mode BatchNorms inside `modules`, before they are updated."""
+        snap = []
+        if not self.training:
+            return snap
+        for mod in modules:
+            for m in mod.modules():
+                if isinstance(m, nn.modules.batchnorm._BatchNorm) and m.training and m.track_running_stats:
+                    snap.append((m, m.running_mean.clone(), m.running_var.clone()))
+        return snap
+
+    @staticmethod
+    def _replay_bn_update(snap):
+        """Apply the SAME momentum update once more: r1 = (1-m) r0 + m v  =>  r2 = (1-m) r1 + m v = 2 r1 - r0
+        + m (r0 - r1)... written with v eliminated: r2 = r1 + (1 - m) (r1 - r0)."""
+        for m, mean0, var0 in snap:
+            mom = m.momentum
+            # through .data: the first pass's autograd node holds these buffers (training-mode backward never reads
+            # them), and the reference's second forward updates them in place all the same
+            m.running_mean.data.add_((m.running_mean.data - mean0) * (1.0 - mom))
+            m.running_var.data.add_((m.running_var.data - var0) * (1.0 - mom))
+            if m.num_batches_tracked is not None:
+                m.num_batches_tracked.add_(1)
 
     def vote(self, tq_map, t_conf, r_conf):
         """Ego-motion voting (odom_pred.py:347-357): confidence-weighted mean of the global maps."""

@@ -283,10 +283,12 @@ def main():
         x = rn(2, 6, H, W)
         x = x * (torch.rand(2, 1, H, W, generator=g) > 0.6).float()
         xs.append(x)
-    hsd = {k: np_(v) for k, v in head.state_dict().items()}
+    hsd = {k: np_(v).copy() for k, v in head.state_dict().items()}   # copy: numpy views alias the live buffers
     res = head([x.clone() for x in xs])
+    after = {k: np_(v) for k, v in head.state_dict().items() if "running_" in k or "num_batches" in k}
     np.savez_compressed(os.path.join(HERE, "head_small.npz"),
                         **{"sd/" + k: v for k, v in hsd.items()},
+                        **{"sd_after/" + k: v for k, v in after.items()},
                         **{"x%d" % i: np_(x) for i, x in enumerate(xs)},
                         t_pred=np_(res["translation_preds"][0]), r_pred=np_(res["rotation_preds"][0]),
                         tq_map_g=np_(res["tq_map_g"]), t_conf=np_(res["t_conf"]), r_conf=np_(res["r_conf"]),

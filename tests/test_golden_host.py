@@ -212,6 +212,11 @@ def check_head(head, g, device):
         np.testing.assert_allclose(p.detach().cpu().numpy(), g["py%d_pred" % i], rtol=1e-3,
                                    atol=1e-5 * float(np.abs(g["py%d_pred" % i]).max()) + 1e-4)
         np.testing.assert_allclose(m.detach().cpu().numpy(), g["py%d_mask" % i], rtol=1e-3, atol=1e-7)
+    # BatchNorm running statistics after one training forward (the confidence trunks are updated twice per step)
+    sd = head.state_dict()
+    for k in g.files:
+        if k.startswith("sd_after/"):
+            np.testing.assert_allclose(sd[k[9:]].cpu().numpy(), g[k], rtol=2e-4, atol=1e-6, err_msg=k)
     return res
 
 
