@@ -216,6 +216,30 @@ RSLO_API int rslo_icp_step(const float *p1, const float *n1, const float *tgt, c
 RSLO_API int rslo_transform_points(const float *x, const float *R, const float *t, int B, int M, float *out,
                           void *stream);
 
+/* a21  pyramid supervision of the per-cell local transformation maps, all levels in one launch
+ *      (rslo/models/voxel_odom_net.py:706-760 pyramid part of create_loss; target map of gen_tq_maps
+ *      voxel_odom_net.py:575-600 = generate_pointwise_local_transformation_tch rslo/data/dataset.py:118-168,
+ *      nearest-resampled per level by F.interpolate; per-sample masked L2 of AdaptiveWeightedL2Loss
+ *      rslo/core/losses.py:144-197).
+ *      level l: pred [B,7,h,w] (t_l xyz, q wxyz), mask [B,Cm,h,w] (channel 0 weighs the translation part,
+ *      channel Cm-1 the rotation part).  tq [B,7] = global pose targets (t, q wxyz).  The target of a cell is
+ *      t_l = R(q)^-1 (t_g - x) + x with x the centre of the nearest cell of the H0 x W0 map.
+ *      loss_b [L,B,2] = sum(diff^2 mask) / (n_ch sum(mask) + 1e-12) for (T, R);  den [L,B,2] = n_ch sum(mask).
+ *      done: [L*B] int32 counters, zero on entry, left zero on exit.  bwd writes levels[l].dpred [B,7,h,w]. */
+typedef struct {
+  const float *pred;
+  const float *mask;
+  float *dpred;          /* bwd only */
+  int32_t h, w, mask_channels;
+} RsloPyramidLevel;
+RSLO_API size_t rslo_pyramid_l2_ws_bytes(const RsloPyramidLevel *h_levels, int n_levels, int B);
+RSLO_API int rslo_pyramid_l2_fwd(const RsloPyramidLevel *h_levels, int n_levels, int B, const float *tq, int H0,
+                                 int W0, const float *h_origin3, const float *h_vsize3, void *ws, size_t ws_bytes,
+                                 int32_t *done, float *loss_b, float *den, void *stream);
+RSLO_API int rslo_pyramid_l2_bwd(const RsloPyramidLevel *h_levels, int n_levels, int B, const float *tq, int H0,
+                                 int W0, const float *h_origin3, const float *h_vsize3, const float *grad_loss_b,
+                                 const float *den, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

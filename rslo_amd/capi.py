@@ -58,6 +58,9 @@ SIGNATURES = {
     "rslo_icp_ws_bytes": (_sz, [_i, _i]),
     "rslo_icp_step": (C.c_int, [_vp] * 6 + [_i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
     "rslo_transform_points": (C.c_int, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "rslo_pyramid_l2_ws_bytes": (_sz, [_vp, _i, _i]),
+    "rslo_pyramid_l2_fwd": (C.c_int, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp]),
+    "rslo_pyramid_l2_bwd": (C.c_int, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
 }
 
 
@@ -429,3 +432,55 @@ def transform_points(x, R, t):
     _chk(lib().rslo_transform_points(_ptr(x, torch.float32, "x"), _ptr(R, torch.float32, "R"),
                                      _ptr(t, torch.float32, "t"), B, M, _ptr(out), _stream()), "rslo_transform_points")
     return out
+
+
+# --------------------------------------------------------------------------------------
+# pyramid supervision
+# --------------------------------------------------------------------------------------
+class _PyramidLevel(C.Structure):
+    _fields_ = [("pred", C.c_void_p), ("mask", C.c_void_p), ("dpred", C.c_void_p),
+                ("h", C.c_int32), ("w", C.c_int32), ("mask_channels", C.c_int32)]
+
+
+_py_done = {}
+
+
+def _pyramid_levels(preds, masks, dpreds=None):
+    B = preds[0].shape[0]
+    arr = (_PyramidLevel * len(preds))()
+    for l, (p, m) in enumerate(zip(preds, masks)):
+        if p.dim() != 4 or p.shape[1] != 7 or m.shape[0] != B or p.shape[0] != B or m.shape[2:] != p.shape[2:]:
+            raise RsloHipError("pyramid_l2: level %d pred %s / mask %s" % (l, tuple(p.shape), tuple(m.shape)))
+        arr[l].pred = _ptr(p, torch.float32, "pred").value
+        arr[l].mask = _ptr(m, torch.float32, "mask").value
+        arr[l].dpred = _ptr(dpreds[l], torch.float32, "dpred").value if dpreds is not None else None
+        arr[l].h, arr[l].w, arr[l].mask_channels = p.shape[2], p.shape[3], m.shape[1]
+    return arr, B
+
+
+def pyramid_l2_fwd(preds, masks, tq, H0, W0, origin, vsize):
+    """preds[l] [B,7,h,w], masks[l] [B,Cm,h,w], tq [B,7] -> (loss_b [L,B,2], den [L,B,2])."""
+    arr, B = _pyramid_levels(preds, masks)
+    dev = tq.device
+    L = len(preds)
+    done = _py_done.get(dev)
+    if done is None or done.numel() < L * B:
+        done = _py_done[dev] = torch.zeros((max(L * B, 64),), dtype=torch.int32, device=dev)
+    wsb = lib().rslo_pyramid_l2_ws_bytes(arr, L, B)
+    ws = _ws(wsb, dev)
+    loss_b = torch.empty((L, B, 2), dtype=torch.float32, device=dev)
+    den = torch.empty((L, B, 2), dtype=torch.float32, device=dev)
+    _chk(lib().rslo_pyramid_l2_fwd(arr, L, B, _ptr(tq, torch.float32, "tq"), int(H0), int(W0),
+                                   _F3(*[float(v) for v in origin]), _F3(*[float(v) for v in vsize]), _ptr(ws), wsb,
+                                   _ptr(done), _ptr(loss_b), _ptr(den), _stream()), "rslo_pyramid_l2_fwd")
+    return loss_b, den
+
+
+def pyramid_l2_bwd(preds, masks, tq, H0, W0, origin, vsize, grad_loss_b, den):
+    dpreds = [torch.empty_like(p) for p in preds]
+    arr, B = _pyramid_levels(preds, masks, dpreds)
+    _chk(lib().rslo_pyramid_l2_bwd(arr, len(preds), B, _ptr(tq, torch.float32, "tq"), int(H0), int(W0),
+                                   _F3(*[float(v) for v in origin]), _F3(*[float(v) for v in vsize]),
+                                   _ptr(grad_loss_b, torch.float32, "grad"), _ptr(den, torch.float32, "den"),
+                                   _stream()), "rslo_pyramid_l2_bwd")
+    return dpreds

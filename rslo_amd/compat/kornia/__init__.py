@@ -24,10 +24,9 @@ def quaternion_to_rotation_matrix(quaternion):
     twx, twy, twz = tx * w, ty * w, tz * w
     txx, txy, txz = tx * x, ty * x, tz * x
     tyy, tyz, tzz = ty * y, tz * y, tz * z
-    one = torch.tensor(1.0, dtype=q.dtype, device=q.device)
-    m = torch.stack([one - (tyy + tzz), txy - twz, txz + twy,
-                     txy + twz, one - (txx + tzz), tyz - twx,
-                     txz - twy, tyz + twx, one - (txx + tyy)], dim=-1).view(-1, 3, 3)
+    m = torch.stack([1.0 - (tyy + tzz), txy - twz, txz + twy,
+                     txy + twz, 1.0 - (txx + tzz), tyz - twx,
+                     txz - twy, tyz + twx, 1.0 - (txx + tyy)], dim=-1).view(-1, 3, 3)
     if len(quaternion.shape) == 1:
         m = torch.squeeze(m, dim=0)
     return m

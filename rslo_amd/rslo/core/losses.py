@@ -67,6 +67,59 @@ class AdaptiveWeightedL2Loss(Loss):
         return _adaptive_reduce(loss_b, self.alpha, focal_gamma)
 
 
+class _PyramidL2Fn(torch.autograd.Function):
+    """Masked per-sample L2 of every pyramid level against the on-the-fly local-transform target
+    (rslo_pyramid_l2_fwd / _bwd): (tq, geom, masks, *preds) -> loss_b [L,B,2] (T, R)."""
+
+    @staticmethod
+    def forward(ctx, tq, geom, masks, *preds):
+        preds = [p.contiguous() for p in preds]
+        loss_b, den = capi.pyramid_l2_fwd(preds, masks, tq, *geom)
+        ctx.save_for_backward(tq, den, *preds)
+        ctx.masks, ctx.geom = masks, geom
+        return loss_b
+
+    @staticmethod
+    def backward(ctx, g):
+        tq, den, *preds = ctx.saved_tensors
+        dpreds = capi.pyramid_l2_bwd(preds, ctx.masks, tq, *ctx.geom, g.contiguous(), den)
+        return (None, None, None, *dpreds)
+
+
+_const_cache = {}
+
+
+def _const(values, device):
+    """Small constant vector on `device`, uploaded once (a per-step torch.tensor(list) would sync the stream)."""
+    key = (tuple(float(v) for v in values), str(device))
+    t = _const_cache.get(key)
+    if t is None:
+        t = _const_cache[key] = torch.tensor(key[0], dtype=torch.float32, device=device)
+    return t
+
+
+def pyramid_l2_losses(preds, masks, tq, geom, loss_T, loss_R):
+    """All pyramid levels in one fused launch.  preds[l] [B,7,h,w], masks[l] [B,Cm,h,w] (no gradient),
+    tq [B,7] detached targets, geom = (H0, W0, origin xyz, cell size xyz) of the target map.
+    Returns `scaled` [L,2]: loss_weight * AdaptiveWeightedL2Loss per level for (translation, rotation)."""
+    masks = [m.detach().contiguous().float() for m in masks]
+    loss_b = _PyramidL2Fn.apply(tq.detach().contiguous().float(), geom, masks, *[p.float() for p in preds])
+    B = loss_b.shape[1]
+    alpha = torch.cat([loss_T.alpha, loss_R.alpha])                      # [2]
+    y = torch.exp(-alpha) * loss_b                                       # [L,B,2]
+    if loss_T.focal_gamma == 0 and loss_R.focal_gamma == 0:
+        out = y.sum(1) / (B + 1e-12) + alpha                             # fw = 1 / (B + 1e-12)
+    else:
+        cols = []
+        for k, g in enumerate((loss_T.focal_gamma, loss_R.focal_gamma)):
+            fw = y[..., k] ** g
+            fw = fw / (fw.sum(1, keepdim=True) + 1e-12)
+            cols.append((fw * y[..., k]).sum(1))
+        out = torch.stack(cols, -1) + alpha
+    # python-scalar weights (the translation / rotation weights change every warm-up step: no constant upload)
+    return torch.cat([out[:, :1] * loss_T._loss_weight, out[:, 1:] * loss_R._loss_weight], 1)
+
+
 def span_cov2(cov_param):
     """7 covariance parameters -> (Sigma [..,3,3], eigenvectors V): cumulative eigenvalues
     l1 = p0, l2 = l1 + p1, l3 = l2 + p2; V = R(quat p3..6 / (|.| + 1e-9)) with the channels read as

@@ -23,6 +23,8 @@ import torchplus
 from torch import nn
 from torch.nn import functional as F
 
+from rslo.core import losses
+from rslo.data.dataset import _grid_geometry as _tq_map_geometry
 from rslo.data.dataset import generate_pointwise_local_transformation_tch
 from rslo.models import middle, odom_pred, voxel_encoder
 
@@ -111,6 +113,7 @@ class UnVoxelOdomNetICP3(nn.Module):
         self.icp_iter = icp_iter
         self.measure_time = measure_time
         self.cpu_extras = False
+        self.fused_pyramid = True      # pyramid supervision through rslo_pyramid_l2_* (GPU tensors)
 
         self.voxel_feature_extractor = voxel_encoder.get_vfe_class(vfe_class_name)(
             num_input_features, vfe_use_norm, num_filters=vfe_num_filters, with_distance=with_distance,
@@ -309,10 +312,15 @@ class UnVoxelOdomNetICP3(nn.Module):
             preds_dict, example, self._translation_loss, self._rotation_loss,
             pyramid_rotation_loss=self._pyramid_rotation_loss,
             pyramid_translation_loss=self._pyramid_translation_loss, consistency_loss=self._consistency_loss)
-        pyramid_loss = torch.zeros([1], dtype=T_preds[0].dtype, device=T_preds[0].device)
         n = len(py_T)
-        for i, (tl, rl) in enumerate(zip(py_T, py_R)):
-            pyramid_loss = pyramid_loss + self._pyloss_exp_w_base ** (n - i) * (tl + rl)
+        if getattr(self, "_py_scaled", None) is not None:     # fused pyramid path: one weighted sum over [L,2]
+            w = losses._const([self._pyloss_exp_w_base ** (n - i) for i in range(n)], T_preds[0].device)
+            pyramid_loss = (w * self._py_scaled.sum(1)).sum().reshape(1)
+            self._py_scaled = None
+        else:
+            pyramid_loss = torch.zeros([1], dtype=T_preds[0].dtype, device=T_preds[0].device)
+            for i, (tl, rl) in enumerate(zip(py_T, py_R)):
+                pyramid_loss = pyramid_loss + self._pyloss_exp_w_base ** (n - i) * (tl + rl)
         loss = t_loss + r_loss + pyramid_loss + C_loss
         self.end_timer("create_loss forward")
         return {"loss": loss, "translation_loss": t_loss.detach(), "rotation_loss": r_loss.detach(),
@@ -349,7 +357,11 @@ class UnVoxelOdomNetICP3(nn.Module):
             if len(preds_dict["middle_conf_preds"]) == 0:
                 raise NotImplementedError("hier_points supervision without a covariance head (SURVEY.md 8f-4)")
             feats = preds_dict["voxel_features"]
-            cols = [0, 1, 2, 4, 5, 6] if feats[0].shape[1] > 6 else [0, 1, 2, 3, 4, 5]
+            # xyz + normal columns (intensity dropped); slices, not an index list (no host->device index upload)
+            if feats[0].shape[1] > 6:
+                feats = [torch.cat([f[:, 0:3], f[:, 4:7]], 1) for f in feats]
+            else:
+                feats = [f[:, 0:6] for f in feats]
             B = example["num_voxels"][0].shape[0]
             # rows of sample b inside frame t (frames hold the samples back to back)
             if B == 1:
@@ -361,7 +373,7 @@ class UnVoxelOdomNetICP3(nn.Module):
                 offs = [sum(counts[t][:b]) for t in range(len(feats))]
                 # the reference truncates every frame of a sample to the shortest one (voxel_odom_net.py:646-651)
                 min_len = min(counts[t][b] for t in range(len(feats)))
-                points = [feats[t][offs[t]:offs[t] + min_len][:, cols][None] for t in range(len(feats))]
+                points = [feats[t][offs[t]:offs[t] + min_len][None] for t in range(len(feats))]
                 confs = [preds_dict["middle_conf_preds"][t][offs[t]:offs[t] + min_len][None] for t in range(len(feats))]
                 per_sample.append(create_cycle_constraint_data(points, 1) + create_cycle_constraint_data(confs, 1))
                 lens.append(min_len)
@@ -375,7 +387,9 @@ class UnVoxelOdomNetICP3(nn.Module):
                 padded = [[F.pad(x, (0, 0, 0, Lmax - n)) for x in ps] for ps, n in zip(per_sample, lens)]
                 pts1, pts2, cov1, cov2 = (torch.cat([p[k] for p in padded], 0) for k in range(4))
                 cnt_host = [n for n in lens for _ in range(npairs)]
-                cnt_dev = torch.tensor(cnt_host, dtype=torch.int32, device=device)
+                cnt_dev = torch.tensor(cnt_host, dtype=torch.int32)
+                if device.type == "cuda":      # pinned + async: a pageable upload would drain the stream
+                    cnt_dev = cnt_dev.pin_memory().to(device, non_blocking=True)
 
             weights = [0.01, 0.01, 0.05, 0.1, 1]
             for R_pred, T_pred, weight in zip(rotation_preds, translation_preds, weights[-len(translation_preds):]):
@@ -402,21 +416,36 @@ class UnVoxelOdomNetICP3(nn.Module):
             rotation_targets = rotation_targets * torch.sign(rotation_targets[:, 0:1])
             translation_targets = (res_r @ T_pred[..., None].detach() + res_t[..., None]).squeeze(-1)
 
-        if len(pyramid_preds) > 0:
-            example["tq_maps"] = self.gen_tq_maps(
-                torch.cat([translation_targets, rotation_targets], dim=-1).reshape(-1, 7),
-                spatial_size=pyramid_preds[-1][0].shape[2:], pc_range=self.odom_predictor.point_cloud_range,
-                cubic_tq_map=self.odom_predictor._cubic_pred_height > 0)
-        pyramid_targets = list(example["tq_maps"])
-
         T_loss = sum(translation_loss(p, translation_targets) for p in translation_preds)
         R_loss = sum(rotation_loss(p, rotation_targets) for p in rotation_preds)
         if pyramid_translation_loss is None or pyramid_rotation_loss is None:
             return T_loss, R_loss
 
+        self._py_scaled = None
+        tq_targets = torch.cat([translation_targets, rotation_targets], dim=-1).reshape(-1, 7)
+        example["tq_targets"] = tq_targets
+        levels = [(pp[0], pp[1]) if isinstance(pp, (tuple, list)) else (pp, None) for pp in pyramid_preds]
+        cubic = self.odom_predictor._cubic_pred_height > 0
+        fused = (self.fused_pyramid and len(levels) > 0 and not cubic and tq_targets.is_cuda
+                 and all(m is not None and p.dim() == 4 for p, m in levels))
+        if fused:
+            # targets are recomputed per cell inside the kernel: the [B,7,H,W] map of gen_tq_maps is never built
+            H0, W0 = (int(v) for v in levels[-1][0].shape[2:])
+            _, vs, origin = _tq_map_geometry([1, H0, W0], self.odom_predictor.point_cloud_range)
+            scaled = losses.pyramid_l2_losses([p for p, _ in levels], [m for _, m in levels], tq_targets,
+                                              (H0, W0, origin, vs), pyramid_translation_loss, pyramid_rotation_loss)
+            self._py_scaled = scaled
+            pyramid_T_losses = list(scaled[:, 0:1].unbind(0))
+            pyramid_R_losses = list(scaled[:, 1:2].unbind(0))
+            return T_loss, R_loss, pyramid_T_losses, pyramid_R_losses, C_loss
+
+        if len(pyramid_preds) > 0:
+            example["tq_maps"] = self.gen_tq_maps(
+                tq_targets, spatial_size=pyramid_preds[-1][0].shape[2:],
+                pc_range=self.odom_predictor.point_cloud_range, cubic_tq_map=cubic)
+        pyramid_targets = list(example["tq_maps"])
         pyramid_T_losses, pyramid_R_losses = [], []
-        for pp in pyramid_preds:
-            pred, pred_mask = (pp[0], pp[1]) if isinstance(pp, (tuple, list)) else (pp, None)
+        for pred, pred_mask in levels:
             T_p, R_p = pred[:, :3], pred[:, 3:]
             T_tgt, R_tgt = pyramid_targets[0][:, :3], pyramid_targets[0][:, 3:]
             if T_tgt.shape != T_p.shape:

@@ -105,7 +105,9 @@ class SparseConvTensor:
         if offs is None:
             b = index.coords[:, 0].contiguous()
             probe = torch.arange(self.batch_size + 1, dtype=b.dtype, device=b.device)
-            offs = torch.searchsorted(b, probe).tolist()
+            dev = torch.searchsorted(b, probe).to(torch.int32)
+            index.batch_offs_dev = dev
+            offs = dev.tolist()
             index.batch_offs = offs
         return offs
 
@@ -204,10 +206,7 @@ def _segmented_bn_act(x, bn, slope):
     """Training-mode nn.BatchNorm1d over each frame of the batched tensor, fused with the activation."""
     index = x.site_index()
     offs = x.batch_offsets()
-    dev_off = getattr(index, "batch_offs_dev", None)
-    if dev_off is None:
-        dev_off = torch.tensor(offs, dtype=torch.int32, device=x.features.device)
-        index.batch_offs_dev = dev_off
+    dev_off = index.batch_offs_dev
     S = x.batch_size
     max_len = max(offs[b + 1] - offs[b] for b in range(S))
     y = _SegBNActFn.apply(x.features, bn.weight, bn.bias, bn, dev_off, S, max_len, slope)
@@ -366,6 +365,8 @@ class SparseSequential(SparseModule):
         for m in self._modules.values():
             if isinstance(m, (SparseConvolution, SparseSequential)):
                 x = m.plan(x)
+            elif isinstance(m, nn.modules.batchnorm._BatchNorm) and m.training and x.indices.is_cuda:
+                x.batch_offsets()      # per-frame statistics need the row ranges: read them here, not mid-forward
         return x
 
     def forward(self, x):
