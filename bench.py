@@ -231,7 +231,7 @@ def main():
         ret = model(ex)
         ret["loss"].mean().backward()
         if dist_on:
-            average_gradients(net)
+            average_gradients(net, mean=True)
         if not args.no_optim:
             torch.nn.utils.clip_grad_norm_(params, 10.0)
             opt.step()

@@ -99,6 +99,9 @@ class OdomPredEncDecBase(nn.Module):
         self.blocks = nn.ModuleList(blocks)
         self.deblocks = nn.ModuleList(deblocks)
         self.skip_blocks = nn.ModuleList(skip_blocks)
+        # registration slot of the pyramid heads: subclasses fill it, its position fixes the parameter ORDER
+        # (optimizer checkpoints index parameters by position; reference odom_pred.py registers it here)
+        self.pyramid_motion_blocks = nn.ModuleList()
 
         last = num_upsample_filters[-1]
         self.tq_map_conv = nn.Sequential(nn.Conv2d(last, 64, kernel_size=3, padding=1), self.BatchNorm2d(64),

@@ -1,39 +1,62 @@
-"""Data-parallel helpers of the hot path (reference: rslo/utils/distributed_utils.py:53-71,238-314).
+"""Data-parallel helpers of the training driver (reference: rslo/utils/distributed_utils.py:12-314).
 
-The path shards by frame pair: every rank runs the whole network on its own samples and the only
-mandatory exchange is the gradient all-reduce.  On MI355X that is RCCL over xGMI through torch.distributed
-(backend "nccl"); ring all-reduce is per-link bound, so the 48 MB of gradients go as ONE flat bucket instead of
-the reference's per-parameter all-reduce loop (213 latency-bound messages)."""
+The path shards by frame pair: every rank runs the whole network on its own samples; the only mandatory exchange
+is the gradient all-reduce.  On MI355X that is RCCL over xGMI through torch.distributed (backend "nccl").  xGMI rings
+are per-link bound and launch-latency dominated for small messages, so the ~12 M fp32 gradients (48 MB) travel as ONE
+flat bucket instead of the reference's per-parameter loop (213 messages), and parameters are broadcast as one
+flat buffer per dtype.
+
+Semantics kept from the reference:
+  * `average_gradients` SUMS (the driver divides the loss by the world size first, train_hdf5.py:666-669);
+    `mean=True` folds the division in (used by bench.py);
+  * the samplers reproduce the reference's index lists exactly (numpy global RNG seeded with 7,
+    distributed_utils.py:212,270), so a resumed or multi-rank run sees the same samples.
+"""
 import math
+import os
 
+import numpy as np
 import torch
 import torch.distributed as dist
+from torch.nn import Module
 from torch.utils.data.sampler import Sampler
 
 
-def average_gradients(model, bucket=True):
-    """All-reduce (mean) the gradients of `model` across ranks: one flat fp32 bucket."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+def _active():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def gradients_multiply(model, multiplier=1):
+    grads = [p.grad for p in model.parameters() if p.requires_grad and p.grad is not None]
+    if grads:
+        torch._foreach_mul_(grads, multiplier)
+
+
+def average_gradients(model, bucket=True, mean=False):
+    """All-reduce the gradients of `model` across ranks as one flat fp32 bucket (sum; mean=True divides by the
+    world size)."""
+    if not _active():
         return
-    params = [p for p in model.parameters() if p.requires_grad and p.grad is not None]
-    if not params:
+    grads = [p.grad for p in model.parameters() if p.requires_grad and p.grad is not None]
+    if not grads:
         return
     world = dist.get_world_size()
     if not bucket:
-        for p in params:
-            dist.all_reduce(p.grad.data)
-            p.grad.data.div_(world)
+        for g in grads:
+            dist.all_reduce(g)
+            if mean:
+                g.div_(world)
         return
-    grads = [p.grad for p in params]
     flat = torch.cat([g.reshape(-1) for g in grads])
     dist.all_reduce(flat)
-    flat.div_(world)
+    if mean:
+        flat.div_(world)
     torch._foreach_copy_(grads, [c.view_as(g) for c, g in zip(flat.split([g.numel() for g in grads]), grads)])
 
 
 def broadcast_params(model, src=0):
-    """Rank `src` -> all, one flattened broadcast per dtype (reference: per-tensor loop, :68-71)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    """Rank `src` -> all: parameters and buffers, one flattened broadcast per dtype."""
+    if not _active():
         return
     by_dtype = {}
     for t in model.state_dict().values():
@@ -47,34 +70,157 @@ def broadcast_params(model, src=0):
             off += t.numel()
 
 
-class DistributedGivenIterationSamplerEpoch(Sampler):
-    """Index shard of one rank for a fixed number of iterations: every rank shuffles the dataset with the SAME
-    seed, repeats it to cover total_iter * batch_size * world_size samples and takes its contiguous slice
-    [total_size * rank, total_size * (rank + 1)) (reference :238-314; seed 7, :270).  Yields (index, seed)."""
+class DistModule(Module):
+    """Keeps replicas in sync at construction (broadcast); gradients are reduced explicitly by
+    `average_gradients` after backward."""
 
-    def __init__(self, dataset_len, total_iter, batch_size, world_size=None, rank=None, last_iter=-1, seed=7):
-        if world_size is None:
-            world_size = dist.get_world_size() if dist.is_initialized() else 1
-        if rank is None:
-            rank = dist.get_rank() if dist.is_initialized() else 0
-        assert rank < world_size
-        self.dataset_len = dataset_len
-        self.total_iter, self.batch_size = total_iter, batch_size
-        self.world_size, self.rank, self.last_iter, self.seed = world_size, rank, last_iter, seed
-        self.total_size = total_iter * batch_size
-        self.indices = self._gen()
+    def __init__(self, module):
+        super().__init__()
+        self.module = module
+        broadcast_params(self.module)
 
-    def _gen(self):
-        g = torch.Generator().manual_seed(self.seed)
-        all_size = self.total_size * self.world_size
-        reps = int(math.ceil(all_size / self.dataset_len))
-        idx = torch.cat([torch.randperm(self.dataset_len, generator=g) for _ in range(reps)])[:all_size]
-        beg = self.total_size * self.rank
-        return idx[beg:beg + self.total_size].tolist()
+    def forward(self, *inputs, **kwargs):
+        return self.module(*inputs, **kwargs)
+
+
+class ParallelWrapper(Module):
+    def __init__(self, net, parallel_mode="none"):
+        super().__init__()
+        assert parallel_mode in ("dist", "data_parallel", "none")
+        self.parallel_mode = parallel_mode
+        if parallel_mode == "none":
+            self.net = net
+        elif parallel_mode == "dist":
+            self.net = DistModule(net)
+        else:
+            raise NotImplementedError("single-process DataParallel is not an MI355X configuration: "
+                                      "one process per GPU (parallel_mode='dist')")
+        self.module = net
+
+    def forward(self, *inputs, **kwargs):
+        return self.net(*inputs, **kwargs)
+
+
+def dist_init(port):
+    """SLURM launch (SLURM_PROCID / SLURM_NTASKS / SLURM_NODELIST) -> RCCL process group; returns (rank, world).
+    The first host of the node list becomes MASTER_ADDR; unlike the reference no site-specific host-name slicing
+    (distributed_utils.py:96-101) is applied."""
+    import multiprocessing as mp
+    if mp.get_start_method(allow_none=True) != "spawn":
+        mp.set_start_method("spawn", force=True)
+    rank = int(os.environ["SLURM_PROCID"])
+    world = int(os.environ["SLURM_NTASKS"])
+    nodes = os.environ["SLURM_NODELIST"]
+    if "[" in nodes:                      # "prefix[a-b,c]" -> "prefixa"
+        head, rest = nodes.split("[", 1)
+        first = rest.replace("]", "").split(",")[0].split("-")[0]
+        nodes = head + first
+    addr = nodes.split(",")[0]
+    if torch.cuda.is_available():
+        torch.cuda.set_device(rank % torch.cuda.device_count())
+    os.environ.update(MASTER_PORT=str(port), MASTER_ADDR=addr, WORLD_SIZE=str(world), RANK=str(rank))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group(backend="nccl")
+    return dist.get_rank(), dist.get_world_size()
+
+
+def _world_rank(world_size, rank):
+    if world_size is None:
+        world_size = dist.get_world_size()
+    if rank is None:
+        rank = dist.get_rank()
+    assert rank < world_size
+    return world_size, rank
+
+
+def _n(dataset):
+    return dataset if isinstance(dataset, int) else len(dataset)
+
+
+class DistributedSequatialSampler(Sampler):
+    """Un-shuffled strided shard (evaluation): rank r gets indices r, r + R, r + 2R, ... of the dataset padded by
+    wrap-around to a multiple of R (reference :117-175)."""
+
+    def __init__(self, dataset, num_replicas=None, rank=None):
+        num_replicas, rank = _world_rank(num_replicas, rank)
+        self.dataset, self.num_replicas, self.rank, self.epoch = dataset, num_replicas, rank, 0
+        self.num_samples = int(math.ceil(_n(dataset) / num_replicas))
+        self.total_size = self.num_samples * num_replicas
 
     def __iter__(self):
-        start = (self.last_iter + 1) * self.batch_size
-        return iter([(i, self.seed) for i in self.indices[start:]])
+        idx = list(range(_n(self.dataset)))
+        idx += idx[:self.total_size - len(idx)]
+        return iter(idx[self.rank:self.total_size:self.num_replicas])
 
     def __len__(self):
-        return self.total_size - (self.last_iter + 1) * self.batch_size
+        return self.num_samples
+
+    def set_epoch(self, epoch):
+        self.epoch = epoch
+
+
+class _GivenIteration(Sampler):
+    """total_iter * batch_size samples for this rank: every rank builds the same global list (seed 7) and takes the
+    contiguous slice [total_size * rank, total_size * (rank + 1)); iteration resumes after `last_iter`."""
+
+    def __init__(self, dataset, total_iter, batch_size, world_size=None, rank=None, last_iter=-1):
+        self.world_size, self.rank = _world_rank(world_size, rank)
+        self.dataset, self.total_iter, self.batch_size, self.last_iter = dataset, total_iter, batch_size, last_iter
+        self.total_size = total_iter * batch_size
+        self.call = 0
+        self.indices = self.gen_new_list()
+
+    def __iter__(self):
+        self.call = 1
+        return iter(self.indices[(self.last_iter + 1) * self.batch_size:])
+
+    def __len__(self):          # display only: the resume offset is not subtracted (reference :227-232)
+        return self.total_size
+
+    def set_epoch(self, epoch):
+        pass
+
+    def _shard(self, arr):
+        beg = self.total_size * self.rank
+        out = arr[beg:beg + self.total_size]
+        assert len(out) == self.total_size
+        return out
+
+
+class DistributedGivenIterationSampler(_GivenIteration):
+    """Tile the dataset to the global size, ONE shuffle of the whole list (reference :178-236)."""
+
+    def gen_new_list(self):
+        np.random.seed(7)
+        all_size = self.total_size * self.world_size
+        base = np.arange(_n(self.dataset))[:all_size]
+        reps = (all_size - 1) // base.shape[0] + 1
+        idx = np.tile(base, reps)[:all_size]
+        np.random.shuffle(idx)
+        return self._shard(idx)
+
+
+class DistributedGivenIterationSamplerEpoch(_GivenIteration):
+    """Epoch-wise: a fresh permutation of the dataset per epoch, concatenated; yields (index, seed) where seed is
+    the position in the global list (the dataset uses it to seed its per-sample augmentation).  review_cycle = c > 0
+    (1/c integral) replays every block of c * len(dataset) samples twice in a row (reference :238-314)."""
+
+    def __init__(self, dataset, total_iter, batch_size, world_size=None, rank=None, last_iter=-1, review_cycle=-1):
+        self.review_cycle = review_cycle
+        super().__init__(dataset, total_iter, batch_size, world_size, rank, last_iter)
+
+    def gen_new_list(self):
+        np.random.seed(7)
+        all_size = self.total_size * self.world_size
+        base = np.arange(_n(self.dataset))[:all_size]
+        reps = (all_size - 1) // base.shape[0] + 1
+        idx = np.concatenate([np.random.permutation(base) for _ in range(reps)])
+        seeds = np.arange(idx.size)
+        if self.review_cycle > 0:
+            assert (1 / self.review_cycle) % 1 == 0
+            block = int(self.review_cycle * _n(self.dataset))
+            rows = len(idx) // block
+            idx = np.tile(idx[:rows * block].reshape(rows, block), (1, 2)).reshape(-1)
+            seeds = np.tile(seeds[:rows * block].reshape(rows, block), (1, 2)).reshape(-1)
+        idx, seeds = self._shard(idx[:all_size]), self._shard(seeds[:all_size])
+        return list(zip(list(idx), list(seeds)))

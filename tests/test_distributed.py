@@ -46,7 +46,7 @@ def _worker(rank, world, port, q):
     head.train()
     # (1) manual bucketed all-reduce
     head_loss(head, rank_input(rank)).backward()
-    average_gradients(head)
+    average_gradients(head, mean=True)
     g_manual = torch.cat([p.grad.reshape(-1) for p in head.parameters() if p.grad is not None])
     # (2) DDP with unused parameters tolerated (77 of 290 tensors never get a gradient in the real net)
     head2 = small_head()
@@ -55,8 +55,8 @@ def _worker(rank, world, port, q):
     out = ddp([x.clone() for x in rank_input(rank)])
     ((out["translation_preds"][0] ** 2).sum() + (out["rotation_preds"][0][:, 1:] ** 2).sum()).backward()
     g_ddp = torch.cat([p.grad.reshape(-1) for p in head2.parameters() if p.grad is not None])
-    sampler = DistributedGivenIterationSamplerEpoch(dataset_len=50, total_iter=6, batch_size=2)
-    q.put((rank, g_manual.numpy(), g_ddp.numpy(), [i for i, _ in sampler], {k: v.numpy() for k, v in head.state_dict().items()}))
+    sampler = DistributedGivenIterationSamplerEpoch(list(range(50)), total_iter=60, batch_size=2)
+    q.put((rank, g_manual.numpy(), g_ddp.numpy(), [[int(i), int(sd)] for i, sd in sampler], {k: v.numpy() for k, v in head.state_dict().items()}))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -98,15 +98,43 @@ def test_two_rank_gradient_allreduce_and_sharding():
         head_loss(h, rank_input(r)).backward()
         grads.append(torch.cat([p.grad.reshape(-1) for p in h.parameters() if p.grad is not None]).numpy())
     np.testing.assert_allclose(gm0, (grads[0] + grads[1]) / 2, rtol=1e-4, atol=1e-6)
-    # sharding: same global shuffle, disjoint contiguous slices, 6 iterations x batch 2 each
-    assert len(idx0) == len(idx1) == 12
-    g = torch.Generator().manual_seed(7)
-    perm = torch.cat([torch.randperm(50, generator=g) for _ in range(1)])[:24].tolist()
-    assert idx0 == perm[:12] and idx1 == perm[12:24]
+    # sharding: the reference's own index lists (tests/golden/samplers.json), rank/world taken from the process group
+    gold = samplers_gold()
+    assert idx0 == gold["epoch_r0"] and idx1 == gold["epoch_r1"]
 
 
-def test_sampler_resume():
-    from rslo.utils.distributed_utils import DistributedGivenIterationSamplerEpoch as S
-    full = [i for i, _ in S(100, 10, 3, world_size=4, rank=2)]
-    resumed = [i for i, _ in S(100, 10, 3, world_size=4, rank=2, last_iter=3)]
-    assert resumed == full[12:] and len(full) == 30
+def samplers_gold():
+    import json
+    return json.load(open(os.path.join(os.path.dirname(__file__), "golden", "samplers.json")))
+
+
+def test_samplers_match_reference_index_lists():
+    """Index lists produced by the reference's samplers (make_golden_train.py): epoch-wise with seeds, resume,
+    review cycle, single-shuffle variant and the sequential eval shard."""
+    from rslo.utils import distributed_utils as DU
+    gold = samplers_gold()
+    data = list(range(50))
+    for rank in (0, 1):
+        as_list = lambda it: [[int(i), int(s)] for i, s in it]   # noqa: E731
+        assert as_list(DU.DistributedGivenIterationSamplerEpoch(data, 60, 2, world_size=2, rank=rank)) == gold["epoch_r%d" % rank]
+        assert as_list(DU.DistributedGivenIterationSamplerEpoch(data, 60, 2, world_size=2, rank=rank, last_iter=9)) \
+            == gold["epoch_resume_r%d" % rank]
+        assert as_list(DU.DistributedGivenIterationSamplerEpoch(data, 60, 2, world_size=2, rank=rank, review_cycle=0.5)) \
+            == gold["epoch_review_r%d" % rank]
+        assert [int(i) for i in DU.DistributedGivenIterationSampler(data, 60, 2, world_size=2, rank=rank)] \
+            == gold["given_r%d" % rank]
+        assert [int(i) for i in DU.DistributedSequatialSampler(list(range(51)), 2, rank)] == gold["seq_r%d" % rank]
+    s = DU.DistributedGivenIterationSamplerEpoch(data, 60, 2, world_size=2, rank=1, last_iter=9)
+    assert len(s) == 120 and len(list(s)) == 100
+
+
+def test_average_gradients_sums_like_the_reference_single_process():
+    """World size 1 / no process group: no-op; gradients_multiply scales in place."""
+    from rslo.utils.distributed_utils import average_gradients, gradients_multiply
+    lin = torch.nn.Linear(3, 2)
+    lin(torch.ones(1, 3)).sum().backward()
+    g = lin.weight.grad.clone()
+    average_gradients(lin)
+    assert torch.equal(lin.weight.grad, g)
+    gradients_multiply(lin, 0.5)
+    assert torch.equal(lin.weight.grad, g * 0.5)

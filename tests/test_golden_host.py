@@ -47,7 +47,7 @@ def test_state_dict_keys_and_shapes_match_reference():
     ref = json.load(open(os.path.join(GOLD, "state_dict_keys.json")))
     net = build_net()
     sd = net.state_dict()
-    assert sorted(sd.keys()) == sorted(ref["keys"].keys())
+    assert list(sd.keys()) == list(ref["keys"].keys())      # same ORDER: optimizer checkpoints are positional
     for k, shp in ref["keys"].items():
         assert list(sd[k].shape) == shp, k
     assert sum(p.numel() for p in net.parameters()) == ref["num_params"] == 12004079

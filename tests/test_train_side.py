@@ -1,0 +1,105 @@
+"""Training-side row: optimizer builder + OptimWrapper + OneCycle + checkpoint index against golden
+vectors produced by the reference's own modules (tests/golden/make_golden_train.py)."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import rslo_amd  # noqa: F401
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+sys.path.insert(0, GOLD)
+from make_golden_train import TOTAL_STEP, run, tiny_net   # noqa: E402  (the scripted toy problem, not reference code)
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(os.path.join(GOLD, "train_side.npz")), json.load(open(os.path.join(GOLD, "train_side.json")))
+
+
+def shipped_optimizer_cfg():
+    from rslo.utils import config_text
+    return config_text.shipped_config().train_config.optimizer
+
+
+def test_one_cycle_adam_trajectory_matches_reference(gold):
+    from rslo.builder import lr_scheduler_builder, optimizer_builder
+    g, meta = gold
+    assert meta["total_step"] == TOTAL_STEP
+    net = tiny_net()
+    opt, lrs, moms, traj = run(optimizer_builder, lr_scheduler_builder, shipped_optimizer_cfg(), net)
+    np.testing.assert_allclose(lrs, g["lrs"], rtol=1e-12, atol=0)
+    np.testing.assert_allclose(moms, g["moms"], rtol=1e-12, atol=0)
+    np.testing.assert_allclose(traj, g["traj"], rtol=2e-6, atol=1e-7)
+    sd = opt.state_dict()
+    lay = meta["layout"]
+    assert [len(x["params"]) for x in sd["param_groups"]] == lay["group_sizes"]      # 4 layer groups x (non-BN, BN)
+    assert sorted(sd["state"][0].keys()) == lay["state_keys"]
+    assert [x["weight_decay"] for x in sd["param_groups"]] == lay["weight_decay_in_groups"]
+    assert opt.name == lay["name"] == "adam_optimizer"
+    assert set(lay["group_keys"]) <= set(sd["param_groups"][0].keys()) | {"params"}
+
+
+def test_shipped_network_gets_eight_param_groups():
+    from rslo.builder import optimizer_builder
+    from test_golden_host import build_net
+    net = build_net()
+    opt = optimizer_builder.build(shipped_optimizer_cfg(), net)
+    sizes = [len(g["params"]) for g in opt.param_groups]
+    assert len(sizes) == 8 and sizes[0] == sizes[1] == 0                 # the VFE has no parameters
+    assert sum(sizes) == sum(1 for p in net.parameters() if p.requires_grad) == 288
+    assert sizes[7] == 0 and sizes[6] == 2                               # losses: 2 learnable alphas, no BN
+    # nn.BatchNorm1d of the covariance branch is the only "BN" half of the middle group (SyncBN is not in bn_types)
+    assert sizes[3] == 10 and sizes[5] == 0
+
+
+def test_checkpoint_index_matches_reference(tmp_path, gold):
+    import torchplus.train as T
+    _, meta = gold
+    net = tiny_net()
+    net.name = "voxelnet"
+    from rslo.builder import optimizer_builder
+    opt = optimizer_builder.build(shipped_optimizer_cfg(), net)
+    for step in (10, 20, 30, 40, 50):
+        T.save_models(str(tmp_path), [net, opt], step, max_to_keep=3)
+    assert json.load(open(tmp_path / "checkpoints.json")) == meta["ckpt_index"]
+    assert sorted(os.listdir(tmp_path)) == meta["ckpt_files"]
+    assert os.path.basename(T.latest_checkpoint(str(tmp_path), "voxelnet")) == meta["ckpt_latest"]
+    # restore round trip, by name
+    net2 = tiny_net()
+    net2.name = "voxelnet"
+    with torch.no_grad():
+        for p in net2.parameters():
+            p.add_(1.0)
+    T.try_restore_latest_checkpoints(str(tmp_path), [net2])
+    for a, b in zip(net.state_dict().values(), net2.state_dict().values()):
+        assert torch.equal(a, b)
+    with pytest.raises(ValueError):
+        T.restore_latest_checkpoints(str(tmp_path), {"missing": net2})
+    T.restore_models(str(tmp_path), [net2], 40)
+
+
+def test_other_schedules_known_answers():
+    from torchplus.train import learning_schedules_fastai as lsf
+
+    class Fake:
+        lr = 0
+        mom = 0
+    o = Fake()
+    s = lsf.ManualStepping(o, 100, [0.8, 0.9], [1e-3, 1e-4, 5e-5])
+    got = []
+    for i in (0, 79, 80, 89, 90, 99):
+        s.step(i)
+        got.append(o.lr)
+    assert got == [1e-3, 1e-3, 1e-4, 1e-4, 5e-5, 5e-5]
+    s = lsf.ExponentialDecay(o, 100, 3e-4, 0.1, 0.8, staircase=True)
+    s.step(0); a = o.lr
+    s.step(10); b = o.lr
+    s.step(25); c = o.lr
+    assert a == 3e-4 and abs(b - 3e-4 * 0.8) < 1e-18 and abs(c - 3e-4 * 0.64) < 1e-18
+    s = lsf.LRSchedulerStep(o, 10, [(0, "lambda p: 1.0 + p"), (0.5, "lambda p: 3.0")], [(0, "lambda p: 0.9")])
+    s.step(2); assert abs(o.lr - 1.4) < 1e-12 and o.mom == 0.9
+    s.step(7); assert o.lr == 3.0
