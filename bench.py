@@ -217,7 +217,13 @@ def main():
         from rslo.utils.distributed_utils import average_gradients, broadcast_params
         broadcast_params(net, 0)
     params = [p for p in net.parameters() if p.requires_grad]
-    opt = torch.optim.Adam(params, lr=8e-5, betas=(0.9, 0.99), fused=True)
+    # the reference's training step: 8-group Adam behind OptimWrapper (decoupled weight decay) + OneCycle schedule,
+    # built from the shipped train_config (train_hdf5.py:408-411,478-480,618,661-674)
+    from rslo.builder import lr_scheduler_builder, optimizer_builder
+    from rslo.utils import config_text
+    train_cfg = config_text.shipped_config().train_config
+    opt = optimizer_builder.build(train_cfg.optimizer, net)
+    sched = lr_scheduler_builder.build(train_cfg.optimizer, opt, train_cfg.steps)
 
     clouds = workload.kitti_pairs(args.batch, n_el=args.rings, start=rank * args.batch)
     clouds = [[torch.from_numpy(c).to(dev) for c in pair] for pair in clouds]
@@ -227,7 +233,8 @@ def main():
         ex = fixed_example if fixed_example is not None else workload.make_example(net, clouds, device=dev)
         if fixed_example is not None:
             ex = dict(ex)
-        opt.zero_grad(set_to_none=True)
+        sched.step(net.get_global_step())
+        opt.zero_grad()
         ret = model(ex)
         ret["loss"].mean().backward()
         if dist_on:
@@ -235,6 +242,7 @@ def main():
         if not args.no_optim:
             torch.nn.utils.clip_grad_norm_(params, 10.0)
             opt.step()
+            net.update_global_step()
         return ret
 
     probe = ConvProbe(capi)

@@ -161,7 +161,11 @@ class UnVoxelOdomNetICP3(nn.Module):
         return self
 
     def update_global_step(self):
+        ver, val = self._step_cache
+        known = ver == self.global_step._version
         self.global_step += 1
+        if known:      # keep the host mirror in step: no device read on the next get_global_step()
+            self._step_cache = (self.global_step._version, val + 1)
 
     def get_global_step(self):
         ver, val = self._step_cache
@@ -368,28 +372,38 @@ class UnVoxelOdomNetICP3(nn.Module):
                 counts = [[f.shape[0]] for f in feats]
             else:
                 counts = [[int(v) for v in example["num_voxels"][t].reshape(-1).tolist()] for t in range(len(feats))]
-            per_sample, lens = [], []
-            for b in range(B):
-                offs = [sum(counts[t][:b]) for t in range(len(feats))]
-                # the reference truncates every frame of a sample to the shortest one (voxel_odom_net.py:646-651)
-                min_len = min(counts[t][b] for t in range(len(feats)))
-                points = [feats[t][offs[t]:offs[t] + min_len][None] for t in range(len(feats))]
-                confs = [preds_dict["middle_conf_preds"][t][offs[t]:offs[t] + min_len][None] for t in range(len(feats))]
-                per_sample.append(create_cycle_constraint_data(points, 1) + create_cycle_constraint_data(confs, 1))
-                lens.append(min_len)
-            npairs = per_sample[0][0].shape[0]
-            # all pairs of all samples as ONE zero-padded batch [B * npairs, Lmax, .] + per-pair valid counts
+            T_ = len(feats)
+            confs_all = preds_dict["middle_conf_preds"]
+            # the reference truncates every frame of a sample to the shortest one (voxel_odom_net.py:646-651)
+            lens = [min(counts[t][b] for t in range(T_)) for b in range(B)]
             if B == 1:
-                pts1, pts2, cov1, cov2 = per_sample[0]
+                points = [feats[t][:lens[0]][None] for t in range(T_)]
+                confs = [confs_all[t][:lens[0]][None] for t in range(T_)]
                 cnt_dev = cnt_host = None
             else:
+                # all samples as ONE zero-padded batch [B, Lmax, .] per frame: a single row gather per frame
+                # (row offsets / lengths go up as one small pinned upload -- no per-sample slicing and padding ops)
                 Lmax = max(lens)
-                padded = [[F.pad(x, (0, 0, 0, Lmax - n)) for x in ps] for ps, n in zip(per_sample, lens)]
-                pts1, pts2, cov1, cov2 = (torch.cat([p[k] for p in padded], 0) for k in range(4))
-                cnt_host = [n for n in lens for _ in range(npairs)]
-                cnt_dev = torch.tensor(cnt_host, dtype=torch.int32)
+                offs = [[sum(counts[t][:b]) for b in range(B)] for t in range(T_)]
+                meta = torch.tensor(offs + [lens], dtype=torch.int64)
                 if device.type == "cuda":      # pinned + async: a pageable upload would drain the stream
-                    cnt_dev = cnt_dev.pin_memory().to(device, non_blocking=True)
+                    meta = meta.pin_memory().to(device, non_blocking=True)
+                r = torch.arange(Lmax, device=device)
+                valid = r[None, :] < meta[T_][:, None]                                # [B, Lmax]
+                vf = valid.to(dtype)[..., None]
+                points, confs = [], []
+                for t in range(T_):
+                    rows = torch.where(valid, meta[t][:, None] + r[None, :], 0).reshape(-1)
+                    both = torch.cat([feats[t], confs_all[t]], 1).index_select(0, rows).view(B, Lmax, -1) * vf
+                    points.append(both[..., :feats[t].shape[1]])
+                    confs.append(both[..., feats[t].shape[1]:])
+                npairs_ = T_ * (T_ - 1) // 2
+                cnt_host = [n for n in lens for _ in range(npairs_)]
+                cnt_dev = meta[T_].to(torch.int32)
+                if npairs_ > 1:
+                    cnt_dev = cnt_dev.repeat_interleave(npairs_)
+            pts1, pts2 = create_cycle_constraint_data(points, 1)      # [B * npairs, L, 6], sample-major
+            cov1, cov2 = create_cycle_constraint_data(confs, 1)
 
             weights = [0.01, 0.01, 0.05, 0.1, 1]
             for R_pred, T_pred, weight in zip(rotation_preds, translation_preds, weights[-len(translation_preds):]):
