@@ -240,6 +240,15 @@ RSLO_API int rslo_pyramid_l2_bwd(const RsloPyramidLevel *h_levels, int n_levels,
                                  int W0, const float *h_origin3, const float *h_vsize3, const float *grad_loss_b,
                                  const float *den, void *stream);
 
+/* a20  ragged batch assembly of the consistency loss (rslo/models/voxel_odom_net.py:629-651: each sample's frames are
+ *      truncated to the shortest; all samples of one frame are gathered into ONE zero-padded batch):
+ *      out[b, r, :] = r < len[b] ? src[off[b] + r, :] : 0   (src [N,C], out [B,Lmax,C]);  bwd is the inverse copy,
+ *      rows of src outside every [off[b], off[b]+len[b]) get 0.  off/len: int32 [B] on the device. */
+RSLO_API int rslo_pad_rows_fwd(const float *src, int64_t N, int C, const int32_t *off, const int32_t *len, int B,
+                               int Lmax, float *out, void *stream);
+RSLO_API int rslo_pad_rows_bwd(const float *dout, int64_t N, int C, const int32_t *off, const int32_t *len, int B,
+                               int Lmax, float *dsrc, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

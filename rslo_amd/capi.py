@@ -58,6 +58,8 @@ SIGNATURES = {
     "rslo_icp_ws_bytes": (_sz, [_i, _i]),
     "rslo_icp_step": (C.c_int, [_vp] * 6 + [_i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
     "rslo_transform_points": (C.c_int, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "rslo_pad_rows_fwd": (C.c_int, [_vp, _i64, _i, _vp, _vp, _i, _i, _vp, _vp]),
+    "rslo_pad_rows_bwd": (C.c_int, [_vp, _i64, _i, _vp, _vp, _i, _i, _vp, _vp]),
     "rslo_pyramid_l2_ws_bytes": (_sz, [_vp, _i, _i]),
     "rslo_pyramid_l2_fwd": (C.c_int, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp]),
     "rslo_pyramid_l2_bwd": (C.c_int, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
@@ -484,3 +486,21 @@ def pyramid_l2_bwd(preds, masks, tq, H0, W0, origin, vsize, grad_loss_b, den):
                                    _ptr(grad_loss_b, torch.float32, "grad"), _ptr(den, torch.float32, "den"),
                                    _stream()), "rslo_pyramid_l2_bwd")
     return dpreds
+
+
+def pad_rows_fwd(src, off, length, Lmax):
+    """src [N,C] -> [B,Lmax,C]: rows off[b] .. off[b]+len[b] of src, zero padded."""
+    N, Cc = src.shape
+    B = off.shape[0]
+    out = torch.empty((B, Lmax, Cc), dtype=torch.float32, device=src.device)
+    _chk(lib().rslo_pad_rows_fwd(_ptr(src, torch.float32, "src"), N, Cc, _ptr(off, torch.int32, "off"),
+                                 _ptr(length, torch.int32, "len"), B, int(Lmax), _ptr(out), _stream()), "rslo_pad_rows_fwd")
+    return out
+
+
+def pad_rows_bwd(dout, off, length, N):
+    B, Lmax, Cc = dout.shape
+    dsrc = torch.empty((N, Cc), dtype=torch.float32, device=dout.device)
+    _chk(lib().rslo_pad_rows_bwd(_ptr(dout, torch.float32, "dout"), N, Cc, _ptr(off, torch.int32, "off"),
+                                 _ptr(length, torch.int32, "len"), B, int(Lmax), _ptr(dsrc), _stream()), "rslo_pad_rows_bwd")
+    return dsrc

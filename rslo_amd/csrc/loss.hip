@@ -500,3 +500,58 @@ extern "C" int rslo_transform_points(const float *x, const float *R, const float
   RSLO_CHECK_LAUNCH("transform_points");
   return RSLO_OK;
 }
+
+// ----------------------------------------------------------------------------------------------------
+// Ragged batch assembly for the consistency loss (voxel_odom_net.py:629-651: every sample's frames are cut to the
+// shortest one; here all samples of a frame become ONE zero-padded [B, Lmax, C] batch).  Rows of sample b are
+// src[off[b] .. off[b] + len[b]); the backward is the inverse copy (no atomics: the ranges are disjoint).
+// ----------------------------------------------------------------------------------------------------
+__global__ void k_pad_rows_fwd(const float *__restrict__ src, int C, const int32_t *__restrict__ off,
+                               const int32_t *__restrict__ len, int Lmax, float *__restrict__ out, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % C);
+  const int64_t row = i / C;
+  const int r = (int)(row % Lmax), b = (int)(row / Lmax);
+  out[i] = r < len[b] ? src[((int64_t)off[b] + r) * C + c] : 0.0f;
+}
+
+__global__ void k_pad_rows_bwd(const float *__restrict__ dout, int C, const int32_t *__restrict__ off,
+                               const int32_t *__restrict__ len, int B, int Lmax, float *__restrict__ dsrc,
+                               int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % C);
+  const int64_t row = i / C;
+  float v = 0.0f;
+  for (int b = 0; b < B; ++b) {
+    const int64_t r = row - off[b];
+    if (r >= 0 && r < len[b]) {
+      v = dout[((int64_t)b * Lmax + r) * C + c];
+      break;
+    }
+  }
+  dsrc[i] = v;
+}
+
+extern "C" int rslo_pad_rows_fwd(const float *src, int64_t N, int C, const int32_t *off, const int32_t *len, int B,
+                                 int Lmax, float *out, void *stream) {
+  RSLO_CHECK_ARG(src && off && len && out && C > 0 && B > 0 && Lmax >= 0 && N >= 0, "rslo_pad_rows_fwd: bad arguments");
+  const int64_t total = (int64_t)B * Lmax * C;
+  if (total == 0) return RSLO_OK;
+  hipLaunchKernelGGL(k_pad_rows_fwd, dim3((unsigned)rslo_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, src, C,
+                     off, len, Lmax, out, total);
+  RSLO_CHECK_LAUNCH("k_pad_rows_fwd");
+  return RSLO_OK;
+}
+
+extern "C" int rslo_pad_rows_bwd(const float *dout, int64_t N, int C, const int32_t *off, const int32_t *len, int B,
+                                 int Lmax, float *dsrc, void *stream) {
+  RSLO_CHECK_ARG(dout && off && len && dsrc && C > 0 && B > 0 && Lmax >= 0 && N >= 0, "rslo_pad_rows_bwd: bad arguments");
+  const int64_t total = N * C;
+  if (total == 0) return RSLO_OK;
+  hipLaunchKernelGGL(k_pad_rows_bwd, dim3((unsigned)rslo_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, dout, C,
+                     off, len, B, Lmax, dsrc, total);
+  RSLO_CHECK_LAUNCH("k_pad_rows_bwd");
+  return RSLO_OK;
+}

@@ -86,6 +86,33 @@ class _PyramidL2Fn(torch.autograd.Function):
         return (None, None, None, *dpreds)
 
 
+class _PadRowsFn(torch.autograd.Function):
+    """Ragged rows -> zero-padded batch (rslo_pad_rows_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, src, off, length, Lmax):
+        src = src.contiguous()
+        ctx.save_for_backward(off, length)
+        ctx.n = src.shape[0]
+        return capi.pad_rows_fwd(src, off, length, Lmax)
+
+    @staticmethod
+    def backward(ctx, g):
+        off, length = ctx.saved_tensors
+        return capi.pad_rows_bwd(g.contiguous(), off, length, ctx.n), None, None, None
+
+
+def pad_rows(src, off, length, Lmax):
+    """src [N,C], off/length int32 [B] (device) -> [B,Lmax,C]; rows of sample b = src[off[b] : off[b]+length[b]]."""
+    if src.is_cuda:
+        return _PadRowsFn.apply(src, off, length, Lmax)
+    B = off.shape[0]
+    out = src.new_zeros(B, Lmax, src.shape[1])
+    for b, (o, n) in enumerate(zip(off.tolist(), length.tolist())):
+        out[b, :n] = src[o:o + n]
+    return out
+
+
 _const_cache = {}
 
 

@@ -385,21 +385,17 @@ class UnVoxelOdomNetICP3(nn.Module):
                 # (row offsets / lengths go up as one small pinned upload -- no per-sample slicing and padding ops)
                 Lmax = max(lens)
                 offs = [[sum(counts[t][:b]) for b in range(B)] for t in range(T_)]
-                meta = torch.tensor(offs + [lens], dtype=torch.int64)
+                meta = torch.tensor(offs + [lens], dtype=torch.int32)
                 if device.type == "cuda":      # pinned + async: a pageable upload would drain the stream
                     meta = meta.pin_memory().to(device, non_blocking=True)
-                r = torch.arange(Lmax, device=device)
-                valid = r[None, :] < meta[T_][:, None]                                # [B, Lmax]
-                vf = valid.to(dtype)[..., None]
                 points, confs = [], []
                 for t in range(T_):
-                    rows = torch.where(valid, meta[t][:, None] + r[None, :], 0).reshape(-1)
-                    both = torch.cat([feats[t], confs_all[t]], 1).index_select(0, rows).view(B, Lmax, -1) * vf
+                    both = losses.pad_rows(torch.cat([feats[t], confs_all[t]], 1), meta[t], meta[T_], Lmax)
                     points.append(both[..., :feats[t].shape[1]])
                     confs.append(both[..., feats[t].shape[1]:])
                 npairs_ = T_ * (T_ - 1) // 2
                 cnt_host = [n for n in lens for _ in range(npairs_)]
-                cnt_dev = meta[T_].to(torch.int32)
+                cnt_dev = meta[T_]
                 if npairs_ > 1:
                     cnt_dev = cnt_dev.repeat_interleave(npairs_)
             pts1, pts2 = create_cycle_constraint_data(points, 1)      # [B * npairs, L, 6], sample-major

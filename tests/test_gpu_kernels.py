@@ -307,3 +307,21 @@ def test_c5_dense_scan_geometry(hip):
     W = torch.randn((27, 16, 32), device="cuda", generator=g) * 0.1
     y = hip.spconv_fwd(x, W, None, nb)
     np.testing.assert_allclose(y.cpu().numpy(), O.spconv_fwd(x.cpu().numpy(), W.cpu().numpy(), None, onb), **CONV_TOL)
+
+
+def test_pad_rows_fwd_bwd(hip):
+    """rslo_pad_rows_fwd/_bwd: ragged rows -> zero-padded batch and its inverse copy (exact)."""
+    import torch
+    from rslo.core import losses
+    g = torch.Generator().manual_seed(0)
+    src = torch.randn(1000, 13, generator=g)
+    off = torch.tensor([0, 300, 450, 900], dtype=torch.int32)
+    length = torch.tensor([250, 150, 400, 100], dtype=torch.int32)
+    ref_in = src.clone().requires_grad_(True)
+    ref = losses.pad_rows(ref_in, off, length, 400)            # CPU formulation (slicing)
+    w = torch.randn(4, 400, 13, generator=g)
+    (ref * w).sum().backward()
+    dev_in = src.cuda().requires_grad_(True)
+    out = losses.pad_rows(dev_in, off.cuda(), length.cuda(), 400)
+    (out * w.cuda()).sum().backward()
+    assert torch.equal(out.cpu(), ref) and torch.equal(dev_in.grad.cpu(), ref_in.grad)
