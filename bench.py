@@ -71,7 +71,9 @@ class ConvProbe:
 
     def install(self):
         capi = self.capi
-        self._orig = {"spconv_fwd": capi.spconv_fwd, "spconv_dgrad": capi.spconv_dgrad}
+        # capi.spconv_dgrad runs through spconv_fwd on transposed weights for MFMA-shaped channels, so the forward
+        # entry sees both directions; only the odd-channel data gradients use the dedicated entry point
+        self._orig = {"spconv_fwd": capi.spconv_fwd, "spconv_dgrad_direct": capi.spconv_dgrad_direct}
         probe = self
 
         def timed(fn, name_fn):
@@ -98,7 +100,7 @@ class ConvProbe:
                     probe.kernel_name(cout, cin, nbrT.shape[0], True))
 
         capi.spconv_fwd = timed(self._orig["spconv_fwd"], fwd_meta)
-        capi.spconv_dgrad = timed(self._orig["spconv_dgrad"], dgrad_meta)
+        capi.spconv_dgrad_direct = timed(self._orig["spconv_dgrad_direct"], dgrad_meta)
 
     def uninstall(self):
         for k, f in self._orig.items():

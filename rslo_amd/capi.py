@@ -36,6 +36,7 @@ SIGNATURES = {
     "rslo_rulebook_conv_T": (C.c_int, [_vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "rslo_spconv_fwd": (C.c_int, [_vp, _i, _vp, _vp, _vp, _i64, _i, _i, _i, _f, _vp, _vp]),
     "rslo_spconv_dgrad": (C.c_int, [_vp, _i, _vp, _vp, _i64, _i, _i, _i, _vp, _vp]),
+    "rslo_weight_transpose": (C.c_int, [_vp, _i, _i, _i, _vp, _vp]),
     "rslo_spconv_wgrad_ws_bytes": (_sz, [_i64, _i, _i, _i]),
     "rslo_spconv_wgrad": (C.c_int, [_vp, _i, _vp, _i, _vp, _i64, _i, _vp, _sz, _vp, _vp, _vp]),
     "rslo_rulebook_pairs_ws_bytes": (_sz, [_i64, _i]),
@@ -231,8 +232,27 @@ def spconv_fwd(x, W, bias, nbr, flip_k=False, act_slope=1.0):
     return out
 
 
+def weight_transpose(W):
+    """W [K,Cin,Cout] -> [K,Cout,Cin]."""
+    K, cin, cout = W.shape
+    Wt = torch.empty((K, cout, cin), dtype=torch.float32, device=W.device)
+    _chk(lib().rslo_weight_transpose(_ptr(W, torch.float32, "W"), K, cin, cout, _ptr(Wt), _stream()),
+         "rslo_weight_transpose")
+    return Wt
+
+
 def spconv_dgrad(dout, W, nbrT, flip_k=False):
-    """dout [Nout,Cout], W [K,Cin,Cout], nbrT [Nin,K] -> din [Nin,Cin]."""
+    """dout [Nout,Cout], W [K,Cin,Cout], nbrT [Nin,K] -> din [Nin,Cin].
+    For MFMA-shaped channel counts the gradient runs through the forward kernel on the transposed weights
+    (coalesced weight reads); other shapes use the dedicated entry point."""
+    Kw, cin, cout = W.shape
+    if cin % 16 == 0 and cout % 16 == 0:
+        return spconv_fwd(dout, weight_transpose(W), None, nbrT, flip_k=flip_k)
+    return spconv_dgrad_direct(dout, W, nbrT, flip_k)
+
+
+def spconv_dgrad_direct(dout, W, nbrT, flip_k=False):
+    """rslo_spconv_dgrad itself (weights read in place, transposed access)."""
     n_in, K = nbrT.shape
     Kw, cin, cout = W.shape
     if Kw != K or dout.shape[1] != cout:

@@ -41,6 +41,9 @@ def run(name, x, W, nbr, fn, check=True):
     if fn == "dgrad":
         call = lambda: capi.spconv_dgrad(x, W, nbr, flip_k=True)
         cin_op, cout_op = cout, cin
+    elif fn == "dgradT":     # dgrad as a forward conv with per-offset transposed weights (coalesced B reads)
+        call = lambda: capi.spconv_fwd(x, W.transpose(1, 2).contiguous(), None, nbr, flip_k=True)
+        cin_op, cout_op = cout, cin
     else:
         call = lambda: capi.spconv_fwd(x, W, None, nbr)
         cin_op, cout_op = cin, cout
@@ -64,6 +67,7 @@ for li, ((ix, nbr), (ci, co)) in enumerate(zip(levels, chans)):
     n = nbr.shape[0]
     run("subm%d %d->%d fwd" % (li, ci, co), rn(n, ci), rn(27, ci, co) * 0.1, nbr, "fwd")
     run("subm%d %d->%d dgrad" % (li, ci, co), rn(n, co), rn(27, ci, co) * 0.1, nbr, "dgrad", check=False)
+    run("subm%d %d->%d dgradT" % (li, ci, co), rn(n, co), rn(27, ci, co) * 0.1, nbr, "dgradT", check=False)
 run("subm0 7->16 fwd", rn(levels[0][1].shape[0], 7), rn(27, 7, 16) * 0.1, levels[0][1], "fwd")
 run("subm0 16->7 fwd", rn(levels[0][1].shape[0], 16), rn(27, 16, 7) * 0.1, levels[0][1], "fwd")
 for ci, ((nbr, nbrT), (a, b)) in enumerate(zip(convs, [(16, 32), (32, 64), (64, 64)])):

@@ -1,5 +1,7 @@
-"""Post-process a rocprofv3 kernel trace CSV: per-kernel stats restricted to the LAST n steps of bench.py
-(a step starts with the first k_vox_insert of its 2*batch voxelizer launches).  Writes a small CSV/markdown."""
+"""Post-process a rocprofv3 kernel trace CSV: per-kernel stats restricted to n steady-state steps of bench.py
+(a step starts with the first k_vox_insert of its 2*batch voxelizer launches).  The window is the n steps BEFORE
+the last one, [start of step -(n+1), start of the last step): the last step's tail would include bench.py's
+post-timing summary work (pair counting for the roofline figures).  Writes a small text summary."""
 import csv
 import sys
 from collections import defaultdict
@@ -13,10 +15,11 @@ with open(path) as f:
         rows.append((int(d["Start_Timestamp"]), int(d["End_Timestamp"]), d["Kernel_Name"]))
 rows.sort()
 vox = [s for s, e, n in rows if n.startswith("k_vox_insert")]
-assert len(vox) >= n_steps * vox_per_step, (len(vox), n_steps, vox_per_step)
-t0 = vox[-n_steps * vox_per_step]
-sel = [(s, e, n) for s, e, n in rows if s >= t0]
-wall = (max(e for s, e, n in sel) - t0) / 1e6
+assert len(vox) >= (n_steps + 1) * vox_per_step, (len(vox), n_steps, vox_per_step)
+t0 = vox[-(n_steps + 1) * vox_per_step]
+t1 = vox[-vox_per_step]
+sel = [(s, e, n) for s, e, n in rows if t0 <= s < t1]
+wall = (t1 - t0) / 1e6
 agg = defaultdict(lambda: [0, 0])
 for s, e, n in sel:
     a = agg[n]
@@ -44,7 +47,7 @@ for n, (c, t) in agg.items():
     cats[cat(n)] += t / 1e6
 busy = sum(cats.values())
 lines = []
-lines.append("# last %d step(s): wall %.2f ms/step, GPU busy %.2f ms/step, %d dispatches/step" %
+lines.append("# %d steady-state step(s): wall %.2f ms/step, GPU busy %.2f ms/step, %d dispatches/step" %
              (n_steps, wall / n_steps, busy / n_steps, len(sel) // n_steps))
 lines.append("## by category (ms/step)")
 for k, v in sorted(cats.items(), key=lambda kv: -kv[1]):

@@ -135,6 +135,11 @@ def test_subm_conv_fwd_bwd(hip, cin, cout):
     np.testing.assert_allclose(y2, O.spconv_fwd(x, W, None, nbr), **CONV_TOL)
     gx = hip.spconv_dgrad(dev(gy), dev(W), dn, flip_k=True).cpu().numpy()
     np.testing.assert_allclose(gx, O.spconv_dgrad(gy, W, nbr[:, ::-1].copy()), **CONV_TOL)
+    # the dedicated entry point (weights read in place) and the forward kernel on transposed weights agree
+    gx2 = hip.spconv_dgrad_direct(dev(gy), dev(W), dn, flip_k=True).cpu().numpy()
+    np.testing.assert_allclose(gx2, gx, rtol=1e-5, atol=1e-5)
+    Wt = hip.weight_transpose(dev(W)).cpu().numpy()
+    assert (Wt == np.ascontiguousarray(W.transpose(0, 2, 1))).all()
     gw, gb = hip.spconv_wgrad(dev(x), dev(gy), dn, cin, cout)
     ow, ob = O.spconv_wgrad(x, gy, nbr, cin, cout)
     np.testing.assert_allclose(gw.cpu().numpy(), ow, rtol=1e-4, atol=1e-4)
