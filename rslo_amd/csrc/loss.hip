@@ -220,9 +220,16 @@ __global__ __launch_bounds__(RB_THREADS) void k_resid_bwd(const float *__restric
                                                           float *__restrict__ gcov2) {
   const int b = blockIdx.y;
   const int i = blockIdx.x * RB_THREADS + threadIdx.x;
-  if (i >= N) return;
-  float *g1 = gcov1 + ((int64_t)b * N + i) * 7;
-  if (!(dist[(int64_t)b * N + i] < thr[b])) {
+  const int lane = threadIdx.x;                      // RB_THREADS == 64: one wave per block
+  const bool in_range = i < N;
+  const bool roi = in_range && (dist[(int64_t)b * N + i] < thr[b]);
+  // values this lane scatter-adds to its partner row j: 3 (target point) + 7 (target covariance parameters)
+  float sc[10];
+#pragma unroll
+  for (int k = 0; k < 10; ++k) sc[k] = 0.f;
+  int j = -1 - lane;                                 // unique key for lanes without a partner
+  if (in_range && !roi) {
+    float *g1 = gcov1 + ((int64_t)b * N + i) * 7;
 #pragma unroll
     for (int k = 0; k < 7; ++k) g1[k] = 0.f;
     if (gp1) {
@@ -230,62 +237,88 @@ __global__ __launch_bounds__(RB_THREADS) void k_resid_bwd(const float *__restric
       gp1[((int64_t)b * N + i) * 3 + 1] = 0.f;
       gp1[((int64_t)b * N + i) * 3 + 2] = 0.f;
     }
-    return;
   }
-  const float wgt = gloss[b] / cnt[b];
-  const int j = idx[(int64_t)b * N + i];
-  const float *a = p1 + ((int64_t)b * N + i) * 3, *t = tgt + ((int64_t)b * M + j) * 3;
-  const float *pc1 = cov1 + ((int64_t)b * N + i) * 7, *pc2 = cov2 + ((int64_t)b * M + j) * 7;
-  float R[9];
+  if (roi) {
+    float *g1 = gcov1 + ((int64_t)b * N + i) * 7;
+    const float wgt = gloss[b] / cnt[b];
+    j = idx[(int64_t)b * N + i];
+    const float *a = p1 + ((int64_t)b * N + i) * 3, *t = tgt + ((int64_t)b * M + j) * 3;
+    const float *pc1 = cov1 + ((int64_t)b * N + i) * 7, *pc2 = cov2 + ((int64_t)b * M + j) * 7;
+    float R[9];
 #pragma unroll
-  for (int k = 0; k < 9; ++k) R[k] = Rd[b * 9 + k];
-  Cov7 c1, c2;
-  float S1[9], S2[9], sg[9], I[9];
-  cov_build(pc1, c1, S1);
-  cov_build(pc2, c2, S2);
-  sigma_of(S1, S2, R, sg);
-  inv3(sg, I);
-  const float d0 = a[0] - t[0], d1 = a[1] - t[1], d2 = a[2] - t[2];
-  float v[3] = {I[0] * d0 + I[1] * d1 + I[2] * d2, I[3] * d0 + I[4] * d1 + I[5] * d2,
-                I[6] * d0 + I[7] * d1 + I[8] * d2};
-  // sigma^-1 is symmetric up to rounding: use the symmetrised inverse for the log-det term
-  float G[9];
+    for (int k = 0; k < 9; ++k) R[k] = Rd[b * 9 + k];
+    Cov7 c1, c2;
+    float S1[9], S2[9], sg[9], I[9];
+    cov_build(pc1, c1, S1);
+    cov_build(pc2, c2, S2);
+    sigma_of(S1, S2, R, sg);
+    inv3(sg, I);
+    const float d0 = a[0] - t[0], d1 = a[1] - t[1], d2 = a[2] - t[2];
+    float v[3] = {I[0] * d0 + I[1] * d1 + I[2] * d2, I[3] * d0 + I[4] * d1 + I[5] * d2,
+                  I[6] * d0 + I[7] * d1 + I[8] * d2};
+    // sigma^-1 is symmetric up to rounding: use the symmetrised inverse for the log-det term
+    float G[9];
 #pragma unroll
-  for (int r = 0; r < 3; ++r)
+    for (int r = 0; r < 3; ++r)
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
-      G[r * 3 + c] = wgt * (-v[r] * v[c] + reg * 0.25f * (I[r * 3 + c] + I[c * 3 + r]));
-  // d(sq)/dd = (sigma^-1 + sigma^-T) d
-  const float u0 = I[0] * d0 + I[3] * d1 + I[6] * d2, u1 = I[1] * d0 + I[4] * d1 + I[7] * d2,
-              u2 = I[2] * d0 + I[5] * d1 + I[8] * d2;
-  const float gd[3] = {wgt * (v[0] + u0), wgt * (v[1] + u1), wgt * (v[2] + u2)};
-  if (gp1) {
-    gp1[((int64_t)b * N + i) * 3 + 0] = gd[0];
-    gp1[((int64_t)b * N + i) * 3 + 1] = gd[1];
-    gp1[((int64_t)b * N + i) * 3 + 2] = gd[2];
+      for (int c = 0; c < 3; ++c)
+        G[r * 3 + c] = wgt * (-v[r] * v[c] + reg * 0.25f * (I[r * 3 + c] + I[c * 3 + r]));
+    // d(sq)/dd = (sigma^-1 + sigma^-T) d
+    const float u0 = I[0] * d0 + I[3] * d1 + I[6] * d2, u1 = I[1] * d0 + I[4] * d1 + I[7] * d2,
+                u2 = I[2] * d0 + I[5] * d1 + I[8] * d2;
+    const float gd[3] = {wgt * (v[0] + u0), wgt * (v[1] + u1), wgt * (v[2] + u2)};
+    if (gp1) {
+      gp1[((int64_t)b * N + i) * 3 + 0] = gd[0];
+      gp1[((int64_t)b * N + i) * 3 + 1] = gd[1];
+      gp1[((int64_t)b * N + i) * 3 + 2] = gd[2];
+    }
+    sc[0] = -gd[0];
+    sc[1] = -gd[1];
+    sc[2] = -gd[2];
+    float g7[7];
+    cov_backward(pc1, c1, G, g7);
+#pragma unroll
+    for (int k = 0; k < 7; ++k) g1[k] = g7[k];
+    // G2 = R^T G R
+    float RtG[9], G2[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) RtG[r * 3 + c] = R[0 * 3 + r] * G[0 * 3 + c] + R[1 * 3 + r] * G[1 * 3 + c] + R[2 * 3 + r] * G[2 * 3 + c];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) G2[r * 3 + c] = RtG[r * 3 + 0] * R[0 * 3 + c] + RtG[r * 3 + 1] * R[1 * 3 + c] + RtG[r * 3 + 2] * R[2 * 3 + c];
+    cov_backward(pc2, c2, G2, g7);
+#pragma unroll
+    for (int k = 0; k < 7; ++k) sc[3 + k] = g7[k];
   }
-  float *gt = gtgt + ((int64_t)b * M + j) * 3;
-  atomicAdd(gt + 0, -gd[0]);
-  atomicAdd(gt + 1, -gd[1]);
-  atomicAdd(gt + 2, -gd[2]);
-  float g7[7];
-  cov_backward(pc1, c1, G, g7);
+  // Source points are in scan order, so the sources of one partner mostly sit in consecutive lanes; when the two
+  // clouds overlap badly (early training) thousands of sources share a few partners and per-lane atomics serialise
+  // on those rows.  Each run of equal partners inside the wave is summed with a segmented scan and added once.
+  const int jp = __shfl_up(j, 1, 64);
+  const bool head = lane == 0 || jp != j;
+  const unsigned long long heads = __ballot(head);
+  const int start = 63 - __builtin_clzll(heads & ((2ull << lane) - 1ull));
 #pragma unroll
-  for (int k = 0; k < 7; ++k) g1[k] = g7[k];
-  // G2 = R^T G R
-  float RtG[9], G2[9];
+  for (int d = 1; d < 64; d <<= 1) {
 #pragma unroll
-  for (int r = 0; r < 3; ++r)
+    for (int k = 0; k < 10; ++k) {
+      const float t = __shfl_up(sc[k], d, 64);
+      if (lane - d >= start) sc[k] += t;
+    }
+  }
+  const int jn = __shfl_down(j, 1, 64);
+  const bool tail = lane == 63 || jn != j;
+  if (tail && j >= 0) {
+    float *gt = gtgt + ((int64_t)b * M + j) * 3;
+    atomicAdd(gt + 0, sc[0]);
+    atomicAdd(gt + 1, sc[1]);
+    atomicAdd(gt + 2, sc[2]);
+    float *g2 = gcov2 + ((int64_t)b * M + j) * 7;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) RtG[r * 3 + c] = R[0 * 3 + r] * G[0 * 3 + c] + R[1 * 3 + r] * G[1 * 3 + c] + R[2 * 3 + r] * G[2 * 3 + c];
-#pragma unroll
-  for (int r = 0; r < 3; ++r)
-#pragma unroll
-    for (int c = 0; c < 3; ++c) G2[r * 3 + c] = RtG[r * 3 + 0] * R[0 * 3 + c] + RtG[r * 3 + 1] * R[1 * 3 + c] + RtG[r * 3 + 2] * R[2 * 3 + c];
-  cov_backward(pc2, c2, G2, g7);
-  float *g2 = gcov2 + ((int64_t)b * M + j) * 7;
-#pragma unroll
-  for (int k = 0; k < 7; ++k) atomicAdd(g2 + k, g7[k]);
+    for (int k = 0; k < 7; ++k) atomicAdd(g2 + k, sc[3 + k]);
+  }
 }
 
 extern "C" int rslo_cov_residual_bwd(const float *p1, const float *tgt, const float *cov1, const float *cov2,

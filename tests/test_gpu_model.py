@@ -299,3 +299,4 @@ def test_training_batched_loss_equals_per_sample(hip):
     assert rel(both["C_loss"], (ra["C_loss"] + rb["C_loss"]) / 2) < 1e-4
     assert rel(both["translation_preds"], torch.cat([ra["translation_preds"], rb["translation_preds"]])) < 1e-4
     assert rel(both["translation_loss"], (ra["translation_loss"] + rb["translation_loss"]) / 2) < 1e-3
+
