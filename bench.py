@@ -34,8 +34,8 @@ MFMA_F32_PEAK_TF = 157.3   # dense fp32-input MFMA peak = the fp32 vector peak (
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=4, help="frame pairs per GPU (C3: 4)")
     ap.add_argument("--rings", type=int, default=64, help="64 = KITTI-shaped ~131k points; 128 = dense scan")
     ap.add_argument("--no-optim", action="store_true", help="time forward+backward only")

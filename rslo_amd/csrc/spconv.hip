@@ -864,12 +864,18 @@ __global__ void k_wgrad2_reduce(const float *__restrict__ ws, const int32_t *__r
 
 // column sums of x [rows, cols] -> partial[block][cols]; one block per CS_ROWS rows, consecutive threads read
 // consecutive floats (whole rows), 256 / cols_pad row-parts per block reduced through LDS in a fixed order
-#define CS_ROWS 512
-__global__ __launch_bounds__(256) void k_colsum_partial(const float *__restrict__ x, int64_t rows, int cols,
-                                                        int cols_pad, float *__restrict__ partial) {
+// Single-launch column sum (bias gradient): blocks of CS1_ROWS rows write partial rows; the block that finishes
+// last (device counter, reset for the next launch on the same stream) adds the partial rows in block order --
+// deterministic, and one dispatch instead of a two-level tree.
+#define CS1_ROWS 128
+__device__ unsigned int g_colsum_done = 0;
+__global__ __launch_bounds__(256) void k_colsum_once(const float *__restrict__ x, int64_t rows, int cols,
+                                                     int cols_pad, float *__restrict__ partial,
+                                                     float *__restrict__ result) {
   __shared__ float red[256];
+  __shared__ bool last;
   const int c = threadIdx.x % cols_pad, part = threadIdx.x / cols_pad, nparts = 256 / cols_pad;
-  const int64_t r0 = (int64_t)blockIdx.x * CS_ROWS, r1 = (r0 + CS_ROWS < rows) ? r0 + CS_ROWS : rows;
+  const int64_t r0 = (int64_t)blockIdx.x * CS1_ROWS, r1 = (r0 + CS1_ROWS < rows) ? r0 + CS1_ROWS : rows;
   float s = 0.f;
   if (c < cols)
     for (int64_t r = r0 + part; r < r1; r += nparts) s += x[r * cols + c];
@@ -880,6 +886,23 @@ __global__ __launch_bounds__(256) void k_colsum_partial(const float *__restrict_
     for (int p = 0; p < nparts; ++p) t += red[p * cols_pad + c];
     partial[(int64_t)blockIdx.x * cols + c] = t;
   }
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) last = atomicAdd(&g_colsum_done, 1u) == gridDim.x - 1;
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  s = 0.f;
+  if (c < cols)
+    for (unsigned b = part; b < gridDim.x; b += nparts) s += partial[(int64_t)b * cols + c];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (part == 0 && c < cols) {
+    float t = 0.f;
+    for (int p = 0; p < nparts; ++p) t += red[p * cols_pad + c];
+    result[c] = t;
+  }
+  if (threadIdx.x == 0) g_colsum_done = 0;
 }
 
 extern "C" size_t rslo_rulebook_pairs_ws_bytes(int64_t n_rows, int K) {
@@ -889,8 +912,8 @@ extern "C" size_t rslo_rulebook_pairs_ws_bytes(int64_t n_rows, int K) {
 
 extern "C" size_t rslo_spconv_wgrad_pairs_ws_bytes(int64_t n_out, int K, int cin, int cout) {
   const int64_t nch = rslo_cdiv(n_out > 0 ? n_out : 1, WG2_CHUNK);
-  const int64_t ncs = rslo_cdiv(n_out > 0 ? n_out : 1, CS_ROWS);
-  return ((size_t)nch * (size_t)K * cin * cout + (size_t)(ncs + ncs / CS_ROWS + 8) * cout) * sizeof(float);
+  const int64_t ncs = rslo_cdiv(n_out > 0 ? n_out : 1, CS1_ROWS);
+  return ((size_t)nch * (size_t)K * cin * cout + (size_t)(ncs + 8) * cout) * sizeof(float);
 }
 
 extern "C" int rslo_spconv_wgrad_pairs(const float *in, int cin, const float *dout, int cout,
@@ -931,19 +954,9 @@ extern "C" int rslo_spconv_wgrad_pairs(const float *in, int cin, const float *do
   hipLaunchKernelGGL(k_wgrad2_reduce, dim3((unsigned)rslo_cdiv(cc, 256), (unsigned)K), dim3(256), 0, st,
                      (const float *)ws, koff, K, cc, dW);
   if (dbias) {
-    // tree of column sums: n_out rows -> ceil(/512) partial rows -> ... -> 1 row (written straight to dbias)
     float *wsb = (float *)ws + (int64_t)nch * nW;
-    const float *src = dout;
-    int64_t rows = n_out;
-    while (true) {
-      const int64_t nblk = rslo_cdiv(rows, CS_ROWS);
-      float *dst = (nblk == 1) ? dbias : wsb;
-      hipLaunchKernelGGL(k_colsum_partial, dim3((unsigned)nblk), dim3(256), 0, st, src, rows, cout, co, dst);
-      if (nblk == 1) break;
-      src = dst;
-      rows = nblk;
-      wsb += nblk * cout;
-    }
+    hipLaunchKernelGGL(k_colsum_once, dim3((unsigned)rslo_cdiv(n_out, CS1_ROWS)), dim3(256), 0, st, dout, n_out,
+                       cout, co, wsb, dbias);
   }
   RSLO_CHECK_LAUNCH("wgrad_pairs");
   return RSLO_OK;
