@@ -181,6 +181,17 @@ RSLO_API int rslo_chamfer_nn(const float *xyz1 /*[B,N,3]*/, const float *xyz2 /*
 RSLO_API int rslo_chamfer_nn_ragged(const float *xyz1, const float *xyz2, int B, int N, int M, const int32_t *ncnt,
                            const int32_t *mcnt, float *dist, int32_t *idx, void *ws, size_t ws_bytes,
                            void *stream);
+/*     Exact search with spatial pruning (Morton bucket sort of both clouds, 64-point target tiles with bounding
+ *     boxes, box lower bound in the distance's own operation order => bit-identical to the exhaustive scan).
+ *     rslo_chamfer_nn / _ragged dispatch to it for N >= 1024 and M >= 2048 (RSLO_CHAMFER=brute|grid overrides);
+ *     rslo_chamfer_ws_bytes covers both. */
+RSLO_API int rslo_chamfer_brute_nn(const float *xyz1, const float *xyz2, int B, int N, int M, const int32_t *ncnt,
+                                   const int32_t *mcnt, float *dist, int32_t *idx, void *ws, size_t ws_bytes,
+                                   void *stream);   /* the exhaustive scan, explicitly */
+RSLO_API size_t rslo_chamfer_grid_ws_bytes(int B, int N, int M);
+RSLO_API int rslo_chamfer_grid_nn(const float *xyz1, const float *xyz2, int B, int N, int M, const int32_t *ncnt,
+                                  const int32_t *mcnt, float *dist, int32_t *idx, void *ws, size_t ws_bytes,
+                                  void *stream);
 RSLO_API int rslo_chamfer_grad(const float *xyz1, const float *xyz2, int B, int N, int M,
                       const float *graddist1, const int32_t *idx1, float *gradxyz1 /*[B,N,3]*/,
                       float *gradxyz2 /*[B,M,3]*/, void *stream);

@@ -52,6 +52,9 @@ SIGNATURES = {
     "rslo_chamfer_ws_bytes": (_sz, [_i, _i, _i]),
     "rslo_chamfer_nn": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "rslo_chamfer_nn_ragged": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "rslo_chamfer_brute_nn": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "rslo_chamfer_grid_ws_bytes": (_sz, [_i, _i, _i]),
+    "rslo_chamfer_grid_nn": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "rslo_chamfer_grad": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "rslo_cov_residual_ws_bytes": (_sz, [_i, _i]),
     "rslo_cov_residual_fwd": (C.c_int, [_vp] * 8 + [_i, _i, _i, _f, _vp, _sz, _vp, _vp, _vp]),
@@ -366,8 +369,10 @@ def dense_gather(dense, coords, C_, batch, dims):
 # --------------------------------------------------------------------------------------
 # chamfer
 # --------------------------------------------------------------------------------------
-def chamfer_nn(xyz1, xyz2, dist=None, idx=None, ncnt=None, mcnt=None):
-    """ncnt / mcnt: optional int32 [B] device tensors for a ragged (padded) batch."""
+def chamfer_nn(xyz1, xyz2, dist=None, idx=None, ncnt=None, mcnt=None, method=None):
+    """ncnt / mcnt: optional int32 [B] device tensors for a ragged (padded) batch.
+    method: None (library picks), "brute" (exhaustive scan) or "grid" (pruned search) -- identical results."""
+    entry = {None: "rslo_chamfer_nn_ragged", "brute": "rslo_chamfer_brute_nn", "grid": "rslo_chamfer_grid_nn"}[method]
     B, N, _ = xyz1.shape
     M = xyz2.shape[1]
     dev = xyz1.device
@@ -377,10 +382,10 @@ def chamfer_nn(xyz1, xyz2, dist=None, idx=None, ncnt=None, mcnt=None):
         idx = torch.empty((B, N), dtype=torch.int32, device=dev)
     wsb = lib().rslo_chamfer_ws_bytes(B, N, M)
     ws = _ws(wsb, dev)
-    _chk(lib().rslo_chamfer_nn_ragged(_ptr(xyz1, torch.float32, "xyz1"), _ptr(xyz2, torch.float32, "xyz2"), B, N, M,
-                                      _ptr(ncnt, torch.int32, "ncnt"), _ptr(mcnt, torch.int32, "mcnt"),
-                                      _ptr(dist, torch.float32, "dist"), _ptr(idx, torch.int32, "idx"), _ptr(ws), wsb,
-                                      _stream()), "rslo_chamfer_nn_ragged")
+    _chk(getattr(lib(), entry)(_ptr(xyz1, torch.float32, "xyz1"), _ptr(xyz2, torch.float32, "xyz2"), B, N, M,
+                               _ptr(ncnt, torch.int32, "ncnt"), _ptr(mcnt, torch.int32, "mcnt"),
+                               _ptr(dist, torch.float32, "dist"), _ptr(idx, torch.int32, "idx"), _ptr(ws), wsb,
+                               _stream()), entry)
     return dist, idx
 
 

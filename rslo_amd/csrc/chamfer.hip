@@ -153,8 +153,30 @@ static int chamfer_segments(int B, int N, int M) {
   return S;
 }
 
-extern "C" size_t rslo_chamfer_ws_bytes(int B, int N, int M) {
+extern "C" size_t rslo_chamfer_grid_ws_bytes(int B, int N, int M);
+extern "C" int rslo_chamfer_brute_nn(const float *xyz1, const float *xyz2, int B, int N, int M, const int32_t *ncnt,
+                                     const int32_t *mcnt, float *dist, int32_t *idx, void *ws, size_t ws_bytes,
+                                     void *stream);
+extern "C" int rslo_chamfer_grid_nn(const float *xyz1, const float *xyz2, int B, int N, int M, const int32_t *ncnt,
+                                    const int32_t *mcnt, float *dist, int32_t *idx, void *ws, size_t ws_bytes,
+                                    void *stream);
+
+// which search runs behind rslo_chamfer_nn*: the pruned one once the clouds are large enough to amortise its
+// five small launches (same results either way); RSLO_CHAMFER=brute|grid forces one
+static bool chamfer_use_grid(int N, int M) {
+  static const char *force = getenv("RSLO_CHAMFER");
+  if (force && force[0] == 'b') return false;
+  if (force && force[0] == 'g') return true;
+  return N >= 1024 && M >= 2048;
+}
+
+static size_t chamfer_brute_ws_bytes(int B, int N, int M) {
   return (size_t)chamfer_segments(B, N, M) * (size_t)(B > 0 ? B : 1) * (size_t)(N > 0 ? N : 1) * 8;
+}
+
+extern "C" size_t rslo_chamfer_ws_bytes(int B, int N, int M) {
+  const size_t a = chamfer_brute_ws_bytes(B, N, M), g = rslo_chamfer_grid_ws_bytes(B, N, M);
+  return a > g ? a : g;
 }
 
 extern "C" int rslo_chamfer_nn_ragged(const float *xyz1, const float *xyz2, int B, int N, int M,
@@ -172,8 +194,18 @@ extern "C" int rslo_chamfer_nn_ragged(const float *xyz1, const float *xyz2, int 
   hipStream_t st = (hipStream_t)stream;
   RSLO_CHECK_ARG(B >= 0 && N >= 0 && M >= 1, "chamfer_nn: need M >= 1");
   if (B == 0 || N == 0) return RSLO_OK;
+  if (chamfer_use_grid(N, M)) return rslo_chamfer_grid_nn(xyz1, xyz2, B, N, M, ncnt, mcnt, dist, idx, ws, ws_bytes, stream);
+  return rslo_chamfer_brute_nn(xyz1, xyz2, B, N, M, ncnt, mcnt, dist, idx, ws, ws_bytes, stream);
+}
+
+extern "C" int rslo_chamfer_brute_nn(const float *xyz1, const float *xyz2, int B, int N, int M, const int32_t *ncnt,
+                                     const int32_t *mcnt, float *dist, int32_t *idx, void *ws, size_t ws_bytes,
+                                     void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  RSLO_CHECK_ARG(B >= 0 && N >= 0 && M >= 1, "chamfer_nn: need M >= 1");
+  if (B == 0 || N == 0) return RSLO_OK;
   const int S = chamfer_segments(B, N, M);
-  if (ws_bytes < rslo_chamfer_ws_bytes(B, N, M)) {
+  if (ws_bytes < chamfer_brute_ws_bytes(B, N, M)) {
     rslo_set_error("chamfer_nn: workspace too small");
     return RSLO_EWS;
   }

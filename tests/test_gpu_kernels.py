@@ -262,6 +262,55 @@ def test_chamfer_full_size_properties(hip):
     assert (i.cpu().numpy() == oi).all() and (d.cpu().numpy() == od).all()
 
 
+@pytest.mark.parametrize("method", ["brute", "grid"])
+def test_chamfer_methods_bitexact_vs_oracle(hip, method):
+    """Both searches behind rslo_chamfer_nn (exhaustive scan / spatially pruned) give the oracle's bits: random clouds,
+    clustered clouds with exact duplicates (ties -> lowest index), far-apart clouds, points outside the key range,
+    ragged batches with +inf padding rows."""
+    rng = np.random.default_rng(11)
+    cases = []
+    cases.append(((rng.normal(size=(2, 3000, 3)) * 10).astype(np.float32), (rng.normal(size=(2, 2500, 3)) * 10).astype(np.float32)))
+    base = (rng.normal(size=(1, 400, 3)) * 20).astype(np.float32)
+    dup = np.concatenate([base, base[:, ::-1], base + np.float32(1e-3)], 1)               # duplicates: ties
+    cases.append((np.concatenate([base, base * np.float32(1.0001)], 1), dup))
+    cases.append((rng.uniform(-70, 70, size=(1, 2000, 3)).astype(np.float32) + np.float32(300.0),
+                  rng.uniform(-70, 70, size=(1, 2100, 3)).astype(np.float32)))             # no overlap, outside the grid
+    cases.append((rng.uniform(-2000, 2000, size=(1, 1500, 3)).astype(np.float32),
+                  rng.uniform(-2000, 2000, size=(1, 1700, 3)).astype(np.float32)))         # clamped keys everywhere
+    for a, c in cases:
+        d, i = hip.chamfer_nn(dev(a), dev(c), method=method)
+        od, oi = O.chamfer_nn(a, c)
+        assert (i.cpu().numpy() == oi).all() and (d.cpu().numpy() == od).all()
+    # ragged: pair b uses its first cnt[b] points on both sides; padding rows answer (+inf, 0)
+    a = (rng.normal(size=(3, 2048, 3)) * 15).astype(np.float32)
+    c = (rng.normal(size=(3, 2304, 3)) * 15).astype(np.float32)
+    ncnt, mcnt = np.array([2048, 1000, 1], np.int32), np.array([2304, 700, 3], np.int32)
+    d, i = hip.chamfer_nn(dev(a), dev(c), ncnt=dev(ncnt), mcnt=dev(mcnt), method=method)
+    d, i = d.cpu().numpy(), i.cpu().numpy()
+    for b in range(3):
+        od, oi = O.chamfer_nn(a[b:b + 1, :ncnt[b]], c[b:b + 1, :mcnt[b]])
+        assert (i[b, :ncnt[b]] == oi[0]).all() and (d[b, :ncnt[b]] == od[0]).all()
+        assert np.isinf(d[b, ncnt[b]:]).all() and (i[b, ncnt[b]:] == 0).all()
+
+
+def test_chamfer_grid_equals_brute_at_full_size(hip):
+    """BASELINE size, ragged batch of 4 KITTI-shaped pairs: the pruned search returns the exhaustive scan's bits, for
+    well-aligned clouds and for a grossly wrong pose (early-training case: most queries far from every target)."""
+    v, c, n = O.voxelize(S.scan(), S.PC_RANGE, S.VOXEL_SIZE, 10, 40000)
+    p = O.vfe_mean(v, n)[:, :3].copy()
+    rng = np.random.default_rng(3)
+    N = len(p)
+    a = np.stack([p, p[rng.permutation(N)], p, p]).astype(np.float32)
+    th = np.float32(2.2)
+    Rz = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1]], np.float32)
+    Rx = np.array([[1, 0, 0], [0, np.cos(th), -np.sin(th)], [0, np.sin(th), np.cos(th)]], np.float32)
+    c = np.stack([p + np.float32([0.8, 0.05, 0.0]), p + np.float32([0.3, -0.2, 0.02]), p @ Rz.T, p @ (Rx @ Rz).T + np.float32(5.0)])
+    cnt = np.array([N, N - 777, N, N - 5000], np.int32)
+    db, ib = hip.chamfer_nn(dev(a), dev(c.astype(np.float32)), ncnt=dev(cnt), mcnt=dev(cnt), method="brute")
+    dg, ig = hip.chamfer_nn(dev(a), dev(c.astype(np.float32)), ncnt=dev(cnt), mcnt=dev(cnt), method="grid")
+    assert torch.equal(ib, ig) and torch.equal(db, dg)
+
+
 def test_segmented_batchnorm_matches_torch_per_frame(hip):
     """rslo_segbn_fwd/bwd == nn.BatchNorm1d applied frame by frame (+ LeakyReLU), incl. running statistics."""
     torch.manual_seed(0)
