@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=4, help="frame pairs per GPU (C3: 4)")
     ap.add_argument("--rings", type=int, default=64, help="64 = KITTI-shaped ~131k points; 128 = dense scan")
     ap.add_argument("--no-optim", action="store_true", help="time forward+backward only")
+    ap.add_argument("--no-prefetch", action="store_true", help="voxelize / plan inside the step on the training stream")
     ap.add_argument("--no-voxelize", action="store_true", help="voxelize once outside the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP events (roofline=null)")
@@ -231,13 +232,25 @@ def main():
     clouds = [[torch.from_numpy(c).to(dev) for c in pair] for pair in clouds]
     fixed_example = workload.make_example(net, clouds, device=dev) if args.no_voxelize else None
 
+    # the next batch is voxelized and its rulebooks planned on a side stream while the current step runs (what the
+    # reference's DataLoader workers do on the CPU); every step still voxelizes its own 2 x batch clouds
+    prefetch = None
+    if fixed_example is None and not args.no_prefetch:
+        prefetch = workload.ExamplePrefetcher(net, device=dev)
+        prefetch.submit(clouds)
+
     def step():
-        ex = fixed_example if fixed_example is not None else workload.make_example(net, clouds, device=dev)
-        if fixed_example is not None:
-            ex = dict(ex)
+        if prefetch is not None:
+            ex = prefetch.get()
+        elif fixed_example is not None:
+            ex = dict(fixed_example)
+        else:
+            ex = workload.make_example(net, clouds, device=dev)
         sched.step(net.get_global_step())
         opt.zero_grad()
         ret = model(ex)
+        if prefetch is not None:
+            prefetch.submit(clouds)
         ret["loss"].mean().backward()
         if dist_on:
             average_gradients(net, mean=True)
@@ -301,7 +314,8 @@ def main():
                                    "%s), bs=%d frame pairs/GPU, fp32, %d-ring scans (~%d pts/frame), dp%d"
                                    % ("" if args.no_optim else " + Adam step", args.batch, args.rings, n_points, world),
                        "frame_pairs_per_gpu": args.batch, "points_per_frame": n_points,
-                       "voxelize_in_step": not args.no_voxelize, "optimizer_in_step": not args.no_optim,
+                       "voxelize_in_step": not args.no_voxelize, "voxelize_prefetch_stream": prefetch is not None,
+                       "optimizer_in_step": not args.no_optim,
                        "final_loss": round(loss_val, 4)},
             "roofline": roof,
             "cpu_baseline": None,

@@ -90,14 +90,25 @@ class SpMiddleFHDWithCov2_3(nn.Module):
         )
         self.max_batch_size = 6
 
-    def forward(self, voxel_features, coors, batch_size):
-        coors = coors.int()
-        x = spconv.SparseConvTensor(voxel_features, coors, self.sparse_shape, batch_size)
-        # all rulebooks first (they depend on coordinates only): the 4 host reads of output-site counts happen
-        # before any convolution is queued, then the ~20 conv launches run without a sync in between
+    def plan(self, coors, batch_size, with_pairs=False):
+        """Every rulebook of the encoder for these coordinates, without touching features: returns the planned
+        (feature-less) SparseConvTensor to hand to forward(..., plan=).  Rulebooks depend on coordinates only, so a data
+        loader can build them ahead of the step (rslo_amd.workload.ExamplePrefetcher does, on a side stream)."""
+        x = spconv.SparseConvTensor(None, coors.int(), self.sparse_shape, batch_size)
         p0 = self.middle_conv.plan(x)
         self.middle_conv_tail.plan(p0)
         self.middle_cov_deconv.plan(p0)
+        if with_pairs:      # the pair-list form used by the weight gradients (otherwise built lazily in backward)
+            for rb in x.indice_dict.values():
+                rb.pairs()
+        return x
+
+    def forward(self, voxel_features, coors, batch_size, plan=None):
+        # all rulebooks first (they depend on coordinates only): the host reads of output-site counts happen
+        # before any convolution is queued, then the ~20 conv launches run without a sync in between
+        if plan is None:
+            plan = self.plan(coors, batch_size)
+        x = plan._like(voxel_features)
         ret0 = self.middle_conv(x)
         ret = self.middle_conv_tail(ret0)
         cov = self.middle_cov_deconv(ret0).features

@@ -211,6 +211,26 @@ class UnVoxelOdomNetICP3(nn.Module):
         return {k: v / max(1, self._time_count_dict[k]) for k, v in self._time_total_dict.items()}
 
     # ------------------------------------------------------------------ forward
+    @staticmethod
+    def _merge_coords(coors, batch_size):
+        merged = []
+        for t, c in enumerate(coors):
+            c = c.int()
+            if t:
+                c = c.clone()
+                c[:, 0] += t * batch_size
+            merged.append(c)
+        return torch.cat(merged, 0)
+
+    def plan_example(self, example):
+        """Attach the encoder's rulebooks to `example` ahead of the step ("sparse_plan"): they depend on the voxel
+        coordinates only.  network_forward picks the plan up instead of building it."""
+        coors = example["coordinates"]
+        B = example["num_voxels"][0].shape[0]
+        example["sparse_plan"] = self.middle_feature_extractor.plan(self._merge_coords(coors, B), len(coors) * B,
+                                                                    with_pairs=self.training)
+        return example
+
     def network_forward(self, voxels, num_points, coors, batch_size, example):
         assert len(voxels) == len(num_points) == len(coors), "The lengths should be same."
         T = len(voxels)
@@ -220,14 +240,10 @@ class UnVoxelOdomNetICP3(nn.Module):
 
         self.start_timer("middle forward")
         # one batched encoder pass: frame t of sample b gets batch index t * B + b
-        merged = []
-        for t in range(T):
-            c = coors[t].int()
-            if t:
-                c = c.clone()
-                c[:, 0] += t * batch_size
-            merged.append(c)
-        bev, cov = self.middle_feature_extractor(torch.cat(voxel_features, 0), torch.cat(merged, 0), T * batch_size)
+        plan = example.get("sparse_plan") if example is not None else None
+        if plan is None:
+            plan = self.middle_feature_extractor.plan(self._merge_coords(coors, batch_size), T * batch_size)
+        bev, cov = self.middle_feature_extractor(torch.cat(voxel_features, 0), plan.indices, T * batch_size, plan=plan)
         spatial_features = list(bev.split(batch_size, dim=0))
         middle_conf_preds = list(cov.split([f.shape[0] for f in voxel_features], dim=0))
         self.end_timer("middle forward")

@@ -63,3 +63,76 @@ def kitti_pairs(batch, n_el=64, start=0):
         p0, p1, _ = synthetic.frame_pair(start + b, n_el=n_el)
         out.append([p0, p1])
     return out
+
+
+class ExamplePrefetcher:
+    """Voxelization + rulebook planning of the NEXT batch on a side stream / helper thread while the current step runs
+    (the role the reference gives its DataLoader workers, which voxelize on the CPU: rslo/data/preprocess.py:461-512;
+    here the voxelizer is a GPU kernel, so "loading ahead" means a second HIP stream).  All host reads of data-dependent
+    sizes (voxel counts, strided-conv output counts) then wait on the side stream only; the training stream never
+    drains.
+
+        pf = ExamplePrefetcher(net); pf.submit(clouds)
+        loop:  ex = pf.get();  out = net(ex);  pf.submit(next_clouds);  out["loss"].backward(); ...
+
+    submit() right before backward(): the helper needs the Python interpreter lock only while the main thread sits in
+    the C++ autograd engine.  The two most recent examples are kept alive so memory handed to the training stream is
+    not recycled by the side stream while still in use."""
+
+    def __init__(self, net, max_voxels=synthetic.MAX_VOXELS, device="cuda", plan=True):
+        import queue
+        import threading
+        device = torch.device(device)
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        self.net, self.max_voxels, self.device, self.plan = net, max_voxels, device, plan
+        self.stream = torch.cuda.Stream(self.device)
+        self._in, self._out = queue.Queue(), queue.Queue()
+        self._keep = []
+        self._thread = threading.Thread(target=self._work, daemon=True)
+        self._thread.start()
+
+    def _work(self):
+        torch.cuda.set_device(self.device)
+        while True:
+            job = self._in.get()
+            if job is None:
+                return
+            clouds, prev_done = job
+            try:
+                if prev_done is not None:
+                    prev_done.synchronize()          # everything older than the previous step has left the GPU
+                del self._keep[:-1]
+                with torch.cuda.stream(self.stream):
+                    ex = make_example(self.net, clouds, self.max_voxels, self.device)
+                    if self.plan:
+                        self.net.plan_example(ex)
+                    ready = torch.cuda.Event()
+                    ready.record(self.stream)
+                self._keep.append(ex)
+                self._out.put((ex, ready, None))
+            except Exception as e:      # surface in get()
+                self._out.put((None, None, e))
+
+    def submit(self, clouds):
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(self.device))
+        self._in.put((clouds, done))
+
+    def get(self):
+        import queue
+        while True:
+            try:
+                ex, ready, err = self._out.get(timeout=5.0)
+                break
+            except queue.Empty:
+                if not self._thread.is_alive():
+                    raise RuntimeError("ExamplePrefetcher: the helper thread died")
+        if err is not None:
+            raise err
+        torch.cuda.current_stream(self.device).wait_event(ready)
+        return ex
+
+    def close(self):
+        self._in.put(None)
+        self._thread.join(timeout=10)
