@@ -6,6 +6,46 @@ from torch import nn
 ReduceOp = dist.ReduceOp
 
 
+_pending_counts = None
+
+
+class defer_batch_counts:
+    """Inside this context the single-rank SyncBatchNorm layers do not launch their own `num_batches_tracked += 1`
+    (45 one-element kernels per forward of the BEV head); the increments are collected and applied at exit with one
+    multi-tensor add per distinct increment.  Same buffer values after the forward."""
+
+    def __enter__(self):
+        global _pending_counts
+        self.prev, _pending_counts = _pending_counts, []
+        return self
+
+    def __exit__(self, *exc):
+        global _pending_counts
+        pending, _pending_counts = _pending_counts, self.prev
+        by_id = {}
+        for t in pending:
+            ent = by_id.setdefault(id(t), [t, 0])
+            ent[1] += 1
+        for inc in sorted({c for _, c in by_id.values()}):
+            ts = [t for t, c in by_id.values() if c == inc]
+            if ts[0].is_cuda:
+                torch._foreach_add_(ts, inc)
+            else:
+                for t in ts:
+                    t.add_(inc)
+        return False
+
+
+def count_batch(bn):
+    """`bn.num_batches_tracked += 1`, deferred when inside defer_batch_counts()."""
+    if bn.num_batches_tracked is None:
+        return
+    if _pending_counts is not None:
+        _pending_counts.append(bn.num_batches_tracked)
+    else:
+        bn.num_batches_tracked.add_(1)
+
+
 class SyncBatchNorm(nn.SyncBatchNorm):
     """apex.parallel.SyncBatchNorm signature on torch's RCCL-backed SyncBatchNorm.  With a single
     process (or no process group) it is exactly BatchNorm (biased variance for normalisation,
@@ -21,8 +61,8 @@ class SyncBatchNorm(nn.SyncBatchNorm):
     def forward(self, x):
         single = not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
         if single or not self.training:
-            if self.training and self.track_running_stats and self.num_batches_tracked is not None:
-                self.num_batches_tracked.add_(1)
+            if self.training and self.track_running_stats:
+                count_batch(self)
             use_batch = self.training or not self.track_running_stats
             return F.batch_norm(x, self.running_mean if self.track_running_stats else None,
                                 self.running_var if self.track_running_stats else None, self.weight, self.bias,

@@ -4,6 +4,8 @@
 xs = [bev_0, bev_1(, bev_2)] each [B,128,96,176] -> all (i<j) pairs -> encoder-decoder -> per-cell
 local (t, q) map -> local->global transform -> confidence-weighted mean = the pair's pose.
 """
+import contextlib
+
 import apex
 import apex.amp as amp
 import torch
@@ -16,6 +18,18 @@ from rslo.layers.MaskConv import MaskConv
 from rslo.models.odom_pred_base import OdomPredEncDecBase, conf_trunk
 from rslo.utils.pose_utils import rotate_vec_by_q
 from torchplus.nn import Empty
+
+# with the ROCm apex stand-in the per-layer `num_batches_tracked += 1` launches are batched (compat/apex/parallel.py);
+# with a real apex they run as usual
+_defer_batch_counts = getattr(apex.parallel, "defer_batch_counts", contextlib.nullcontext)
+
+
+def _count_batch(bn):
+    fn = getattr(apex.parallel, "count_batch", None)
+    if fn is not None:
+        fn(bn)
+    elif bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
 
 REGISTERED_ODOM_PRED_CLASSES = {}
 
@@ -58,6 +72,10 @@ class UNOdomPredEncDecSVDTempMaskBase(OdomPredEncDecBase):
 
     @amp.float_function
     def forward(self, xs, tq_map_gt=None, local_spatial_features=None, **kwargs):
+        with _defer_batch_counts():      # one multi-tensor add for all num_batches_tracked buffers of the head
+            return self._forward(xs)
+
+    def _forward(self, xs):
         if not isinstance(xs, list):
             xs = [xs]
         if self._cycle_constraint:
@@ -144,8 +162,7 @@ class UNOdomPredEncDecSVDTempMaskBase(OdomPredEncDecBase):
             # them), and the reference's second forward updates them in place all the same
             m.running_mean.data.add_((m.running_mean.data - mean0) * (1.0 - mom))
             m.running_var.data.add_((m.running_var.data - var0) * (1.0 - mom))
-            if m.num_batches_tracked is not None:
-                m.num_batches_tracked.add_(1)
+            _count_batch(m)
 
     def vote(self, tq_map, t_conf, r_conf):
         """Ego-motion voting (odom_pred.py:347-357): confidence-weighted mean of the global maps."""
