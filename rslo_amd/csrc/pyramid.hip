@@ -104,12 +104,14 @@ __global__ __launch_bounds__(PY_THREADS) void k_pyramid_fwd(PyLevels lv, int B, 
     for (int k = 0; k < PY_THREADS / 64; ++k) v += red[threadIdx.x][k];
     part[((size_t)row * gridDim.x + blockIdx.x) * 4 + threadIdx.x] = v;
   }
-  __threadfence();
   __syncthreads();
-  if (threadIdx.x == 0) is_last = (atomicAdd(&done[row], 1) == nblk - 1);
+  if (threadIdx.x == 0) {      // one lane releases / acquires for the block (an all-lane fence costs 2-4x)
+    __threadfence();
+    is_last = (atomicAdd(&done[row], 1) == nblk - 1);
+    if (is_last) __threadfence();
+  }
   __syncthreads();
   if (!is_last) return;
-  __threadfence();
   if (threadIdx.x < 4) {
     double v = 0.0;
     for (int k = 0; k < nblk; ++k) v += part[((size_t)row * gridDim.x + k) * 4 + threadIdx.x];

@@ -864,21 +864,32 @@ __global__ void k_wgrad2_reduce(const float *__restrict__ ws, const int32_t *__r
 
 // column sums of x [rows, cols] -> partial[block][cols]; one block per CS_ROWS rows, consecutive threads read
 // consecutive floats (whole rows), 256 / cols_pad row-parts per block reduced through LDS in a fixed order
-// Single-launch column sum (bias gradient): blocks of CS1_ROWS rows write partial rows; the block that finishes
-// last (device counter, reset for the next launch on the same stream) adds the partial rows in block order --
-// deterministic, and one dispatch instead of a two-level tree.
-#define CS1_ROWS 128
+// Single-launch column sum (bias gradient): at most CS1_MAXBLK blocks, each over a contiguous slab of rows, write
+// partial rows; the block that finishes last (device counter, reset for the next launch on the same stream) adds the
+// partial rows in block order (loads unrolled 8 deep: they are independent, only the adds are ordered) --
+// deterministic, one dispatch.
+#define CS1_MAXBLK 512
 __device__ unsigned int g_colsum_done = 0;
-__global__ __launch_bounds__(256) void k_colsum_once(const float *__restrict__ x, int64_t rows, int cols,
-                                                     int cols_pad, float *__restrict__ partial,
+__global__ __launch_bounds__(256) void k_colsum_once(const float *__restrict__ x, int64_t rows, int rows_per_blk,
+                                                     int cols, int cols_pad, float *__restrict__ partial,
                                                      float *__restrict__ result) {
   __shared__ float red[256];
   __shared__ bool last;
   const int c = threadIdx.x % cols_pad, part = threadIdx.x / cols_pad, nparts = 256 / cols_pad;
-  const int64_t r0 = (int64_t)blockIdx.x * CS1_ROWS, r1 = (r0 + CS1_ROWS < rows) ? r0 + CS1_ROWS : rows;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_blk, r1 = (r0 + rows_per_blk < rows) ? r0 + rows_per_blk : rows;
   float s = 0.f;
-  if (c < cols)
-    for (int64_t r = r0 + part; r < r1; r += nparts) s += x[r * cols + c];
+  if (c < cols) {
+    for (int64_t r = r0 + part; r < r1; r += 8 * nparts) {      // 8 independent loads in flight, ordered adds
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int64_t rr = r + (int64_t)u * nparts;
+        v[u] = rr < r1 ? x[rr * cols + c] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+  }
   red[threadIdx.x] = s;
   __syncthreads();
   if (part == 0 && c < cols) {
@@ -886,15 +897,28 @@ __global__ __launch_bounds__(256) void k_colsum_once(const float *__restrict__ x
     for (int p = 0; p < nparts; ++p) t += red[p * cols_pad + c];
     partial[(int64_t)blockIdx.x * cols + c] = t;
   }
-  __threadfence();
   __syncthreads();
-  if (threadIdx.x == 0) last = atomicAdd(&g_colsum_done, 1u) == gridDim.x - 1;
+  if (threadIdx.x == 0) {      // ONE lane releases the block's partial row (a fence by all 256 lanes costs 2-4x, and
+    __threadfence();           // blocks sharing a CU serialise on it: MI355X_MICROARCH.md, fence table)
+    last = atomicAdd(&g_colsum_done, 1u) == gridDim.x - 1;
+    if (last) __threadfence();
+  }
   __syncthreads();
   if (!last) return;
-  __threadfence();
   s = 0.f;
-  if (c < cols)
-    for (unsigned b = part; b < gridDim.x; b += nparts) s += partial[(int64_t)b * cols + c];
+  if (c < cols) {
+    const int nb = (int)gridDim.x;
+    for (int b = part; b < nb; b += 8 * nparts) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int bb = b + u * nparts;
+        v[u] = bb < nb ? __builtin_nontemporal_load(&partial[(int64_t)bb * cols + c]) : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+  }
   red[threadIdx.x] = s;
   __syncthreads();
   if (part == 0 && c < cols) {
@@ -912,8 +936,7 @@ extern "C" size_t rslo_rulebook_pairs_ws_bytes(int64_t n_rows, int K) {
 
 extern "C" size_t rslo_spconv_wgrad_pairs_ws_bytes(int64_t n_out, int K, int cin, int cout) {
   const int64_t nch = rslo_cdiv(n_out > 0 ? n_out : 1, WG2_CHUNK);
-  const int64_t ncs = rslo_cdiv(n_out > 0 ? n_out : 1, CS1_ROWS);
-  return ((size_t)nch * (size_t)K * cin * cout + (size_t)(ncs + 8) * cout) * sizeof(float);
+  return ((size_t)nch * (size_t)K * cin * cout + (size_t)(CS1_MAXBLK + 8) * cout) * sizeof(float);
 }
 
 extern "C" int rslo_spconv_wgrad_pairs(const float *in, int cin, const float *dout, int cout,
@@ -955,7 +978,9 @@ extern "C" int rslo_spconv_wgrad_pairs(const float *in, int cin, const float *do
                      (const float *)ws, koff, K, cc, dW);
   if (dbias) {
     float *wsb = (float *)ws + (int64_t)nch * nW;
-    hipLaunchKernelGGL(k_colsum_once, dim3((unsigned)rslo_cdiv(n_out, CS1_ROWS)), dim3(256), 0, st, dout, n_out,
+    int rpb = (int)rslo_cdiv(n_out, CS1_MAXBLK);
+    rpb = rpb < 64 ? 64 : rpb;
+    hipLaunchKernelGGL(k_colsum_once, dim3((unsigned)rslo_cdiv(n_out, rpb)), dim3(256), 0, st, dout, n_out, rpb,
                        cout, co, wsb, dbias);
   }
   RSLO_CHECK_LAUNCH("wgrad_pairs");
