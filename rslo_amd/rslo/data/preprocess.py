@@ -73,3 +73,42 @@ def example_convert_to_torch(example, dtype=torch.float32, device=None):
             return x
         out[k] = [conv(x) for x in v] if isinstance(v, list) else conv(v)
     return out
+
+
+# --------------------------------------------------------------------------------------------------------------
+# y-flip augmentation (reference: prep_pointcloud, rslo/data/preprocess.py:335-386, flip_odometry :230-245)
+# --------------------------------------------------------------------------------------------------------------
+def flip_odometry(old_odom):
+    """Pose (t, q wxyz) of the scene mirrored in the x-z plane: R' = F R F^T, t' = F t with F = diag(1, -1, 1).
+    For a quaternion that conjugation is (w, x, y, z) -> (w, -x, y, -z); the result is put on the w >= 0 hemisphere like
+    the reference's matrix round trip does."""
+    o = np.asarray(old_odom, dtype=np.float64)
+    q = np.array([o[3], -o[4], o[5], -o[6]])
+    q = q / np.linalg.norm(q)
+    if q[0] < 0:
+        q = -q
+    return np.concatenate([[o[0], -o[1], o[2]], q], axis=-1)
+
+
+def flip_points_y(points):
+    """In place: y -> -y for the coordinates and for the normal's y component (column 5; column 8 when a second
+    normal is present).  Works on numpy arrays and torch tensors (the GPU-resident clouds of the prefetcher)."""
+    points[:, 1] = -points[:, 1]
+    if points.shape[1] >= 6:
+        points[:, 5] = -points[:, 5]
+    if points.shape[1] >= 9:
+        points[:, 8] = -points[:, 8]
+    return points
+
+
+def random_flip_y(input_dict, points_list, rng=np.random):
+    """With probability 1/2 mirror all frames of the sample and every pairwise odometry (and icp_odometry) with it."""
+    if not rng.rand() > 0.5:
+        return False
+    for p in points_list:
+        flip_points_y(p)
+    for key in ("odometry", "icp_odometry"):
+        if input_dict.get(key, None) is not None:
+            for i in range(len(input_dict[key])):
+                input_dict[key][i] = flip_odometry(input_dict[key][i])
+    return True

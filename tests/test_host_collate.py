@@ -39,3 +39,32 @@ def test_merge_accepts_torch_inputs():
     m, n = merge_second_batch([ta, tb]), merge_second_batch([a, b])
     assert (m["coordinates"][1].numpy() == n["coordinates"][1]).all()
     assert (m["voxels"][0].numpy() == n["voxels"][0]).all()
+
+
+def test_flip_y_augmentation_matches_matrix_conjugation():
+    """flip_odometry == the reference's route through rotation matrices (F R F^T, F t), checked with scipy."""
+    from scipy.spatial.transform import Rotation as Rot
+    from rslo.data.preprocess import flip_odometry, flip_points_y, random_flip_y
+    r = np.random.default_rng(0)
+    F = np.diag([1.0, -1.0, 1.0])
+    for _ in range(20):
+        q = r.normal(size=4); q /= np.linalg.norm(q)
+        t = r.normal(size=3)
+        new = flip_odometry(np.concatenate([t, q]))
+        R_old = Rot.from_quat(np.roll(q, -1)).as_matrix()
+        x, y, z, w = Rot.from_matrix(F @ R_old @ F.T).as_quat()
+        q_ref = np.array([w, x, y, z]) * (1 if w >= 0 else -1)
+        np.testing.assert_allclose(new[:3], F @ t, atol=1e-12)
+        np.testing.assert_allclose(new[3:], q_ref, atol=1e-9)
+    pts = r.normal(size=(10, 7)).astype(np.float32)
+    ref = pts.copy()
+    flip_points_y(pts)
+    assert (pts[:, 1] == -ref[:, 1]).all() and (pts[:, 5] == -ref[:, 5]).all() and (pts[:, [0, 2, 3, 4, 6]] == ref[:, [0, 2, 3, 4, 6]]).all()
+    t = torch.from_numpy(ref.copy())
+    assert torch.equal(flip_points_y(t), torch.from_numpy(pts))
+
+    class Always:
+        def rand(self):
+            return 0.9
+    d = {"odometry": [np.array([1.0, 2.0, 3.0, 1.0, 0.0, 0.0, 0.0])], "icp_odometry": None}
+    assert random_flip_y(d, [ref.copy()], rng=Always()) and d["odometry"][0][1] == -2.0
