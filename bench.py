@@ -60,11 +60,14 @@ class ConvProbe:
         self._orig = {}
 
     @staticmethod
-    def kernel_name(cin_op, cout_op, n_out, trans):
-        """The template instantiation rslo_spconv_fwd/dgrad dispatches to (rslo_amd/csrc/spconv.hip)."""
+    def kernel_name(cin_op, cout_op, n_out, trans, split=False):
+        """The template instantiation the entry point dispatches to (rslo_amd/csrc/spconv.hip)."""
         t = "true" if trans else "false"
+        rbw = 2 if n_out >= 256 * 32 * 8 else 1
+        if split:
+            return "k_spconv_v6<%d, %d, %d>" % (cin_op, cout_op, rbw)
         if cin_op % 16 == 0 and cout_op % 16 == 0:
-            return "k_spconv_v3<%d, %d, %d, %s>" % (cin_op, cout_op, 2 if n_out >= 256 * 32 * 8 else 1, t)
+            return "k_spconv_v3<%d, %d, %d, %s>" % (cin_op, cout_op, rbw, t)
         ci = 8 if cin_op <= 8 else (16 if cin_op <= 16 else (32 if cin_op <= 32 else 64))
         co = 16 if cout_op <= 16 else (32 if cout_op <= 32 else 64)
         rb = 2 if (n_out >= 256 * 128 * 2 and co >= 32) else 1
@@ -72,9 +75,10 @@ class ConvProbe:
 
     def install(self):
         capi = self.capi
-        # capi.spconv_dgrad runs through spconv_fwd on transposed weights for MFMA-shaped channels, so the forward
-        # entry sees both directions; only the odd-channel data gradients use the dedicated entry point
-        self._orig = {"spconv_fwd": capi.spconv_fwd, "spconv_dgrad_direct": capi.spconv_dgrad_direct}
+        # the lowest-level wrappers: capi.spconv_fwd / spconv_dgrad only dispatch to these (the data gradient of
+        # MFMA-shaped layers runs through a forward kernel on transposed weights)
+        names = ("spconv_fwd_direct", "spconv_fwd_split", "spconv_dgrad_direct")
+        self._orig = {n: getattr(capi, n) for n in names}
         probe = self
 
         def timed(fn, name_fn):
@@ -95,12 +99,17 @@ class ConvProbe:
             return ("fwd", cin, cout, K, nbr.shape[0], nbr if probe.keep_tables else None,
                     probe.kernel_name(cin, cout, nbr.shape[0], False))
 
+        def split_meta(x, Ws, bias, nbr, cin, cout, flip_k=False, act_slope=1.0):
+            return ("fwd", cin, cout, nbr.shape[1], nbr.shape[0], nbr if probe.keep_tables else None,
+                    probe.kernel_name(cin, cout, nbr.shape[0], False, split=True))
+
         def dgrad_meta(dout, W, nbrT, flip_k=False):
             K, cin, cout = W.shape
             return ("dgrad", cout, cin, K, nbrT.shape[0], nbrT if probe.keep_tables else None,
                     probe.kernel_name(cout, cin, nbrT.shape[0], True))
 
-        capi.spconv_fwd = timed(self._orig["spconv_fwd"], fwd_meta)
+        capi.spconv_fwd_direct = timed(self._orig["spconv_fwd_direct"], fwd_meta)
+        capi.spconv_fwd_split = timed(self._orig["spconv_fwd_split"], split_meta)
         capi.spconv_dgrad_direct = timed(self._orig["spconv_dgrad_direct"], dgrad_meta)
 
     def uninstall(self):
@@ -139,6 +148,12 @@ class ConvProbe:
         else:
             roof = {"bound": "hbm", "kernel": name, "achieved": round(g["GBps"], 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(g["GBps"] / HBM_PEAK_GBS, 4), "traffic": None}
+        if "k_spconv_v6" in name:
+            # fp32 products computed as six bf16 MFMAs on exactly split operands (rslo_amd/csrc/spconv.hip, v6): the
+            # algorithmic fp32 flops are priced against the fp32 MFMA peak; the bf16 matrix-core work issued is 6x that
+            roof["matrix_core_path"] = "fp32 = 3-way exact bf16 split, 6 x v_mfma_f32_16x16x32_bf16 per product block"
+            roof["issued_bf16_TFLOPs"] = round(6 * g["TFLOPs"], 1)
+            roof["issued_bf16_frac_of_2500TF"] = round(6 * g["TFLOPs"] / 2500.0, 4)
         roof.update({"arithmetic_intensity_flop_per_byte": round(ai, 2), "algorithmic_GBps": round(g["GBps"], 1),
                      "hbm_frac": round(g["GBps"] / HBM_PEAK_GBS, 4), "algorithmic_TFLOPs": round(g["TFLOPs"], 2),
                      "avg_launch_us": round(g["avg_us"], 2), "launches_per_step": g["launches"] // max(steps, 1),

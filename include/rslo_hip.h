@@ -122,6 +122,17 @@ RSLO_API int rslo_spconv_dgrad(const float *dout, int cout, const float *W, cons
  *     rslo_spconv_dgrad(dout, Cout, W, nbrT, ...) with weight reads contiguous along the lane index
  *     (12-50 % faster on the 64-channel layers); the host mirror uses this form. */
 RSLO_API int rslo_weight_transpose(const float *W, int K, int cin, int cout, float *Wt, void *stream);
+/*     fp32-accurate sparse conv on the bf16 matrix cores (channel counts 32 / 64): every fp32 value is split exactly
+ *     into three bf16 pieces (hi + mid + lo); six bf16 MFMAs (hh, hm, mh, hl, mm, lh) with fp32 accumulation replace
+ *     the fp32 MFMAs -- error below one fp32 ulp per product, 2.5x fewer matrix-core cycles.
+ *     rslo_weight_split: W [K,Cin_w,Cout_w] fp32 -> Ws (3 planes of bf16, K*cin_op*cout_op each, MFMA operand order);
+ *     transpose = 1 gives the operator of the data gradient (cin_op = Cout_w, cout_op = Cin_w).
+ *     rslo_spconv_fwd_split == rslo_spconv_fwd with the split weights. */
+RSLO_API size_t rslo_weight_split_bytes(int K, int cin, int cout);
+RSLO_API int rslo_weight_split(const float *W, int K, int cin_op, int cout_op, int transpose, void *Ws, void *stream);
+RSLO_API int rslo_spconv_fwd_split(const float *in, int cin, const void *Ws, const float *bias, const int32_t *nbr,
+                                   int64_t n_out, int K, int cout, int flip_k, float act_slope, float *out,
+                                   void *stream);
 RSLO_API size_t rslo_spconv_wgrad_ws_bytes(int64_t n_out, int K, int cin, int cout);
 RSLO_API int rslo_spconv_wgrad(const float *in, int cin, const float *dout, int cout, const int32_t *nbr,
                       int64_t n_out, int K, void *ws, size_t ws_bytes, float *dW /*[K,cin,cout]*/,

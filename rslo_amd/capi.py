@@ -37,6 +37,9 @@ SIGNATURES = {
     "rslo_spconv_fwd": (C.c_int, [_vp, _i, _vp, _vp, _vp, _i64, _i, _i, _i, _f, _vp, _vp]),
     "rslo_spconv_dgrad": (C.c_int, [_vp, _i, _vp, _vp, _i64, _i, _i, _i, _vp, _vp]),
     "rslo_weight_transpose": (C.c_int, [_vp, _i, _i, _i, _vp, _vp]),
+    "rslo_weight_split_bytes": (_sz, [_i, _i, _i]),
+    "rslo_weight_split": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "rslo_spconv_fwd_split": (C.c_int, [_vp, _i, _vp, _vp, _vp, _i64, _i, _i, _i, C.c_float, _vp, _vp]),
     "rslo_spconv_wgrad_ws_bytes": (_sz, [_i64, _i, _i, _i]),
     "rslo_spconv_wgrad": (C.c_int, [_vp, _i, _vp, _i, _vp, _i64, _i, _vp, _sz, _vp, _vp, _vp]),
     "rslo_rulebook_pairs_ws_bytes": (_sz, [_i64, _i]),
@@ -222,12 +225,49 @@ def rulebook_conv(index, ks, stride, pad):
 # --------------------------------------------------------------------------------------
 # sparse conv arithmetic
 # --------------------------------------------------------------------------------------
+SPLIT_BF16 = os.environ.get("RSLO_SPCONV_SPLIT", "1") != "0"     # fp32 via 3-way bf16 splitting on the matrix cores
+
+
+def weight_split(W, transpose=False):
+    """W [K,Cin,Cout] fp32 -> split-bf16 operand planes for rslo_spconv_fwd_split (transpose: data-gradient operator)."""
+    K, cin, cout = W.shape
+    cin_op, cout_op = (cout, cin) if transpose else (cin, cout)
+    Ws = torch.empty((lib().rslo_weight_split_bytes(K, cin, cout),), dtype=torch.uint8, device=W.device)
+    _chk(lib().rslo_weight_split(_ptr(W, torch.float32, "W"), K, cin_op, cout_op, int(transpose), _ptr(Ws), _stream()),
+         "rslo_weight_split")
+    return Ws
+
+
+def spconv_fwd_split(x, Ws, bias, nbr, cin, cout, flip_k=False, act_slope=1.0):
+    n_out, K = nbr.shape
+    if x.shape[1] != cin:
+        raise RsloHipError("spconv_fwd_split: shape mismatch")
+    out = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
+    _chk(lib().rslo_spconv_fwd_split(_ptr(x, torch.float32, "x"), cin, _ptr(Ws), _ptr(bias, torch.float32, "bias"),
+                                     _ptr(nbr, torch.int32, "nbr"), n_out, K, cout, int(flip_k), float(act_slope),
+                                     _ptr(out), _stream()), "rslo_spconv_fwd_split")
+    return out
+
+
+def _splittable(cin, cout):
+    return SPLIT_BF16 and cin in (32, 64) and cout in (32, 64)
+
+
 def spconv_fwd(x, W, bias, nbr, flip_k=False, act_slope=1.0):
     """x [Nin,Cin], W [K,Cin,Cout], nbr [Nout,K] -> [Nout,Cout]."""
     n_out, K = nbr.shape
     Kw, cin, cout = W.shape
     if Kw != K or x.shape[1] != cin:
         raise RsloHipError("spconv_fwd: shape mismatch x%s W%s nbr%s" % (tuple(x.shape), tuple(W.shape), tuple(nbr.shape)))
+    if _splittable(cin, cout):
+        return spconv_fwd_split(x, weight_split(W), bias, nbr, cin, cout, flip_k, act_slope)
+    return spconv_fwd_direct(x, W, bias, nbr, flip_k, act_slope)
+
+
+def spconv_fwd_direct(x, W, bias, nbr, flip_k=False, act_slope=1.0):
+    """rslo_spconv_fwd itself (fp32 MFMA kernels)."""
+    n_out, K = nbr.shape
+    Kw, cin, cout = W.shape
     out = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
     _chk(lib().rslo_spconv_fwd(_ptr(x, torch.float32, "x"), cin, _ptr(W, torch.float32, "W"),
                                _ptr(bias, torch.float32, "bias"), _ptr(nbr, torch.int32, "nbr"), n_out, K, cout,
@@ -249,6 +289,8 @@ def spconv_dgrad(dout, W, nbrT, flip_k=False):
     For MFMA-shaped channel counts the gradient runs through the forward kernel on the transposed weights
     (coalesced weight reads); other shapes use the dedicated entry point."""
     Kw, cin, cout = W.shape
+    if _splittable(cout, cin):
+        return spconv_fwd_split(dout, weight_split(W, transpose=True), None, nbrT, cout, cin, flip_k)
     if cin % 16 == 0 and cout % 16 == 0:
         return spconv_fwd(dout, weight_transpose(W), None, nbrT, flip_k=flip_k)
     return spconv_dgrad_direct(dout, W, nbrT, flip_k)

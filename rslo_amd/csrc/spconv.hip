@@ -448,6 +448,197 @@ __global__ __launch_bounds__(SPC_THREADS) void k_spconv_v3(const float *__restri
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// v6: fp32-accurate sparse conv on the bf16 matrix cores (channel counts 32 / 64).
+// gfx950 issues v_mfma_f32_16x16x4_f32 at 1/16 of the bf16 MFMA rate (2048 flop / 32 cycles against 16384 flop / ~17
+// cycles for v_mfma_f32_16x16x32_bf16).  An fp32 number splits EXACTLY into three bf16 pieces by truncation
+// (a = hi + mid + lo, 8 significant bits each); products of pieces are exact in fp32 and the matrix core accumulates
+// in fp32, so   a*b = hh + (hm + mh) + (hl + mm + lh) + O(2^-24 |ab|)   -- six bf16 MFMAs with K = 32 replace
+// eight fp32 MFMAs with K = 4 per 16x16x32 block: 2.5x fewer matrix-core cycles at fp32-level accuracy (the three
+// dropped terms are below one fp32 ulp of the product).  Weights are split once per call by k_weight_split (which
+// also transposes for the data gradient); activations are split in registers after the gather (2 and + 2 sub per
+// value, v_perm to pack pairs).
+// Operand layout of v_mfma_f32_16x16x32_bf16: lane (g = l>>4, li = l&15) holds A[row li][8 k-values of group g] and
+// B[the same 8 k-values][col li]; k-value e of group g in K-step s is input channel 32 s + 8 g + e, so a lane gathers
+// 32 contiguous bytes of its row per K-step.  C/D as in the fp32 form (col li, rows 4g..4g+3).
+// ---------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// Ws[plane][k][s][g][co][e] (bf16 bits), plane 0/1/2 = hi/mid/lo, input channel ci = 32 s + 8 g + e.
+// src index: TRANSPOSE ? W[k][co_out = ci][..]: the conv computed is  out[:, co] = sum_ci in[:, ci] * M[ci][co]  with
+// M = W[k] (forward) or W[k]^T (data gradient: ci runs over Cout of W, co over Cin of W).
+__global__ void k_weight_split(const float *__restrict__ W, int K, int cin_op, int cout_op, int transpose,
+                               unsigned short *__restrict__ Ws) {
+  const int64_t n = (int64_t)K * cin_op * cout_op;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  // i enumerates the destination (k, s, g, co, e)
+  const int e = (int)(i & 7);
+  int64_t r = i >> 3;
+  const int co = (int)(r % cout_op);
+  r /= cout_op;
+  const int g = (int)(r & 3);
+  r >>= 2;
+  const int S = cin_op / 32;
+  const int sk = (int)(r % S);
+  const int k = (int)(r / S);
+  const int ci = 32 * sk + 8 * g + e;
+  // position co = 16 nb + li holds output channel NB li + nb (a lane's NB accumulator columns are then NB consecutive
+  // channels: one 16-byte store per row in the epilogue), NB = cout_op / 16
+  const int ch = (cout_op / 16) * (co & 15) + (co >> 4);
+  const float w = transpose ? W[((int64_t)k * cout_op + ch) * cin_op + ci]      // W is [K, Cin_w = cout_op, Cout_w = cin_op]
+                            : W[((int64_t)k * cin_op + ci) * cout_op + ch];
+  const unsigned wb = __float_as_uint(w);
+  const unsigned hb = wb & 0xffff0000u;
+  const float r1 = w - __uint_as_float(hb);
+  const unsigned mb = __float_as_uint(r1) & 0xffff0000u;
+  const float r2 = r1 - __uint_as_float(mb);
+  Ws[i] = (unsigned short)(hb >> 16);
+  Ws[n + i] = (unsigned short)(mb >> 16);
+  Ws[2 * n + i] = (unsigned short)(__float_as_uint(r2) >> 16);
+}
+
+struct Split8 {
+  u32x4 h, m, l;
+};
+
+// 8 fp32 values (two float4) -> three bf16x8 operands
+__device__ __forceinline__ Split8 split8(const float4 a, const float4 b, bool ok) {
+  float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  unsigned hb[8], mb[8], lb[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float x = ok ? v[e] : 0.f;
+    hb[e] = __float_as_uint(x) & 0xffff0000u;
+    const float r1 = x - __uint_as_float(hb[e]);
+    mb[e] = __float_as_uint(r1) & 0xffff0000u;
+    lb[e] = __float_as_uint(r1 - __uint_as_float(mb[e]));
+  }
+  Split8 o;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    o.h[p] = __builtin_amdgcn_perm(hb[2 * p + 1], hb[2 * p], 0x07060302u);
+    o.m[p] = __builtin_amdgcn_perm(mb[2 * p + 1], mb[2 * p], 0x07060302u);
+    o.l[p] = __builtin_amdgcn_perm(lb[2 * p + 1], lb[2 * p], 0x07060302u);
+  }
+  return o;
+}
+
+#define MFMA_BF16(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), C, 0, 0, 0)
+
+template <int CIN_T, int COUT_T, int RBW>
+__global__ __launch_bounds__(SPC_THREADS) void k_spconv_v6(const float *__restrict__ in,
+                                                           const unsigned short *__restrict__ Ws,
+                                                           const float *__restrict__ bias,
+                                                           const int32_t *__restrict__ nbr, int64_t n_out,
+                                                           int K, int flip_k, float slope,
+                                                           float *__restrict__ out) {
+  constexpr int NS = CIN_T / 32;       // K-steps of 32 input channels
+  constexpr int NB = COUT_T / 16;      // 16-column blocks: column li of block nb = output channel NB li + nb
+  constexpr int ROWS = 16 * RBW;
+  __shared__ int32_t nbl[SPC_WAVES][ROWS * SPC_MAXK];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int64_t n_tiles = (n_out + ROWS - 1) / ROWS;
+  const int64_t n_blocks = (n_tiles + SPC_WAVES - 1) / SPC_WAVES;
+  const int64_t vb = xcd_tile(n_blocks);
+  const int64_t tile = vb * SPC_WAVES + wid;
+  const bool active = vb < n_blocks && tile < n_tiles;
+  const int64_t row0 = tile * ROWS;
+
+  if (active) {
+    const int64_t lim = (n_out - row0) * K;
+    for (int e = lane; e < ROWS * K; e += 64) nbl[wid][e] = (e < lim) ? nbr[row0 * K + e] : -1;
+  }
+  __syncthreads();
+  if (!active) return;
+
+  unsigned mask = 0;
+  for (int k = 0; k < K; ++k) {
+    bool any = false;
+#pragma unroll
+    for (int rb = 0; rb < RBW; ++rb) any |= nbl[wid][(rb * 16 + li) * K + k] >= 0;
+    if (__ballot(any) != 0ull) mask |= 1u << k;
+  }
+  mask = __builtin_amdgcn_readfirstlane(mask);
+
+  f32x4 acc[RBW][NB];
+#pragma unroll
+  for (int rb = 0; rb < RBW; ++rb)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[rb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int64_t plane = (int64_t)K * CIN_T * COUT_T;          // bf16 elements per plane
+  while (mask) {
+    const int k = __builtin_ctz(mask);
+    mask &= mask - 1;
+    const int kk = flip_k ? (K - 1 - k) : k;
+    const float *ap[RBW];
+    bool ok[RBW];
+#pragma unroll
+    for (int rb = 0; rb < RBW; ++rb) {
+      const int32_t r = nbl[wid][(rb * 16 + li) * K + k];
+      ok[rb] = r >= 0;
+      ap[rb] = in + (int64_t)(ok[rb] ? r : 0) * CIN_T + 8 * g;
+    }
+#pragma unroll
+    for (int sk = 0; sk < NS; ++sk) {
+      Split8 a[RBW];
+#pragma unroll
+      for (int rb = 0; rb < RBW; ++rb) {
+        const float4 x0 = *reinterpret_cast<const float4 *>(ap[rb] + 32 * sk);
+        const float4 x1 = *reinterpret_cast<const float4 *>(ap[rb] + 32 * sk + 4);
+        a[rb] = split8(x0, x1, ok[rb]);
+      }
+      // Ws[plane][kk][sk][g][co][8]: 16 bytes per lane, consecutive li -> consecutive 16 bytes
+      const unsigned short *wb = Ws + ((((int64_t)kk * NS + sk) * 4 + g) * COUT_T + li) * 8;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const u32x4 bh = *reinterpret_cast<const u32x4 *>(wb + nb * 16 * 8);
+        const u32x4 bm = *reinterpret_cast<const u32x4 *>(wb + plane + nb * 16 * 8);
+        const u32x4 bl = *reinterpret_cast<const u32x4 *>(wb + 2 * plane + nb * 16 * 8);
+        // smallest terms first; consecutive MFMAs alternate between the row blocks' accumulators
+#pragma unroll
+        for (int rb = 0; rb < RBW; ++rb) acc[rb][nb] = MFMA_BF16(a[rb].l, bh, acc[rb][nb]);
+#pragma unroll
+        for (int rb = 0; rb < RBW; ++rb) acc[rb][nb] = MFMA_BF16(a[rb].m, bm, acc[rb][nb]);
+#pragma unroll
+        for (int rb = 0; rb < RBW; ++rb) acc[rb][nb] = MFMA_BF16(a[rb].h, bl, acc[rb][nb]);
+#pragma unroll
+        for (int rb = 0; rb < RBW; ++rb) acc[rb][nb] = MFMA_BF16(a[rb].m, bh, acc[rb][nb]);
+#pragma unroll
+        for (int rb = 0; rb < RBW; ++rb) acc[rb][nb] = MFMA_BF16(a[rb].h, bm, acc[rb][nb]);
+#pragma unroll
+        for (int rb = 0; rb < RBW; ++rb) acc[rb][nb] = MFMA_BF16(a[rb].h, bh, acc[rb][nb]);
+      }
+    }
+  }
+
+  // epilogue: lane (g, li) holds rows 4g+j, output channels NB*li .. NB*li+NB-1
+  VecF<NB> bv;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) bv.v[nb] = bias ? bias[NB * li + nb] : 0.f;
+#pragma unroll
+  for (int rb = 0; rb < RBW; ++rb)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t row = row0 + rb * 16 + 4 * g + j;
+      if (row >= n_out) continue;
+      float o[NB];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        float v = acc[rb][nb][j] + bv.v[nb];
+        o[nb] = v > 0.f ? v : v * slope;
+      }
+      float *dst = out + row * COUT_T + NB * li;
+      if constexpr (NB == 4)
+        *reinterpret_cast<float4 *>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+      else
+        *reinterpret_cast<float2 *>(dst) = make_float2(o[0], o[1]);
+    }
+}
+
 // W [K, Cin, Cout] -> Wt [K, Cout, Cin]: lets the data gradient run through the FORWARD kernel (dgrad = conv of
 // dout with the per-offset transposed weights), whose weight reads are contiguous along the lane index.  The
 // TRANS instantiations read W with a Cin*4-byte lane stride (64 cache lines per wave load) and measured
@@ -473,6 +664,44 @@ extern "C" int rslo_weight_transpose(const float *W, int K, int cin, int cout, f
   dim3 grid((unsigned)rslo_cdiv(cout, 32), (unsigned)rslo_cdiv(cin, 32), (unsigned)K);
   hipLaunchKernelGGL(k_weight_transpose, grid, dim3(32, 8), 0, (hipStream_t)stream, W, cin, cout, Wt);
   RSLO_CHECK_LAUNCH("k_weight_transpose");
+  return RSLO_OK;
+}
+
+
+extern "C" size_t rslo_weight_split_bytes(int K, int cin, int cout) { return (size_t)3 * K * cin * cout * sizeof(unsigned short); }
+
+extern "C" int rslo_weight_split(const float *W, int K, int cin_op, int cout_op, int transpose, void *Ws, void *stream) {
+  RSLO_CHECK_ARG(W && Ws && K >= 1, "rslo_weight_split: bad arguments");
+  RSLO_CHECK_ARG((cin_op == 32 || cin_op == 64) && (cout_op == 32 || cout_op == 64),
+                 "rslo_weight_split: channel counts must be 32 or 64");
+  const int64_t n = (int64_t)K * cin_op * cout_op;
+  hipLaunchKernelGGL(k_weight_split, dim3((unsigned)rslo_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, W, K, cin_op,
+                     cout_op, transpose, (unsigned short *)Ws);
+  RSLO_CHECK_LAUNCH("k_weight_split");
+  return RSLO_OK;
+}
+
+extern "C" int rslo_spconv_fwd_split(const float *in, int cin, const void *Ws, const float *bias, const int32_t *nbr,
+                                     int64_t n_out, int K, int cout, int flip_k, float act_slope, float *out,
+                                     void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  RSLO_CHECK_ARG((cin == 32 || cin == 64) && (cout == 32 || cout == 64), "spconv_fwd_split: channels must be 32 or 64");
+  RSLO_CHECK_ARG(K >= 1 && K <= SPC_MAXK, "spconv_fwd_split: K must be in 1..27");
+  if (n_out == 0) return RSLO_OK;
+  const unsigned short *ws = (const unsigned short *)Ws;
+  const int rbw = (n_out >= 256 * 32 * 8) ? 2 : 1;
+#define SPC6_CASE(CI, CO)                                                                                    \
+  if (cin == CI && cout == CO) {                                                                             \
+    if (rbw == 2)                                                                                            \
+      hipLaunchKernelGGL((k_spconv_v6<CI, CO, 2>), dim3(xcd_grid(rslo_cdiv(rslo_cdiv(n_out, 32), 4))),       \
+                         dim3(SPC_THREADS), 0, st, in, ws, bias, nbr, n_out, K, flip_k, act_slope, out);     \
+    else                                                                                                     \
+      hipLaunchKernelGGL((k_spconv_v6<CI, CO, 1>), dim3(xcd_grid(rslo_cdiv(rslo_cdiv(n_out, 16), 4))),       \
+                         dim3(SPC_THREADS), 0, st, in, ws, bias, nbr, n_out, K, flip_k, act_slope, out);     \
+  }
+  SPC6_CASE(32, 32) SPC6_CASE(32, 64) SPC6_CASE(64, 32) SPC6_CASE(64, 64)
+#undef SPC6_CASE
+  RSLO_CHECK_LAUNCH("spconv_v6");
   return RSLO_OK;
 }
 
