@@ -241,6 +241,14 @@ RSLO_API int rslo_icp_step(const float *p1, const float *n1, const float *tgt, c
                   void *stream);
 RSLO_API int rslo_transform_points(const float *x, const float *R, const float *t, int B, int M, float *out,
                           void *stream);
+/*     The same rigid map on rows of `row_stride` floats (t may be NULL), and its pose gradient
+ *     dR[b] = sum_j g[b][j] x[b][j]^T, dt[b] = sum_j g[b][j]  (p2_moved / n2_moved of the loss assembly,
+ *     rslo/models/voxel_odom_net.py:668-676).  done: int32 [B] counters, zero on entry, left zero. */
+RSLO_API int rslo_transform_rows(const float *x, int row_stride, const float *R, const float *t, int B, int M,
+                                 float *out, void *stream);
+RSLO_API size_t rslo_transform_rows_bwd_ws_bytes(int B, int M);
+RSLO_API int rslo_transform_rows_bwd(const float *x, int row_stride, const float *gout, int B, int M, void *ws,
+                                     size_t ws_bytes, int32_t *done, float *dR, float *dt, void *stream);
 
 /* a21  pyramid supervision of the per-cell local transformation maps, all levels in one launch
  *      (rslo/models/voxel_odom_net.py:706-760 pyramid part of create_loss; target map of gen_tq_maps

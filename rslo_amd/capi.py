@@ -65,6 +65,9 @@ SIGNATURES = {
     "rslo_icp_ws_bytes": (_sz, [_i, _i]),
     "rslo_icp_step": (C.c_int, [_vp] * 6 + [_i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
     "rslo_transform_points": (C.c_int, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "rslo_transform_rows": (C.c_int, [_vp, _i, _vp, _vp, _i, _i, _vp, _vp]),
+    "rslo_transform_rows_bwd_ws_bytes": (_sz, [_i, _i]),
+    "rslo_transform_rows_bwd": (C.c_int, [_vp, _i, _vp, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp]),
     "rslo_pad_rows_fwd": (C.c_int, [_vp, _i64, _i, _vp, _vp, _i, _i, _vp, _vp]),
     "rslo_pad_rows_bwd": (C.c_int, [_vp, _i64, _i, _vp, _vp, _i, _i, _vp, _vp]),
     "rslo_pyramid_l2_ws_bytes": (_sz, [_vp, _i, _i]),
@@ -571,3 +574,45 @@ def pad_rows_bwd(dout, off, length, N):
     _chk(lib().rslo_pad_rows_bwd(_ptr(dout, torch.float32, "dout"), N, Cc, _ptr(off, torch.int32, "off"),
                                  _ptr(length, torch.int32, "len"), B, int(Lmax), _ptr(dsrc), _stream()), "rslo_pad_rows_bwd")
     return dsrc
+
+
+def _rows_view(x):
+    """[B,M,3] view whose rows are `stride` floats apart inside a contiguous [B,M,C] tensor -> (ptr, stride)."""
+    B, M, three = x.shape
+    if three != 3 or x.dtype != torch.float32 or not x.is_cuda:
+        raise RsloHipError("transform_rows: need a float32 cuda [B,M,3] tensor")
+    sb, sm, sc = x.stride()
+    if sc != 1 or sb != M * sm or sm < 3:
+        x = x.contiguous()
+        sm = 3
+    return x, C.c_void_p(x.data_ptr()), sm
+
+
+def transform_rows(x, R, t=None):
+    """out[b,j] = R[b] x[b,j] (+ t[b]);  x may be a column slice of a wider row-major tensor."""
+    x, ptr, stride = _rows_view(x)
+    B, M, _ = x.shape
+    out = torch.empty((B, M, 3), dtype=torch.float32, device=x.device)
+    _chk(lib().rslo_transform_rows(ptr, stride, _ptr(R, torch.float32, "R"), _ptr(t, torch.float32, "t"), B, M,
+                                   _ptr(out), _stream()), "rslo_transform_rows")
+    return out
+
+
+_tr_done = {}
+
+
+def transform_rows_bwd(x, gout):
+    """-> (dR [B,3,3], dt [B,3]) of out = R x + t."""
+    x, ptr, stride = _rows_view(x)
+    B, M, _ = x.shape
+    dev = x.device
+    done = _tr_done.get(dev)
+    if done is None or done.numel() < B:
+        done = _tr_done[dev] = torch.zeros((max(B, 64),), dtype=torch.int32, device=dev)
+    wsb = lib().rslo_transform_rows_bwd_ws_bytes(B, M)
+    ws = _ws(wsb, dev)
+    dR = torch.empty((B, 3, 3), dtype=torch.float32, device=dev)
+    dt = torch.empty((B, 3), dtype=torch.float32, device=dev)
+    _chk(lib().rslo_transform_rows_bwd(ptr, stride, _ptr(gout, torch.float32, "gout"), B, M, _ptr(ws), wsb, _ptr(done),
+                                       _ptr(dR), _ptr(dt), _stream()), "rslo_transform_rows_bwd")
+    return dR, dt

@@ -534,6 +534,104 @@ extern "C" int rslo_transform_points(const float *x, const float *R, const float
   return RSLO_OK;
 }
 
+// out[b][j] = R[b] x[b][j] (+ t[b]) for rows of `row_stride` floats (the xyz / normal columns of the padded loss batch
+// are used in place), and its backward w.r.t. the pose: dR[b] = sum_j g[b][j] x[b][j]^T, dt[b] = sum_j g[b][j]
+// (block partial sums in double, last block adds them in block order: deterministic; replaces 6 tiny-tile rocBLAS
+// bmm launches of 0.1-0.2 ms each).  voxel_odom_net.py:668-676 (p2_moved / n2_moved).
+__global__ void k_transform_rows(const float *__restrict__ x, int row_stride, const float *__restrict__ R,
+                                 const float *__restrict__ t, int M, float *__restrict__ out) {
+  const int b = blockIdx.y;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= M) return;
+  const float *p = x + ((int64_t)b * M + j) * row_stride;
+  const float *r = R + b * 9;
+  float *o = out + ((int64_t)b * M + j) * 3;
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+    o[a] = r[a * 3 + 0] * p[0] + r[a * 3 + 1] * p[1] + r[a * 3 + 2] * p[2] + (t ? t[b * 3 + a] : 0.f);
+}
+
+#define TR_THREADS 256
+__global__ __launch_bounds__(TR_THREADS) void k_transform_rows_bwd(const float *__restrict__ x, int row_stride,
+                                                                   const float *__restrict__ g, int M,
+                                                                   double *__restrict__ part, int *__restrict__ done,
+                                                                   float *__restrict__ dR, float *__restrict__ dt) {
+  const int b = blockIdx.y;
+  const int j = blockIdx.x * TR_THREADS + threadIdx.x;
+  double s[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) s[k] = 0.0;
+  if (j < M) {
+    const float *p = x + ((int64_t)b * M + j) * row_stride;
+    const float *q = g + ((int64_t)b * M + j) * 3;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) s[a * 3 + c] = (double)q[a] * (double)p[c];
+      s[9 + a] = q[a];
+    }
+  }
+  __shared__ double red[12][TR_THREADS / 64];
+  __shared__ int is_last;
+#pragma unroll
+  for (int k = 0; k < 12; ++k) {
+    double v = s[k];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 12) {
+    double v = 0.0;
+    for (int w = 0; w < TR_THREADS / 64; ++w) v += red[threadIdx.x][w];
+    part[((int64_t)b * gridDim.x + blockIdx.x) * 12 + threadIdx.x] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    is_last = atomicAdd(&done[b], 1) == (int)gridDim.x - 1;
+    if (is_last) __threadfence();
+  }
+  __syncthreads();
+  if (!is_last) return;
+  if (threadIdx.x < 12) {
+    double v = 0.0;
+    for (unsigned k = 0; k < gridDim.x; ++k) v += part[((int64_t)b * gridDim.x + k) * 12 + threadIdx.x];
+    if (threadIdx.x < 9)
+      dR[b * 9 + threadIdx.x] = (float)v;
+    else
+      dt[b * 3 + threadIdx.x - 9] = (float)v;
+  }
+  if (threadIdx.x == 0) done[b] = 0;
+}
+
+extern "C" int rslo_transform_rows(const float *x, int row_stride, const float *R, const float *t, int B, int M,
+                                   float *out, void *stream) {
+  RSLO_CHECK_ARG(x && R && out && row_stride >= 3, "rslo_transform_rows: bad arguments");
+  if (B == 0 || M == 0) return RSLO_OK;
+  hipLaunchKernelGGL(k_transform_rows, dim3((unsigned)rslo_cdiv(M, 256), B), dim3(256), 0, (hipStream_t)stream, x,
+                     row_stride, R, t, M, out);
+  RSLO_CHECK_LAUNCH("transform_rows");
+  return RSLO_OK;
+}
+
+extern "C" size_t rslo_transform_rows_bwd_ws_bytes(int B, int M) {
+  return (size_t)(B > 0 ? B : 1) * (size_t)rslo_cdiv(M > 0 ? M : 1, TR_THREADS) * 12 * sizeof(double);
+}
+
+extern "C" int rslo_transform_rows_bwd(const float *x, int row_stride, const float *gout, int B, int M, void *ws,
+                                       size_t ws_bytes, int32_t *done, float *dR, float *dt, void *stream) {
+  RSLO_CHECK_ARG(x && gout && done && dR && dt && row_stride >= 3 && M >= 1, "rslo_transform_rows_bwd: bad arguments");
+  if (B == 0) return RSLO_OK;
+  if (ws_bytes < rslo_transform_rows_bwd_ws_bytes(B, M)) {
+    rslo_set_error("transform_rows_bwd: workspace too small");
+    return RSLO_EWS;
+  }
+  hipLaunchKernelGGL(k_transform_rows_bwd, dim3((unsigned)rslo_cdiv(M, TR_THREADS), B), dim3(TR_THREADS), 0,
+                     (hipStream_t)stream, x, row_stride, gout, M, (double *)ws, (int *)done, dR, dt);
+  RSLO_CHECK_LAUNCH("transform_rows_bwd");
+  return RSLO_OK;
+}
+
 // ----------------------------------------------------------------------------------------------------
 // Ragged batch assembly for the consistency loss (voxel_odom_net.py:629-651: every sample's frames are cut to the
 // shortest one; here all samples of a frame become ONE zero-padded [B, Lmax, C] batch).  Rows of sample b are

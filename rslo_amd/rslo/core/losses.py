@@ -113,6 +113,31 @@ def pad_rows(src, off, length, Lmax):
     return out
 
 
+class _RigidMoveFn(torch.autograd.Function):
+    """out = R x + t for a batch of point sets; gradients flow to the pose (R, t) only -- the points are network
+    inputs (rslo_transform_rows / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, x, R, t):
+        ctx.save_for_backward(x)
+        ctx.has_t = t is not None
+        return capi.transform_rows(x, R.contiguous(), None if t is None else t.contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        dR, dt = capi.transform_rows_bwd(x, g.contiguous())
+        return None, dR, (dt if ctx.has_t else None)
+
+
+def rigid_move(x, R, t=None):
+    """x [B,M,3] (no gradient), R [B,3,3], t [B,3] or None -> R x (+ t), differentiable in R and t."""
+    if x.is_cuda:
+        return _RigidMoveFn.apply(x.detach(), R, t)
+    out = x.detach() @ R.transpose(-1, -2)
+    return out if t is None else out + t[:, None]
+
+
 _const_cache = {}
 
 

@@ -427,8 +427,9 @@ class UnVoxelOdomNetICP3(nn.Module):
                     R_pred = torch.eye(3, device=device, dtype=dtype).expand(R_pred.shape[0], 3, 3).contiguous()
                     T_pred = torch.zeros_like(T_pred)
                 icp_iter = self.icp_iter if step > 1500 else 5
-                p2_moved = pts2[:, :, :3] @ R_pred.transpose(-1, -2) + T_pred[:, None]
-                n2_moved = pts2[:, :, 3:] @ R_pred.detach().transpose(-1, -2)
+                # the points/normals are network inputs: only the pose receives a gradient through the move
+                p2_moved = losses.rigid_move(pts2[:, :, :3], R_pred, T_pred)
+                n2_moved = losses.rigid_move(pts2[:, :, 3:], R_pred.detach())
                 lb, res_r, res_t = consistency_loss.pair_losses(
                     pts1[:, :, :3], p2_moved, cov_pred=cov1, cov_target=cov2, R_pred=R_pred, t_pred=T_pred,
                     normal_pred=pts1[:, :, 3:].detach(), normal_target=n2_moved.detach(), icp_iter=icp_iter,

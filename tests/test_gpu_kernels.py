@@ -379,3 +379,23 @@ def test_pad_rows_fwd_bwd(hip):
     out = losses.pad_rows(dev_in, off.cuda(), length.cuda(), 400)
     (out * w.cuda()).sum().backward()
     assert torch.equal(out.cpu(), ref) and torch.equal(dev_in.grad.cpu(), ref_in.grad)
+
+
+def test_rigid_move_fwd_bwd(hip):
+    """rslo_transform_rows / _bwd on a column slice of a wider tensor == x @ R^T + t and its pose gradients."""
+    from rslo.core import losses
+    g = torch.Generator().manual_seed(4)
+    wide = torch.randn(3, 1500, 6, generator=g)
+    R = torch.randn(3, 3, 3, generator=g, requires_grad=True)
+    t = torch.randn(3, 3, generator=g, requires_grad=True)
+    w = torch.randn(3, 1500, 3, generator=g)
+    ref = losses.rigid_move(wide[:, :, 3:], R, t)               # CPU formulation
+    (ref * w).sum().backward()
+    Rd, td = R.detach().cuda().requires_grad_(True), t.detach().cuda().requires_grad_(True)
+    out = losses.rigid_move(wide.cuda()[:, :, 3:], Rd, td)
+    (out * w.cuda()).sum().backward()
+    assert float((out.cpu() - ref).abs().max()) < 1e-5
+    assert float((Rd.grad.cpu() - R.grad).abs().max() / R.grad.abs().max()) < 1e-5
+    assert float((td.grad.cpu() - t.grad).abs().max() / t.grad.abs().max()) < 1e-5
+    out2 = losses.rigid_move(wide.cuda()[:, :, :3], Rd.detach())
+    assert float((out2.cpu() - wide[:, :, :3] @ R.detach().transpose(-1, -2)).abs().max()) < 1e-5
