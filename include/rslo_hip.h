@@ -283,6 +283,29 @@ RSLO_API int rslo_pad_rows_fwd(const float *src, int64_t N, int C, const int32_t
 RSLO_API int rslo_pad_rows_bwd(const float *dout, int64_t N, int C, const int32_t *off, const int32_t *len, int B,
                                int Lmax, float *dsrc, void *stream);
 
+/* a10-a12  training-mode (Sync)BatchNorm2d of the dense head fused with activation and residual add, NCHW fp32
+ *      (apex.parallel.SyncBatchNorm via rslo/layers/SparseConv.py:96-113; rslo/models/custom_resnet_spc.py:224-298).
+ *      stats [2C+1] doubles = per-channel sum, sum of squares, element count: the caller all-reduces them across ranks
+ *      between rslo_bn2d_stats and rslo_bn2d_apply (nothing to do on one rank).  apply: y = act(gamma (x-mean) invstd +
+ *      beta (+ res)), running statistics updated with `momentum` (unbiased variance), mean / invstd saved.
+ *      backward: rslo_bn2d_bwd_reduce gives red [2C] = sum g, sum g x^ (g = dy act'(y); all-reduce across ranks) and
+ *      the LOCAL dgamma / dbeta; rslo_bn2d_bwd_apply gives dx (and dres = g).  done: int32 [C], zero on entry / exit. */
+RSLO_API size_t rslo_bn2d_ws_bytes(int N, int C, int HW);
+RSLO_API int rslo_bn2d_stats(const float *x, int N, int C, int HW, void *ws, size_t ws_bytes, int32_t *done,
+                             double *stats, void *stream);
+RSLO_API int rslo_bn2d_apply(const float *x, const float *res, const double *stats, const float *gamma,
+                             const float *beta, int N, int C, int HW, float eps, float momentum, float act_slope,
+                             float *running_mean, float *running_var, float *save_mean, float *save_invstd, float *y,
+                             void *stream);
+RSLO_API int rslo_bn2d_bwd_reduce(const float *dy, const float *y, const float *x, const float *save_mean,
+                                  const float *save_invstd, int N, int C, int HW, float act_slope, int has_act,
+                                  void *ws, size_t ws_bytes, int32_t *done, double *red, float *dgamma, float *dbeta,
+                                  void *stream);
+RSLO_API int rslo_bn2d_bwd_apply(const float *dy, const float *y, const float *x, const float *gamma,
+                                 const float *save_mean, const float *save_invstd, const double *red, double count,
+                                 int N, int C, int HW, float act_slope, int has_act, float *dx, float *dres,
+                                 void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -68,6 +68,14 @@ SIGNATURES = {
     "rslo_transform_rows": (C.c_int, [_vp, _i, _vp, _vp, _i, _i, _vp, _vp]),
     "rslo_transform_rows_bwd_ws_bytes": (_sz, [_i, _i]),
     "rslo_transform_rows_bwd": (C.c_int, [_vp, _i, _vp, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp]),
+    "rslo_bn2d_ws_bytes": (_sz, [_i, _i, _i]),
+    "rslo_bn2d_stats": (C.c_int, [_vp, _i, _i, _i, _vp, _sz, _vp, _vp, _vp]),
+    "rslo_bn2d_apply": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, C.c_float, C.c_float, C.c_float, _vp, _vp, _vp,
+                                  _vp, _vp, _vp]),
+    "rslo_bn2d_bwd_reduce": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, C.c_float, _i, _vp, _sz, _vp, _vp, _vp, _vp,
+                                       _vp]),
+    "rslo_bn2d_bwd_apply": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, _i, _i, _i, C.c_float, _i, _vp, _vp,
+                                      _vp]),
     "rslo_pad_rows_fwd": (C.c_int, [_vp, _i64, _i, _vp, _vp, _i, _i, _vp, _vp]),
     "rslo_pad_rows_bwd": (C.c_int, [_vp, _i64, _i, _vp, _vp, _i, _i, _vp, _vp]),
     "rslo_pyramid_l2_ws_bytes": (_sz, [_vp, _i, _i]),
@@ -616,3 +624,68 @@ def transform_rows_bwd(x, gout):
     _chk(lib().rslo_transform_rows_bwd(ptr, stride, _ptr(gout, torch.float32, "gout"), B, M, _ptr(ws), wsb, _ptr(done),
                                        _ptr(dR), _ptr(dt), _stream()), "rslo_transform_rows_bwd")
     return dR, dt
+
+
+# --------------------------------------------------------------------------------------
+# fused (Sync)BatchNorm2d + activation + residual of the dense head
+# --------------------------------------------------------------------------------------
+_bn_done = {}
+
+
+def _bn_counters(dev, C_):
+    done = _bn_done.get(dev)
+    if done is None or done.numel() < C_:
+        done = _bn_done[dev] = torch.zeros((max(C_, 512),), dtype=torch.int32, device=dev)
+    return done
+
+
+def bn2d_stats(x):
+    """x [N,C,H,W] -> stats [2C+1] float64 (sum, sum of squares per channel, element count)."""
+    N, Cc, H, W = x.shape
+    dev = x.device
+    wsb = lib().rslo_bn2d_ws_bytes(N, Cc, H * W)
+    ws = _ws(wsb, dev)
+    stats = torch.empty((2 * Cc + 1,), dtype=torch.float64, device=dev)
+    _chk(lib().rslo_bn2d_stats(_ptr(x, torch.float32, "x"), N, Cc, H * W, _ptr(ws), wsb, _ptr(_bn_counters(dev, Cc)),
+                               _ptr(stats), _stream()), "rslo_bn2d_stats")
+    return stats
+
+
+def bn2d_apply(x, res, stats, gamma, beta, running_mean, running_var, momentum, eps, slope):
+    N, Cc, H, W = x.shape
+    dev = x.device
+    y = torch.empty_like(x)
+    mean = torch.empty((Cc,), dtype=torch.float32, device=dev)
+    invstd = torch.empty((Cc,), dtype=torch.float32, device=dev)
+    _chk(lib().rslo_bn2d_apply(_ptr(x, torch.float32, "x"), _ptr(res, torch.float32, "res"), _ptr(stats, torch.float64),
+                               _ptr(gamma, torch.float32, "gamma"), _ptr(beta, torch.float32, "beta"), N, Cc, H * W,
+                               float(eps), float(momentum), float(slope), _ptr(running_mean, torch.float32),
+                               _ptr(running_var, torch.float32), _ptr(mean), _ptr(invstd), _ptr(y), _stream()),
+         "rslo_bn2d_apply")
+    return y, mean, invstd
+
+
+def bn2d_bwd_reduce(dy, y, x, mean, invstd, slope, has_act, want_affine=True):
+    N, Cc, H, W = x.shape
+    dev = x.device
+    wsb = lib().rslo_bn2d_ws_bytes(N, Cc, H * W)
+    ws = _ws(wsb, dev)
+    red = torch.empty((2 * Cc,), dtype=torch.float64, device=dev)
+    dgamma = torch.empty((Cc,), dtype=torch.float32, device=dev) if want_affine else None
+    dbeta = torch.empty((Cc,), dtype=torch.float32, device=dev) if want_affine else None
+    _chk(lib().rslo_bn2d_bwd_reduce(_ptr(dy, torch.float32, "dy"), _ptr(y, torch.float32, "y"), _ptr(x, torch.float32, "x"),
+                                    _ptr(mean), _ptr(invstd), N, Cc, H * W, float(slope), int(has_act), _ptr(ws), wsb,
+                                    _ptr(_bn_counters(dev, Cc)), _ptr(red), _ptr(dgamma), _ptr(dbeta), _stream()),
+         "rslo_bn2d_bwd_reduce")
+    return red, dgamma, dbeta
+
+
+def bn2d_bwd_apply(dy, y, x, gamma, mean, invstd, red, count, slope, has_act, want_res):
+    N, Cc, H, W = x.shape
+    dx = torch.empty_like(x)
+    dres = torch.empty_like(x) if want_res else None
+    _chk(lib().rslo_bn2d_bwd_apply(_ptr(dy, torch.float32, "dy"), _ptr(y, torch.float32, "y"), _ptr(x, torch.float32, "x"),
+                                   _ptr(gamma, torch.float32, "gamma"), _ptr(mean), _ptr(invstd), _ptr(red, torch.float64),
+                                   float(count), N, Cc, H * W, float(slope), int(has_act), _ptr(dx), _ptr(dres),
+                                   _stream()), "rslo_bn2d_bwd_apply")
+    return dx, dres

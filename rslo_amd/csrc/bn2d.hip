@@ -1,0 +1,324 @@
+// Training-mode (Sync)BatchNorm2d of the dense BEV head fused with its activation and residual add, NCHW fp32
+// (reference: apex.parallel.SyncBatchNorm used through rslo/layers/SparseConv.py:96-113 in
+//  rslo/models/custom_resnet_spc.py:224-298 and the conv-BN-ReLU stacks of rslo/models/odom_pred.py).
+//
+// One code path for 1..N ranks: [stats kernel] -> (all-reduce of 2C+1 doubles when the process group has more than one
+// rank) -> [apply kernel: normalise + affine + residual + (Leaky)ReLU, running statistics, saved mean / invstd];
+// backward: [reduce kernel: sum g, sum g x^ with g = dy * act'(y)] -> (all-reduce of 2C doubles) -> [apply kernel: dx,
+// d_residual].  Two launches per direction instead of BN + activation + add (three kernels and three autograd nodes),
+// and across ranks ONE small collective per direction instead of torch SyncBatchNorm's gather / reduce sequences.
+// Sums are accumulated in double; partial sums are added in block order by the last block of a channel: deterministic.
+// HBM-bound elementwise work: forward reads x twice (+ residual) and writes y; backward reads dy, y, x twice, writes dx.
+#include "rslo_common.h"
+
+#define BN_THREADS 256
+
+__device__ __forceinline__ void bn_block_sum2(double a, double b, double *out2) {
+  __shared__ double red[2][BN_THREADS / 64];
+  for (int o = 32; o > 0; o >>= 1) {
+    a += __shfl_down(a, o, 64);
+    b += __shfl_down(b, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = a;
+    red[1][threadIdx.x >> 6] = b;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s0 = 0.0, s1 = 0.0;
+    for (int w = 0; w < BN_THREADS / 64; ++w) {
+      s0 += red[0][w];
+      s1 += red[1][w];
+    }
+    out2[0] = s0;
+    out2[1] = s1;
+  }
+  __syncthreads();
+}
+
+// grid (SPLIT, C).  part [C][SPLIT][2]; done [C] zero on entry / exit; stats [2C+1] = sum[c], sumsq[c], count.
+__global__ __launch_bounds__(BN_THREADS) void k_bn2d_stats(const float *__restrict__ x, int N, int C, int HW,
+                                                           int64_t per_blk, double *__restrict__ part,
+                                                           int *__restrict__ done, double *__restrict__ stats) {
+  const int c = blockIdx.y, sp = blockIdx.x, S = gridDim.x;
+  const int64_t total = (int64_t)N * HW;
+  const int64_t e0 = (int64_t)sp * per_blk, e1 = (e0 + per_blk < total) ? e0 + per_blk : total;
+  double s = 0.0, q = 0.0;
+  for (int64_t n = e0 / HW; n * HW < e1; ++n) {        // the slice [e0, e1) row by row: no per-element division
+    const int64_t lo = (e0 > n * HW ? e0 - n * HW : 0), hi = (e1 < (n + 1) * HW ? e1 - n * HW : HW);
+    const float *row = x + (n * C + c) * (int64_t)HW;
+    if (((HW | lo) & 3) == 0) {
+      for (int64_t k = lo + 4 * threadIdx.x; k + 3 < hi; k += 4 * BN_THREADS) {
+        const float4 v = *reinterpret_cast<const float4 *>(row + k);
+        s += ((double)v.x + v.y) + ((double)v.z + v.w);
+        q += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
+      }
+      const int64_t tail = lo + ((hi - lo) & ~(int64_t)3);
+      for (int64_t k = tail + threadIdx.x; k < hi; k += BN_THREADS) {
+        s += row[k];
+        q += (double)row[k] * row[k];
+      }
+    } else {
+      for (int64_t k = lo + threadIdx.x; k < hi; k += BN_THREADS) {
+        s += row[k];
+        q += (double)row[k] * row[k];
+      }
+    }
+  }
+  __shared__ double res[2];
+  __shared__ int is_last;
+  bn_block_sum2(s, q, res);
+  if (threadIdx.x == 0) {
+    part[((int64_t)c * S + sp) * 2 + 0] = res[0];
+    part[((int64_t)c * S + sp) * 2 + 1] = res[1];
+    __threadfence();
+    is_last = atomicAdd(&done[c], 1) == S - 1;
+    if (is_last) {
+      __threadfence();
+      double a = 0.0, b = 0.0;
+      for (int k = 0; k < S; ++k) {
+        a += part[((int64_t)c * S + k) * 2 + 0];
+        b += part[((int64_t)c * S + k) * 2 + 1];
+      }
+      stats[c] = a;
+      stats[C + c] = b;
+      if (c == 0) stats[2 * C] = (double)total;
+      done[c] = 0;
+    }
+  }
+}
+
+// y = act(gamma * (x - mean) * invstd + beta (+ res)); one thread per 4 consecutive hw of one (n, c) row when HW % 4 == 0
+__global__ __launch_bounds__(BN_THREADS) void k_bn2d_apply(const float *__restrict__ x, const float *__restrict__ res,
+                                                           const double *__restrict__ stats,
+                                                           const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                           int N, int C, int HW, float eps, float momentum, float slope,
+                                                           float *__restrict__ run_mean, float *__restrict__ run_var,
+                                                           float *__restrict__ save_mean, float *__restrict__ save_invstd,
+                                                           float *__restrict__ y) {
+  const int row = blockIdx.y;                 // n * C + c
+  const int c = row % C;
+  const double cnt = stats[2 * C];
+  const double m = stats[c] / cnt;
+  double var = stats[C + c] / cnt - m * m;
+  var = var > 0.0 ? var : 0.0;
+  const float mean = (float)m, invstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  const float a1 = g * invstd, a0 = b - mean * a1;
+  if (row < C && blockIdx.x == 0 && threadIdx.x == 0) {   // n == 0: one thread per channel keeps the statistics
+    save_mean[c] = mean;
+    save_invstd[c] = invstd;
+    if (run_mean) {
+      const double unbiased = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
+      run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mean;
+      run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)unbiased;
+    }
+  }
+  const int64_t base = (int64_t)row * HW;
+  const int hw = (blockIdx.x * BN_THREADS + threadIdx.x) * 4;
+  if (hw >= HW) return;
+  if ((HW & 3) == 0) {
+    float4 v = *reinterpret_cast<const float4 *>(x + base + hw);
+    float4 r = res ? *reinterpret_cast<const float4 *>(res + base + hw) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 o;
+    o.x = v.x * a1 + a0 + r.x;
+    o.y = v.y * a1 + a0 + r.y;
+    o.z = v.z * a1 + a0 + r.z;
+    o.w = v.w * a1 + a0 + r.w;
+    o.x = o.x > 0.f ? o.x : o.x * slope;
+    o.y = o.y > 0.f ? o.y : o.y * slope;
+    o.z = o.z > 0.f ? o.z : o.z * slope;
+    o.w = o.w > 0.f ? o.w : o.w * slope;
+    *reinterpret_cast<float4 *>(y + base + hw) = o;
+  } else {
+    for (int k = hw; k < hw + 4 && k < HW; ++k) {
+      float o = x[base + k] * a1 + a0 + (res ? res[base + k] : 0.f);
+      y[base + k] = o > 0.f ? o : o * slope;
+    }
+  }
+}
+
+// sums of g = dy * act'(y) and g * x^ per channel.  red [2C] (for the cross-rank sum), dgamma / dbeta = the LOCAL sums.
+__global__ __launch_bounds__(BN_THREADS) void k_bn2d_bwd_reduce(const float *__restrict__ dy, const float *__restrict__ y,
+                                                                const float *__restrict__ x,
+                                                                const float *__restrict__ save_mean,
+                                                                const float *__restrict__ save_invstd, int N, int C,
+                                                                int HW, int64_t per_blk, float slope, int has_act,
+                                                                double *__restrict__ part, int *__restrict__ done,
+                                                                double *__restrict__ red, float *__restrict__ dgamma,
+                                                                float *__restrict__ dbeta) {
+  const int c = blockIdx.y, sp = blockIdx.x, S = gridDim.x;
+  const int64_t total = (int64_t)N * HW;
+  const int64_t e0 = (int64_t)sp * per_blk, e1 = (e0 + per_blk < total) ? e0 + per_blk : total;
+  const float mean = save_mean[c], invstd = save_invstd[c];
+  double s = 0.0, q = 0.0;
+  for (int64_t n = e0 / HW; n * HW < e1; ++n) {
+    const int64_t lo = (e0 > n * HW ? e0 - n * HW : 0), hi = (e1 < (n + 1) * HW ? e1 - n * HW : HW);
+    const int64_t base = (n * C + c) * (int64_t)HW;
+    if (((HW | lo) & 3) == 0) {
+      for (int64_t k = lo + 4 * threadIdx.x; k + 3 < hi; k += 4 * BN_THREADS) {
+        const float4 d = *reinterpret_cast<const float4 *>(dy + base + k);
+        const float4 v = *reinterpret_cast<const float4 *>(x + base + k);
+        float g[4] = {d.x, d.y, d.z, d.w};
+        if (has_act) {
+          const float4 o = *reinterpret_cast<const float4 *>(y + base + k);
+          g[0] = o.x > 0.f ? g[0] : g[0] * slope;
+          g[1] = o.y > 0.f ? g[1] : g[1] * slope;
+          g[2] = o.z > 0.f ? g[2] : g[2] * slope;
+          g[3] = o.w > 0.f ? g[3] : g[3] * slope;
+        }
+        const float xh[4] = {(v.x - mean) * invstd, (v.y - mean) * invstd, (v.z - mean) * invstd, (v.w - mean) * invstd};
+        s += ((double)g[0] + g[1]) + ((double)g[2] + g[3]);
+        q += ((double)g[0] * xh[0] + (double)g[1] * xh[1]) + ((double)g[2] * xh[2] + (double)g[3] * xh[3]);
+      }
+      const int64_t tail = lo + ((hi - lo) & ~(int64_t)3);
+      for (int64_t k = tail + threadIdx.x; k < hi; k += BN_THREADS) {
+        float g = dy[base + k];
+        if (has_act) g = y[base + k] > 0.f ? g : g * slope;
+        s += g;
+        q += (double)g * (double)((x[base + k] - mean) * invstd);
+      }
+    } else {
+      for (int64_t k = lo + threadIdx.x; k < hi; k += BN_THREADS) {
+        float g = dy[base + k];
+        if (has_act) g = y[base + k] > 0.f ? g : g * slope;
+        s += g;
+        q += (double)g * (double)((x[base + k] - mean) * invstd);
+      }
+    }
+  }
+  __shared__ double res[2];
+  __shared__ int is_last;
+  bn_block_sum2(s, q, res);
+  if (threadIdx.x == 0) {
+    part[((int64_t)c * S + sp) * 2 + 0] = res[0];
+    part[((int64_t)c * S + sp) * 2 + 1] = res[1];
+    __threadfence();
+    is_last = atomicAdd(&done[c], 1) == S - 1;
+    if (is_last) {
+      __threadfence();
+      double a = 0.0, b = 0.0;
+      for (int k = 0; k < S; ++k) {
+        a += part[((int64_t)c * S + k) * 2 + 0];
+        b += part[((int64_t)c * S + k) * 2 + 1];
+      }
+      red[c] = a;
+      red[C + c] = b;
+      if (dbeta) dbeta[c] = (float)a;
+      if (dgamma) dgamma[c] = (float)b;
+      done[c] = 0;
+    }
+  }
+}
+
+// dx = gamma invstd (g - sum_g / cnt - x^ sum_gx / cnt);  dres = g
+__global__ __launch_bounds__(BN_THREADS) void k_bn2d_bwd_apply(const float *__restrict__ dy, const float *__restrict__ y,
+                                                               const float *__restrict__ x,
+                                                               const float *__restrict__ gamma,
+                                                               const float *__restrict__ save_mean,
+                                                               const float *__restrict__ save_invstd,
+                                                               const double *__restrict__ red, double cnt, int C, int HW,
+                                                               float slope, int has_act, float *__restrict__ dx,
+                                                               float *__restrict__ dres) {
+  const int row = blockIdx.y, c = row % C;
+  const float mean = save_mean[c], invstd = save_invstd[c];
+  const float k0 = (gamma ? gamma[c] : 1.f) * invstd;
+  const float mg = (float)(red[c] / cnt), mgx = (float)(red[C + c] / cnt);
+  const int64_t base = (int64_t)row * HW;
+  const int hw0 = (blockIdx.x * BN_THREADS + threadIdx.x) * 4;
+  if (hw0 >= HW) return;
+  if ((HW & 3) == 0) {
+    const float4 d = *reinterpret_cast<const float4 *>(dy + base + hw0);
+    const float4 v = *reinterpret_cast<const float4 *>(x + base + hw0);
+    float g[4] = {d.x, d.y, d.z, d.w};
+    if (has_act) {
+      const float4 o = *reinterpret_cast<const float4 *>(y + base + hw0);
+      g[0] = o.x > 0.f ? g[0] : g[0] * slope;
+      g[1] = o.y > 0.f ? g[1] : g[1] * slope;
+      g[2] = o.z > 0.f ? g[2] : g[2] * slope;
+      g[3] = o.w > 0.f ? g[3] : g[3] * slope;
+    }
+    float4 r;
+    r.x = k0 * (g[0] - mg - (v.x - mean) * invstd * mgx);
+    r.y = k0 * (g[1] - mg - (v.y - mean) * invstd * mgx);
+    r.z = k0 * (g[2] - mg - (v.z - mean) * invstd * mgx);
+    r.w = k0 * (g[3] - mg - (v.w - mean) * invstd * mgx);
+    *reinterpret_cast<float4 *>(dx + base + hw0) = r;
+    if (dres) *reinterpret_cast<float4 *>(dres + base + hw0) = make_float4(g[0], g[1], g[2], g[3]);
+    return;
+  }
+  for (int k = hw0; k < hw0 + 4 && k < HW; ++k) {
+    float g = dy[base + k];
+    if (has_act) g = y[base + k] > 0.f ? g : g * slope;
+    const float xh = (x[base + k] - mean) * invstd;
+    dx[base + k] = k0 * (g - mg - xh * mgx);
+    if (dres) dres[base + k] = g;
+  }
+}
+
+static int64_t bn_per_blk(int N, int C, int HW, int *S) {
+  const int64_t total = (int64_t)N * HW;
+  int s = 1024 / (C > 0 ? C : 1);
+  if (s < 1) s = 1;
+  const int64_t max_s = rslo_cdiv(total, 2048);
+  if (s > max_s) s = (int)(max_s > 0 ? max_s : 1);
+  *S = s;
+  return rslo_cdiv(rslo_cdiv(total, s), 4) * 4;     /* slices start on 16-byte boundaries when HW % 4 == 0 */
+}
+
+extern "C" size_t rslo_bn2d_ws_bytes(int N, int C, int HW) {
+  int S;
+  bn_per_blk(N, C, HW, &S);
+  return (size_t)C * S * 2 * sizeof(double);
+}
+
+extern "C" int rslo_bn2d_stats(const float *x, int N, int C, int HW, void *ws, size_t ws_bytes, int32_t *done,
+                               double *stats, void *stream) {
+  RSLO_CHECK_ARG(x && ws && done && stats && N >= 1 && C >= 1 && HW >= 1, "rslo_bn2d_stats: bad arguments");
+  RSLO_CHECK_ARG(ws_bytes >= rslo_bn2d_ws_bytes(N, C, HW), "rslo_bn2d_stats: workspace too small");
+  int S;
+  const int64_t per = bn_per_blk(N, C, HW, &S);
+  hipLaunchKernelGGL(k_bn2d_stats, dim3(S, C), dim3(BN_THREADS), 0, (hipStream_t)stream, x, N, C, HW, per, (double *)ws,
+                     (int *)done, stats);
+  RSLO_CHECK_LAUNCH("k_bn2d_stats");
+  return RSLO_OK;
+}
+
+extern "C" int rslo_bn2d_apply(const float *x, const float *res, const double *stats, const float *gamma,
+                               const float *beta, int N, int C, int HW, float eps, float momentum, float act_slope,
+                               float *running_mean, float *running_var, float *save_mean, float *save_invstd, float *y,
+                               void *stream) {
+  RSLO_CHECK_ARG(x && stats && save_mean && save_invstd && y, "rslo_bn2d_apply: bad arguments");
+  dim3 grid((unsigned)rslo_cdiv(rslo_cdiv(HW, 4), BN_THREADS), (unsigned)(N * C));
+  hipLaunchKernelGGL(k_bn2d_apply, grid, dim3(BN_THREADS), 0, (hipStream_t)stream, x, res, stats, gamma, beta, N, C, HW,
+                     eps, momentum, act_slope, running_mean, running_var, save_mean, save_invstd, y);
+  RSLO_CHECK_LAUNCH("k_bn2d_apply");
+  return RSLO_OK;
+}
+
+extern "C" int rslo_bn2d_bwd_reduce(const float *dy, const float *y, const float *x, const float *save_mean,
+                                    const float *save_invstd, int N, int C, int HW, float act_slope, int has_act,
+                                    void *ws, size_t ws_bytes, int32_t *done, double *red, float *dgamma, float *dbeta,
+                                    void *stream) {
+  RSLO_CHECK_ARG(dy && x && save_mean && save_invstd && ws && done && red, "rslo_bn2d_bwd_reduce: bad arguments");
+  RSLO_CHECK_ARG(!has_act || y, "rslo_bn2d_bwd_reduce: y is needed for the activation mask");
+  RSLO_CHECK_ARG(ws_bytes >= rslo_bn2d_ws_bytes(N, C, HW), "rslo_bn2d_bwd_reduce: workspace too small");
+  int S;
+  const int64_t per = bn_per_blk(N, C, HW, &S);
+  hipLaunchKernelGGL(k_bn2d_bwd_reduce, dim3(S, C), dim3(BN_THREADS), 0, (hipStream_t)stream, dy, y, x, save_mean,
+                     save_invstd, N, C, HW, per, act_slope, has_act, (double *)ws, (int *)done, red, dgamma, dbeta);
+  RSLO_CHECK_LAUNCH("k_bn2d_bwd_reduce");
+  return RSLO_OK;
+}
+
+extern "C" int rslo_bn2d_bwd_apply(const float *dy, const float *y, const float *x, const float *gamma,
+                                   const float *save_mean, const float *save_invstd, const double *red, double count,
+                                   int N, int C, int HW, float act_slope, int has_act, float *dx, float *dres,
+                                   void *stream) {
+  RSLO_CHECK_ARG(dy && x && save_mean && save_invstd && red && dx && count > 0, "rslo_bn2d_bwd_apply: bad arguments");
+  dim3 grid((unsigned)rslo_cdiv(rslo_cdiv(HW, 4), BN_THREADS), (unsigned)(N * C));
+  hipLaunchKernelGGL(k_bn2d_bwd_apply, grid, dim3(BN_THREADS), 0, (hipStream_t)stream, dy, y, x, gamma, save_mean,
+                     save_invstd, red, count, C, HW, act_slope, has_act, dx, dres);
+  RSLO_CHECK_LAUNCH("k_bn2d_bwd_apply");
+  return RSLO_OK;
+}

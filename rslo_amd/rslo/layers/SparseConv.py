@@ -18,8 +18,25 @@ class SPC_SyncBN2d(apex.parallel.SyncBatchNorm):
         assert noise_scale_std == 0 and noise_shift_std == 0, "BN noise is not used by the RSLO hot path"
         self.add_noise = False
 
-    def forward(self, x):
-        return _pair(super().forward, x)
+    def forward(self, x, act_slope=None, residual=None):
+        """(feature, mask) pairs: the mask passes through; act_slope / residual are the optional fused epilogue of the
+        ROCm SyncBatchNorm stand-in (y = act(bn(x) + residual))."""
+        if isinstance(x, (tuple, list)):
+            res = residual[0] if isinstance(residual, (tuple, list)) else residual
+            return [self._feature(x[0], act_slope, res), x[1]]
+        return self._feature(x, act_slope, residual)
+
+    def _feature(self, x, act_slope, residual):
+        if act_slope is None and residual is None:
+            return super().forward(x)
+        if hasattr(super(), "fusable"):
+            return super().forward(x, act_slope=act_slope, residual=residual)
+        y = super().forward(x)          # a real apex SyncBatchNorm: separate ops
+        if residual is not None:
+            y = y + residual
+        if act_slope is not None:
+            y = nn.functional.leaky_relu(y, act_slope) if act_slope != 0.0 else nn.functional.relu(y)
+        return y
 
 
 class SPC_BN2d(nn.BatchNorm2d):
@@ -35,3 +52,32 @@ class SPC_ReLU(nn.ReLU):
 class SPC_LeakyReLU(nn.LeakyReLU):
     def forward(self, x):
         return _pair(super().forward, x)
+
+
+def act_slope_of(m):
+    """Negative slope of a (SPC_)ReLU / LeakyReLU module, None for anything else."""
+    if isinstance(m, nn.LeakyReLU):
+        return float(m.negative_slope)
+    if isinstance(m, nn.ReLU):
+        return 0.0
+    return None
+
+
+class FusedSequential(nn.Sequential):
+    """nn.Sequential that hands a following (Leaky)ReLU to a normalisation layer able to fuse it (the ROCm
+    SyncBatchNorm stand-in: one kernel pair per direction for BN + activation).  Same children, same state-dict keys,
+    same results as nn.Sequential."""
+
+    def forward(self, x):
+        mods = list(self._modules.values())
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            slope = act_slope_of(mods[i + 1]) if i + 1 < len(mods) else None
+            if slope is not None and isinstance(m, SPC_SyncBN2d):
+                x = m(x, act_slope=slope)
+                i += 2
+                continue
+            x = m(x)
+            i += 1
+        return x

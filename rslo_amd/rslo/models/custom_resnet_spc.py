@@ -3,7 +3,7 @@
 import torch
 import torch.nn as nn
 
-from rslo.layers.SparseConv import SPC_LeakyReLU, SPC_ReLU
+from rslo.layers.SparseConv import SPC_LeakyReLU, SPC_ReLU, SPC_SyncBN2d, act_slope_of
 
 
 def conv1x1(in_planes, out_planes, stride=1, Conv2d=None, groups=1):
@@ -45,6 +45,16 @@ class BasicBlock(nn.Module):
         self.use_se = self.use_sa = False
 
     def forward(self, x):
+        if isinstance(self.bn1, SPC_SyncBN2d) and isinstance(self.bn2, SPC_SyncBN2d):
+            # BN + ReLU and BN + residual add + ReLU as fused epilogues of the normalisation kernels
+            slope = act_slope_of(self.relu)
+            out = self.bn1(self.conv1(x), act_slope=slope)
+            out = self.conv2(out)
+            residual = x if self.downsample is None else self.downsample(x)
+            y = self.bn2(out, act_slope=slope, residual=residual)
+            if isinstance(y, (list, tuple)):      # (feature, mask) pairs: masks are averaged like SPC_add does
+                y = [y[0], ((out[1] + residual[1]) / 2).float()]
+            return y
         out = self.relu(self.bn1(self.conv1(x)))
         out = self.bn2(self.conv2(out))
         residual = x if self.downsample is None else self.downsample(x)

@@ -17,6 +17,7 @@ from rslo.layers.confidence import ConfidenceModule, masked_spatial_softmax
 from rslo.layers.MaskConv import MaskConv
 from rslo.models.odom_pred_base import OdomPredEncDecBase, conf_trunk
 from rslo.utils.pose_utils import rotate_vec_by_q
+from rslo.layers.SparseConv import FusedSequential
 from torchplus.nn import Empty
 
 # with the ROCm apex stand-in the per-layer `num_batches_tracked += 1` launches are batched (compat/apex/parallel.py);
@@ -57,7 +58,7 @@ class UNOdomPredEncDecSVDTempMaskBase(OdomPredEncDecBase):
         motion, tconf, qconf = [], [], []
         if self.pred_pyramid_motion:
             for c in nuf:
-                motion.append(nn.Sequential(
+                motion.append(FusedSequential(
                     nn.Conv2d(c, c // 2, kernel_size=3, stride=1, padding=1), self.BatchNorm2d(c // 2), self.ReLU(),
                     nn.Conv2d(c // 2, 64, kernel_size=3, stride=1, padding=1), self.BatchNorm2d(64), self.ReLU(),
                     nn.Conv2d(64, 7, 1, stride=1)))
@@ -199,10 +200,10 @@ class UNRResNetOdomPredEncDecSVDTempMask(UNOdomPredEncDecSVDTempMaskBase):
         BatchNorm2d = self.BatchNorm2d if use_norm else Empty
         downsample = None
         if stride != 1 or inplanes != planes * block.expansion:
-            downsample = nn.Sequential(conv1x1(inplanes, planes * block.expansion, stride, Conv2d=conv2d,
+            downsample = FusedSequential(conv1x1(inplanes, planes * block.expansion, stride, Conv2d=conv2d,
                                                groups=first_groups), BatchNorm2d(planes * block.expansion))
         layers = [block(inplanes, planes, stride, downsample, BN=BatchNorm2d, Conv2d=conv2d, groups=first_groups)]
         self.inplanes = planes * block.expansion
         for _ in range(1, num_blocks):
             layers.append(block(self.inplanes, planes, BN=BatchNorm2d, Conv2d=conv2d))
-        return nn.Sequential(*layers), self.inplanes
+        return FusedSequential(*layers), self.inplanes

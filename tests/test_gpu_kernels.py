@@ -399,3 +399,121 @@ def test_rigid_move_fwd_bwd(hip):
     assert float((td.grad.cpu() - t.grad).abs().max() / t.grad.abs().max()) < 1e-5
     out2 = losses.rigid_move(wide.cuda()[:, :, :3], Rd.detach())
     assert float((out2.cpu() - wide[:, :, :3] @ R.detach().transpose(-1, -2)).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("slope,with_res", [(None, False), (0.0, False), (0.0, True), (0.1, True)])
+def test_fused_bn2d_act_matches_torch(hip, slope, with_res):
+    """rslo_bn2d_* (stats -> apply, reduce -> apply) == nn.BatchNorm2d(train) [+ residual] [+ (Leaky)ReLU]: outputs,
+    running statistics, input / residual / affine gradients; odd spatial size exercises the scalar tails."""
+    import apex.parallel as AP
+    torch.manual_seed(0)
+    for shape in [(4, 64, 24, 44), (2, 32, 7, 9)]:
+        x = (torch.randn(*shape, device="cuda") * 2 + 0.3).requires_grad_(True)
+        res = torch.randn(*shape, device="cuda", requires_grad=True) if with_res else None
+        gy = torch.randn(*shape, device="cuda")
+        ref = torch.nn.BatchNorm2d(shape[1], eps=1e-3, momentum=0.01).cuda().train()
+        mine = AP.SyncBatchNorm(shape[1], eps=1e-3, momentum=0.01).cuda().train()
+        with torch.no_grad():
+            ref.weight.uniform_(0.5, 1.5); ref.bias.uniform_(-0.5, 0.5)
+        mine.load_state_dict(ref.state_dict())
+        y = ref(x)
+        if with_res:
+            y = y + res
+        if slope is not None:
+            y = torch.nn.functional.leaky_relu(y, slope)
+        (y * gy).sum().backward()
+        want = [x.grad.clone(), res.grad.clone() if with_res else None, ref.weight.grad.clone(), ref.bias.grad.clone()]
+        x.grad = None
+        if with_res:
+            res.grad = None
+        AP.FUSED_BN = "1"          # force the fused kernels on this single rank
+        try:
+            assert mine.fusable(x)
+            y2 = mine(x, act_slope=slope, residual=res)
+        finally:
+            AP.FUSED_BN = "auto"
+        (y2 * gy).sum().backward()
+        assert float((y2 - y).abs().max()) < 2e-5
+        assert float((mine.running_mean - ref.running_mean).abs().max()) < 1e-6
+        assert float((mine.running_var - ref.running_var).abs().max()) < 1e-5
+        assert int(mine.num_batches_tracked) == int(ref.num_batches_tracked) == 1
+        got = [x.grad, res.grad if with_res else None, mine.weight.grad, mine.bias.grad]
+        for a, b in zip(got, want):
+            if b is not None:
+                assert float((a - b).abs().max() / (b.abs().max() + 1e-12)) < 2e-4
+
+
+def test_fused_bn2d_cross_rank_statistics_by_hand(hip):
+    """The multi-rank path all-reduces the [2C+1] statistics between the two kernels: summing the statistics of two
+    half batches by hand and applying them to each half must equal BatchNorm over the whole batch."""
+    torch.manual_seed(1)
+    x = torch.randn(4, 16, 12, 22, device="cuda") * 1.5 + 0.2
+    g = torch.ones(16, device="cuda"); b = torch.zeros(16, device="cuda")
+    sa, sb = hip.bn2d_stats(x[:2].contiguous()), hip.bn2d_stats(x[2:].contiguous())
+    tot = sa + sb                                     # what dist.all_reduce(SUM) produces on every rank
+    rm, rv = torch.zeros(16, device="cuda"), torch.ones(16, device="cuda")
+    ya, mean, invstd = hip.bn2d_apply(x[:2].contiguous(), None, tot, g, b, rm, rv, 0.1, 1e-5, 1.0)
+    yb, _, _ = hip.bn2d_apply(x[2:].contiguous(), None, tot, g, b, None, None, 0.1, 1e-5, 1.0)
+    ref = torch.nn.functional.batch_norm(x, None, None, g, b, True, 0.1, 1e-5)
+    assert float((torch.cat([ya, yb]) - ref).abs().max()) < 2e-5
+    assert float((mean - x.mean((0, 2, 3))).abs().max()) < 1e-5
+
+
+def _syncbn_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)     # two ranks on ONE GPU: gloo moves the CUDA tensors
+    import rslo_amd  # noqa: F401
+    import apex.parallel as AP
+    torch.manual_seed(0)
+    full = torch.randn(4, 16, 12, 22) * 1.5 + 0.2
+    res_full = torch.randn(4, 16, 12, 22)
+    gy_full = torch.randn(4, 16, 12, 22)
+    sl = slice(2 * rank, 2 * rank + 2)
+    x = full[sl].cuda().requires_grad_(True)
+    res = res_full[sl].cuda().requires_grad_(True)
+    bn = AP.SyncBatchNorm(16, eps=1e-3, momentum=0.01).cuda().train()
+    assert bn.fusable(x)                                             # world size 2 -> fused path by default
+    y = bn(x, act_slope=0.0, residual=res)
+    (y * gy_full[sl].cuda()).sum().backward()
+    q.put((rank, y.detach().cpu().numpy(), x.grad.cpu().numpy(), res.grad.cpu().numpy(), bn.weight.grad.cpu().numpy(),
+           bn.bias.grad.cpu().numpy(), bn.running_mean.cpu().numpy(), bn.running_var.cpu().numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_fused_syncbn_two_ranks_equals_full_batch(hip):
+    """Two processes (gloo, same GPU) each hold half of a batch: the fused SyncBatchNorm path must reproduce
+    BatchNorm over the whole batch -- outputs, input / residual gradients, running statistics; the affine gradients are
+    the LOCAL sums (data parallel averages parameter gradients afterwards)."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_syncbn_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted([q.get(timeout=300) for _ in range(2)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    torch.manual_seed(0)
+    full = (torch.randn(4, 16, 12, 22) * 1.5 + 0.2).requires_grad_(True)
+    res_full = torch.randn(4, 16, 12, 22).requires_grad_(True)
+    gy_full = torch.randn(4, 16, 12, 22)
+    ref = torch.nn.BatchNorm2d(16, eps=1e-3, momentum=0.01).train()
+    y = torch.relu(ref(full) + res_full)
+    (y * gy_full).sum().backward()
+    y_got = np.concatenate([out[0][1], out[1][1]])
+    gx_got = np.concatenate([out[0][2], out[1][2]])
+    gr_got = np.concatenate([out[0][3], out[1][3]])
+    np.testing.assert_allclose(y_got, y.detach().numpy(), rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(gx_got, full.grad.numpy(), rtol=1e-3, atol=2e-5)
+    np.testing.assert_allclose(gr_got, res_full.grad.numpy(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(out[0][4] + out[1][4], ref.weight.grad.numpy(), rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(out[0][5] + out[1][5], ref.bias.grad.numpy(), rtol=1e-3, atol=1e-4)
+    for r in range(2):
+        np.testing.assert_allclose(out[r][6], ref.running_mean.numpy(), rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(out[r][7], ref.running_var.numpy(), rtol=1e-4, atol=1e-6)
