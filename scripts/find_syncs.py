@@ -8,10 +8,11 @@ net, _ = workload.build_network(); net.train(); net.global_step.fill_(2000)
 params = [p for p in net.parameters() if p.requires_grad]
 opt = torch.optim.Adam(params, lr=8e-5, fused=True)
 clouds = [[torch.from_numpy(c).cuda() for c in pair] for pair in workload.kitti_pairs(4)]
+pf = workload.ExamplePrefetcher(net); pf.submit(clouds)
 def step():
-    ex = workload.make_example(net, clouds)
+    ex = pf.get()
     opt.zero_grad(set_to_none=True)
-    ret = net(ex); ret["loss"].mean().backward()
+    ret = net(ex); pf.submit(clouds); ret["loss"].mean().backward()
     torch.nn.utils.clip_grad_norm_(params, 10.0); opt.step()
 for _ in range(3): step()
 torch.cuda.synchronize()
