@@ -340,3 +340,37 @@ def test_prefetched_example_equals_inline(hip):
         assert rel(g, ref[i][2]) < 2e-2
         net2.zero_grad(set_to_none=True)
     pf.close()
+
+
+def test_short_training_run_stays_finite(hip):
+    """End-to-end behaviour of the assembled step (encoder + head + loss + the reference's optimizer wrapper and
+    OneCycle schedule): 25 optimizer steps on one reduced synthetic pair keep the loss and every parameter finite and
+    move the weights.  (No monotone-decrease claim: from a random initialisation at step 2000 -- no warm-up, the
+    predicted pose drives the association -- the reference's self-supervised loss is chaotic for the first steps.)"""
+    from rslo.builder import lr_scheduler_builder, optimizer_builder
+    from rslo.utils import config_text
+    torch.manual_seed(3)
+    net, _ = workload.build_network()
+    net.train()
+    net.global_step.fill_(2000)
+    cfg = config_text.shipped_config().train_config
+    opt = optimizer_builder.build(cfg.optimizer, net)
+    sched = lr_scheduler_builder.build(cfg.optimizer, opt, 60)        # a 60-step cycle: the peak lr is reached at step 3
+    a = reduced_pair(11)
+    clouds = [[torch.from_numpy(a[0]).cuda(), torch.from_numpy(a[1]).cuda()]]
+    params = [p for p in net.parameters() if p.requires_grad]
+    before = torch.cat([p.detach().reshape(-1) for p in params]).clone()
+    losses = []
+    for it in range(25):
+        sched.step(it)
+        opt.zero_grad()
+        ret = net(workload.make_example(net, clouds))
+        ret["loss"].mean().backward()
+        torch.nn.utils.clip_grad_norm_(params, 10.0)
+        opt.step()
+        losses.append(float(ret["loss"]))
+    assert all(np.isfinite(losses))
+    assert all(bool(torch.isfinite(p).all()) for p in params)
+    assert max(losses) < 1e6, losses
+    after = torch.cat([p.detach().reshape(-1) for p in params])
+    assert float((after - before).abs().max()) > 1e-4
