@@ -133,6 +133,13 @@ RSLO_API int rslo_weight_split(const float *W, int K, int cin_op, int cout_op, i
 RSLO_API int rslo_spconv_fwd_split(const float *in, int cin, const void *Ws, const float *bias, const int32_t *nbr,
                                    int64_t n_out, int K, int cout, int flip_k, float act_slope, float *out,
                                    void *stream);
+/*     bf16 feature path (BASELINE config C4: bf16 features, int32 rulebook, fp32 accumulate): in / out are bf16 rows
+ *     [N,C], Wb the weights rounded to bf16 in MFMA operand order (rslo_weight_to_bf16, K*cin*cout*2 bytes; transpose
+ *     = 1 for the data gradient), bias fp32.  Channel counts 32 / 64. */
+RSLO_API int rslo_weight_to_bf16(const float *W, int K, int cin_op, int cout_op, int transpose, void *Wb, void *stream);
+RSLO_API int rslo_spconv_fwd_bf16(const void *in, int cin, const void *Wb, const float *bias, const int32_t *nbr,
+                                  int64_t n_out, int K, int cout, int flip_k, float act_slope, void *out,
+                                  void *stream);
 RSLO_API size_t rslo_spconv_wgrad_ws_bytes(int64_t n_out, int K, int cin, int cout);
 RSLO_API int rslo_spconv_wgrad(const float *in, int cin, const float *dout, int cout, const int32_t *nbr,
                       int64_t n_out, int K, void *ws, size_t ws_bytes, float *dW /*[K,cin,cout]*/,

@@ -40,6 +40,8 @@ SIGNATURES = {
     "rslo_weight_split_bytes": (_sz, [_i, _i, _i]),
     "rslo_weight_split": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "rslo_spconv_fwd_split": (C.c_int, [_vp, _i, _vp, _vp, _vp, _i64, _i, _i, _i, C.c_float, _vp, _vp]),
+    "rslo_weight_to_bf16": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "rslo_spconv_fwd_bf16": (C.c_int, [_vp, _i, _vp, _vp, _vp, _i64, _i, _i, _i, C.c_float, _vp, _vp]),
     "rslo_spconv_wgrad_ws_bytes": (_sz, [_i64, _i, _i, _i]),
     "rslo_spconv_wgrad": (C.c_int, [_vp, _i, _vp, _i, _vp, _i64, _i, _vp, _sz, _vp, _vp, _vp]),
     "rslo_rulebook_pairs_ws_bytes": (_sz, [_i64, _i]),
@@ -257,6 +259,31 @@ def spconv_fwd_split(x, Ws, bias, nbr, cin, cout, flip_k=False, act_slope=1.0):
     _chk(lib().rslo_spconv_fwd_split(_ptr(x, torch.float32, "x"), cin, _ptr(Ws), _ptr(bias, torch.float32, "bias"),
                                      _ptr(nbr, torch.int32, "nbr"), n_out, K, cout, int(flip_k), float(act_slope),
                                      _ptr(out), _stream()), "rslo_spconv_fwd_split")
+    return out
+
+
+def weight_to_bf16(W, transpose=False):
+    """W [K,Cin,Cout] fp32 -> bf16 operand plane for rslo_spconv_fwd_bf16."""
+    K, cin, cout = W.shape
+    cin_op, cout_op = (cout, cin) if transpose else (cin, cout)
+    Wb = torch.empty((K * cin * cout,), dtype=torch.bfloat16, device=W.device)
+    _chk(lib().rslo_weight_to_bf16(_ptr(W, torch.float32, "W"), K, cin_op, cout_op, int(transpose), _ptr(Wb), _stream()),
+         "rslo_weight_to_bf16")
+    return Wb
+
+
+def spconv_fwd_bf16(x, W, bias, nbr, flip_k=False, act_slope=1.0, transpose=False):
+    """bf16 feature path: x [Nin,Cin] bfloat16, W [K,Cin,Cout] fp32 master weights, bias fp32 -> [Nout,Cout] bfloat16.
+    transpose=True applies W[k]^T (the data gradient; x is then dout [Nout,Cout], nbr the transposed table)."""
+    n_out, K = nbr.shape
+    Kw, cin, cout = W.shape
+    cin_op, cout_op = (cout, cin) if transpose else (cin, cout)
+    if Kw != K or x.shape[1] != cin_op or x.dtype != torch.bfloat16:
+        raise RsloHipError("spconv_fwd_bf16: shape / dtype mismatch")
+    out = torch.empty((n_out, cout_op), dtype=torch.bfloat16, device=x.device)
+    _chk(lib().rslo_spconv_fwd_bf16(_ptr(x, torch.bfloat16, "x"), cin_op, _ptr(weight_to_bf16(W, transpose)),
+                                    _ptr(bias, torch.float32, "bias"), _ptr(nbr, torch.int32, "nbr"), n_out, K, cout_op,
+                                    int(flip_k), float(act_slope), _ptr(out), _stream()), "rslo_spconv_fwd_bf16")
     return out
 
 

@@ -668,6 +668,171 @@ extern "C" int rslo_weight_transpose(const float *W, int K, int cin, int cout, f
 }
 
 
+// ---------------------------------------------------------------------------------------
+// bf16 feature path (BASELINE config C4: bf16 features, 32-bit rulebook indices, fp32 accumulation).
+// Same wave-granular structure as v6 without the operand split: the gathered bf16 rows ARE the MFMA operands
+// (16 bytes per lane and K-step), weights are rounded once per call to bf16 in operand order (k_weight_bf16), the
+// accumulators, bias and activation stay fp32, the output is rounded to bf16 (RNE).  One MFMA where v6 issues six:
+// the kernel is bound by the row gather (half the bytes of fp32), not by the matrix cores.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned short f32_to_bf16_rne(float f) {
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);   // NaN stays NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+
+__global__ void k_weight_bf16(const float *__restrict__ W, int K, int cin_op, int cout_op, int transpose,
+                              unsigned short *__restrict__ Wb) {
+  const int64_t n = (int64_t)K * cin_op * cout_op;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int e = (int)(i & 7);
+  int64_t r = i >> 3;
+  const int co = (int)(r % cout_op);
+  r /= cout_op;
+  const int g = (int)(r & 3);
+  r >>= 2;
+  const int S = cin_op / 32;
+  const int sk = (int)(r % S);
+  const int k = (int)(r / S);
+  const int ci = 32 * sk + 8 * g + e;
+  const int ch = (cout_op / 16) * (co & 15) + (co >> 4);
+  const float w = transpose ? W[((int64_t)k * cout_op + ch) * cin_op + ci] : W[((int64_t)k * cin_op + ci) * cout_op + ch];
+  Wb[i] = f32_to_bf16_rne(w);
+}
+
+template <int CIN_T, int COUT_T, int RBW>
+__global__ __launch_bounds__(SPC_THREADS) void k_spconv_bf16(const unsigned short *__restrict__ in,
+                                                             const unsigned short *__restrict__ Wb,
+                                                             const float *__restrict__ bias,
+                                                             const int32_t *__restrict__ nbr, int64_t n_out, int K,
+                                                             int flip_k, float slope, unsigned short *__restrict__ out) {
+  constexpr int NS = CIN_T / 32;
+  constexpr int NB = COUT_T / 16;
+  constexpr int ROWS = 16 * RBW;
+  __shared__ int32_t nbl[SPC_WAVES][ROWS * SPC_MAXK];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int64_t n_tiles = (n_out + ROWS - 1) / ROWS;
+  const int64_t n_blocks = (n_tiles + SPC_WAVES - 1) / SPC_WAVES;
+  const int64_t vb = xcd_tile(n_blocks);
+  const int64_t tile = vb * SPC_WAVES + wid;
+  const bool active = vb < n_blocks && tile < n_tiles;
+  const int64_t row0 = tile * ROWS;
+
+  if (active) {
+    const int64_t lim = (n_out - row0) * K;
+    for (int e = lane; e < ROWS * K; e += 64) nbl[wid][e] = (e < lim) ? nbr[row0 * K + e] : -1;
+  }
+  __syncthreads();
+  if (!active) return;
+
+  unsigned mask = 0;
+  for (int k = 0; k < K; ++k) {
+    bool any = false;
+#pragma unroll
+    for (int rb = 0; rb < RBW; ++rb) any |= nbl[wid][(rb * 16 + li) * K + k] >= 0;
+    if (__ballot(any) != 0ull) mask |= 1u << k;
+  }
+  mask = __builtin_amdgcn_readfirstlane(mask);
+
+  f32x4 acc[RBW][NB];
+#pragma unroll
+  for (int rb = 0; rb < RBW; ++rb)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[rb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  while (mask) {
+    const int k = __builtin_ctz(mask);
+    mask &= mask - 1;
+    const int kk = flip_k ? (K - 1 - k) : k;
+    const unsigned short *ap[RBW];
+    bool ok[RBW];
+#pragma unroll
+    for (int rb = 0; rb < RBW; ++rb) {
+      const int32_t r = nbl[wid][(rb * 16 + li) * K + k];
+      ok[rb] = r >= 0;
+      ap[rb] = in + (int64_t)(ok[rb] ? r : 0) * CIN_T + 8 * g;
+    }
+#pragma unroll
+    for (int sk = 0; sk < NS; ++sk) {
+      u32x4 a[RBW];
+#pragma unroll
+      for (int rb = 0; rb < RBW; ++rb) {
+        const u32x4 v = *reinterpret_cast<const u32x4 *>(ap[rb] + 32 * sk);
+        a[rb] = ok[rb] ? v : (u32x4){0u, 0u, 0u, 0u};
+      }
+      const unsigned short *wb = Wb + ((((int64_t)kk * NS + sk) * 4 + g) * COUT_T + li) * 8;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const u32x4 b = *reinterpret_cast<const u32x4 *>(wb + nb * 16 * 8);
+#pragma unroll
+        for (int rb = 0; rb < RBW; ++rb) acc[rb][nb] = MFMA_BF16(a[rb], b, acc[rb][nb]);
+      }
+    }
+  }
+
+  VecF<NB> bv;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) bv.v[nb] = bias ? bias[NB * li + nb] : 0.f;
+#pragma unroll
+  for (int rb = 0; rb < RBW; ++rb)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t row = row0 + rb * 16 + 4 * g + j;
+      if (row >= n_out) continue;
+      unsigned short o[NB];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        float v = acc[rb][nb][j] + bv.v[nb];
+        o[nb] = f32_to_bf16_rne(v > 0.f ? v : v * slope);
+      }
+      unsigned short *dst = out + row * COUT_T + NB * li;
+      if constexpr (NB == 4)
+        *reinterpret_cast<uint2 *>(dst) = make_uint2((unsigned)o[0] | ((unsigned)o[1] << 16), (unsigned)o[2] | ((unsigned)o[3] << 16));
+      else
+        *reinterpret_cast<unsigned *>(dst) = (unsigned)o[0] | ((unsigned)o[1] << 16);
+    }
+}
+
+extern "C" int rslo_weight_to_bf16(const float *W, int K, int cin_op, int cout_op, int transpose, void *Wb, void *stream) {
+  RSLO_CHECK_ARG(W && Wb && K >= 1, "rslo_weight_to_bf16: bad arguments");
+  RSLO_CHECK_ARG((cin_op == 32 || cin_op == 64) && (cout_op == 32 || cout_op == 64),
+                 "rslo_weight_to_bf16: channel counts must be 32 or 64");
+  const int64_t n = (int64_t)K * cin_op * cout_op;
+  hipLaunchKernelGGL(k_weight_bf16, dim3((unsigned)rslo_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, W, K, cin_op,
+                     cout_op, transpose, (unsigned short *)Wb);
+  RSLO_CHECK_LAUNCH("k_weight_bf16");
+  return RSLO_OK;
+}
+
+extern "C" int rslo_spconv_fwd_bf16(const void *in, int cin, const void *Wb, const float *bias, const int32_t *nbr,
+                                    int64_t n_out, int K, int cout, int flip_k, float act_slope, void *out,
+                                    void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  RSLO_CHECK_ARG((cin == 32 || cin == 64) && (cout == 32 || cout == 64), "spconv_fwd_bf16: channels must be 32 or 64");
+  RSLO_CHECK_ARG(K >= 1 && K <= SPC_MAXK, "spconv_fwd_bf16: K must be in 1..27");
+  if (n_out == 0) return RSLO_OK;
+  const unsigned short *x = (const unsigned short *)in, *w = (const unsigned short *)Wb;
+  unsigned short *o = (unsigned short *)out;
+  const int rbw = (n_out >= 256 * 32 * 8) ? 2 : 1;
+#define SPCB_CASE(CI, CO)                                                                                   \
+  if (cin == CI && cout == CO) {                                                                            \
+    if (rbw == 2)                                                                                           \
+      hipLaunchKernelGGL((k_spconv_bf16<CI, CO, 2>), dim3(xcd_grid(rslo_cdiv(rslo_cdiv(n_out, 32), 4))),    \
+                         dim3(SPC_THREADS), 0, st, x, w, bias, nbr, n_out, K, flip_k, act_slope, o);        \
+    else                                                                                                    \
+      hipLaunchKernelGGL((k_spconv_bf16<CI, CO, 1>), dim3(xcd_grid(rslo_cdiv(rslo_cdiv(n_out, 16), 4))),    \
+                         dim3(SPC_THREADS), 0, st, x, w, bias, nbr, n_out, K, flip_k, act_slope, o);        \
+  }
+  SPCB_CASE(32, 32) SPCB_CASE(32, 64) SPCB_CASE(64, 32) SPCB_CASE(64, 64)
+#undef SPCB_CASE
+  RSLO_CHECK_LAUNCH("spconv_bf16");
+  return RSLO_OK;
+}
+
 extern "C" size_t rslo_weight_split_bytes(int K, int cin, int cout) { return (size_t)3 * K * cin * cout * sizeof(unsigned short); }
 
 extern "C" int rslo_weight_split(const float *W, int K, int cin_op, int cout_op, int transpose, void *Ws, void *stream) {

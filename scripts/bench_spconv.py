@@ -41,6 +41,10 @@ def run(name, x, W, nbr, fn, check=True):
     if fn == "dgrad":
         call = lambda: capi.spconv_dgrad(x, W, nbr, flip_k=True)
         cin_op, cout_op = cout, cin
+    elif fn == "bf16":       # C4 feature path: bf16 rows in / out, fp32 accumulate
+        xb = x.to(torch.bfloat16)
+        call = lambda: capi.spconv_fwd_bf16(xb, W, None, nbr)
+        cin_op, cout_op = cin, cout
     elif fn == "dgradT":     # dgrad as a forward conv with per-offset transposed weights (coalesced B reads)
         call = lambda: capi.spconv_fwd(x, W.transpose(1, 2).contiguous(), None, nbr, flip_k=True)
         cin_op, cout_op = cout, cin
@@ -53,7 +57,8 @@ def run(name, x, W, nbr, fn, check=True):
     for _ in range(REPS): call()
     e1.record(); torch.cuda.synchronize()
     us = 1e3 * e0.elapsed_time(e1) / REPS
-    byts = P * cin_op * 4 + n_out * cout_op * 4 + 8 * P + K * cin * cout * 4
+    sz = 2 if fn == "bf16" else 4
+    byts = P * cin_op * sz + n_out * cout_op * sz + 8 * P + K * cin * cout * sz
     fl = 2 * P * cin * cout
     err = ""
     if check and fn == "fwd":
@@ -68,6 +73,8 @@ for li, ((ix, nbr), (ci, co)) in enumerate(zip(levels, chans)):
     run("subm%d %d->%d fwd" % (li, ci, co), rn(n, ci), rn(27, ci, co) * 0.1, nbr, "fwd")
     run("subm%d %d->%d dgrad" % (li, ci, co), rn(n, co), rn(27, ci, co) * 0.1, nbr, "dgrad", check=False)
     run("subm%d %d->%d dgradT" % (li, ci, co), rn(n, co), rn(27, ci, co) * 0.1, nbr, "dgradT", check=False)
+    if ci >= 32:
+        run("subm%d %d->%d bf16" % (li, ci, co), rn(n, ci), rn(27, ci, co) * 0.1, nbr, "bf16", check=False)
 run("subm0 7->16 fwd", rn(levels[0][1].shape[0], 7), rn(27, 7, 16) * 0.1, levels[0][1], "fwd")
 run("subm0 16->7 fwd", rn(levels[0][1].shape[0], 16), rn(27, 16, 7) * 0.1, levels[0][1], "fwd")
 for ci, ((nbr, nbrT), (a, b)) in enumerate(zip(convs, [(16, 32), (32, 64), (64, 64)])):

@@ -517,3 +517,30 @@ def test_fused_syncbn_two_ranks_equals_full_batch(hip):
     for r in range(2):
         np.testing.assert_allclose(out[r][6], ref.running_mean.numpy(), rtol=1e-4, atol=1e-6)
         np.testing.assert_allclose(out[r][7], ref.running_var.numpy(), rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("cin,cout", [(64, 64), (32, 64), (64, 32), (32, 32)])
+def test_bf16_feature_conv_matches_oracle_on_rounded_operands(hip, cin, cout):
+    """BASELINE config C4 (bf16 features, int32 rulebook, fp32 accumulate): rslo_spconv_fwd_bf16 on bf16-rounded
+    inputs / weights equals the double-precision oracle on the SAME rounded operands up to the final bf16 rounding of
+    the output (half an ulp = 2^-9 relative) -- forward with bias + LeakyReLU, and the data gradient (transposed)."""
+    rng = np.random.default_rng(cin * 3 + cout)
+    dims, B = [9, 30, 28], 2
+    coords = rand_sites(rng, B, dims, 2500)
+    nbr = O.rulebook_subm(coords, B, dims)
+    bf = lambda a: torch.from_numpy(a).to(torch.bfloat16)             # RNE
+    x = rng.normal(size=(len(coords), cin)).astype(np.float32)
+    W = (rng.normal(size=(27, cin, cout)) / np.sqrt(cin * 4)).astype(np.float32)
+    b = rng.normal(size=(cout,)).astype(np.float32)
+    xr, Wr = bf(x).float().numpy(), bf(W).float().numpy()
+    y = hip.spconv_fwd_bf16(bf(x).cuda(), dev(W), dev(b), dev(nbr), act_slope=0.01)
+    assert y.dtype == torch.bfloat16
+    yo = O.spconv_fwd(xr, Wr, b, nbr)
+    yo = np.where(yo > 0, yo, yo * np.float32(0.01))
+    err = np.abs(y.float().cpu().numpy() - yo)
+    assert float((err / (np.abs(yo) + 1e-2)).max()) < 2.0 ** -8 + 1e-3
+    gy = rng.normal(size=(len(coords), cout)).astype(np.float32)
+    gx = hip.spconv_fwd_bf16(bf(gy).cuda(), dev(W), None, dev(nbr), flip_k=True, transpose=True)
+    go = O.spconv_dgrad(bf(gy).float().numpy(), Wr, nbr[:, ::-1].copy())
+    err = np.abs(gx.float().cpu().numpy() - go)
+    assert gx.shape == (len(coords), cin) and float((err / (np.abs(go) + 1e-2)).max()) < 2.0 ** -8 + 1e-3
