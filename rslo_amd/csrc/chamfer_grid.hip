@@ -7,8 +7,8 @@
 //     lb = (ex^2 + ey^2) + ez^2,  e = max(lo - q, q - hi, 0)
 // in the SAME operation order as the distance.  fp32 rounding is monotone, so every point p of the tile has a
 // computed distance d(p) >= lb bit for bit: a tile whose lb exceeds the current best of all 64 lanes cannot hold a
-// winner (nor a tie) and is skipped; surviving tiles are evaluated point by point (points broadcast with
-// v_readlane) under the order-independent rule "smaller distance, then smaller original index".
+// winner (nor a tie) and is skipped; surviving tiles are evaluated point by point (staged in the wave's LDS slot and
+// read as broadcasts) under the order-independent rule "smaller distance, then smaller original index".
 // The result is therefore independent of the sort order and identical to the exhaustive scan, at ~5 % of its
 // distance evaluations for overlapping clouds.  Sorting only affects speed, never the answer: points outside the
 // key range are clamped into border cells.

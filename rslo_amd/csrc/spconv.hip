@@ -854,7 +854,8 @@ extern "C" int rslo_spconv_fwd_split(const float *in, int cin, const void *Ws, c
   RSLO_CHECK_ARG(K >= 1 && K <= SPC_MAXK, "spconv_fwd_split: K must be in 1..27");
   if (n_out == 0) return RSLO_OK;
   const unsigned short *ws = (const unsigned short *)Ws;
-  const int rbw = (n_out >= 256 * 32 * 8) ? 2 : 1;
+  static const int force_rbw = getenv("RSLO_SPCONV_RBW") ? atoi(getenv("RSLO_SPCONV_RBW")) : 0;
+  const int rbw = force_rbw ? force_rbw : ((n_out >= 256 * 32 * 8) ? 2 : 1);
 #define SPC6_CASE(CI, CO)                                                                                    \
   if (cin == CI && cout == CO) {                                                                             \
     if (rbw == 2)                                                                                            \
