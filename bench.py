@@ -210,11 +210,19 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # RSLO_BENCH_ONE_GPU=1: all ranks share GPU 0 and talk through gloo -- a functional check of the multi-rank
+        # code path (SyncBN statistics exchange, gradient all-reduce) on a single-GPU box; not a performance mode
+        one_gpu = os.environ.get("RSLO_BENCH_ONE_GPU", "0") == "1"
+        if one_gpu:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", str(rank))
         os.environ.setdefault("WORLD_SIZE", str(world))
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if dist_on else 0)
