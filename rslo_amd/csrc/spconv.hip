@@ -1245,6 +1245,135 @@ __global__ __launch_bounds__(SPC_THREADS) void k_wgrad2(const float *__restrict_
   }
 }
 
+// Weight gradient on the bf16 matrix cores with exactly split fp32 operands (the wgrad counterpart of k_spconv_v6; channel
+// counts 32 / 64).  The contraction index of v_mfma_f32_16x16x32_bf16 runs over 32 pairs; lane group g takes pairs
+// {4 e + g : e = 0..7} of a 32-pair chunk as its 8 k-values -- exactly the pairs whose rows this lane gathers anyway
+// (one float4 / float2 of its own channels per pair), so no transposition is needed: the 8 gathered values of a
+// channel are split (hi + mid + lo) and packed straight into the A / B operands.  6 MFMAs per 16x16 block and 32 pairs
+// instead of 8 fp32 MFMAs: 2.5x fewer matrix-core cycles, same fixed-order reductions as k_wgrad2.
+template <int CIN_T, int COUT_T>
+__global__ __launch_bounds__(SPC_THREADS) void k_wgrad3(const float *__restrict__ in, const float *__restrict__ dout,
+                                                        const int32_t *__restrict__ pin,
+                                                        const int32_t *__restrict__ pout,
+                                                        const int32_t *__restrict__ koff, int K,
+                                                        float *__restrict__ ws) {
+  constexpr int CB = CIN_T / 16, NB = COUT_T / 16;
+  __shared__ __attribute__((aligned(16))) float red[CIN_T * COUT_T];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int k = blockIdx.y;
+  const int pk0 = koff[k], pk1 = koff[k + 1];
+  const int p0 = pk0 + (int)blockIdx.x * WG2_CHUNK;
+  if (p0 >= pk1) return;
+  const int p1 = (p0 + WG2_CHUNK < pk1) ? p0 + WG2_CHUNK : pk1;
+
+  f32x4 acc[CB][NB];
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[cb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int w0 = p0 + wid * (WG2_CHUNK / SPC_WAVES);
+  const int w1 = (w0 + WG2_CHUNK / SPC_WAVES < p1) ? w0 + WG2_CHUNK / SPC_WAVES : p1;
+  for (int q = w0; q < w1; q += 64) {
+    const int myp = q + lane;
+    const int32_t my_i = (myp < w1) ? pin[myp] : -1;
+    const int32_t my_o = (myp < w1) ? pout[myp] : 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (q + h * 32 >= w1) break;
+      // B operands (dout) are split and packed for all NB blocks; the A side keeps the 8 gathered fp32 rows and is split
+      // one 16-channel block at a time inside the product loop (register budget: 2 waves per SIMD)
+      u32x4 bh[NB], bm[NB], bl[NB];
+      float araw[8][CB];
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {                      // k-values e = 2p, 2p+1 -> dword p of every operand
+        unsigned xb[2][NB][3];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int src = h * 32 + 4 * (2 * p + t) + g;
+          const int32_t ri = __shfl(my_i, src, 64);
+          const int32_t ro = __shfl(my_o, src, 64);
+          const bool ok = ri >= 0;
+          const VecF<CB> va = load_vec<CB>(in + (int64_t)(ok ? ri : 0) * CIN_T + CB * li);
+          const VecF<NB> vb = load_vec<NB>(dout + (int64_t)ro * COUT_T + NB * li);
+#pragma unroll
+          for (int cb = 0; cb < CB; ++cb) araw[2 * p + t][cb] = ok ? va.v[cb] : 0.f;
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) {
+            const float x = ok ? vb.v[nb] : 0.f;
+            const unsigned hb = __float_as_uint(x) & 0xffff0000u;
+            const float r1 = x - __uint_as_float(hb);
+            const unsigned mb = __float_as_uint(r1) & 0xffff0000u;
+            xb[t][nb][0] = hb;
+            xb[t][nb][1] = mb;
+            xb[t][nb][2] = __float_as_uint(r1 - __uint_as_float(mb));
+          }
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          bh[nb][p] = __builtin_amdgcn_perm(xb[1][nb][0], xb[0][nb][0], 0x07060302u);
+          bm[nb][p] = __builtin_amdgcn_perm(xb[1][nb][1], xb[0][nb][1], 0x07060302u);
+          bl[nb][p] = __builtin_amdgcn_perm(xb[1][nb][2], xb[0][nb][2], 0x07060302u);
+        }
+      }
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) {
+        u32x4 ah, am, al;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          unsigned xa[2][3];
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const float x = araw[2 * p + t][cb];
+            const unsigned hb = __float_as_uint(x) & 0xffff0000u;
+            const float r1 = x - __uint_as_float(hb);
+            const unsigned mb = __float_as_uint(r1) & 0xffff0000u;
+            xa[t][0] = hb;
+            xa[t][1] = mb;
+            xa[t][2] = __float_as_uint(r1 - __uint_as_float(mb));
+          }
+          ah[p] = __builtin_amdgcn_perm(xa[1][0], xa[0][0], 0x07060302u);
+          am[p] = __builtin_amdgcn_perm(xa[1][1], xa[0][1], 0x07060302u);
+          al[p] = __builtin_amdgcn_perm(xa[1][2], xa[0][2], 0x07060302u);
+        }
+        // six products per block, smallest first; consecutive MFMAs hit different accumulators (the NB column blocks)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[cb][nb] = MFMA_BF16(al, bh[nb], acc[cb][nb]);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[cb][nb] = MFMA_BF16(am, bm[nb], acc[cb][nb]);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[cb][nb] = MFMA_BF16(ah, bl[nb], acc[cb][nb]);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[cb][nb] = MFMA_BF16(am, bh[nb], acc[cb][nb]);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[cb][nb] = MFMA_BF16(ah, bm[nb], acc[cb][nb]);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[cb][nb] = MFMA_BF16(ah, bh[nb], acc[cb][nb]);
+      }
+    }
+  }
+
+  for (int w = 0; w < SPC_WAVES; ++w) {
+    if (wid == w) {
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int ci = CB * (4 * g + j) + cb, co = NB * li + nb;
+            float v = acc[cb][nb][j];
+            if (w) v += red[ci * COUT_T + co];
+            red[ci * COUT_T + co] = v;
+          }
+    }
+    __syncthreads();
+  }
+  float *dst = ws + ((int64_t)blockIdx.x * K + k) * CIN_T * COUT_T;
+  for (int e = tid; e < CIN_T * COUT_T; e += SPC_THREADS) dst[e] = red[e];
+}
+
 __global__ void k_wgrad2_reduce(const float *__restrict__ ws, const int32_t *__restrict__ koff, int K, int cc,
                                 float *__restrict__ dW) {
   const int k = blockIdx.y;
@@ -1355,6 +1484,15 @@ extern "C" int rslo_spconv_wgrad_pairs(const float *in, int cin, const float *do
   const int ci = cin <= 16 ? 16 : (cin <= 32 ? 32 : 64), co = pad_cout(cout);
   const bool exact = (ci == cin && co == cout);
   dim3 grid((unsigned)nch, (unsigned)K);
+  static const bool split_on = !(getenv("RSLO_SPCONV_SPLIT") && getenv("RSLO_SPCONV_SPLIT")[0] == '0');
+  if (split_on && exact && (cin == 32 || cin == 64) && (cout == 32 || cout == 64)) {
+#define WG3_CASE(CI, CO)                                                                                  \
+    if (cin == CI && cout == CO)                                                                          \
+      hipLaunchKernelGGL((k_wgrad3<CI, CO>), grid, dim3(SPC_THREADS), 0, st, in, dout, pairs_in, pairs_out, koff, K, \
+                         (float *)ws);
+    WG3_CASE(32, 32) WG3_CASE(32, 64) WG3_CASE(64, 32) WG3_CASE(64, 64)
+#undef WG3_CASE
+  } else {
 #define WG2_CASE(CI, CO)                                                                                  \
   if (ci == CI && co == CO) {                                                                             \
     if (exact)                                                                                            \
@@ -1368,6 +1506,7 @@ extern "C" int rslo_spconv_wgrad_pairs(const float *in, int cin, const float *do
   WG2_CASE(32, 16) WG2_CASE(32, 32) WG2_CASE(32, 64)
   WG2_CASE(64, 16) WG2_CASE(64, 32) WG2_CASE(64, 64)
 #undef WG2_CASE
+  }
   const int cc = cin * cout;
   hipLaunchKernelGGL(k_wgrad2_reduce, dim3((unsigned)rslo_cdiv(cc, 256), (unsigned)K), dim3(256), 0, st,
                      (const float *)ws, koff, K, cc, dW);
