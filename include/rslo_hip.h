@@ -156,9 +156,15 @@ RSLO_API size_t rslo_spconv_wgrad_pairs_ws_bytes(int64_t n_out, int K, int cin, 
 RSLO_API int rslo_spconv_wgrad_pairs(const float *in, int cin, const float *dout, int cout, const int32_t *pairs_in,
                             const int32_t *pairs_out, const int32_t *koff, int64_t n_out, int K, void *ws,
                             size_t ws_bytes, float *dW /*[K,cin,cout]*/, float *dbias /*[cout] or NULL*/,
-                            void *stream);
+                            const float *bias_partial /*[n_bias_partial,cout] from rslo_leaky_bwd_colsum, or NULL*/,
+                            int n_bias_partial, void *stream);
 /* LeakyReLU backward from the saved OUTPUT (sign-preserving): g = dout * (y > 0 ? 1 : slope). */
 RSLO_API int rslo_leaky_bwd(const float *y, const float *dout, int64_t n, float slope, float *g, void *stream);
+/*     The same plus per-block column sums of g (stage 1 of the bias gradient; cols must divide 1024):
+ *     partial [rslo_leaky_bwd_colsum_blocks(rows, cols), cols] is handed to rslo_spconv_wgrad_pairs. */
+RSLO_API int64_t rslo_leaky_bwd_colsum_blocks(int64_t rows, int cols);
+RSLO_API int rslo_leaky_bwd_colsum(const float *y, const float *dout, int64_t rows, int cols, float slope, float *g,
+                                   float *partial, void *stream);
 
 /* a7  Per-frame BatchNorm1d (+ fused LeakyReLU) of the covariance branch (nn.BatchNorm1d at
  *     rslo/models/middle.py:181-198; the reference feeds one frame per call, so statistics are per frame).

@@ -89,7 +89,7 @@ def rulebook_pairs(nbr):
             torch.tensor(koff, dtype=torch.int32))
 
 
-def spconv_wgrad_pairs(x, dout, pairs, n_out, K, cin, cout, with_bias=True):
+def spconv_wgrad_pairs(x, dout, pairs, n_out, K, cin, cout, with_bias=True, bias_partial=None):
     pin, pout, koff = (_np(p) for p in pairs)
     xd, gd = _np(x).astype(np.float64), _np(dout).astype(np.float64)
     dW = np.zeros((K, cin, cout), np.float64)
@@ -101,8 +101,9 @@ def spconv_wgrad_pairs(x, dout, pairs, n_out, K, cin, cout, with_bias=True):
     return torch.from_numpy(dW.astype(np.float32)), db
 
 
-def leaky_bwd(y, dout, slope):
-    return torch.where(y > 0, dout, dout * slope)
+def leaky_bwd(y, dout, slope, colsum=False):
+    g = torch.where(y > 0, dout, dout * slope)
+    return (g, None) if colsum else g
 
 
 def dense_scatter(feat, coords, batch, dims):

@@ -47,7 +47,9 @@ SIGNATURES = {
     "rslo_rulebook_pairs_ws_bytes": (_sz, [_i64, _i]),
     "rslo_rulebook_pairs": (C.c_int, [_vp, _i64, _i, _vp, _sz, _vp, _vp, _vp, _vp]),
     "rslo_spconv_wgrad_pairs_ws_bytes": (_sz, [_i64, _i, _i, _i]),
-    "rslo_spconv_wgrad_pairs": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i64, _i, _vp, _sz, _vp, _vp, _vp]),
+    "rslo_spconv_wgrad_pairs": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i64, _i, _vp, _sz, _vp, _vp, _vp, _i, _vp]),
+    "rslo_leaky_bwd_colsum_blocks": (_i64, [_i64, _i]),
+    "rslo_leaky_bwd_colsum": (C.c_int, [_vp, _vp, _i64, _i, C.c_float, _vp, _vp, _vp]),
     "rslo_leaky_bwd": (C.c_int, [_vp, _vp, _i64, _f, _vp, _vp]),
     "rslo_segbn_ws_bytes": (_sz, [_i, _i64, _i]),
     "rslo_segbn_fwd": (C.c_int, [_vp, _i, _vp, _i, _i64, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _sz, _vp, _vp, _vp, _vp]),
@@ -375,8 +377,9 @@ def rulebook_pairs(nbr):
     return pin, pout, koff
 
 
-def spconv_wgrad_pairs(x, dout, pairs, n_out, K, cin, cout, with_bias=True):
-    """pairs = (pairs_in, pairs_out, koff) over rows of x (in) and dout (out)."""
+def spconv_wgrad_pairs(x, dout, pairs, n_out, K, cin, cout, with_bias=True, bias_partial=None):
+    """pairs = (pairs_in, pairs_out, koff) over rows of x (in) and dout (out).
+    bias_partial: per-block column sums of dout from leaky_bwd(..., colsum=True) (saves a pass over dout)."""
     pin, pout, koff = pairs
     dev = x.device
     dW = torch.empty((K, cin, cout), dtype=torch.float32, device=dev)
@@ -386,15 +389,28 @@ def spconv_wgrad_pairs(x, dout, pairs, n_out, K, cin, cout, with_bias=True):
     _chk(lib().rslo_spconv_wgrad_pairs(_ptr(x, torch.float32, "x"), cin, _ptr(dout, torch.float32, "dout"), cout,
                                        _ptr(pin, torch.int32, "pairs_in"), _ptr(pout, torch.int32, "pairs_out"),
                                        _ptr(koff, torch.int32, "koff"), n_out, K, _ptr(ws), wsb, _ptr(dW), _ptr(db),
-                                       _stream()), "rslo_spconv_wgrad_pairs")
+                                       _ptr(bias_partial if with_bias else None),
+                                       0 if bias_partial is None else bias_partial.shape[0], _stream()),
+         "rslo_spconv_wgrad_pairs")
     return dW, db
 
 
-def leaky_bwd(y, dout, slope):
+def leaky_bwd(y, dout, slope, colsum=False):
+    """g = dout * (y > 0 ? 1 : slope); colsum=True also returns per-block column sums of g ([blocks, cols]) when the
+    row width divides 1024 (else None)."""
     g = torch.empty_like(dout)
+    if colsum:
+        rows, cols = dout.shape
+        if cols >= 4 and 1024 % cols == 0:
+            nblk = int(lib().rslo_leaky_bwd_colsum_blocks(rows, cols))
+            part = torch.empty((nblk, cols), dtype=torch.float32, device=dout.device)
+            _chk(lib().rslo_leaky_bwd_colsum(_ptr(y, torch.float32, "y"), _ptr(dout, torch.float32, "dout"), rows, cols,
+                                             float(slope), _ptr(g), _ptr(part), _stream()), "rslo_leaky_bwd_colsum")
+            return g, part
+        colsum = None
     _chk(lib().rslo_leaky_bwd(_ptr(y, torch.float32, "y"), _ptr(dout, torch.float32, "dout"), y.numel(),
                               float(slope), _ptr(g), _stream()), "rslo_leaky_bwd")
-    return g
+    return (g, None) if colsum is None else g
 
 
 def segbn_fwd(x, seg_off, S, max_len, gamma, beta, running_mean, running_var, momentum, eps, act_slope):

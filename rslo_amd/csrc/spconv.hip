@@ -1374,9 +1374,39 @@ __global__ __launch_bounds__(SPC_THREADS) void k_wgrad3(const float *__restrict_
   for (int e = tid; e < CIN_T * COUT_T; e += SPC_THREADS) dst[e] = red[e];
 }
 
+// grid (ceil(cc / 256), K [+ 1]): row k < K adds the chunk partials of offset k in chunk order; the optional row K adds
+// the bias-gradient partial rows bpart [n_bpart][cout] in row order (8 independent loads in flight, ordered adds).
 __global__ void k_wgrad2_reduce(const float *__restrict__ ws, const int32_t *__restrict__ koff, int K, int cc,
-                                float *__restrict__ dW) {
+                                float *__restrict__ dW, const float *__restrict__ bpart, int n_bpart, int cout,
+                                float *__restrict__ dbias) {
   const int k = blockIdx.y;
+  if (k == K) {
+    if (blockIdx.x != 0) return;
+    __shared__ float red[256];
+    const int cp = cout <= 16 ? 16 : (cout <= 32 ? 32 : 64);
+    const int c = threadIdx.x % cp, part = threadIdx.x / cp, nparts = 256 / cp;
+    float s = 0.f;
+    if (c < cout) {
+      for (int b = part; b < n_bpart; b += 8 * nparts) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int bb = b + u * nparts;
+          v[u] = bb < n_bpart ? bpart[(int64_t)bb * cout + c] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+      }
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (part == 0 && c < cout) {
+      float t = 0.f;
+      for (int q = 0; q < nparts; ++q) t += red[q * cp + c];
+      dbias[c] = t;
+    }
+    return;
+  }
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= cc) return;
   const int n = koff[k + 1] - koff[k];
@@ -1386,19 +1416,13 @@ __global__ void k_wgrad2_reduce(const float *__restrict__ ws, const int32_t *__r
   dW[(int64_t)k * cc + e] = s;
 }
 
-// column sums of x [rows, cols] -> partial[block][cols]; one block per CS_ROWS rows, consecutive threads read
-// consecutive floats (whole rows), 256 / cols_pad row-parts per block reduced through LDS in a fixed order
-// Single-launch column sum (bias gradient): at most CS1_MAXBLK blocks, each over a contiguous slab of rows, write
-// partial rows; the block that finishes last (device counter, reset for the next launch on the same stream) adds the
-// partial rows in block order (loads unrolled 8 deep: they are independent, only the adds are ordered) --
-// deterministic, one dispatch.
+// Bias gradient = column sums of the (activation-masked) output gradient, in two deterministic stages without fences:
+// stage 1 writes one partial row per block -- either k_colsum_partial below or, for layers with a fused activation,
+// k_leaky_bwd_colsum, which forms g = dout * act'(y) anyway --, stage 2 is the extra grid row of k_wgrad2_reduce.
 #define CS1_MAXBLK 512
-__device__ unsigned int g_colsum_done = 0;
-__global__ __launch_bounds__(256) void k_colsum_once(const float *__restrict__ x, int64_t rows, int rows_per_blk,
-                                                     int cols, int cols_pad, float *__restrict__ partial,
-                                                     float *__restrict__ result) {
+__global__ __launch_bounds__(256) void k_colsum_partial(const float *__restrict__ x, int64_t rows, int rows_per_blk,
+                                                        int cols, int cols_pad, float *__restrict__ partial) {
   __shared__ float red[256];
-  __shared__ bool last;
   const int c = threadIdx.x % cols_pad, part = threadIdx.x / cols_pad, nparts = 256 / cols_pad;
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_blk, r1 = (r0 + rows_per_blk < rows) ? r0 + rows_per_blk : rows;
   float s = 0.f;
@@ -1421,36 +1445,6 @@ __global__ __launch_bounds__(256) void k_colsum_once(const float *__restrict__ x
     for (int p = 0; p < nparts; ++p) t += red[p * cols_pad + c];
     partial[(int64_t)blockIdx.x * cols + c] = t;
   }
-  __syncthreads();
-  if (threadIdx.x == 0) {      // ONE lane releases the block's partial row (a fence by all 256 lanes costs 2-4x, and
-    __threadfence();           // blocks sharing a CU serialise on it: MI355X_MICROARCH.md, fence table)
-    last = atomicAdd(&g_colsum_done, 1u) == gridDim.x - 1;
-    if (last) __threadfence();
-  }
-  __syncthreads();
-  if (!last) return;
-  s = 0.f;
-  if (c < cols) {
-    const int nb = (int)gridDim.x;
-    for (int b = part; b < nb; b += 8 * nparts) {
-      float v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int bb = b + u * nparts;
-        v[u] = bb < nb ? __builtin_nontemporal_load(&partial[(int64_t)bb * cols + c]) : 0.f;
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) s += v[u];
-    }
-  }
-  red[threadIdx.x] = s;
-  __syncthreads();
-  if (part == 0 && c < cols) {
-    float t = 0.f;
-    for (int p = 0; p < nparts; ++p) t += red[p * cols_pad + c];
-    result[c] = t;
-  }
-  if (threadIdx.x == 0) g_colsum_done = 0;
 }
 
 extern "C" size_t rslo_rulebook_pairs_ws_bytes(int64_t n_rows, int K) {
@@ -1466,7 +1460,7 @@ extern "C" size_t rslo_spconv_wgrad_pairs_ws_bytes(int64_t n_out, int K, int cin
 extern "C" int rslo_spconv_wgrad_pairs(const float *in, int cin, const float *dout, int cout,
                                        const int32_t *pairs_in, const int32_t *pairs_out, const int32_t *koff,
                                        int64_t n_out, int K, void *ws, size_t ws_bytes, float *dW, float *dbias,
-                                       void *stream) {
+                                       const float *bias_partial, int n_bias_partial, void *stream) {
   hipStream_t st = (hipStream_t)stream;
   RSLO_CHECK_ARG(cin >= 1 && cin <= 64 && cout >= 1 && cout <= 64, "wgrad: channels must be in 1..64");
   RSLO_CHECK_ARG(K >= 1 && K <= SPC_MAXK, "wgrad: K must be in 1..27");
@@ -1508,15 +1502,23 @@ extern "C" int rslo_spconv_wgrad_pairs(const float *in, int cin, const float *do
 #undef WG2_CASE
   }
   const int cc = cin * cout;
-  hipLaunchKernelGGL(k_wgrad2_reduce, dim3((unsigned)rslo_cdiv(cc, 256), (unsigned)K), dim3(256), 0, st,
-                     (const float *)ws, koff, K, cc, dW);
+  const float *bpart = nullptr;
+  int n_bpart = 0;
   if (dbias) {
-    float *wsb = (float *)ws + (int64_t)nch * nW;
-    int rpb = (int)rslo_cdiv(n_out, CS1_MAXBLK);
-    rpb = rpb < 64 ? 64 : rpb;
-    hipLaunchKernelGGL(k_colsum_once, dim3((unsigned)rslo_cdiv(n_out, rpb)), dim3(256), 0, st, dout, n_out, rpb,
-                       cout, co, wsb, dbias);
+    if (bias_partial) {          // stage 1 already done by rslo_leaky_bwd_colsum
+      bpart = bias_partial;
+      n_bpart = n_bias_partial;
+    } else {
+      float *wsb = (float *)ws + (int64_t)nch * nW;
+      int rpb = (int)rslo_cdiv(n_out, CS1_MAXBLK);
+      rpb = rpb < 64 ? 64 : rpb;
+      n_bpart = (int)rslo_cdiv(n_out, rpb);
+      hipLaunchKernelGGL(k_colsum_partial, dim3((unsigned)n_bpart), dim3(256), 0, st, dout, n_out, rpb, cout, co, wsb);
+      bpart = wsb;
+    }
   }
+  hipLaunchKernelGGL(k_wgrad2_reduce, dim3((unsigned)rslo_cdiv(cc, 256), (unsigned)(K + (dbias ? 1 : 0))), dim3(256), 0, st,
+                     (const float *)ws, koff, K, cc, dW, bpart, n_bpart, cout, dbias);
   RSLO_CHECK_LAUNCH("wgrad_pairs");
   return RSLO_OK;
 }
@@ -1535,6 +1537,55 @@ __global__ void k_leaky_bwd(const float *__restrict__ y, const float *__restrict
   } else {
     for (; i < n; ++i) g[i] = y[i] > 0.f ? dout[i] : dout[i] * slope;
   }
+}
+
+// g = dout * act'(y) AND the per-block column sums of g (stage 1 of the bias gradient).  A block owns LB_TILES tiles of
+// 1024 consecutive floats; 1024 % cols == 0, so a thread's 4 columns are the same in every tile.
+#define LB_TILES 8
+__global__ __launch_bounds__(256) void k_leaky_bwd_colsum(const float *__restrict__ y, const float *__restrict__ dout,
+                                                          int64_t n, int cols, float slope, float *__restrict__ g,
+                                                          float *__restrict__ partial) {
+  __shared__ float red[1024];
+  const int64_t base = (int64_t)blockIdx.x * (1024 * LB_TILES) + 4 * threadIdx.x;
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < LB_TILES; ++t) {
+    const int64_t i = base + (int64_t)t * 1024;
+    if (i < n) {               // n % 4 == 0 (cols % 4 == 0)
+      const float4 yv = *reinterpret_cast<const float4 *>(y + i);
+      float4 d = *reinterpret_cast<const float4 *>(dout + i);
+      d.x = yv.x > 0.f ? d.x : d.x * slope;
+      d.y = yv.y > 0.f ? d.y : d.y * slope;
+      d.z = yv.z > 0.f ? d.z : d.z * slope;
+      d.w = yv.w > 0.f ? d.w : d.w * slope;
+      *reinterpret_cast<float4 *>(g + i) = d;
+      s[0] += d.x; s[1] += d.y; s[2] += d.z; s[3] += d.w;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) red[4 * threadIdx.x + k] = s[k];
+  __syncthreads();
+  if ((int)threadIdx.x < cols) {      // position p of the 1024-float tile holds column p % cols
+    float t = 0.f;
+    for (int p = threadIdx.x; p < 1024; p += cols) t += red[p];
+    partial[(int64_t)blockIdx.x * cols + threadIdx.x] = t;
+  }
+}
+
+extern "C" int64_t rslo_leaky_bwd_colsum_blocks(int64_t rows, int cols) {
+  return rslo_cdiv(rows * cols > 0 ? rows * cols : 1, 1024 * LB_TILES);
+}
+
+extern "C" int rslo_leaky_bwd_colsum(const float *y, const float *dout, int64_t rows, int cols, float slope, float *g,
+                                     float *partial /*[blocks, cols]*/, void *stream) {
+  RSLO_CHECK_ARG(y && dout && g && partial, "rslo_leaky_bwd_colsum: bad arguments");
+  RSLO_CHECK_ARG(cols >= 4 && cols <= 256 && 1024 % cols == 0, "rslo_leaky_bwd_colsum: cols must divide 1024");
+  if (rows == 0) return RSLO_OK;
+  const int64_t nblk = rslo_leaky_bwd_colsum_blocks(rows, cols);
+  hipLaunchKernelGGL(k_leaky_bwd_colsum, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, y, dout, rows * cols,
+                     cols, slope, g, partial);
+  RSLO_CHECK_LAUNCH("leaky_bwd_colsum");
+  return RSLO_OK;
 }
 
 extern "C" int rslo_leaky_bwd(const float *y, const float *dout, int64_t n, float slope, float *g,

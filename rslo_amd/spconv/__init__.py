@@ -162,8 +162,12 @@ class _SparseConvFn(torch.autograd.Function):
         cin, cout = weight.shape[-2], weight.shape[-1]
         W3 = weight.reshape(K, cin, cout)
         g = gy.contiguous()
+        bias_partial = None
         if slope != 1.0:
-            g = capi.leaky_bwd(y, g, slope)
+            want = has_bias and ctx.needs_input_grad[2] and ctx.rb is not None
+            g = capi.leaky_bwd(y, g, slope, colsum=want)
+            if want:
+                g, bias_partial = g
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             if subm:      # pair (i -> o via k)  <=>  (o -> i via K-1-k)
@@ -175,7 +179,8 @@ class _SparseConvFn(torch.autograd.Function):
                 pin, pout, koff = ctx.rb.pairs()
                 # an inverse conv runs over the same pairs with the roles of the two sides swapped
                 pairs = (pout, pin, koff) if ctx.inverse else (pin, pout, koff)
-                gw, gb = capi.spconv_wgrad_pairs(x, g, pairs, g.shape[0], K, cin, cout, with_bias=has_bias)
+                gw, gb = capi.spconv_wgrad_pairs(x, g, pairs, g.shape[0], K, cin, cout, with_bias=has_bias,
+                                                 bias_partial=bias_partial)
             else:
                 gw, gb = capi.spconv_wgrad(x, g, nbr, cin, cout, with_bias=has_bias)
             gw = gw.reshape(weight.shape)
