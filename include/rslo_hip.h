@@ -252,6 +252,10 @@ RSLO_API int rslo_icp_step(const float *p1, const float *n1, const float *tgt, c
                   const float *thr, int B, int N, int M, void *ws, size_t ws_bytes, float *res_r /*[B,9] in/out*/,
                   float *res_t /*[B,3] in/out*/, float *step_R /*[B,9] or NULL*/, float *step_t /*[B,3] or NULL*/,
                   void *stream);
+/* a18  ROI threshold (rslo/core/losses.py:326-334): thr[b] = max(k-th smallest of dist[b][0..counts[b]), 1) with
+ *      k = 1 + int(counts[b] * ratio); counts NULL = N everywhere.  Exact (radix select), no sort. */
+RSLO_API int rslo_roi_threshold(const float *dist, int B, int N, const int32_t *counts, double ratio, float *thr,
+                                void *stream);
 RSLO_API int rslo_transform_points(const float *x, const float *R, const float *t, int B, int M, float *out,
                           void *stream);
 /*     The same rigid map on rows of `row_stride` floats (t may be NULL), and its pose gradient

@@ -80,6 +80,7 @@ SIGNATURES = {
                                        _vp]),
     "rslo_bn2d_bwd_apply": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, _i, _i, _i, C.c_float, _i, _vp, _vp,
                                       _vp]),
+    "rslo_roi_threshold": (C.c_int, [_vp, _i, _i, _vp, C.c_double, _vp, _vp]),
     "rslo_pad_rows_fwd": (C.c_int, [_vp, _i64, _i, _vp, _vp, _i, _i, _vp, _vp]),
     "rslo_pad_rows_bwd": (C.c_int, [_vp, _i64, _i, _vp, _vp, _i, _i, _vp, _vp]),
     "rslo_pyramid_l2_ws_bytes": (_sz, [_vp, _i, _i]),
@@ -732,3 +733,12 @@ def bn2d_bwd_apply(dy, y, x, gamma, mean, invstd, red, count, slope, has_act, wa
                                    float(count), N, Cc, H * W, float(slope), int(has_act), _ptr(dx), _ptr(dres),
                                    _stream()), "rslo_bn2d_bwd_apply")
     return dx, dres
+
+
+def roi_threshold(dist, counts, ratio):
+    """dist [B,N] (+inf padded), counts int32 [B] or None -> thr [B] = max(kth(dist_b, 1 + int(cnt_b * ratio)), 1)."""
+    B, N = dist.shape
+    thr = torch.empty((B,), dtype=torch.float32, device=dist.device)
+    _chk(lib().rslo_roi_threshold(_ptr(dist, torch.float32, "dist"), B, N, _ptr(counts, torch.int32, "counts"),
+                                  float(ratio), _ptr(thr), _stream()), "rslo_roi_threshold")
+    return thr

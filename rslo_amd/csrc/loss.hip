@@ -534,6 +534,69 @@ extern "C" int rslo_transform_points(const float *x, const float *R, const float
   return RSLO_OK;
 }
 
+// ROI threshold of the consistency loss (rslo/core/losses.py:326-334): thr[b] = max(k-th smallest of dist[b][0..cnt_b),
+// 1.0) with k = 1 + int(cnt_b * ratio) (clamped to [1, cnt_b]).  Exact selection by a 4-pass MSB radix select on the
+// float bit patterns (distances are >= 0, so the unsigned order of the bits is the order of the values; NaN sorts last
+// like torch.sort) -- one block per pair instead of a full sort of 31 k values per pair.
+__global__ __launch_bounds__(1024) void k_roi_threshold(const float *__restrict__ dist, int N,
+                                                        const int32_t *__restrict__ counts, double ratio,
+                                                        float *__restrict__ thr) {
+  __shared__ unsigned hist[256];
+  __shared__ unsigned s_prefix, s_k;
+  const int b = blockIdx.x;
+  const int cnt = counts ? counts[b] : N;
+  const unsigned *d = reinterpret_cast<const unsigned *>(dist) + (int64_t)b * N;
+  if (cnt <= 0) {
+    if (threadIdx.x == 0) thr[b] = 1.0f;
+    return;
+  }
+  long long k = 1 + (long long)((double)cnt * ratio);
+  k = k > cnt ? cnt : (k < 1 ? 1 : k);
+  if (threadIdx.x == 0) {
+    s_prefix = 0u;
+    s_k = (unsigned)k;
+  }
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 24 - 8 * pass;
+    if (threadIdx.x < 256) hist[threadIdx.x] = 0u;
+    __syncthreads();
+    const unsigned prefix = s_prefix;
+    const unsigned himask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
+    for (int i = threadIdx.x; i < cnt; i += 1024) {
+      const unsigned v = d[i];
+      if ((v & himask) == prefix) atomicAdd(&hist[(v >> shift) & 0xffu], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned kk = s_k, acc = 0u;
+      int digit = 255;
+      for (int j = 0; j < 256; ++j) {
+        if (acc + hist[j] >= kk) {
+          digit = j;
+          break;
+        }
+        acc += hist[j];
+      }
+      s_k = kk - acc;
+      s_prefix = prefix | ((unsigned)digit << shift);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float v = __uint_as_float(s_prefix);
+    thr[b] = v > 1.0f ? v : 1.0f;      // torch.max(m, 1): NaN m stays NaN there; distances are never NaN on this path
+  }
+}
+
+extern "C" int rslo_roi_threshold(const float *dist, int B, int N, const int32_t *counts, double ratio, float *thr,
+                                  void *stream) {
+  RSLO_CHECK_ARG(dist && thr && B >= 0 && N >= 1, "rslo_roi_threshold: bad arguments");
+  if (B == 0) return RSLO_OK;
+  hipLaunchKernelGGL(k_roi_threshold, dim3(B), dim3(1024), 0, (hipStream_t)stream, dist, N, counts, ratio, thr);
+  RSLO_CHECK_LAUNCH("k_roi_threshold");
+  return RSLO_OK;
+}
+
 // out[b][j] = R[b] x[b][j] (+ t[b]) for rows of `row_stride` floats (the xyz / normal columns of the padded loss batch
 // are used in place), and its backward w.r.t. the pose: dR[b] = sum_j g[b][j] x[b][j]^T, dt[b] = sum_j g[b][j]
 // (block partial sums in double, last block adds them in block order: deterministic; replaces 6 tiny-tile rocBLAS

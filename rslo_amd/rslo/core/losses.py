@@ -347,6 +347,8 @@ class Aleat5_1ChamferL2NormalWeightedALLSVDLoss(Loss):
         return torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs]), torch.cat([o[2] for o in outs])
 
     def _thr(self, dist, counts):
+        if dist.is_cuda:
+            return capi.roi_threshold(dist.contiguous(), counts, self.penalize_ratio)
         if counts is None:
             return roi_threshold(dist, self.penalize_ratio).reshape(-1).contiguous()
         return roi_threshold_ragged(dist, counts, self.penalize_ratio).reshape(-1).contiguous()

@@ -48,3 +48,8 @@ print("%-60s %8s %10s %10s" % ("op", "n/step", "selfcpu ms", "cuda ms"))
 for e in rows:
     print("%-60s %8.1f %10.3f %10.3f" % (e.key[:60], e.count / N, e.self_cpu_time_total / N / 1e3, getattr(e, "self_device_time_total", 0) / N / 1e3))
 print("total ops/step", sum(e.count for e in ka) / N)
+
+print("---- by device time")
+rows = sorted(ka, key=lambda e: -getattr(e, "self_device_time_total", 0))[:45]
+for e in rows:
+    print("%-60s %8.1f %10.3f" % (e.key[:60], e.count / N, getattr(e, "self_device_time_total", 0) / N / 1e3))

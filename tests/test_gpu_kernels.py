@@ -544,3 +544,21 @@ def test_bf16_feature_conv_matches_oracle_on_rounded_operands(hip, cin, cout):
     go = O.spconv_dgrad(bf(gy).float().numpy(), Wr, nbr[:, ::-1].copy())
     err = np.abs(gx.float().cpu().numpy() - go)
     assert gx.shape == (len(coords), cin) and float((err / (np.abs(go) + 1e-2)).max()) < 2.0 ** -8 + 1e-3
+
+
+def test_roi_threshold_radix_select_is_exact(hip):
+    """rslo_roi_threshold == sort-based k-th value (bit-exact), ragged counts, duplicates, +inf padding, tiny rows."""
+    from rslo.core import losses
+    g = torch.Generator().manual_seed(5)
+    d = torch.rand(5, 4000, generator=g) ** 3 * 40
+    d[1, :2000] = d[1, 2000:4000]                     # duplicates
+    d[2] = 0.25                                        # all equal -> threshold clamps to 1
+    cnt = torch.tensor([4000, 3999, 4000, 1, 37], dtype=torch.int32)
+    for b in range(5):
+        d[b, cnt[b]:] = float("inf")
+    for ratio in (0.97, 0.5, 1.0):
+        want = losses.roi_threshold_ragged(d, cnt, ratio).reshape(-1)
+        got = hip.roi_threshold(d.cuda(), cnt.cuda(), ratio).cpu()
+        assert torch.equal(got, want), (ratio, got, want)
+    want = losses.roi_threshold(d[:1], 0.97).reshape(-1)
+    assert torch.equal(hip.roi_threshold(d[:1].cuda().contiguous(), None, 0.97).cpu(), want)
