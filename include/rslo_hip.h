@@ -323,6 +323,20 @@ RSLO_API int rslo_bn2d_bwd_apply(const float *dy, const float *y, const float *x
                                  int N, int C, int HW, float act_slope, int has_act, float *dx, float *dres,
                                  void *stream);
 
+/* a13 / a14  local -> global transformation of every BEV cell + confidence-weighted ego-motion vote
+ *      (from_pointwise_local_transformation_tch rslo/data/dataset.py:121-208, rotate_vec_by_q
+ *       rslo/utils/pose_utils.py:130-142, aggregate_tq rslo/models/odom_pred.py:347-357).
+ *      tq_map [B,7,H,W] (t_l xyz, q wxyz), t_conf / r_conf [B,1,H,W]  ->  tq_map_g [B,7,H,W], odom [B,7] (t, q),
+ *      sums [B,2] = (sum t_conf + 1e-12, sum r_conf + 1e-12).  bwd: gradient of odom -> d tq_map, d t_conf, d r_conf
+ *      (tq_map_g carries no gradient on this path).  done: int32 [B], zero on entry / exit. */
+RSLO_API size_t rslo_vote_ws_bytes(int B, int H, int W);
+RSLO_API int rslo_vote_fwd(const float *tq_map, const float *t_conf, const float *r_conf, int B, int H, int W,
+                           const float *h_origin3, const float *h_vsize3, void *ws, size_t ws_bytes, int32_t *done,
+                           float *tq_map_g, float *odom, float *sums, void *stream);
+RSLO_API int rslo_vote_bwd(const float *tq_map, const float *t_conf, const float *r_conf, int B, int H, int W,
+                           const float *h_origin3, const float *h_vsize3, const float *odom, const float *sums,
+                           const float *g_odom, float *d_tq_map, float *d_t_conf, float *d_r_conf, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

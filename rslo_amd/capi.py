@@ -81,6 +81,9 @@ SIGNATURES = {
     "rslo_bn2d_bwd_apply": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, _i, _i, _i, C.c_float, _i, _vp, _vp,
                                       _vp]),
     "rslo_roi_threshold": (C.c_int, [_vp, _i, _i, _vp, C.c_double, _vp, _vp]),
+    "rslo_vote_ws_bytes": (_sz, [_i, _i, _i]),
+    "rslo_vote_fwd": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
+    "rslo_vote_bwd": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rslo_pad_rows_fwd": (C.c_int, [_vp, _i64, _i, _vp, _vp, _i, _i, _vp, _vp]),
     "rslo_pad_rows_bwd": (C.c_int, [_vp, _i64, _i, _vp, _vp, _i, _i, _vp, _vp]),
     "rslo_pyramid_l2_ws_bytes": (_sz, [_vp, _i, _i]),
@@ -742,3 +745,39 @@ def roi_threshold(dist, counts, ratio):
     _chk(lib().rslo_roi_threshold(_ptr(dist, torch.float32, "dist"), B, N, _ptr(counts, torch.int32, "counts"),
                                   float(ratio), _ptr(thr), _stream()), "rslo_roi_threshold")
     return thr
+
+
+# --------------------------------------------------------------------------------------
+# local -> global + ego-motion vote
+# --------------------------------------------------------------------------------------
+_vote_done = {}
+
+
+def vote_fwd(tq_map, t_conf, r_conf, origin, vsize):
+    B, _, H, W = tq_map.shape
+    dev = tq_map.device
+    done = _vote_done.get(dev)
+    if done is None or done.numel() < B:
+        done = _vote_done[dev] = torch.zeros((max(B, 64),), dtype=torch.int32, device=dev)
+    wsb = lib().rslo_vote_ws_bytes(B, H, W)
+    ws = _ws(wsb, dev)
+    tq_g = torch.empty_like(tq_map)
+    odom = torch.empty((B, 7), dtype=torch.float32, device=dev)
+    sums = torch.empty((B, 2), dtype=torch.float32, device=dev)
+    _chk(lib().rslo_vote_fwd(_ptr(tq_map, torch.float32, "tq_map"), _ptr(t_conf, torch.float32, "t_conf"),
+                             _ptr(r_conf, torch.float32, "r_conf"), B, H, W, _F3(*[float(v) for v in origin]),
+                             _F3(*[float(v) for v in vsize]), _ptr(ws), wsb, _ptr(done), _ptr(tq_g), _ptr(odom),
+                             _ptr(sums), _stream()), "rslo_vote_fwd")
+    return tq_g, odom, sums
+
+
+def vote_bwd(tq_map, t_conf, r_conf, origin, vsize, odom, sums, g_odom):
+    B, _, H, W = tq_map.shape
+    d_tq = torch.empty_like(tq_map)
+    d_tc = torch.empty_like(t_conf)
+    d_rc = torch.empty_like(r_conf)
+    _chk(lib().rslo_vote_bwd(_ptr(tq_map, torch.float32, "tq_map"), _ptr(t_conf, torch.float32, "t_conf"),
+                             _ptr(r_conf, torch.float32, "r_conf"), B, H, W, _F3(*[float(v) for v in origin]),
+                             _F3(*[float(v) for v in vsize]), _ptr(odom), _ptr(sums), _ptr(g_odom, torch.float32, "g"),
+                             _ptr(d_tq), _ptr(d_tc), _ptr(d_rc), _stream()), "rslo_vote_bwd")
+    return d_tq, d_tc, d_rc

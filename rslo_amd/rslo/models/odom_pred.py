@@ -12,7 +12,9 @@ import torch
 from torch import nn
 
 import rslo.models.custom_resnet_spc as resnet
-from rslo.data.dataset import from_pointwise_local_transformation_tch
+import numpy as np
+
+from rslo.data.dataset import _grid_geometry, from_pointwise_local_transformation_tch
 from rslo.layers.confidence import ConfidenceModule, masked_spatial_softmax
 from rslo.layers.MaskConv import MaskConv
 from rslo.models.odom_pred_base import OdomPredEncDecBase, conf_trunk
@@ -51,6 +53,7 @@ class UNOdomPredEncDecSVDTempMaskBase(OdomPredEncDecBase):
     def __init__(self, use_svd=True, *args, **kwargs):
         super().__init__(*args, **kwargs)
         self.use_svd = use_svd
+        self.fused_vote = True      # local->global + vote through rslo_vote_fwd / _bwd on GPU tensors
         if use_svd:
             raise NotImplementedError("use_svd=True vote is a 'next' row (SURVEY.md 8f-4)")
         nuf = list(kwargs.get("num_upsample_filters"))
@@ -166,7 +169,13 @@ class UNOdomPredEncDecSVDTempMaskBase(OdomPredEncDecBase):
             _count_batch(m)
 
     def vote(self, tq_map, t_conf, r_conf):
-        """Ego-motion voting (odom_pred.py:347-357): confidence-weighted mean of the global maps."""
+        """Ego-motion voting (odom_pred.py:347-357): confidence-weighted mean of the global maps.  GPU tensors go
+        through the fused local->global + vote kernels (rslo_vote_fwd / _bwd); the global map they return carries no
+        gradient (it only feeds the logging extras), the voted pose does."""
+        if tq_map.is_cuda and tq_map.dim() == 4 and self.fused_vote:
+            _, vs, origin = _grid_geometry([1, tq_map.shape[2], tq_map.shape[3]], self.point_cloud_range)
+            return _VoteFn.apply(tq_map, t_conf, r_conf, tuple(float(np.float32(v)) for v in origin),
+                                 tuple(float(np.float32(v)) for v in vs))
         tq_map_g = from_pointwise_local_transformation_tch(tq_map, self.point_cloud_range)
         t = (tq_map_g[:, :3] * t_conf).sum(dim=(2, 3)) / (t_conf.sum(dim=(2, 3)) + 1e-12)
         q = (tq_map_g[:, 3:] * r_conf).sum(dim=(2, 3)) / (r_conf.sum(dim=(2, 3)) + 1e-12)
@@ -175,6 +184,25 @@ class UNOdomPredEncDecSVDTempMaskBase(OdomPredEncDecBase):
     def aggregate_tq(self, tq_maps, selected_masks, t_confs, r_confs):
         assert len(tq_maps) == len(selected_masks) == len(t_confs) == len(r_confs)
         return [self.vote(m, tc, rc)[1] for m, tc, rc in zip(tq_maps, t_confs, r_confs)]
+
+
+class _VoteFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tq_map, t_conf, r_conf, origin, vsize):
+        from rslo_amd import capi
+        tq_map, t_conf, r_conf = tq_map.contiguous(), t_conf.contiguous(), r_conf.contiguous()
+        tq_g, odom, sums = capi.vote_fwd(tq_map, t_conf, r_conf, origin, vsize)
+        ctx.save_for_backward(tq_map, t_conf, r_conf, odom, sums)
+        ctx.geom = (origin, vsize)
+        ctx.mark_non_differentiable(tq_g)
+        return tq_g, odom
+
+    @staticmethod
+    def backward(ctx, _g_map, g_odom):
+        from rslo_amd import capi
+        tq_map, t_conf, r_conf, odom, sums = ctx.saved_tensors
+        d_tq, d_tc, d_rc = capi.vote_bwd(tq_map, t_conf, r_conf, *ctx.geom, odom, sums, g_odom.contiguous())
+        return d_tq, d_tc, d_rc, None, None
 
 
 def conv1x1(in_planes, out_planes, stride=1, Conv2d=None, groups=1):

@@ -374,3 +374,30 @@ def test_short_training_run_stays_finite(hip):
     assert max(losses) < 1e6, losses
     after = torch.cat([p.detach().reshape(-1) for p in params])
     assert float((after - before).abs().max()) > 1e-4
+
+
+def test_fused_vote_matches_torch_formulation(hip):
+    """rslo_vote_fwd/_bwd == from_pointwise_local_transformation_tch + confidence-weighted means (the reference
+    formulation, op by op): global map, voted pose, gradients of the local map and of both confidences."""
+    torch.manual_seed(13)
+    net, _ = workload.build_network()
+    head = net.odom_predictor
+    B, H, W = 3, 96, 176
+    tq = torch.randn(B, 7, H, W, device="cuda")
+    tq[:, :3] *= 3.0
+    tq[:, 3:] = torch.nn.functional.normalize(tq[:, 3:] + torch.tensor([2.0, 0, 0, 0], device="cuda").view(1, 4, 1, 1), dim=1)
+    tq[0, 3:, :4] *= 1.3                                        # not exactly unit: the rotation uses q as given
+    tc = torch.softmax(torch.randn(B, 1, H * W, device="cuda"), -1).view(B, 1, H, W)
+    rc = torch.softmax(torch.randn(B, 1, H * W, device="cuda") * 2, -1).view(B, 1, H, W)
+    go = torch.randn(B, 7, device="cuda")
+    res = []
+    for fused in (True, False):
+        head.fused_vote = fused
+        a, b, c = tq.clone().requires_grad_(True), tc.clone().requires_grad_(True), rc.clone().requires_grad_(True)
+        tq_g, odom = head.vote(a, b, c)
+        (odom * go).sum().backward()
+        res.append((tq_g.detach(), odom.detach(), a.grad, b.grad, c.grad))
+    head.fused_vote = True
+    assert rel(res[0][0], res[1][0]) < 1e-5 and rel(res[0][1], res[1][1]) < 1e-5
+    for k in (2, 3, 4):
+        assert rel(res[0][k], res[1][k]) < 1e-4, k
