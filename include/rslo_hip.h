@@ -337,6 +337,16 @@ RSLO_API int rslo_vote_bwd(const float *tq_map, const float *t_conf, const float
                            const float *h_origin3, const float *h_vsize3, const float *odom, const float *sums,
                            const float *g_odom, float *d_tq_map, float *d_t_conf, float *d_r_conf, void *stream);
 
+/* a16 / a20  per-pair pose algebra of the loss assembly (one thread per frame pair):
+ *      rslo_quat_to_rot: q (w,x,y,z) -> R [B,9] with kornia 0.4.0 semantics (normalise with eps 1e-12 first;
+ *      rslo/models/voxel_odom_net.py:675) and its backward;  rslo_pose_targets: pseudo-targets of the ICP refinement
+ *      (voxel_odom_net.py:709-735): q* = sign-fixed (w,x,y,z) quaternion of res_R R_pred (kornia's four-branch
+ *      matrix -> quaternion, eps 1e-8), t* = res_R T_pred + res_t. */
+RSLO_API int rslo_quat_to_rot(const float *q_wxyz, int B, float *R, void *stream);
+RSLO_API int rslo_quat_to_rot_bwd(const float *q_wxyz, const float *gR, int B, float *gq, void *stream);
+RSLO_API int rslo_pose_targets(const float *res_r, const float *res_t, const float *R_pred, const float *T_pred, int B,
+                               float *rot_targets_wxyz, float *trans_targets, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -84,6 +84,9 @@ SIGNATURES = {
     "rslo_vote_ws_bytes": (_sz, [_i, _i, _i]),
     "rslo_vote_fwd": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
     "rslo_vote_bwd": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "rslo_quat_to_rot": (C.c_int, [_vp, _i, _vp, _vp]),
+    "rslo_quat_to_rot_bwd": (C.c_int, [_vp, _vp, _i, _vp, _vp]),
+    "rslo_pose_targets": (C.c_int, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "rslo_pad_rows_fwd": (C.c_int, [_vp, _i64, _i, _vp, _vp, _i, _i, _vp, _vp]),
     "rslo_pad_rows_bwd": (C.c_int, [_vp, _i64, _i, _vp, _vp, _i, _i, _vp, _vp]),
     "rslo_pyramid_l2_ws_bytes": (_sz, [_vp, _i, _i]),
@@ -781,3 +784,31 @@ def vote_bwd(tq_map, t_conf, r_conf, origin, vsize, odom, sums, g_odom):
                              _F3(*[float(v) for v in vsize]), _ptr(odom), _ptr(sums), _ptr(g_odom, torch.float32, "g"),
                              _ptr(d_tq), _ptr(d_tc), _ptr(d_rc), _stream()), "rslo_vote_bwd")
     return d_tq, d_tc, d_rc
+
+
+# --------------------------------------------------------------------------------------
+# per-pair pose algebra
+# --------------------------------------------------------------------------------------
+def quat_to_rot(q):
+    B = q.shape[0]
+    R = torch.empty((B, 3, 3), dtype=torch.float32, device=q.device)
+    _chk(lib().rslo_quat_to_rot(_ptr(q, torch.float32, "q"), B, _ptr(R), _stream()), "rslo_quat_to_rot")
+    return R
+
+
+def quat_to_rot_bwd(q, gR):
+    B = q.shape[0]
+    gq = torch.empty((B, 4), dtype=torch.float32, device=q.device)
+    _chk(lib().rslo_quat_to_rot_bwd(_ptr(q, torch.float32, "q"), _ptr(gR, torch.float32, "gR"), B, _ptr(gq), _stream()),
+         "rslo_quat_to_rot_bwd")
+    return gq
+
+
+def pose_targets(res_r, res_t, R_pred, T_pred):
+    B = res_r.shape[0]
+    rot = torch.empty((B, 4), dtype=torch.float32, device=res_r.device)
+    trans = torch.empty((B, 3), dtype=torch.float32, device=res_r.device)
+    _chk(lib().rslo_pose_targets(_ptr(res_r, torch.float32, "res_r"), _ptr(res_t, torch.float32, "res_t"),
+                                 _ptr(R_pred, torch.float32, "R_pred"), _ptr(T_pred, torch.float32, "T_pred"), B,
+                                 _ptr(rot), _ptr(trans), _stream()), "rslo_pose_targets")
+    return rot, trans

@@ -138,6 +138,39 @@ def rigid_move(x, R, t=None):
     return out if t is None else out + t[:, None]
 
 
+class _QuatToRotFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q):
+        q = q.contiguous()
+        ctx.save_for_backward(q)
+        return capi.quat_to_rot(q)
+
+    @staticmethod
+    def backward(ctx, gR):
+        (q,) = ctx.saved_tensors
+        return capi.quat_to_rot_bwd(q, gR.contiguous())
+
+
+def quat_wxyz_to_rot(q):
+    """(w,x,y,z) [B,4] -> R [B,3,3] = kornia.quaternion_to_rotation_matrix(roll(q, -1)) (normalising, eps 1e-12)."""
+    if q.is_cuda and q.dtype == torch.float32 and q.dim() == 2:
+        return _QuatToRotFn.apply(q)
+    import torchplus
+    return kornia.quaternion_to_rotation_matrix(torchplus.roll(q, shift=-1, dim=-1))
+
+
+def icp_pose_targets(res_r, res_t, R_pred, T_pred):
+    """Pseudo-targets from the ICP refinement (voxel_odom_net.py:709-735), no gradient: (q* wxyz with w >= 0, t*)."""
+    R_pred, T_pred = R_pred.detach(), T_pred.detach()
+    if res_r.is_cuda:
+        return capi.pose_targets(res_r.contiguous(), res_t.contiguous(), R_pred.contiguous(), T_pred.contiguous())
+    import torchplus
+    rot = kornia.rotation_matrix_to_quaternion((res_r @ R_pred).contiguous())
+    rot = torchplus.roll(rot, 1, dim=-1)
+    rot = rot * torch.sign(rot[:, 0:1])
+    return rot, (res_r @ T_pred[..., None] + res_t[..., None]).squeeze(-1)
+
+
 _const_cache = {}
 
 

@@ -422,7 +422,7 @@ class UnVoxelOdomNetICP3(nn.Module):
                 if R_pred.shape[-1] == 9:
                     R_pred = R_pred.reshape(-1, 3, 3)
                 else:
-                    R_pred = kornia.quaternion_to_rotation_matrix(torchplus.roll(R_pred, shift=-1, dim=-1))
+                    R_pred = losses.quat_wxyz_to_rot(R_pred)
                 if step <= 1500:   # warm-up: the consistency loss sees the identity pose
                     R_pred = torch.eye(3, device=device, dtype=dtype).expand(R_pred.shape[0], 3, 3).contiguous()
                     T_pred = torch.zeros_like(T_pred)
@@ -438,10 +438,7 @@ class UnVoxelOdomNetICP3(nn.Module):
                 C_loss = C_loss + (1 - warm_weight) * weight * l
 
         if res_r is not None and res_t is not None:
-            rotation_targets = kornia.rotation_matrix_to_quaternion((res_r @ R_pred.detach()).contiguous())
-            rotation_targets = torchplus.roll(rotation_targets, 1, dim=-1)
-            rotation_targets = rotation_targets * torch.sign(rotation_targets[:, 0:1])
-            translation_targets = (res_r @ T_pred[..., None].detach() + res_t[..., None]).squeeze(-1)
+            rotation_targets, translation_targets = losses.icp_pose_targets(res_r, res_t, R_pred, T_pred)
 
         T_loss = sum(translation_loss(p, translation_targets) for p in translation_preds)
         R_loss = sum(rotation_loss(p, rotation_targets) for p in rotation_preds)
