@@ -189,20 +189,36 @@ def pyramid_l2_losses(preds, masks, tq, geom, loss_T, loss_R):
     Returns `scaled` [L,2]: loss_weight * AdaptiveWeightedL2Loss per level for (translation, rotation)."""
     masks = [m.detach().contiguous().float() for m in masks]
     loss_b = _PyramidL2Fn.apply(tq.detach().contiguous().float(), geom, masks, *[p.float() for p in preds])
-    B = loss_b.shape[1]
+    return _adaptive_reduce_pair(loss_b, loss_T, loss_R)
+
+
+def _adaptive_reduce_pair(loss_b, loss_T, loss_R):
+    """loss_b [..., B, 2] (per-sample translation / rotation terms) -> [..., 2]: loss_weight * (exp(-a) sum_b fw_b l_b + a)
+    for both AdaptiveWeightedL2Loss modules at once (losses.py:190-196)."""
+    B = loss_b.shape[-2]
     alpha = torch.cat([loss_T.alpha, loss_R.alpha])                      # [2]
-    y = torch.exp(-alpha) * loss_b                                       # [L,B,2]
+    y = torch.exp(-alpha) * loss_b                                       # [..., B, 2]
     if loss_T.focal_gamma == 0 and loss_R.focal_gamma == 0:
-        out = y.sum(1) / (B + 1e-12) + alpha                             # fw = 1 / (B + 1e-12)
+        out = y.sum(-2) / (B + 1e-12) + alpha                            # fw = 1 / (B + 1e-12)
     else:
         cols = []
         for k, g in enumerate((loss_T.focal_gamma, loss_R.focal_gamma)):
             fw = y[..., k] ** g
-            fw = fw / (fw.sum(1, keepdim=True) + 1e-12)
-            cols.append((fw * y[..., k]).sum(1))
+            fw = fw / (fw.sum(-1, keepdim=True) + 1e-12)
+            cols.append((fw * y[..., k]).sum(-1))
         out = torch.stack(cols, -1) + alpha
     # python-scalar weights (the translation / rotation weights change every warm-up step: no constant upload)
-    return torch.cat([out[:, :1] * loss_T._loss_weight, out[:, 1:] * loss_R._loss_weight], 1)
+    return torch.cat([out[..., :1] * loss_T._loss_weight, out[..., 1:] * loss_R._loss_weight], -1)
+
+
+def pose_l2_losses(T_pred, T_tgt, R_pred, R_tgt, loss_T, loss_R):
+    """translation_loss(T_pred, T_tgt) and rotation_loss(R_pred, R_tgt) (unmasked AdaptiveWeightedL2Loss) evaluated
+    together on one [B,7] difference: -> (T_loss [1], R_loss [1])."""
+    d = torch.cat([T_pred - T_tgt, R_pred - R_tgt], 1)
+    sq = d * d
+    loss_b = torch.stack([sq[:, :3].sum(1) / (3 + 1e-12), sq[:, 3:].sum(1) / (4 + 1e-12)], 1)     # mask = ones
+    out = _adaptive_reduce_pair(loss_b, loss_T, loss_R)
+    return out[0:1], out[1:2]
 
 
 def span_cov2(cov_param):

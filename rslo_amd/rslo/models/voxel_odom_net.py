@@ -440,8 +440,15 @@ class UnVoxelOdomNetICP3(nn.Module):
         if res_r is not None and res_t is not None:
             rotation_targets, translation_targets = losses.icp_pose_targets(res_r, res_t, R_pred, T_pred)
 
-        T_loss = sum(translation_loss(p, translation_targets) for p in translation_preds)
-        R_loss = sum(rotation_loss(p, rotation_targets) for p in rotation_preds)
+        if (len(translation_preds) == 1 and len(rotation_preds) == 1
+                and isinstance(translation_loss, losses.AdaptiveWeightedL2Loss)
+                and isinstance(rotation_loss, losses.AdaptiveWeightedL2Loss)
+                and translation_preds[0].shape[-1] == 3 and rotation_preds[0].shape[-1] == 4):
+            T_loss, R_loss = losses.pose_l2_losses(translation_preds[0], translation_targets, rotation_preds[0],
+                                                   rotation_targets, translation_loss, rotation_loss)
+        else:
+            T_loss = sum(translation_loss(p, translation_targets) for p in translation_preds)
+            R_loss = sum(rotation_loss(p, rotation_targets) for p in rotation_preds)
         if pyramid_translation_loss is None or pyramid_rotation_loss is None:
             return T_loss, R_loss
 
