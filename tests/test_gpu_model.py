@@ -401,3 +401,32 @@ def test_fused_vote_matches_torch_formulation(hip):
     assert rel(res[0][0], res[1][0]) < 1e-5 and rel(res[0][1], res[1][1]) < 1e-5
     for k in (2, 3, 4):
         assert rel(res[0][k], res[1][k]) < 1e-4, k
+
+
+def test_three_frame_samples_batched_equals_per_sample(hip):
+    """seq_length 3 (the shipped training config): 3 frames -> 3 pairs per sample.  A ragged batch of two such samples
+    must reproduce the per-sample consistency loss / poses (BN in eval mode so that samples do not couple)."""
+    torch.manual_seed(6)
+    net, _ = workload.build_network()
+    net.train()
+    for m in net.modules():
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            m.eval()
+    net.global_step.fill_(2000)
+    with torch.no_grad():
+        last = net.odom_predictor.tq_map_conv[6]
+        last.weight.mul_(0.01)
+        last.bias.copy_(torch.tensor([0.8, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0]))
+    a0, a1, _ = reduced_pair(21)
+    a2 = reduced_pair(22)[1]
+    b0, b1, _ = reduced_pair(23, rings=32)
+    b2 = reduced_pair(24, rings=32)[1]
+    sa, sb = [a0, a1, a2], [b0, b1, b2]
+    both = net(workload.make_example(net, [sa, sb]))
+    ra = net(workload.make_example(net, [sa]))
+    rb = net(workload.make_example(net, [sb]))
+    assert both["translation_preds"].shape == (6, 3)
+    assert rel(both["translation_preds"], torch.cat([ra["translation_preds"], rb["translation_preds"]])) < 1e-4
+    assert rel(both["rotation_preds"], torch.cat([ra["rotation_preds"], rb["rotation_preds"]])) < 1e-4
+    assert rel(both["C_loss"], (ra["C_loss"] + rb["C_loss"]) / 2) < 2e-4
+    both["loss"].mean().backward()
