@@ -235,6 +235,9 @@ def main():
     net, _ = workload.build_network(device=dev)
     net.train()
     net.global_step.fill_(2000)          # past the warm-up: predicted pose in the loss, icp_iter = 2
+    if os.environ.get("RSLO_HEAD_NHWC", "0") == "1":     # experiment: dense head in channels-last
+        net.odom_predictor.to(memory_format=torch.channels_last)
+        net.odom_predictor.channels_last = True
     model = net
     if dist_on:
         # Data parallel without the DDP wrapper: identical initial weights (broadcast), and after backward ONE flat

@@ -28,8 +28,9 @@ class MaskConv(nn.Module):
         if not isinstance(x, (list, tuple)):
             x = [x, (x.abs().sum(dim=1, keepdim=True) != 0).float().detach()]
         tensor, mask = x
-        with torch.no_grad():
-            mask = self.mask_pool(mask)
+        if mask is not None:        # None: the caller declared the mask unused (odom_pred.py, `track_masks`)
+            with torch.no_grad():
+                mask = self.mask_pool(mask)
         return [self.conv1(tensor), mask]
 
 

@@ -14,15 +14,21 @@ def conv3x3(in_planes, out_planes, stride=1, Conv2d=None, groups=1):
     return Conv2d(in_planes, out_planes, kernel_size=3, stride=stride, padding=1, bias=False, groups=groups)
 
 
+def _mask_mean(ma, mb):
+    if ma is None or mb is None:        # mask declared unused by the caller (MaskConv passes None through)
+        return None
+    return ((ma + mb) / 2).float()
+
+
 def SPC_add(a, b):
     if isinstance(a, (list, tuple)):
-        return [a[0] + b[0], ((a[1] + b[1]) / 2).float()]
+        return [a[0] + b[0], _mask_mean(a[1], b[1])]
     return a + b
 
 
 def SPC_cat(a, b):
     if isinstance(a, (list, tuple)):
-        return [torch.cat([a[0], b[0]], dim=1), ((a[1] + b[1]) / 2).float()]
+        return [torch.cat([a[0], b[0]], dim=1), _mask_mean(a[1], b[1])]
     return torch.cat([a, b], dim=1)
 
 
@@ -53,7 +59,7 @@ class BasicBlock(nn.Module):
             residual = x if self.downsample is None else self.downsample(x)
             y = self.bn2(out, act_slope=slope, residual=residual)
             if isinstance(y, (list, tuple)):      # (feature, mask) pairs: masks are averaged like SPC_add does
-                y = [y[0], ((out[1] + residual[1]) / 2).float()]
+                y = [y[0], _mask_mean(out[1], residual[1])]
             return y
         out = self.relu(self.bn1(self.conv1(x)))
         out = self.bn2(self.conv2(out))

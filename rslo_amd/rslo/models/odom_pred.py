@@ -54,6 +54,10 @@ class UNOdomPredEncDecSVDTempMaskBase(OdomPredEncDecBase):
         super().__init__(*args, **kwargs)
         self.use_svd = use_svd
         self.fused_vote = True      # local->global + vote through rslo_vote_fwd / _bwd on GPU tensors
+        # The MaskConv encoder carries an occupancy mask next to the features (max-pooled per conv, averaged at every
+        # residual add); nothing in this head ever reads it (only x[0] leaves the encoder), so by default it is not
+        # propagated: ~80 small launches per step that cannot change any output.  True restores the propagation.
+        self.track_masks = False
         if use_svd:
             raise NotImplementedError("use_svd=True vote is a 'next' row (SURVEY.md 8f-4)")
         nuf = list(kwargs.get("num_upsample_filters"))
@@ -89,6 +93,10 @@ class UNOdomPredEncDecSVDTempMaskBase(OdomPredEncDecBase):
             input_mask = input_mask_bool.to(dtype=xs[0].dtype)
 
         x = torch.cat(xs, dim=1)
+        if getattr(self, "channels_last", False):     # experiment switch (bench.py RSLO_HEAD_NHWC=1), see DESIGN.md
+            x = x.contiguous(memory_format=torch.channels_last)
+        if not self.track_masks:
+            x = [x, None]
         ups = []
         for blk, skip in zip(self.blocks, self.skip_blocks):
             x = blk(x)

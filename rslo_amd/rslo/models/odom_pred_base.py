@@ -132,6 +132,8 @@ class OdomPredEncDecBase(nn.Module):
             for j in range(i + 1, len(xs)):
                 first.append(xs[i])
                 second.append(xs[j])
+        if len(first) == 1:      # two frames: the stack + reshape of one element is the tensor itself
+            return [first[0], second[0]]
         return [torch.stack(first, dim=1).reshape(-1, Cc, H, W), torch.stack(second, dim=1).reshape(-1, Cc, H, W)]
 
     def unravel_prediction(self, pred, seq_len):
