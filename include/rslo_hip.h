@@ -337,6 +337,17 @@ RSLO_API int rslo_vote_bwd(const float *tq_map, const float *t_conf, const float
                            const float *h_origin3, const float *h_vsize3, const float *odom, const float *sums,
                            const float *g_odom, float *d_tq_map, float *d_t_conf, float *d_r_conf, void *stream);
 
+/* a10 - a12  weight gradient of the BEV head's dense 3x3 convolutions (torch.nn.Conv2d / MaskConv.conv1 built in
+ *      rslo/models/odom_pred.py:65-134,398-426 and rslo/models/custom_resnet_spc.py:224-298; in the reference the
+ *      gradient comes from cuDNN through autograd).  NCHW fp32, kernel 3x3, padding 1, stride 1 or 2, cin % 16 == 0,
+ *      cout % 32 == 0:  dW [cout,cin,3,3] = sum over batch and output pixels of dout [B,cout,Ho,Wo] x shifted
+ *      in [B,cin,H,W].  bf16 matrix cores on exactly split fp32 operands, fixed summation order (no atomics).
+ *      rslo_conv2d_wgrad_supported returns 1 for shapes the kernel takes (others stay on the library path). */
+RSLO_API int rslo_conv2d_wgrad_supported(int cin, int cout, int H, int W, int stride);
+RSLO_API size_t rslo_conv2d_wgrad_ws_bytes(int B, int cin, int cout, int H, int W, int stride);
+RSLO_API int rslo_conv2d_wgrad(const float *in, const float *dout, int B, int cin, int cout, int H, int W, int stride,
+                               float *dW, void *ws, size_t ws_bytes, void *stream);
+
 /* a16 / a20  per-pair pose algebra of the loss assembly (one thread per frame pair):
  *      rslo_quat_to_rot: q (w,x,y,z) -> R [B,9] with kornia 0.4.0 semantics (normalise with eps 1e-12 first;
  *      rslo/models/voxel_odom_net.py:675) and its backward;  rslo_pose_targets: pseudo-targets of the ICP refinement

@@ -195,3 +195,22 @@ def chamfer_grad(xyz1, xyz2, graddist1, idx1):
     g2 = np.empty((B, M, 3), np.float32)
     lib().orc_chamfer_grad(B, N, M, _p(a), _p(b), _p(g), _p(i), _p(g1), _p(g2))
     return g1, g2
+
+
+def conv2d_wgrad(x, dout, stride=1):
+    """Weight gradient of the BEV head's dense 3x3 / padding-1 Conv2d layers (torch.nn.Conv2d built in
+    rslo/models/odom_pred.py:65-134 and rslo/layers/MaskConv.py:33-37; cross-correlation, zero padding):
+    dW[o,i,ky,kx] = sum_{b,y,x} dout[b,o,y,x] * xpad[b,i,S*y+ky,S*x+kx], accumulated in float64.
+    x [B,Cin,H,W], dout [B,Cout,Ho,Wo] -> [Cout,Cin,3,3] float64."""
+    x = np.asarray(x, np.float64)
+    g = np.asarray(dout, np.float64)
+    B, Cin, H, W = x.shape
+    Ho, Wo = g.shape[2], g.shape[3]
+    xp = np.zeros((B, Cin, H + 2, W + 2))
+    xp[:, :, 1:H + 1, 1:W + 1] = x
+    dW = np.empty((g.shape[1], Cin, 3, 3))
+    for ky in range(3):
+        for kx in range(3):
+            win = xp[:, :, ky:ky + stride * (Ho - 1) + 1:stride, kx:kx + stride * (Wo - 1) + 1:stride]
+            dW[:, :, ky, kx] = np.einsum("boyx,biyx->oi", g, win, optimize=True)
+    return dW

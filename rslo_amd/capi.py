@@ -84,6 +84,9 @@ SIGNATURES = {
     "rslo_vote_ws_bytes": (_sz, [_i, _i, _i]),
     "rslo_vote_fwd": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
     "rslo_vote_bwd": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "rslo_conv2d_wgrad_supported": (C.c_int, [_i, _i, _i, _i, _i]),
+    "rslo_conv2d_wgrad_ws_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "rslo_conv2d_wgrad": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "rslo_quat_to_rot": (C.c_int, [_vp, _i, _vp, _vp]),
     "rslo_quat_to_rot_bwd": (C.c_int, [_vp, _vp, _i, _vp, _vp]),
     "rslo_pose_targets": (C.c_int, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
@@ -784,6 +787,27 @@ def vote_bwd(tq_map, t_conf, r_conf, origin, vsize, odom, sums, g_odom):
                              _F3(*[float(v) for v in vsize]), _ptr(odom), _ptr(sums), _ptr(g_odom, torch.float32, "g"),
                              _ptr(d_tq), _ptr(d_tc), _ptr(d_rc), _stream()), "rslo_vote_bwd")
     return d_tq, d_tc, d_rc
+
+
+# --------------------------------------------------------------------------------------
+# dense 3x3 conv2d weight gradient (BEV head)
+# --------------------------------------------------------------------------------------
+def conv2d_wgrad_supported(cin, cout, H, W, stride):
+    return bool(lib().rslo_conv2d_wgrad_supported(int(cin), int(cout), int(H), int(W), int(stride)))
+
+
+def conv2d_wgrad(x, dout, stride=1):
+    """x [B,cin,H,W], dout [B,cout,Ho,Wo] (contiguous NCHW fp32) -> dW [cout,cin,3,3] of a 3x3 / padding-1 conv."""
+    B, cin, H, W = x.shape
+    cout = dout.shape[1]
+    wsb = lib().rslo_conv2d_wgrad_ws_bytes(B, cin, cout, H, W, stride)
+    if wsb == 0:
+        raise RsloHipError("rslo_conv2d_wgrad: unsupported shape %s -> %s stride %d" % (tuple(x.shape), tuple(dout.shape), stride))
+    ws = _ws(wsb, x.device)
+    dW = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=x.device)
+    _chk(lib().rslo_conv2d_wgrad(_ptr(x, torch.float32, "x"), _ptr(dout, torch.float32, "dout"), B, cin, cout, H, W,
+                                 stride, _ptr(dW), _ptr(ws), wsb, _stream()), "rslo_conv2d_wgrad")
+    return dW
 
 
 # --------------------------------------------------------------------------------------

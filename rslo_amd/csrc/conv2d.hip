@@ -1,0 +1,496 @@
+// Dense 2-D convolution weight gradient for the BEV head (3x3, stride 1 or 2, padding 1, NCHW fp32) on the bf16 matrix
+// cores with exactly split operands -- the dense counterpart of k_wgrad3 (spconv.hip).
+//
+//   dW[co][ci][ky][kx] = sum_{b,y,x} dout[b][co][y][x] * in[b][ci][S y + ky - 1][S x + kx - 1]
+//
+// is a GEMM whose contraction index runs over the OUTPUT pixels, which are contiguous in NCHW for both operands: a
+// 32-pixel chunk of one image plane is one v_mfma_f32_16x16x32_bf16 step, lane (li = lane & 15, g = lane >> 4) holding
+// pixels 8g..8g+7 of channel li -- two 16-byte loads, no transposition, no LDS staging.  The tap (ky, kx) only shifts
+// the input window by (ky-1) W + (kx-1) floats (dword-aligned 16-byte loads) and masks the pixels whose neighbour falls
+// outside the image.  Every fp32 operand value is split into three bf16 terms (hi + mid + lo, truncation splits, exact)
+// and the six significant products are accumulated smallest first in fp32: fp32-accurate results at 6/16 of the fp32
+// MFMA cycles.
+//
+// Work decomposition: a wave owns a [16 cin] x [16 NB cout] x 9-tap block of dW (36 accumulator tiles for NB = 4); the
+// 4 waves of a workgroup take interleaved chunks of one pixel slab and are added in LDS in wave order; slab partials go
+// to a workspace and are added in slab order by k_conv2d_wgrad_reduce (which also writes the OIHW layout): fixed
+// summation order, no atomics, bit-reproducible run to run (MIOpen's split-K kernels for these shapes use atomics).
+#include "rslo_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+
+#define C2_THREADS 256
+#define C2_WAVES 4
+#define MFMA_BF16(A, B, C) \
+  __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), C, 0, 0, 0)
+
+struct Split3 {
+  u32x4 h, m, l;
+};
+
+// 8 fp32 values -> three bf16x8 operands; bit e of `mask` keeps value e, cleared bits give zeros
+__device__ __forceinline__ Split3 split_masked(const float (&v)[8], unsigned mask) {
+  unsigned hb[8], mb[8], lb[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float x = ((mask >> e) & 1u) ? v[e] : 0.f;
+    hb[e] = __float_as_uint(x) & 0xffff0000u;
+    const float r1 = x - __uint_as_float(hb[e]);
+    mb[e] = __float_as_uint(r1) & 0xffff0000u;
+    lb[e] = __float_as_uint(r1 - __uint_as_float(mb[e]));
+  }
+  Split3 o;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    o.h[p] = __builtin_amdgcn_perm(hb[2 * p + 1], hb[2 * p], 0x07060302u);
+    o.m[p] = __builtin_amdgcn_perm(mb[2 * p + 1], mb[2 * p], 0x07060302u);
+    o.l[p] = __builtin_amdgcn_perm(lb[2 * p + 1], lb[2 * p], 0x07060302u);
+  }
+  return o;
+}
+
+// 8 consecutive floats at base[idx .. idx+7]; lanes whose window leaves [0, total) read element-wise under the mask
+__device__ __forceinline__ void load8(const float *__restrict__ base, int64_t idx, int64_t total, unsigned mask,
+                                      float (&v)[8]) {
+  if (idx >= 0 && idx + 8 <= total) {
+    const f32x4u a = *(const f32x4u *)(base + idx);
+    const f32x4u b = *(const f32x4u *)(base + idx + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+    v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = ((mask >> e) & 1u) ? base[idx + e] : 0.f;
+  }
+}
+
+// stride-2 input window: the 8 values in[idx + 2e]; 15 consecutive floats are loaded where they fit
+__device__ __forceinline__ void load8_s2(const float *__restrict__ base, int64_t idx, int64_t total, unsigned mask,
+                                         float (&v)[8]) {
+  if (idx >= 0 && idx + 16 <= total) {
+    const f32x4u a = *(const f32x4u *)(base + idx);
+    const f32x4u b = *(const f32x4u *)(base + idx + 4);
+    const f32x4u c = *(const f32x4u *)(base + idx + 8);
+    const f32x4u d = *(const f32x4u *)(base + idx + 12);
+    v[0] = a.x; v[1] = a.z; v[2] = b.x; v[3] = b.z;
+    v[4] = c.x; v[5] = c.z; v[6] = d.x; v[7] = d.z;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = ((mask >> e) & 1u) ? base[idx + 2 * e] : 0.f;
+  }
+}
+
+struct Conv2dGeom {
+  int B, cin, cout, H, W;       // H, W: OUTPUT size (= input size for stride 1)
+  int Hin, Win;                 // input size
+  int cpi;                      // 32-pixel chunks per output image plane
+  int chunks_per_slab;
+  int n_cin_tiles, n_cout_tiles;
+};
+
+// grid (n_cin_tiles * n_cout_tiles, n_slabs); ws [slab][tile][9][16][16 NB]
+template <int NB, int STRIDE, int DIAG = 0>
+__global__ __launch_bounds__(C2_THREADS, 2) void k_conv2d_wgrad(const float *__restrict__ in,
+                                                             const float *__restrict__ dout, Conv2dGeom gm,
+                                                             float *__restrict__ ws) {
+  constexpr int CO_T = 16 * NB;
+  __shared__ __attribute__((aligned(16))) float red[9 * 16 * CO_T];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int tile = blockIdx.x;
+  const int ct = tile / gm.n_cout_tiles, ot = tile - ct * gm.n_cout_tiles;
+  const int ci0 = ct * 16, co0 = ot * CO_T;
+  const int HW = gm.H * gm.W;
+  const int64_t HWin = (int64_t)gm.Hin * gm.Win;
+  const int64_t in_total = (int64_t)gm.B * gm.cin * HWin, out_total = (int64_t)gm.B * gm.cout * HW;
+  const int n_chunks = gm.B * gm.cpi;
+  const int c_begin = blockIdx.y * gm.chunks_per_slab;
+  const int c_end = min(c_begin + gm.chunks_per_slab, n_chunks);
+
+  f32x4 acc[9][NB];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[t][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int c = c_begin + wid; c < c_end; c += C2_WAVES) {
+    const int b = c / gm.cpi;
+    const int p = (c - b * gm.cpi) * 32 + 8 * g;          // this lane's first output pixel in the plane
+    int y = p / gm.W, x = p - (p / gm.W) * gm.W;
+    const int y0 = y, x0 = x;
+    // validity of the lane's 8 pixels per tap row / column
+    unsigned vp = 0, vx0 = 0, vx2 = 0, vy0 = 0, vy2 = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const unsigned bit = 1u << e;
+      if (p + e < HW) vp |= bit;
+      if (STRIDE * x - 1 >= 0) vx0 |= bit;
+      if (STRIDE * x + 1 < gm.Win) vx2 |= bit;
+      if (STRIDE * y - 1 >= 0) vy0 |= bit;
+      if (STRIDE * y + 1 < gm.Hin) vy2 |= bit;
+      if (++x == gm.W) { x = 0; ++y; }
+    }
+    // dout operands of all NB cout blocks
+    u32x4 bh[NB], bm[NB], bl[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      float v[8];
+      load8(dout, ((int64_t)b * gm.cout + co0 + 16 * nb + li) * HW + p, out_total, vp, v);
+      const Split3 s = split_masked(v, vp);
+      bh[nb] = s.h; bm[nb] = s.m; bl[nb] = s.l;
+    }
+    const int64_t plane = ((int64_t)b * gm.cin + ci0 + li) * HWin;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        unsigned mask = vp;
+        if (ky == 0) mask &= vy0;
+        if (ky == 2) mask &= vy2;
+        if (kx == 0) mask &= vx0;
+        if (kx == 2) mask &= vx2;
+        float v[8];
+        if (DIAG == 1) {                                   // timing experiment: no input loads
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = __int_as_float(0x3f800000 + (lane << 8) + e + c);
+        } else if (STRIDE == 1) {
+          load8(in, plane + p + (ky - 1) * gm.Win + (kx - 1), in_total, mask, v);
+        } else {
+          // the 8 output pixels may wrap to the next output row: input index is not affine across the wrap
+          const int wrap = gm.W - x0;                       // first element that lies in the next output row (>= 8: none)
+          if (wrap >= 8) {
+            load8_s2(in, plane + (int64_t)(2 * y0 + ky - 1) * gm.Win + 2 * x0 + kx - 1, in_total, mask, v);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const int yy = e < wrap ? y0 : y0 + 1, xx = e < wrap ? x0 + e : e - wrap;
+              v[e] = ((mask >> e) & 1u) ? in[plane + (int64_t)(2 * yy + ky - 1) * gm.Win + 2 * xx + kx - 1] : 0.f;
+            }
+          }
+        }
+        const Split3 a = split_masked(v, mask);
+        const int t = ky * 3 + kx;
+        if (DIAG == 2) {                                   // timing experiment: no matrix-core work
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) acc[t][nb][0] += __uint_as_float(a.l[nb] ^ a.m[nb] ^ a.h[nb] ^ bh[nb][0] ^ bm[nb][1] ^ bl[nb][2]);
+          continue;
+        }
+        // six products per block, smallest first; consecutive MFMAs hit different accumulators
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[t][nb] = MFMA_BF16(a.l, bh[nb], acc[t][nb]);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[t][nb] = MFMA_BF16(a.m, bm[nb], acc[t][nb]);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[t][nb] = MFMA_BF16(a.h, bl[nb], acc[t][nb]);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[t][nb] = MFMA_BF16(a.m, bh[nb], acc[t][nb]);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[t][nb] = MFMA_BF16(a.h, bm[nb], acc[t][nb]);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[t][nb] = MFMA_BF16(a.h, bh[nb], acc[t][nb]);
+      }
+    }
+  }
+
+  // waves are added in wave order through LDS: red[t][ci][co]
+  for (int w = 0; w < C2_WAVES; ++w) {
+    if (wid == w) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int e = (t * 16 + 4 * g + j) * CO_T + 16 * nb + li;
+            float v = acc[t][nb][j];
+            if (w) v += red[e];
+            red[e] = v;
+          }
+    }
+    __syncthreads();
+  }
+  float *dst = ws + ((int64_t)blockIdx.y * gridDim.x + tile) * (9 * 16 * CO_T);
+  for (int e = tid; e < 9 * 16 * CO_T; e += C2_THREADS) dst[e] = red[e];
+}
+
+// Stride-1 kernel: the three taps of one kernel row read the same 10-float window r[0..9] = in[p-1 .. p+8] of an input
+// row, so the window is split ONCE (hi/mid/lo) and the three operands are assembled from two packings of it: even pairs
+// E[i] = (r[2i], r[2i+1]) serve kx = 0 (E[0..3]) and kx = 2 (E[1..4]), odd pairs O[i] = (r[2i+1], r[2i+2]) serve
+// kx = 1 -- 77 VALU operations per row instead of 180.  Border masks are formed from the row-wrap position (no
+// per-pixel compares) and applied as bit masks on the packed operands, only in chunks where some lane needs them.
+// The 4 waves are added through two LDS regions in two phases ((w0 + w2) + (w1 + w3), fixed order).
+template <int NB>
+__global__ __launch_bounds__(C2_THREADS, NB == 2 ? 3 : 2) void k_conv2d_wgrad_s1(const float *__restrict__ in,
+                                                                               const float *__restrict__ dout,
+                                                                               Conv2dGeom gm, float invW,
+                                                                               float *__restrict__ ws) {
+  constexpr int CO_T = 16 * NB, LDW = CO_T + 4;
+  __shared__ __attribute__((aligned(16))) float red[2][9 * 16 * LDW];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int tile = blockIdx.x;
+  const int ct = tile / gm.n_cout_tiles, ot = tile - ct * gm.n_cout_tiles;
+  const int ci0 = ct * 16, co0 = ot * CO_T;
+  const int W = gm.W, H = gm.H, HW = H * W;
+  const int64_t in_total = (int64_t)gm.B * gm.cin * HW, out_total = (int64_t)gm.B * gm.cout * HW;
+  const int n_chunks = gm.B * gm.cpi;
+  const int c_begin = blockIdx.y * gm.chunks_per_slab;
+  const int c_end = min(c_begin + gm.chunks_per_slab, n_chunks);
+
+  f32x4 acc[9][NB];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[t][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int c = c_begin + wid; c < c_end; c += C2_WAVES) {
+    const int b = c / gm.cpi;
+    const int p = (c - b * gm.cpi) * 32 + 8 * g;          // this lane's first pixel in the plane
+    int y0 = (int)((float)p * invW);
+    int x0 = p - y0 * W;
+    if (x0 < 0) { x0 += W; --y0; }
+    if (x0 >= W) { x0 -= W; ++y0; }
+    const int wrap = W - x0;                              // element index of the first pixel of row y0 + 1 (>= 8: none)
+    const unsigned first = wrap >= 8 ? 0xffu : ((1u << wrap) - 1u);                  // pixels in row y0
+    const unsigned vp = p + 8 <= HW ? 0xffu : (p < HW ? ((1u << (HW - p)) - 1u) : 0u);
+    const unsigned nx0 = ~((x0 == 0 ? 1u : 0u) | (wrap < 8 ? (1u << wrap) : 0u));    // x >= 1
+    const unsigned nx2 = ~(wrap <= 8 ? (1u << (wrap - 1)) : 0u);                     // x <= W - 2
+    const unsigned vy0 = y0 >= 1 ? 0xffu : (~first & 0xffu);                         // y >= 1
+    const unsigned vy2 = (y0 <= H - 2 ? first : 0u) | (y0 <= H - 3 ? (~first & 0xffu) : 0u);   // y <= H - 2
+    const bool slow = __any((int)((vp & nx0 & nx2 & vy0 & vy2 & 0xffu) != 0xffu));
+
+    // dout operands of all NB cout blocks
+    u32x4 bh[NB], bm[NB], bl[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      float v[8];
+      load8(dout, ((int64_t)b * gm.cout + co0 + 16 * nb + li) * HW + p, out_total, vp, v);
+      const Split3 s = split_masked(v, slow ? vp : 0xffu);
+      bh[nb] = s.h; bm[nb] = s.m; bl[nb] = s.l;
+    }
+    const int64_t plane = ((int64_t)b * gm.cin + ci0 + li) * HW;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int64_t idx = plane + p + (ky - 1) * W;        // r[j] = in[idx - 1 + j]
+      float r[10];
+      if (idx >= 1 && idx + 9 <= in_total) {
+        const f32x4u a = *(const f32x4u *)(in + idx);
+        const f32x4u bq = *(const f32x4u *)(in + idx + 4);
+        r[0] = in[idx - 1];
+        r[1] = a.x; r[2] = a.y; r[3] = a.z; r[4] = a.w;
+        r[5] = bq.x; r[6] = bq.y; r[7] = bq.z; r[8] = bq.w;
+        r[9] = in[idx + 8];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 10; ++j) {
+          const int64_t q = idx - 1 + j;
+          r[j] = (q >= 0 && q < in_total) ? in[q] : 0.f;
+        }
+      }
+      unsigned hb[10], mb[10], lb[10];
+#pragma unroll
+      for (int j = 0; j < 10; ++j) {
+        hb[j] = __float_as_uint(r[j]) & 0xffff0000u;
+        const float r1 = r[j] - __uint_as_float(hb[j]);
+        mb[j] = __float_as_uint(r1) & 0xffff0000u;
+        lb[j] = __float_as_uint(r1 - __uint_as_float(mb[j]));
+      }
+      unsigned Eh[5], Em[5], El[5], Oh[4], Om[4], Ol[4];
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        Eh[i] = __builtin_amdgcn_perm(hb[2 * i + 1], hb[2 * i], 0x07060302u);
+        Em[i] = __builtin_amdgcn_perm(mb[2 * i + 1], mb[2 * i], 0x07060302u);
+        El[i] = __builtin_amdgcn_perm(lb[2 * i + 1], lb[2 * i], 0x07060302u);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        Oh[i] = __builtin_amdgcn_perm(hb[2 * i + 2], hb[2 * i + 1], 0x07060302u);
+        Om[i] = __builtin_amdgcn_perm(mb[2 * i + 2], mb[2 * i + 1], 0x07060302u);
+        Ol[i] = __builtin_amdgcn_perm(lb[2 * i + 2], lb[2 * i + 1], 0x07060302u);
+      }
+      const unsigned my = vp & (ky == 0 ? vy0 : (ky == 2 ? vy2 : 0xffu));
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        u32x4 ah, am, al;
+#pragma unroll
+        for (int pd = 0; pd < 4; ++pd) {
+          ah[pd] = kx == 0 ? Eh[pd] : (kx == 1 ? Oh[pd] : Eh[pd + 1]);
+          am[pd] = kx == 0 ? Em[pd] : (kx == 1 ? Om[pd] : Em[pd + 1]);
+          al[pd] = kx == 0 ? El[pd] : (kx == 1 ? Ol[pd] : El[pd + 1]);
+        }
+        if (slow) {
+          const unsigned m = my & (kx == 0 ? nx0 : (kx == 2 ? nx2 : 0xffu));
+#pragma unroll
+          for (int pd = 0; pd < 4; ++pd) {
+            const unsigned dm = ((0u - ((m >> (2 * pd)) & 1u)) & 0x0000ffffu) |
+                                ((0u - ((m >> (2 * pd + 1)) & 1u)) & 0xffff0000u);
+            ah[pd] &= dm; am[pd] &= dm; al[pd] &= dm;
+          }
+        }
+        const int t = ky * 3 + kx;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[t][nb] = MFMA_BF16(al, bh[nb], acc[t][nb]);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[t][nb] = MFMA_BF16(am, bm[nb], acc[t][nb]);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[t][nb] = MFMA_BF16(ah, bl[nb], acc[t][nb]);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[t][nb] = MFMA_BF16(am, bh[nb], acc[t][nb]);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[t][nb] = MFMA_BF16(ah, bm[nb], acc[t][nb]);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[t][nb] = MFMA_BF16(ah, bh[nb], acc[t][nb]);
+      }
+    }
+  }
+
+  // (w0 + w2) in region 0, (w1 + w3) in region 1, then region 0 + region 1 on the way out
+  float *my_red = red[wid & 1];
+#pragma unroll
+  for (int ph = 0; ph < 2; ++ph) {
+    if ((wid >> 1) == ph) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int e = (t * 16 + 4 * g + j) * LDW + 16 * nb + li;
+            float v = acc[t][nb][j];
+            if (ph) v = my_red[e] + v;
+            my_red[e] = v;
+          }
+    }
+    __syncthreads();
+  }
+  float *dst = ws + ((int64_t)blockIdx.y * gridDim.x + tile) * (9 * 16 * CO_T);
+  for (int e = tid; e < 9 * 16 * CO_T; e += C2_THREADS) {
+    const int row = e / CO_T, co = e - row * CO_T;
+    dst[e] = red[0][row * LDW + co] + red[1][row * LDW + co];
+  }
+}
+
+// 32 (tile, tap, ci, co) elements x 8 slab groups per block: group sg adds slabs sg, sg+8, ... in order, the 8 group sums
+// are added in group order (fixed summation order); writes dW in OIHW
+__global__ __launch_bounds__(256) void k_conv2d_wgrad_reduce(const float *__restrict__ ws, int n_slabs, int n_tiles,
+                                                             int n_cout_tiles, int co_t, int cin, int cout,
+                                                             float *__restrict__ dW) {
+  __shared__ float part[8][32];
+  const int per_tile = 9 * 16 * co_t;
+  const int64_t n = (int64_t)n_tiles * per_tile;
+  const int se = threadIdx.x & 31, sg = threadIdx.x >> 5;
+  const int64_t e = (int64_t)blockIdx.x * 32 + se;
+  float s = 0.f;
+  if (e < n) {
+    int sl = sg;
+    for (; sl + 24 < n_slabs; sl += 32) {
+      const float a0 = ws[(int64_t)(sl + 0) * n + e], a1 = ws[(int64_t)(sl + 8) * n + e];
+      const float a2 = ws[(int64_t)(sl + 16) * n + e], a3 = ws[(int64_t)(sl + 24) * n + e];
+      s += a0; s += a1; s += a2; s += a3;
+    }
+    for (; sl < n_slabs; sl += 8) s += ws[(int64_t)sl * n + e];
+  }
+  part[sg][se] = s;
+  __syncthreads();
+  if (sg != 0 || e >= n) return;
+  float t8 = part[0][se];
+#pragma unroll
+  for (int q = 1; q < 8; ++q) t8 += part[q][se];
+  const int tile = (int)(e / per_tile), r = (int)(e - (int64_t)tile * per_tile);
+  const int t = r / (16 * co_t), r2 = r - t * 16 * co_t;
+  const int ci = r2 / co_t, co = r2 - ci * co_t;
+  const int ct = tile / n_cout_tiles, ot = tile - ct * n_cout_tiles;
+  dW[((int64_t)(ot * co_t + co) * cin + ct * 16 + ci) * 9 + t] = t8;
+}
+
+static int conv2d_plan(int B, int cin, int cout, int H, int W, int stride, Conv2dGeom *gm, int *nb, int *n_slabs) {
+  if (!(stride == 1 || stride == 2) || B <= 0 || H <= 0 || W < 8 || cin % 16 != 0 || cout % 32 != 0) return 0;
+  // measured (scripts/bench_conv2d_wgrad.py): the stride-2 kernel re-reads a 15-float window per tap and loses to the
+  // library on the full-resolution map (256->128 at 96x176: 170-210 us vs 131 us); smaller maps win (35-42 vs 49-57 us)
+  if (stride == 2 && (int64_t)H * W >= 96 * 176) return 0;
+  static int nb_pref = -1;
+  if (nb_pref < 0) {
+    const char *e = getenv("RSLO_CONV2D_NB");
+    nb_pref = e ? atoi(e) : 2;
+  }
+  *nb = (cout % 64 == 0 && nb_pref == 4) ? 4 : 2;
+  gm->B = B; gm->cin = cin; gm->cout = cout;
+  gm->Hin = H; gm->Win = W;
+  gm->H = stride == 1 ? H : (H - 1) / 2 + 1;          // (H + 2 - 3) / S + 1
+  gm->W = stride == 1 ? W : (W - 1) / 2 + 1;
+  if (gm->W < 8) return 0;
+  gm->cpi = (int)rslo_cdiv((int64_t)gm->H * gm->W, 32);
+  gm->n_cin_tiles = cin / 16;
+  gm->n_cout_tiles = cout / (16 * *nb);
+  const int tiles = gm->n_cin_tiles * gm->n_cout_tiles;
+  const int n_chunks = B * gm->cpi;
+  static int target = -1;
+  if (target < 0) {
+    const char *e = getenv("RSLO_CONV2D_WGS");
+    target = e ? atoi(e) : 768;
+    if (target < 1) target = 768;
+  }
+  int s = (int)rslo_cdiv(target, tiles);
+  const int max_s = n_chunks / 8 > 0 ? n_chunks / 8 : 1;   // at least 2 chunks per wave
+  if (s > max_s) s = max_s;
+  if (s < 1) s = 1;
+  gm->chunks_per_slab = (int)rslo_cdiv(n_chunks, s);
+  *n_slabs = (int)rslo_cdiv(n_chunks, gm->chunks_per_slab);
+  return 1;
+}
+
+extern "C" int rslo_conv2d_wgrad_supported(int cin, int cout, int H, int W, int stride) {
+  Conv2dGeom gm;
+  int nb, ns;
+  return conv2d_plan(1, cin, cout, H, W, stride, &gm, &nb, &ns);
+}
+
+extern "C" size_t rslo_conv2d_wgrad_ws_bytes(int B, int cin, int cout, int H, int W, int stride) {
+  Conv2dGeom gm;
+  int nb, ns;
+  if (!conv2d_plan(B, cin, cout, H, W, stride, &gm, &nb, &ns)) return 0;
+  return (size_t)ns * gm.n_cin_tiles * gm.n_cout_tiles * 9 * 16 * 16 * nb * sizeof(float);
+}
+
+extern "C" int rslo_conv2d_wgrad(const float *in, const float *dout, int B, int cin, int cout, int H, int W,
+                                 int stride, float *dW, void *ws, size_t ws_bytes, void *stream) {
+  Conv2dGeom gm;
+  int nb, ns;
+  RSLO_CHECK_ARG(conv2d_plan(B, cin, cout, H, W, stride, &gm, &nb, &ns),
+                 "rslo_conv2d_wgrad: unsupported shape cin=%d cout=%d H=%d W=%d stride=%d", cin, cout, H, W, stride);
+  RSLO_CHECK_ARG(ws_bytes >= rslo_conv2d_wgrad_ws_bytes(B, cin, cout, H, W, stride), "rslo_conv2d_wgrad: workspace too small");
+  RSLO_CHECK_ARG((int64_t)B * cin * H * W < (int64_t(1) << 40), "rslo_conv2d_wgrad: tensor too large");
+  hipStream_t st = (hipStream_t)stream;
+  const int tiles = gm.n_cin_tiles * gm.n_cout_tiles;
+  const dim3 grid(tiles, ns);
+#define C2_LAUNCH(NBv, Sv) \
+  hipLaunchKernelGGL((k_conv2d_wgrad<NBv, Sv>), grid, dim3(C2_THREADS), 0, st, in, dout, gm, (float *)ws)
+  static int diag = -1;
+  if (diag < 0) {
+    const char *e = getenv("RSLO_CONV2D_DIAG");
+    diag = e ? atoi(e) : 0;
+  }
+  if (diag == 1 && nb == 4 && stride == 1)
+    hipLaunchKernelGGL((k_conv2d_wgrad<4, 1, 1>), grid, dim3(C2_THREADS), 0, st, in, dout, gm, (float *)ws);
+  else if (diag == 2 && nb == 4 && stride == 1)
+    hipLaunchKernelGGL((k_conv2d_wgrad<4, 1, 2>), grid, dim3(C2_THREADS), 0, st, in, dout, gm, (float *)ws);
+  else if (stride == 1 && diag != 3) {
+    const float invW = 1.0f / (float)gm.W;
+    if (nb == 4)
+      hipLaunchKernelGGL((k_conv2d_wgrad_s1<4>), grid, dim3(C2_THREADS), 0, st, in, dout, gm, invW, (float *)ws);
+    else
+      hipLaunchKernelGGL((k_conv2d_wgrad_s1<2>), grid, dim3(C2_THREADS), 0, st, in, dout, gm, invW, (float *)ws);
+  } else if (nb == 4 && stride == 1) C2_LAUNCH(4, 1);
+  else if (nb == 4) C2_LAUNCH(4, 2);
+  else if (stride == 1) C2_LAUNCH(2, 1);
+  else C2_LAUNCH(2, 2);
+#undef C2_LAUNCH
+  RSLO_CHECK_LAUNCH("k_conv2d_wgrad");
+  const int64_t n = (int64_t)tiles * 9 * 16 * 16 * nb;
+  hipLaunchKernelGGL(k_conv2d_wgrad_reduce, dim3((unsigned)rslo_cdiv(n, 32)), dim3(256), 0, st, (const float *)ws, ns,
+                     tiles, gm.n_cout_tiles, 16 * nb, cin, cout, dW);
+  RSLO_CHECK_LAUNCH("k_conv2d_wgrad_reduce");
+  return RSLO_OK;
+}

@@ -4,6 +4,8 @@ only propagated (max-pooled with the conv's geometry) for later use.  Dense conv
 import torch
 import torch.nn as nn
 
+from rslo.layers.hip_conv2d import Conv2d
+
 
 class MaskMaxPool2d(nn.MaxPool2d):
     def forward(self, x):
@@ -19,7 +21,7 @@ class MaskConv(nn.Module):
         assert max_pool_mask, "conv-propagated masks are not used by the RSLO hot path"
         self.out_channels = out_channels
         self.use_bias = bias
-        self.conv1 = nn.Conv2d(in_channels, out_channels, kernel_size=kernel_size, stride=stride, bias=False,
+        self.conv1 = Conv2d(in_channels, out_channels, kernel_size=kernel_size, stride=stride, bias=False,
                                padding=padding, groups=groups)
         self.max_pool_mask = True
         self.mask_pool = nn.MaxPool2d(kernel_size, stride=stride, padding=padding)

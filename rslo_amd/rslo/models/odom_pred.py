@@ -16,6 +16,7 @@ import numpy as np
 
 from rslo.data.dataset import _grid_geometry, from_pointwise_local_transformation_tch
 from rslo.layers.confidence import ConfidenceModule, masked_spatial_softmax
+from rslo.layers.hip_conv2d import Conv2d
 from rslo.layers.MaskConv import MaskConv
 from rslo.models.odom_pred_base import OdomPredEncDecBase, conf_trunk
 from rslo.utils.pose_utils import rotate_vec_by_q
@@ -66,9 +67,9 @@ class UNOdomPredEncDecSVDTempMaskBase(OdomPredEncDecBase):
         if self.pred_pyramid_motion:
             for c in nuf:
                 motion.append(FusedSequential(
-                    nn.Conv2d(c, c // 2, kernel_size=3, stride=1, padding=1), self.BatchNorm2d(c // 2), self.ReLU(),
-                    nn.Conv2d(c // 2, 64, kernel_size=3, stride=1, padding=1), self.BatchNorm2d(64), self.ReLU(),
-                    nn.Conv2d(64, 7, 1, stride=1)))
+                    Conv2d(c, c // 2, kernel_size=3, stride=1, padding=1), self.BatchNorm2d(c // 2), self.ReLU(),
+                    Conv2d(c // 2, 64, kernel_size=3, stride=1, padding=1), self.BatchNorm2d(64), self.ReLU(),
+                    Conv2d(64, 7, 1, stride=1)))
                 tconf.append(ConfidenceModule(conf_trunk(c, self.BatchNorm2d, self.ReLU), conf_type=conf_type))
                 qconf.append(ConfidenceModule(conf_trunk(c, self.BatchNorm2d, self.ReLU), conf_type=conf_type))
         self.pyramid_motion_blocks = nn.ModuleList(motion)

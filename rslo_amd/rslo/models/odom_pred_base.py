@@ -11,6 +11,7 @@ from torch import nn
 
 from rslo.layers.common import ParameterLayer
 from rslo.layers.confidence import ConfidenceModule
+from rslo.layers.hip_conv2d import Conv2d
 from rslo.layers.MaskConv import MaskConv, MaskConvTranspose2d
 from rslo.layers.SparseConv import SPC_BN2d, SPC_LeakyReLU, SPC_ReLU, SPC_SyncBN2d, FusedSequential
 from torchplus.nn import Empty
@@ -19,9 +20,9 @@ from torchplus.tools import change_default_args
 
 def conf_trunk(cin, BatchNorm2d, ReLU):
     """64 -> 64 -> 32 -> 1 confidence trunk (odom_pred_base.py:250-276)."""
-    return FusedSequential(nn.Conv2d(cin, 64, kernel_size=3, padding=1), BatchNorm2d(64), ReLU(),
-                         nn.Conv2d(64, 32, kernel_size=3, padding=1), BatchNorm2d(32), ReLU(),
-                         nn.Conv2d(32, 1, kernel_size=1))
+    return FusedSequential(Conv2d(cin, 64, kernel_size=3, padding=1), BatchNorm2d(64), ReLU(),
+                         Conv2d(64, 32, kernel_size=3, padding=1), BatchNorm2d(32), ReLU(),
+                         Conv2d(32, 1, kernel_size=1))
 
 
 class OdomPredEncDecBase(nn.Module):
@@ -85,12 +86,12 @@ class OdomPredEncDecBase(nn.Module):
                                               use_norm=self._enc_use_norm)
             blocks.append(block)
             if i - self._upsample_start_idx >= 0:
-                skip_blocks.append(FusedSequential(nn.Conv2d(num_out, num_out, kernel_size=3, stride=1, padding=1),
+                skip_blocks.append(FusedSequential(Conv2d(num_out, num_out, kernel_size=3, stride=1, padding=1),
                                                  self.BatchNorm2d(num_out), self.ReLU()))
         for i, nuf in enumerate(num_upsample_filters):
             cin = num_filters[-1] * 2 if i == 0 else num_upsample_filters[i - 1] + num_filters[-(i + 1)]
             deblocks.append(FusedSequential(nn.Upsample(scale_factor=upsample_strides[i]),
-                                          nn.Conv2d(cin, nuf, kernel_size=3, stride=1, padding=1),
+                                          Conv2d(cin, nuf, kernel_size=3, stride=1, padding=1),
                                           self.BatchNorm2d(nuf), self.ReLU()))
         if self.pred_pyramid_motion:
             self.mask_gen_pools = nn.ModuleList(
@@ -104,9 +105,9 @@ class OdomPredEncDecBase(nn.Module):
         self.pyramid_motion_blocks = nn.ModuleList()
 
         last = num_upsample_filters[-1]
-        self.tq_map_conv = FusedSequential(nn.Conv2d(last, 64, kernel_size=3, padding=1), self.BatchNorm2d(64),
-                                         self.ReLU(), nn.Conv2d(64, 32, kernel_size=3, padding=1),
-                                         self.BatchNorm2d(32), self.ReLU(), nn.Conv2d(32, 7, kernel_size=1))
+        self.tq_map_conv = FusedSequential(Conv2d(last, 64, kernel_size=3, padding=1), self.BatchNorm2d(64),
+                                         self.ReLU(), Conv2d(64, 32, kernel_size=3, padding=1),
+                                         self.BatchNorm2d(32), self.ReLU(), Conv2d(32, 7, kernel_size=1))
         self.q_map_conf = ConfidenceModule(conf_trunk(last, self.BatchNorm2d, self.ReLU), conf_type=conf_type)
         self.t_map_conf = ConfidenceModule(conf_trunk(last, self.BatchNorm2d, self.ReLU), conf_type=conf_type)
 

@@ -592,3 +592,55 @@ def test_pose_algebra_kernels_match_kornia_restatement(hip):
     rd, td = losses.icp_pose_targets(res_r.cuda(), res_t.cuda(), Rp.cuda(), Tp.cuda())
     assert float((td.cpu() - tc).abs().max()) < 1e-5
     assert float((rd.cpu() - rc).abs().max()) < 2e-5
+
+
+# ------------------------------------------------------------------------------- dense conv2d weight gradient (BEV head)
+@pytest.mark.parametrize("B,cin,cout,H,W,stride", [
+    (2, 32, 64, 12, 22, 1),      # plane of 264 pixels: ragged last 32-pixel chunk
+    (1, 16, 32, 24, 44, 1),      # 32-wide cout block
+    (3, 48, 64, 25, 23, 1),      # odd sizes, rows wrap inside a lane's 8 pixels
+    (2, 48, 64, 25, 23, 2),      # stride 2, odd input
+    (2, 32, 128, 24, 44, 2),     # stride 2, even input (last input column / row never read by kx = ky = 2 ... by the pad)
+    (1, 64, 64, 96, 176, 1),     # full-resolution BEV map
+])
+def test_conv2d_wgrad_matches_float64_oracle(hip, B, cin, cout, H, W, stride):
+    """fp32 tolerance: |err| <= 2e-5 * max|dW| against the float64 restatement (the split-bf16 products are exact to
+    2^-24 relative per term; the rest is fp32 accumulation over B*H*W terms); torch's own fp32 result must be no
+    closer than 4x."""
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((B, cin, H, W)).astype(np.float32)
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    g = rng.standard_normal((B, cout, Ho, Wo)).astype(np.float32)
+    assert hip.conv2d_wgrad_supported(cin, cout, H, W, stride)
+    got = hip.conv2d_wgrad(dev(x), dev(g), stride).cpu().numpy().astype(np.float64)
+    ref = O.conv2d_wgrad(x, g, stride)
+    scale = np.abs(ref).max()
+    err = np.abs(got - ref).max()
+    assert err <= 2e-5 * scale, (err, scale)
+    tw = torch.zeros((cout, cin, 3, 3), device="cuda", requires_grad=True)
+    torch.nn.functional.conv2d(dev(x), tw, None, stride, 1).backward(dev(g))
+    err_lib = np.abs(tw.grad.cpu().numpy().astype(np.float64) - ref).max()
+    assert err <= 4 * err_lib + 1e-6 * scale, (err, err_lib)
+    # bit-reproducible (fixed summation order)
+    again = hip.conv2d_wgrad(dev(x), dev(g), stride).cpu().numpy().astype(np.float64)
+    assert np.array_equal(got, again)
+
+
+def test_hip_conv2d_module_gradients_match_library(hip):
+    from rslo.layers.hip_conv2d import Conv2d
+    torch.manual_seed(5)
+    for stride, bias in [(1, True), (2, False)]:
+        m = Conv2d(32, 64, 3, stride=stride, padding=1, bias=bias).cuda()
+        x = torch.randn(2, 32, 24, 44, device="cuda", requires_grad=True)
+        y = m(x)
+        gy = torch.randn_like(y)
+        y.backward(gy)
+        got = [x.grad.clone(), m.weight.grad.clone()] + ([m.bias.grad.clone()] if bias else [])
+        x.grad = None; m.zero_grad()
+        m.hip_wgrad = False
+        y2 = m(x)
+        y2.backward(gy)
+        ref = [x.grad, m.weight.grad] + ([m.bias.grad] if bias else [])
+        assert torch.equal(y, y2)
+        for a, b in zip(got, ref):
+            assert torch.allclose(a, b, rtol=1e-4, atol=1e-4 * float(b.abs().max()))

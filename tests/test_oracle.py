@@ -228,3 +228,16 @@ def test_chamfer_vs_cdist_and_tie_break():
     c2 = np.repeat(c[:, :10], 3, axis=1)  # duplicated targets: lowest index must win
     d2, i2 = O.chamfer_nn(a, c2)
     assert (i2 % 3 == 0).all()
+
+
+@pytest.mark.parametrize("stride,H,W", [(1, 7, 9), (2, 7, 9), (2, 8, 10)])
+def test_dense_conv2d_wgrad_restatement_matches_autograd(stride, H, W):
+    """The numpy restatement of the BEV head's Conv2d weight gradient vs torch's own autograd (float64)."""
+    import torch
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((2, 5, H, W))
+    w = torch.zeros((4, 5, 3, 3), dtype=torch.float64, requires_grad=True)
+    y = torch.nn.functional.conv2d(torch.from_numpy(x), w, None, stride, 1)
+    g = rng.standard_normal(tuple(y.shape))
+    y.backward(torch.from_numpy(g))
+    np.testing.assert_allclose(O.conv2d_wgrad(x, g, stride), w.grad.numpy(), rtol=1e-12, atol=1e-12)
