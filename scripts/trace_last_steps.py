@@ -55,6 +55,12 @@ for k, v in sorted(cats.items(), key=lambda kv: -kv[1]):
 lines.append("## top kernels: calls/step, total ms/step, avg us")
 for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:60]:
     lines.append("%6.1f %9.3f %10.1f  %s" % (c / n_steps, t / 1e6 / n_steps, t / c / 1e3, n[:150]))
+import os
+detail = os.environ.get("DETAIL")        # e.g. DETAIL=miopenSp3AsmConv: every call's duration (us) in launch order
+if detail:
+    for key in detail.split(","):
+        d = [(e - s_) / 1e3 for s_, e, n in sel if key in n]
+        lines.append("## calls of *%s* in launch order (us): %s" % (key, " ".join("%.0f" % v for v in d)))
 txt = "\n".join(lines)
 print(txt)
 if out:
