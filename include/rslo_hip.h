@@ -348,6 +348,28 @@ RSLO_API size_t rslo_conv2d_wgrad_ws_bytes(int B, int cin, int cout, int H, int 
 RSLO_API int rslo_conv2d_wgrad(const float *in, const float *dout, int B, int cin, int cout, int H, int W, int stride,
                                float *dW, void *ws, size_t ws_bytes, void *stream);
 
+/* a10 - a12  forward and data gradient of the same layers (3x3, stride 1, padding 1, NCHW fp32; channels % 32 == 0):
+ *      out[b][m] = bias[m] + sum_k A[m][k] (*) in[b][k].  rslo_conv2d_wsplit turns the layer's weight W [cout,cin,3,3]
+ *      into split-bf16 MFMA operands: transpose = 0 for the forward pass (m = cout, k = cin), transpose = 1 for the
+ *      data gradient (m = cin, k = cout, taps flipped; pass dout as `in`).  rslo_conv2d_fwd's cin / cout are the
+ *      contraction / produced channel counts of THAT call.  bias may be NULL. */
+RSLO_API int rslo_conv2d_fwd_supported(int cin, int cout, int H, int W);
+RSLO_API size_t rslo_conv2d_wsplit_bytes(int cin, int cout);
+RSLO_API int rslo_conv2d_wsplit(const float *W, int cin, int cout, int transpose, void *Ws, void *stream);
+/*      rslo_conv2d_wsplit_many: the same split for all layers of a model, both orientations, in ONE launch (the weights
+ *      are constant between optimizer steps): desc_dev = device array of n_layers descriptors, max_weight_elems =
+ *      max over layers of cin * cout * 9. */
+typedef struct {
+  const float *W;   /* [cout,cin,3,3] */
+  void *ws_fwd;     /* rslo_conv2d_wsplit_bytes(cin, cout) bytes, transpose = 0 */
+  void *ws_dgrad;   /* same size, transpose = 1 */
+  int32_t cin, cout;
+} RsloConv2dSplitDesc;
+RSLO_API int rslo_conv2d_wsplit_many(const RsloConv2dSplitDesc *desc_dev, int n_layers, int64_t max_weight_elems,
+                                     void *stream);
+RSLO_API int rslo_conv2d_fwd(const float *in, const void *Ws, const float *bias, int B, int cin, int cout, int H, int W,
+                             float *out, void *stream);
+
 /* a16 / a20  per-pair pose algebra of the loss assembly (one thread per frame pair):
  *      rslo_quat_to_rot: q (w,x,y,z) -> R [B,9] with kornia 0.4.0 semantics (normalise with eps 1e-12 first;
  *      rslo/models/voxel_odom_net.py:675) and its backward;  rslo_pose_targets: pseudo-targets of the ICP refinement

@@ -214,3 +214,34 @@ def conv2d_wgrad(x, dout, stride=1):
             win = xp[:, :, ky:ky + stride * (Ho - 1) + 1:stride, kx:kx + stride * (Wo - 1) + 1:stride]
             dW[:, :, ky, kx] = np.einsum("boyx,biyx->oi", g, win, optimize=True)
     return dW
+
+
+def conv2d_fwd(x, w, bias=None):
+    """Dense 3x3 / stride-1 / padding-1 Conv2d forward (cross-correlation, zero padding; torch.nn.Conv2d as built in
+    rslo/models/odom_pred.py:65-134), float64.  x [B,Cin,H,W], w [Cout,Cin,3,3] -> [B,Cout,H,W]."""
+    x = np.asarray(x, np.float64)
+    w = np.asarray(w, np.float64)
+    B, Cin, H, W = x.shape
+    xp = np.zeros((B, Cin, H + 2, W + 2))
+    xp[:, :, 1:H + 1, 1:W + 1] = x
+    out = np.zeros((B, w.shape[0], H, W))
+    for ky in range(3):
+        for kx in range(3):
+            out += np.einsum("oi,biyx->boyx", w[:, :, ky, kx], xp[:, :, ky:ky + H, kx:kx + W], optimize=True)
+    if bias is not None:
+        out += np.asarray(bias, np.float64)[None, :, None, None]
+    return out
+
+
+def conv2d_dgrad(dout, w):
+    """Data gradient of the same layer: dx[b,i,y,x] = sum_{o,ky,kx} dout[b,o,y-ky+1,x-kx+1] w[o,i,ky,kx], float64."""
+    g = np.asarray(dout, np.float64)
+    w = np.asarray(w, np.float64)
+    B, Cout, H, W = g.shape
+    gp = np.zeros((B, Cout, H + 2, W + 2))
+    gp[:, :, 1:H + 1, 1:W + 1] = g
+    dx = np.zeros((B, w.shape[1], H, W))
+    for ky in range(3):
+        for kx in range(3):
+            dx += np.einsum("oi,boyx->biyx", w[:, :, ky, kx], gp[:, :, 2 - ky:2 - ky + H, 2 - kx:2 - kx + W], optimize=True)
+    return dx

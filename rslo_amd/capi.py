@@ -87,6 +87,11 @@ SIGNATURES = {
     "rslo_conv2d_wgrad_supported": (C.c_int, [_i, _i, _i, _i, _i]),
     "rslo_conv2d_wgrad_ws_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "rslo_conv2d_wgrad": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "rslo_conv2d_fwd_supported": (C.c_int, [_i, _i, _i, _i]),
+    "rslo_conv2d_wsplit_bytes": (_sz, [_i, _i]),
+    "rslo_conv2d_wsplit": (C.c_int, [_vp, _i, _i, _i, _vp, _vp]),
+    "rslo_conv2d_wsplit_many": (C.c_int, [_vp, _i, _i64, _vp]),
+    "rslo_conv2d_fwd": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "rslo_quat_to_rot": (C.c_int, [_vp, _i, _vp, _vp]),
     "rslo_quat_to_rot_bwd": (C.c_int, [_vp, _vp, _i, _vp, _vp]),
     "rslo_pose_targets": (C.c_int, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
@@ -808,6 +813,57 @@ def conv2d_wgrad(x, dout, stride=1):
     _chk(lib().rslo_conv2d_wgrad(_ptr(x, torch.float32, "x"), _ptr(dout, torch.float32, "dout"), B, cin, cout, H, W,
                                  stride, _ptr(dW), _ptr(ws), wsb, _stream()), "rslo_conv2d_wgrad")
     return dW
+
+
+def conv2d_fwd_supported(cin, cout, H, W):
+    return bool(lib().rslo_conv2d_fwd_supported(int(cin), int(cout), int(H), int(W)))
+
+
+def conv2d_wsplit(w, transpose=False):
+    """w [cout,cin,3,3] fp32 -> split-bf16 MFMA operands (int16 tensor) for conv2d_fwd; transpose=True: data gradient."""
+    cout, cin = w.shape[0], w.shape[1]
+    ws = torch.empty((lib().rslo_conv2d_wsplit_bytes(cin, cout) // 2,), dtype=torch.int16, device=w.device)
+    _chk(lib().rslo_conv2d_wsplit(_ptr(w, torch.float32, "w"), cin, cout, 1 if transpose else 0, _ptr(ws), _stream()),
+         "rslo_conv2d_wsplit")
+    return ws
+
+
+class Conv2dSplitDesc(C.Structure):
+    _fields_ = [("W", C.c_void_p), ("ws_fwd", C.c_void_p), ("ws_dgrad", C.c_void_p), ("cin", C.c_int32),
+                ("cout", C.c_int32)]
+
+
+def conv2d_wsplit_many(weights):
+    """weights: list of [cout,cin,3,3] fp32 CUDA tensors.  Returns (plan, [(ws_fwd, ws_dgrad) per layer]); call
+    conv2d_wsplit_run(plan) after every weight update: it refreshes all operands in one launch."""
+    dev = weights[0].device
+    sizes = [lib().rslo_conv2d_wsplit_bytes(w.shape[1], w.shape[0]) // 2 for w in weights]
+    pool = torch.empty((2 * sum(sizes),), dtype=torch.int16, device=dev)
+    views, off = [], 0
+    arr = (Conv2dSplitDesc * len(weights))()
+    for i, (w, n) in enumerate(zip(weights, sizes)):
+        f, t = pool[off:off + n], pool[off + n:off + 2 * n]
+        off += 2 * n
+        views.append((f, t))
+        arr[i] = Conv2dSplitDesc(_ptr(w, torch.float32, "w").value, f.data_ptr(), t.data_ptr(), w.shape[1], w.shape[0])
+    host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+    table = host.to(dev)
+    plan = {"table": table, "n": len(weights), "max": max(int(w.numel()) for w in weights), "pool": pool,
+            "ptrs": [w.data_ptr() for w in weights]}
+    return plan, views
+
+
+def conv2d_wsplit_run(plan):
+    _chk(lib().rslo_conv2d_wsplit_many(_ptr(plan["table"]), plan["n"], plan["max"], _stream()), "rslo_conv2d_wsplit_many")
+
+
+def conv2d_fwd(x, ws, bias, cout):
+    """x [B,cin,H,W] contiguous fp32, ws from conv2d_wsplit -> [B,cout,H,W] (3x3, stride 1, padding 1)."""
+    B, cin, H, W = x.shape
+    out = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device)
+    _chk(lib().rslo_conv2d_fwd(_ptr(x, torch.float32, "x"), _ptr(ws), _ptr(bias, torch.float32, "bias") if bias is not None
+                               else None, B, cin, cout, H, W, _ptr(out), _stream()), "rslo_conv2d_fwd")
+    return out
 
 
 # --------------------------------------------------------------------------------------

@@ -91,7 +91,7 @@ struct Conv2dGeom {
 };
 
 // grid (n_cin_tiles * n_cout_tiles, n_slabs); ws [slab][tile][9][16][16 NB]
-template <int NB, int STRIDE, int DIAG = 0>
+template <int NB, int STRIDE>
 __global__ __launch_bounds__(C2_THREADS, 2) void k_conv2d_wgrad(const float *__restrict__ in,
                                                              const float *__restrict__ dout, Conv2dGeom gm,
                                                              float *__restrict__ ws) {
@@ -152,10 +152,7 @@ __global__ __launch_bounds__(C2_THREADS, 2) void k_conv2d_wgrad(const float *__r
         if (kx == 0) mask &= vx0;
         if (kx == 2) mask &= vx2;
         float v[8];
-        if (DIAG == 1) {                                   // timing experiment: no input loads
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = __int_as_float(0x3f800000 + (lane << 8) + e + c);
-        } else if (STRIDE == 1) {
+        if (STRIDE == 1) {
           load8(in, plane + p + (ky - 1) * gm.Win + (kx - 1), in_total, mask, v);
         } else {
           // the 8 output pixels may wrap to the next output row: input index is not affine across the wrap
@@ -172,11 +169,6 @@ __global__ __launch_bounds__(C2_THREADS, 2) void k_conv2d_wgrad(const float *__r
         }
         const Split3 a = split_masked(v, mask);
         const int t = ky * 3 + kx;
-        if (DIAG == 2) {                                   // timing experiment: no matrix-core work
-#pragma unroll
-          for (int nb = 0; nb < NB; ++nb) acc[t][nb][0] += __uint_as_float(a.l[nb] ^ a.m[nb] ^ a.h[nb] ^ bh[nb][0] ^ bm[nb][1] ^ bl[nb][2]);
-          continue;
-        }
         // six products per block, smallest first; consecutive MFMAs hit different accumulators
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) acc[t][nb] = MFMA_BF16(a.l, bh[nb], acc[t][nb]);
@@ -467,24 +459,13 @@ extern "C" int rslo_conv2d_wgrad(const float *in, const float *dout, int B, int 
   const dim3 grid(tiles, ns);
 #define C2_LAUNCH(NBv, Sv) \
   hipLaunchKernelGGL((k_conv2d_wgrad<NBv, Sv>), grid, dim3(C2_THREADS), 0, st, in, dout, gm, (float *)ws)
-  static int diag = -1;
-  if (diag < 0) {
-    const char *e = getenv("RSLO_CONV2D_DIAG");
-    diag = e ? atoi(e) : 0;
-  }
-  if (diag == 1 && nb == 4 && stride == 1)
-    hipLaunchKernelGGL((k_conv2d_wgrad<4, 1, 1>), grid, dim3(C2_THREADS), 0, st, in, dout, gm, (float *)ws);
-  else if (diag == 2 && nb == 4 && stride == 1)
-    hipLaunchKernelGGL((k_conv2d_wgrad<4, 1, 2>), grid, dim3(C2_THREADS), 0, st, in, dout, gm, (float *)ws);
-  else if (stride == 1 && diag != 3) {
+  if (stride == 1) {
     const float invW = 1.0f / (float)gm.W;
     if (nb == 4)
       hipLaunchKernelGGL((k_conv2d_wgrad_s1<4>), grid, dim3(C2_THREADS), 0, st, in, dout, gm, invW, (float *)ws);
     else
       hipLaunchKernelGGL((k_conv2d_wgrad_s1<2>), grid, dim3(C2_THREADS), 0, st, in, dout, gm, invW, (float *)ws);
-  } else if (nb == 4 && stride == 1) C2_LAUNCH(4, 1);
-  else if (nb == 4) C2_LAUNCH(4, 2);
-  else if (stride == 1) C2_LAUNCH(2, 1);
+  } else if (nb == 4) C2_LAUNCH(4, 2);
   else C2_LAUNCH(2, 2);
 #undef C2_LAUNCH
   RSLO_CHECK_LAUNCH("k_conv2d_wgrad");
@@ -492,5 +473,276 @@ extern "C" int rslo_conv2d_wgrad(const float *in, const float *dout, int B, int 
   hipLaunchKernelGGL(k_conv2d_wgrad_reduce, dim3((unsigned)rslo_cdiv(n, 32)), dim3(256), 0, st, (const float *)ws, ns,
                      tiles, gm.n_cout_tiles, 16 * nb, cin, cout, dW);
   RSLO_CHECK_LAUNCH("k_conv2d_wgrad_reduce");
+  return RSLO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Forward / data gradient of the dense 3x3, stride-1, padding-1 convolution (NCHW fp32), same split-bf16 arithmetic.
+//
+//   out[b][m][y][x] = bias[m] + sum_{k, ky, kx} A[m][k][ky][kx] * in[b][k][y + ky - 1][x + kx - 1]
+//
+// forward: A = W (m = cout, k = cin); data gradient: A[m = cin][k = cout][ky][kx] = W[k][m][2 - ky][2 - kx], in = dout.
+// The contraction index of the MFMA runs over 32 input channels, which are strided in NCHW, so a workgroup stages the
+// halo tile ((TR + 2) x 18 pixels x 32 channels) ONCE per channel chunk through LDS: each thread loads the 8 channels
+// of one pixel (lanes along x: coalesced), splits them into hi / mid / lo bf16 and writes three 16-byte pixel-major
+// rows; all 9 taps then read their B operands (pixel = column, 8 channels per lane) with one ds_read_b128 per plane at
+// a shifted pixel address -- every input value is split once per workgroup instead of once per tap.  A operands
+// (weights) are split beforehand by k_conv2d_wsplit into the exact MFMA fragment order (16 bytes per lane and plane).
+// Workgroup = 4 waves as 2 (output-channel halves) x 2 (row halves); out tile = 32 MTW channels x TR x 16 pixels.
+// ---------------------------------------------------------------------------------------------------------------------
+#define C2F_PXB 208      // bytes per staged pixel: 3 planes x 32 channels x 2 B + 16 B pad (conflict-free b128 reads)
+
+// Ws [cin_k / 32][9][n_m / 16][3][64][8] bf16 from W [cout][cin][3][3]; transpose = 0: m = cout, k = cin (forward);
+// transpose = 1: m = cin, k = cout, taps flipped (data gradient)
+__global__ void k_conv2d_wsplit(const float *__restrict__ W, int cin, int cout, int transpose,
+                                unsigned short *__restrict__ Ws) {
+  const int n_m = transpose ? cin : cout, n_k = transpose ? cout : cin;
+  const int n_mt = n_m / 16;
+  const int64_t n = (int64_t)n_k * 9 * n_m;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int e = (int)(i & 7), lane = (int)((i >> 3) & 63);
+  int64_t r = i >> 9;
+  const int mt = (int)(r % n_mt); r /= n_mt;
+  const int tap = (int)(r % 9);
+  const int chunk = (int)(r / 9);
+  const int m = mt * 16 + (lane & 15), k = chunk * 32 + 8 * (lane >> 4) + e;
+  const float x = transpose ? W[((int64_t)k * cin + m) * 9 + (8 - tap)] : W[((int64_t)m * cin + k) * 9 + tap];
+  const unsigned hb = __float_as_uint(x) & 0xffff0000u;
+  const float r1 = x - __uint_as_float(hb);
+  const unsigned mb = __float_as_uint(r1) & 0xffff0000u;
+  const float r2 = r1 - __uint_as_float(mb);
+  const int64_t base = ((((int64_t)chunk * 9 + tap) * n_mt + mt) * 3) * 512 + lane * 8 + e;
+  Ws[base] = (unsigned short)(hb >> 16);
+  Ws[base + 512] = (unsigned short)(mb >> 16);
+  Ws[base + 1024] = (unsigned short)(__float_as_uint(r2) >> 16);
+}
+
+// all layers of a model in one launch: grid (ceil(max_n / 256), 2 * n_layers); row 2 l + t splits layer l with
+// transpose = t into desc[l].ws_fwd / ws_dgrad
+__global__ void k_conv2d_wsplit_many(const RsloConv2dSplitDesc *__restrict__ desc) {
+  const RsloConv2dSplitDesc d = desc[blockIdx.y >> 1];
+  const int transpose = blockIdx.y & 1;
+  const int cin = d.cin, cout = d.cout;
+  const float *__restrict__ W = d.W;
+  unsigned short *__restrict__ Ws = (unsigned short *)(transpose ? d.ws_dgrad : d.ws_fwd);
+  const int n_m = transpose ? cin : cout, n_k = transpose ? cout : cin;
+  const int n_mt = n_m / 16;
+  const int64_t n = (int64_t)n_k * 9 * n_m;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int e = (int)(i & 7), lane = (int)((i >> 3) & 63);
+  int64_t r = i >> 9;
+  const int mt = (int)(r % n_mt); r /= n_mt;
+  const int tap = (int)(r % 9);
+  const int chunk = (int)(r / 9);
+  const int m = mt * 16 + (lane & 15), k = chunk * 32 + 8 * (lane >> 4) + e;
+  const float x = transpose ? W[((int64_t)k * cin + m) * 9 + (8 - tap)] : W[((int64_t)m * cin + k) * 9 + tap];
+  const unsigned hb = __float_as_uint(x) & 0xffff0000u;
+  const float r1 = x - __uint_as_float(hb);
+  const unsigned mb = __float_as_uint(r1) & 0xffff0000u;
+  const float r2 = r1 - __uint_as_float(mb);
+  const int64_t base = ((((int64_t)chunk * 9 + tap) * n_mt + mt) * 3) * 512 + lane * 8 + e;
+  Ws[base] = (unsigned short)(hb >> 16);
+  Ws[base + 512] = (unsigned short)(mb >> 16);
+  Ws[base + 1024] = (unsigned short)(__float_as_uint(r2) >> 16);
+}
+
+struct Conv2dFwdGeom {
+  int B, cin, cout, H, W;      // cin = contraction channels, cout = produced channels of THIS call
+  int tiles_x, tiles_y;
+};
+
+template <int TR, int MTW>
+__global__ __launch_bounds__(256, 2) void k_conv2d_fwd(const float *__restrict__ in, const unsigned short *__restrict__ Ws,
+                                                    const float *__restrict__ bias, Conv2dFwdGeom gm,
+                                                    float *__restrict__ out) {
+  constexpr int NTW = TR / 2, HR = TR + 2, NPX = HR * 18;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[NPX * C2F_PXB];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int wm = wid & 1, wn = wid >> 1;
+  int bx = blockIdx.x;
+  const int tx = bx % gm.tiles_x; bx /= gm.tiles_x;
+  const int ty = bx % gm.tiles_y;
+  const int b = bx / gm.tiles_y;
+  const int x0 = tx * 16, y0 = ty * TR;
+  const int H = gm.H, W = gm.W;
+  const int64_t HW = (int64_t)H * W;
+  const int n_mt = gm.cout / 16;
+  const int mt0 = blockIdx.y * 2 * MTW + wm * MTW;          // first 16-channel output block of this wave
+
+  f32x4 acc[MTW][NTW];
+#pragma unroll
+  for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // staging tasks of this thread: task = (channel octet o, pixel q), q fastest; NTASK rounds of 256 threads
+  constexpr int NTASK = (NPX * 4 + 255) / 256;
+  const float *tsrc[NTASK];
+  int tdst[NTASK];
+#pragma unroll
+  for (int r = 0; r < NTASK; ++r) {
+    const int task = tid + r * 256;
+    const int o = task / NPX, q = task - o * NPX;
+    const int qy = q / 18, qx = q - qy * 18;
+    const int y = y0 - 1 + qy, x = x0 - 1 + qx;
+    const bool ok = task < NPX * 4 && y >= 0 && y < H && x >= 0 && x < W;
+    tsrc[r] = ok ? in + ((int64_t)b * gm.cin + 8 * o) * HW + (int64_t)y * W + x : nullptr;
+    tdst[r] = task < NPX * 4 ? q * C2F_PXB + o * 16 : -1;
+  }
+  float raw[NTASK][8];
+  const int n_chunks = gm.cin / 32;
+#pragma unroll
+  for (int r = 0; r < NTASK; ++r)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) raw[r][j] = tsrc[r] ? tsrc[r][j * HW] : 0.f;
+  for (int chunk = 0; chunk < n_chunks; ++chunk) {
+    // split the prefetched values of this chunk into LDS, then prefetch the next chunk's (in flight during the MFMAs)
+#pragma unroll
+    for (int r = 0; r < NTASK; ++r) {
+      if (tdst[r] >= 0) {
+        const Split3 s = split_masked(raw[r], 0xffu);
+        unsigned char *dst = lds + tdst[r];
+        *(u32x4 *)(dst) = s.h;
+        *(u32x4 *)(dst + 64) = s.m;
+        *(u32x4 *)(dst + 128) = s.l;
+      }
+    }
+    if (chunk + 1 < n_chunks) {
+#pragma unroll
+      for (int r = 0; r < NTASK; ++r)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) raw[r][j] = tsrc[r] ? tsrc[r][((int64_t)(chunk + 1) * 32 + j) * HW] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int tap = ky * 3 + kx;
+        u32x4 ah[MTW], am[MTW], al[MTW];
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) {
+          const unsigned short *wp = Ws + ((((int64_t)chunk * 9 + tap) * n_mt + mt0 + mt) * 3) * 512 + lane * 8;
+          ah[mt] = *(const u32x4 *)(wp);
+          am[mt] = *(const u32x4 *)(wp + 512);
+          al[mt] = *(const u32x4 *)(wp + 1024);
+        }
+        u32x4 bh[NTW], bm[NTW], bl[NTW];
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+          const unsigned char *bp = lds + ((wn * NTW + nt + ky) * 18 + li + kx) * C2F_PXB + g * 16;
+          bh[nt] = *(const u32x4 *)(bp);
+          bm[nt] = *(const u32x4 *)(bp + 64);
+          bl[nt] = *(const u32x4 *)(bp + 128);
+        }
+        // six products per block, smallest first; consecutive MFMAs hit different accumulators
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = MFMA_BF16(al[mt], bh[nt], acc[mt][nt]);
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = MFMA_BF16(am[mt], bm[nt], acc[mt][nt]);
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = MFMA_BF16(ah[mt], bl[nt], acc[mt][nt]);
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = MFMA_BF16(am[mt], bh[nt], acc[mt][nt]);
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = MFMA_BF16(ah[mt], bm[nt], acc[mt][nt]);
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = MFMA_BF16(ah[mt], bh[nt], acc[mt][nt]);
+      }
+    }
+    __syncthreads();
+  }
+
+  const int x = x0 + li;
+#pragma unroll
+  for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = (mt0 + mt) * 16 + 4 * g + j;
+      const float bv = bias ? bias[m] : 0.f;
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) {
+        const int y = y0 + wn * NTW + nt;
+        if (x < W && y < H) out[((int64_t)b * gm.cout + m) * HW + (int64_t)y * W + x] = acc[mt][nt][j] + bv;
+      }
+    }
+}
+
+static int conv2d_fwd_plan(int B, int cin, int cout, int H, int W, int *tr, int *mtw) {
+  if (B <= 0 || H <= 0 || W <= 0 || cin % 32 != 0 || cout % 32 != 0) return 0;
+  static int cfg_tr = -1, cfg_mtw = -1;
+  if (cfg_tr < 0) {
+    const char *e = getenv("RSLO_CONV2D_FWD_CFG");      // "TR,MTW" forces one configuration (experiments)
+    cfg_tr = cfg_mtw = 0;
+    if (e) sscanf(e, "%d,%d", &cfg_tr, &cfg_mtw);
+  }
+  int t = 8, m = 2;
+  if (cout % 64 != 0) m = 1;
+  const int64_t wgs = (int64_t)B * rslo_cdiv(H, t) * rslo_cdiv(W, 16) * (cout / (32 * m));
+  if (wgs < 384 && m == 2) m = 1;
+  if ((int64_t)B * rslo_cdiv(H, t) * rslo_cdiv(W, 16) * (cout / (32 * m)) < 384 || H % 8 != 0) t = 4;
+  if (cfg_tr == 4 || cfg_tr == 8) t = cfg_tr;
+  if ((cfg_mtw == 1 || cfg_mtw == 2) && cout % (32 * cfg_mtw) == 0) m = cfg_mtw;
+  *tr = t; *mtw = m;
+  return 1;
+}
+
+extern "C" int rslo_conv2d_fwd_supported(int cin, int cout, int H, int W) {
+  int t, m;
+  return conv2d_fwd_plan(1, cin, cout, H, W, &t, &m);
+}
+
+extern "C" size_t rslo_conv2d_wsplit_bytes(int cin, int cout) { return (size_t)3 * 9 * cin * cout * sizeof(unsigned short); }
+
+extern "C" int rslo_conv2d_wsplit(const float *W, int cin, int cout, int transpose, void *Ws, void *stream) {
+  RSLO_CHECK_ARG(cin % 32 == 0 && cout % 32 == 0, "rslo_conv2d_wsplit: channels must be multiples of 32 (%d, %d)", cin, cout);
+  const int64_t n = (int64_t)cin * cout * 9;
+  hipLaunchKernelGGL(k_conv2d_wsplit, dim3((unsigned)rslo_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, W, cin, cout,
+                     transpose, (unsigned short *)Ws);
+  RSLO_CHECK_LAUNCH("k_conv2d_wsplit");
+  return RSLO_OK;
+}
+
+extern "C" int rslo_conv2d_wsplit_many(const RsloConv2dSplitDesc *desc_dev, int n_layers, int64_t max_weight_elems,
+                                       void *stream) {
+  RSLO_CHECK_ARG(n_layers > 0 && n_layers < 32768 && max_weight_elems > 0, "rslo_conv2d_wsplit_many: bad sizes");
+  hipLaunchKernelGGL(k_conv2d_wsplit_many, dim3((unsigned)rslo_cdiv(max_weight_elems, 256), (unsigned)(2 * n_layers)),
+                     dim3(256), 0, (hipStream_t)stream, desc_dev);
+  RSLO_CHECK_LAUNCH("k_conv2d_wsplit_many");
+  return RSLO_OK;
+}
+
+extern "C" int rslo_conv2d_fwd(const float *in, const void *Ws, const float *bias, int B, int cin, int cout, int H, int W,
+                               float *out, void *stream) {
+  int tr, mtw;
+  RSLO_CHECK_ARG(conv2d_fwd_plan(B, cin, cout, H, W, &tr, &mtw), "rslo_conv2d_fwd: unsupported shape cin=%d cout=%d H=%d W=%d",
+                 cin, cout, H, W);
+  Conv2dFwdGeom gm;
+  gm.B = B; gm.cin = cin; gm.cout = cout; gm.H = H; gm.W = W;
+  gm.tiles_x = (int)rslo_cdiv(W, 16);
+  gm.tiles_y = (int)rslo_cdiv(H, tr);
+  const dim3 grid((unsigned)(B * gm.tiles_x * gm.tiles_y), (unsigned)(cout / (32 * mtw)));
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned short *ws = (const unsigned short *)Ws;
+  if (tr == 8 && mtw == 2) hipLaunchKernelGGL((k_conv2d_fwd<8, 2>), grid, dim3(256), 0, st, in, ws, bias, gm, out);
+  else if (tr == 8) hipLaunchKernelGGL((k_conv2d_fwd<8, 1>), grid, dim3(256), 0, st, in, ws, bias, gm, out);
+  else if (mtw == 2) hipLaunchKernelGGL((k_conv2d_fwd<4, 2>), grid, dim3(256), 0, st, in, ws, bias, gm, out);
+  else hipLaunchKernelGGL((k_conv2d_fwd<4, 1>), grid, dim3(256), 0, st, in, ws, bias, gm, out);
+  RSLO_CHECK_LAUNCH("k_conv2d_fwd");
   return RSLO_OK;
 }

@@ -1,22 +1,43 @@
-"""Conv2d of the BEV head with the weight gradient on the hand-written gfx950 kernel.
+"""Conv2d of the BEV head on the hand-written gfx950 kernels (csrc/conv2d.hip).
 
 The reference builds its BEV encoder-decoder from torch.nn.Conv2d (rslo/models/odom_pred.py:65-134,398-426,
-rslo/layers/MaskConv.py:20-73) and leaves all three convolution passes to cuDNN.  Here forward and data gradient stay
-with the library (MIOpen's fp32 Winograd kernels), the weight gradient of every 3x3 / padding-1 layer whose shape the
-kernel takes goes through rslo_conv2d_wgrad (csrc/conv2d.hip): one kernel + one reduce instead of MIOpen's
-split-K igemm + 4 layout transposes + a zero fill, fixed summation order.  Same parameters, same state-dict keys."""
+rslo/layers/MaskConv.py:20-73) and leaves all three convolution passes to cuDNN.  Here the weight gradient of every
+3x3 / padding-1 layer whose shape the kernel takes goes through rslo_conv2d_wgrad (csrc/conv2d.hip): one kernel + one
+reduce instead of MIOpen's split-K igemm + 4 layout transposes + a zero fill, fixed summation order.  Forward and data
+gradient default to the library (MIOpen's fp32 Winograd kernels); rslo_conv2d_fwd is selectable (HIP_PASSES below).
+Same parameters, same state-dict keys."""
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+# which passes of an eligible layer run on the hand-written kernels: "w" weight gradient, "f" forward, "d" data gradient.
+# Default "w": inside the training step the forward / data-gradient kernel (k_conv2d_fwd) measures slower than MIOpen's
+# Winograd kernels (4.6 vs 4.3 ms per step, profiles/README.md) although it wins the isolated per-layer timing
+# (scripts/bench_conv2d_fwd.py); it stays tested and selectable (RSLO_CONV2D_PASSES=wfd).
+HIP_PASSES = os.environ.get("RSLO_CONV2D_PASSES", "w")
+
 
 class _Conv3x3Fn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, bias, stride):
+    def forward(ctx, x, w, bias, stride, hip_fd, hip_w):
         x = x.contiguous()
+        ctx.hip_w = hip_w
         ctx.save_for_backward(x, w)
         ctx.stride = stride
         ctx.has_bias = bias is not None
+        ctx.hip_fd = hip_fd
+        ctx.ws_t = None
+        if hip_fd:
+            from rslo_amd import capi
+            ws = _PRESPLIT.get(w.data_ptr())           # operands refreshed for all layers in one launch (presplit())
+            if ws is not None and ws[2] != w._version:
+                ws = None
+            if "d" in HIP_PASSES:
+                ctx.ws_t = ws[1] if ws is not None else capi.conv2d_wsplit(w, True)
+            if "f" in HIP_PASSES:
+                return capi.conv2d_fwd(x, ws[0] if ws is not None else capi.conv2d_wsplit(w, False), bias, w.shape[0])
         return F.conv2d(x, w, bias, stride, 1)
 
     @staticmethod
@@ -27,13 +48,45 @@ class _Conv3x3Fn(torch.autograd.Function):
         dy = dy.contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = torch.ops.aten.convolution_backward(dy, x, w, None, [s, s], [1, 1], [1, 1], False, [0, 0], 1,
-                                                     [True, False, False])[0]
+            if ctx.ws_t is not None:
+                dx = capi.conv2d_fwd(dy, ctx.ws_t, None, w.shape[1])
+            else:
+                dx = torch.ops.aten.convolution_backward(dy, x, w, None, [s, s], [1, 1], [1, 1], False, [0, 0], 1,
+                                                         [True, False, False])[0]
         if ctx.needs_input_grad[1]:
-            dw = capi.conv2d_wgrad(x, dy, s)
+            if ctx.hip_w:
+                dw = capi.conv2d_wgrad(x, dy, s)
+            else:
+                dw = torch.ops.aten.convolution_backward(dy, x, w, None, [s, s], [1, 1], [1, 1], False, [0, 0], 1,
+                                                         [False, True, False])[1]
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.sum((0, 2, 3))
-        return dx, dw, db, None
+        return dx, dw, db, None, None, None
+
+
+_PRESPLIT = {}      # weight.data_ptr() -> (ws_fwd, ws_dgrad, weight._version at split time)
+_PLANS = {}         # id(root module) -> (plan, weights, views)
+
+
+def presplit(root):
+    """Refresh the split-bf16 operands of every eligible Conv2d under `root` (both orientations) in ONE launch; the
+    layers pick them up while the weights' version counters are unchanged (i.e. until the next optimizer step)."""
+    if "f" not in HIP_PASSES and "d" not in HIP_PASSES:
+        return
+    from rslo_amd import capi
+    ent = _PLANS.get(id(root))
+    if ent is None or any(w.data_ptr() != p for w, p in zip(ent[1], ent[0]["ptrs"])):
+        ws = [m.weight for m in root.modules()
+              if isinstance(m, Conv2d) and m.hip_wgrad and m.kernel_size == (3, 3) and m.stride == (1, 1)
+              and m.padding == (1, 1) and m.dilation == (1, 1) and m.groups == 1 and m.weight.is_cuda
+              and m.weight.dtype == torch.float32 and m.in_channels % 32 == 0 and m.out_channels % 32 == 0]
+        if not ws:
+            return
+        plan, views = capi.conv2d_wsplit_many(ws)
+        ent = _PLANS[id(root)] = (plan, ws, views)
+    capi.conv2d_wsplit_run(ent[0])
+    for w, (f, t) in zip(ent[1], ent[2]):
+        _PRESPLIT[w.data_ptr()] = (f, t, w._version)
 
 
 class Conv2d(nn.Conv2d):
@@ -52,11 +105,14 @@ class Conv2d(nn.Conv2d):
         key = (x.shape[2], x.shape[3])
         if ok is None or ok[0] != key:
             from rslo_amd import capi
-            ok = self._hip_ok = (key, capi.conv2d_wgrad_supported(self.in_channels, self.out_channels, key[0], key[1],
-                                                                 self.stride[0]))
-        return ok[1]
+            w_ok = "w" in HIP_PASSES and capi.conv2d_wgrad_supported(self.in_channels, self.out_channels, key[0],
+                                                                     key[1], self.stride[0])
+            fd_ok = self.stride == (1, 1) and capi.conv2d_fwd_supported(self.in_channels, self.out_channels, key[0],
+                                                                       key[1]) and ("f" in HIP_PASSES or "d" in HIP_PASSES)
+            ok = self._hip_ok = (key, w_ok, fd_ok)
+        return ok[1] or ok[2]
 
     def _conv_forward(self, input, weight, bias):
         if self._eligible(input):
-            return _Conv3x3Fn.apply(input, weight, bias, self.stride[0])
+            return _Conv3x3Fn.apply(input, weight, bias, self.stride[0], self._hip_ok[2], self._hip_ok[1])
         return super()._conv_forward(input, weight, bias)

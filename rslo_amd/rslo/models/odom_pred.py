@@ -16,6 +16,7 @@ import numpy as np
 
 from rslo.data.dataset import _grid_geometry, from_pointwise_local_transformation_tch
 from rslo.layers.confidence import ConfidenceModule, masked_spatial_softmax
+from rslo.layers import hip_conv2d
 from rslo.layers.hip_conv2d import Conv2d
 from rslo.layers.MaskConv import MaskConv
 from rslo.models.odom_pred_base import OdomPredEncDecBase, conf_trunk
@@ -87,6 +88,8 @@ class UNOdomPredEncDecSVDTempMaskBase(OdomPredEncDecBase):
     def _forward(self, xs):
         if not isinstance(xs, list):
             xs = [xs]
+        if xs[0].is_cuda and self.training and torch.is_grad_enabled():
+            hip_conv2d.presplit(self)       # split-bf16 operands of all 3x3 layers for this step, one launch
         if self._cycle_constraint:
             xs = self.create_cycle_constraint_data(xs)
         with torch.no_grad():   # occupancy of the FIRST frame of each pair only (odom_pred.py:165-168)

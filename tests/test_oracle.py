@@ -241,3 +241,16 @@ def test_dense_conv2d_wgrad_restatement_matches_autograd(stride, H, W):
     g = rng.standard_normal(tuple(y.shape))
     y.backward(torch.from_numpy(g))
     np.testing.assert_allclose(O.conv2d_wgrad(x, g, stride), w.grad.numpy(), rtol=1e-12, atol=1e-12)
+
+
+def test_dense_conv2d_fwd_dgrad_restatement_matches_torch():
+    import torch
+    rng = np.random.default_rng(4)
+    x = torch.from_numpy(rng.standard_normal((2, 5, 7, 9))).requires_grad_(True)
+    w = torch.from_numpy(rng.standard_normal((4, 5, 3, 3)))
+    bias = torch.from_numpy(rng.standard_normal(4))
+    y = torch.nn.functional.conv2d(x, w, bias, 1, 1)
+    g = rng.standard_normal(tuple(y.shape))
+    y.backward(torch.from_numpy(g))
+    np.testing.assert_allclose(O.conv2d_fwd(x.detach().numpy(), w.numpy(), bias.numpy()), y.detach().numpy(), rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(O.conv2d_dgrad(g, w.numpy()), x.grad.numpy(), rtol=1e-12, atol=1e-12)
