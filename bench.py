@@ -303,12 +303,14 @@ def main():
     # per-launch HIP events on the last PROBE_STEPS timed steps only (the events themselves cost host time)
     probe_steps = min(3, args.steps)
     t0 = time.perf_counter()
+    cpu0 = time.thread_time()           # CPU time of the issuing thread: close to the wall time = host-bound step
     for i in range(args.steps):
         if use_probe and i == args.steps - probe_steps:
             probe.enabled = True
         if use_probe and i == args.steps - 1:
             probe.keep_tables = True
         ret = step()
+    cpu_issue = time.thread_time() - cpu0
     barrier()
     elapsed = time.perf_counter() - t0
     probe.enabled = False
@@ -342,6 +344,7 @@ def main():
                        "frame_pairs_per_gpu": args.batch, "points_per_frame": n_points,
                        "voxelize_in_step": not args.no_voxelize, "voxelize_prefetch_stream": prefetch is not None,
                        "optimizer_in_step": not args.no_optim,
+                       "host_issue_ms_per_step": round(1e3 * cpu_issue / args.steps, 3),
                        "final_loss": round(loss_val, 4)},
             "roofline": roof,
             "cpu_baseline": None,

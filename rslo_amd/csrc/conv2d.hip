@@ -553,7 +553,7 @@ struct Conv2dFwdGeom {
   int tiles_x, tiles_y;
 };
 
-template <int TR, int MTW>
+template <int TR, int MTW, bool FULLA>
 __global__ __launch_bounds__(256, 2) void k_conv2d_fwd(const float *__restrict__ in, const unsigned short *__restrict__ Ws,
                                                     const float *__restrict__ bias, Conv2dFwdGeom gm,
                                                     float *__restrict__ out) {
@@ -598,6 +598,26 @@ __global__ __launch_bounds__(256, 2) void k_conv2d_fwd(const float *__restrict__
   for (int r = 0; r < NTASK; ++r)
 #pragma unroll
     for (int j = 0; j < 8; ++j) raw[r][j] = tsrc[r] ? tsrc[r][j * HW] : 0.f;
+  // weight operands are fetched one tap ahead (they come from L2 / Infinity Cache: the split weights of a whole model do
+  // not stay in one XCD's L2 between layers); tap 0 of a chunk is requested before the staging barrier
+  // FULLA (small maps, few MFMAs per tap): all 9 taps of a chunk are held in registers and each tap's registers are
+  // refilled for the NEXT chunk right after its MFMAs -- a prefetch distance of 9 taps
+  constexpr int NA = FULLA ? 9 : 1;
+  u32x4 ah[NA][MTW], am[NA][MTW], al[NA][MTW], nh[MTW], nm[MTW], nl[MTW];
+  const unsigned short *wbase = Ws + (int64_t)mt0 * 3 * 512 + lane * 8;
+#define C2F_LOAD_A(CH, TAP, H_, M_, L_)                                                                  \
+  _Pragma("unroll") for (int mt = 0; mt < MTW; ++mt) {                                                    \
+    const unsigned short *wp = wbase + ((((int64_t)(CH) * 9 + (TAP)) * n_mt + mt) * 3) * 512;           \
+    H_[mt] = *(const u32x4 *)(wp);                                                                        \
+    M_[mt] = *(const u32x4 *)(wp + 512);                                                                  \
+    L_[mt] = *(const u32x4 *)(wp + 1024);                                                                 \
+  }
+  if (FULLA) {
+#pragma unroll
+    for (int t = 0; t < NA; ++t) { C2F_LOAD_A(0, t, ah[t], am[t], al[t]) }
+  } else {
+    C2F_LOAD_A(0, 0, ah[0], am[0], al[0])
+  }
   for (int chunk = 0; chunk < n_chunks; ++chunk) {
     // split the prefetched values of this chunk into LDS, then prefetch the next chunk's (in flight during the MFMAs)
 #pragma unroll
@@ -622,13 +642,14 @@ __global__ __launch_bounds__(256, 2) void k_conv2d_fwd(const float *__restrict__
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) {
         const int tap = ky * 3 + kx;
-        u32x4 ah[MTW], am[MTW], al[MTW];
-#pragma unroll
-        for (int mt = 0; mt < MTW; ++mt) {
-          const unsigned short *wp = Ws + ((((int64_t)chunk * 9 + tap) * n_mt + mt0 + mt) * 3) * 512 + lane * 8;
-          ah[mt] = *(const u32x4 *)(wp);
-          am[mt] = *(const u32x4 *)(wp + 512);
-          al[mt] = *(const u32x4 *)(wp + 1024);
+        constexpr int ta = 0;
+        const int ia = FULLA ? tap : ta;
+        if (!FULLA) {
+          if (tap < 8) {
+            C2F_LOAD_A(chunk, tap + 1, nh, nm, nl)
+          } else if (chunk + 1 < n_chunks) {
+            C2F_LOAD_A(chunk + 1, 0, nh, nm, nl)
+          }
         }
         u32x4 bh[NTW], bm[NTW], bl[NTW];
 #pragma unroll
@@ -642,31 +663,40 @@ __global__ __launch_bounds__(256, 2) void k_conv2d_fwd(const float *__restrict__
 #pragma unroll
         for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
-          for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = MFMA_BF16(al[mt], bh[nt], acc[mt][nt]);
+          for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = MFMA_BF16(al[ia][mt], bh[nt], acc[mt][nt]);
 #pragma unroll
         for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
-          for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = MFMA_BF16(am[mt], bm[nt], acc[mt][nt]);
+          for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = MFMA_BF16(am[ia][mt], bm[nt], acc[mt][nt]);
 #pragma unroll
         for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
-          for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = MFMA_BF16(ah[mt], bl[nt], acc[mt][nt]);
+          for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = MFMA_BF16(ah[ia][mt], bl[nt], acc[mt][nt]);
 #pragma unroll
         for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
-          for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = MFMA_BF16(am[mt], bh[nt], acc[mt][nt]);
+          for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = MFMA_BF16(am[ia][mt], bh[nt], acc[mt][nt]);
 #pragma unroll
         for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
-          for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = MFMA_BF16(ah[mt], bm[nt], acc[mt][nt]);
+          for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = MFMA_BF16(ah[ia][mt], bm[nt], acc[mt][nt]);
 #pragma unroll
         for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
-          for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = MFMA_BF16(ah[mt], bh[nt], acc[mt][nt]);
+          for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = MFMA_BF16(ah[ia][mt], bh[nt], acc[mt][nt]);
+        if (FULLA) {
+          if (chunk + 1 < n_chunks) { C2F_LOAD_A(chunk + 1, tap, ah[ia], am[ia], al[ia]) }
+        } else {
+#pragma unroll
+          for (int mt = 0; mt < MTW; ++mt) {
+            ah[0][mt] = nh[mt]; am[0][mt] = nm[mt]; al[0][mt] = nl[mt];
+          }
+        }
       }
     }
     __syncthreads();
   }
+#undef C2F_LOAD_A
 
   const int x = x0 + li;
 #pragma unroll
@@ -691,11 +721,10 @@ static int conv2d_fwd_plan(int B, int cin, int cout, int H, int W, int *tr, int 
     cfg_tr = cfg_mtw = 0;
     if (e) sscanf(e, "%d,%d", &cfg_tr, &cfg_mtw);
   }
-  int t = 8, m = 2;
-  if (cout % 64 != 0) m = 1;
-  const int64_t wgs = (int64_t)B * rslo_cdiv(H, t) * rslo_cdiv(W, 16) * (cout / (32 * m));
-  if (wgs < 384 && m == 2) m = 1;
-  if ((int64_t)B * rslo_cdiv(H, t) * rslo_cdiv(W, 16) * (cout / (32 * m)) < 384 || H % 8 != 0) t = 4;
+  // measured inside the training step (profiles/README.md): 4-row tiles, one 16-channel block per wave and the whole
+  // chunk's weight operands prefetched 9 taps ahead win on every map size of the head (45 vs 67 us on 48x88, 23 vs 54 us
+  // on 12x22 against the 8-row / one-tap-ahead configurations, which stay selectable for experiments)
+  int t = 4, m = 1;
   if (cfg_tr == 4 || cfg_tr == 8) t = cfg_tr;
   if ((cfg_mtw == 1 || cfg_mtw == 2) && cout % (32 * cfg_mtw) == 0) m = cfg_mtw;
   *tr = t; *mtw = m;
@@ -739,10 +768,10 @@ extern "C" int rslo_conv2d_fwd(const float *in, const void *Ws, const float *bia
   const dim3 grid((unsigned)(B * gm.tiles_x * gm.tiles_y), (unsigned)(cout / (32 * mtw)));
   hipStream_t st = (hipStream_t)stream;
   const unsigned short *ws = (const unsigned short *)Ws;
-  if (tr == 8 && mtw == 2) hipLaunchKernelGGL((k_conv2d_fwd<8, 2>), grid, dim3(256), 0, st, in, ws, bias, gm, out);
-  else if (tr == 8) hipLaunchKernelGGL((k_conv2d_fwd<8, 1>), grid, dim3(256), 0, st, in, ws, bias, gm, out);
-  else if (mtw == 2) hipLaunchKernelGGL((k_conv2d_fwd<4, 2>), grid, dim3(256), 0, st, in, ws, bias, gm, out);
-  else hipLaunchKernelGGL((k_conv2d_fwd<4, 1>), grid, dim3(256), 0, st, in, ws, bias, gm, out);
+  if (tr == 8 && mtw == 2) hipLaunchKernelGGL((k_conv2d_fwd<8, 2, false>), grid, dim3(256), 0, st, in, ws, bias, gm, out);
+  else if (tr == 8) hipLaunchKernelGGL((k_conv2d_fwd<8, 1, false>), grid, dim3(256), 0, st, in, ws, bias, gm, out);
+  else if (mtw == 2) hipLaunchKernelGGL((k_conv2d_fwd<4, 2, false>), grid, dim3(256), 0, st, in, ws, bias, gm, out);
+  else hipLaunchKernelGGL((k_conv2d_fwd<4, 1, true>), grid, dim3(256), 0, st, in, ws, bias, gm, out);
   RSLO_CHECK_LAUNCH("k_conv2d_fwd");
   return RSLO_OK;
 }

@@ -4,19 +4,18 @@ The reference builds its BEV encoder-decoder from torch.nn.Conv2d (rslo/models/o
 rslo/layers/MaskConv.py:20-73) and leaves all three convolution passes to cuDNN.  Here the weight gradient of every
 3x3 / padding-1 layer whose shape the kernel takes goes through rslo_conv2d_wgrad (csrc/conv2d.hip): one kernel + one
 reduce instead of MIOpen's split-K igemm + 4 layout transposes + a zero fill, fixed summation order.  Forward and data
-gradient default to the library (MIOpen's fp32 Winograd kernels); rslo_conv2d_fwd is selectable (HIP_PASSES below).
-Same parameters, same state-dict keys."""
+gradient of the stride-1 layers go through rslo_conv2d_fwd with operands split once per step for the whole head
+(presplit); stride-2 and 1x1 layers, eval / no-grad calls and CPU tensors stay plain nn.Conv2d.  Same parameters, same
+state-dict keys."""
 import os
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-# which passes of an eligible layer run on the hand-written kernels: "w" weight gradient, "f" forward, "d" data gradient.
-# Default "w": inside the training step the forward / data-gradient kernel (k_conv2d_fwd) measures slower than MIOpen's
-# Winograd kernels (4.6 vs 4.3 ms per step, profiles/README.md) although it wins the isolated per-layer timing
-# (scripts/bench_conv2d_fwd.py); it stays tested and selectable (RSLO_CONV2D_PASSES=wfd).
-HIP_PASSES = os.environ.get("RSLO_CONV2D_PASSES", "w")
+# which passes of an eligible layer run on the hand-written kernels: "w" weight gradient, "f" forward, "d" data gradient
+# ("" = everything on the library, for A/B measurements)
+HIP_PASSES = os.environ.get("RSLO_CONV2D_PASSES", "wfd")
 
 
 class _Conv3x3Fn(torch.autograd.Function):
