@@ -108,6 +108,23 @@ class ConvProbe:
             return ("dgrad", cout, cin, K, nbrT.shape[0], nbrT if probe.keep_tables else None,
                     probe.kernel_name(cout, cin, nbrT.shape[0], True))
 
+        # dense 3x3 convolutions of the BEV head (csrc/conv2d.hip): algorithmic flops 2 B Ho Wo Cin Cout 9; bytes = input +
+        # output (+ split weights / + weight gradient), each touched once
+        def c2f_meta(x, ws, bias, cout):
+            B, cin, H, W = x.shape
+            return ("dense", 2 * B * H * W * cin * cout * 9, 4 * B * H * W * (cin + cout) + 54 * cin * cout,
+                    "k_conv2d_fwd<4, 1, true> [%d->%d %dx%d]" % (cin, cout, H, W))
+
+        def c2w_meta(x, dout, stride=1):
+            B, cin, H, W = x.shape
+            cout, Ho, Wo = dout.shape[1], dout.shape[2], dout.shape[3]
+            return ("dense", 2 * B * Ho * Wo * cin * cout * 9, 4 * B * (H * W * cin + Ho * Wo * cout) + 36 * cin * cout,
+                    ("k_conv2d_wgrad_s1<2>" if stride == 1 else "k_conv2d_wgrad<2, 2>") + " [%d->%d %dx%d]" % (cin, cout, H, W))
+
+        if os.environ.get("RSLO_CONV2D_FWD_CFG") is None and os.environ.get("RSLO_CONV2D_NB") is None:
+            for n, meta in (("conv2d_fwd", c2f_meta), ("conv2d_wgrad", c2w_meta)):
+                self._orig[n] = getattr(capi, n)
+                setattr(capi, n, timed(self._orig[n], meta))
         capi.spconv_fwd_direct = timed(self._orig["spconv_fwd_direct"], fwd_meta)
         capi.spconv_fwd_split = timed(self._orig["spconv_fwd_split"], split_meta)
         capi.spconv_dgrad_direct = timed(self._orig["spconv_dgrad_direct"], dgrad_meta)
@@ -122,13 +139,16 @@ class ConvProbe:
         torch.cuda.synchronize()
         per_step = len(self.records) // max(steps, 1)
         last = self.records[-per_step:]
-        pairs = [int((m[5] >= 0).sum().item()) for (m, _, _) in last]
+        pairs = [int((m[5] >= 0).sum().item()) if m[0] != "dense" else 0 for (m, _, _) in last]
         groups = {}
         for i, (m, e0, e1) in enumerate(self.records):
-            kind, cin, cout, K, n_out, _, name = m
-            P = pairs[i % per_step]
-            byts = P * cin * 4 + n_out * cout * 4 + 8 * P + K * cin * cout * 4
-            flops = 2 * P * cin * cout
+            if m[0] == "dense":
+                _, flops, byts, name = m
+            else:
+                kind, cin, cout, K, n_out, _, name = m
+                P = pairs[i % per_step]
+                byts = P * cin * 4 + n_out * cout * 4 + 8 * P + K * cin * cout * 4
+                flops = 2 * P * cin * cout
             g = groups.setdefault(name, {"launches": 0, "ms": 0.0, "bytes": 0, "flops": 0})
             g["launches"] += 1
             g["ms"] += e0.elapsed_time(e1)
@@ -138,39 +158,57 @@ class ConvProbe:
             g["avg_us"] = 1e3 * g["ms"] / g["launches"]
             g["GBps"] = g["bytes"] / (g["ms"] * 1e-3) / 1e9
             g["TFLOPs"] = g["flops"] / (g["ms"] * 1e-3) / 1e12
-        name = max(groups, key=lambda n: groups[n]["ms"])
-        g = groups[name]
-        # which roof bounds it: arithmetic intensity vs the fp32 ridge (157.3 TF / 8 TB/s = 19.7 flop/B)
-        ai = g["flops"] / g["bytes"]
-        if ai >= MFMA_F32_PEAK_TF * 1e3 / HBM_PEAK_GBS:
-            roof = {"bound": "mfma", "kernel": name, "achieved": round(g["TFLOPs"], 2), "peak": MFMA_F32_PEAK_TF,
-                    "unit": "TFLOP/s", "frac": round(g["TFLOPs"] / MFMA_F32_PEAK_TF, 4), "traffic": None}
-        else:
-            roof = {"bound": "hbm", "kernel": name, "achieved": round(g["GBps"], 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(g["GBps"] / HBM_PEAK_GBS, 4), "traffic": None}
-        if "k_spconv_v6" in name:
-            # fp32 products computed as six bf16 MFMAs on exactly split operands (rslo_amd/csrc/spconv.hip, v6): the
-            # algorithmic fp32 flops are priced against the fp32 MFMA peak; the bf16 matrix-core work issued is 6x that
-            roof["matrix_core_path"] = "fp32 = 3-way exact bf16 split, 6 x v_mfma_f32_16x16x32_bf16 per product block"
-            roof["issued_bf16_TFLOPs"] = round(6 * g["TFLOPs"], 1)
-            roof["issued_bf16_frac_of_2500TF"] = round(6 * g["TFLOPs"] / 2500.0, 4)
-        roof.update({"arithmetic_intensity_flop_per_byte": round(ai, 2), "algorithmic_GBps": round(g["GBps"], 1),
-                     "hbm_frac": round(g["GBps"] / HBM_PEAK_GBS, 4), "algorithmic_TFLOPs": round(g["TFLOPs"], 2),
-                     "avg_launch_us": round(g["avg_us"], 2), "launches_per_step": g["launches"] // max(steps, 1),
-                     "algorithmic_bytes_per_launch": int(g["bytes"] // g["launches"]),
-                     "algorithmic_flops_per_launch": int(g["flops"] // g["launches"])})
-        # HBM-side bytes per launch from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md), collected
-        # with rocprofv3 on this same command (scripts/pmc_bench_traffic.sh) and committed under profiles/
         try:
             with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_bench.json")) as f:
-                tr = json.load(f)
-            if name in tr.get("kernels", {}):
-                roof["traffic"] = int(tr["kernels"][name]["hbm_bytes_per_launch"])
-                roof["traffic_source"] = "profiles/r01_pmc_traffic_bench.json"
-        except (OSError, ValueError, KeyError):
-            pass
-        tot_ms = sum(x["ms"] for x in groups.values())
-        tot_b = sum(x["bytes"] for x in groups.values())
+                pmc = json.load(f).get("kernels", {})
+        except (OSError, ValueError):
+            pmc = {}
+
+        def roof_of(gname):
+            g = groups[gname]
+            name = gname.split(" [")[0]          # dense groups are keyed kernel + layer shape
+            # which roof bounds it: arithmetic intensity vs the fp32 ridge (157.3 TF / 8 TB/s = 19.7 flop/B)
+            ai = g["flops"] / g["bytes"]
+            if ai >= MFMA_F32_PEAK_TF * 1e3 / HBM_PEAK_GBS:
+                r = {"bound": "mfma", "kernel": name, "achieved": round(g["TFLOPs"], 2), "peak": MFMA_F32_PEAK_TF,
+                     "unit": "TFLOP/s", "frac": round(g["TFLOPs"] / MFMA_F32_PEAK_TF, 4), "traffic": None}
+            else:
+                r = {"bound": "hbm", "kernel": name, "achieved": round(g["GBps"], 1), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": round(g["GBps"] / HBM_PEAK_GBS, 4), "traffic": None}
+            if "k_spconv_v6" in name or "k_conv2d" in name:
+                # fp32 products computed as six bf16 MFMAs on exactly split operands (csrc/spconv.hip v6, csrc/conv2d.hip):
+                # the algorithmic fp32 flops are priced against the fp32 MFMA peak; the bf16 matrix-core work issued is 6x
+                r["matrix_core_path"] = "fp32 = 3-way exact bf16 split, 6 x v_mfma_f32_16x16x32_bf16 per product block"
+                r["issued_bf16_TFLOPs"] = round(6 * g["TFLOPs"], 1)
+                r["issued_bf16_frac_of_2500TF"] = round(6 * g["TFLOPs"] / 2500.0, 4)
+            r.update({"arithmetic_intensity_flop_per_byte": round(ai, 2), "algorithmic_GBps": round(g["GBps"], 1),
+                      "hbm_frac": round(g["GBps"] / HBM_PEAK_GBS, 4), "algorithmic_TFLOPs": round(g["TFLOPs"], 2),
+                      "avg_launch_us": round(g["avg_us"], 2), "launches_per_step": g["launches"] // max(steps, 1),
+                      "ms_per_step": round(g["ms"] / max(steps, 1), 3),
+                      "algorithmic_bytes_per_launch": int(g["bytes"] // g["launches"]),
+                      "algorithmic_flops_per_launch": int(g["flops"] // g["launches"])})
+            # HBM-side bytes per launch from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md), collected
+            # with rocprofv3 on this same command (scripts/pmc_bench_traffic.sh) and committed under profiles/
+            if gname != name:
+                r["layer_shape"] = gname.split(" [")[1].rstrip("]")
+            if name in pmc:
+                r["traffic"] = int(pmc[name]["hbm_bytes_per_launch"])
+                r["traffic_source"] = "profiles/r01_pmc_traffic_bench.json" + (
+                    " (average over all layer shapes of this kernel)" if gname != name else "")
+            return r
+
+        # the dominant kernel = the (kernel instantiation, problem shape) with the largest total time per step among the
+        # probed hand-written convolution kernels; the top entry of the other family (sparse gather conv / dense BEV
+        # conv) is reported next to it
+        by_ms = sorted(groups, key=lambda n: -groups[n]["ms"])
+        name = by_ms[0]
+        roof = roof_of(name)
+        dense_first = "k_conv2d" in name
+        other = [n for n in by_ms if ("k_conv2d" in n) != dense_first]
+        if other:
+            roof["other_family_top_kernel"] = roof_of(other[0])
+        tot_ms = sum(x["ms"] for n, x in groups.items() if "k_conv2d" not in n)
+        tot_b = sum(x["bytes"] for n, x in groups.items() if "k_conv2d" not in n)
         roof["all_spconv_fwd_dgrad"] = {"ms_per_step": round(tot_ms / max(steps, 1), 3),
                                         "GBps": round(tot_b / (tot_ms * 1e-3) / 1e9, 1)}
         return groups, roof

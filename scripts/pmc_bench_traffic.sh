@@ -12,7 +12,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     agg = collections.defaultdict(list)
     for d in csv.DictReader(open(f)):
         n = d["Kernel_Name"]
-        if ("k_spconv" in n or "k_wgrad2<" in n or "k_weight_split" in n or "k_chamfer_part" in n or "k_cg_search" in n) and d["Counter_Name"] == c:
+        if ("k_spconv" in n or "k_wgrad2<" in n or "k_wgrad3<" in n or "k_conv2d" in n or "k_weight_split" in n or "k_chamfer_part" in n or "k_cg_search" in n) and d["Counter_Name"] == c:
             agg[re.sub(r"^void ", "", n.split("(")[0])].append(float(d["Counter_Value"]))
     for k, v in agg.items():
         res[k][c] = sum(v) / len(v); res[k]["launches"] = len(v)
