@@ -300,8 +300,10 @@ def main():
     # reference's DataLoader workers do on the CPU); every step still voxelizes its own 2 x batch clouds
     prefetch = None
     if fixed_example is None and not args.no_prefetch:
-        prefetch = workload.ExamplePrefetcher(net, device=dev)
-        prefetch.submit(clouds)
+        depth = int(os.environ.get("RSLO_PREFETCH_DEPTH", "1"))
+        prefetch = workload.ExamplePrefetcher(net, device=dev, depth=depth)
+        for _ in range(depth):
+            prefetch.submit(clouds)
 
     def step():
         if prefetch is not None:

@@ -323,6 +323,17 @@ RSLO_API int rslo_bn2d_bwd_apply(const float *dy, const float *y, const float *x
                                  int N, int C, int HW, float act_slope, int has_act, float *dx, float *dres,
                                  void *stream);
 
+/*      Single-rank forms (no statistics exchange): statistics slices + apply in two launches, the apply kernels add
+ *      the slice partials themselves.  Same results as stats -> apply / bwd_reduce -> bwd_apply with one rank. */
+RSLO_API int rslo_bn2d_fwd_local(const float *x, const float *res, const float *gamma, const float *beta, int N, int C,
+                                 int HW, float eps, float momentum, float act_slope, float *running_mean,
+                                 float *running_var, float *save_mean, float *save_invstd, float *y, void *ws,
+                                 size_t ws_bytes, void *stream);
+RSLO_API int rslo_bn2d_bwd_local(const float *dy, const float *y, const float *x, const float *gamma,
+                                 const float *save_mean, const float *save_invstd, int N, int C, int HW,
+                                 float act_slope, int has_act, float *dx, float *dres, float *dgamma, float *dbeta,
+                                 void *ws, size_t ws_bytes, void *stream);
+
 /* a13 / a14  local -> global transformation of every BEV cell + confidence-weighted ego-motion vote
  *      (from_pointwise_local_transformation_tch rslo/data/dataset.py:121-208, rotate_vec_by_q
  *       rslo/utils/pose_utils.py:130-142, aggregate_tq rslo/models/odom_pred.py:347-357).

@@ -80,6 +80,10 @@ SIGNATURES = {
                                        _vp]),
     "rslo_bn2d_bwd_apply": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, _i, _i, _i, C.c_float, _i, _vp, _vp,
                                       _vp]),
+    "rslo_bn2d_fwd_local": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, C.c_float, C.c_float, C.c_float, _vp, _vp, _vp, _vp,
+                                      _vp, _vp, _sz, _vp]),
+    "rslo_bn2d_bwd_local": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, C.c_float, _i, _vp, _vp, _vp, _vp, _vp,
+                                      _sz, _vp]),
     "rslo_roi_threshold": (C.c_int, [_vp, _i, _i, _vp, C.c_double, _vp, _vp]),
     "rslo_vote_ws_bytes": (_sz, [_i, _i, _i]),
     "rslo_vote_fwd": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
@@ -747,6 +751,39 @@ def bn2d_bwd_apply(dy, y, x, gamma, mean, invstd, red, count, slope, has_act, wa
                                    float(count), N, Cc, H * W, float(slope), int(has_act), _ptr(dx), _ptr(dres),
                                    _stream()), "rslo_bn2d_bwd_apply")
     return dx, dres
+
+
+def bn2d_fwd_local(x, res, gamma, beta, running_mean, running_var, momentum, eps, slope):
+    """Single-rank y = act(BN_train(x) + res): two launches.  -> y, save_mean, save_invstd."""
+    N, Cc, H, W = x.shape
+    dev = x.device
+    wsb = lib().rslo_bn2d_ws_bytes(N, Cc, H * W)
+    ws = _ws(wsb, dev)
+    y = torch.empty_like(x)
+    mean = torch.empty((Cc,), dtype=torch.float32, device=dev)
+    invstd = torch.empty((Cc,), dtype=torch.float32, device=dev)
+    _chk(lib().rslo_bn2d_fwd_local(_ptr(x, torch.float32, "x"), _ptr(res, torch.float32, "res"),
+                                   _ptr(gamma, torch.float32, "gamma"), _ptr(beta, torch.float32, "beta"), N, Cc, H * W,
+                                   float(eps), float(momentum), float(slope), _ptr(running_mean, torch.float32),
+                                   _ptr(running_var, torch.float32), _ptr(mean), _ptr(invstd), _ptr(y), _ptr(ws), wsb,
+                                   _stream()), "rslo_bn2d_fwd_local")
+    return y, mean, invstd
+
+
+def bn2d_bwd_local(dy, y, x, gamma, mean, invstd, slope, has_act, want_res, want_affine=True):
+    N, Cc, H, W = x.shape
+    dev = x.device
+    wsb = lib().rslo_bn2d_ws_bytes(N, Cc, H * W)
+    ws = _ws(wsb, dev)
+    dx = torch.empty_like(x)
+    dres = torch.empty_like(x) if want_res else None
+    dgamma = torch.empty((Cc,), dtype=torch.float32, device=dev) if want_affine else None
+    dbeta = torch.empty((Cc,), dtype=torch.float32, device=dev) if want_affine else None
+    _chk(lib().rslo_bn2d_bwd_local(_ptr(dy, torch.float32, "dy"), _ptr(y, torch.float32, "y"), _ptr(x, torch.float32, "x"),
+                                   _ptr(gamma, torch.float32, "gamma"), _ptr(mean), _ptr(invstd), N, Cc, H * W,
+                                   float(slope), int(has_act), _ptr(dx), _ptr(dres), _ptr(dgamma), _ptr(dbeta), _ptr(ws),
+                                   wsb, _stream()), "rslo_bn2d_bwd_local")
+    return dx, dres, dgamma, dbeta
 
 
 def roi_threshold(dist, counts, ratio):

@@ -48,11 +48,11 @@ def count_batch(bn):
         bn.num_batches_tracked.add_(1)
 
 
-# "auto": the fused kernels run when the process group has more than one rank (they replace torch SyncBatchNorm's
-# statistics gather + separate activation/add with two kernels and one all-reduce per direction); on a single rank
-# MIOpen's one-kernel BatchNorm + a separate activation measured faster (31 vs 45 us per layer, fwd + bwd).
-# "1" forces the fused path everywhere, "0" disables it.
-FUSED_BN = os.environ.get("RSLO_FUSED_BN", "auto")
+# "1" (default): the fused kernels of csrc/bn2d.hip run on any number of ranks -- one rank: statistics slices + apply,
+# two launches per direction (26 us per layer fwd + bwd against 35 us for MIOpen's BatchNorm + separate ReLU / add
+# kernels); more ranks: slices -> finish -> all-reduce -> apply, replacing torch SyncBatchNorm's statistics gather +
+# separate activation / add.  "auto": fused only with more than one rank, "0": never (library kernels).
+FUSED_BN = os.environ.get("RSLO_FUSED_BN", "1")
 
 
 def _world(group):
@@ -71,27 +71,33 @@ class _FusedBNActFn(torch.autograd.Function):
         x = x.contiguous()
         res = None if residual is None else residual.contiguous()
         world = _world(group)
-        stats = capi.bn2d_stats(x)
-        if world > 1:
-            dist.all_reduce(stats, group=group)
         track = bn.track_running_stats and bn.running_mean is not None
-        y, mean, invstd = capi.bn2d_apply(x, res, stats, weight, bias, bn.running_mean if track else None,
-                                          bn.running_var if track else None,
-                                          bn.momentum if bn.momentum is not None else 0.0, bn.eps, slope)
-        ctx.save_for_backward(x, y if slope != 1.0 else None, weight, mean, invstd, stats)
+        mom = bn.momentum if bn.momentum is not None else 0.0
+        if world > 1:
+            stats = capi.bn2d_stats(x)
+            dist.all_reduce(stats, group=group)
+            y, mean, invstd = capi.bn2d_apply(x, res, stats, weight, bias, bn.running_mean if track else None,
+                                              bn.running_var if track else None, mom, bn.eps, slope)
+        else:           # one rank: no exchange, the apply kernel adds the slice partials itself (two launches)
+            y, mean, invstd = capi.bn2d_fwd_local(x, res, weight, bias, bn.running_mean if track else None,
+                                                  bn.running_var if track else None, mom, bn.eps, slope)
+        ctx.save_for_backward(x, y if slope != 1.0 else None, weight, mean, invstd)
         ctx.meta = (slope, group, world, residual is not None, weight is not None)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         from rslo_amd import capi
-        x, y, weight, mean, invstd, stats = ctx.saved_tensors
+        x, y, weight, mean, invstd = ctx.saved_tensors
         slope, group, world, has_res, affine = ctx.meta
         gy = gy.contiguous()
         has_act = slope != 1.0
+        if world == 1:
+            dx, dres, dgamma, dbeta = capi.bn2d_bwd_local(gy, y, x, weight, mean, invstd, slope, has_act, has_res,
+                                                          want_affine=affine)
+            return dx, dgamma, dbeta, dres, None, None, None
         red, dgamma, dbeta = capi.bn2d_bwd_reduce(gy, y, x, mean, invstd, slope, has_act, want_affine=affine)
-        if world > 1:
-            dist.all_reduce(red, group=group)
+        dist.all_reduce(red, group=group)
         count = float(x.shape[0] * x.shape[2] * x.shape[3] * world)      # equal batch on every rank (data parallel)
         dx, dres = capi.bn2d_bwd_apply(gy, y, x, weight, mean, invstd, red, count, slope, has_act, has_res)
         return dx, dgamma, dbeta, dres, None, None, None
@@ -114,7 +120,7 @@ class SyncBatchNorm(nn.SyncBatchNorm):
         if FUSED_BN == "0" or not (self.training and isinstance(x, torch.Tensor) and x.is_cuda and x.dim() == 4
                                    and x.dtype == torch.float32):
             return False
-        return FUSED_BN == "1" or _world(self.process_group) > 1
+        return FUSED_BN != "auto" or _world(self.process_group) > 1
 
     def forward(self, x, act_slope=None, residual=None):
         """act_slope / residual: optional fused epilogue  y = act(bn(x) + residual)  (act_slope 0 = ReLU, None = no

@@ -66,26 +66,31 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn2d_stats(const float *__restri
     }
   }
   __shared__ double res[2];
-  __shared__ int is_last;
   bn_block_sum2(s, q, res);
   if (threadIdx.x == 0) {
     part[((int64_t)c * S + sp) * 2 + 0] = res[0];
     part[((int64_t)c * S + sp) * 2 + 1] = res[1];
-    __threadfence();
-    is_last = atomicAdd(&done[c], 1) == S - 1;
-    if (is_last) {
-      __threadfence();
-      double a = 0.0, b = 0.0;
-      for (int k = 0; k < S; ++k) {
-        a += part[((int64_t)c * S + k) * 2 + 0];
-        b += part[((int64_t)c * S + k) * 2 + 1];
-      }
-      stats[c] = a;
-      stats[C + c] = b;
-      if (c == 0) stats[2 * C] = (double)total;
-      done[c] = 0;
-    }
   }
+}
+
+// Second stage of both reductions: one thread per channel adds its S slice partials in slice order.  A separate launch
+// instead of a last-block finish: the device-scope fence a last-block scheme needs writes back the XCD's L2, which on
+// this part costs ~10 us per launch right after a convolution has filled it with dirty lines (measured: 12-24 us per
+// reduction with the fence).
+__global__ void k_bn2d_finish(const double *__restrict__ part, int S, int C, double count, double *__restrict__ out,
+                              float *__restrict__ fa, float *__restrict__ fb) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double a = 0.0, b = 0.0;
+  for (int k = 0; k < S; ++k) {
+    a += part[((int64_t)c * S + k) * 2 + 0];
+    b += part[((int64_t)c * S + k) * 2 + 1];
+  }
+  out[c] = a;
+  out[C + c] = b;
+  if (count >= 0.0 && c == 0) out[2 * C] = count;
+  if (fa) fa[c] = (float)a;
+  if (fb) fb[c] = (float)b;
 }
 
 // y = act(gamma * (x - mean) * invstd + beta (+ res)); one thread per 4 consecutive hw of one (n, c) row when HW % 4 == 0
@@ -95,12 +100,25 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn2d_apply(const float *__restri
                                                            int N, int C, int HW, float eps, float momentum, float slope,
                                                            float *__restrict__ run_mean, float *__restrict__ run_var,
                                                            float *__restrict__ save_mean, float *__restrict__ save_invstd,
-                                                           float *__restrict__ y) {
+                                                           float *__restrict__ y, const double *__restrict__ part,
+                                                           int S) {
   const int row = blockIdx.y;                 // n * C + c
   const int c = row % C;
-  const double cnt = stats[2 * C];
-  const double m = stats[c] / cnt;
-  double var = stats[C + c] / cnt - m * m;
+  double cnt, sum, sumsq;
+  if (part) {                                 // single rank: add the slice partials here (no finish launch)
+    cnt = (double)N * HW;
+    sum = sumsq = 0.0;
+    for (int k = 0; k < S; ++k) {
+      sum += part[((int64_t)c * S + k) * 2 + 0];
+      sumsq += part[((int64_t)c * S + k) * 2 + 1];
+    }
+  } else {
+    cnt = stats[2 * C];
+    sum = stats[c];
+    sumsq = stats[C + c];
+  }
+  const double m = sum / cnt;
+  double var = sumsq / cnt - m * m;
   var = var > 0.0 ? var : 0.0;
   const float mean = (float)m, invstd = (float)(1.0 / sqrt(var + (double)eps));
   const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
@@ -188,26 +206,10 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn2d_bwd_reduce(const float *__r
     }
   }
   __shared__ double res[2];
-  __shared__ int is_last;
   bn_block_sum2(s, q, res);
   if (threadIdx.x == 0) {
     part[((int64_t)c * S + sp) * 2 + 0] = res[0];
     part[((int64_t)c * S + sp) * 2 + 1] = res[1];
-    __threadfence();
-    is_last = atomicAdd(&done[c], 1) == S - 1;
-    if (is_last) {
-      __threadfence();
-      double a = 0.0, b = 0.0;
-      for (int k = 0; k < S; ++k) {
-        a += part[((int64_t)c * S + k) * 2 + 0];
-        b += part[((int64_t)c * S + k) * 2 + 1];
-      }
-      red[c] = a;
-      red[C + c] = b;
-      if (dbeta) dbeta[c] = (float)a;
-      if (dgamma) dgamma[c] = (float)b;
-      done[c] = 0;
-    }
   }
 }
 
@@ -219,11 +221,28 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn2d_bwd_apply(const float *__re
                                                                const float *__restrict__ save_invstd,
                                                                const double *__restrict__ red, double cnt, int C, int HW,
                                                                float slope, int has_act, float *__restrict__ dx,
-                                                               float *__restrict__ dres) {
+                                                               float *__restrict__ dres, const double *__restrict__ part,
+                                                               int S, float *__restrict__ dgamma,
+                                                               float *__restrict__ dbeta) {
   const int row = blockIdx.y, c = row % C;
   const float mean = save_mean[c], invstd = save_invstd[c];
   const float k0 = (gamma ? gamma[c] : 1.f) * invstd;
-  const float mg = (float)(red[c] / cnt), mgx = (float)(red[C + c] / cnt);
+  double ra, rb;
+  if (part) {                                 // single rank: add the slice partials here (no finish launch)
+    ra = rb = 0.0;
+    for (int k = 0; k < S; ++k) {
+      ra += part[((int64_t)c * S + k) * 2 + 0];
+      rb += part[((int64_t)c * S + k) * 2 + 1];
+    }
+    if (row < C && blockIdx.x == 0 && threadIdx.x == 0) {
+      if (dbeta) dbeta[c] = (float)ra;
+      if (dgamma) dgamma[c] = (float)rb;
+    }
+  } else {
+    ra = red[c];
+    rb = red[C + c];
+  }
+  const float mg = (float)(ra / cnt), mgx = (float)(rb / cnt);
   const int64_t base = (int64_t)row * HW;
   const int hw0 = (blockIdx.x * BN_THREADS + threadIdx.x) * 4;
   if (hw0 >= HW) return;
@@ -281,6 +300,9 @@ extern "C" int rslo_bn2d_stats(const float *x, int N, int C, int HW, void *ws, s
   hipLaunchKernelGGL(k_bn2d_stats, dim3(S, C), dim3(BN_THREADS), 0, (hipStream_t)stream, x, N, C, HW, per, (double *)ws,
                      (int *)done, stats);
   RSLO_CHECK_LAUNCH("k_bn2d_stats");
+  hipLaunchKernelGGL(k_bn2d_finish, dim3((unsigned)rslo_cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, (const double *)ws,
+                     S, C, (double)((int64_t)N * HW), stats, (float *)nullptr, (float *)nullptr);
+  RSLO_CHECK_LAUNCH("k_bn2d_finish");
   return RSLO_OK;
 }
 
@@ -291,8 +313,49 @@ extern "C" int rslo_bn2d_apply(const float *x, const float *res, const double *s
   RSLO_CHECK_ARG(x && stats && save_mean && save_invstd && y, "rslo_bn2d_apply: bad arguments");
   dim3 grid((unsigned)rslo_cdiv(rslo_cdiv(HW, 4), BN_THREADS), (unsigned)(N * C));
   hipLaunchKernelGGL(k_bn2d_apply, grid, dim3(BN_THREADS), 0, (hipStream_t)stream, x, res, stats, gamma, beta, N, C, HW,
-                     eps, momentum, act_slope, running_mean, running_var, save_mean, save_invstd, y);
+                     eps, momentum, act_slope, running_mean, running_var, save_mean, save_invstd, y,
+                     (const double *)nullptr, 0);
   RSLO_CHECK_LAUNCH("k_bn2d_apply");
+  return RSLO_OK;
+}
+
+extern "C" int rslo_bn2d_fwd_local(const float *x, const float *res, const float *gamma, const float *beta, int N, int C,
+                                   int HW, float eps, float momentum, float act_slope, float *running_mean,
+                                   float *running_var, float *save_mean, float *save_invstd, float *y, void *ws,
+                                   size_t ws_bytes, void *stream) {
+  RSLO_CHECK_ARG(x && ws && save_mean && save_invstd && y && N >= 1 && C >= 1 && HW >= 1, "rslo_bn2d_fwd_local: bad arguments");
+  RSLO_CHECK_ARG(ws_bytes >= rslo_bn2d_ws_bytes(N, C, HW), "rslo_bn2d_fwd_local: workspace too small");
+  int S;
+  const int64_t per = bn_per_blk(N, C, HW, &S);
+  hipLaunchKernelGGL(k_bn2d_stats, dim3(S, C), dim3(BN_THREADS), 0, (hipStream_t)stream, x, N, C, HW, per, (double *)ws,
+                     (int *)nullptr, (double *)nullptr);
+  RSLO_CHECK_LAUNCH("k_bn2d_stats");
+  dim3 grid((unsigned)rslo_cdiv(rslo_cdiv(HW, 4), BN_THREADS), (unsigned)(N * C));
+  hipLaunchKernelGGL(k_bn2d_apply, grid, dim3(BN_THREADS), 0, (hipStream_t)stream, x, res, (const double *)nullptr, gamma,
+                     beta, N, C, HW, eps, momentum, act_slope, running_mean, running_var, save_mean, save_invstd, y,
+                     (const double *)ws, S);
+  RSLO_CHECK_LAUNCH("k_bn2d_apply");
+  return RSLO_OK;
+}
+
+extern "C" int rslo_bn2d_bwd_local(const float *dy, const float *y, const float *x, const float *gamma,
+                                   const float *save_mean, const float *save_invstd, int N, int C, int HW,
+                                   float act_slope, int has_act, float *dx, float *dres, float *dgamma, float *dbeta,
+                                   void *ws, size_t ws_bytes, void *stream) {
+  RSLO_CHECK_ARG(dy && x && save_mean && save_invstd && ws && dx, "rslo_bn2d_bwd_local: bad arguments");
+  RSLO_CHECK_ARG(!has_act || y, "rslo_bn2d_bwd_local: y is needed for the activation mask");
+  RSLO_CHECK_ARG(ws_bytes >= rslo_bn2d_ws_bytes(N, C, HW), "rslo_bn2d_bwd_local: workspace too small");
+  int S;
+  const int64_t per = bn_per_blk(N, C, HW, &S);
+  hipLaunchKernelGGL(k_bn2d_bwd_reduce, dim3(S, C), dim3(BN_THREADS), 0, (hipStream_t)stream, dy, y, x, save_mean,
+                     save_invstd, N, C, HW, per, act_slope, has_act, (double *)ws, (int *)nullptr, (double *)nullptr,
+                     (float *)nullptr, (float *)nullptr);
+  RSLO_CHECK_LAUNCH("k_bn2d_bwd_reduce");
+  dim3 grid((unsigned)rslo_cdiv(rslo_cdiv(HW, 4), BN_THREADS), (unsigned)(N * C));
+  hipLaunchKernelGGL(k_bn2d_bwd_apply, grid, dim3(BN_THREADS), 0, (hipStream_t)stream, dy, y, x, gamma, save_mean,
+                     save_invstd, (const double *)nullptr, (double)((int64_t)N * HW), C, HW, act_slope, has_act, dx, dres,
+                     (const double *)ws, S, dgamma, dbeta);
+  RSLO_CHECK_LAUNCH("k_bn2d_bwd_apply");
   return RSLO_OK;
 }
 
@@ -308,6 +371,9 @@ extern "C" int rslo_bn2d_bwd_reduce(const float *dy, const float *y, const float
   hipLaunchKernelGGL(k_bn2d_bwd_reduce, dim3(S, C), dim3(BN_THREADS), 0, (hipStream_t)stream, dy, y, x, save_mean,
                      save_invstd, N, C, HW, per, act_slope, has_act, (double *)ws, (int *)done, red, dgamma, dbeta);
   RSLO_CHECK_LAUNCH("k_bn2d_bwd_reduce");
+  hipLaunchKernelGGL(k_bn2d_finish, dim3((unsigned)rslo_cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, (const double *)ws,
+                     S, C, -1.0, red, dbeta, dgamma);
+  RSLO_CHECK_LAUNCH("k_bn2d_finish");
   return RSLO_OK;
 }
 
@@ -318,7 +384,8 @@ extern "C" int rslo_bn2d_bwd_apply(const float *dy, const float *y, const float 
   RSLO_CHECK_ARG(dy && x && save_mean && save_invstd && red && dx && count > 0, "rslo_bn2d_bwd_apply: bad arguments");
   dim3 grid((unsigned)rslo_cdiv(rslo_cdiv(HW, 4), BN_THREADS), (unsigned)(N * C));
   hipLaunchKernelGGL(k_bn2d_bwd_apply, grid, dim3(BN_THREADS), 0, (hipStream_t)stream, dy, y, x, gamma, save_mean,
-                     save_invstd, red, count, C, HW, act_slope, has_act, dx, dres);
+                     save_invstd, red, count, C, HW, act_slope, has_act, dx, dres, (const double *)nullptr, 0,
+                     (float *)nullptr, (float *)nullptr);
   RSLO_CHECK_LAUNCH("k_bn2d_bwd_apply");
   return RSLO_OK;
 }

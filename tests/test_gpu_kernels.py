@@ -431,7 +431,7 @@ def test_fused_bn2d_act_matches_torch(hip, slope, with_res):
             assert mine.fusable(x)
             y2 = mine(x, act_slope=slope, residual=res)
         finally:
-            AP.FUSED_BN = "auto"
+            AP.FUSED_BN = os.environ.get("RSLO_FUSED_BN", "1")
         (y2 * gy).sum().backward()
         assert float((y2 - y).abs().max()) < 2e-5
         assert float((mine.running_mean - ref.running_mean).abs().max()) < 1e-6
