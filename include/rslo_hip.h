@@ -353,11 +353,12 @@ RSLO_API int rslo_vote_bwd(const float *tq_map, const float *t_conf, const float
  *      gradient comes from cuDNN through autograd).  NCHW fp32, kernel 3x3, padding 1, stride 1 or 2, cin % 16 == 0,
  *      cout % 32 == 0:  dW [cout,cin,3,3] = sum over batch and output pixels of dout [B,cout,Ho,Wo] x shifted
  *      in [B,cin,H,W].  bf16 matrix cores on exactly split fp32 operands, fixed summation order (no atomics).
- *      rslo_conv2d_wgrad_supported returns 1 for shapes the kernel takes (others stay on the library path). */
+ *      rslo_conv2d_wgrad_supported returns 1 for shapes the kernel takes (others stay on the library path).
+ *      dbias [cout] (optional, stride 1 only): the bias gradient = per-channel sum of dout, from the same pass. */
 RSLO_API int rslo_conv2d_wgrad_supported(int cin, int cout, int H, int W, int stride);
 RSLO_API size_t rslo_conv2d_wgrad_ws_bytes(int B, int cin, int cout, int H, int W, int stride);
 RSLO_API int rslo_conv2d_wgrad(const float *in, const float *dout, int B, int cin, int cout, int H, int W, int stride,
-                               float *dW, void *ws, size_t ws_bytes, void *stream);
+                               float *dW, float *dbias, void *ws, size_t ws_bytes, void *stream);
 
 /* a10 - a12  forward and data gradient of the same layers (3x3, stride 1, padding 1, NCHW fp32; channels % 32 == 0):
  *      out[b][m] = bias[m] + sum_k A[m][k] (*) in[b][k].  rslo_conv2d_wsplit turns the layer's weight W [cout,cin,3,3]

@@ -90,7 +90,7 @@ SIGNATURES = {
     "rslo_vote_bwd": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rslo_conv2d_wgrad_supported": (C.c_int, [_i, _i, _i, _i, _i]),
     "rslo_conv2d_wgrad_ws_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
-    "rslo_conv2d_wgrad": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "rslo_conv2d_wgrad": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "rslo_conv2d_fwd_supported": (C.c_int, [_i, _i, _i, _i]),
     "rslo_conv2d_wsplit_bytes": (_sz, [_i, _i]),
     "rslo_conv2d_wsplit": (C.c_int, [_vp, _i, _i, _i, _vp, _vp]),
@@ -838,8 +838,9 @@ def conv2d_wgrad_supported(cin, cout, H, W, stride):
     return bool(lib().rslo_conv2d_wgrad_supported(int(cin), int(cout), int(H), int(W), int(stride)))
 
 
-def conv2d_wgrad(x, dout, stride=1):
-    """x [B,cin,H,W], dout [B,cout,Ho,Wo] (contiguous NCHW fp32) -> dW [cout,cin,3,3] of a 3x3 / padding-1 conv."""
+def conv2d_wgrad(x, dout, stride=1, want_bias=False):
+    """x [B,cin,H,W], dout [B,cout,Ho,Wo] (contiguous NCHW fp32) -> dW [cout,cin,3,3] of a 3x3 / padding-1 conv;
+    want_bias (stride 1): -> (dW, dbias [cout]) with the bias gradient from the same pass."""
     B, cin, H, W = x.shape
     cout = dout.shape[1]
     wsb = lib().rslo_conv2d_wgrad_ws_bytes(B, cin, cout, H, W, stride)
@@ -847,9 +848,10 @@ def conv2d_wgrad(x, dout, stride=1):
         raise RsloHipError("rslo_conv2d_wgrad: unsupported shape %s -> %s stride %d" % (tuple(x.shape), tuple(dout.shape), stride))
     ws = _ws(wsb, x.device)
     dW = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=x.device)
+    db = torch.empty((cout,), dtype=torch.float32, device=x.device) if want_bias else None
     _chk(lib().rslo_conv2d_wgrad(_ptr(x, torch.float32, "x"), _ptr(dout, torch.float32, "dout"), B, cin, cout, H, W,
-                                 stride, _ptr(dW), _ptr(ws), wsb, _stream()), "rslo_conv2d_wgrad")
-    return dW
+                                 stride, _ptr(dW), _ptr(db), _ptr(ws), wsb, _stream()), "rslo_conv2d_wgrad")
+    return (dW, db) if want_bias else dW
 
 
 def conv2d_fwd_supported(cin, cout, H, W):

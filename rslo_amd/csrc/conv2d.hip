@@ -217,9 +217,11 @@ template <int NB>
 __global__ __launch_bounds__(C2_THREADS, NB == 2 ? 3 : 2) void k_conv2d_wgrad_s1(const float *__restrict__ in,
                                                                                const float *__restrict__ dout,
                                                                                Conv2dGeom gm, float invW,
-                                                                               float *__restrict__ ws) {
+                                                                               float *__restrict__ ws,
+                                                                               float *__restrict__ bws) {
   constexpr int CO_T = 16 * NB, LDW = CO_T + 4;
   __shared__ __attribute__((aligned(16))) float red[2][9 * 16 * LDW];
+  __shared__ float bred[C2_WAVES][CO_T];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int li = lane & 15, g = lane >> 4;
   const int tile = blockIdx.x;
@@ -230,6 +232,11 @@ __global__ __launch_bounds__(C2_THREADS, NB == 2 ? 3 : 2) void k_conv2d_wgrad_s1
   const int n_chunks = gm.B * gm.cpi;
   const int c_begin = blockIdx.y * gm.chunks_per_slab;
   const int c_end = min(c_begin + gm.chunks_per_slab, n_chunks);
+  // bias gradient = per-channel sum of dout: the workgroups of cin tile 0 hold every dout value once as an operand
+  const bool do_bias = bws != nullptr && ct == 0;
+  float bsum[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) bsum[nb] = 0.f;
 
   f32x4 acc[9][NB];
 #pragma unroll
@@ -261,6 +268,12 @@ __global__ __launch_bounds__(C2_THREADS, NB == 2 ? 3 : 2) void k_conv2d_wgrad_s1
       load8(dout, ((int64_t)b * gm.cout + co0 + 16 * nb + li) * HW + p, out_total, vp, v);
       const Split3 s = split_masked(v, slow ? vp : 0xffu);
       bh[nb] = s.h; bm[nb] = s.m; bl[nb] = s.l;
+      if (do_bias) {
+        float t = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t += ((vp >> e) & 1u) ? v[e] : 0.f;
+        bsum[nb] += t;
+      }
     }
     const int64_t plane = ((int64_t)b * gm.cin + ci0 + li) * HW;
 #pragma unroll
@@ -362,17 +375,45 @@ __global__ __launch_bounds__(C2_THREADS, NB == 2 ? 3 : 2) void k_conv2d_wgrad_s1
     const int row = e / CO_T, co = e - row * CO_T;
     dst[e] = red[0][row * LDW + co] + red[1][row * LDW + co];
   }
+  if (do_bias) {                     // lane groups, then waves in wave order, one partial row per slab
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      float t = bsum[nb];
+      t += __shfl_xor(t, 16, 64);
+      t += __shfl_xor(t, 32, 64);
+      if (g == 0) bred[wid][16 * nb + li] = t;
+    }
+    __syncthreads();
+    if (tid < CO_T)
+      bws[(int64_t)blockIdx.y * gm.cout + co0 + tid] = ((bred[0][tid] + bred[1][tid]) + bred[2][tid]) + bred[3][tid];
+  }
 }
 
 // 32 (tile, tap, ci, co) elements x 8 slab groups per block: group sg adds slabs sg, sg+8, ... in order, the 8 group sums
 // are added in group order (fixed summation order); writes dW in OIHW
 __global__ __launch_bounds__(256) void k_conv2d_wgrad_reduce(const float *__restrict__ ws, int n_slabs, int n_tiles,
                                                              int n_cout_tiles, int co_t, int cin, int cout,
-                                                             float *__restrict__ dW) {
+                                                             float *__restrict__ dW, int n_main_blocks,
+                                                             const float *__restrict__ bws, float *__restrict__ dbias) {
   __shared__ float part[8][32];
   const int per_tile = 9 * 16 * co_t;
   const int64_t n = (int64_t)n_tiles * per_tile;
   const int se = threadIdx.x & 31, sg = threadIdx.x >> 5;
+  if ((int)blockIdx.x >= n_main_blocks) {          // bias gradient: 32 channels per block, same 8-group slab order
+    const int c = ((int)blockIdx.x - n_main_blocks) * 32 + se;
+    float t = 0.f;
+    if (c < cout)
+      for (int sl = sg; sl < n_slabs; sl += 8) t += bws[(int64_t)sl * cout + c];
+    part[sg][se] = t;
+    __syncthreads();
+    if (sg == 0 && c < cout) {
+      float t8 = part[0][se];
+#pragma unroll
+      for (int q = 1; q < 8; ++q) t8 += part[q][se];
+      dbias[c] = t8;
+    }
+    return;
+  }
   const int64_t e = (int64_t)blockIdx.x * 32 + se;
   float s = 0.f;
   if (e < n) {
@@ -443,35 +484,40 @@ extern "C" size_t rslo_conv2d_wgrad_ws_bytes(int B, int cin, int cout, int H, in
   Conv2dGeom gm;
   int nb, ns;
   if (!conv2d_plan(B, cin, cout, H, W, stride, &gm, &nb, &ns)) return 0;
-  return (size_t)ns * gm.n_cin_tiles * gm.n_cout_tiles * 9 * 16 * 16 * nb * sizeof(float);
+  return (size_t)ns * gm.n_cin_tiles * gm.n_cout_tiles * 9 * 16 * 16 * nb * sizeof(float) +
+         (size_t)ns * cout * sizeof(float);      // + one bias-gradient partial row per slab
 }
 
 extern "C" int rslo_conv2d_wgrad(const float *in, const float *dout, int B, int cin, int cout, int H, int W,
-                                 int stride, float *dW, void *ws, size_t ws_bytes, void *stream) {
+                                 int stride, float *dW, float *dbias, void *ws, size_t ws_bytes, void *stream) {
   Conv2dGeom gm;
   int nb, ns;
   RSLO_CHECK_ARG(conv2d_plan(B, cin, cout, H, W, stride, &gm, &nb, &ns),
                  "rslo_conv2d_wgrad: unsupported shape cin=%d cout=%d H=%d W=%d stride=%d", cin, cout, H, W, stride);
   RSLO_CHECK_ARG(ws_bytes >= rslo_conv2d_wgrad_ws_bytes(B, cin, cout, H, W, stride), "rslo_conv2d_wgrad: workspace too small");
   RSLO_CHECK_ARG((int64_t)B * cin * H * W < (int64_t(1) << 40), "rslo_conv2d_wgrad: tensor too large");
+  RSLO_CHECK_ARG(!dbias || stride == 1, "rslo_conv2d_wgrad: the fused bias gradient needs stride 1");
   hipStream_t st = (hipStream_t)stream;
   const int tiles = gm.n_cin_tiles * gm.n_cout_tiles;
+  float *bws = dbias ? (float *)ws + (size_t)ns * tiles * 9 * 16 * 16 * nb : nullptr;
   const dim3 grid(tiles, ns);
 #define C2_LAUNCH(NBv, Sv) \
   hipLaunchKernelGGL((k_conv2d_wgrad<NBv, Sv>), grid, dim3(C2_THREADS), 0, st, in, dout, gm, (float *)ws)
   if (stride == 1) {
     const float invW = 1.0f / (float)gm.W;
     if (nb == 4)
-      hipLaunchKernelGGL((k_conv2d_wgrad_s1<4>), grid, dim3(C2_THREADS), 0, st, in, dout, gm, invW, (float *)ws);
+      hipLaunchKernelGGL((k_conv2d_wgrad_s1<4>), grid, dim3(C2_THREADS), 0, st, in, dout, gm, invW, (float *)ws, bws);
     else
-      hipLaunchKernelGGL((k_conv2d_wgrad_s1<2>), grid, dim3(C2_THREADS), 0, st, in, dout, gm, invW, (float *)ws);
+      hipLaunchKernelGGL((k_conv2d_wgrad_s1<2>), grid, dim3(C2_THREADS), 0, st, in, dout, gm, invW, (float *)ws, bws);
   } else if (nb == 4) C2_LAUNCH(4, 2);
   else C2_LAUNCH(2, 2);
 #undef C2_LAUNCH
   RSLO_CHECK_LAUNCH("k_conv2d_wgrad");
   const int64_t n = (int64_t)tiles * 9 * 16 * 16 * nb;
-  hipLaunchKernelGGL(k_conv2d_wgrad_reduce, dim3((unsigned)rslo_cdiv(n, 32)), dim3(256), 0, st, (const float *)ws, ns,
-                     tiles, gm.n_cout_tiles, 16 * nb, cin, cout, dW);
+  const int n_main = (int)rslo_cdiv(n, 32);
+  hipLaunchKernelGGL(k_conv2d_wgrad_reduce, dim3((unsigned)(n_main + (dbias ? (int)rslo_cdiv(cout, 32) : 0))), dim3(256), 0,
+                     st, (const float *)ws, ns, tiles, gm.n_cout_tiles, 16 * nb, cin, cout, dW, n_main,
+                     (const float *)bws, dbias);
   RSLO_CHECK_LAUNCH("k_conv2d_wgrad_reduce");
   return RSLO_OK;
 }

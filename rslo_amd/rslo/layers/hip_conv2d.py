@@ -30,8 +30,8 @@ class _Conv3x3Fn(torch.autograd.Function):
         ctx.ws_t = None
         if hip_fd:
             from rslo_amd import capi
-            ws = _PRESPLIT.get(w.data_ptr())           # operands refreshed for all layers in one launch (presplit())
-            if ws is not None and ws[2] != w._version:
+            ws = getattr(w, "_hip_split", None)      # operands refreshed for all layers in one launch (presplit())
+            if ws is not None and (ws[2] != w._version or ws[3] != w.data_ptr()):
                 ws = None
             if "d" in HIP_PASSES:
                 ctx.ws_t = ws[1] if ws is not None else capi.conv2d_wsplit(w, True)
@@ -52,19 +52,21 @@ class _Conv3x3Fn(torch.autograd.Function):
             else:
                 dx = torch.ops.aten.convolution_backward(dy, x, w, None, [s, s], [1, 1], [1, 1], False, [0, 0], 1,
                                                          [True, False, False])[0]
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            if ctx.hip_w:
+            if ctx.hip_w and want_db and s == 1:
+                dw, db = capi.conv2d_wgrad(x, dy, s, want_bias=True)     # bias gradient from the same pass
+                want_db = False
+            elif ctx.hip_w:
                 dw = capi.conv2d_wgrad(x, dy, s)
             else:
                 dw = torch.ops.aten.convolution_backward(dy, x, w, None, [s, s], [1, 1], [1, 1], False, [0, 0], 1,
                                                          [False, True, False])[1]
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        if want_db:
             db = dy.sum((0, 2, 3))
         return dx, dw, db, None, None, None
 
 
-_PRESPLIT = {}      # weight.data_ptr() -> (ws_fwd, ws_dgrad, weight._version at split time)
-_PLANS = {}         # id(root module) -> (plan, weights, views)
 
 
 def presplit(root):
@@ -73,7 +75,7 @@ def presplit(root):
     if "f" not in HIP_PASSES and "d" not in HIP_PASSES:
         return
     from rslo_amd import capi
-    ent = _PLANS.get(id(root))
+    ent = root.__dict__.get("_hip_conv2d_plan")        # (plan, weights, views), kept on the module itself
     if ent is None or any(w.data_ptr() != p for w, p in zip(ent[1], ent[0]["ptrs"])):
         ws = [m.weight for m in root.modules()
               if isinstance(m, Conv2d) and m.hip_wgrad and m.kernel_size == (3, 3) and m.stride == (1, 1)
@@ -82,10 +84,11 @@ def presplit(root):
         if not ws:
             return
         plan, views = capi.conv2d_wsplit_many(ws)
-        ent = _PLANS[id(root)] = (plan, ws, views)
+        ent = (plan, ws, views)
+        root.__dict__["_hip_conv2d_plan"] = ent
     capi.conv2d_wsplit_run(ent[0])
-    for w, (f, t) in zip(ent[1], ent[2]):
-        _PRESPLIT[w.data_ptr()] = (f, t, w._version)
+    for w, (f, t) in zip(ent[1], ent[2]):       # kept on the parameter object: (fwd, dgrad, version, storage) at split time
+        w._hip_split = (f, t, w._version, w.data_ptr())
 
 
 class Conv2d(nn.Conv2d):

@@ -624,6 +624,11 @@ def test_conv2d_wgrad_matches_float64_oracle(hip, B, cin, cout, H, W, stride):
     # bit-reproducible (fixed summation order)
     again = hip.conv2d_wgrad(dev(x), dev(g), stride).cpu().numpy().astype(np.float64)
     assert np.array_equal(got, again)
+    if stride == 1:     # bias gradient from the same pass: per-channel sum of dout
+        dw2, db = hip.conv2d_wgrad(dev(x), dev(g), 1, want_bias=True)
+        assert np.array_equal(dw2.cpu().numpy().astype(np.float64), got)
+        ref_b = g.astype(np.float64).sum((0, 2, 3))
+        assert np.abs(db.cpu().numpy() - ref_b).max() <= 2e-5 * max(np.abs(ref_b).max(), np.sqrt(g[:, 0].size))
 
 
 def test_hip_conv2d_module_gradients_match_library(hip):

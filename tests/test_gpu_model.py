@@ -328,6 +328,11 @@ def test_prefetched_example_equals_inline(hip):
     for i, clouds in enumerate(batches):
         ex = pf.get()
         assert "sparse_plan" in ex
+        inline = workload.make_example(net2, clouds)        # the example itself is bit-identical to the in-line one
+        for key in ("voxels", "coordinates", "num_points"):
+            assert len(ex[key]) == len(inline[key])
+            for a, b in zip(ex[key], inline[key]):
+                assert torch.equal(a, b), key
         r = net2(ex)
         if i + 1 < len(batches):
             pf.submit(batches[i + 1])
@@ -336,8 +341,9 @@ def test_prefetched_example_equals_inline(hip):
         # two runs of the SAME path already differ at the 1e-6 level (library BN/conv reductions are not run-to-run
         # bit-stable) and a nearest-neighbour or ROI-threshold tie that flips moves the loss by ~2e-5
         # (scripts/determinism.py shows the same spread with and without the prefetcher)
-        assert rel(r["loss"], ref[i][0]) < 1e-4 and rel(r["translation_preds"], ref[i][1]) < 1e-4
-        assert rel(g, ref[i][2]) < 2e-2
+        # -- so the numeric comparison only guards against a wrong example, not against those flips
+        assert rel(r["loss"], ref[i][0]) < 5e-4 and rel(r["translation_preds"], ref[i][1]) < 5e-4
+        assert rel(g, ref[i][2]) < 5e-2
         net2.zero_grad(set_to_none=True)
     pf.close()
 
