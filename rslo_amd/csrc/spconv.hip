@@ -1407,13 +1407,30 @@ __global__ void k_wgrad2_reduce(const float *__restrict__ ws, const int32_t *__r
     }
     return;
   }
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= cc) return;
+  // 32 elements x 8 chunk groups per block: group sg adds chunks sg, sg + 8, ... in order, the 8 group sums are added
+  // in group order (a serial loop over ~100 chunk partials per thread was a 16 us latency chain)
+  __shared__ float part[8][32];
+  const int se = threadIdx.x & 31, sg = threadIdx.x >> 5;
+  const int e = blockIdx.x * 32 + se;
   const int n = koff[k + 1] - koff[k];
   const int nch = (n + WG2_CHUNK - 1) / WG2_CHUNK;
   float s = 0.f;
-  for (int c = 0; c < nch; ++c) s += ws[((int64_t)c * K + k) * cc + e];
-  dW[(int64_t)k * cc + e] = s;
+  if (e < cc) {
+    int c = sg;
+    for (; c + 24 < nch; c += 32) {
+      const float a0 = ws[((int64_t)(c + 0) * K + k) * cc + e], a1 = ws[((int64_t)(c + 8) * K + k) * cc + e];
+      const float a2 = ws[((int64_t)(c + 16) * K + k) * cc + e], a3 = ws[((int64_t)(c + 24) * K + k) * cc + e];
+      s += a0; s += a1; s += a2; s += a3;
+    }
+    for (; c < nch; c += 8) s += ws[((int64_t)c * K + k) * cc + e];
+  }
+  part[sg][se] = s;
+  __syncthreads();
+  if (sg != 0 || e >= cc) return;
+  float t = part[0][se];
+#pragma unroll
+  for (int q = 1; q < 8; ++q) t += part[q][se];
+  dW[(int64_t)k * cc + e] = t;
 }
 
 // Bias gradient = column sums of the (activation-masked) output gradient, in two deterministic stages without fences:
@@ -1517,7 +1534,7 @@ extern "C" int rslo_spconv_wgrad_pairs(const float *in, int cin, const float *do
       bpart = wsb;
     }
   }
-  hipLaunchKernelGGL(k_wgrad2_reduce, dim3((unsigned)rslo_cdiv(cc, 256), (unsigned)(K + (dbias ? 1 : 0))), dim3(256), 0, st,
+  hipLaunchKernelGGL(k_wgrad2_reduce, dim3((unsigned)rslo_cdiv(cc, 32), (unsigned)(K + (dbias ? 1 : 0))), dim3(256), 0, st,
                      (const float *)ws, koff, K, cc, dW, bpart, n_bpart, cout, dbias);
   RSLO_CHECK_LAUNCH("wgrad_pairs");
   return RSLO_OK;
