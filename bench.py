@@ -115,7 +115,7 @@ class ConvProbe:
             return ("dense", 2 * B * H * W * cin * cout * 9, 4 * B * H * W * (cin + cout) + 54 * cin * cout,
                     "k_conv2d_fwd<4, 1, true> [%d->%d %dx%d]" % (cin, cout, H, W))
 
-        def c2w_meta(x, dout, stride=1):
+        def c2w_meta(x, dout, stride=1, want_bias=False):
             B, cin, H, W = x.shape
             cout, Ho, Wo = dout.shape[1], dout.shape[2], dout.shape[3]
             return ("dense", 2 * B * Ho * Wo * cin * cout * 9, 4 * B * (H * W * cin + Ho * Wo * cout) + 36 * cin * cout,
@@ -305,9 +305,13 @@ def main():
         for _ in range(depth):
             prefetch.submit(clouds)
 
+    wait = [0.0]
+
     def step():
         if prefetch is not None:
+            tw = time.perf_counter()
             ex = prefetch.get()
+            wait[0] += time.perf_counter() - tw
         elif fixed_example is not None:
             ex = dict(fixed_example)
         else:
@@ -342,6 +346,7 @@ def main():
     barrier()
     # per-launch HIP events on the last PROBE_STEPS timed steps only (the events themselves cost host time)
     probe_steps = min(3, args.steps)
+    wait[0] = 0.0
     t0 = time.perf_counter()
     cpu0 = time.thread_time()           # CPU time of the issuing thread: close to the wall time = host-bound step
     for i in range(args.steps):
@@ -385,6 +390,7 @@ def main():
                        "voxelize_in_step": not args.no_voxelize, "voxelize_prefetch_stream": prefetch is not None,
                        "optimizer_in_step": not args.no_optim,
                        "host_issue_ms_per_step": round(1e3 * cpu_issue / args.steps, 3),
+                       "prefetch_wait_ms_per_step": round(1e3 * wait[0] / args.steps, 3),
                        "final_loss": round(loss_val, 4)},
             "roofline": roof,
             "cpu_baseline": None,
