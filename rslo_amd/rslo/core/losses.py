@@ -216,7 +216,8 @@ def pose_l2_losses(T_pred, T_tgt, R_pred, R_tgt, loss_T, loss_R):
     together on one [B,7] difference: -> (T_loss [1], R_loss [1])."""
     d = torch.cat([T_pred - T_tgt, R_pred - R_tgt], 1)
     sq = d * d
-    loss_b = torch.stack([sq[:, :3].sum(1) / (3 + 1e-12), sq[:, 3:].sum(1) / (4 + 1e-12)], 1)     # mask = ones
+    sq_t, sq_r = sq.split([3, 4], dim=1)
+    loss_b = torch.stack([sq_t.sum(1) / (3 + 1e-12), sq_r.sum(1) / (4 + 1e-12)], 1)     # mask = ones
     out = _adaptive_reduce_pair(loss_b, loss_T, loss_R)
     return out[0:1], out[1:2]
 
@@ -231,7 +232,8 @@ def span_cov2(cov_param):
     l2 = l1 + p[:, 1]
     l3 = l2 + p[:, 2]
     lam = torch.stack([l1, l2, l3], -1)
-    q = p[:, 3:] / (torch.norm(p[:, 3:], dim=-1, keepdim=True) + 1e-9)
+    pq = p[:, 3:]
+    q = pq / (torch.norm(pq, dim=-1, keepdim=True) + 1e-9)
     V = kornia.quaternion_to_rotation_matrix(q)
     sigma = (V * lam[:, None, :]) @ V.transpose(-1, -2)
     return sigma.reshape(*shp, 3, 3), V.reshape(*shp, 3, 3)

@@ -124,7 +124,8 @@ class UNOdomPredEncDecSVDTempMaskBase(OdomPredEncDecBase):
         x_tail = x
 
         tq_map = self.tq_map_conv(x)
-        tq_map = torch.cat([tq_map[:, :3], tq_map[:, 3:] / torch.norm(tq_map[:, 3:], dim=1, keepdim=True)], dim=1)
+        t_part, q_part = tq_map.split([3, 4], dim=1)      # one split: its backward is one cat, not 3 x (zeros + copy)
+        tq_map = torch.cat([t_part, q_part / torch.norm(q_part, dim=1, keepdim=True)], dim=1)
 
         if not self.dense_predict:
             raise NotImplementedError("the fc (non-dense) head is outside the RSLO hot path")
@@ -148,7 +149,7 @@ class UNOdomPredEncDecSVDTempMaskBase(OdomPredEncDecBase):
 
         translations, rotations = [], []
         for o in odoms:
-            t, r = o[:, :3], o[:, 3:]
+            t, r = o.split([3, 4], dim=1)
             if self.odom_format == "r(x+t)":
                 t = rotate_vec_by_q(t, r)
             r = r / (torch.norm(r, dim=1, keepdim=True) + 1e-12)
@@ -162,22 +163,35 @@ class UNOdomPredEncDecSVDTempMaskBase(OdomPredEncDecBase):
         snap = []
         if not self.training:
             return snap
-        for mod in modules:
-            for m in mod.modules():
-                if isinstance(m, nn.modules.batchnorm._BatchNorm) and m.training and m.track_running_stats:
-                    snap.append((m, m.running_mean.clone(), m.running_var.clone()))
+        bns = [m for mod in modules for m in mod.modules()
+               if isinstance(m, nn.modules.batchnorm._BatchNorm) and m.training and m.track_running_stats]
+        if bns and bns[0].running_mean.is_cuda:      # all copies in one multi-tensor launch
+            cp = torch._foreach_add([b for m in bns for b in (m.running_mean.data, m.running_var.data)], 0.0)
+            return [(m, cp[2 * i], cp[2 * i + 1]) for i, m in enumerate(bns)]
+        for m in bns:
+            snap.append((m, m.running_mean.clone(), m.running_var.clone()))
         return snap
 
     @staticmethod
     def _replay_bn_update(snap):
         """Apply the SAME momentum update once more: r1 = (1-m) r0 + m v  =>  r2 = (1-m) r1 + m v = 2 r1 - r0
         + m (r0 - r1)... written with v eliminated: r2 = r1 + (1 - m) (r1 - r0)."""
-        for m, mean0, var0 in snap:
-            mom = m.momentum
-            # through .data: the first pass's autograd node holds these buffers (training-mode backward never reads
-            # them), and the reference's second forward updates them in place all the same
-            m.running_mean.data.add_((m.running_mean.data - mean0) * (1.0 - mom))
-            m.running_var.data.add_((m.running_var.data - var0) * (1.0 - mom))
+        if not snap:
+            return
+        # through .data: the first pass's autograd node holds these buffers (training-mode backward never reads them),
+        # and the reference's second forward updates them in place all the same; all layers in three multi-tensor ops
+        cur = [b for m, _, _ in snap for b in (m.running_mean.data, m.running_var.data)]
+        old = [b for _, mean0, var0 in snap for b in (mean0, var0)]
+        moms = {m.momentum for m, _, _ in snap}
+        if cur[0].is_cuda and len(moms) == 1:
+            delta = torch._foreach_sub(cur, old)
+            torch._foreach_mul_(delta, 1.0 - moms.pop())
+            torch._foreach_add_(cur, delta)
+        else:
+            for m, mean0, var0 in snap:
+                m.running_mean.data.add_((m.running_mean.data - mean0) * (1.0 - m.momentum))
+                m.running_var.data.add_((m.running_var.data - var0) * (1.0 - m.momentum))
+        for m, _, _ in snap:
             _count_batch(m)
 
     def vote(self, tq_map, t_conf, r_conf):
