@@ -391,6 +391,8 @@ def main():
                        "optimizer_in_step": not args.no_optim,
                        "host_issue_ms_per_step": round(1e3 * cpu_issue / args.steps, 3),
                        "prefetch_wait_ms_per_step": round(1e3 * wait[0] / args.steps, 3),
+                       "prefetch_thread_cpu_ms_per_step": (round(1e3 * prefetch.cpu_seconds / max(prefetch.jobs, 1), 3)
+                                                           if prefetch is not None and hasattr(prefetch, "jobs") else None),
                        "final_loss": round(loss_val, 4)},
             "roofline": roof,
             "cpu_baseline": None,

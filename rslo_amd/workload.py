@@ -108,6 +108,8 @@ class ExamplePrefetcher:
             if job is None:
                 return
             clouds, prev_done = job
+            import time
+            c0 = time.thread_time()
             try:
                 if prev_done is not None:
                     prev_done.synchronize()          # everything older than the previous step has left the GPU
@@ -119,6 +121,8 @@ class ExamplePrefetcher:
                     ready = torch.cuda.Event()
                     ready.record(self.stream)
                 self._keep.append(ex)
+                self.cpu_seconds = getattr(self, "cpu_seconds", 0.0) + (time.thread_time() - c0)
+                self.jobs = getattr(self, "jobs", 0) + 1
                 self._out.put((ex, ready, None))
             except Exception as e:      # surface in get()
                 self._out.put((None, None, e))
