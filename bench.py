@@ -47,6 +47,14 @@ def parse():
     return ap.parse_args()
 
 
+def _flush_c_stdio():
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+
+
 # --------------------------------------------------------------------------------------------- kernel events
 class ConvProbe:
     """Wraps the sparse-conv C-ABI calls with HIP events on the launching stream and records the
@@ -283,6 +291,10 @@ def main():
         # find_unused_parameters=True (77 of 290 tensors never get a gradient) costs ~8 ms of host time per step here.
         from rslo.utils.distributed_utils import average_gradients, broadcast_params
         broadcast_params(net, 0)
+        # RCCL writes its version banner (NCCL_DEBUG=VERSION on this pool) through C stdio, which would otherwise be
+        # flushed at process exit, AFTER the JSON line: push it out now, on every rank
+        torch.cuda.synchronize()
+        _flush_c_stdio()
     params = [p for p in net.parameters() if p.requires_grad]
     # the reference's training step: 8-group Adam behind OptimWrapper (decoupled weight decay) + OneCycle schedule,
     # built from the shipped train_config (train_hdf5.py:408-411,478-480,618,661-674)
@@ -402,10 +414,12 @@ def main():
                 line["cpu_baseline"] = cpu_baseline(args)
             except Exception as e:   # the baseline is informational; never lose the measurement over it
                 line["cpu_baseline"] = {"error": repr(e)}
-        print(json.dumps(line), flush=True)
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()
+    _flush_c_stdio()                 # anything the collectives library still holds goes out before the result
+    if rank == 0:
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":
