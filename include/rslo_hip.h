@@ -130,6 +130,17 @@ RSLO_API int rslo_weight_transpose(const float *W, int K, int cin, int cout, flo
  *     rslo_spconv_fwd_split == rslo_spconv_fwd with the split weights. */
 RSLO_API size_t rslo_weight_split_bytes(int K, int cin, int cout);
 RSLO_API int rslo_weight_split(const float *W, int K, int cin_op, int cout_op, int transpose, void *Ws, void *stream);
+/*      rslo_weight_split_many: the same split for every 32/64-channel layer of a model, both orientations (forward and
+ *      data gradient), in ONE launch -- the weights are constant between optimizer steps.  desc_dev = device array of
+ *      n_layers descriptors, max_weight_elems = max over layers of K * cin * cout. */
+typedef struct {
+  const float *W;   /* [K,cin,cout] */
+  void *ws_fwd;     /* rslo_weight_split_bytes(K, cin, cout) bytes: operand of rslo_spconv_fwd_split(x, .., cin, cout) */
+  void *ws_dgrad;   /* same size: operand of the data-gradient call rslo_spconv_fwd_split(dout, .., cout, cin) */
+  int32_t K, cin, cout;
+} RsloWeightSplitDesc;
+RSLO_API int rslo_weight_split_many(const RsloWeightSplitDesc *desc_dev, int n_layers, int64_t max_weight_elems,
+                                    void *stream);
 RSLO_API int rslo_spconv_fwd_split(const float *in, int cin, const void *Ws, const float *bias, const int32_t *nbr,
                                    int64_t n_out, int K, int cout, int flip_k, float act_slope, float *out,
                                    void *stream);

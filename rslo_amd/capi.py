@@ -39,6 +39,7 @@ SIGNATURES = {
     "rslo_weight_transpose": (C.c_int, [_vp, _i, _i, _i, _vp, _vp]),
     "rslo_weight_split_bytes": (_sz, [_i, _i, _i]),
     "rslo_weight_split": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "rslo_weight_split_many": (C.c_int, [_vp, _i, _i64, _vp]),
     "rslo_spconv_fwd_split": (C.c_int, [_vp, _i, _vp, _vp, _vp, _i64, _i, _i, _i, C.c_float, _vp, _vp]),
     "rslo_weight_to_bf16": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "rslo_spconv_fwd_bf16": (C.c_int, [_vp, _i, _vp, _vp, _vp, _i64, _i, _i, _i, C.c_float, _vp, _vp]),
@@ -262,8 +263,40 @@ def rulebook_conv(index, ks, stride, pad):
 SPLIT_BF16 = os.environ.get("RSLO_SPCONV_SPLIT", "1") != "0"     # fp32 via 3-way bf16 splitting on the matrix cores
 
 
+class WeightSplitDesc(C.Structure):
+    _fields_ = [("W", C.c_void_p), ("ws_fwd", C.c_void_p), ("ws_dgrad", C.c_void_p), ("K", C.c_int32), ("cin", C.c_int32),
+                ("cout", C.c_int32)]
+
+
+def weight_split_many(weights):
+    """weights: list of [K,cin,cout] fp32 CUDA tensors with 32/64 channels.  -> (plan, [(ws_fwd, ws_dgrad)]); run
+    weight_split_run(plan) after every weight update (one launch for all layers and both orientations)."""
+    dev = weights[0].device
+    sizes = [lib().rslo_weight_split_bytes(*w.shape) for w in weights]
+    pool = torch.empty((2 * sum(sizes),), dtype=torch.uint8, device=dev)
+    arr = (WeightSplitDesc * len(weights))()
+    views, off = [], 0
+    for i, (w, n) in enumerate(zip(weights, sizes)):
+        f, t = pool[off:off + n], pool[off + n:off + 2 * n]
+        off += 2 * n
+        views.append((f, t))
+        arr[i] = WeightSplitDesc(_ptr(w, torch.float32, "w").value, f.data_ptr(), t.data_ptr(), *w.shape)
+    table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+    return {"table": table, "n": len(weights), "max": max(int(w.numel()) for w in weights), "pool": pool,
+            "ptrs": [w.data_ptr() for w in weights]}, views
+
+
+def weight_split_run(plan):
+    _chk(lib().rslo_weight_split_many(_ptr(plan["table"]), plan["n"], plan["max"], _stream()), "rslo_weight_split_many")
+
+
 def weight_split(W, transpose=False):
-    """W [K,Cin,Cout] fp32 -> split-bf16 operand planes for rslo_spconv_fwd_split (transpose: data-gradient operator)."""
+    """W [K,Cin,Cout] fp32 -> split-bf16 operand planes for rslo_spconv_fwd_split (transpose: data-gradient operator).
+    Operands refreshed for the whole model by weight_split_many (kept on the parameter object) are reused while the
+    parameter is unchanged."""
+    pre = getattr(W, "_hip_split", None)
+    if pre is not None and pre[2] == W._version and pre[3] == W.data_ptr():
+        return pre[1] if transpose else pre[0]
     K, cin, cout = W.shape
     cin_op, cout_op = (cout, cin) if transpose else (cin, cout)
     Ws = torch.empty((lib().rslo_weight_split_bytes(K, cin, cout),), dtype=torch.uint8, device=W.device)

@@ -467,10 +467,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // Ws[plane][k][s][g][co][e] (bf16 bits), plane 0/1/2 = hi/mid/lo, input channel ci = 32 s + 8 g + e.
 // src index: TRANSPOSE ? W[k][co_out = ci][..]: the conv computed is  out[:, co] = sum_ci in[:, ci] * M[ci][co]  with
 // M = W[k] (forward) or W[k]^T (data gradient: ci runs over Cout of W, co over Cin of W).
-__global__ void k_weight_split(const float *__restrict__ W, int K, int cin_op, int cout_op, int transpose,
-                               unsigned short *__restrict__ Ws) {
+__device__ __forceinline__ void weight_split_elem(const float *__restrict__ W, int K, int cin_op, int cout_op,
+                                                  int transpose, unsigned short *__restrict__ Ws, int64_t i) {
   const int64_t n = (int64_t)K * cin_op * cout_op;
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   // i enumerates the destination (k, s, g, co, e)
   const int e = (int)(i & 7);
@@ -496,6 +495,20 @@ __global__ void k_weight_split(const float *__restrict__ W, int K, int cin_op, i
   Ws[i] = (unsigned short)(hb >> 16);
   Ws[n + i] = (unsigned short)(mb >> 16);
   Ws[2 * n + i] = (unsigned short)(__float_as_uint(r2) >> 16);
+}
+
+__global__ void k_weight_split(const float *__restrict__ W, int K, int cin_op, int cout_op, int transpose,
+                               unsigned short *__restrict__ Ws) {
+  weight_split_elem(W, K, cin_op, cout_op, transpose, Ws, (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// every MFMA-shaped layer of a model, both orientations, in one launch: grid (ceil(max_n / 256), 2 * n_layers); row
+// 2 l + t writes layer l's operand for the forward (t = 0) or the data-gradient (t = 1) kernel call
+__global__ void k_weight_split_many(const RsloWeightSplitDesc *__restrict__ desc) {
+  const RsloWeightSplitDesc d = desc[blockIdx.y >> 1];
+  const int t = blockIdx.y & 1;
+  weight_split_elem(d.W, d.K, t ? d.cout : d.cin, t ? d.cin : d.cout, t, (unsigned short *)(t ? d.ws_dgrad : d.ws_fwd),
+                    (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 struct Split8 {
@@ -843,6 +856,15 @@ extern "C" int rslo_weight_split(const float *W, int K, int cin_op, int cout_op,
   hipLaunchKernelGGL(k_weight_split, dim3((unsigned)rslo_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, W, K, cin_op,
                      cout_op, transpose, (unsigned short *)Ws);
   RSLO_CHECK_LAUNCH("k_weight_split");
+  return RSLO_OK;
+}
+
+extern "C" int rslo_weight_split_many(const RsloWeightSplitDesc *desc_dev, int n_layers, int64_t max_weight_elems,
+                                      void *stream) {
+  RSLO_CHECK_ARG(desc_dev && n_layers > 0 && n_layers < 32768 && max_weight_elems > 0, "rslo_weight_split_many: bad sizes");
+  hipLaunchKernelGGL(k_weight_split_many, dim3((unsigned)rslo_cdiv(max_weight_elems, 256), (unsigned)(2 * n_layers)),
+                     dim3(256), 0, (hipStream_t)stream, desc_dev);
+  RSLO_CHECK_LAUNCH("k_weight_split_many");
   return RSLO_OK;
 }
 

@@ -139,6 +139,35 @@ class _DenseFn(torch.autograd.Function):
         return capi.dense_gather(g.contiguous(), coords, C_, batch, dims), None, None, None
 
 
+def _w3(weight, K, cin, cout):
+    """[kd,kh,kw,cin,cout] parameter -> [K,cin,cout] view that carries the parameter's pre-split operands (presplit())."""
+    W3 = weight.reshape(K, cin, cout)
+    pre = getattr(weight, "_hip_split", None)
+    if pre is not None:
+        W3._hip_split = pre
+    return W3
+
+
+def presplit(root):
+    """Refresh the split-bf16 operands of every 32/64-channel sparse convolution under `root` (forward and data-gradient
+    orientation) in ONE launch; capi.weight_split() then reuses them while the parameters are unchanged."""
+    if not capi.SPLIT_BF16:
+        return
+    ent = root.__dict__.get("_hip_spconv_plan")
+    if ent is None or any(w.data_ptr() != p for w, p in zip(ent[1], ent[0]["ptrs"])):
+        ws = [m.weight for m in root.modules()
+              if isinstance(m, SparseConvolution) and m.weight.is_cuda and m.weight.dtype == torch.float32
+              and m.in_channels in (32, 64) and m.out_channels in (32, 64)]
+        if not ws:
+            return
+        plan, views = capi.weight_split_many([w.reshape(-1, w.shape[-2], w.shape[-1]) for w in ws])
+        ent = (plan, ws, views)
+        root.__dict__["_hip_spconv_plan"] = ent
+    capi.weight_split_run(ent[0])
+    for w, (f, t) in zip(ent[1], ent[2]):
+        w._hip_split = (f, t, w._version, w.data_ptr())
+
+
 class _SparseConvFn(torch.autograd.Function):
     """y = act(bias + sum_k x[nbr[:,k]] @ W[k]) and its dgrad/wgrad, all through the C ABI."""
 
@@ -147,7 +176,7 @@ class _SparseConvFn(torch.autograd.Function):
         ctx.rb, ctx.inverse = rb, inverse
         K = nbr.shape[1]
         cin, cout = weight.shape[-2], weight.shape[-1]
-        W3 = weight.reshape(K, cin, cout)
+        W3 = _w3(weight, K, cin, cout)
         x = x.contiguous()
         y = capi.spconv_fwd(x, W3, bias, nbr, flip_k=False, act_slope=slope)
         ctx.save_for_backward(x, weight, y if slope != 1.0 else None, nbr, nbrT)
@@ -160,7 +189,7 @@ class _SparseConvFn(torch.autograd.Function):
         subm, slope, has_bias = ctx.meta
         K = nbr.shape[1]
         cin, cout = weight.shape[-2], weight.shape[-1]
-        W3 = weight.reshape(K, cin, cout)
+        W3 = _w3(weight, K, cin, cout)
         g = gy.contiguous()
         bias_partial = None
         if slope != 1.0:
