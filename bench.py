@@ -319,7 +319,17 @@ def main():
 
     wait = [0.0]
 
+    phases = os.environ.get("RSLO_BENCH_PHASES") == "1"       # wall / CPU time of the issuing thread per phase (stderr)
+    ph = {k: [0.0, 0.0] for k in ("get", "fwd", "bwd", "opt")}
+
+    def mark(name, w0, c0):
+        if phases:
+            ph[name][0] += time.perf_counter() - w0
+            ph[name][1] += time.thread_time() - c0
+        return time.perf_counter(), time.thread_time()
+
     def step():
+        w0, c0 = time.perf_counter(), time.thread_time()
         if prefetch is not None:
             tw = time.perf_counter()
             ex = prefetch.get()
@@ -328,18 +338,22 @@ def main():
             ex = dict(fixed_example)
         else:
             ex = workload.make_example(net, clouds, device=dev)
+        w0, c0 = mark("get", w0, c0)
         sched.step(net.get_global_step())
         opt.zero_grad()
         ret = model(ex)
         if prefetch is not None:
             prefetch.submit(clouds)
+        w0, c0 = mark("fwd", w0, c0)
         ret["loss"].mean().backward()
         if dist_on:
             average_gradients(net, mean=True)
+        w0, c0 = mark("bwd", w0, c0)
         if not args.no_optim:
             torch.nn.utils.clip_grad_norm_(params, 10.0)
             opt.step()
             net.update_global_step()
+        mark("opt", w0, c0)
         return ret
 
     probe = ConvProbe(capi)
@@ -359,6 +373,8 @@ def main():
     # per-launch HIP events on the last PROBE_STEPS timed steps only (the events themselves cost host time)
     probe_steps = min(3, args.steps)
     wait[0] = 0.0
+    for v in ph.values():
+        v[0] = v[1] = 0.0
     t0 = time.perf_counter()
     cpu0 = time.thread_time()           # CPU time of the issuing thread: close to the wall time = host-bound step
     for i in range(args.steps):
@@ -376,6 +392,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    if phases and rank == 0:
+        print("phases (wall ms, cpu ms per step): " + ", ".join(
+            "%s %.2f/%.2f" % (k, 1e3 * v[0] / args.steps, 1e3 * v[1] / args.steps) for k, v in ph.items()), file=sys.stderr)
     loss_val = float(ret["loss"].detach().mean().item())
     if rank == 0:
         roof = None

@@ -154,6 +154,11 @@ def _ptr(t, dtype=None, name="tensor"):
     return C.c_void_p(t.data_ptr())
 
 
+def _dp(t):
+    """data pointer of an optional tensor the caller already knows to be a contiguous CUDA tensor of the right type"""
+    return None if t is None else t.data_ptr()
+
+
 def _i3(x):
     return _I3(*[int(v) for v in x])
 
@@ -786,36 +791,52 @@ def bn2d_bwd_apply(dy, y, x, gamma, mean, invstd, red, count, slope, has_act, wa
     return dx, dres
 
 
+_bn_ws_bytes = {}
+
+
+def _bn2d_ws(N, Cc, HW, dev):
+    key = (N, Cc, HW)
+    n = _bn_ws_bytes.get(key)
+    if n is None:
+        n = _bn_ws_bytes[key] = lib().rslo_bn2d_ws_bytes(N, Cc, HW)
+    return torch.empty((n,), dtype=torch.uint8, device=dev), n
+
+
 def bn2d_fwd_local(x, res, gamma, beta, running_mean, running_var, momentum, eps, slope):
-    """Single-rank y = act(BN_train(x) + res): two launches.  -> y, save_mean, save_invstd."""
+    """Single-rank y = act(BN_train(x) + res): two launches.  -> y, save_mean, save_invstd.  (Hot host path: x / res are
+    checked, everything else comes from module state or is allocated here.)"""
     N, Cc, H, W = x.shape
     dev = x.device
-    wsb = lib().rslo_bn2d_ws_bytes(N, Cc, H * W)
-    ws = _ws(wsb, dev)
+    HW = H * W
+    ws, wsb = _bn2d_ws(N, Cc, HW, dev)
     y = torch.empty_like(x)
-    mean = torch.empty((Cc,), dtype=torch.float32, device=dev)
-    invstd = torch.empty((Cc,), dtype=torch.float32, device=dev)
-    _chk(lib().rslo_bn2d_fwd_local(_ptr(x, torch.float32, "x"), _ptr(res, torch.float32, "res"),
-                                   _ptr(gamma, torch.float32, "gamma"), _ptr(beta, torch.float32, "beta"), N, Cc, H * W,
-                                   float(eps), float(momentum), float(slope), _ptr(running_mean, torch.float32),
-                                   _ptr(running_var, torch.float32), _ptr(mean), _ptr(invstd), _ptr(y), _ptr(ws), wsb,
-                                   _stream()), "rslo_bn2d_fwd_local")
-    return y, mean, invstd
+    stat = torch.empty((2, Cc), dtype=torch.float32, device=dev)
+    rc = lib().rslo_bn2d_fwd_local(_ptr(x, torch.float32, "x"), _ptr(res, torch.float32, "res"), _dp(gamma), _dp(beta), N,
+                                   Cc, HW, eps, momentum, slope, _dp(running_mean), _dp(running_var), stat.data_ptr(),
+                                   stat.data_ptr() + 4 * Cc, y.data_ptr(), ws.data_ptr(), wsb, _stream())
+    if rc:
+        _chk(rc, "rslo_bn2d_fwd_local")
+    return y, stat[0], stat[1]
 
 
 def bn2d_bwd_local(dy, y, x, gamma, mean, invstd, slope, has_act, want_res, want_affine=True):
     N, Cc, H, W = x.shape
     dev = x.device
-    wsb = lib().rslo_bn2d_ws_bytes(N, Cc, H * W)
-    ws = _ws(wsb, dev)
+    HW = H * W
+    ws, wsb = _bn2d_ws(N, Cc, HW, dev)
     dx = torch.empty_like(x)
     dres = torch.empty_like(x) if want_res else None
-    dgamma = torch.empty((Cc,), dtype=torch.float32, device=dev) if want_affine else None
-    dbeta = torch.empty((Cc,), dtype=torch.float32, device=dev) if want_affine else None
-    _chk(lib().rslo_bn2d_bwd_local(_ptr(dy, torch.float32, "dy"), _ptr(y, torch.float32, "y"), _ptr(x, torch.float32, "x"),
-                                   _ptr(gamma, torch.float32, "gamma"), _ptr(mean), _ptr(invstd), N, Cc, H * W,
-                                   float(slope), int(has_act), _ptr(dx), _ptr(dres), _ptr(dgamma), _ptr(dbeta), _ptr(ws),
-                                   wsb, _stream()), "rslo_bn2d_bwd_local")
+    if want_affine:
+        dgb = torch.empty((2, Cc), dtype=torch.float32, device=dev)
+        dgamma, dbeta = dgb[0], dgb[1]
+        pg, pb = dgb.data_ptr(), dgb.data_ptr() + 4 * Cc
+    else:
+        dgamma = dbeta = pg = pb = None
+    rc = lib().rslo_bn2d_bwd_local(_ptr(dy, torch.float32, "dy"), _dp(y), x.data_ptr(), _dp(gamma), mean.data_ptr(),
+                                   invstd.data_ptr(), N, Cc, HW, slope, 1 if has_act else 0, dx.data_ptr(), _dp(dres), pg,
+                                   pb, ws.data_ptr(), wsb, _stream())
+    if rc:
+        _chk(rc, "rslo_bn2d_bwd_local")
     return dx, dres, dgamma, dbeta
 
 
@@ -871,19 +892,28 @@ def conv2d_wgrad_supported(cin, cout, H, W, stride):
     return bool(lib().rslo_conv2d_wgrad_supported(int(cin), int(cout), int(H), int(W), int(stride)))
 
 
+_c2w_ws_bytes = {}
+
+
 def conv2d_wgrad(x, dout, stride=1, want_bias=False):
     """x [B,cin,H,W], dout [B,cout,Ho,Wo] (contiguous NCHW fp32) -> dW [cout,cin,3,3] of a 3x3 / padding-1 conv;
     want_bias (stride 1): -> (dW, dbias [cout]) with the bias gradient from the same pass."""
     B, cin, H, W = x.shape
     cout = dout.shape[1]
-    wsb = lib().rslo_conv2d_wgrad_ws_bytes(B, cin, cout, H, W, stride)
+    key = (B, cin, cout, H, W, stride)
+    wsb = _c2w_ws_bytes.get(key)
+    if wsb is None:
+        wsb = _c2w_ws_bytes[key] = lib().rslo_conv2d_wgrad_ws_bytes(B, cin, cout, H, W, stride)
     if wsb == 0:
         raise RsloHipError("rslo_conv2d_wgrad: unsupported shape %s -> %s stride %d" % (tuple(x.shape), tuple(dout.shape), stride))
-    ws = _ws(wsb, x.device)
-    dW = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=x.device)
-    db = torch.empty((cout,), dtype=torch.float32, device=x.device) if want_bias else None
-    _chk(lib().rslo_conv2d_wgrad(_ptr(x, torch.float32, "x"), _ptr(dout, torch.float32, "dout"), B, cin, cout, H, W,
-                                 stride, _ptr(dW), _ptr(db), _ptr(ws), wsb, _stream()), "rslo_conv2d_wgrad")
+    dev = x.device
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+    dW = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=dev)
+    db = torch.empty((cout,), dtype=torch.float32, device=dev) if want_bias else None
+    rc = lib().rslo_conv2d_wgrad(_ptr(x, torch.float32, "x"), _ptr(dout, torch.float32, "dout"), B, cin, cout, H, W,
+                                 stride, dW.data_ptr(), _dp(db), ws.data_ptr(), wsb, _stream())
+    if rc:
+        _chk(rc, "rslo_conv2d_wgrad")
     return (dW, db) if want_bias else dW
 
 
@@ -933,8 +963,10 @@ def conv2d_fwd(x, ws, bias, cout):
     """x [B,cin,H,W] contiguous fp32, ws from conv2d_wsplit -> [B,cout,H,W] (3x3, stride 1, padding 1)."""
     B, cin, H, W = x.shape
     out = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device)
-    _chk(lib().rslo_conv2d_fwd(_ptr(x, torch.float32, "x"), _ptr(ws), _ptr(bias, torch.float32, "bias") if bias is not None
-                               else None, B, cin, cout, H, W, _ptr(out), _stream()), "rslo_conv2d_fwd")
+    rc = lib().rslo_conv2d_fwd(_ptr(x, torch.float32, "x"), ws.data_ptr(), _dp(bias), B, cin, cout, H, W, out.data_ptr(),
+                               _stream())
+    if rc:
+        _chk(rc, "rslo_conv2d_fwd")
     return out
 
 

@@ -56,7 +56,7 @@ FUSED_BN = os.environ.get("RSLO_FUSED_BN", "1")
 
 
 def _world(group):
-    if not (dist.is_available() and dist.is_initialized()):
+    if not dist.is_initialized():
         return 1
     return dist.get_world_size(group) if group is not None else dist.get_world_size()
 

@@ -407,7 +407,7 @@ def test_fused_bn2d_act_matches_torch(hip, slope, with_res):
     running statistics, input / residual / affine gradients; odd spatial size exercises the scalar tails."""
     import apex.parallel as AP
     torch.manual_seed(0)
-    for shape in [(4, 64, 24, 44), (2, 32, 7, 9)]:
+    for shape in [(4, 64, 24, 44), (2, 32, 7, 9), (2, 16, 96, 176)]:      # one-launch forms (two block sizes), slice form
         x = (torch.randn(*shape, device="cuda") * 2 + 0.3).requires_grad_(True)
         res = torch.randn(*shape, device="cuda", requires_grad=True) if with_res else None
         gy = torch.randn(*shape, device="cuda")
