@@ -134,14 +134,15 @@ class UNOdomPredEncDecSVDTempMaskBase(OdomPredEncDecBase):
         # its only other effect -- a second running-statistics update of the trunk's BatchNorms with the same batch
         # statistics -- is replayed algebraically.
         bn_before = self._snapshot_bn((self.t_map_conf, self.q_map_conf))
-        t_conf, t_logit = self.t_map_conf(x_tail, extra_mask=input_mask, return_logit=True)
-        r_conf, r_logit = self.q_map_conf(x_tail, extra_mask=input_mask, return_logit=True)
+        outside = ~input_mask_bool        # shared by the four masked softmaxes below
+        t_conf, t_logit = self.t_map_conf(x_tail, extra_mask=input_mask, return_logit=True, outside=outside)
+        r_conf, r_logit = self.q_map_conf(x_tail, extra_mask=input_mask, return_logit=True, outside=outside)
         tq_map_g, odom = self.vote(tq_map, t_conf, r_conf)
         odoms = [odom]
 
         with torch.no_grad():   # temperature-20 confidences -> loss masks
-            temp_tq_conf = torch.cat([masked_spatial_softmax(t_logit.detach(), input_mask, 20),
-                                      masked_spatial_softmax(r_logit.detach(), input_mask, 20)], 1)
+            temp_tq_conf = torch.cat([masked_spatial_softmax(t_logit.detach(), input_mask, 20, outside),
+                                      masked_spatial_softmax(r_logit.detach(), input_mask, 20, outside)], 1)
             self._replay_bn_update(bn_before)
         pyramid_motion = py_preds + [[tq_map * input_mask, input_mask * temp_tq_conf]]
         for p in range(2, len(pyramid_motion) + 1):
