@@ -393,6 +393,17 @@ RSLO_API int rslo_conv2d_wsplit_many(const RsloConv2dSplitDesc *desc_dev, int n_
 RSLO_API int rslo_conv2d_fwd(const float *in, const void *Ws, const float *bias, int B, int cin, int cout, int H, int W,
                              float *out, void *stream);
 
+/* a11 / a12  the 1x1 output convolutions of the head (torch.nn.Conv2d(c, 7, 1) / (32, 1, 1): rslo/models/odom_pred.py:71,
+ *      rslo/models/odom_pred_base.py:22-24,107-109), cout <= 8, NCHW fp32, HW = H * W:
+ *      forward (+ bias), data gradient, weight gradient (+ bias gradient from the same pass, fixed summation order). */
+RSLO_API int rslo_conv1x1_supported(int cin, int cout);
+RSLO_API int rslo_conv1x1_fwd(const float *x, const float *W, const float *bias, int B, int cin, int cout, int HW,
+                              float *out, void *stream);
+RSLO_API int rslo_conv1x1_dgrad(const float *dy, const float *W, int B, int cin, int cout, int HW, float *dx, void *stream);
+RSLO_API size_t rslo_conv1x1_wgrad_ws_bytes(int B, int cin, int cout, int HW);
+RSLO_API int rslo_conv1x1_wgrad(const float *x, const float *dy, int B, int cin, int cout, int HW, float *dW, float *dbias,
+                                void *ws, size_t ws_bytes, void *stream);
+
 /* a16 / a20  per-pair pose algebra of the loss assembly (one thread per frame pair):
  *      rslo_quat_to_rot: q (w,x,y,z) -> R [B,9] with kornia 0.4.0 semantics (normalise with eps 1e-12 first;
  *      rslo/models/voxel_odom_net.py:675) and its backward;  rslo_pose_targets: pseudo-targets of the ICP refinement

@@ -245,3 +245,11 @@ def conv2d_dgrad(dout, w):
         for kx in range(3):
             dx += np.einsum("oi,boyx->biyx", w[:, :, ky, kx], gp[:, :, 2 - ky:2 - ky + H, 2 - kx:2 - kx + W], optimize=True)
     return dx
+
+
+def conv1x1_fwd(x, w, bias=None):
+    """1x1 Conv2d (torch.nn.Conv2d(c, 7, 1), rslo/models/odom_pred.py:71): out[b,o,y,x] = bias[o] + sum_i w[o,i] x[b,i,y,x]."""
+    out = np.einsum("oi,biyx->boyx", np.asarray(w, np.float64)[:, :, 0, 0], np.asarray(x, np.float64))
+    if bias is not None:
+        out = out + np.asarray(bias, np.float64)[None, :, None, None]
+    return out

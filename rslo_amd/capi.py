@@ -97,6 +97,11 @@ SIGNATURES = {
     "rslo_conv2d_wsplit": (C.c_int, [_vp, _i, _i, _i, _vp, _vp]),
     "rslo_conv2d_wsplit_many": (C.c_int, [_vp, _i, _i64, _vp]),
     "rslo_conv2d_fwd": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "rslo_conv1x1_supported": (C.c_int, [_i, _i]),
+    "rslo_conv1x1_fwd": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "rslo_conv1x1_dgrad": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "rslo_conv1x1_wgrad_ws_bytes": (_sz, [_i, _i, _i, _i]),
+    "rslo_conv1x1_wgrad": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "rslo_quat_to_rot": (C.c_int, [_vp, _i, _vp, _vp]),
     "rslo_quat_to_rot_bwd": (C.c_int, [_vp, _vp, _i, _vp, _vp]),
     "rslo_pose_targets": (C.c_int, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
@@ -968,6 +973,48 @@ def conv2d_fwd(x, ws, bias, cout):
     if rc:
         _chk(rc, "rslo_conv2d_fwd")
     return out
+
+
+def conv1x1_supported(cin, cout):
+    return bool(lib().rslo_conv1x1_supported(int(cin), int(cout)))
+
+
+def conv1x1_fwd(x, w, bias):
+    """x [B,cin,H,W], w [cout,cin,1,1] (cout <= 8), bias [cout] or None -> [B,cout,H,W]."""
+    B, cin, H, W = x.shape
+    cout = w.shape[0]
+    out = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device)
+    rc = lib().rslo_conv1x1_fwd(_ptr(x, torch.float32, "x"), _ptr(w, torch.float32, "w"), _dp(bias), B, cin, cout, H * W,
+                                out.data_ptr(), _stream())
+    if rc:
+        _chk(rc, "rslo_conv1x1_fwd")
+    return out
+
+
+def conv1x1_dgrad(dy, w):
+    B, cout, H, W = dy.shape
+    cin = w.shape[1]
+    dx = torch.empty((B, cin, H, W), dtype=torch.float32, device=dy.device)
+    rc = lib().rslo_conv1x1_dgrad(_ptr(dy, torch.float32, "dy"), _ptr(w, torch.float32, "w"), B, cin, cout, H * W,
+                                  dx.data_ptr(), _stream())
+    if rc:
+        _chk(rc, "rslo_conv1x1_dgrad")
+    return dx
+
+
+def conv1x1_wgrad(x, dy, want_bias=True):
+    B, cin, H, W = x.shape
+    cout = dy.shape[1]
+    dev = x.device
+    wsb = lib().rslo_conv1x1_wgrad_ws_bytes(B, cin, cout, H * W)
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+    dW = torch.empty((cout, cin, 1, 1), dtype=torch.float32, device=dev)
+    db = torch.empty((cout,), dtype=torch.float32, device=dev) if want_bias else None
+    rc = lib().rslo_conv1x1_wgrad(_ptr(x, torch.float32, "x"), _ptr(dy, torch.float32, "dy"), B, cin, cout, H * W,
+                                  dW.data_ptr(), _dp(db), ws.data_ptr(), wsb, _stream())
+    if rc:
+        _chk(rc, "rslo_conv1x1_wgrad")
+    return dW, db
 
 
 # --------------------------------------------------------------------------------------

@@ -821,3 +821,154 @@ extern "C" int rslo_conv2d_fwd(const float *in, const void *Ws, const float *bia
   RSLO_CHECK_LAUNCH("k_conv2d_fwd");
   return RSLO_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 1x1 output convolutions of the head (32/64 -> 7 or 1 channels: tq_map_conv.6, pyramid_motion_blocks.*.6, the
+// confidence logits): HBM-bound row operations, one thread per pixel.  The library path spends 5 launches per backward
+// on them (igemm + layout transposes + fills); here forward, data gradient and weight + bias gradient are one or two.
+// ---------------------------------------------------------------------------------------------------------------------
+#define C11_MAXCO 8
+#define C11_MAXW (C11_MAXCO * 256)
+
+// out[b][co][p] = bias[co] + sum_ci W[co][ci] x[b][ci][p]
+__global__ __launch_bounds__(256) void k_conv1x1_fwd(const float *__restrict__ x, const float *__restrict__ W,
+                                                     const float *__restrict__ bias, int B, int cin, int cout, int HW,
+                                                     float *__restrict__ out) {
+  __shared__ float w[C11_MAXW];
+  for (int e = threadIdx.x; e < cout * cin; e += 256) w[e] = W[e];
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)B * HW) return;
+  const int b = (int)(i / HW), p = (int)(i - (int64_t)b * HW);
+  float acc[C11_MAXCO];
+#pragma unroll
+  for (int co = 0; co < C11_MAXCO; ++co) acc[co] = (bias && co < cout) ? bias[co] : 0.f;
+  const float *xp = x + (int64_t)b * cin * HW + p;
+  for (int ci = 0; ci < cin; ++ci) {
+    const float xv = xp[(int64_t)ci * HW];
+#pragma unroll
+    for (int co = 0; co < C11_MAXCO; ++co)
+      if (co < cout) acc[co] += w[co * cin + ci] * xv;
+  }
+  float *op = out + (int64_t)b * cout * HW + p;
+#pragma unroll
+  for (int co = 0; co < C11_MAXCO; ++co)
+    if (co < cout) op[(int64_t)co * HW] = acc[co];
+}
+
+// dx[b][ci][p] = sum_co W[co][ci] dy[b][co][p]
+__global__ __launch_bounds__(256) void k_conv1x1_dgrad(const float *__restrict__ dy, const float *__restrict__ W, int B,
+                                                       int cin, int cout, int HW, float *__restrict__ dx) {
+  __shared__ float w[C11_MAXW];
+  for (int e = threadIdx.x; e < cout * cin; e += 256) w[e] = W[e];
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)B * HW) return;
+  const int b = (int)(i / HW), p = (int)(i - (int64_t)b * HW);
+  float g[C11_MAXCO];
+  const float *gp = dy + (int64_t)b * cout * HW + p;
+#pragma unroll
+  for (int co = 0; co < C11_MAXCO; ++co) g[co] = co < cout ? gp[(int64_t)co * HW] : 0.f;
+  float *dp = dx + (int64_t)b * cin * HW + p;
+  for (int ci = 0; ci < cin; ++ci) {
+    float s = 0.f;
+#pragma unroll
+    for (int co = 0; co < C11_MAXCO; ++co)
+      if (co < cout) s += w[co * cin + ci] * g[co];
+    dp[(int64_t)ci * HW] = s;
+  }
+}
+
+// grid (cin + 1, S): block (ci, slab) sums dy[b][co][p] * x[b][ci][p] over its pixel slab (ci == cin: x = 1, the bias
+// gradient); part [S][cin + 1][C11_MAXCO]
+__global__ __launch_bounds__(256) void k_conv1x1_wgrad(const float *__restrict__ x, const float *__restrict__ dy, int B,
+                                                       int cin, int cout, int HW, int64_t per_slab,
+                                                       float *__restrict__ part) {
+  const int ci = blockIdx.x, slab = blockIdx.y;
+  const int64_t total = (int64_t)B * HW;
+  const int64_t i0 = (int64_t)slab * per_slab, i1 = (i0 + per_slab < total) ? i0 + per_slab : total;
+  float acc[C11_MAXCO];
+#pragma unroll
+  for (int co = 0; co < C11_MAXCO; ++co) acc[co] = 0.f;
+  for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+    const int b = (int)(i / HW), p = (int)(i - (int64_t)b * HW);
+    const float xv = ci < cin ? x[((int64_t)b * cin + ci) * HW + p] : 1.f;
+    const float *gp = dy + (int64_t)b * cout * HW + p;
+#pragma unroll
+    for (int co = 0; co < C11_MAXCO; ++co)
+      if (co < cout) acc[co] += gp[(int64_t)co * HW] * xv;
+  }
+  __shared__ float red[C11_MAXCO][4];
+#pragma unroll
+  for (int co = 0; co < C11_MAXCO; ++co) {
+    float v = acc[co];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((threadIdx.x & 63) == 0) red[co][threadIdx.x >> 6] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < C11_MAXCO)
+    part[((int64_t)slab * (cin + 1) + ci) * C11_MAXCO + threadIdx.x] =
+        ((red[threadIdx.x][0] + red[threadIdx.x][1]) + red[threadIdx.x][2]) + red[threadIdx.x][3];
+}
+
+// dW[co][ci] (and dbias[co] from the virtual channel ci == cin) = slab partials added in slab order
+__global__ void k_conv1x1_wgrad_reduce(const float *__restrict__ part, int S, int cin, int cout, float *__restrict__ dW,
+                                       float *__restrict__ dbias) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (cin + 1) * cout) return;
+  const int ci = e / cout, co = e - ci * cout;
+  float s = 0.f;
+  for (int k = 0; k < S; ++k) s += part[((int64_t)k * (cin + 1) + ci) * C11_MAXCO + co];
+  if (ci < cin) dW[co * cin + ci] = s;
+  else if (dbias) dbias[co] = s;
+}
+
+static int conv1x1_slabs(int B, int cin, int HW, int64_t *per) {
+  const int64_t total = (int64_t)B * HW;
+  int s = 1024 / (cin + 1);
+  if (s < 1) s = 1;
+  const int64_t max_s = rslo_cdiv(total, 2048);
+  if (s > max_s) s = (int)(max_s > 0 ? max_s : 1);
+  *per = rslo_cdiv(total, s);
+  return (int)rslo_cdiv(total, *per);
+}
+
+extern "C" int rslo_conv1x1_supported(int cin, int cout) { return cin >= 1 && cin <= 256 && cout >= 1 && cout <= C11_MAXCO; }
+
+extern "C" size_t rslo_conv1x1_wgrad_ws_bytes(int B, int cin, int cout, int HW) {
+  int64_t per;
+  return (size_t)conv1x1_slabs(B, cin, HW, &per) * (cin + 1) * C11_MAXCO * sizeof(float);
+}
+
+extern "C" int rslo_conv1x1_fwd(const float *x, const float *W, const float *bias, int B, int cin, int cout, int HW,
+                                float *out, void *stream) {
+  RSLO_CHECK_ARG(x && W && out && rslo_conv1x1_supported(cin, cout) && B >= 1 && HW >= 1, "rslo_conv1x1_fwd: bad arguments");
+  hipLaunchKernelGGL(k_conv1x1_fwd, dim3((unsigned)rslo_cdiv((int64_t)B * HW, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                     W, bias, B, cin, cout, HW, out);
+  RSLO_CHECK_LAUNCH("k_conv1x1_fwd");
+  return RSLO_OK;
+}
+
+extern "C" int rslo_conv1x1_dgrad(const float *dy, const float *W, int B, int cin, int cout, int HW, float *dx,
+                                  void *stream) {
+  RSLO_CHECK_ARG(dy && W && dx && rslo_conv1x1_supported(cin, cout) && B >= 1 && HW >= 1, "rslo_conv1x1_dgrad: bad arguments");
+  hipLaunchKernelGGL(k_conv1x1_dgrad, dim3((unsigned)rslo_cdiv((int64_t)B * HW, 256)), dim3(256), 0, (hipStream_t)stream,
+                     dy, W, B, cin, cout, HW, dx);
+  RSLO_CHECK_LAUNCH("k_conv1x1_dgrad");
+  return RSLO_OK;
+}
+
+extern "C" int rslo_conv1x1_wgrad(const float *x, const float *dy, int B, int cin, int cout, int HW, float *dW,
+                                  float *dbias, void *ws, size_t ws_bytes, void *stream) {
+  RSLO_CHECK_ARG(x && dy && dW && ws && rslo_conv1x1_supported(cin, cout) && B >= 1 && HW >= 1, "rslo_conv1x1_wgrad: bad arguments");
+  RSLO_CHECK_ARG(ws_bytes >= rslo_conv1x1_wgrad_ws_bytes(B, cin, cout, HW), "rslo_conv1x1_wgrad: workspace too small");
+  int64_t per;
+  const int S = conv1x1_slabs(B, cin, HW, &per);
+  hipLaunchKernelGGL(k_conv1x1_wgrad, dim3((unsigned)(cin + 1), (unsigned)S), dim3(256), 0, (hipStream_t)stream, x, dy, B,
+                     cin, cout, HW, per, (float *)ws);
+  RSLO_CHECK_LAUNCH("k_conv1x1_wgrad");
+  hipLaunchKernelGGL(k_conv1x1_wgrad_reduce, dim3((unsigned)rslo_cdiv((cin + 1) * cout, 256)), dim3(256), 0,
+                     (hipStream_t)stream, (const float *)ws, S, cin, cout, dW, dbias);
+  RSLO_CHECK_LAUNCH("k_conv1x1_wgrad_reduce");
+  return RSLO_OK;
+}

@@ -69,6 +69,30 @@ class _Conv3x3Fn(torch.autograd.Function):
 
 
 
+class _Conv1x1Fn(torch.autograd.Function):
+    """1x1 / stride-1 output convolutions with at most 8 output channels through rslo_conv1x1_* (csrc/conv2d.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        from rslo_amd import capi
+        x = x.contiguous()
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return capi.conv1x1_fwd(x, w, bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        from rslo_amd import capi
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = capi.conv1x1_dgrad(dy, w)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw, db = capi.conv1x1_wgrad(x, dy, want_bias=ctx.has_bias)
+        return dx, dw, db
+
+
 def presplit(root):
     """Refresh the split-bf16 operands of every eligible Conv2d under `root` (both orientations) in ONE launch; the
     layers pick them up while the weights' version counters are unchanged (i.e. until the next optimizer step)."""
@@ -115,6 +139,11 @@ class Conv2d(nn.Conv2d):
         return ok[1] or ok[2]
 
     def _conv_forward(self, input, weight, bias):
+        if (self.kernel_size == (1, 1) and self.out_channels <= 8 and self.in_channels <= 256 and self.hip_wgrad
+                and "w" in HIP_PASSES and input.is_cuda and input.dtype == torch.float32 and input.dim() == 4
+                and torch.is_grad_enabled() and weight.requires_grad and self.stride == (1, 1)
+                and self.padding == (0, 0) and self.dilation == (1, 1) and self.groups == 1):
+            return _Conv1x1Fn.apply(input, weight, bias)
         if self._eligible(input):
             return _Conv3x3Fn.apply(input, weight, bias, self.stride[0], self._hip_ok[2], self._hip_ok[1])
         return super()._conv_forward(input, weight, bias)

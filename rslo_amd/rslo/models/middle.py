@@ -115,7 +115,8 @@ class SpMiddleFHDWithCov2_3(nn.Module):
         ret = self.middle_conv_tail(ret0)
         cov = self.middle_cov_deconv(ret0).features
         # eigenvalue increments > 0 (middle.py:237), out of place
-        cov = torch.cat([F.elu(cov[:, :3]) + 1 + 1e-6, cov[:, 3:]], dim=1)
+        lam, rest = cov.split([3, cov.shape[1] - 3], dim=1)
+        cov = torch.cat([F.elu(lam) + 1 + 1e-6, rest], dim=1)
         dense = ret.dense()
         N, Cc, D, H, W = dense.shape
         return dense.view(N, Cc * D, H, W), cov

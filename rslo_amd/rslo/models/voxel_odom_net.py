@@ -407,8 +407,10 @@ class UnVoxelOdomNetICP3(nn.Module):
                 points, confs = [], []
                 for t in range(T_):
                     both = losses.pad_rows(torch.cat([feats[t], confs_all[t]], 1), meta[t], meta[T_], Lmax)
-                    points.append(both[..., :feats[t].shape[1]])
-                    confs.append(both[..., feats[t].shape[1]:])
+                    nf = feats[t].shape[1]            # one split: its backward is one cat, not 2 x (zeros + copy) + add
+                    pt, cf = both.split([nf, both.shape[-1] - nf], dim=-1)
+                    points.append(pt)
+                    confs.append(cf)
                 npairs_ = T_ * (T_ - 1) // 2
                 cnt_host = [n for n in lens for _ in range(npairs_)]
                 cnt_dev = meta[T_]
@@ -466,8 +468,9 @@ class UnVoxelOdomNetICP3(nn.Module):
             scaled = losses.pyramid_l2_losses([p for p, _ in levels], [m for _, m in levels], tq_targets,
                                               (H0, W0, origin, vs), pyramid_translation_loss, pyramid_rotation_loss)
             self._py_scaled = scaled
-            pyramid_T_losses = list(scaled[:, 0:1].unbind(0))
-            pyramid_R_losses = list(scaled[:, 1:2].unbind(0))
+            cols = [row.split(1) for row in scaled.unbind(0)]      # [L,2] -> per level ([1], [1])
+            pyramid_T_losses = [c[0] for c in cols]
+            pyramid_R_losses = [c[1] for c in cols]
             return T_loss, R_loss, pyramid_T_losses, pyramid_R_losses, C_loss
 
         if len(pyramid_preds) > 0:

@@ -38,16 +38,25 @@ torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
     step(); torch.cuda.synchronize()
 cnt, dev = collections.Counter(), collections.Counter()
+ops = collections.defaultdict(collections.Counter)       # label -> top-level aten op under it -> launches
 for e in prof.events():
     ks = getattr(e, "kernels", None)
     if not ks: continue
-    p, lab = e, None
+    p, lab, top = e, None, e.name
     while p is not None:
         if p.name.startswith(("M:", "F:")): lab = p.name; break
+        top = p.name
         p = p.cpu_parent
     lab = lab or "<none>"
     cnt[lab] += len(ks); dev[lab] += sum(k.duration for k in ks)
+    ops[lab][top] += len(ks)
 print("%-70s %6s %9s" % ("innermost label", "n", "gpu ms"))
 for s, v in sorted(dev.items(), key=lambda kv: -kv[1])[:90]:
     print("%-70s %6d %9.3f" % (s[:70], cnt[s], v / 1e3))
 print("total gpu-op count", sum(cnt.values()), "gpu ms", sum(dev.values()) / 1e3)
+
+for lab in os.environ.get("OPS_OF", "").split(","):
+    if lab in ops:
+        print("== launches under", lab)
+        for k, v in ops[lab].most_common(40):
+            print("  %4d  %s" % (v, k[:100]))
