@@ -312,7 +312,7 @@ def main():
     # reference's DataLoader workers do on the CPU); every step still voxelizes its own 2 x batch clouds
     prefetch = None
     if fixed_example is None and not args.no_prefetch:
-        depth = int(os.environ.get("RSLO_PREFETCH_DEPTH", "1"))
+        depth = int(os.environ.get("RSLO_PREFETCH_DEPTH", "2"))
         prefetch = workload.ExamplePrefetcher(net, device=dev, depth=depth)
         for _ in range(depth):
             prefetch.submit(clouds)
