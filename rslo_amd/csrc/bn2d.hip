@@ -390,6 +390,59 @@ __global__ __launch_bounds__(T) void k_bn2d_bwd_small(const float *__restrict__ 
   }
 }
 
+// multi-rank forms of the small maps: the channel's sums go straight into the tensor that is all-reduced (no slice
+// partials, no finish launch)
+template <int T>
+__global__ __launch_bounds__(T) void k_bn2d_stats_small(const float *__restrict__ x, int N, int C, int HW,
+                                                        double *__restrict__ stats) {
+  const int c = blockIdx.x;
+  double s = 0.0, q = 0.0;
+  for (int n = 0; n < N; ++n) {
+    const float *row = x + ((int64_t)n * C + c) * HW;
+    for (int k = threadIdx.x; k < HW; k += T) {
+      const float v = row[k];
+      s += v;
+      q += (double)v * v;
+    }
+  }
+  __shared__ double tot[2];
+  bn_block_sum2_t<T>(s, q, tot);
+  if (threadIdx.x == 0) {
+    stats[c] = tot[0];
+    stats[C + c] = tot[1];
+    if (c == 0) stats[2 * C] = (double)N * HW;
+  }
+}
+
+template <int T>
+__global__ __launch_bounds__(T) void k_bn2d_bwd_reduce_small(const float *__restrict__ dy, const float *__restrict__ y,
+                                                             const float *__restrict__ x,
+                                                             const float *__restrict__ save_mean,
+                                                             const float *__restrict__ save_invstd, int N, int C,
+                                                             int HW, float slope, int has_act, double *__restrict__ red,
+                                                             float *__restrict__ dgamma, float *__restrict__ dbeta) {
+  const int c = blockIdx.x;
+  const float mean = save_mean[c], invstd = save_invstd[c];
+  double s = 0.0, q = 0.0;
+  for (int n = 0; n < N; ++n) {
+    const int64_t base = ((int64_t)n * C + c) * HW;
+    for (int k = threadIdx.x; k < HW; k += T) {
+      float g = dy[base + k];
+      if (has_act) g = y[base + k] > 0.f ? g : g * slope;
+      s += g;
+      q += (double)g * (double)((x[base + k] - mean) * invstd);
+    }
+  }
+  __shared__ double tot[2];
+  bn_block_sum2_t<T>(s, q, tot);
+  if (threadIdx.x == 0) {
+    red[c] = tot[0];
+    red[C + c] = tot[1];
+    if (dbeta) dbeta[c] = (float)tot[0];
+    if (dgamma) dgamma[c] = (float)tot[1];
+  }
+}
+
 static int64_t bn_per_blk(int N, int C, int HW, int *S) {
   const int64_t total = (int64_t)N * HW;
   int s = 1024 / (C > 0 ? C : 1);
@@ -410,6 +463,14 @@ extern "C" int rslo_bn2d_stats(const float *x, int N, int C, int HW, void *ws, s
                                double *stats, void *stream) {
   RSLO_CHECK_ARG(x && ws && done && stats && N >= 1 && C >= 1 && HW >= 1, "rslo_bn2d_stats: bad arguments");
   RSLO_CHECK_ARG(ws_bytes >= rslo_bn2d_ws_bytes(N, C, HW), "rslo_bn2d_stats: workspace too small");
+  if ((int64_t)N * HW <= BN_SMALL_MAX) {
+    if (HW <= 1024)
+      hipLaunchKernelGGL((k_bn2d_stats_small<256>), dim3(C), dim3(256), 0, (hipStream_t)stream, x, N, C, HW, stats);
+    else
+      hipLaunchKernelGGL((k_bn2d_stats_small<1024>), dim3(C), dim3(1024), 0, (hipStream_t)stream, x, N, C, HW, stats);
+    RSLO_CHECK_LAUNCH("k_bn2d_stats_small");
+    return RSLO_OK;
+  }
   int S;
   const int64_t per = bn_per_blk(N, C, HW, &S);
   hipLaunchKernelGGL(k_bn2d_stats, dim3(S, C), dim3(BN_THREADS), 0, (hipStream_t)stream, x, N, C, HW, per, (double *)ws,
@@ -501,6 +562,16 @@ extern "C" int rslo_bn2d_bwd_reduce(const float *dy, const float *y, const float
   RSLO_CHECK_ARG(dy && x && save_mean && save_invstd && ws && done && red, "rslo_bn2d_bwd_reduce: bad arguments");
   RSLO_CHECK_ARG(!has_act || y, "rslo_bn2d_bwd_reduce: y is needed for the activation mask");
   RSLO_CHECK_ARG(ws_bytes >= rslo_bn2d_ws_bytes(N, C, HW), "rslo_bn2d_bwd_reduce: workspace too small");
+  if ((int64_t)N * HW <= BN_SMALL_MAX) {
+    if (HW <= 1024)
+      hipLaunchKernelGGL((k_bn2d_bwd_reduce_small<256>), dim3(C), dim3(256), 0, (hipStream_t)stream, dy, y, x, save_mean,
+                         save_invstd, N, C, HW, act_slope, has_act, red, dgamma, dbeta);
+    else
+      hipLaunchKernelGGL((k_bn2d_bwd_reduce_small<1024>), dim3(C), dim3(1024), 0, (hipStream_t)stream, dy, y, x, save_mean,
+                         save_invstd, N, C, HW, act_slope, has_act, red, dgamma, dbeta);
+    RSLO_CHECK_LAUNCH("k_bn2d_bwd_reduce_small");
+    return RSLO_OK;
+  }
   int S;
   const int64_t per = bn_per_blk(N, C, HW, &S);
   hipLaunchKernelGGL(k_bn2d_bwd_reduce, dim3(S, C), dim3(BN_THREADS), 0, (hipStream_t)stream, dy, y, x, save_mean,

@@ -447,16 +447,29 @@ def test_fused_bn2d_cross_rank_statistics_by_hand(hip):
     """The multi-rank path all-reduces the [2C+1] statistics between the two kernels: summing the statistics of two
     half batches by hand and applying them to each half must equal BatchNorm over the whole batch."""
     torch.manual_seed(1)
-    x = torch.randn(4, 16, 12, 22, device="cuda") * 1.5 + 0.2
-    g = torch.ones(16, device="cuda"); b = torch.zeros(16, device="cuda")
-    sa, sb = hip.bn2d_stats(x[:2].contiguous()), hip.bn2d_stats(x[2:].contiguous())
-    tot = sa + sb                                     # what dist.all_reduce(SUM) produces on every rank
-    rm, rv = torch.zeros(16, device="cuda"), torch.ones(16, device="cuda")
-    ya, mean, invstd = hip.bn2d_apply(x[:2].contiguous(), None, tot, g, b, rm, rv, 0.1, 1e-5, 1.0)
-    yb, _, _ = hip.bn2d_apply(x[2:].contiguous(), None, tot, g, b, None, None, 0.1, 1e-5, 1.0)
-    ref = torch.nn.functional.batch_norm(x, None, None, g, b, True, 0.1, 1e-5)
-    assert float((torch.cat([ya, yb]) - ref).abs().max()) < 2e-5
-    assert float((mean - x.mean((0, 2, 3))).abs().max()) < 1e-5
+    for shape in [(4, 16, 12, 22), (4, 8, 96, 176)]:          # direct per-channel sums / slice partials + finish
+        C_ = shape[1]
+        x = torch.randn(*shape, device="cuda") * 1.5 + 0.2
+        g = torch.ones(C_, device="cuda"); b = torch.zeros(C_, device="cuda")
+        sa, sb = hip.bn2d_stats(x[:2].contiguous()), hip.bn2d_stats(x[2:].contiguous())
+        tot = sa + sb                                     # what dist.all_reduce(SUM) produces on every rank
+        rm, rv = torch.zeros(C_, device="cuda"), torch.ones(C_, device="cuda")
+        ya, mean, invstd = hip.bn2d_apply(x[:2].contiguous(), None, tot, g, b, rm, rv, 0.1, 1e-5, 1.0)
+        yb, _, _ = hip.bn2d_apply(x[2:].contiguous(), None, tot, g, b, None, None, 0.1, 1e-5, 1.0)
+        ref = torch.nn.functional.batch_norm(x, None, None, g, b, True, 0.1, 1e-5)
+        assert float((torch.cat([ya, yb]) - ref).abs().max()) < 2e-5
+        assert float((mean - x.mean((0, 2, 3))).abs().max()) < 1e-5
+        # backward sums: both halves' reductions added by hand == the full-batch gradient
+        gy = torch.randn_like(x)
+        reds = [hip.bn2d_bwd_reduce(gy[h].contiguous(), None, x[h].contiguous(), mean, invstd, 1.0, False)[0]
+                for h in (slice(0, 2), slice(2, 4))]
+        red = reds[0] + reds[1]
+        cnt = float(x.shape[0] * x.shape[2] * x.shape[3])
+        dx = torch.cat([hip.bn2d_bwd_apply(gy[h].contiguous(), None, x[h].contiguous(), g, mean, invstd, red, cnt, 1.0,
+                                           False, False)[0] for h in (slice(0, 2), slice(2, 4))])
+        xr = x.clone().requires_grad_(True)
+        torch.nn.functional.batch_norm(xr, None, None, g, b, True, 0.1, 1e-5).backward(gy)
+        assert float((dx - xr.grad).abs().max()) < 2e-5 * max(1.0, float(xr.grad.abs().max()))
 
 
 def _syncbn_worker(rank, world, port, q):
