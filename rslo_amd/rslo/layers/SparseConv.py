@@ -68,16 +68,43 @@ class FusedSequential(nn.Sequential):
     SyncBatchNorm stand-in: one kernel pair per direction for BN + activation).  Same children, same state-dict keys,
     same results as nn.Sequential."""
 
-    def forward(self, x):
+    def _steps(self):
+        """[(module, fused activation slope or None)], rebuilt after the children change."""
+        steps = self.__dict__.get("_fused_steps")
+        if steps is not None:
+            return steps
         mods = list(self._modules.values())
-        i = 0
+        steps, i = [], 0
         while i < len(mods):
             m = mods[i]
             slope = act_slope_of(mods[i + 1]) if i + 1 < len(mods) else None
             if slope is not None and isinstance(m, SPC_SyncBN2d):
-                x = m(x, act_slope=slope)
+                steps.append((m, slope))
                 i += 2
-                continue
-            x = m(x)
-            i += 1
+            else:
+                steps.append((m, None))
+                i += 1
+        self.__dict__["_fused_steps"] = steps
+        return steps
+
+    def add_module(self, name, module):
+        self.__dict__.pop("_fused_steps", None)
+        super().add_module(name, module)
+
+    def __setitem__(self, idx, module):
+        self.__dict__.pop("_fused_steps", None)
+        super().__setitem__(idx, module)
+
+    def __delitem__(self, idx):
+        self.__dict__.pop("_fused_steps", None)
+        super().__delitem__(idx)
+
+    def __setattr__(self, name, value):
+        if isinstance(value, nn.Module) or name in self.__dict__.get("_modules", ()):
+            self.__dict__.pop("_fused_steps", None)
+        super().__setattr__(name, value)
+
+    def forward(self, x):
+        for m, slope in self._steps():
+            x = m(x) if slope is None else m(x, act_slope=slope)
         return x

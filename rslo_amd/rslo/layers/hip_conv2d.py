@@ -120,15 +120,26 @@ class Conv2d(nn.Conv2d):
     ungrouped on a CUDA fp32 tensor and the shape is supported; anything else is plain nn.Conv2d."""
     hip_wgrad = True
 
+    def _kind(self):
+        """Static part of the dispatch (module configuration only): "1x1", "3x3" or None.  Cached per configuration."""
+        key = (self.kernel_size, self.stride, self.padding, self.dilation, self.groups, self.padding_mode,
+               self.in_channels, self.out_channels)
+        cached = self.__dict__.get("_hip_kind")
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        kind = None
+        if self.dilation == (1, 1) and self.groups == 1 and self.padding_mode == "zeros":
+            if (self.kernel_size == (1, 1) and self.stride == (1, 1) and self.padding == (0, 0)
+                    and self.out_channels <= 8 and self.in_channels <= 256):
+                kind = "1x1"
+            elif self.kernel_size == (3, 3) and self.padding == (1, 1) and self.stride in ((1, 1), (2, 2)):
+                kind = "3x3"
+        self.__dict__["_hip_kind"] = (key, kind)
+        return kind
+
     def _eligible(self, x):
-        if not (self.hip_wgrad and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and torch.is_grad_enabled()
-                and self.weight.requires_grad):
-            return False
-        if self.kernel_size != (3, 3) or self.padding != (1, 1) or self.dilation != (1, 1) or self.groups != 1 \
-                or self.stride not in ((1, 1), (2, 2)) or self.padding_mode != "zeros":
-            return False
         ok = getattr(self, "_hip_ok", None)
-        key = (x.shape[2], x.shape[3])
+        key = (x.shape[2], x.shape[3], HIP_PASSES)
         if ok is None or ok[0] != key:
             from rslo_amd import capi
             w_ok = "w" in HIP_PASSES and capi.conv2d_wgrad_supported(self.in_channels, self.out_channels, key[0],
@@ -139,11 +150,11 @@ class Conv2d(nn.Conv2d):
         return ok[1] or ok[2]
 
     def _conv_forward(self, input, weight, bias):
-        if (self.kernel_size == (1, 1) and self.out_channels <= 8 and self.in_channels <= 256 and self.hip_wgrad
-                and "w" in HIP_PASSES and input.is_cuda and input.dtype == torch.float32 and input.dim() == 4
-                and torch.is_grad_enabled() and weight.requires_grad and self.stride == (1, 1)
-                and self.padding == (0, 0) and self.dilation == (1, 1) and self.groups == 1):
-            return _Conv1x1Fn.apply(input, weight, bias)
-        if self._eligible(input):
-            return _Conv3x3Fn.apply(input, weight, bias, self.stride[0], self._hip_ok[2], self._hip_ok[1])
+        if (self.hip_wgrad and input.is_cuda and input.dtype == torch.float32 and input.dim() == 4
+                and torch.is_grad_enabled() and weight.requires_grad):
+            kind = self._kind()
+            if kind == "1x1" and "w" in HIP_PASSES:
+                return _Conv1x1Fn.apply(input, weight, bias)
+            if kind == "3x3" and self._eligible(input):
+                return _Conv3x3Fn.apply(input, weight, bias, self.stride[0], self._hip_ok[2], self._hip_ok[1])
         return super()._conv_forward(input, weight, bias)
