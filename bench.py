@@ -172,6 +172,12 @@ class ConvProbe:
         except (OSError, ValueError):
             pmc = {}
 
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_mfma_busy.json")) as f:
+                pmc_busy = json.load(f).get("kernels", {})
+        except (OSError, ValueError):
+            pmc_busy = {}
+
         def roof_of(gname):
             g = groups[gname]
             name = gname.split(" [")[0]          # dense groups are keyed kernel + layer shape
@@ -199,6 +205,9 @@ class ConvProbe:
             # with rocprofv3 on this same command (scripts/pmc_bench_traffic.sh) and committed under profiles/
             if gname != name:
                 r["layer_shape"] = gname.split(" [")[1].rstrip("]")
+            if name in pmc_busy:       # matrix-core busy cycles / (shader cycles x 1024 SIMDs), scripts/pmc_mfma_busy.sh
+                r["mfma_busy_pct"] = pmc_busy[name]["mfma_busy_pct"]
+                r["mfma_busy_source"] = "profiles/r01_pmc_mfma_busy.json"
             if name in pmc:
                 r["traffic"] = int(pmc[name]["hbm_bytes_per_launch"])
                 r["traffic_source"] = "profiles/r01_pmc_traffic_bench.json" + (
