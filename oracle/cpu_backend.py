@@ -37,7 +37,27 @@ def voxelize(points, pc_range, voxel_size, grid_xyz, max_points, max_voxels):
     return vox, coords, num, torch.tensor([M], dtype=torch.int32)
 
 
+def _is64(*ts):
+    return any(isinstance(t, torch.Tensor) and t.dtype == torch.float64 for t in ts)
+
+
+def _conv64(x, W, nbr, transpose):
+    """float64 arbiter of the sparse conv on a neighbour table: y[o] = sum_k x[nbr[o,k]] @ W[k] (or W[k]^T) -- used
+    when the host modules are run in double precision to separate rounding from errors (tests/test_gpu_model.py)."""
+    n, K = nbr.shape
+    W = W.reshape(K, W.shape[-2], W.shape[-1])
+    y = np.zeros((n, W.shape[1] if transpose else W.shape[2]))
+    for k in range(K):
+        rows = np.nonzero(nbr[:, k] >= 0)[0]
+        if len(rows):
+            y[rows] += x[nbr[rows, k]] @ (W[k].T if transpose else W[k])
+    return y
+
+
 def vfe_mean(voxels, num_points):
+    if _is64(voxels):
+        m = voxels.sum(1) / num_points.to(voxels.dtype).reshape(-1, 1)
+        return torch.cat([m[:, :4], m[:, 4:7] / (m[:, 4:7].norm(dim=-1, keepdim=True) + 1e-12)], 1)
     return torch.from_numpy(O.vfe_mean(_np(voxels), _np(num_points)))
 
 
@@ -58,6 +78,13 @@ def spconv_fwd(x, W, bias, nbr, flip_k=False, act_slope=1.0):
     Wn = _np(W)
     if flip_k:
         Wn = Wn[::-1].copy()
+    if _is64(x, W):
+        y = _conv64(_np(x).astype(np.float64), Wn.astype(np.float64), _np(nbr), False)
+        if bias is not None:
+            y = y + _np(bias).astype(np.float64)
+        if act_slope != 1.0:
+            y = np.where(y > 0, y, y * act_slope)
+        return torch.from_numpy(y)
     y = O.spconv_fwd(_np(x), Wn, None if bias is None else _np(bias), _np(nbr))
     if act_slope != 1.0:
         y = np.where(y > 0, y, y * np.float32(act_slope)).astype(np.float32)
@@ -68,10 +95,20 @@ def spconv_dgrad(dout, W, nbrT, flip_k=False):
     Wn = _np(W)
     if flip_k:
         Wn = Wn[::-1].copy()
+    if _is64(dout, W):
+        return torch.from_numpy(_conv64(_np(dout).astype(np.float64), Wn.astype(np.float64), _np(nbrT), True))
     return torch.from_numpy(O.spconv_dgrad(_np(dout), Wn, _np(nbrT)))
 
 
 def spconv_wgrad(x, dout, nbr, cin, cout, with_bias=True):
+    if _is64(x, dout):
+        t, xd, gd = _np(nbr), _np(x).astype(np.float64), _np(dout).astype(np.float64)
+        dW = np.zeros((t.shape[1], cin, cout))
+        for k in range(t.shape[1]):
+            rows = np.nonzero(t[:, k] >= 0)[0]
+            if len(rows):
+                dW[k] = xd[t[rows, k]].T @ gd[rows]
+        return torch.from_numpy(dW), (torch.from_numpy(gd.sum(0)) if with_bias else None)
     dW, db = O.spconv_wgrad(_np(x), _np(dout), _np(nbr), cin, cout)
     return torch.from_numpy(dW), (torch.from_numpy(db) if with_bias else None)
 
@@ -97,6 +134,8 @@ def spconv_wgrad_pairs(x, dout, pairs, n_out, K, cin, cout, with_bias=True, bias
         a, b = int(koff[k]), int(koff[k + 1])
         if b > a:
             dW[k] = xd[pin[a:b]].T @ gd[pout[a:b]]
+    if _is64(x, dout):
+        return torch.from_numpy(dW), (torch.from_numpy(gd.sum(0)) if with_bias else None)
     db = torch.from_numpy(gd.sum(0).astype(np.float32)) if with_bias else None
     return torch.from_numpy(dW.astype(np.float32)), db
 
@@ -107,6 +146,11 @@ def leaky_bwd(y, dout, slope, colsum=False):
 
 
 def dense_scatter(feat, coords, batch, dims):
+    if _is64(feat):
+        out = torch.zeros(batch, *[int(d) for d in dims], feat.shape[1], dtype=feat.dtype)
+        c = coords.long()
+        out[c[:, 0], c[:, 1], c[:, 2], c[:, 3]] = feat
+        return out.permute(0, 4, 1, 2, 3).contiguous()
     return torch.from_numpy(O.dense(_np(feat), _np(coords), batch, list(dims)))
 
 
@@ -116,6 +160,14 @@ def dense_gather(dense, coords, C_, batch, dims):
 
 
 def chamfer_nn(xyz1, xyz2, dist=None, idx=None, ncnt=None, mcnt=None):
+    if _is64(xyz1, xyz2):       # neighbour choice by the fp32 search, distance recomputed in double
+        _, i = chamfer_nn(xyz1.float(), xyz2.float(), None, None, ncnt, mcnt)
+        nb = torch.gather(xyz2, 1, i.long()[..., None].expand(-1, -1, 3))
+        d = ((xyz1 - nb) ** 2).sum(-1)
+        if ncnt is not None:
+            d = torch.where(torch.arange(d.shape[1])[None] < torch.as_tensor(ncnt).reshape(-1, 1).long(), d,
+                            torch.full_like(d, float("inf")))
+        return d, i
     if ncnt is None and mcnt is None:
         d, i = O.chamfer_nn(_np(xyz1), _np(xyz2))
     else:       # ragged batch: pair by pair on the valid prefixes, padding rows get +inf / 0
@@ -137,6 +189,11 @@ def chamfer_nn(xyz1, xyz2, dist=None, idx=None, ncnt=None, mcnt=None):
 
 
 def chamfer_grad(xyz1, xyz2, graddist1, idx1, g1=None, g2=None):
+    if _is64(xyz1, xyz2, graddist1):
+        nb = torch.gather(xyz2, 1, idx1.long()[..., None].expand(-1, -1, 3))
+        a = 2 * graddist1[..., None] * (xyz1 - nb)
+        b = torch.zeros_like(xyz2).scatter_add_(1, idx1.long()[..., None].expand(-1, -1, 3), -a)
+        return a, b
     a, b = O.chamfer_grad(_np(xyz1), _np(xyz2), _np(graddist1), _np(idx1))
     a, b = torch.from_numpy(a), torch.from_numpy(b)
     if g1 is not None:

@@ -12,7 +12,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librslo_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
+# -fno-slp-vectorize: the SLP pass pairs independent fp32 operations into v_pk_*_f32, which issue at half rate on
+# gfx950 and need their operands in adjacent registers (extra v_mov): measured 80 -> 128 us on k_wgrad3<64,64>
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-fno-slp-vectorize",
          "-Wno-unused-result"]
 
 
@@ -38,8 +40,7 @@ def build(force=False, verbose=True):
     for s in sources():
         o = os.path.join(HERE, "_obj", os.path.basename(s) + ".o")
         objs.append(o)
-        cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
-               "-Wno-unused-result", "-c", s, "-o", o]
+        cmd = [HIPCC] + FLAGS + ["-c", s, "-o", o]
         if verbose:
             print("[rslo_amd.build]", " ".join(cmd), flush=True)
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -33,21 +33,14 @@ struct Split3 {
 
 // 8 fp32 values -> three bf16x8 operands; bit e of `mask` keeps value e, cleared bits give zeros
 __device__ __forceinline__ Split3 split_masked(const float (&v)[8], unsigned mask) {
-  unsigned hb[8], mb[8], lb[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const float x = ((mask >> e) & 1u) ? v[e] : 0.f;
-    hb[e] = __float_as_uint(x) & 0xffff0000u;
-    const float r1 = x - __uint_as_float(hb[e]);
-    mb[e] = __float_as_uint(r1) & 0xffff0000u;
-    lb[e] = __float_as_uint(r1 - __uint_as_float(mb[e]));
-  }
   Split3 o;
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
-    o.h[p] = __builtin_amdgcn_perm(hb[2 * p + 1], hb[2 * p], 0x07060302u);
-    o.m[p] = __builtin_amdgcn_perm(mb[2 * p + 1], mb[2 * p], 0x07060302u);
-    o.l[p] = __builtin_amdgcn_perm(lb[2 * p + 1], lb[2 * p], 0x07060302u);
+    const RsloSplit2 s = rslo_split2(((mask >> (2 * p)) & 1u) ? v[2 * p] : 0.f,
+                                     ((mask >> (2 * p + 1)) & 1u) ? v[2 * p + 1] : 0.f);
+    o.h[p] = s.h;
+    o.m[p] = s.m;
+    o.l[p] = s.l;
   }
   return o;
 }
@@ -294,26 +287,21 @@ __global__ __launch_bounds__(C2_THREADS, NB == 2 ? 3 : 2) void k_conv2d_wgrad_s1
           r[j] = (q >= 0 && q < in_total) ? in[q] : 0.f;
         }
       }
-      unsigned hb[10], mb[10], lb[10];
-#pragma unroll
-      for (int j = 0; j < 10; ++j) {
-        hb[j] = __float_as_uint(r[j]) & 0xffff0000u;
-        const float r1 = r[j] - __uint_as_float(hb[j]);
-        mb[j] = __float_as_uint(r1) & 0xffff0000u;
-        lb[j] = __float_as_uint(r1 - __uint_as_float(mb[j]));
-      }
+      // even pairs (2i, 2i+1) by the packed round-to-nearest split; odd pairs (2i+1, 2i+2) = high half of even pair
+      // i | low half of even pair i+1
       unsigned Eh[5], Em[5], El[5], Oh[4], Om[4], Ol[4];
 #pragma unroll
       for (int i = 0; i < 5; ++i) {
-        Eh[i] = __builtin_amdgcn_perm(hb[2 * i + 1], hb[2 * i], 0x07060302u);
-        Em[i] = __builtin_amdgcn_perm(mb[2 * i + 1], mb[2 * i], 0x07060302u);
-        El[i] = __builtin_amdgcn_perm(lb[2 * i + 1], lb[2 * i], 0x07060302u);
+        const RsloSplit2 sp = rslo_split2(r[2 * i], r[2 * i + 1]);
+        Eh[i] = sp.h;
+        Em[i] = sp.m;
+        El[i] = sp.l;
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        Oh[i] = __builtin_amdgcn_perm(hb[2 * i + 2], hb[2 * i + 1], 0x07060302u);
-        Om[i] = __builtin_amdgcn_perm(mb[2 * i + 2], mb[2 * i + 1], 0x07060302u);
-        Ol[i] = __builtin_amdgcn_perm(lb[2 * i + 2], lb[2 * i + 1], 0x07060302u);
+        Oh[i] = __builtin_amdgcn_perm(Eh[i + 1], Eh[i], 0x05040302u);
+        Om[i] = __builtin_amdgcn_perm(Em[i + 1], Em[i], 0x05040302u);
+        Ol[i] = __builtin_amdgcn_perm(El[i + 1], El[i], 0x05040302u);
       }
       const unsigned my = vp & (ky == 0 ? vy0 : (ky == 2 ? vy2 : 0xffu));
 #pragma unroll
@@ -554,14 +542,8 @@ __global__ void k_conv2d_wsplit(const float *__restrict__ W, int cin, int cout, 
   const int chunk = (int)(r / 9);
   const int m = mt * 16 + (lane & 15), k = chunk * 32 + 8 * (lane >> 4) + e;
   const float x = transpose ? W[((int64_t)k * cin + m) * 9 + (8 - tap)] : W[((int64_t)m * cin + k) * 9 + tap];
-  const unsigned hb = __float_as_uint(x) & 0xffff0000u;
-  const float r1 = x - __uint_as_float(hb);
-  const unsigned mb = __float_as_uint(r1) & 0xffff0000u;
-  const float r2 = r1 - __uint_as_float(mb);
   const int64_t base = ((((int64_t)chunk * 9 + tap) * n_mt + mt) * 3) * 512 + lane * 8 + e;
-  Ws[base] = (unsigned short)(hb >> 16);
-  Ws[base + 512] = (unsigned short)(mb >> 16);
-  Ws[base + 1024] = (unsigned short)(__float_as_uint(r2) >> 16);
+  rslo_split1(x, Ws[base], Ws[base + 512], Ws[base + 1024]);
 }
 
 // all layers of a model in one launch: grid (ceil(max_n / 256), 2 * n_layers); row 2 l + t splits layer l with
@@ -584,14 +566,8 @@ __global__ void k_conv2d_wsplit_many(const RsloConv2dSplitDesc *__restrict__ des
   const int chunk = (int)(r / 9);
   const int m = mt * 16 + (lane & 15), k = chunk * 32 + 8 * (lane >> 4) + e;
   const float x = transpose ? W[((int64_t)k * cin + m) * 9 + (8 - tap)] : W[((int64_t)m * cin + k) * 9 + tap];
-  const unsigned hb = __float_as_uint(x) & 0xffff0000u;
-  const float r1 = x - __uint_as_float(hb);
-  const unsigned mb = __float_as_uint(r1) & 0xffff0000u;
-  const float r2 = r1 - __uint_as_float(mb);
   const int64_t base = ((((int64_t)chunk * 9 + tap) * n_mt + mt) * 3) * 512 + lane * 8 + e;
-  Ws[base] = (unsigned short)(hb >> 16);
-  Ws[base + 512] = (unsigned short)(mb >> 16);
-  Ws[base + 1024] = (unsigned short)(__float_as_uint(r2) >> 16);
+  rslo_split1(x, Ws[base], Ws[base + 512], Ws[base + 1024]);
 }
 
 struct Conv2dFwdGeom {

@@ -487,14 +487,7 @@ __device__ __forceinline__ void weight_split_elem(const float *__restrict__ W, i
   const int ch = (cout_op / 16) * (co & 15) + (co >> 4);
   const float w = transpose ? W[((int64_t)k * cout_op + ch) * cin_op + ci]      // W is [K, Cin_w = cout_op, Cout_w = cin_op]
                             : W[((int64_t)k * cin_op + ci) * cout_op + ch];
-  const unsigned wb = __float_as_uint(w);
-  const unsigned hb = wb & 0xffff0000u;
-  const float r1 = w - __uint_as_float(hb);
-  const unsigned mb = __float_as_uint(r1) & 0xffff0000u;
-  const float r2 = r1 - __uint_as_float(mb);
-  Ws[i] = (unsigned short)(hb >> 16);
-  Ws[n + i] = (unsigned short)(mb >> 16);
-  Ws[2 * n + i] = (unsigned short)(__float_as_uint(r2) >> 16);
+  rslo_split1(w, Ws[i], Ws[n + i], Ws[2 * n + i]);
 }
 
 __global__ void k_weight_split(const float *__restrict__ W, int K, int cin_op, int cout_op, int transpose,
@@ -517,22 +510,14 @@ struct Split8 {
 
 // 8 fp32 values (two float4) -> three bf16x8 operands
 __device__ __forceinline__ Split8 split8(const float4 a, const float4 b, bool ok) {
-  float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-  unsigned hb[8], mb[8], lb[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const float x = ok ? v[e] : 0.f;
-    hb[e] = __float_as_uint(x) & 0xffff0000u;
-    const float r1 = x - __uint_as_float(hb[e]);
-    mb[e] = __float_as_uint(r1) & 0xffff0000u;
-    lb[e] = __float_as_uint(r1 - __uint_as_float(mb[e]));
-  }
+  const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
   Split8 o;
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
-    o.h[p] = __builtin_amdgcn_perm(hb[2 * p + 1], hb[2 * p], 0x07060302u);
-    o.m[p] = __builtin_amdgcn_perm(mb[2 * p + 1], mb[2 * p], 0x07060302u);
-    o.l[p] = __builtin_amdgcn_perm(lb[2 * p + 1], lb[2 * p], 0x07060302u);
+    const RsloSplit2 s = rslo_split2(ok ? v[2 * p] : 0.f, ok ? v[2 * p + 1] : 0.f);
+    o.h[p] = s.h;
+    o.m[p] = s.m;
+    o.l[p] = s.l;
   }
   return o;
 }
@@ -1310,7 +1295,7 @@ __global__ __launch_bounds__(SPC_THREADS) void k_wgrad3(const float *__restrict_
       float araw[8][CB];
 #pragma unroll
       for (int p = 0; p < 4; ++p) {                      // k-values e = 2p, 2p+1 -> dword p of every operand
-        unsigned xb[2][NB][3];
+        float xb[2][NB];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           const int src = h * 32 + 4 * (2 * p + t) + g;
@@ -1322,21 +1307,14 @@ __global__ __launch_bounds__(SPC_THREADS) void k_wgrad3(const float *__restrict_
 #pragma unroll
           for (int cb = 0; cb < CB; ++cb) araw[2 * p + t][cb] = ok ? va.v[cb] : 0.f;
 #pragma unroll
-          for (int nb = 0; nb < NB; ++nb) {
-            const float x = ok ? vb.v[nb] : 0.f;
-            const unsigned hb = __float_as_uint(x) & 0xffff0000u;
-            const float r1 = x - __uint_as_float(hb);
-            const unsigned mb = __float_as_uint(r1) & 0xffff0000u;
-            xb[t][nb][0] = hb;
-            xb[t][nb][1] = mb;
-            xb[t][nb][2] = __float_as_uint(r1 - __uint_as_float(mb));
-          }
+          for (int nb = 0; nb < NB; ++nb) xb[t][nb] = ok ? vb.v[nb] : 0.f;
         }
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-          bh[nb][p] = __builtin_amdgcn_perm(xb[1][nb][0], xb[0][nb][0], 0x07060302u);
-          bm[nb][p] = __builtin_amdgcn_perm(xb[1][nb][1], xb[0][nb][1], 0x07060302u);
-          bl[nb][p] = __builtin_amdgcn_perm(xb[1][nb][2], xb[0][nb][2], 0x07060302u);
+          const RsloSplit2 sb = rslo_split2(xb[0][nb], xb[1][nb]);
+          bh[nb][p] = sb.h;
+          bm[nb][p] = sb.m;
+          bl[nb][p] = sb.l;
         }
       }
 #pragma unroll
@@ -1344,20 +1322,10 @@ __global__ __launch_bounds__(SPC_THREADS) void k_wgrad3(const float *__restrict_
         u32x4 ah, am, al;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-          unsigned xa[2][3];
-#pragma unroll
-          for (int t = 0; t < 2; ++t) {
-            const float x = araw[2 * p + t][cb];
-            const unsigned hb = __float_as_uint(x) & 0xffff0000u;
-            const float r1 = x - __uint_as_float(hb);
-            const unsigned mb = __float_as_uint(r1) & 0xffff0000u;
-            xa[t][0] = hb;
-            xa[t][1] = mb;
-            xa[t][2] = __float_as_uint(r1 - __uint_as_float(mb));
-          }
-          ah[p] = __builtin_amdgcn_perm(xa[1][0], xa[0][0], 0x07060302u);
-          am[p] = __builtin_amdgcn_perm(xa[1][1], xa[0][1], 0x07060302u);
-          al[p] = __builtin_amdgcn_perm(xa[1][2], xa[0][2], 0x07060302u);
+          const RsloSplit2 sa = rslo_split2(araw[2 * p][cb], araw[2 * p + 1][cb]);
+          ah[p] = sa.h;
+          am[p] = sa.m;
+          al[p] = sa.l;
         }
         // six products per block, smallest first; consecutive MFMAs hit different accumulators (the NB column blocks)
 #pragma unroll

