@@ -203,7 +203,70 @@ def test_encoder_fwd_bwd_matches_cpu_oracle(hip):
             assert rel(p.grad, pc.grad) < 5e-3, n
 
 
+def three_way(net, ex):
+    """One training step three ways on the same inputs and parameters: HIP kernels (fp32), the same host modules over
+    the CPU oracle in fp32 (the reference-semantics path), and over the oracle backend in float64 (the arbiter that
+    separates rounding from errors).  Returns [(outputs, network)] in that order."""
+    net_c32 = copy.deepcopy(net).cpu()
+    net_f64 = copy.deepcopy(net).cpu().double()
+    ret = net(ex)
+    ret["loss"].backward()
+    ex_cpu = example_to_cpu(ex)
+    with cpu_backend.patched():
+        ret_c = net_c32(ex_cpu)
+        ret_c["loss"].backward()
+        ret_64 = net_f64(example_to_f64(ex_cpu))
+        ret_64["loss"].backward()
+    return (ret, net), (ret_c, net_c32), (ret_64, net_f64)
+
+
+def gradient_errors(nets, skip):
+    """Per parameter: (max-rel error of the GPU gradient vs float64, of the CPU-fp32 gradient vs float64, name)."""
+    (gpu, c32, f64) = nets
+    rows = []
+    for (n, p), (_, pc), (_, p64) in zip(gpu.named_parameters(), c32.named_parameters(), f64.named_parameters()):
+        if n in skip:
+            continue
+        if p64.grad is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
+            continue
+        assert p.grad is not None, n
+        if float(p64.grad.abs().max()) < 1e-6:    # analytically zero (e.g. the softmax-shift bias of a confidence head)
+            assert float(p.grad.abs().max()) < 1e-5, n
+            continue
+        rows.append((rel(p.grad, p64.grad), rel(pc.grad, p64.grad), n))
+    return rows
+
+
+def check_three_way(net, ex, median_bar, max_bar, ratio_bar):
+    """Bars (measured values in DESIGN.md section 4; scripts/parity_report.py prints the full table):
+      * poses within 1e-4 relative of the CPU path AND of the float64 arbiter (north star),
+      * loss terms within 2e-4 relative (measured <= 5e-5: C_loss, which sees the pose through residuals of ~0.1 m
+        on coordinates of ~50 m),
+      * gradients against float64.  The consistency loss differentiates residuals of ~0.1 m between points ~50 m from
+        the sensor, so a pose that differs by 1e-6 (fp32 rounding of either implementation) moves every gradient
+        by ~1e-3: BOTH fp32 paths sit at 3e-4..3e-3 from float64, which is why the bar is on the distance to the
+        arbiter and on the ratio to the CPU path's own distance, not on GPU-vs-CPU alone."""
+    (ret, _), (ret_c, _), (ret_64, _) = res = three_way(net, ex)
+    for k in ("translation_preds", "rotation_preds"):
+        assert rel(ret[k], ret_c[k]) < 1e-4, k
+        assert rel(ret[k], ret_64[k]) < 1e-4, k
+    for k in ("loss", "translation_loss", "rotation_loss", "pyramid_loss", "C_loss"):
+        assert rel(ret[k], ret_c[k]) < 2e-4, k
+        assert rel(ret[k], ret_64[k]) < 2e-4, k
+    rows = gradient_errors([r[1] for r in res], bias_before_bn(net))
+    assert len(rows) >= 170   # 213 of 290 parameter tensors receive gradients (SURVEY.md App-A.2)
+    e_gpu = np.array([r[0] for r in rows])
+    e_cpu = np.array([r[1] for r in rows])
+    worst = rows[int(e_gpu.argmax())]
+    assert np.median(e_gpu) < median_bar, (np.median(e_gpu), np.median(e_cpu))
+    assert e_gpu.max() < max_bar, worst
+    assert np.median(e_gpu) < ratio_bar * np.median(e_cpu), (np.median(e_gpu), np.median(e_cpu))
+    return rows
+
+
 def test_full_network_fwd_bwd_matches_cpu_oracle(hip):
+    """Reduced pair (every 4th ring, ~9-10 k voxels per frame), one sample."""
     torch.manual_seed(7)
     net, _ = workload.build_network()
     net.train()
@@ -211,35 +274,22 @@ def test_full_network_fwd_bwd_matches_cpu_oracle(hip):
     trained_like_init(net)
     p0, p1, _ = reduced_pair(1)
     ex = workload.make_example(net, [[p0, p1]])
-    net_cpu = clone_to_cpu(net)
-    ret = net(ex)
-    ret["loss"].backward()
-    with cpu_backend.patched():
-        ret_c = net_cpu(example_to_cpu(ex))
-        ret_c["loss"].backward()
-    # pose output within 1e-4 relative of the CPU reference-semantics path (north star)
-    assert rel(ret["translation_preds"], ret_c["translation_preds"]) < 1e-4
-    assert rel(ret["rotation_preds"], ret_c["rotation_preds"]) < 1e-4
-    # loss terms hang off the ICP pseudo-targets (amplified fp32 differences): 2e-3 relative
-    for k in ("loss", "translation_loss", "rotation_loss", "pyramid_loss", "C_loss"):
-        assert rel(ret[k], ret_c[k]) < 2e-3, k
-    checked = 0
-    skip = bias_before_bn(net)
-    for (n, p), (_, pc) in zip(net.named_parameters(), net_cpu.named_parameters()):
-        if n in skip:
-            continue
-        if pc.grad is None:
-            assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
-            continue
-        assert p.grad is not None, n
-        if float(pc.grad.abs().max()) < 1e-6:     # analytically zero (e.g. the softmax-shift bias of a confidence head)
-            assert float(p.grad.abs().max()) < 1e-5, n
-            continue
-        # sparse encoder + loss parameters: 2e-2; the dense head runs through MIOpen on one side and the CPU
-        # conv on the other over ~30 chained fp32 layers on a random-init net (ReLU masks flip): 5e-2
-        assert rel(p.grad, pc.grad) < (5e-2 if n.startswith("odom_predictor.") else 2e-2), n
-        checked += 1
-    assert checked >= 170   # 213 of 290 parameter tensors receive gradients
+    # measured: median 4e-4..1e-3 (CPU fp32 path: 3e-4), max 1.6e-2
+    check_three_way(net, ex, median_bar=2e-3, max_bar=2.5e-2, ratio_bar=8.0)
+
+
+def test_c3_full_size_step_matches_cpu_oracle(hip):
+    """BASELINE config C3 itself: 4 frame pairs of full 64-ring scans (~130 k voxels in the batched encoder pass),
+    forward + loss + backward, against the CPU path and the float64 arbiter (about 90 s of CPU work)."""
+    torch.manual_seed(7)
+    net, _ = workload.build_network()
+    net.train()
+    net.global_step.fill_(2000)
+    trained_like_init(net)
+    ex = workload.make_example(net, [list(reduced_pair(b + 1, rings=64)[:2]) for b in range(4)])
+    assert sum(int(v.sum()) for v in ex["num_voxels"]) > 200000
+    # measured: median 2.9e-3 (CPU fp32 path: 3.1e-3, ratio 1.05), max 3.8e-2
+    check_three_way(net, ex, median_bar=6e-3, max_bar=6e-2, ratio_bar=2.0)
 
 
 def test_eval_forward_batched_equals_per_sample(hip):
