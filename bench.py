@@ -102,16 +102,16 @@ class ConvProbe:
                 return out
             return wrapper
 
-        def fwd_meta(x, W, bias, nbr, flip_k=False, act_slope=1.0):
+        def fwd_meta(x, W, bias, nbr, flip_k=False, act_slope=1.0, order=None):
             K, cin, cout = W.shape
             return ("fwd", cin, cout, K, nbr.shape[0], nbr if probe.keep_tables else None,
                     probe.kernel_name(cin, cout, nbr.shape[0], False))
 
-        def split_meta(x, Ws, bias, nbr, cin, cout, flip_k=False, act_slope=1.0):
+        def split_meta(x, Ws, bias, nbr, cin, cout, flip_k=False, act_slope=1.0, order=None):
             return ("fwd", cin, cout, nbr.shape[1], nbr.shape[0], nbr if probe.keep_tables else None,
                     probe.kernel_name(cin, cout, nbr.shape[0], False, split=True))
 
-        def dgrad_meta(dout, W, nbrT, flip_k=False):
+        def dgrad_meta(dout, W, nbrT, flip_k=False, order=None):
             K, cin, cout = W.shape
             return ("dgrad", cout, cin, K, nbrT.shape[0], nbrT if probe.keep_tables else None,
                     probe.kernel_name(cout, cin, nbrT.shape[0], True))

@@ -113,11 +113,13 @@ RSLO_API int rslo_rulebook_conv_T(const int32_t *coords_in, int64_t N, int B, co
  * wgrad: dW[k]  = sum_o in[nbr[o][k]]^T dout[o]      (deterministic two-stage reduce)
  * Supported channel counts: 1..64 on both sides.
  * ------------------------------------------------------------------------------------ */
+/*     row_order (int32 [n_out] or NULL): the order in which the table rows are grouped into the kernels' 16/32-row tiles
+ *     (rslo_rulebook_row_order).  Purely a scheduling hint: out[o] is written for every o and does not depend on it. */
 RSLO_API int rslo_spconv_fwd(const float *in, int cin, const float *W, const float *bias, const int32_t *nbr,
-                    int64_t n_out, int K, int cout, int flip_k, float act_slope, float *out,
-                    void *stream);
-RSLO_API int rslo_spconv_dgrad(const float *dout, int cout, const float *W, const int32_t *nbrT, int64_t n_in,
-                      int K, int cin, int flip_k, float *din, void *stream);
+                    const int32_t *row_order, int64_t n_out, int K, int cout, int flip_k, float act_slope,
+                    float *out, void *stream);
+RSLO_API int rslo_spconv_dgrad(const float *dout, int cout, const float *W, const int32_t *nbrT,
+                      const int32_t *row_order, int64_t n_in, int K, int cin, int flip_k, float *din, void *stream);
 /*     W [K,Cin,Cout] -> Wt [K,Cout,Cin].  rslo_spconv_fwd(dout, Cout, Wt, NULL, nbrT, ...) then equals
  *     rslo_spconv_dgrad(dout, Cout, W, nbrT, ...) with weight reads contiguous along the lane index
  *     (12-50 % faster on the 64-channel layers); the host mirror uses this form. */
@@ -142,19 +144,26 @@ typedef struct {
 RSLO_API int rslo_weight_split_many(const RsloWeightSplitDesc *desc_dev, int n_layers, int64_t max_weight_elems,
                                     void *stream);
 RSLO_API int rslo_spconv_fwd_split(const float *in, int cin, const void *Ws, const float *bias, const int32_t *nbr,
-                                   int64_t n_out, int K, int cout, int flip_k, float act_slope, float *out,
-                                   void *stream);
+                                   const int32_t *row_order, int64_t n_out, int K, int cout, int flip_k,
+                                   float act_slope, float *out, void *stream);
 /*     bf16 feature path (BASELINE config C4: bf16 features, int32 rulebook, fp32 accumulate): in / out are bf16 rows
  *     [N,C], Wb the weights rounded to bf16 in MFMA operand order (rslo_weight_to_bf16, K*cin*cout*2 bytes; transpose
  *     = 1 for the data gradient), bias fp32.  Channel counts 32 / 64. */
 RSLO_API int rslo_weight_to_bf16(const float *W, int K, int cin_op, int cout_op, int transpose, void *Wb, void *stream);
 RSLO_API int rslo_spconv_fwd_bf16(const void *in, int cin, const void *Wb, const float *bias, const int32_t *nbr,
-                                  int64_t n_out, int K, int cout, int flip_k, float act_slope, void *out,
-                                  void *stream);
+                                  const int32_t *row_order, int64_t n_out, int K, int cout, int flip_k,
+                                  float act_slope, void *out, void *stream);
 RSLO_API size_t rslo_spconv_wgrad_ws_bytes(int64_t n_out, int K, int cin, int cout);
 RSLO_API int rslo_spconv_wgrad(const float *in, int cin, const float *dout, int cout, const int32_t *nbr,
                       int64_t n_out, int K, void *ws, size_t ws_bytes, float *dW /*[K,cin,cout]*/,
                       float *dbias /*[cout] or NULL*/, void *stream);
+/* Scheduling order of a neighbour table's rows for rslo_spconv_fwd / _dgrad / _fwd_split / _fwd_bf16: inside every
+ * window of 2048 consecutive rows, rows are sorted by their neighbour mask so that the kernels' 16/32-row tiles issue
+ * matrix operations for fewer kernel offsets no row of the tile needs.  order [n_rows] is a permutation of 0..n_rows-1
+ * (deterministic).  flip_k = 1: order for calls made with flip_k = 1 (SubM data gradient).  Replaces nothing in the
+ * reference: spconv's gather-GEMM-scatter walks complete pair lists per offset and has no tile skipping to feed. */
+RSLO_API int rslo_rulebook_row_order(const int32_t *nbr, int64_t n_rows, int K, int flip_k, int32_t *order,
+                                     void *stream);
 /* Pair-list view of a neighbour table (the spconv-1.x rulebook layout): pairs of offset k are contiguous in
  * [koff[k], koff[k+1]) in ascending output row; pairs_in/out need room for n_rows*K entries (upper bound),
  * koff [K+1] lives on the device.  Built once per indice_key; feeds the weight-gradient kernel. */

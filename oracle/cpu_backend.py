@@ -74,7 +74,7 @@ def rulebook_conv(index, ks, stride, pad):
     return SiteIndex(torch.from_numpy(oc), index.batch, od), torch.from_numpy(nbr), torch.from_numpy(nbrT)
 
 
-def spconv_fwd(x, W, bias, nbr, flip_k=False, act_slope=1.0):
+def spconv_fwd(x, W, bias, nbr, flip_k=False, act_slope=1.0, order=None):
     Wn = _np(W)
     if flip_k:
         Wn = Wn[::-1].copy()
@@ -91,7 +91,7 @@ def spconv_fwd(x, W, bias, nbr, flip_k=False, act_slope=1.0):
     return torch.from_numpy(y)
 
 
-def spconv_dgrad(dout, W, nbrT, flip_k=False):
+def spconv_dgrad(dout, W, nbrT, flip_k=False, order=None):
     Wn = _np(W)
     if flip_k:
         Wn = Wn[::-1].copy()
@@ -111,6 +111,10 @@ def spconv_wgrad(x, dout, nbr, cin, cout, with_bias=True):
         return torch.from_numpy(dW), (torch.from_numpy(gd.sum(0)) if with_bias else None)
     dW, db = O.spconv_wgrad(_np(x), _np(dout), _np(nbr), cin, cout)
     return torch.from_numpy(dW), (torch.from_numpy(db) if with_bias else None)
+
+
+def rulebook_row_order(nbr, flip_k=False):
+    return None         # a scheduling hint of the GPU kernels; results do not depend on it
 
 
 def rulebook_pairs(nbr):
@@ -204,7 +208,7 @@ def chamfer_grad(xyz1, xyz2, graddist1, idx1, g1=None, g2=None):
 
 
 _NAMES = ["SiteIndex", "voxelize", "vfe_mean", "rulebook_subm", "conv_out_dims", "rulebook_conv", "spconv_fwd",
-          "spconv_dgrad", "spconv_wgrad", "rulebook_pairs", "spconv_wgrad_pairs", "leaky_bwd", "dense_scatter", "dense_gather", "chamfer_nn", "chamfer_grad"]
+          "spconv_dgrad", "spconv_wgrad", "rulebook_row_order", "rulebook_pairs", "spconv_wgrad_pairs", "leaky_bwd", "dense_scatter", "dense_gather", "chamfer_nn", "chamfer_grad"]
 
 
 @contextlib.contextmanager

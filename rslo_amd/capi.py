@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librslo_hip.so")
+LIB_PATH = os.environ.get("RSLO_HIP_LIB") or os.path.join(_HERE, "librslo_hip.so")   # override: kernel experiments only
 _lib = None
 
 _I3 = C.c_int32 * 3
@@ -34,17 +34,18 @@ SIGNATURES = {
     "rslo_conv_out_coords": (C.c_int, [_vp, _vp, _i64, _i, _vp, _vp, _i64, _vp]),
     "rslo_rulebook_conv": (C.c_int, [_vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "rslo_rulebook_conv_T": (C.c_int, [_vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
-    "rslo_spconv_fwd": (C.c_int, [_vp, _i, _vp, _vp, _vp, _i64, _i, _i, _i, _f, _vp, _vp]),
-    "rslo_spconv_dgrad": (C.c_int, [_vp, _i, _vp, _vp, _i64, _i, _i, _i, _vp, _vp]),
+    "rslo_spconv_fwd": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _f, _vp, _vp]),
+    "rslo_spconv_dgrad": (C.c_int, [_vp, _i, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _vp]),
     "rslo_weight_transpose": (C.c_int, [_vp, _i, _i, _i, _vp, _vp]),
     "rslo_weight_split_bytes": (_sz, [_i, _i, _i]),
     "rslo_weight_split": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "rslo_weight_split_many": (C.c_int, [_vp, _i, _i64, _vp]),
-    "rslo_spconv_fwd_split": (C.c_int, [_vp, _i, _vp, _vp, _vp, _i64, _i, _i, _i, C.c_float, _vp, _vp]),
+    "rslo_spconv_fwd_split": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, C.c_float, _vp, _vp]),
     "rslo_weight_to_bf16": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp]),
-    "rslo_spconv_fwd_bf16": (C.c_int, [_vp, _i, _vp, _vp, _vp, _i64, _i, _i, _i, C.c_float, _vp, _vp]),
+    "rslo_spconv_fwd_bf16": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, C.c_float, _vp, _vp]),
     "rslo_spconv_wgrad_ws_bytes": (_sz, [_i64, _i, _i, _i]),
     "rslo_spconv_wgrad": (C.c_int, [_vp, _i, _vp, _i, _vp, _i64, _i, _vp, _sz, _vp, _vp, _vp]),
+    "rslo_rulebook_row_order": (C.c_int, [_vp, _i64, _i, _i, _vp, _vp]),
     "rslo_rulebook_pairs_ws_bytes": (_sz, [_i64, _i]),
     "rslo_rulebook_pairs": (C.c_int, [_vp, _i64, _i, _vp, _sz, _vp, _vp, _vp, _vp]),
     "rslo_spconv_wgrad_pairs_ws_bytes": (_sz, [_i64, _i, _i, _i]),
@@ -315,14 +316,28 @@ def weight_split(W, transpose=False):
     return Ws
 
 
-def spconv_fwd_split(x, Ws, bias, nbr, cin, cout, flip_k=False, act_slope=1.0):
+ROW_ORDER = os.environ.get("RSLO_ROW_ORDER", "1") != "0"        # mask-sorted tile order (rslo_rulebook_row_order)
+
+
+def rulebook_row_order(nbr, flip_k=False):
+    """Scheduling order of the table's rows (int32 [n]); None when switched off (RSLO_ROW_ORDER=0)."""
+    if not ROW_ORDER:
+        return None
+    n, K = nbr.shape
+    order = torch.empty((n,), dtype=torch.int32, device=nbr.device)
+    _chk(lib().rslo_rulebook_row_order(_ptr(nbr, torch.int32, "nbr"), n, K, int(flip_k), _ptr(order), _stream()),
+         "rslo_rulebook_row_order")
+    return order
+
+
+def spconv_fwd_split(x, Ws, bias, nbr, cin, cout, flip_k=False, act_slope=1.0, order=None):
     n_out, K = nbr.shape
     if x.shape[1] != cin:
         raise RsloHipError("spconv_fwd_split: shape mismatch")
     out = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
     _chk(lib().rslo_spconv_fwd_split(_ptr(x, torch.float32, "x"), cin, _ptr(Ws), _ptr(bias, torch.float32, "bias"),
-                                     _ptr(nbr, torch.int32, "nbr"), n_out, K, cout, int(flip_k), float(act_slope),
-                                     _ptr(out), _stream()), "rslo_spconv_fwd_split")
+                                     _ptr(nbr, torch.int32, "nbr"), _ptr(order, torch.int32, "order"), n_out, K, cout,
+                                     int(flip_k), float(act_slope), _ptr(out), _stream()), "rslo_spconv_fwd_split")
     return out
 
 
@@ -336,7 +351,7 @@ def weight_to_bf16(W, transpose=False):
     return Wb
 
 
-def spconv_fwd_bf16(x, W, bias, nbr, flip_k=False, act_slope=1.0, transpose=False):
+def spconv_fwd_bf16(x, W, bias, nbr, flip_k=False, act_slope=1.0, transpose=False, order=None):
     """bf16 feature path: x [Nin,Cin] bfloat16, W [K,Cin,Cout] fp32 master weights, bias fp32 -> [Nout,Cout] bfloat16.
     transpose=True applies W[k]^T (the data gradient; x is then dout [Nout,Cout], nbr the transposed table)."""
     n_out, K = nbr.shape
@@ -346,7 +361,8 @@ def spconv_fwd_bf16(x, W, bias, nbr, flip_k=False, act_slope=1.0, transpose=Fals
         raise RsloHipError("spconv_fwd_bf16: shape / dtype mismatch")
     out = torch.empty((n_out, cout_op), dtype=torch.bfloat16, device=x.device)
     _chk(lib().rslo_spconv_fwd_bf16(_ptr(x, torch.bfloat16, "x"), cin_op, _ptr(weight_to_bf16(W, transpose)),
-                                    _ptr(bias, torch.float32, "bias"), _ptr(nbr, torch.int32, "nbr"), n_out, K, cout_op,
+                                    _ptr(bias, torch.float32, "bias"), _ptr(nbr, torch.int32, "nbr"),
+                                    _ptr(order, torch.int32, "order"), n_out, K, cout_op,
                                     int(flip_k), float(act_slope), _ptr(out), _stream()), "rslo_spconv_fwd_bf16")
     return out
 
@@ -355,24 +371,25 @@ def _splittable(cin, cout):
     return SPLIT_BF16 and cin in (32, 64) and cout in (32, 64)
 
 
-def spconv_fwd(x, W, bias, nbr, flip_k=False, act_slope=1.0):
-    """x [Nin,Cin], W [K,Cin,Cout], nbr [Nout,K] -> [Nout,Cout]."""
+def spconv_fwd(x, W, bias, nbr, flip_k=False, act_slope=1.0, order=None):
+    """x [Nin,Cin], W [K,Cin,Cout], nbr [Nout,K] -> [Nout,Cout].  order: optional rulebook_row_order(nbr)."""
     n_out, K = nbr.shape
     Kw, cin, cout = W.shape
     if Kw != K or x.shape[1] != cin:
         raise RsloHipError("spconv_fwd: shape mismatch x%s W%s nbr%s" % (tuple(x.shape), tuple(W.shape), tuple(nbr.shape)))
     if _splittable(cin, cout):
-        return spconv_fwd_split(x, weight_split(W), bias, nbr, cin, cout, flip_k, act_slope)
-    return spconv_fwd_direct(x, W, bias, nbr, flip_k, act_slope)
+        return spconv_fwd_split(x, weight_split(W), bias, nbr, cin, cout, flip_k, act_slope, order)
+    return spconv_fwd_direct(x, W, bias, nbr, flip_k, act_slope, order)
 
 
-def spconv_fwd_direct(x, W, bias, nbr, flip_k=False, act_slope=1.0):
+def spconv_fwd_direct(x, W, bias, nbr, flip_k=False, act_slope=1.0, order=None):
     """rslo_spconv_fwd itself (fp32 MFMA kernels)."""
     n_out, K = nbr.shape
     Kw, cin, cout = W.shape
     out = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
     _chk(lib().rslo_spconv_fwd(_ptr(x, torch.float32, "x"), cin, _ptr(W, torch.float32, "W"),
-                               _ptr(bias, torch.float32, "bias"), _ptr(nbr, torch.int32, "nbr"), n_out, K, cout,
+                               _ptr(bias, torch.float32, "bias"), _ptr(nbr, torch.int32, "nbr"),
+                               _ptr(order, torch.int32, "order"), n_out, K, cout,
                                int(flip_k), float(act_slope), _ptr(out), _stream()), "rslo_spconv_fwd")
     return out
 
@@ -386,19 +403,19 @@ def weight_transpose(W):
     return Wt
 
 
-def spconv_dgrad(dout, W, nbrT, flip_k=False):
+def spconv_dgrad(dout, W, nbrT, flip_k=False, order=None):
     """dout [Nout,Cout], W [K,Cin,Cout], nbrT [Nin,K] -> din [Nin,Cin].
     For MFMA-shaped channel counts the gradient runs through the forward kernel on the transposed weights
     (coalesced weight reads); other shapes use the dedicated entry point."""
     Kw, cin, cout = W.shape
     if _splittable(cout, cin):
-        return spconv_fwd_split(dout, weight_split(W, transpose=True), None, nbrT, cout, cin, flip_k)
+        return spconv_fwd_split(dout, weight_split(W, transpose=True), None, nbrT, cout, cin, flip_k, order=order)
     if cin % 16 == 0 and cout % 16 == 0:
-        return spconv_fwd(dout, weight_transpose(W), None, nbrT, flip_k=flip_k)
-    return spconv_dgrad_direct(dout, W, nbrT, flip_k)
+        return spconv_fwd(dout, weight_transpose(W), None, nbrT, flip_k=flip_k, order=order)
+    return spconv_dgrad_direct(dout, W, nbrT, flip_k, order)
 
 
-def spconv_dgrad_direct(dout, W, nbrT, flip_k=False):
+def spconv_dgrad_direct(dout, W, nbrT, flip_k=False, order=None):
     """rslo_spconv_dgrad itself (weights read in place, transposed access)."""
     n_in, K = nbrT.shape
     Kw, cin, cout = W.shape
@@ -406,8 +423,8 @@ def spconv_dgrad_direct(dout, W, nbrT, flip_k=False):
         raise RsloHipError("spconv_dgrad: shape mismatch")
     din = torch.empty((n_in, cin), dtype=torch.float32, device=dout.device)
     _chk(lib().rslo_spconv_dgrad(_ptr(dout, torch.float32, "dout"), cout, _ptr(W, torch.float32, "W"),
-                                 _ptr(nbrT, torch.int32, "nbrT"), n_in, K, cin, int(flip_k), _ptr(din),
-                                 _stream()), "rslo_spconv_dgrad")
+                                 _ptr(nbrT, torch.int32, "nbrT"), _ptr(order, torch.int32, "order"), n_in, K, cin,
+                                 int(flip_k), _ptr(din), _stream()), "rslo_spconv_dgrad")
     return din
 
 

@@ -678,3 +678,63 @@ extern "C" int rslo_rulebook_pairs(const int32_t *nbr, int64_t n_rows, int K, vo
   RSLO_CHECK_LAUNCH("rulebook_pairs");
   return RSLO_OK;
 }
+
+// ---------------------------------------------------------------------------------------
+// Row order for the tile-granular sparse-conv kernels.  A wave issues MFMAs for every kernel offset that ANY of its
+// 16/32 rows has a neighbour at; in scan (level 0) or raster (strided levels) order a tile's union mask holds ~1.5x
+// the offsets a row really has.  Sorting the rows of each window of 2048 by their 27-bit neighbour mask puts rows
+// with equal / similar masks into the same tile: useful-MFMA fraction 0.48 -> 0.70 (level 0), 0.61 -> 0.81,
+// 0.71 -> 0.86 (level 2) on KITTI-shaped scans, while rows stay inside their window (gather locality in L2 is kept).
+// One workgroup per window: key = mask << 11 | local row, bitonic sort in LDS (unique keys -> deterministic).
+// flip = 1 reverses the bit order (the mask a SubM data-gradient call walks with flip_k).
+// ---------------------------------------------------------------------------------------
+#define RO_WINDOW 2048
+#define RO_THREADS 256
+
+__global__ __launch_bounds__(RO_THREADS) void k_row_order(const int32_t *__restrict__ nbr, int64_t n, int K, int flip,
+                                                          int32_t *__restrict__ order) {
+  __shared__ unsigned long long key[RO_WINDOW];
+  const int64_t base = (int64_t)blockIdx.x * RO_WINDOW;
+  for (int r = threadIdx.x; r < RO_WINDOW; r += RO_THREADS) {
+    const int64_t row = base + r;
+    unsigned long long kv = ~0ull;
+    if (row < n) {
+      unsigned m = 0;
+      for (int k = 0; k < K; ++k)
+        if (nbr[row * K + k] >= 0) m |= 1u << (flip ? (K - 1 - k) : k);
+      kv = ((unsigned long long)m << 11) | (unsigned)r;
+    }
+    key[r] = kv;
+  }
+  __syncthreads();
+  for (int size = 2; size <= RO_WINDOW; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = threadIdx.x; t < RO_WINDOW / 2; t += RO_THREADS) {
+        const int lo = 2 * t - (t & (stride - 1));       // index with bit `stride` cleared
+        const int hi = lo + stride;
+        const bool up = (lo & size) == 0;
+        const unsigned long long a = key[lo], b = key[hi];
+        if ((a > b) == up) {
+          key[lo] = b;
+          key[hi] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int r = threadIdx.x; r < RO_WINDOW; r += RO_THREADS) {
+    const int64_t row = base + r;
+    if (row < n) order[row] = (int32_t)(base + (int64_t)(key[r] & 2047ull));
+  }
+}
+
+extern "C" int rslo_rulebook_row_order(const int32_t *nbr, int64_t n_rows, int K, int flip_k, int32_t *order,
+                                       void *stream) {
+  RSLO_CHECK_ARG(K >= 1 && K <= 27, "rslo_rulebook_row_order: K must be in 1..27");
+  if (n_rows == 0) return RSLO_OK;
+  RSLO_CHECK_ARG(nbr && order, "rslo_rulebook_row_order: null pointer");
+  hipLaunchKernelGGL(k_row_order, dim3((unsigned)rslo_cdiv(n_rows, RO_WINDOW)), dim3(RO_THREADS), 0,
+                     (hipStream_t)stream, nbr, n_rows, K, flip_k, order);
+  RSLO_CHECK_LAUNCH("k_row_order");
+  return RSLO_OK;
+}

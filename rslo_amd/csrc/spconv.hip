@@ -307,6 +307,32 @@ __global__ __launch_bounds__(SPC_THREADS) void k_spconv_v2(const float *__restri
 // ---------------------------------------------------------------------------------------
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+// Tile setup shared by the wave-granular kernels (v3 / v6 / bf16): the ROWS output rows of a wave's tile -- taken through
+// the optional row order (rslo_rulebook_row_order: rows with similar neighbour masks adjacent, so that a tile's union
+// mask, i.e. the offsets it has to issue MFMAs for, shrinks from ~1.5x to ~1.15x of the real neighbour count) -- and
+// their neighbour rows go into the wave's LDS slab.  Results do not depend on the order: an offset a row lacks
+// contributes exact zeros.
+template <int ROWS>
+__device__ __forceinline__ void spc_load_tile(const int32_t *__restrict__ nbr, const int32_t *__restrict__ order,
+                                              int64_t row0, int64_t n_out, int K, int lane,
+                                              int32_t *__restrict__ nbl, int32_t *__restrict__ orow) {
+  if (order == nullptr) {
+    const int64_t lim = (n_out - row0) * K;
+    for (int e = lane; e < ROWS * K; e += 64) nbl[e] = (e < lim) ? nbr[row0 * K + e] : -1;
+    for (int r = lane; r < ROWS; r += 64) orow[r] = (row0 + r < n_out) ? (int32_t)(row0 + r) : -1;
+  } else {
+    for (int r = lane; r < ROWS; r += 64) orow[r] = (row0 + r < n_out) ? order[row0 + r] : -1;
+    const int half = lane >> 5, k = lane & 31;     // two table rows per load instruction
+#pragma unroll 4
+    for (int r = 0; r < ROWS; r += 2) {
+      const int64_t q = row0 + r + half;
+      const int32_t src = (q < n_out) ? order[q] : -1;
+      if (k < K) nbl[(r + half) * K + k] = (src >= 0) ? nbr[(int64_t)src * K + k] : -1;
+    }
+  }
+}
+
+
 template <int N>
 struct VecF {
   float v[N];
@@ -331,13 +357,15 @@ template <int CIN_T, int COUT_T, int RBW, bool TRANS>
 __global__ __launch_bounds__(SPC_THREADS) void k_spconv_v3(const float *__restrict__ in,
                                                            const float *__restrict__ W,
                                                            const float *__restrict__ bias,
-                                                           const int32_t *__restrict__ nbr, int64_t n_out,
+                                                           const int32_t *__restrict__ nbr,
+                                                           const int32_t *__restrict__ order, int64_t n_out,
                                                            int K, int flip_k, float slope,
                                                            float *__restrict__ out) {
   constexpr int NJ = CIN_T / 16;
   constexpr int NB = COUT_T / 16;
   constexpr int ROWS = 16 * RBW;
   __shared__ int32_t nbl[SPC_WAVES][ROWS * SPC_MAXK];
+  __shared__ int32_t orow[SPC_WAVES][ROWS];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int li = lane & 15, g = lane >> 4;
@@ -348,10 +376,7 @@ __global__ __launch_bounds__(SPC_THREADS) void k_spconv_v3(const float *__restri
   const bool active = vb < n_blocks && tile < n_tiles;
   const int64_t row0 = tile * ROWS;
 
-  if (active) {
-    const int64_t lim = (n_out - row0) * K;
-    for (int e = lane; e < ROWS * K; e += 64) nbl[wid][e] = (e < lim) ? nbr[row0 * K + e] : -1;
-  }
+  if (active) spc_load_tile<ROWS>(nbr, order, row0, n_out, K, lane, nbl[wid], orow[wid]);
   __syncthreads();
   if (!active) return;
 
@@ -430,8 +455,8 @@ __global__ __launch_bounds__(SPC_THREADS) void k_spconv_v3(const float *__restri
   for (int rb = 0; rb < RBW; ++rb)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int64_t row = row0 + rb * 16 + 4 * g + j;
-      if (row >= n_out) continue;
+      const int64_t row = orow[wid][rb * 16 + 4 * g + j];
+      if (row < 0) continue;
       float o[NB];
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
@@ -522,19 +547,41 @@ __device__ __forceinline__ Split8 split8(const float4 a, const float4 b, bool ok
   return o;
 }
 
+#ifndef SPC_WNT
+#define SPC_WNT 0       // 1: weight-fragment loads carry the non-temporal hint (experiment: keep them out of the vector L1)
+#endif
+#if SPC_WNT
+#define SPC_WLOAD(p) __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p))
+#else
+#define SPC_WLOAD(p) (*reinterpret_cast<const u32x4 *>(p))
+#endif
+#ifndef SPC_ABLATE
+#define SPC_ABLATE 0      // bit 1: no weight loads, 2: no row gathers, 4: no MFMAs, 8: no operand split (scripts/ablate_spconv.sh)
+#endif
+#if SPC_ABLATE & 4
+__device__ __forceinline__ f32x4 fake_mfma(u32x4 a, u32x4 b, f32x4 c) {
+  c[0] += __uint_as_float((a[0] ^ b[0]) & 0x3fffffffu); c[1] += __uint_as_float((a[1] ^ b[1]) & 0x3fffffffu);
+  c[2] += __uint_as_float((a[2] ^ b[2]) & 0x3fffffffu); c[3] += __uint_as_float((a[3] ^ b[3]) & 0x3fffffffu);
+  return c;
+}
+#define MFMA_BF16(A, B, C) fake_mfma(A, B, C)
+#else
 #define MFMA_BF16(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), C, 0, 0, 0)
+#endif
 
 template <int CIN_T, int COUT_T, int RBW>
 __global__ __launch_bounds__(SPC_THREADS) void k_spconv_v6(const float *__restrict__ in,
                                                            const unsigned short *__restrict__ Ws,
                                                            const float *__restrict__ bias,
-                                                           const int32_t *__restrict__ nbr, int64_t n_out,
+                                                           const int32_t *__restrict__ nbr,
+                                                           const int32_t *__restrict__ order, int64_t n_out,
                                                            int K, int flip_k, float slope,
                                                            float *__restrict__ out) {
   constexpr int NS = CIN_T / 32;       // K-steps of 32 input channels
   constexpr int NB = COUT_T / 16;      // 16-column blocks: column li of block nb = output channel NB li + nb
   constexpr int ROWS = 16 * RBW;
   __shared__ int32_t nbl[SPC_WAVES][ROWS * SPC_MAXK];
+  __shared__ int32_t orow[SPC_WAVES][ROWS];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int li = lane & 15, g = lane >> 4;
@@ -545,10 +592,7 @@ __global__ __launch_bounds__(SPC_THREADS) void k_spconv_v6(const float *__restri
   const bool active = vb < n_blocks && tile < n_tiles;
   const int64_t row0 = tile * ROWS;
 
-  if (active) {
-    const int64_t lim = (n_out - row0) * K;
-    for (int e = lane; e < ROWS * K; e += 64) nbl[wid][e] = (e < lim) ? nbr[row0 * K + e] : -1;
-  }
+  if (active) spc_load_tile<ROWS>(nbr, order, row0, n_out, K, lane, nbl[wid], orow[wid]);
   __syncthreads();
   if (!active) return;
 
@@ -585,17 +629,31 @@ __global__ __launch_bounds__(SPC_THREADS) void k_spconv_v6(const float *__restri
       Split8 a[RBW];
 #pragma unroll
       for (int rb = 0; rb < RBW; ++rb) {
+#if SPC_ABLATE & 2      // no row gathers
+        const float t = __int_as_float(0x3f800000 + lane + k + sk);
+        const float4 x0 = make_float4(t, t, t, t), x1 = x0;
+#else
         const float4 x0 = *reinterpret_cast<const float4 *>(ap[rb] + 32 * sk);
         const float4 x1 = *reinterpret_cast<const float4 *>(ap[rb] + 32 * sk + 4);
+#endif
+#if SPC_ABLATE & 8      // no operand split
+        a[rb].h = __builtin_bit_cast(u32x4, x0); a[rb].m = __builtin_bit_cast(u32x4, x1); a[rb].l = a[rb].h ^ a[rb].m;
+#else
         a[rb] = split8(x0, x1, ok[rb]);
+#endif
       }
       // Ws[plane][kk][sk][g][co][8]: 16 bytes per lane, consecutive li -> consecutive 16 bytes
       const unsigned short *wb = Ws + ((((int64_t)kk * NS + sk) * 4 + g) * COUT_T + li) * 8;
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
-        const u32x4 bh = *reinterpret_cast<const u32x4 *>(wb + nb * 16 * 8);
-        const u32x4 bm = *reinterpret_cast<const u32x4 *>(wb + plane + nb * 16 * 8);
-        const u32x4 bl = *reinterpret_cast<const u32x4 *>(wb + 2 * plane + nb * 16 * 8);
+#if SPC_ABLATE & 1      // no weight loads
+        const unsigned t0 = 0x3f803f80u + lane * 65537u + kk * 3 + sk + nb;
+        const u32x4 bh = {t0, t0 + 1, t0 + 2, t0 + 3}, bm = {t0 + 4, t0 + 5, t0 + 6, t0 + 7}, bl = {t0 + 8, t0 + 9, t0, t0};
+#else
+        const u32x4 bh = SPC_WLOAD(wb + nb * 16 * 8);
+        const u32x4 bm = SPC_WLOAD(wb + plane + nb * 16 * 8);
+        const u32x4 bl = SPC_WLOAD(wb + 2 * plane + nb * 16 * 8);
+#endif
         // smallest terms first; consecutive MFMAs alternate between the row blocks' accumulators
 #pragma unroll
         for (int rb = 0; rb < RBW; ++rb) acc[rb][nb] = MFMA_BF16(a[rb].l, bh, acc[rb][nb]);
@@ -621,8 +679,8 @@ __global__ __launch_bounds__(SPC_THREADS) void k_spconv_v6(const float *__restri
   for (int rb = 0; rb < RBW; ++rb)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int64_t row = row0 + rb * 16 + 4 * g + j;
-      if (row >= n_out) continue;
+      const int64_t row = orow[wid][rb * 16 + 4 * g + j];
+      if (row < 0) continue;
       float o[NB];
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
@@ -637,6 +695,22 @@ __global__ __launch_bounds__(SPC_THREADS) void k_spconv_v6(const float *__restri
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// What bounds v6, measured (round 2; scripts/ablate_spconv.sh compiles parts of the kernel out; 64 -> 64, 8 frames,
+// 166 us in that harness): no weight loads 120 us, no row gathers 97 us, neither 92 us (matrix cores + operand split),
+// no operand split 158 us.  Two restructurings were built, verified bit-identical and measured, then removed:
+//   * v7: every operand fetched one offset ahead (whole weight set of the current offset in registers, each
+//     fragment refilled for the next offset right after its MFMAs; next offset's rows gathered before the current
+//     offset's first MFMA; 2 waves per SIMD): 157.5 vs 159.6 us -- latency is not the limiter;
+//   * v8: the weight operands through a two-slot LDS ring, staged once per workgroup and offset (one barrier per
+//     offset, gathers prefetched): 232 us (64 -> 64), 84 vs 71 us (32 -> 32) -- the barrier couples four waves whose
+//     tiles need different offsets, and the ring leaves 2 workgroups per CU;
+//   * a non-temporal hint on the weight loads: 194 us (they do hit in the vector L1 today).
+// Tile orders (scripts/bench_spconv.py ORDER=...): rows sorted by neighbour mask inside windows of 2048 cut the issued
+// MFMAs by 17 % on 64 -> 64 but scatter the gathers (163 vs 160 us); Morton order 193 us; random 199 us: contiguous
+// neighbour rows (raster order) matter more than fewer offsets.  The mask order IS a gain on the sparse transposed
+// tables (inverse convolutions, strided data gradients: 8 of 27 offsets per row): 103 -> 72 us, 102 -> 75, 67 -> 51.
+// ---------------------------------------------------------------------------------------
 // W [K, Cin, Cout] -> Wt [K, Cout, Cin]: lets the data gradient run through the FORWARD kernel (dgrad = conv of
 // dout with the per-offset transposed weights), whose weight reads are contiguous along the lane index.  The
 // TRANS instantiations read W with a Cin*4-byte lane stride (64 cache lines per wave load) and measured
@@ -704,12 +778,14 @@ template <int CIN_T, int COUT_T, int RBW>
 __global__ __launch_bounds__(SPC_THREADS) void k_spconv_bf16(const unsigned short *__restrict__ in,
                                                              const unsigned short *__restrict__ Wb,
                                                              const float *__restrict__ bias,
-                                                             const int32_t *__restrict__ nbr, int64_t n_out, int K,
+                                                             const int32_t *__restrict__ nbr,
+                                                             const int32_t *__restrict__ order, int64_t n_out, int K,
                                                              int flip_k, float slope, unsigned short *__restrict__ out) {
   constexpr int NS = CIN_T / 32;
   constexpr int NB = COUT_T / 16;
   constexpr int ROWS = 16 * RBW;
   __shared__ int32_t nbl[SPC_WAVES][ROWS * SPC_MAXK];
+  __shared__ int32_t orow[SPC_WAVES][ROWS];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int li = lane & 15, g = lane >> 4;
@@ -720,10 +796,7 @@ __global__ __launch_bounds__(SPC_THREADS) void k_spconv_bf16(const unsigned shor
   const bool active = vb < n_blocks && tile < n_tiles;
   const int64_t row0 = tile * ROWS;
 
-  if (active) {
-    const int64_t lim = (n_out - row0) * K;
-    for (int e = lane; e < ROWS * K; e += 64) nbl[wid][e] = (e < lim) ? nbr[row0 * K + e] : -1;
-  }
+  if (active) spc_load_tile<ROWS>(nbr, order, row0, n_out, K, lane, nbl[wid], orow[wid]);
   __syncthreads();
   if (!active) return;
 
@@ -779,8 +852,8 @@ __global__ __launch_bounds__(SPC_THREADS) void k_spconv_bf16(const unsigned shor
   for (int rb = 0; rb < RBW; ++rb)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int64_t row = row0 + rb * 16 + 4 * g + j;
-      if (row >= n_out) continue;
+      const int64_t row = orow[wid][rb * 16 + 4 * g + j];
+      if (row < 0) continue;
       unsigned short o[NB];
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
@@ -807,8 +880,8 @@ extern "C" int rslo_weight_to_bf16(const float *W, int K, int cin_op, int cout_o
 }
 
 extern "C" int rslo_spconv_fwd_bf16(const void *in, int cin, const void *Wb, const float *bias, const int32_t *nbr,
-                                    int64_t n_out, int K, int cout, int flip_k, float act_slope, void *out,
-                                    void *stream) {
+                                    const int32_t *row_order, int64_t n_out, int K, int cout, int flip_k,
+                                    float act_slope, void *out, void *stream) {
   hipStream_t st = (hipStream_t)stream;
   RSLO_CHECK_ARG((cin == 32 || cin == 64) && (cout == 32 || cout == 64), "spconv_fwd_bf16: channels must be 32 or 64");
   RSLO_CHECK_ARG(K >= 1 && K <= SPC_MAXK, "spconv_fwd_bf16: K must be in 1..27");
@@ -820,10 +893,10 @@ extern "C" int rslo_spconv_fwd_bf16(const void *in, int cin, const void *Wb, con
   if (cin == CI && cout == CO) {                                                                            \
     if (rbw == 2)                                                                                           \
       hipLaunchKernelGGL((k_spconv_bf16<CI, CO, 2>), dim3(xcd_grid(rslo_cdiv(rslo_cdiv(n_out, 32), 4))),    \
-                         dim3(SPC_THREADS), 0, st, x, w, bias, nbr, n_out, K, flip_k, act_slope, o);        \
+                         dim3(SPC_THREADS), 0, st, x, w, bias, nbr, row_order, n_out, K, flip_k, act_slope, o);        \
     else                                                                                                    \
       hipLaunchKernelGGL((k_spconv_bf16<CI, CO, 1>), dim3(xcd_grid(rslo_cdiv(rslo_cdiv(n_out, 16), 4))),    \
-                         dim3(SPC_THREADS), 0, st, x, w, bias, nbr, n_out, K, flip_k, act_slope, o);        \
+                         dim3(SPC_THREADS), 0, st, x, w, bias, nbr, row_order, n_out, K, flip_k, act_slope, o);        \
   }
   SPCB_CASE(32, 32) SPCB_CASE(32, 64) SPCB_CASE(64, 32) SPCB_CASE(64, 64)
 #undef SPCB_CASE
@@ -854,8 +927,8 @@ extern "C" int rslo_weight_split_many(const RsloWeightSplitDesc *desc_dev, int n
 }
 
 extern "C" int rslo_spconv_fwd_split(const float *in, int cin, const void *Ws, const float *bias, const int32_t *nbr,
-                                     int64_t n_out, int K, int cout, int flip_k, float act_slope, float *out,
-                                     void *stream) {
+                                     const int32_t *row_order, int64_t n_out, int K, int cout, int flip_k,
+                                     float act_slope, float *out, void *stream) {
   hipStream_t st = (hipStream_t)stream;
   RSLO_CHECK_ARG((cin == 32 || cin == 64) && (cout == 32 || cout == 64), "spconv_fwd_split: channels must be 32 or 64");
   RSLO_CHECK_ARG(K >= 1 && K <= SPC_MAXK, "spconv_fwd_split: K must be in 1..27");
@@ -867,10 +940,10 @@ extern "C" int rslo_spconv_fwd_split(const float *in, int cin, const void *Ws, c
   if (cin == CI && cout == CO) {                                                                             \
     if (rbw == 2)                                                                                            \
       hipLaunchKernelGGL((k_spconv_v6<CI, CO, 2>), dim3(xcd_grid(rslo_cdiv(rslo_cdiv(n_out, 32), 4))),       \
-                         dim3(SPC_THREADS), 0, st, in, ws, bias, nbr, n_out, K, flip_k, act_slope, out);     \
+                         dim3(SPC_THREADS), 0, st, in, ws, bias, nbr, row_order, n_out, K, flip_k, act_slope, out);     \
     else                                                                                                     \
       hipLaunchKernelGGL((k_spconv_v6<CI, CO, 1>), dim3(xcd_grid(rslo_cdiv(rslo_cdiv(n_out, 16), 4))),       \
-                         dim3(SPC_THREADS), 0, st, in, ws, bias, nbr, n_out, K, flip_k, act_slope, out);     \
+                         dim3(SPC_THREADS), 0, st, in, ws, bias, nbr, row_order, n_out, K, flip_k, act_slope, out);     \
   }
   SPC6_CASE(32, 32) SPC6_CASE(32, 64) SPC6_CASE(64, 32) SPC6_CASE(64, 64)
 #undef SPC6_CASE
@@ -883,7 +956,7 @@ static int pad_cout(int c) { return c <= 16 ? 16 : (c <= 32 ? 32 : 64); }
 
 template <bool TRANS>
 static int launch_spconv(const float *in, int cin, const float *W, const float *bias, const int32_t *nbr,
-                         int64_t n_out, int K, int cout, int flip_k, float slope, float *out,
+                         const int32_t *order, int64_t n_out, int K, int cout, int flip_k, float slope, float *out,
                          hipStream_t st) {
   RSLO_CHECK_ARG(cin >= 1 && cin <= 64 && cout >= 1 && cout <= 64, "spconv: channels must be in 1..64");
   RSLO_CHECK_ARG(K >= 1 && K <= SPC_MAXK, "spconv: K must be in 1..27");
@@ -899,10 +972,10 @@ static int launch_spconv(const float *in, int cin, const float *W, const float *
     if (ci == CI && co == CO) {                                                                            \
       if (rbw == 2)                                                                                        \
         hipLaunchKernelGGL((k_spconv_v3<CI, CO, 2, TRANS>), dim3(xcd_grid(rslo_cdiv(rslo_cdiv(n_out, 32), 4))), \
-                           dim3(SPC_THREADS), 0, st, in, W, bias, nbr, n_out, K, flip_k, slope, out);      \
+                           dim3(SPC_THREADS), 0, st, in, W, bias, nbr, order, n_out, K, flip_k, slope, out); \
       else                                                                                                 \
         hipLaunchKernelGGL((k_spconv_v3<CI, CO, 1, TRANS>), dim3(xcd_grid(rslo_cdiv(rslo_cdiv(n_out, 16), 4))), \
-                           dim3(SPC_THREADS), 0, st, in, W, bias, nbr, n_out, K, flip_k, slope, out);      \
+                           dim3(SPC_THREADS), 0, st, in, W, bias, nbr, order, n_out, K, flip_k, slope, out); \
     }
     SPC3_CASE(16, 16) SPC3_CASE(16, 32) SPC3_CASE(16, 64)
     SPC3_CASE(32, 16) SPC3_CASE(32, 32) SPC3_CASE(32, 64)
@@ -967,18 +1040,19 @@ static int launch_spconv(const float *in, int cin, const float *W, const float *
 }
 
 extern "C" int rslo_spconv_fwd(const float *in, int cin, const float *W, const float *bias,
-                               const int32_t *nbr, int64_t n_out, int K, int cout, int flip_k,
-                               float act_slope, float *out, void *stream) {
-  return launch_spconv<false>(in, cin, W, bias, nbr, n_out, K, cout, flip_k, act_slope, out,
+                               const int32_t *nbr, const int32_t *row_order, int64_t n_out, int K, int cout,
+                               int flip_k, float act_slope, float *out, void *stream) {
+  return launch_spconv<false>(in, cin, W, bias, nbr, row_order, n_out, K, cout, flip_k, act_slope, out,
                               (hipStream_t)stream);
 }
 
 // din[i][a] = sum_k sum_b dout[nbrT[i][k]][b] W[kk][a][b]: the same kernel with the roles of the
 // channel counts swapped and W_k read transposed.
 extern "C" int rslo_spconv_dgrad(const float *dout, int cout, const float *W, const int32_t *nbrT,
-                                 int64_t n_in, int K, int cin, int flip_k, float *din, void *stream) {
+                                 const int32_t *row_order, int64_t n_in, int K, int cin, int flip_k, float *din,
+                                 void *stream) {
   RSLO_CHECK_ARG(cout <= 8 || cout % 4 == 0, "spconv_dgrad: cout > 8 must be a multiple of 4");
-  return launch_spconv<true>(dout, cout, W, nullptr, nbrT, n_in, K, cin, flip_k, 1.0f, din,
+  return launch_spconv<true>(dout, cout, W, nullptr, nbrT, row_order, n_in, K, cin, flip_k, 1.0f, din,
                              (hipStream_t)stream);
 }
 

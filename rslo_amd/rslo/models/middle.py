@@ -98,8 +98,9 @@ class SpMiddleFHDWithCov2_3(nn.Module):
         p0 = self.middle_conv.plan(x)
         self.middle_conv_tail.plan(p0)
         self.middle_cov_deconv.plan(p0)
-        if with_pairs:      # the pair-list form used by the weight gradients (otherwise built lazily in backward)
-            for rb in x.indice_dict.values():
+        for rb in x.indice_dict.values():
+            rb.order("nbrT")    # tile scheduling order of the transposed tables (inverse conv / strided data gradient)
+            if with_pairs:      # the pair-list form used by the weight gradients (otherwise built lazily in backward)
                 rb.pairs()
         return x
 

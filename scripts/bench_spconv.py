@@ -35,21 +35,46 @@ def ref_conv(x, W, nbr):
         y[m] += x[nbr[m, k].long()] @ W[k]
     return y
 
-def run(name, x, W, nbr, fn, check=True):
+ORDER = os.environ.get("ORDER", "none")     # tile order experiment: none | mask | morton | mortonN (block of 2^N cells) | random
+
+
+def morton_key(c, shift=0):
+    """(b, z, y, x) int32 -> int64 key: batch on top, then the bits of (z, y, x) >> shift interleaved, ties by row."""
+    z, y, x = (c[:, 1].long() >> shift), (c[:, 2].long() >> shift), (c[:, 3].long() >> shift)
+    key = torch.zeros_like(x)
+    for b in range(11):
+        key |= ((x >> b) & 1) << (3 * b) | ((y >> b) & 1) << (3 * b + 1) | ((z >> b) & 1) << (3 * b + 2)
+    return (c[:, 0].long() << 40) | key
+
+
+def make_order(nbr, coords):
+    if ORDER == "none" or coords is None or coords.shape[0] != nbr.shape[0]:
+        return None
+    if ORDER == "mask":
+        return capi.rulebook_row_order(nbr)
+    if ORDER == "random":
+        return torch.randperm(nbr.shape[0], device="cuda").int()
+    shift = int(ORDER[6:] or 0)
+    key = morton_key(coords, shift)
+    return torch.sort(key, stable=True)[1].int()
+
+
+def run(name, x, W, nbr, fn, check=True, coords=None):
     if ONLY and ONLY not in name: return
+    order = make_order(nbr, coords)
     P = int((nbr >= 0).sum()); n_out, K = nbr.shape; cin, cout = W.shape[1], W.shape[2]
     if fn == "dgrad":
-        call = lambda: capi.spconv_dgrad(x, W, nbr, flip_k=True)
+        call = lambda: capi.spconv_dgrad(x, W, nbr, flip_k=True, order=order)
         cin_op, cout_op = cout, cin
     elif fn == "bf16":       # C4 feature path: bf16 rows in / out, fp32 accumulate
         xb = x.to(torch.bfloat16)
-        call = lambda: capi.spconv_fwd_bf16(xb, W, None, nbr)
+        call = lambda: capi.spconv_fwd_bf16(xb, W, None, nbr, order=order)
         cin_op, cout_op = cin, cout
     elif fn == "dgradT":     # dgrad as a forward conv with per-offset transposed weights (coalesced B reads)
-        call = lambda: capi.spconv_fwd(x, W.transpose(1, 2).contiguous(), None, nbr, flip_k=True)
+        call = lambda: capi.spconv_fwd(x, W.transpose(1, 2).contiguous(), None, nbr, flip_k=True, order=order)
         cin_op, cout_op = cout, cin
     else:
-        call = lambda: capi.spconv_fwd(x, W, None, nbr)
+        call = lambda: capi.spconv_fwd(x, W, None, nbr, order=order)
         cin_op, cout_op = cin, cout
     y = call(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -70,16 +95,16 @@ rn = lambda *s: torch.randn(*s, device="cuda", generator=g)
 chans = [(16, 16), (32, 32), (64, 64), (64, 64)]
 for li, ((ix, nbr), (ci, co)) in enumerate(zip(levels, chans)):
     n = nbr.shape[0]
-    run("subm%d %d->%d fwd" % (li, ci, co), rn(n, ci), rn(27, ci, co) * 0.1, nbr, "fwd")
-    run("subm%d %d->%d dgrad" % (li, ci, co), rn(n, co), rn(27, ci, co) * 0.1, nbr, "dgrad", check=False)
-    run("subm%d %d->%d dgradT" % (li, ci, co), rn(n, co), rn(27, ci, co) * 0.1, nbr, "dgradT", check=False)
+    run("subm%d %d->%d fwd" % (li, ci, co), rn(n, ci), rn(27, ci, co) * 0.1, nbr, "fwd", coords=ix.coords)
+    run("subm%d %d->%d dgrad" % (li, ci, co), rn(n, co), rn(27, ci, co) * 0.1, nbr, "dgrad", check=False, coords=ix.coords)
+    run("subm%d %d->%d dgradT" % (li, ci, co), rn(n, co), rn(27, ci, co) * 0.1, nbr, "dgradT", check=False, coords=ix.coords)
     if ci >= 32:
-        run("subm%d %d->%d bf16" % (li, ci, co), rn(n, ci), rn(27, ci, co) * 0.1, nbr, "bf16", check=False)
+        run("subm%d %d->%d bf16" % (li, ci, co), rn(n, ci), rn(27, ci, co) * 0.1, nbr, "bf16", check=False, coords=ix.coords)
 run("subm0 7->16 fwd", rn(levels[0][1].shape[0], 7), rn(27, 7, 16) * 0.1, levels[0][1], "fwd")
 run("subm0 16->7 fwd", rn(levels[0][1].shape[0], 16), rn(27, 16, 7) * 0.1, levels[0][1], "fwd")
 for ci, ((nbr, nbrT), (a, b)) in enumerate(zip(convs, [(16, 32), (32, 64), (64, 64)])):
-    run("conv%d %d->%d fwd" % (ci, a, b), rn(nbrT.shape[0], a), rn(27, a, b) * 0.1, nbr, "fwd")
-    run("inv%d %d->%d fwd" % (ci, b, a), rn(nbr.shape[0], b), rn(27, b, a) * 0.1, nbrT, "fwd")
+    run("conv%d %d->%d fwd" % (ci, a, b), rn(nbrT.shape[0], a), rn(27, a, b) * 0.1, nbr, "fwd", coords=levels[ci + 1][0].coords)
+    run("inv%d %d->%d fwd" % (ci, b, a), rn(nbr.shape[0], b), rn(27, b, a) * 0.1, nbrT, "fwd", coords=levels[ci][0].coords)
 # wgrad
 for li, ((ix, nbr), (ci, co)) in enumerate(zip(levels, chans)):
     if ONLY and "wgrad" not in ONLY: continue

@@ -103,6 +103,61 @@ def test_rulebooks_bitexact_kitti_scan_batch2(hip):
     assert od == [2, 96, 176]
 
 
+def _row_order_ref(nbr, flip):
+    """numpy restatement of rslo_rulebook_row_order: windows of 2048 rows, ascending (mask, row)."""
+    n, K = nbr.shape
+    bits = (K - 1 - np.arange(K)) if flip else np.arange(K)
+    mask = ((nbr >= 0).astype(np.int64) << bits).sum(1)
+    out = np.empty(n, np.int32)
+    for s in range(0, n, 2048):
+        m = mask[s:s + 2048]
+        out[s:s + 2048] = s + np.lexsort((np.arange(len(m)), m))
+    return out
+
+
+@pytest.mark.parametrize("flip", [False, True])
+def test_row_order_is_the_windowed_mask_sort(hip, flip):
+    rng = np.random.default_rng(5)
+    dims = [9, 60, 70]
+    coords = rand_sites(rng, 2, dims, 7000)          # 3.4 windows, ragged tail
+    idx = hip.SiteIndex(dev(coords), 2, dims)
+    nbr = hip.rulebook_subm(idx, [3, 3, 3])
+    order = hip.rulebook_row_order(nbr, flip_k=flip).cpu().numpy()
+    assert (np.sort(order) == np.arange(len(coords))).all()
+    assert (order == _row_order_ref(nbr.cpu().numpy(), flip)).all()
+    # K = 3 tables (the (3,1,1) convolution) and an empty table
+    _, nb3, _ = hip.rulebook_conv(idx, [3, 1, 1], [2, 1, 1], [0, 0, 0])
+    assert (hip.rulebook_row_order(nb3, flip_k=flip).cpu().numpy() == _row_order_ref(nb3.cpu().numpy(), flip)).all()
+    assert hip.rulebook_row_order(nbr[:0], flip_k=flip).shape == (0,)
+
+
+@pytest.mark.parametrize("cin,cout", [(16, 16), (32, 32), (64, 64), (32, 64), (16, 32)])
+def test_conv_results_do_not_depend_on_row_order(hip, cin, cout):
+    """The order only regroups rows into tiles: forward, data gradient (flip_k) and the bf16 path give the same BITS
+    with the mask-sorted order, with a random permutation and without one (ragged sizes: 16/32-row tile tails)."""
+    rng = np.random.default_rng(cin + cout)
+    dims = [9, 60, 70]
+    for n in (5000, 8200 + 17):
+        coords = rand_sites(rng, 2, dims, n)
+        idx = hip.SiteIndex(dev(coords), 2, dims)
+        nbr = hip.rulebook_subm(idx, [3, 3, 3])
+        x = torch.randn(len(coords), cin, device="cuda")
+        W = torch.randn(27, cin, cout, device="cuda") * 0.1
+        b = torch.randn(cout, device="cuda")
+        g = torch.randn(len(coords), cout, device="cuda")
+        orders = [hip.rulebook_row_order(nbr), hip.rulebook_row_order(nbr, flip_k=True),
+                  torch.randperm(len(coords), device="cuda").int()]
+        y0 = hip.spconv_fwd(x, W, b, nbr, act_slope=0.01)
+        d0 = hip.spconv_dgrad(g, W, nbr, flip_k=True)
+        for o in orders:
+            assert torch.equal(hip.spconv_fwd(x, W, b, nbr, act_slope=0.01, order=o), y0)
+            assert torch.equal(hip.spconv_dgrad(g, W, nbr, flip_k=True, order=o), d0)
+        if cin >= 32 and cout >= 32:
+            xb = x.to(torch.bfloat16)
+            yb = hip.spconv_fwd_bf16(xb, W, b, nbr, act_slope=0.01)
+            assert torch.equal(hip.spconv_fwd_bf16(xb, W, b, nbr, act_slope=0.01, order=orders[0]), yb)
+
+
 def test_rulebook_empty_input(hip):
     idx = hip.SiteIndex(torch.zeros((0, 4), dtype=torch.int32, device="cuda"), 1, [5, 8, 8])
     assert hip.rulebook_subm(idx, [3, 3, 3]).shape == (0, 27)
