@@ -460,3 +460,8 @@ class Aleat5_1ChamferL2NormalWeightedALLSVDLoss(Loss):
                     _, sel, assoc, w = self._associate(src, moved, normal_pred.detach())
 
         return loss_b, res_r, res_t
+
+
+from rslo import reference_fallback as _reference_fallback  # noqa: E402
+
+__getattr__ = _reference_fallback(__name__)   # names outside the hot path: the checkout's own file, if one is on the path

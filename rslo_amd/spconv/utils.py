@@ -8,6 +8,12 @@ height_threshold = -1 the filter keeps everything, which is the only mode implem
   * a CUDA tensor [P,F]  -> returns CUDA tensors (the fast path: voxelization stays on the GPU), or
   * a numpy array [P,F]  -> round-trips through the GPU and returns numpy arrays like the reference.
 There is no CPU implementation here.
+
+Worker processes.  The reference voxelizes on the CPU inside forked DataLoader workers (rslo/data/preprocess.py:493).
+A forked child of a process that has already initialised HIP cannot use the device, so the numpy path REFUSES there
+with an explanatory error instead of hanging in the runtime.  Supported arrangements: (a) hand the raw points to the
+training process and voxelize there on a side stream (rslo_amd.workload.ExamplePrefetcher -- what bench.py does);
+(b) DataLoader(..., multiprocessing_context="spawn"), each worker then owns a HIP context of its own.
 """
 import numpy as np
 import torch
@@ -37,6 +43,12 @@ class VoxelGenerator:
         maxv = int(max_voxels or self._max_voxels)
         as_numpy = isinstance(points, np.ndarray)
         if as_numpy:
+            if torch.cuda._is_in_bad_fork():
+                raise RuntimeError(
+                    "VoxelGenerator.generate(numpy) was called in a forked child of a process that had already "
+                    "initialised the GPU; HIP cannot be used there.  Start DataLoader workers with "
+                    "multiprocessing_context='spawn', or pass the points to the training process and voxelize there "
+                    "(rslo_amd.workload.ExamplePrefetcher).")
             pts = torch.from_numpy(np.ascontiguousarray(points, dtype=np.float32)).cuda()
         else:
             pts = points.contiguous().float()

@@ -68,3 +68,14 @@ def test_flip_y_augmentation_matches_matrix_conjugation():
             return 0.9
     d = {"odometry": [np.array([1.0, 2.0, 3.0, 1.0, 0.0, 0.0, 0.0])], "icp_odometry": None}
     assert random_flip_y(d, [ref.copy()], rng=Always()) and d["odometry"][0][1] == -2.0
+
+
+def test_numpy_voxel_generator_refuses_in_a_forked_gpu_child(monkeypatch):
+    """spconv.utils.VoxelGenerator.generate(numpy) inside a forked child of a GPU process: clear error, no hang."""
+    import pytest
+    import torch
+    from spconv.utils import VoxelGenerator
+    vg = VoxelGenerator([0.1, 0.1, 0.2], [-70.4, -38.4, -3, 70.4, 38.4, 5], 10, 20000)
+    monkeypatch.setattr(torch.cuda, "_is_in_bad_fork", lambda: True)
+    with pytest.raises(RuntimeError, match="spawn"):
+        vg.generate(np.zeros((10, 7), np.float32))
