@@ -340,6 +340,8 @@ RSLO_API int rslo_bn2d_bwd_reduce(const float *dy, const float *y, const float *
                                   void *stream);
 RSLO_API int rslo_bn2d_bwd_apply(const float *dy, const float *y, const float *x, const float *gamma,
                                  const float *save_mean, const float *save_invstd, const double *red, double count,
+                                 const double *count_dev /* or NULL: element count over all ranks on the device, e.g.
+                                 &stats[2C] after the forward all-reduce (uneven per-rank batches); overrides count */,
                                  int N, int C, int HW, float act_slope, int has_act, float *dx, float *dres,
                                  void *stream);
 

@@ -9,19 +9,46 @@ Layout
                            `from rslo.models import ...`, `from thirdparty.chamfer_distance...`)
   compat/                  apex / kornia stand-ins, used only when the real packages are absent
 
-Importing this package puts those top-level names on sys.path (the reference asks its users to
-put $ROOT and $ROOT/rslo on PYTHONPATH in the same way, README.md:72-73).
+Importing this package makes exactly those four top-level names resolve to the mirror (the reference asks its
+users to put $ROOT and $ROOT/rslo on PYTHONPATH for the same purpose, README.md:72-73).  The package directory itself
+is NOT put on sys.path: `capi`, `build`, `workload`, ... stay importable only as `rslo_amd.<name>`, so they cannot
+shadow unrelated installed packages or be loaded twice under two names.
 """
+import importlib.abc
+import importlib.machinery
 import importlib.util
 import os
 import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-if _HERE not in sys.path:
-    sys.path.insert(0, _HERE)
+_MIRRORED = ("spconv", "rslo", "torchplus", "thirdparty")
 _COMPAT = os.path.join(_HERE, "compat")
-for _name in ("apex", "kornia"):
-    if _name not in sys.modules and importlib.util.find_spec(_name) is None and _COMPAT not in sys.path:
-        sys.path.append(_COMPAT)
+
+
+class _MirrorFinder(importlib.abc.MetaPathFinder):
+    """Top-level `spconv` / `rslo` / `torchplus` / `thirdparty` -> the directories next to this file (ahead of anything
+    installed); `apex` / `kornia` -> compat/ only when the real package is absent.  Submodules follow the packages'
+    own __path__ (which rslo/__init__.py may extend with a reference checkout)."""
+
+    def find_spec(self, name, path=None, target=None):
+        if path is not None:
+            return None
+        if name in _MIRRORED:
+            return importlib.machinery.PathFinder.find_spec(name, [_HERE])
+        if name in ("apex", "kornia"):
+            rest = [f for f in sys.meta_path if f is not self]
+            for f in rest:
+                try:
+                    spec = f.find_spec(name, None, None)
+                except Exception:
+                    spec = None
+                if spec is not None:
+                    return spec
+            return importlib.machinery.PathFinder.find_spec(name, [_COMPAT])
+        return None
+
+
+if not any(isinstance(f, _MirrorFinder) for f in sys.meta_path):
+    sys.meta_path.insert(0, _MirrorFinder())
 
 __version__ = "0.1.0"

@@ -80,8 +80,8 @@ SIGNATURES = {
                                   _vp, _vp, _vp]),
     "rslo_bn2d_bwd_reduce": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, C.c_float, _i, _vp, _sz, _vp, _vp, _vp, _vp,
                                        _vp]),
-    "rslo_bn2d_bwd_apply": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, _i, _i, _i, C.c_float, _i, _vp, _vp,
-                                      _vp]),
+    "rslo_bn2d_bwd_apply": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, _vp, _i, _i, _i, C.c_float, _i, _vp,
+                                      _vp, _vp]),
     "rslo_bn2d_fwd_local": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, C.c_float, C.c_float, C.c_float, _vp, _vp, _vp, _vp,
                                       _vp, _vp, _sz, _vp]),
     "rslo_bn2d_bwd_local": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, C.c_float, _i, _vp, _vp, _vp, _vp, _vp,
@@ -802,13 +802,14 @@ def bn2d_bwd_reduce(dy, y, x, mean, invstd, slope, has_act, want_affine=True):
     return red, dgamma, dbeta
 
 
-def bn2d_bwd_apply(dy, y, x, gamma, mean, invstd, red, count, slope, has_act, want_res):
+def bn2d_bwd_apply(dy, y, x, gamma, mean, invstd, red, count, slope, has_act, want_res, count_dev=None):
     N, Cc, H, W = x.shape
     dx = torch.empty_like(x)
     dres = torch.empty_like(x) if want_res else None
     _chk(lib().rslo_bn2d_bwd_apply(_ptr(dy, torch.float32, "dy"), _ptr(y, torch.float32, "y"), _ptr(x, torch.float32, "x"),
                                    _ptr(gamma, torch.float32, "gamma"), _ptr(mean), _ptr(invstd), _ptr(red, torch.float64),
-                                   float(count), N, Cc, H * W, float(slope), int(has_act), _ptr(dx), _ptr(dres),
+                                   float(count), _ptr(count_dev, torch.float64, "count_dev"), N, Cc, H * W, float(slope),
+                                   int(has_act), _ptr(dx), _ptr(dres),
                                    _stream()), "rslo_bn2d_bwd_apply")
     return dx, dres
 

@@ -72,23 +72,25 @@ class _FusedBNActFn(torch.autograd.Function):
         res = None if residual is None else residual.contiguous()
         world = _world(group)
         track = bn.track_running_stats and bn.running_mean is not None
-        mom = bn.momentum if bn.momentum is not None else 0.0
+        mom = bn.momentum          # fusable() leaves momentum=None (cumulative average) to the unfused path
+        cnt_all = None
         if world > 1:
             stats = capi.bn2d_stats(x)
             dist.all_reduce(stats, group=group)
             y, mean, invstd = capi.bn2d_apply(x, res, stats, weight, bias, bn.running_mean if track else None,
                                               bn.running_var if track else None, mom, bn.eps, slope)
+            cnt_all = stats[-1:]        # element count over all ranks (ranks may hold different batch sizes)
         else:           # one rank: no exchange, the apply kernel adds the slice partials itself (two launches)
             y, mean, invstd = capi.bn2d_fwd_local(x, res, weight, bias, bn.running_mean if track else None,
                                                   bn.running_var if track else None, mom, bn.eps, slope)
-        ctx.save_for_backward(x, y if slope != 1.0 else None, weight, mean, invstd)
+        ctx.save_for_backward(x, y if slope != 1.0 else None, weight, mean, invstd, cnt_all)
         ctx.meta = (slope, group, world, residual is not None, weight is not None)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         from rslo_amd import capi
-        x, y, weight, mean, invstd = ctx.saved_tensors
+        x, y, weight, mean, invstd, cnt_all = ctx.saved_tensors
         slope, group, world, has_res, affine = ctx.meta
         gy = gy.contiguous()
         has_act = slope != 1.0
@@ -98,8 +100,9 @@ class _FusedBNActFn(torch.autograd.Function):
             return dx, dgamma, dbeta, dres, None, None, None
         red, dgamma, dbeta = capi.bn2d_bwd_reduce(gy, y, x, mean, invstd, slope, has_act, want_affine=affine)
         dist.all_reduce(red, group=group)
-        count = float(x.shape[0] * x.shape[2] * x.shape[3] * world)      # equal batch on every rank (data parallel)
-        dx, dres = capi.bn2d_bwd_apply(gy, y, x, weight, mean, invstd, red, count, slope, has_act, has_res)
+        # the count all-reduced in the forward pass, read on the device: exact for uneven per-rank batches, no host sync
+        dx, dres = capi.bn2d_bwd_apply(gy, y, x, weight, mean, invstd, red, 0.0, slope, has_act, has_res,
+                                       count_dev=cnt_all)
         return dx, dgamma, dbeta, dres, None, None, None
 
 
@@ -117,8 +120,8 @@ class SyncBatchNorm(nn.SyncBatchNorm):
 
     def fusable(self, x):
         """The fused kernels take training-mode float32 NCHW tensors on the GPU (any number of ranks)."""
-        if FUSED_BN == "0" or not (self.training and isinstance(x, torch.Tensor) and x.is_cuda and x.dim() == 4
-                                   and x.dtype == torch.float32):
+        if FUSED_BN == "0" or self.momentum is None or not (self.training and isinstance(x, torch.Tensor) and x.is_cuda
+                                                            and x.dim() == 4 and x.dtype == torch.float32):
             return False
         return FUSED_BN != "auto" or _world(self.process_group) > 1
 
@@ -143,9 +146,13 @@ class SyncBatchNorm(nn.SyncBatchNorm):
             if self.training and self.track_running_stats:
                 count_batch(self)
             use_batch = self.training or not self.track_running_stats
+            mom = self.momentum
+            if mom is None:         # torch: cumulative moving average, factor 1 / num_batches_tracked (already counted)
+                n = int(self.num_batches_tracked) if self.num_batches_tracked is not None else 0
+                mom = 1.0 / n if (self.training and n > 0) else 0.0
             return F.batch_norm(x, self.running_mean if self.track_running_stats else None,
                                 self.running_var if self.track_running_stats else None, self.weight, self.bias,
-                                use_batch, self.momentum if self.momentum is not None else 0.0, self.eps)
+                                use_batch, mom, self.eps)
         return super().forward(x)
 
 

@@ -4,7 +4,7 @@ rslo/core/losses.py:234,244,359, rslo/models/voxel_odom_net.py:675,729, rslo/mod
 kornia is a third-party dependency that is NOT part of the reference tree and is not installed here, so
 this restates the published 0.4.0 algorithm: quaternions are (x, y, z, w); quaternion -> matrix
 L2-normalises its input first (eps 1e-12); matrix -> quaternion uses the four trace branches with
-eps = 1e-8.  Parity is pinned by algebraic known-answer tests (tests/test_geometry.py), not by kornia.
+eps = 1e-8.  Parity is pinned by algebraic known-answer tests (tests/test_golden_host.py), not by kornia.
 Only used when a real `kornia` is not importable.
 """
 import torch

@@ -219,7 +219,8 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn2d_bwd_apply(const float *__re
                                                                const float *__restrict__ gamma,
                                                                const float *__restrict__ save_mean,
                                                                const float *__restrict__ save_invstd,
-                                                               const double *__restrict__ red, double cnt, int C, int HW,
+                                                               const double *__restrict__ red, double cnt,
+                                                               const double *__restrict__ cnt_dev, int C, int HW,
                                                                float slope, int has_act, float *__restrict__ dx,
                                                                float *__restrict__ dres, const double *__restrict__ part,
                                                                int S, float *__restrict__ dgamma,
@@ -242,6 +243,7 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn2d_bwd_apply(const float *__re
     ra = red[c];
     rb = red[C + c];
   }
+  if (cnt_dev) cnt = *cnt_dev;               // element count over all ranks, as all-reduced in the forward pass
   const float mg = (float)(ra / cnt), mgx = (float)(rb / cnt);
   const int64_t base = (int64_t)row * HW;
   const int hw0 = (blockIdx.x * BN_THREADS + threadIdx.x) * 4;
@@ -549,7 +551,8 @@ extern "C" int rslo_bn2d_bwd_local(const float *dy, const float *y, const float 
   RSLO_CHECK_LAUNCH("k_bn2d_bwd_reduce");
   dim3 grid((unsigned)rslo_cdiv(rslo_cdiv(HW, 4), BN_THREADS), (unsigned)(N * C));
   hipLaunchKernelGGL(k_bn2d_bwd_apply, grid, dim3(BN_THREADS), 0, (hipStream_t)stream, dy, y, x, gamma, save_mean,
-                     save_invstd, (const double *)nullptr, (double)((int64_t)N * HW), C, HW, act_slope, has_act, dx, dres,
+                     save_invstd, (const double *)nullptr, (double)((int64_t)N * HW), (const double *)nullptr, C, HW,
+                     act_slope, has_act, dx, dres,
                      (const double *)ws, S, dgamma, dbeta);
   RSLO_CHECK_LAUNCH("k_bn2d_bwd_apply");
   return RSLO_OK;
@@ -585,12 +588,13 @@ extern "C" int rslo_bn2d_bwd_reduce(const float *dy, const float *y, const float
 
 extern "C" int rslo_bn2d_bwd_apply(const float *dy, const float *y, const float *x, const float *gamma,
                                    const float *save_mean, const float *save_invstd, const double *red, double count,
-                                   int N, int C, int HW, float act_slope, int has_act, float *dx, float *dres,
-                                   void *stream) {
-  RSLO_CHECK_ARG(dy && x && save_mean && save_invstd && red && dx && count > 0, "rslo_bn2d_bwd_apply: bad arguments");
+                                   const double *count_dev, int N, int C, int HW, float act_slope, int has_act,
+                                   float *dx, float *dres, void *stream) {
+  RSLO_CHECK_ARG(dy && x && save_mean && save_invstd && red && dx && (count > 0 || count_dev),
+                 "rslo_bn2d_bwd_apply: bad arguments");
   dim3 grid((unsigned)rslo_cdiv(rslo_cdiv(HW, 4), BN_THREADS), (unsigned)(N * C));
   hipLaunchKernelGGL(k_bn2d_bwd_apply, grid, dim3(BN_THREADS), 0, (hipStream_t)stream, dy, y, x, gamma, save_mean,
-                     save_invstd, red, count, C, HW, act_slope, has_act, dx, dres, (const double *)nullptr, 0,
+                     save_invstd, red, count, count_dev, C, HW, act_slope, has_act, dx, dres, (const double *)nullptr, 0,
                      (float *)nullptr, (float *)nullptr);
   RSLO_CHECK_LAUNCH("k_bn2d_bwd_apply");
   return RSLO_OK;

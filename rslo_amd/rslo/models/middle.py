@@ -109,8 +109,11 @@ class SpMiddleFHDWithCov2_3(nn.Module):
         # before any convolution is queued, then the ~20 conv launches run without a sync in between
         if plan is None:
             plan = self.plan(coors, batch_size)
-        if self.training and voxel_features.is_cuda and torch.is_grad_enabled():
-            spconv.presplit(self)        # split-bf16 weight operands of all 32/64-channel layers, one launch per step
+        if voxel_features.is_cuda:
+            # split-bf16 weight operands of all 32/64-channel layers, one launch per forward -- also in eval / no_grad:
+            # cached operands are validated by the parameter's version counter only, which a write through `.data`
+            # (EMA swaps, p.data.copy_) does not bump, so every forward refreshes them
+            spconv.presplit(self)
         x = plan._like(voxel_features)
         ret0 = self.middle_conv(x)
         ret = self.middle_conv_tail(ret0)

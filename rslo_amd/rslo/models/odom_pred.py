@@ -184,14 +184,19 @@ class UNOdomPredEncDecSVDTempMaskBase(OdomPredEncDecBase):
         cur = [b for m, _, _ in snap for b in (m.running_mean.data, m.running_var.data)]
         old = [b for _, mean0, var0 in snap for b in (mean0, var0)]
         moms = {m.momentum for m, _, _ in snap}
-        if cur[0].is_cuda and len(moms) == 1:
+        if cur[0].is_cuda and len(moms) == 1 and None not in moms:
             delta = torch._foreach_sub(cur, old)
             torch._foreach_mul_(delta, 1.0 - moms.pop())
             torch._foreach_add_(cur, delta)
         else:
             for m, mean0, var0 in snap:
-                m.running_mean.data.add_((m.running_mean.data - mean0) * (1.0 - m.momentum))
-                m.running_var.data.add_((m.running_var.data - var0) * (1.0 - m.momentum))
+                if m.momentum is None:      # cumulative average: the first update used 1/n, the second uses 1/(n+1)
+                    n = float(m.num_batches_tracked)
+                    f = (n - 1.0) / (n + 1.0)
+                else:
+                    f = 1.0 - m.momentum
+                m.running_mean.data.add_((m.running_mean.data - mean0) * f)
+                m.running_var.data.add_((m.running_var.data - var0) * f)
         for m, _, _ in snap:
             _count_batch(m)
 

@@ -32,26 +32,64 @@ def gradients_multiply(model, multiplier=1):
         torch._foreach_mul_(grads, multiplier)
 
 
+_GRAD_SET_RECHECK = 100      # calls between two agreements on the set of parameters that carry gradients
+
+
+def _agreed_grad_set(model, params):
+    """Indices (into `params`) of the parameters that receive a gradient on ANY rank, agreed by one small MAX
+    all-reduce on the first call and every _GRAD_SET_RECHECK calls after it (all ranks count calls alike).  The
+    reference's per-parameter loop (distributed_utils.py:62-75) stays aligned because its frozen torch zero-fills
+    gradients; here `zero_grad(set_to_none=True)` recomputes the non-None set from each step's graph, and a
+    data-dependent branch (an empty mask on one rank) would otherwise change the bucket size on that rank only and
+    hang the collective."""
+    st = model.__dict__.setdefault("_rslo_grad_set", {"calls": 0, "idx": None})
+    if st["idx"] is None or st["calls"] % _GRAD_SET_RECHECK == 0 or st.get("n") != len(params):
+        dev = params[0].device
+        have = torch.tensor([0.0 if p.grad is None else 1.0 for p in params], device=dev)
+        dist.all_reduce(have, op=dist.ReduceOp.MAX)
+        st["idx"] = [i for i, h in enumerate(have.tolist()) if h > 0]
+        st["n"] = len(params)
+    st["calls"] += 1
+    return st["idx"]
+
+
 def average_gradients(model, bucket=True, mean=False):
     """All-reduce the gradients of `model` across ranks as one flat fp32 bucket (sum; mean=True divides by the
-    world size)."""
+    world size).  The bucket covers the agreed set of gradient-carrying parameters (same size on every rank by
+    construction); a rank whose graph skipped one of them this step contributes zeros and receives the sum; a gradient
+    OUTSIDE the agreed set raises instead of being dropped silently."""
     if not _active():
         return
-    grads = [p.grad for p in model.parameters() if p.requires_grad and p.grad is not None]
-    if not grads:
+    params = [p for p in model.parameters() if p.requires_grad]
+    if not params:
+        return
+    idx = _agreed_grad_set(model, params)
+    chosen = set(idx)
+    stray = [i for i, p in enumerate(params) if p.grad is not None and i not in chosen]
+    if stray:
+        raise RuntimeError("average_gradients: %d parameter(s) received a gradient on this rank that no rank had when the "
+                           "gradient set was agreed (data-dependent graph?); call again after "
+                           "model.__dict__.pop('_rslo_grad_set')" % len(stray))
+    if not idx:
         return
     world = dist.get_world_size()
+    sel = [params[i] for i in idx]
+    grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in sel]
     if not bucket:
-        for g in grads:
+        for p, g in zip(sel, grads):
             dist.all_reduce(g)
             if mean:
                 g.div_(world)
+            p.grad = g
         return
     flat = torch.cat([g.reshape(-1) for g in grads])
     dist.all_reduce(flat)
     if mean:
         flat.div_(world)
     torch._foreach_copy_(grads, [c.view_as(g) for c, g in zip(flat.split([g.numel() for g in grads]), grads)])
+    for p, g in zip(sel, grads):
+        if p.grad is None:
+            p.grad = g
 
 
 def broadcast_params(model, src=0):

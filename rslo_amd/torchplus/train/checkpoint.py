@@ -65,13 +65,25 @@ def latest_checkpoint(model_dir, model_name):
     return str(path) if path.is_file() else None
 
 
-def save(model_dir, model, model_name, global_step, max_to_keep=8, keep_latest=True):
+def _to_host(obj):
+    """Copy of a (nested) state dict with every tensor on the host; the live objects stay where they are."""
+    if isinstance(obj, torch.Tensor):
+        return obj.detach().cpu()
+    if isinstance(obj, dict):
+        return type(obj)((k, _to_host(v)) for k, v in obj.items())
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_to_host(v) for v in obj)
+    return obj
+
+
+def save(model_dir, model, model_name, global_step, max_to_keep=8, keep_latest=True, host_copy=False):
     """Writes `<model_name>-<global_step>.tckpt` and updates the index; beyond `max_to_keep` files the oldest
-    entry (keep_latest) or the smallest step is deleted."""
+    entry (keep_latest) or the smallest step is deleted.  host_copy: serialise CPU copies of the state."""
     with _DeferSigint():
         index = _read_index(model_dir)
         fname = _file_name(model_name, global_step)
-        torch.save(model.state_dict(), str(Path(model_dir) / fname))
+        state = model.state_dict()
+        torch.save(_to_host(state) if host_copy else state, str(Path(model_dir) / fname))
         index["latest_ckpt"][model_name] = fname
         known = index["all_ckpts"].get(model_name, []) + [fname]
         alive = []
@@ -129,14 +141,15 @@ def restore_models(model_dir, models, global_step, map_func=None, map_location="
         restore(str(Path(model_dir) / _file_name(name, global_step)), model, map_func, map_location)
 
 
-def save_models(model_dir, models, global_step, max_to_keep=15, keep_latest=True):
+def save_models(model_dir, models, global_step, max_to_keep=15, keep_latest=True, host_copy=False):
     with _DeferSigint():
         for name, model in _named(models).items():
-            save(model_dir, model, name, global_step, max_to_keep, keep_latest)
+            save(model_dir, model, name, global_step, max_to_keep, keep_latest, host_copy=host_copy)
 
 
 def save_models_cpu(model_dir, models, global_step, max_to_keep=15, keep_latest=True):
     """The reference moves network + optimizer state to the host, saves, and moves back
-    (checkpoint.py:178-218).  state_dict tensors are serialised from wherever they live, so the round trip
-    through host memory (2 x 48 MB of copies and a full re-upload) is skipped: same files."""
-    save_models(model_dir, models, global_step, max_to_keep, keep_latest)
+    (checkpoint.py:178-218), so its .tckpt files hold CPU tensors and load anywhere without map_location.  Same
+    guarantee here from host COPIES of the state dicts (network and optimizer, incl. device-resident Adam step
+    counters); the live model / optimizer are not moved back and forth."""
+    save_models(model_dir, models, global_step, max_to_keep, keep_latest, host_copy=True)

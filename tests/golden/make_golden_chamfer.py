@@ -26,7 +26,13 @@ ref.forward(torch.from_numpy(a), torch.from_numpy(c), d1, d2, i1, i2)
 gd = rng.normal(size=(b, n)).astype(np.float32)
 g1, g2 = torch.zeros(b, n, 3), torch.zeros(b, m, 3)
 ref.backward(torch.from_numpy(a), torch.from_numpy(c), g1, g2, torch.from_numpy(gd), torch.zeros(b, m), i1, i2)
+# both directions (cd.forward / cd.backward as ChamferDistance / ChamferDistanceWithIdx use them,
+# chamfer_distance.py:47-130): second-direction outputs and the gradient with BOTH upstream gradients non-zero
+gd2 = rng.normal(size=(b, m)).astype(np.float32)
+h1, h2 = torch.zeros(b, n, 3), torch.zeros(b, m, 3)
+ref.backward(torch.from_numpy(a), torch.from_numpy(c), h1, h2, torch.from_numpy(gd), torch.from_numpy(gd2), i1, i2)
 out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "chamfer_ref.npz")
 np.savez_compressed(out, xyz1=a, xyz2=c, dist1=d1.numpy(), idx1=i1.numpy(), graddist1=gd,
-                    gradxyz1=g1.numpy(), gradxyz2=g2.numpy())
+                    gradxyz1=g1.numpy(), gradxyz2=g2.numpy(), dist2=d2.numpy(), idx2=i2.numpy(), graddist2=gd2,
+                    gradxyz1_both=h1.numpy(), gradxyz2_both=h2.numpy())
 print("wrote", out, os.path.getsize(out))

@@ -138,3 +138,68 @@ def test_average_gradients_sums_like_the_reference_single_process():
     assert torch.equal(lin.weight.grad, g)
     gradients_multiply(lin, 0.5)
     assert torch.equal(lin.weight.grad, g * 0.5)
+
+
+class _TwoBranch(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.a, self.b, self.never = torch.nn.Linear(3, 2), torch.nn.Linear(3, 2), torch.nn.Linear(3, 2)
+
+    def forward(self, x, use_b):
+        y = self.a(x)
+        return y + self.b(x) if use_b else y
+
+
+def _uneven_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rslo.utils.distributed_utils import average_gradients
+    torch.manual_seed(0)
+    net = _TwoBranch()
+    x = torch.ones(1, 3) * (rank + 1)
+    out = {}
+    # step 1: both ranks use branch b -> agreed set {a, b}; `never` stays without a gradient on every rank
+    net(x, True).sum().backward()
+    average_gradients(net)
+    out["s1_b"] = net.b.weight.grad.clone().numpy()
+    assert net.never.weight.grad is None
+    # step 2: rank 1's graph skips branch b (set_to_none zero_grad): the bucket keeps its size, rank 1 sends zeros
+    net.zero_grad(set_to_none=True)
+    net(x, rank == 0).sum().backward()
+    average_gradients(net)
+    out["s2_a"] = net.a.weight.grad.clone().numpy()
+    out["s2_b"] = net.b.weight.grad.clone().numpy()
+    # step 3: a gradient outside the agreed set must raise on the rank that has it, not hang / be dropped
+    net.zero_grad(set_to_none=True)
+    (net(x, True).sum() + (net.never(x).sum() if rank == 0 else 0.0)).backward()
+    try:
+        average_gradients(net)
+        out["s3"] = "ok"
+    except RuntimeError as e:
+        out["s3"] = "raised" if "agreed" in str(e) else str(e)
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+def test_gradient_bucket_keeps_its_size_when_one_rank_skips_a_branch():
+    """with zero_grad(set_to_none=True) the non-None gradient set comes from each step's graph; a rank
+    whose graph skips a parameter must not shrink the flat bucket (hang) -- it contributes zeros."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=_uneven_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    r0, r1 = res[0], res[1]
+    np.testing.assert_array_equal(r0["s1_b"], r1["s1_b"])
+    np.testing.assert_allclose(r0["s1_b"], np.full((2, 3), 3.0))         # d/dW of sum(Wx) = x: 1 + 2
+    np.testing.assert_array_equal(r0["s2_a"], r1["s2_a"])
+    np.testing.assert_allclose(r0["s2_a"], np.full((2, 3), 3.0))
+    np.testing.assert_array_equal(r0["s2_b"], r1["s2_b"])
+    np.testing.assert_allclose(r0["s2_b"], np.full((2, 3), 1.0))         # only rank 0 (x = 1) used the branch
+    assert r0["s3"] == "raised"

@@ -303,6 +303,38 @@ def test_chamfer_golden_and_oracle_bitexact(hip):
         assert (i.cpu().numpy() == oi).all() and (d.cpu().numpy() == od).all()
 
 
+def test_chamfer_two_direction_entry_points_match_reference(hip):
+    """cd.forward_cuda / cd.backward_cuda and the ChamferDistance / ChamferDistanceWithIdx autograd modules
+    (thirdparty/chamfer_distance/chamfer_distance.py:47-130,234-246) against vectors of the reference's own CPU build:
+    distances and indices bit-exact in both directions, gradients with both upstream gradients non-zero."""
+    from thirdparty.chamfer_distance.chamfer_distance import ChamferDistance, ChamferDistanceWithIdx, cd
+    g = np.load(os.path.join(GOLD, "chamfer_ref.npz"))
+    a, c = dev(g["xyz1"]), dev(g["xyz2"])
+    B, N, M = a.shape[0], a.shape[1], c.shape[1]
+    d1, d2 = torch.zeros(B, N, device="cuda"), torch.zeros(B, M, device="cuda")
+    i1 = torch.zeros(B, N, dtype=torch.int32, device="cuda")
+    i2 = torch.zeros(B, M, dtype=torch.int32, device="cuda")
+    cd.forward_cuda(a, c, d1, d2, i1, i2)
+    for got, key in ((d1, "dist1"), (d2, "dist2"), (i1, "idx1"), (i2, "idx2")):
+        assert (got.cpu().numpy() == g[key]).all(), key
+    g1, g2 = torch.zeros_like(a), torch.zeros_like(c)
+    cd.backward_cuda(a, c, g1, g2, dev(g["graddist1"]), dev(g["graddist2"]), i1, i2)
+    np.testing.assert_allclose(g1.cpu().numpy(), g["gradxyz1_both"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(g2.cpu().numpy(), g["gradxyz2_both"], rtol=1e-6, atol=1e-6)
+    # autograd modules
+    ar, cr = a.clone().requires_grad_(True), c.clone().requires_grad_(True)
+    e1, e2, j1, j2 = ChamferDistanceWithIdx()(ar, cr)
+    assert torch.equal(e1, d1) and torch.equal(e2, d2) and torch.equal(j1, i1) and torch.equal(j2, i2)
+    ((e1 * dev(g["graddist1"])).sum() + (e2 * dev(g["graddist2"])).sum()).backward()
+    np.testing.assert_allclose(ar.grad.cpu().numpy(), g["gradxyz1_both"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(cr.grad.cpu().numpy(), g["gradxyz2_both"], rtol=1e-6, atol=1e-6)
+    ar2, cr2 = a.clone().requires_grad_(True), c.clone().requires_grad_(True)
+    f1, f2 = ChamferDistance()(ar2, cr2)
+    (f1 * dev(g["graddist1"])).sum().backward()           # one upstream gradient only: the one-direction vectors
+    np.testing.assert_allclose(ar2.grad.cpu().numpy(), g["gradxyz1"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(cr2.grad.cpu().numpy(), g["gradxyz2"], rtol=1e-6, atol=1e-6)
+
+
 def test_chamfer_full_size_properties(hip):
     """At the BASELINE size (~31k x 31k): self-query gives idx == arange and dist == 0; a sampled
     subset agrees bit-exactly with the oracle."""

@@ -218,6 +218,17 @@ def test_chamfer_golden_vectors():
     assert (i == g["idx1"]).all() and (d == g["dist1"]).all()
 
 
+def test_chamfer_golden_vectors_both_directions():
+    """cd.forward / cd.backward (both directions, chamfer_distance.cpp:116-235) restated as two one-direction calls."""
+    g = np.load(os.path.join(GOLD, "chamfer_ref.npz"))
+    d2, i2 = O.chamfer_nn(g["xyz2"], g["xyz1"])
+    assert (i2 == g["idx2"]).all() and (d2 == g["dist2"]).all()
+    a1, a2 = O.chamfer_grad(g["xyz1"], g["xyz2"], g["graddist1"], g["idx1"])
+    b2, b1 = O.chamfer_grad(g["xyz2"], g["xyz1"], g["graddist2"], g["idx2"])
+    np.testing.assert_allclose(a1 + b1, g["gradxyz1_both"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(a2 + b2, g["gradxyz2_both"], rtol=1e-6, atol=1e-6)
+
+
 def test_chamfer_vs_cdist_and_tie_break():
     rng = np.random.default_rng(6)
     a = rng.normal(size=(1, 400, 3)).astype(np.float32)
