@@ -29,6 +29,29 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E ~8 TB/s (MI355X_MICROARCH.md)
 MFMA_F32_PEAK_TF = 157.3   # dense fp32-input MFMA peak = the fp32 vector peak (MI355X_MICROARCH.md)
+MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md; the 5 PF headline includes 2:1 sparsity)
+
+
+def lib_hash():
+    """First 16 hex digits of the sha256 of librslo_hip.so: the PMC summaries under profiles/ carry the hash of the
+    library they were collected with; counter fields are only quoted when it matches the library being benchmarked."""
+    import hashlib
+    try:
+        with open(os.path.join(ROOT, "rslo_amd", "librslo_hip.so"), "rb") as f:
+            return hashlib.sha256(f.read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def parse():
@@ -44,6 +67,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP events (roofline=null)")
     ap.add_argument("--kernel-report", default="", help="write the per-kernel roofline table to this JSON file")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="f32 = C3 (the headline line); bf16 = the single-GPU half of C4: apex.amp O1, bf16 conv operands")
     return ap.parse_args()
 
 
@@ -53,6 +78,10 @@ def _flush_c_stdio():
         ctypes.CDLL(None).fflush(None)
     except OSError:
         pass
+
+
+PMC_TRAFFIC = "r02_pmc_traffic_bench.json"
+PMC_BUSY = "r02_pmc_mfma_busy.json"
 
 
 # --------------------------------------------------------------------------------------------- kernel events
@@ -68,10 +97,12 @@ class ConvProbe:
         self._orig = {}
 
     @staticmethod
-    def kernel_name(cin_op, cout_op, n_out, trans, split=False):
+    def kernel_name(cin_op, cout_op, n_out, trans, split=False, bf16=False):
         """The template instantiation the entry point dispatches to (rslo_amd/csrc/spconv.hip)."""
         t = "true" if trans else "false"
         rbw = 2 if n_out >= 256 * 32 * 8 else 1
+        if bf16:
+            return "k_spconv_bf16<%d, %d, %d>" % (cin_op, cout_op, rbw)
         if split:
             return "k_spconv_v6<%d, %d, %d>" % (cin_op, cout_op, rbw)
         if cin_op % 16 == 0 and cout_op % 16 == 0:
@@ -85,7 +116,7 @@ class ConvProbe:
         capi = self.capi
         # the lowest-level wrappers: capi.spconv_fwd / spconv_dgrad only dispatch to these (the data gradient of
         # MFMA-shaped layers runs through a forward kernel on transposed weights)
-        names = ("spconv_fwd_direct", "spconv_fwd_split", "spconv_dgrad_direct")
+        names = ("spconv_fwd_direct", "spconv_fwd_split", "spconv_dgrad_direct", "spconv_fwd_bf16")
         self._orig = {n: getattr(capi, n) for n in names}
         probe = self
 
@@ -111,6 +142,12 @@ class ConvProbe:
             return ("fwd", cin, cout, nbr.shape[1], nbr.shape[0], nbr if probe.keep_tables else None,
                     probe.kernel_name(cin, cout, nbr.shape[0], False, split=True))
 
+        def bf16_meta(x, W, bias, nbr, flip_k=False, act_slope=1.0, transpose=False, order=None):
+            K, cin, cout = W.shape
+            ci, co = (cout, cin) if transpose else (cin, cout)
+            return ("bf16", ci, co, K, nbr.shape[0], nbr if probe.keep_tables else None,
+                    probe.kernel_name(ci, co, nbr.shape[0], False, bf16=True))
+
         def dgrad_meta(dout, W, nbrT, flip_k=False, order=None):
             K, cin, cout = W.shape
             return ("dgrad", cout, cin, K, nbrT.shape[0], nbrT if probe.keep_tables else None,
@@ -118,16 +155,17 @@ class ConvProbe:
 
         # dense 3x3 convolutions of the BEV head (csrc/conv2d.hip): algorithmic flops 2 B Ho Wo Cin Cout 9; bytes = input +
         # output (+ split weights / + weight gradient), each touched once
-        def c2f_meta(x, ws, bias, cout):
+        def c2f_meta(x, ws, bias, cout, lp=False):
             B, cin, H, W = x.shape
             return ("dense", 2 * B * H * W * cin * cout * 9, 4 * B * H * W * (cin + cout) + 54 * cin * cout,
-                    "k_conv2d_fwd<4, 1, true> [%d->%d %dx%d]" % (cin, cout, H, W))
+                    "k_conv2d_fwd<4, 1, true%s> [%d->%d %dx%d]" % (", true" if lp else "", cin, cout, H, W))
 
-        def c2w_meta(x, dout, stride=1, want_bias=False):
+        def c2w_meta(x, dout, stride=1, want_bias=False, lp=False):
             B, cin, H, W = x.shape
             cout, Ho, Wo = dout.shape[1], dout.shape[2], dout.shape[3]
             return ("dense", 2 * B * Ho * Wo * cin * cout * 9, 4 * B * (H * W * cin + Ho * Wo * cout) + 36 * cin * cout,
-                    ("k_conv2d_wgrad_s1<2>" if stride == 1 else "k_conv2d_wgrad<2, 2>") + " [%d->%d %dx%d]" % (cin, cout, H, W))
+                    ("k_conv2d_wgrad_s1<2%s>" % (", true" if lp else "") if stride == 1 else "k_conv2d_wgrad<2, 2>")
+                    + " [%d->%d %dx%d]" % (cin, cout, H, W))
 
         if os.environ.get("RSLO_CONV2D_FWD_CFG") is None and os.environ.get("RSLO_CONV2D_NB") is None:
             for n, meta in (("conv2d_fwd", c2f_meta), ("conv2d_wgrad", c2w_meta)):
@@ -136,6 +174,7 @@ class ConvProbe:
         capi.spconv_fwd_direct = timed(self._orig["spconv_fwd_direct"], fwd_meta)
         capi.spconv_fwd_split = timed(self._orig["spconv_fwd_split"], split_meta)
         capi.spconv_dgrad_direct = timed(self._orig["spconv_dgrad_direct"], dgrad_meta)
+        capi.spconv_fwd_bf16 = timed(self._orig["spconv_fwd_bf16"], bf16_meta)
 
     def uninstall(self):
         for k, f in self._orig.items():
@@ -155,7 +194,8 @@ class ConvProbe:
             else:
                 kind, cin, cout, K, n_out, _, name = m
                 P = pairs[i % per_step]
-                byts = P * cin * 4 + n_out * cout * 4 + 8 * P + K * cin * cout * 4
+                sz = 2 if kind == "bf16" else 4          # bytes per feature / weight element
+                byts = P * cin * sz + n_out * cout * sz + 8 * P + K * cin * cout * sz
                 flops = 2 * P * cin * cout
             g = groups.setdefault(name, {"launches": 0, "ms": 0.0, "bytes": 0, "flops": 0})
             g["launches"] += 1
@@ -166,30 +206,41 @@ class ConvProbe:
             g["avg_us"] = 1e3 * g["ms"] / g["launches"]
             g["GBps"] = g["bytes"] / (g["ms"] * 1e-3) / 1e9
             g["TFLOPs"] = g["flops"] / (g["ms"] * 1e-3) / 1e12
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_bench.json")) as f:
-                pmc = json.load(f).get("kernels", {})
-        except (OSError, ValueError):
-            pmc = {}
+        # PMC summaries (scripts/pmc_bench_traffic.sh, scripts/pmc_mfma_busy.sh) are quoted only when they were collected
+        # with the library being benchmarked (they record its hash); otherwise the fields stay null
+        here = lib_hash()
 
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_mfma_busy.json")) as f:
-                pmc_busy = json.load(f).get("kernels", {})
-        except (OSError, ValueError):
-            pmc_busy = {}
+        def load_pmc(fname):
+            try:
+                with open(os.path.join(ROOT, "profiles", fname)) as f:
+                    d = json.load(f)
+            except (OSError, ValueError):
+                return {}, "profiles/%s missing" % fname
+            if d.get("lib_sha256") != here:
+                return {}, "profiles/%s was collected with another build of librslo_hip.so (%s, now %s)" % (
+                    fname, d.get("lib_sha256"), here)
+            return d.get("kernels", {}), None
+        pmc, pmc_note = load_pmc(PMC_TRAFFIC)
+        pmc_busy, busy_note = load_pmc(PMC_BUSY)
 
         def roof_of(gname):
             g = groups[gname]
             name = gname.split(" [")[0]          # dense groups are keyed kernel + layer shape
             # which roof bounds it: arithmetic intensity vs the fp32 ridge (157.3 TF / 8 TB/s = 19.7 flop/B)
             ai = g["flops"] / g["bytes"]
-            if ai >= MFMA_F32_PEAK_TF * 1e3 / HBM_PEAK_GBS:
+            lowp = "k_spconv_bf16" in name or name.endswith(", true>")      # bf16 operands (C4)
+            if lowp and ai >= MFMA_BF16_PEAK_TF * 1e3 / HBM_PEAK_GBS:
+                r = {"bound": "mfma", "kernel": name, "achieved": round(g["TFLOPs"], 2), "peak": MFMA_BF16_PEAK_TF,
+                     "unit": "TFLOP/s", "frac": round(g["TFLOPs"] / MFMA_BF16_PEAK_TF, 4), "traffic": None}
+            elif not lowp and ai >= MFMA_F32_PEAK_TF * 1e3 / HBM_PEAK_GBS:
                 r = {"bound": "mfma", "kernel": name, "achieved": round(g["TFLOPs"], 2), "peak": MFMA_F32_PEAK_TF,
                      "unit": "TFLOP/s", "frac": round(g["TFLOPs"] / MFMA_F32_PEAK_TF, 4), "traffic": None}
             else:
                 r = {"bound": "hbm", "kernel": name, "achieved": round(g["GBps"], 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(g["GBps"] / HBM_PEAK_GBS, 4), "traffic": None}
-            if "k_spconv_v6" in name or "k_conv2d" in name:
+            if lowp:
+                r["matrix_core_path"] = "bf16 operands (round to nearest), fp32 accumulation: 1 x v_mfma_f32_16x16x32_bf16"
+            elif "k_spconv_v6" in name or "k_conv2d" in name:
                 # fp32 products computed as six bf16 MFMAs on exactly split operands (csrc/spconv.hip v6, csrc/conv2d.hip):
                 # the algorithmic fp32 flops are priced against the fp32 MFMA peak; the bf16 matrix-core work issued is 6x
                 r["matrix_core_path"] = "fp32 = 3-way exact bf16 split, 6 x v_mfma_f32_16x16x32_bf16 per product block"
@@ -207,11 +258,15 @@ class ConvProbe:
                 r["layer_shape"] = gname.split(" [")[1].rstrip("]")
             if name in pmc_busy:       # matrix-core busy cycles / (shader cycles x 1024 SIMDs), scripts/pmc_mfma_busy.sh
                 r["mfma_busy_pct"] = pmc_busy[name]["mfma_busy_pct"]
-                r["mfma_busy_source"] = "profiles/r01_pmc_mfma_busy.json"
+                r["mfma_busy_source"] = "profiles/" + PMC_BUSY
+            elif busy_note:
+                r["mfma_busy_note"] = busy_note
             if name in pmc:
                 r["traffic"] = int(pmc[name]["hbm_bytes_per_launch"])
-                r["traffic_source"] = "profiles/r01_pmc_traffic_bench.json" + (
+                r["traffic_source"] = "profiles/" + PMC_TRAFFIC + (
                     " (average over all layer shapes of this kernel)" if gname != name else "")
+            elif pmc_note:
+                r["traffic_note"] = pmc_note
             return r
 
         # the dominant kernel = the (kernel instantiation, problem shape) with the largest total time per step among the
@@ -249,7 +304,8 @@ def cpu_baseline(args):
         ret = net(ex)
         ret["loss"].backward()
         dt = time.time() - t0
-    return {"value": round(1.0 / dt, 4), "unit": "frame-pairs/s", "cores": int(threads), "kind": "port",
+    return {"value": round(1.0 / dt, 4), "unit": "frame-pairs/s", "cores": int(threads), "cpu_model": cpu_model(),
+            "kind": "port",
             "sample": "1 frame pair (2 x %d-ring synthetic scans), voxelize+forward+backward, bs=1, "
                       "oracle C/OpenMP sparse ops + torch-CPU dense head; %.1f s" % (args.rings, dt)}
 
@@ -312,6 +368,8 @@ def main():
     train_cfg = config_text.shipped_config().train_config
     opt = optimizer_builder.build(train_cfg.optimizer, net)
     sched = lr_scheduler_builder.build(train_cfg.optimizer, opt, train_cfg.steps)
+    from apex import amp        # the real package if installed, else rslo_amd/compat/apex
+    net, opt = amp.initialize(net, opt, opt_level="O1" if args.dtype == "bf16" else "O0")   # train_hdf5.py:456-461
 
     clouds = workload.kitti_pairs(args.batch, n_el=args.rings, start=rank * args.batch)
     clouds = [[torch.from_numpy(c).to(dev) for c in pair] for pair in clouds]
@@ -354,7 +412,8 @@ def main():
         if prefetch is not None:
             prefetch.submit(clouds)
         w0, c0 = mark("fwd", w0, c0)
-        ret["loss"].mean().backward()
+        with amp.scale_loss(ret["loss"].mean(), opt) as scaled_loss:       # train_hdf5.py:663
+            scaled_loss.backward()
         if dist_on:
             average_gradients(net, mean=True)
         w0, c0 = mark("bwd", w0, c0)
@@ -386,12 +445,15 @@ def main():
         v[0] = v[1] = 0.0
     t0 = time.perf_counter()
     cpu0 = time.thread_time()           # CPU time of the issuing thread: close to the wall time = host-bound step
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # one event per step: spread of the
+    marks[0].record()                                                                # step time without extra syncs
     for i in range(args.steps):
         if use_probe and i == args.steps - probe_steps:
             probe.enabled = True
         if use_probe and i == args.steps - 1:
             probe.keep_tables = True
         ret = step()
+        marks[i + 1].record()
     cpu_issue = time.thread_time() - cpu0
     barrier()
     elapsed = time.perf_counter() - t0
@@ -405,6 +467,7 @@ def main():
         print("phases (wall ms, cpu ms per step): " + ", ".join(
             "%s %.2f/%.2f" % (k, 1e3 * v[0] / args.steps, 1e3 * v[1] / args.steps) for k, v in ph.items()), file=sys.stderr)
     loss_val = float(ret["loss"].detach().mean().item())
+    per_step = np.array([marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)])
     if rank == 0:
         roof = None
         if use_probe and probe.records:
@@ -422,10 +485,18 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "C3: full fwd+bwd (voxelize + GU encoder + BEV head/vote + chamfer/ICP loss"
-                                   "%s), bs=%d frame pairs/GPU, fp32, %d-ring scans (~%d pts/frame), dp%d"
-                                   % ("" if args.no_optim else " + Adam step", args.batch, args.rings, n_points, world),
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "%s: full fwd+bwd (voxelize + GU encoder + BEV head/vote + chamfer/ICP loss"
+                                   "%s), bs=%d frame pairs/GPU, %s, %d-ring scans (~%d pts/frame), dp%d"
+                                   % ("C3" if args.dtype == "f32" else "C4 (per-GPU part)",
+                                      "" if args.no_optim else " + Adam step", args.batch,
+                                      "fp32" if args.dtype == "f32" else
+                                      "bf16 conv operands / bf16 encoder trunk features, fp32 accumulate + masters (amp O1)",
+                                      args.rings, n_points, world),
+                       "ms_per_step_gpu_timeline": {"median": round(float(np.median(per_step)), 3),
+                                                    "p10": round(float(np.percentile(per_step, 10)), 3),
+                                                    "p90": round(float(np.percentile(per_step, 90)), 3)},
+                       "lib_sha256": lib_hash(),
                        "frame_pairs_per_gpu": args.batch, "points_per_frame": n_points,
                        "voxelize_in_step": not args.no_voxelize, "voxelize_prefetch_stream": prefetch is not None,
                        "optimizer_in_step": not args.no_optim,

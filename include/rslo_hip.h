@@ -153,6 +153,18 @@ RSLO_API int rslo_weight_to_bf16(const float *W, int K, int cin_op, int cout_op,
 RSLO_API int rslo_spconv_fwd_bf16(const void *in, int cin, const void *Wb, const float *bias, const int32_t *nbr,
                                   const int32_t *row_order, int64_t n_out, int K, int cout, int flip_k,
                                   float act_slope, void *out, void *stream);
+/*     bf16 feature path, backward: g = dout * act'(y) on bf16 rows (+ per-block column sums of g in fp32, stage 1 of the
+ *     bias gradient; partial [rslo_leaky_bwd_colsum_bf16_blocks(rows, cols), cols] or NULL; cols must divide 2048), and
+ *     the pair-list weight gradient with bf16 rows on both sides, fp32 accumulation and fp32 dW / dbias (workspace size:
+ *     rslo_spconv_wgrad_pairs_ws_bytes; dbias requires bias_partial).  The data gradient is rslo_spconv_fwd_bf16 on the
+ *     transposed operand (rslo_weight_to_bf16(..., transpose = 1)). */
+RSLO_API int64_t rslo_leaky_bwd_colsum_bf16_blocks(int64_t rows, int cols);
+RSLO_API int rslo_leaky_bwd_colsum_bf16(const void *y, const void *dout, int64_t rows, int cols, float slope, void *g,
+                                        float *partial, void *stream);
+RSLO_API int rslo_spconv_wgrad_pairs_bf16(const void *in, int cin, const void *dout, int cout, const int32_t *pairs_in,
+                                          const int32_t *pairs_out, const int32_t *koff, int64_t n_out, int K, void *ws,
+                                          size_t ws_bytes, float *dW, float *dbias, const float *bias_partial,
+                                          int n_bias_partial, void *stream);
 RSLO_API size_t rslo_spconv_wgrad_ws_bytes(int64_t n_out, int K, int cin, int cout);
 RSLO_API int rslo_spconv_wgrad(const float *in, int cin, const float *dout, int cout, const int32_t *nbr,
                       int64_t n_out, int K, void *ws, size_t ws_bytes, float *dW /*[K,cin,cout]*/,
@@ -403,6 +415,13 @@ RSLO_API int rslo_conv2d_wsplit_many(const RsloConv2dSplitDesc *desc_dev, int n_
                                      void *stream);
 RSLO_API int rslo_conv2d_fwd(const float *in, const void *Ws, const float *bias, int B, int cin, int cout, int H, int W,
                              float *out, void *stream);
+/*      C4 (bf16 operands, fp32 accumulation and storage): the same kernels issuing only the product of the
+ *      round-to-nearest bf16 values of activations and weights (1 MFMA instead of 6).  Ws is the operand block of
+ *      rslo_conv2d_wsplit (its first plane IS the bf16-rounded weight); the stride-2 weight gradient keeps the split form. */
+RSLO_API int rslo_conv2d_fwd_bf16(const float *in, const void *Ws, const float *bias, int B, int cin, int cout, int H,
+                                  int W, float *out, void *stream);
+RSLO_API int rslo_conv2d_wgrad_bf16(const float *in, const float *dout, int B, int cin, int cout, int H, int W,
+                                    int stride, float *dW, float *dbias, void *ws, size_t ws_bytes, void *stream);
 
 /* a11 / a12  the 1x1 output convolutions of the head (torch.nn.Conv2d(c, 7, 1) / (32, 1, 1): rslo/models/odom_pred.py:71,
  *      rslo/models/odom_pred_base.py:22-24,107-109), cout <= 8, NCHW fp32, HW = H * W:

@@ -46,6 +46,10 @@ SIGNATURES = {
     "rslo_spconv_wgrad_ws_bytes": (_sz, [_i64, _i, _i, _i]),
     "rslo_spconv_wgrad": (C.c_int, [_vp, _i, _vp, _i, _vp, _i64, _i, _vp, _sz, _vp, _vp, _vp]),
     "rslo_rulebook_row_order": (C.c_int, [_vp, _i64, _i, _i, _vp, _vp]),
+    "rslo_leaky_bwd_colsum_bf16_blocks": (_i64, [_i64, _i]),
+    "rslo_leaky_bwd_colsum_bf16": (C.c_int, [_vp, _vp, _i64, _i, C.c_float, _vp, _vp, _vp]),
+    "rslo_spconv_wgrad_pairs_bf16": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i64, _i, _vp, _sz, _vp, _vp, _vp, _i,
+                                               _vp]),
     "rslo_rulebook_pairs_ws_bytes": (_sz, [_i64, _i]),
     "rslo_rulebook_pairs": (C.c_int, [_vp, _i64, _i, _vp, _sz, _vp, _vp, _vp, _vp]),
     "rslo_spconv_wgrad_pairs_ws_bytes": (_sz, [_i64, _i, _i, _i]),
@@ -98,6 +102,8 @@ SIGNATURES = {
     "rslo_conv2d_wsplit": (C.c_int, [_vp, _i, _i, _i, _vp, _vp]),
     "rslo_conv2d_wsplit_many": (C.c_int, [_vp, _i, _i64, _vp]),
     "rslo_conv2d_fwd": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "rslo_conv2d_fwd_bf16": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "rslo_conv2d_wgrad_bf16": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "rslo_conv1x1_supported": (C.c_int, [_i, _i]),
     "rslo_conv1x1_fwd": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "rslo_conv1x1_dgrad": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
@@ -490,6 +496,35 @@ def leaky_bwd(y, dout, slope, colsum=False):
     _chk(lib().rslo_leaky_bwd(_ptr(y, torch.float32, "y"), _ptr(dout, torch.float32, "dout"), y.numel(),
                               float(slope), _ptr(g), _stream()), "rslo_leaky_bwd")
     return (g, None) if colsum is None else g
+
+
+def leaky_bwd_bf16(y, dout, slope, colsum=False):
+    """bf16 rows: g = dout * (y > 0 ? 1 : slope) in bf16; colsum -> (g, per-block fp32 column sums [blocks, cols])."""
+    rows, cols = dout.shape
+    g = torch.empty_like(dout)
+    part = None
+    if colsum:
+        nblk = int(lib().rslo_leaky_bwd_colsum_bf16_blocks(rows, cols))
+        part = torch.empty((nblk, cols), dtype=torch.float32, device=dout.device)
+    _chk(lib().rslo_leaky_bwd_colsum_bf16(_ptr(y, torch.bfloat16, "y"), _ptr(dout, torch.bfloat16, "dout"), rows, cols,
+                                          float(slope), _ptr(g), _ptr(part), _stream()), "rslo_leaky_bwd_colsum_bf16")
+    return (g, part) if colsum else g
+
+
+def spconv_wgrad_pairs_bf16(x, dout, pairs, n_out, K, cin, cout, bias_partial=None):
+    """bf16 rows on both sides -> fp32 (dW [K,cin,cout], dbias or None); dbias needs bias_partial (leaky_bwd_bf16)."""
+    pin, pout, koff = pairs
+    dev = x.device
+    dW = torch.empty((K, cin, cout), dtype=torch.float32, device=dev)
+    db = torch.empty((cout,), dtype=torch.float32, device=dev) if bias_partial is not None else None
+    wsb = lib().rslo_spconv_wgrad_pairs_ws_bytes(n_out, K, cin, cout)
+    ws = _ws(wsb, dev)
+    _chk(lib().rslo_spconv_wgrad_pairs_bf16(_ptr(x, torch.bfloat16, "x"), cin, _ptr(dout, torch.bfloat16, "dout"), cout,
+                                            _ptr(pin, torch.int32, "pairs_in"), _ptr(pout, torch.int32, "pairs_out"),
+                                            _ptr(koff, torch.int32, "koff"), n_out, K, _ptr(ws), wsb, _ptr(dW), _ptr(db),
+                                            _ptr(bias_partial), 0 if bias_partial is None else bias_partial.shape[0],
+                                            _stream()), "rslo_spconv_wgrad_pairs_bf16")
+    return dW, db
 
 
 def segbn_fwd(x, seg_off, S, max_len, gamma, beta, running_mean, running_var, momentum, eps, act_slope):
@@ -918,9 +953,9 @@ def conv2d_wgrad_supported(cin, cout, H, W, stride):
 _c2w_ws_bytes = {}
 
 
-def conv2d_wgrad(x, dout, stride=1, want_bias=False):
+def conv2d_wgrad(x, dout, stride=1, want_bias=False, lp=False):
     """x [B,cin,H,W], dout [B,cout,Ho,Wo] (contiguous NCHW fp32) -> dW [cout,cin,3,3] of a 3x3 / padding-1 conv;
-    want_bias (stride 1): -> (dW, dbias [cout]) with the bias gradient from the same pass."""
+    want_bias (stride 1): -> (dW, dbias [cout]) with the bias gradient from the same pass.  lp: bf16 operands (C4)."""
     B, cin, H, W = x.shape
     cout = dout.shape[1]
     key = (B, cin, cout, H, W, stride)
@@ -933,8 +968,9 @@ def conv2d_wgrad(x, dout, stride=1, want_bias=False):
     ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
     dW = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=dev)
     db = torch.empty((cout,), dtype=torch.float32, device=dev) if want_bias else None
-    rc = lib().rslo_conv2d_wgrad(_ptr(x, torch.float32, "x"), _ptr(dout, torch.float32, "dout"), B, cin, cout, H, W,
-                                 stride, dW.data_ptr(), _dp(db), ws.data_ptr(), wsb, _stream())
+    fn = lib().rslo_conv2d_wgrad_bf16 if lp else lib().rslo_conv2d_wgrad
+    rc = fn(_ptr(x, torch.float32, "x"), _ptr(dout, torch.float32, "dout"), B, cin, cout, H, W,
+            stride, dW.data_ptr(), _dp(db), ws.data_ptr(), wsb, _stream())
     if rc:
         _chk(rc, "rslo_conv2d_wgrad")
     return (dW, db) if want_bias else dW
@@ -982,12 +1018,14 @@ def conv2d_wsplit_run(plan):
     _chk(lib().rslo_conv2d_wsplit_many(_ptr(plan["table"]), plan["n"], plan["max"], _stream()), "rslo_conv2d_wsplit_many")
 
 
-def conv2d_fwd(x, ws, bias, cout):
-    """x [B,cin,H,W] contiguous fp32, ws from conv2d_wsplit -> [B,cout,H,W] (3x3, stride 1, padding 1)."""
+def conv2d_fwd(x, ws, bias, cout, lp=False):
+    """x [B,cin,H,W] contiguous fp32, ws from conv2d_wsplit -> [B,cout,H,W] (3x3, stride 1, padding 1).
+    lp: bf16 operands, fp32 accumulation (C4)."""
     B, cin, H, W = x.shape
     out = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device)
-    rc = lib().rslo_conv2d_fwd(_ptr(x, torch.float32, "x"), ws.data_ptr(), _dp(bias), B, cin, cout, H, W, out.data_ptr(),
-                               _stream())
+    fn = lib().rslo_conv2d_fwd_bf16 if lp else lib().rslo_conv2d_fwd
+    rc = fn(_ptr(x, torch.float32, "x"), ws.data_ptr(), _dp(bias), B, cin, cout, H, W, out.data_ptr(),
+            _stream())
     if rc:
         _chk(rc, "rslo_conv2d_fwd")
     return out

@@ -206,7 +206,7 @@ __global__ __launch_bounds__(C2_THREADS, 2) void k_conv2d_wgrad(const float *__r
 // kx = 1 -- 77 VALU operations per row instead of 180.  Border masks are formed from the row-wrap position (no
 // per-pixel compares) and applied as bit masks on the packed operands, only in chunks where some lane needs them.
 // The 4 waves are added through two LDS regions in two phases ((w0 + w2) + (w1 + w3), fixed order).
-template <int NB>
+template <int NB, bool LP = false>
 __global__ __launch_bounds__(C2_THREADS, NB == 2 ? 3 : 2) void k_conv2d_wgrad_s1(const float *__restrict__ in,
                                                                                const float *__restrict__ dout,
                                                                                Conv2dGeom gm, float invW,
@@ -323,6 +323,7 @@ __global__ __launch_bounds__(C2_THREADS, NB == 2 ? 3 : 2) void k_conv2d_wgrad_s1
           }
         }
         const int t = ky * 3 + kx;
+        if constexpr (!LP) {      // LP (bf16 operands, C4): only hh -- the mid / lo pieces are dead code then
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) acc[t][nb] = MFMA_BF16(al, bh[nb], acc[t][nb]);
 #pragma unroll
@@ -333,6 +334,7 @@ __global__ __launch_bounds__(C2_THREADS, NB == 2 ? 3 : 2) void k_conv2d_wgrad_s1
         for (int nb = 0; nb < NB; ++nb) acc[t][nb] = MFMA_BF16(am, bh[nb], acc[t][nb]);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) acc[t][nb] = MFMA_BF16(ah, bm[nb], acc[t][nb]);
+        }
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) acc[t][nb] = MFMA_BF16(ah, bh[nb], acc[t][nb]);
       }
@@ -476,8 +478,21 @@ extern "C" size_t rslo_conv2d_wgrad_ws_bytes(int B, int cin, int cout, int H, in
          (size_t)ns * cout * sizeof(float);      // + one bias-gradient partial row per slab
 }
 
+static int conv2d_wgrad_launch(const float *in, const float *dout, int B, int cin, int cout, int H, int W, int stride,
+                               float *dW, float *dbias, void *ws, size_t ws_bytes, void *stream, bool lp);
+
 extern "C" int rslo_conv2d_wgrad(const float *in, const float *dout, int B, int cin, int cout, int H, int W,
                                  int stride, float *dW, float *dbias, void *ws, size_t ws_bytes, void *stream) {
+  return conv2d_wgrad_launch(in, dout, B, cin, cout, H, W, stride, dW, dbias, ws, ws_bytes, stream, false);
+}
+
+extern "C" int rslo_conv2d_wgrad_bf16(const float *in, const float *dout, int B, int cin, int cout, int H, int W,
+                                      int stride, float *dW, float *dbias, void *ws, size_t ws_bytes, void *stream) {
+  return conv2d_wgrad_launch(in, dout, B, cin, cout, H, W, stride, dW, dbias, ws, ws_bytes, stream, stride == 1);
+}
+
+static int conv2d_wgrad_launch(const float *in, const float *dout, int B, int cin, int cout, int H, int W, int stride,
+                               float *dW, float *dbias, void *ws, size_t ws_bytes, void *stream, bool lp) {
   Conv2dGeom gm;
   int nb, ns;
   RSLO_CHECK_ARG(conv2d_plan(B, cin, cout, H, W, stride, &gm, &nb, &ns),
@@ -493,7 +508,11 @@ extern "C" int rslo_conv2d_wgrad(const float *in, const float *dout, int B, int 
   hipLaunchKernelGGL((k_conv2d_wgrad<NBv, Sv>), grid, dim3(C2_THREADS), 0, st, in, dout, gm, (float *)ws)
   if (stride == 1) {
     const float invW = 1.0f / (float)gm.W;
-    if (nb == 4)
+    if (lp && nb == 4)
+      hipLaunchKernelGGL((k_conv2d_wgrad_s1<4, true>), grid, dim3(C2_THREADS), 0, st, in, dout, gm, invW, (float *)ws, bws);
+    else if (lp)
+      hipLaunchKernelGGL((k_conv2d_wgrad_s1<2, true>), grid, dim3(C2_THREADS), 0, st, in, dout, gm, invW, (float *)ws, bws);
+    else if (nb == 4)
       hipLaunchKernelGGL((k_conv2d_wgrad_s1<4>), grid, dim3(C2_THREADS), 0, st, in, dout, gm, invW, (float *)ws, bws);
     else
       hipLaunchKernelGGL((k_conv2d_wgrad_s1<2>), grid, dim3(C2_THREADS), 0, st, in, dout, gm, invW, (float *)ws, bws);
@@ -575,7 +594,7 @@ struct Conv2dFwdGeom {
   int tiles_x, tiles_y;
 };
 
-template <int TR, int MTW, bool FULLA>
+template <int TR, int MTW, bool FULLA, bool LP = false>
 __global__ __launch_bounds__(256, 2) void k_conv2d_fwd(const float *__restrict__ in, const unsigned short *__restrict__ Ws,
                                                     const float *__restrict__ bias, Conv2dFwdGeom gm,
                                                     float *__restrict__ out) {
@@ -631,8 +650,10 @@ __global__ __launch_bounds__(256, 2) void k_conv2d_fwd(const float *__restrict__
   _Pragma("unroll") for (int mt = 0; mt < MTW; ++mt) {                                                    \
     const unsigned short *wp = wbase + ((((int64_t)(CH) * 9 + (TAP)) * n_mt + mt) * 3) * 512;           \
     H_[mt] = *(const u32x4 *)(wp);                                                                        \
-    M_[mt] = *(const u32x4 *)(wp + 512);                                                                  \
-    L_[mt] = *(const u32x4 *)(wp + 1024);                                                                 \
+    if constexpr (!LP) {                                                                                  \
+      M_[mt] = *(const u32x4 *)(wp + 512);                                                                \
+      L_[mt] = *(const u32x4 *)(wp + 1024);                                                               \
+    }                                                                                                     \
   }
   if (FULLA) {
 #pragma unroll
@@ -648,8 +669,10 @@ __global__ __launch_bounds__(256, 2) void k_conv2d_fwd(const float *__restrict__
         const Split3 s = split_masked(raw[r], 0xffu);
         unsigned char *dst = lds + tdst[r];
         *(u32x4 *)(dst) = s.h;
-        *(u32x4 *)(dst + 64) = s.m;
-        *(u32x4 *)(dst + 128) = s.l;
+        if constexpr (!LP) {      // LP (bf16 operands, C4): only the round-to-nearest bf16 value of each activation
+          *(u32x4 *)(dst + 64) = s.m;
+          *(u32x4 *)(dst + 128) = s.l;
+        }
       }
     }
     if (chunk + 1 < n_chunks) {
@@ -678,10 +701,13 @@ __global__ __launch_bounds__(256, 2) void k_conv2d_fwd(const float *__restrict__
         for (int nt = 0; nt < NTW; ++nt) {
           const unsigned char *bp = lds + ((wn * NTW + nt + ky) * 18 + li + kx) * C2F_PXB + g * 16;
           bh[nt] = *(const u32x4 *)(bp);
-          bm[nt] = *(const u32x4 *)(bp + 64);
-          bl[nt] = *(const u32x4 *)(bp + 128);
+          if constexpr (!LP) {
+            bm[nt] = *(const u32x4 *)(bp + 64);
+            bl[nt] = *(const u32x4 *)(bp + 128);
+          }
         }
-        // six products per block, smallest first; consecutive MFMAs hit different accumulators
+        // six products per block, smallest first; consecutive MFMAs hit different accumulators (LP: the hh product only)
+        if constexpr (!LP) {
 #pragma unroll
         for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
@@ -702,6 +728,7 @@ __global__ __launch_bounds__(256, 2) void k_conv2d_fwd(const float *__restrict__
         for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
           for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = MFMA_BF16(ah[ia][mt], bm[nt], acc[mt][nt]);
+        }
 #pragma unroll
         for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
@@ -711,7 +738,8 @@ __global__ __launch_bounds__(256, 2) void k_conv2d_fwd(const float *__restrict__
         } else {
 #pragma unroll
           for (int mt = 0; mt < MTW; ++mt) {
-            ah[0][mt] = nh[mt]; am[0][mt] = nm[mt]; al[0][mt] = nl[mt];
+            ah[0][mt] = nh[mt];
+            if constexpr (!LP) { am[0][mt] = nm[mt]; al[0][mt] = nl[mt]; }
           }
         }
       }
@@ -778,8 +806,21 @@ extern "C" int rslo_conv2d_wsplit_many(const RsloConv2dSplitDesc *desc_dev, int 
   return RSLO_OK;
 }
 
+static int conv2d_fwd_launch(const float *in, const void *Ws, const float *bias, int B, int cin, int cout, int H, int W,
+                             float *out, void *stream, bool lp);
+
 extern "C" int rslo_conv2d_fwd(const float *in, const void *Ws, const float *bias, int B, int cin, int cout, int H, int W,
                                float *out, void *stream) {
+  return conv2d_fwd_launch(in, Ws, bias, B, cin, cout, H, W, out, stream, false);
+}
+
+extern "C" int rslo_conv2d_fwd_bf16(const float *in, const void *Ws, const float *bias, int B, int cin, int cout, int H,
+                                    int W, float *out, void *stream) {
+  return conv2d_fwd_launch(in, Ws, bias, B, cin, cout, H, W, out, stream, true);
+}
+
+static int conv2d_fwd_launch(const float *in, const void *Ws, const float *bias, int B, int cin, int cout, int H, int W,
+                             float *out, void *stream, bool lp) {
   int tr, mtw;
   RSLO_CHECK_ARG(conv2d_fwd_plan(B, cin, cout, H, W, &tr, &mtw), "rslo_conv2d_fwd: unsupported shape cin=%d cout=%d H=%d W=%d",
                  cin, cout, H, W);
@@ -790,6 +831,13 @@ extern "C" int rslo_conv2d_fwd(const float *in, const void *Ws, const float *bia
   const dim3 grid((unsigned)(B * gm.tiles_x * gm.tiles_y), (unsigned)(cout / (32 * mtw)));
   hipStream_t st = (hipStream_t)stream;
   const unsigned short *ws = (const unsigned short *)Ws;
+  if (lp) {       // bf16 operands (C4): the default tile configuration only
+    const dim3 grid1((unsigned)(B * gm.tiles_x * (int)rslo_cdiv(H, 4)), (unsigned)(cout / 32));
+    gm.tiles_y = (int)rslo_cdiv(H, 4);
+    hipLaunchKernelGGL((k_conv2d_fwd<4, 1, true, true>), grid1, dim3(256), 0, st, in, ws, bias, gm, out);
+    RSLO_CHECK_LAUNCH("k_conv2d_fwd(bf16)");
+    return RSLO_OK;
+  }
   if (tr == 8 && mtw == 2) hipLaunchKernelGGL((k_conv2d_fwd<8, 2, false>), grid, dim3(256), 0, st, in, ws, bias, gm, out);
   else if (tr == 8) hipLaunchKernelGGL((k_conv2d_fwd<8, 1, false>), grid, dim3(256), 0, st, in, ws, bias, gm, out);
   else if (mtw == 2) hipLaunchKernelGGL((k_conv2d_fwd<4, 2, false>), grid, dim3(256), 0, st, in, ws, bias, gm, out);

@@ -1438,6 +1438,120 @@ __global__ __launch_bounds__(SPC_THREADS) void k_wgrad3(const float *__restrict_
   for (int e = tid; e < CIN_T * COUT_T; e += SPC_THREADS) dst[e] = red[e];
 }
 
+// bf16 feature path (BASELINE config C4): the same pair-list weight gradient with bf16 rows on both sides.  The rows ARE
+// the MFMA operands -- one v_mfma_f32_16x16x32_bf16 per 16x16 block and 32 pairs where k_wgrad3 issues six -- and a
+// gathered row is half the bytes.  Lane (g, li) gathers pairs {4e+g}: CB consecutive input channels (CB*li..) and NB
+// consecutive output channels as 2-byte values; element e of the operand for channel cb is the 16-bit half `cb & 1` of
+// dword `cb >> 1` of pair e's load, so two pairs pack into one operand dword with a single v_perm.  fp32 accumulation,
+// fp32 partials, same deterministic two-stage reduction as the fp32 path.
+template <int N>
+struct VecH;          // N bf16 values as dwords
+template <>
+struct VecH<4> {
+  unsigned v[2];
+};
+template <>
+struct VecH<2> {
+  unsigned v[1];
+};
+template <int N>
+__device__ __forceinline__ VecH<N> load_vech(const unsigned short *p) {
+  VecH<N> r;
+  if constexpr (N == 4) {
+    const uint2 t = *reinterpret_cast<const uint2 *>(p);
+    r.v[0] = t.x;
+    r.v[1] = t.y;
+  } else {
+    r.v[0] = *reinterpret_cast<const unsigned *>(p);
+  }
+  return r;
+}
+// 16-bit half `c & 1` of dword c >> 1 of two loads -> (lo = first, hi = second)
+#define PACK_H(A, B, C) __builtin_amdgcn_perm((B).v[(C) >> 1], (A).v[(C) >> 1], ((C)&1) ? 0x07060302u : 0x05040100u)
+
+template <int CIN_T, int COUT_T>
+__global__ __launch_bounds__(SPC_THREADS) void k_wgrad3_bf16(const unsigned short *__restrict__ in,
+                                                             const unsigned short *__restrict__ dout,
+                                                             const int32_t *__restrict__ pin,
+                                                             const int32_t *__restrict__ pout,
+                                                             const int32_t *__restrict__ koff, int K,
+                                                             float *__restrict__ ws) {
+  constexpr int CB = CIN_T / 16, NB = COUT_T / 16;
+  __shared__ __attribute__((aligned(16))) float red[CIN_T * COUT_T];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int k = blockIdx.y;
+  const int pk0 = koff[k], pk1 = koff[k + 1];
+  const int p0 = pk0 + (int)blockIdx.x * WG2_CHUNK;
+  if (p0 >= pk1) return;
+  const int p1 = (p0 + WG2_CHUNK < pk1) ? p0 + WG2_CHUNK : pk1;
+
+  f32x4 acc[CB][NB];
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[cb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int w0 = p0 + wid * (WG2_CHUNK / SPC_WAVES);
+  const int w1 = (w0 + WG2_CHUNK / SPC_WAVES < p1) ? w0 + WG2_CHUNK / SPC_WAVES : p1;
+  for (int q = w0; q < w1; q += 64) {
+    const int myp = q + lane;
+    const int32_t my_i = (myp < w1) ? pin[myp] : -1;
+    const int32_t my_o = (myp < w1) ? pout[myp] : 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (q + h * 32 >= w1) break;
+      VecH<CB> xa[8];
+      VecH<NB> xb[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int src = h * 32 + 4 * e + g;
+        const int32_t ri = __shfl(my_i, src, 64);
+        const int32_t ro = __shfl(my_o, src, 64);
+        const bool ok = ri >= 0;
+        xa[e] = load_vech<CB>(in + (int64_t)(ok ? ri : 0) * CIN_T + CB * li);
+        xb[e] = load_vech<NB>(dout + (int64_t)ro * COUT_T + NB * li);
+        if (!ok) {
+#pragma unroll
+          for (int d = 0; d < (CB + 1) / 2; ++d) xa[e].v[d] = 0u;
+        }
+      }
+      u32x4 b[NB];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) b[nb][p] = PACK_H(xb[2 * p], xb[2 * p + 1], nb);
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) {
+        u32x4 a;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) a[p] = PACK_H(xa[2 * p], xa[2 * p + 1], cb);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[cb][nb] = MFMA_BF16(a, b[nb], acc[cb][nb]);
+      }
+    }
+  }
+
+  for (int w = 0; w < SPC_WAVES; ++w) {
+    if (wid == w) {
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int ci = CB * (4 * g + j) + cb, co = NB * li + nb;
+            float v = acc[cb][nb][j];
+            if (w) v += red[ci * COUT_T + co];
+            red[ci * COUT_T + co] = v;
+          }
+    }
+    __syncthreads();
+  }
+  float *dst = ws + ((int64_t)blockIdx.x * K + k) * CIN_T * COUT_T;
+  for (int e = tid; e < CIN_T * COUT_T; e += SPC_THREADS) dst[e] = red[e];
+}
+
 // grid (ceil(cc / 256), K [+ 1]): row k < K adds the chunk partials of offset k in chunk order; the optional row K adds
 // the bias-gradient partial rows bpart [n_bpart][cout] in row order (8 independent loads in flight, ordered adds).
 __global__ void k_wgrad2_reduce(const float *__restrict__ ws, const int32_t *__restrict__ koff, int K, int cc,
@@ -1604,6 +1718,41 @@ extern "C" int rslo_spconv_wgrad_pairs(const float *in, int cin, const float *do
   return RSLO_OK;
 }
 
+extern "C" int rslo_spconv_wgrad_pairs_bf16(const void *in, int cin, const void *dout, int cout,
+                                            const int32_t *pairs_in, const int32_t *pairs_out, const int32_t *koff,
+                                            int64_t n_out, int K, void *ws, size_t ws_bytes, float *dW, float *dbias,
+                                            const float *bias_partial, int n_bias_partial, void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  RSLO_CHECK_ARG((cin == 32 || cin == 64) && (cout == 32 || cout == 64), "wgrad_pairs_bf16: channels must be 32 or 64");
+  RSLO_CHECK_ARG(K >= 1 && K <= SPC_MAXK, "wgrad_pairs_bf16: K must be in 1..27");
+  RSLO_CHECK_ARG(!dbias || bias_partial, "wgrad_pairs_bf16: the bias gradient needs the column partials of "
+                                         "rslo_leaky_bwd_colsum_bf16");
+  const int64_t nW = (int64_t)K * cin * cout;
+  if (n_out == 0) {
+    RSLO_HIP(hipMemsetAsync(dW, 0, nW * sizeof(float), st));
+    if (dbias) RSLO_HIP(hipMemsetAsync(dbias, 0, cout * sizeof(float), st));
+    return RSLO_OK;
+  }
+  if (ws_bytes < rslo_spconv_wgrad_pairs_ws_bytes(n_out, K, cin, cout)) {
+    rslo_set_error("wgrad_pairs_bf16: workspace too small");
+    return RSLO_EWS;
+  }
+  const int nch = (int)rslo_cdiv(n_out, WG2_CHUNK);
+  dim3 grid((unsigned)nch, (unsigned)K);
+  const unsigned short *x = (const unsigned short *)in, *g = (const unsigned short *)dout;
+#define WG3B_CASE(CI, CO)                                                                                      \
+  if (cin == CI && cout == CO)                                                                                 \
+    hipLaunchKernelGGL((k_wgrad3_bf16<CI, CO>), grid, dim3(SPC_THREADS), 0, st, x, g, pairs_in, pairs_out, koff, K, \
+                       (float *)ws);
+  WG3B_CASE(32, 32) WG3B_CASE(32, 64) WG3B_CASE(64, 32) WG3B_CASE(64, 64)
+#undef WG3B_CASE
+  const int cc = cin * cout;
+  hipLaunchKernelGGL(k_wgrad2_reduce, dim3((unsigned)rslo_cdiv(cc, 32), (unsigned)(K + (dbias ? 1 : 0))), dim3(256), 0, st,
+                     (const float *)ws, koff, K, cc, dW, bias_partial, dbias ? n_bias_partial : 0, cout, dbias);
+  RSLO_CHECK_LAUNCH("wgrad_pairs_bf16");
+  return RSLO_OK;
+}
+
 __global__ void k_leaky_bwd(const float *__restrict__ y, const float *__restrict__ dout, int64_t n,
                             float slope, float *__restrict__ g) {
   int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
@@ -1651,6 +1800,66 @@ __global__ __launch_bounds__(256) void k_leaky_bwd_colsum(const float *__restric
     for (int p = threadIdx.x; p < 1024; p += cols) t += red[p];
     partial[(int64_t)blockIdx.x * cols + threadIdx.x] = t;
   }
+}
+
+// bf16 rows: g = dout * act'(y) written in bf16 (round to nearest), column sums accumulated in fp32 from the ROUNDED g --
+// the values the weight-gradient kernel multiplies.  A block owns LB_TILES tiles of 2048 consecutive values (8 per
+// thread); 2048 % cols == 0.
+__global__ __launch_bounds__(256) void k_leaky_bwd_colsum_bf16(const unsigned short *__restrict__ y,
+                                                               const unsigned short *__restrict__ dout, int64_t n,
+                                                               int cols, float slope, unsigned short *__restrict__ g,
+                                                               float *__restrict__ partial) {
+  __shared__ float red[2048];
+  const int64_t base = (int64_t)blockIdx.x * (2048 * LB_TILES) + 8 * threadIdx.x;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < LB_TILES; ++t) {
+    const int64_t i = base + (int64_t)t * 2048;
+    if (i < n) {               // n % 8 == 0 (cols % 8 == 0)
+      const uint4 yv = *reinterpret_cast<const uint4 *>(y + i);
+      const uint4 dv = *reinterpret_cast<const uint4 *>(dout + i);
+      const unsigned yw[4] = {yv.x, yv.y, yv.z, yv.w}, dw[4] = {dv.x, dv.y, dv.z, dv.w};
+      unsigned ow[4];
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        float g0 = __uint_as_float(dw[d] << 16), g1 = __uint_as_float(dw[d] & 0xffff0000u);
+        // bf16 sign bit: y > 0  <=>  not negative and not zero
+        const bool p0 = (yw[d] & 0x8000u) == 0 && (yw[d] & 0x7fffu) != 0;
+        const bool p1 = (yw[d] & 0x80000000u) == 0 && (yw[d] & 0x7fff0000u) != 0;
+        g0 = p0 ? g0 : g0 * slope;
+        g1 = p1 ? g1 : g1 * slope;
+        ow[d] = rslo_pk_bf16_rn(g0, g1);
+        s[2 * d] += __uint_as_float(ow[d] << 16);
+        s[2 * d + 1] += __uint_as_float(ow[d] & 0xffff0000u);
+      }
+      *reinterpret_cast<uint4 *>(g + i) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) red[8 * threadIdx.x + k] = s[k];
+  __syncthreads();
+  if (partial && (int)threadIdx.x < cols) {
+    float t = 0.f;
+    for (int p = threadIdx.x; p < 2048; p += cols) t += red[p];
+    partial[(int64_t)blockIdx.x * cols + threadIdx.x] = t;
+  }
+}
+
+extern "C" int64_t rslo_leaky_bwd_colsum_bf16_blocks(int64_t rows, int cols) {
+  return rslo_cdiv(rows * cols > 0 ? rows * cols : 1, 2048 * LB_TILES);
+}
+
+extern "C" int rslo_leaky_bwd_colsum_bf16(const void *y, const void *dout, int64_t rows, int cols, float slope, void *g,
+                                          float *partial /*[blocks, cols] or NULL*/, void *stream) {
+  RSLO_CHECK_ARG(y && dout && g, "rslo_leaky_bwd_colsum_bf16: bad arguments");
+  RSLO_CHECK_ARG(cols >= 8 && cols <= 256 && 2048 % cols == 0, "rslo_leaky_bwd_colsum_bf16: cols must divide 2048");
+  if (rows == 0) return RSLO_OK;
+  const int64_t nblk = rslo_leaky_bwd_colsum_bf16_blocks(rows, cols);
+  hipLaunchKernelGGL(k_leaky_bwd_colsum_bf16, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
+                     (const unsigned short *)y, (const unsigned short *)dout, rows * cols, cols, slope, (unsigned short *)g,
+                     partial);
+  RSLO_CHECK_LAUNCH("leaky_bwd_colsum_bf16");
+  return RSLO_OK;
 }
 
 extern "C" int64_t rslo_leaky_bwd_colsum_blocks(int64_t rows, int cols) {

@@ -28,6 +28,8 @@ class _Conv3x3Fn(torch.autograd.Function):
         ctx.has_bias = bias is not None
         ctx.hip_fd = hip_fd
         ctx.ws_t = None
+        from rslo_amd import precision
+        ctx.lp = lp = precision.low_precision() is not None      # C4: bf16 operands, fp32 accumulate / storage
         if hip_fd:
             from rslo_amd import capi
             ws = getattr(w, "_hip_split", None)      # operands refreshed for all layers in one launch (presplit())
@@ -36,7 +38,8 @@ class _Conv3x3Fn(torch.autograd.Function):
             if "d" in HIP_PASSES:
                 ctx.ws_t = ws[1] if ws is not None else capi.conv2d_wsplit(w, True)
             if "f" in HIP_PASSES:
-                return capi.conv2d_fwd(x, ws[0] if ws is not None else capi.conv2d_wsplit(w, False), bias, w.shape[0])
+                return capi.conv2d_fwd(x, ws[0] if ws is not None else capi.conv2d_wsplit(w, False), bias, w.shape[0],
+                                       lp=lp)
         return F.conv2d(x, w, bias, stride, 1)
 
     @staticmethod
@@ -48,17 +51,17 @@ class _Conv3x3Fn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             if ctx.ws_t is not None:
-                dx = capi.conv2d_fwd(dy, ctx.ws_t, None, w.shape[1])
+                dx = capi.conv2d_fwd(dy, ctx.ws_t, None, w.shape[1], lp=ctx.lp)
             else:
                 dx = torch.ops.aten.convolution_backward(dy, x, w, None, [s, s], [1, 1], [1, 1], False, [0, 0], 1,
                                                          [True, False, False])[0]
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             if ctx.hip_w and want_db and s == 1:
-                dw, db = capi.conv2d_wgrad(x, dy, s, want_bias=True)     # bias gradient from the same pass
+                dw, db = capi.conv2d_wgrad(x, dy, s, want_bias=True, lp=ctx.lp)     # bias gradient from the same pass
                 want_db = False
             elif ctx.hip_w:
-                dw = capi.conv2d_wgrad(x, dy, s)
+                dw = capi.conv2d_wgrad(x, dy, s, lp=ctx.lp)
             else:
                 dw = torch.ops.aten.convolution_backward(dy, x, w, None, [s, s], [1, 1], [1, 1], False, [0, 0], 1,
                                                          [False, True, False])[1]

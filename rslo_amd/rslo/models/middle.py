@@ -89,6 +89,11 @@ class SpMiddleFHDWithCov2_3(nn.Module):
             SubMConv3d(16, 7, 3, indice_key="dsubm1"),
         )
         self.max_batch_size = 6
+        # under apex.amp O1 (C4) the trunk's 32/64-channel layers run on bf16 rows; the covariance branch -- whose
+        # output enters matrix inverses / log-determinants in the loss -- stays fp32
+        for m in self.middle_cov_deconv.modules():
+            if isinstance(m, spconv.SparseConvolution):
+                m.allow_low_precision = False
 
     def plan(self, coors, batch_size, with_pairs=False):
         """Every rulebook of the encoder for these coordinates, without touching features: returns the planned

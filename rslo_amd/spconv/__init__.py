@@ -125,7 +125,8 @@ class SparseConvTensor:
         return offs
 
     def dense(self, channels_first=True):
-        out = _DenseFn.apply(self.features, self.site_index().coords, self.batch_size, tuple(self.spatial_shape))
+        feats = self.features if self.features.dtype == torch.float32 else self.features.float()   # bf16 trunk (C4)
+        out = _DenseFn.apply(feats, self.site_index().coords, self.batch_size, tuple(self.spatial_shape))
         if not channels_first:
             out = out.permute(0, 2, 3, 4, 1).contiguous()
         return out
@@ -233,6 +234,54 @@ class _SparseConvFn(torch.autograd.Function):
         return gx, gw, gb, None, None, None, None, None, None
 
 
+class _SparseConvBf16Fn(torch.autograd.Function):
+    """C4 (bf16 features, int32 rulebook, fp32 accumulate): rows in / out are bfloat16, weights and bias fp32 masters
+    rounded to bf16 operands per call; forward = rslo_spconv_fwd_bf16, data gradient = the same kernel on the transposed
+    operand, activation backward + bias partials = rslo_leaky_bwd_colsum_bf16, weight gradient =
+    rslo_spconv_wgrad_pairs_bf16 (fp32 dW / dbias).  Channel counts 32 / 64 on both sides."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, nbr, nbrT, subm, slope, rb, inverse):
+        ctx.rb, ctx.inverse = rb, inverse
+        K = nbr.shape[1]
+        cin, cout = weight.shape[-2], weight.shape[-1]
+        W3 = weight.reshape(K, cin, cout)
+        x = x.contiguous()
+        fwd_key, bwd_key = ("nbrT", "nbr") if inverse else ("nbr", "nbr_flip" if subm else "nbrT")
+        ctx.bwd_key = bwd_key
+        y = capi.spconv_fwd_bf16(x, W3, bias, nbr, act_slope=slope, order=rb.order(fwd_key))
+        ctx.save_for_backward(x, weight, y if slope != 1.0 else None, nbr, nbrT)
+        ctx.meta = (subm, slope, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, y, nbr, nbrT = ctx.saved_tensors
+        subm, slope, has_bias = ctx.meta
+        K = nbr.shape[1]
+        cin, cout = weight.shape[-2], weight.shape[-1]
+        W3 = weight.reshape(K, cin, cout)
+        g = gy.contiguous()
+        want_b = has_bias and ctx.needs_input_grad[2]
+        part = None
+        if slope != 1.0:
+            g = capi.leaky_bwd_bf16(y, g, slope, colsum=want_b)
+            if want_b:
+                g, part = g
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            table, flip = (nbr, True) if subm else (nbrT, False)
+            gx = capi.spconv_fwd_bf16(g, W3, None, table, flip_k=flip, transpose=True, order=ctx.rb.order(ctx.bwd_key))
+        if ctx.needs_input_grad[1] or want_b:
+            pin, pout, koff = ctx.rb.pairs()
+            pairs = (pout, pin, koff) if ctx.inverse else (pin, pout, koff)
+            gw, gb = capi.spconv_wgrad_pairs_bf16(x, g, pairs, g.shape[0], K, cin, cout, bias_partial=part)
+            if want_b and gb is None:         # layer without activation: column sums of the bf16 gradient in fp32
+                gb = g.float().sum(0)
+            gw = gw.reshape(weight.shape)
+        return gx, gw, gb, None, None, None, None, None, None
+
+
 class _SegBNActFn(torch.autograd.Function):
     """Per-frame BatchNorm1d (training statistics) + LeakyReLU through rslo_segbn_fwd / _bwd."""
 
@@ -260,7 +309,8 @@ def _segmented_bn_act(x, bn, slope):
     dev_off = index.batch_offs_dev
     S = x.batch_size
     max_len = max(offs[b + 1] - offs[b] for b in range(S))
-    y = _SegBNActFn.apply(x.features, bn.weight, bn.bias, bn, dev_off, S, max_len, slope)
+    feats = x.features if x.features.dtype == torch.float32 else x.features.float()
+    y = _SegBNActFn.apply(feats, bn.weight, bn.bias, bn, dev_off, S, max_len, slope)
     if bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(sum(1 for b in range(S) if offs[b + 1] > offs[b]))
     return x._like(y)
@@ -340,16 +390,33 @@ class SparseConvolution(SparseModule):
             return x._like(None)
         return x._like(None, rb.out_index.coords, rb.out_index.dims, rb.out_index)
 
+    allow_low_precision = True      # False keeps a layer fp32 under amp O1 (the covariance branch)
+
+    def _low_precision(self, feats):
+        """C4: the 32/64-channel layers take bf16 rows when apex.amp O1 is on (rslo_amd.precision)."""
+        from rslo_amd import precision
+        return (precision.low_precision() is not None and self.allow_low_precision and feats.is_cuda
+                and self.in_channels in (32, 64) and self.out_channels in (32, 64))
+
     def forward(self, x, act_slope=1.0):
         assert isinstance(x, SparseConvTensor)
         rb = self._rulebook(x)
+        feats = x.features
+        if self._low_precision(feats):
+            fn = _SparseConvBf16Fn
+            if feats.dtype != torch.bfloat16:
+                feats = feats.to(torch.bfloat16)      # entering the bf16 trunk (differentiable cast)
+        else:
+            fn = _SparseConvFn
+            if feats.dtype != self.weight.dtype:
+                feats = feats.to(self.weight.dtype)   # leaving it (fp32 layers: 16-channel levels, covariance branch)
         if self.inverse:      # output sites = the saved INPUT sites of the forward twin, same order
-            y = _SparseConvFn.apply(x.features, self.weight, self.bias, rb.nbrT, rb.nbr, False, act_slope, rb, True)
+            y = fn.apply(feats, self.weight, self.bias, rb.nbrT, rb.nbr, False, act_slope, rb, True)
             return x._like(y, rb.in_index.coords, rb.in_index.dims, rb.in_index)
         if self.subm:
-            y = _SparseConvFn.apply(x.features, self.weight, self.bias, rb.nbr, None, True, act_slope, rb, False)
+            y = fn.apply(feats, self.weight, self.bias, rb.nbr, None, True, act_slope, rb, False)
             return x._like(y)
-        y = _SparseConvFn.apply(x.features, self.weight, self.bias, rb.nbr, rb.nbrT, False, act_slope, rb, False)
+        y = fn.apply(feats, self.weight, self.bias, rb.nbr, rb.nbrT, False, act_slope, rb, False)
         return x._like(y, rb.out_index.coords, rb.out_index.dims, rb.out_index)
 
 

@@ -646,6 +646,59 @@ def test_bf16_feature_conv_matches_oracle_on_rounded_operands(hip, cin, cout):
     assert gx.shape == (len(coords), cin) and float((err / (np.abs(go) + 1e-2)).max()) < 2.0 ** -8 + 1e-3
 
 
+@pytest.mark.parametrize("cin,cout", [(64, 64), (32, 64), (64, 32), (32, 32)])
+def test_bf16_backward_kernels_match_oracle_on_rounded_operands(hip, cin, cout):
+    """C4 backward of a sparse layer on bf16 rows: rslo_leaky_bwd_colsum_bf16 (g bit-exact vs the round-to-nearest
+    bf16 of the fp32 formula, column partials = fp32 sums of the ROUNDED g) and rslo_spconv_wgrad_pairs_bf16 (products of
+    bf16 values are exact in fp32, fp32 accumulation: 2e-5 of the largest entry vs the double-precision oracle on the
+    same rounded operands; bias gradient from the partials)."""
+    rng = np.random.default_rng(cin * 5 + cout)
+    dims, B = [9, 30, 28], 2
+    coords = rand_sites(rng, B, dims, 5000)
+    nbr = O.rulebook_subm(coords, B, dims)
+    n = len(coords)
+    bf = lambda a: torch.from_numpy(a).to(torch.bfloat16)             # RNE
+    x = bf(rng.normal(size=(n, cin)).astype(np.float32))
+    y = bf(rng.normal(size=(n, cout)).astype(np.float32))
+    y[::7] = 0.0                                                       # exact zeros take the slope branch (y > 0 false)
+    gy = bf(rng.normal(size=(n, cout)).astype(np.float32))
+    g, part = hip.leaky_bwd_bf16(y.cuda(), gy.cuda(), 0.01, colsum=True)
+    g_ref = torch.where(y.float() > 0, gy.float(), gy.float() * 0.01).to(torch.bfloat16)
+    assert g.dtype == torch.bfloat16 and torch.equal(g.cpu(), g_ref)
+    np.testing.assert_allclose(part.sum(0).cpu().numpy(), g_ref.float().double().sum(0).numpy(), rtol=1e-4, atol=1e-3)
+    pairs = hip.rulebook_pairs(dev(nbr))
+    dW, db = hip.spconv_wgrad_pairs_bf16(x.cuda(), g, pairs, n, 27, cin, cout, bias_partial=part)
+    oW, ob = O.spconv_wgrad(x.float().numpy(), g_ref.float().numpy(), nbr, cin, cout)
+    assert np.abs(dW.cpu().numpy() - oW).max() <= 2e-5 * np.abs(oW).max()
+    np.testing.assert_allclose(db.cpu().numpy(), ob, rtol=1e-4, atol=1e-3)
+    dW2, db2 = hip.spconv_wgrad_pairs_bf16(x.cuda(), g, pairs, n, 27, cin, cout)      # no bias requested
+    assert db2 is None and torch.equal(dW2, dW)
+
+
+@pytest.mark.parametrize("B,cin,cout,H,W", [(2, 32, 64, 12, 22), (1, 64, 64, 96, 176), (2, 96, 64, 25, 23)])
+def test_conv2d_bf16_operand_mode_matches_float64_on_rounded_operands(hip, B, cin, cout, H, W):
+    """C4 dense head: rslo_conv2d_fwd_bf16 / rslo_conv2d_wgrad_bf16 = the product of the round-to-nearest bf16 values of
+    both operands with fp32 accumulation -> 2e-5 of the largest entry vs float64 on the SAME rounded operands (forward
+    with bias, data gradient, weight + bias gradient)."""
+    rng = np.random.default_rng(B + cin + H)
+    r16 = lambda a: torch.from_numpy(a).to(torch.bfloat16).float().numpy()
+    x = rng.standard_normal((B, cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(9 * cin)).astype(np.float32)
+    bias = rng.standard_normal(cout).astype(np.float32)
+    g = rng.standard_normal((B, cout, H, W)).astype(np.float32)
+    y = hip.conv2d_fwd(dev(x), hip.conv2d_wsplit(dev(w), False), dev(bias), cout, lp=True).cpu().numpy()
+    dx = hip.conv2d_fwd(dev(g), hip.conv2d_wsplit(dev(w), True), None, cin, lp=True).cpu().numpy()
+    dw, db = hip.conv2d_wgrad(dev(x), dev(g), 1, want_bias=True, lp=True)
+    ry, rdx = O.conv2d_fwd(r16(x), r16(w), bias), O.conv2d_dgrad(r16(g), r16(w))
+    rdw = O.conv2d_wgrad(r16(x), r16(g))
+    for got, ref in ((y, ry), (dx, rdx), (dw.cpu().numpy(), rdw)):
+        assert np.abs(got - ref).max() <= 2e-5 * np.abs(ref).max()
+    np.testing.assert_allclose(db.cpu().numpy(), g.astype(np.float64).sum((0, 2, 3)), rtol=1e-5, atol=1e-3)   # fp32 sum of dout
+    # and it really is the low-precision product: differs from the fp32-accurate path at the bf16 level
+    y32 = hip.conv2d_fwd(dev(x), hip.conv2d_wsplit(dev(w), False), dev(bias), cout).cpu().numpy()
+    assert 1e-4 < np.abs(y - y32).max() / np.abs(y32).max() < 3e-2
+
+
 def test_roi_threshold_radix_select_is_exact(hip):
     """rslo_roi_threshold == sort-based k-th value (bit-exact), ragged counts, duplicates, +inf padding, tiny rows."""
     from rslo.core import losses

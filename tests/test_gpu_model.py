@@ -296,6 +296,58 @@ def test_c3_full_size_step_matches_cpu_oracle(hip):
     check_three_way(net, ex, median_bar=5e-3, max_bar=5e-2, ratio_bar=2.0)
 
 
+def test_amp_o1_bf16_step_tracks_the_fp32_step(hip):
+    """BASELINE config C4, per-GPU part: apex.amp.initialize(..., "O1") switches the 32/64-channel encoder trunk to
+    bf16 rows and the dense 3x3 convolutions of the head to bf16 operands (fp32 accumulation, fp32 master weights; the
+    covariance branch, BatchNorm, vote and the loss stay fp32).  Stated tolerance against the fp32 step on the same
+    inputs and weights: pose 2e-2 of the largest component, loss terms 5e-2, and every parameter gradient that is not
+    analytically zero points the same way (cosine to the fp32 gradient: median > 0.9, every tensor > 0.6; measured
+    median 0.957, minimum 0.80 -- the consistency loss turns a 1e-3 pose change into a visible change of direction, see
+    check_three_way).  bf16 carries 8 significant bits; the kernels themselves are pinned on rounded operands in
+    test_gpu_kernels.py."""
+    from apex import amp
+    from rslo_amd import precision
+    torch.manual_seed(7)
+    net, _ = workload.build_network()
+    net.train()
+    net.global_step.fill_(2000)
+    trained_like_init(net)
+    ex = workload.make_example(net, [list(reduced_pair(1)[:2])])
+    net16 = copy.deepcopy(net)
+    ret = net(ex)
+    ret["loss"].backward()
+    opt = torch.optim.SGD(net16.parameters(), lr=0.0)
+    try:
+        net16, opt = amp.initialize(net16, opt, opt_level="O1")
+        assert precision.low_precision() is torch.bfloat16 and amp.state_dict()["loss_scale"] == 1.0
+        seen = {}
+        net16.middle_feature_extractor.middle_conv_tail[0].register_forward_hook(
+            lambda m, i, o: seen.update(trunk=o.features.dtype))
+        net16.middle_feature_extractor.middle_cov_deconv[0].register_forward_hook(
+            lambda m, i, o: seen.update(cov=o.features.dtype))
+        ret16 = net16(ex)
+        with amp.scale_loss(ret16["loss"], opt) as scaled:
+            assert scaled is ret16["loss"]
+            scaled.backward()
+    finally:
+        amp.initialize(net16, opt, opt_level="O0")
+    assert precision.low_precision() is None
+    assert seen == {"trunk": torch.bfloat16, "cov": torch.float32}
+    for k in ("translation_preds", "rotation_preds"):
+        assert ret16[k].dtype == torch.float32 and rel(ret16[k], ret[k]) < 2e-2, k
+    for k in ("loss", "translation_loss", "pyramid_loss", "C_loss"):
+        assert rel(ret16[k], ret[k]) < 5e-2, k
+    cos = []
+    skip = bias_before_bn(net)
+    for (n, p), (_, q) in zip(net.named_parameters(), net16.named_parameters()):
+        if n in skip or p.grad is None or float(p.grad.abs().max()) < 1e-6:
+            continue
+        assert q.grad is not None and q.grad.dtype == torch.float32, n
+        cos.append(float(torch.nn.functional.cosine_similarity(p.grad.flatten().double(), q.grad.flatten().double(), dim=0)))
+    cos = np.array(cos)
+    assert len(cos) >= 170 and np.median(cos) > 0.9 and cos.min() > 0.6, (np.median(cos), cos.min())
+
+
 def test_eval_forward_sees_weights_written_through_data(hip):
     """In-place writes through `.data` do not bump a parameter's version counter; the cached split-bf16 operands of
     the sparse convolutions must not survive them."""
