@@ -2,7 +2,10 @@
 (reference: rslo/layers/SparseConv.py:96-132,195-220): they act on the feature tensor and pass the
 mask through untouched."""
 import apex
+import torch
 import torch.nn as nn
+
+from rslo.layers.normalization import MaskSyncBatchNorm, SemiGlobalSyncBatchNorm
 
 
 def _pair(fn, x):
@@ -39,6 +42,33 @@ class SPC_SyncBN2d(apex.parallel.SyncBatchNorm):
         return y
 
 
+class SPC_MaskSyncBN2d(MaskSyncBatchNorm):
+    """(reference: rslo/layers/SparseConv.py:22-58) statistics over the occupied cells; output re-masked."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True, process_group=None,
+                 channel_last=False, fuse_relu=False, noise_scale_std=0, noise_shift_std=0):
+        super().__init__(num_features, eps, momentum, affine, track_running_stats, process_group, channel_last)
+        assert noise_scale_std == 0 and noise_shift_std == 0, "BN noise is not used by the RSLO configurations"
+
+    def forward(self, x):
+        pair = isinstance(x, (tuple, list))
+        tensor, mask = x if pair else (x, (x.abs().sum(dim=1, keepdim=True) > 0).float().detach())
+        y = super().forward([tensor, mask]) * mask
+        return [y, mask] if pair else y
+
+
+class SPC_SemiGlobalSyncBN2d(SemiGlobalSyncBatchNorm):
+    """(reference: rslo/layers/SparseConv.py:60-94)"""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True, process_group=None,
+                 channel_last=False, fuse_relu=False, noise_scale_std=0, noise_shift_std=0):
+        super().__init__(num_features, eps, momentum, affine, track_running_stats, process_group, channel_last)
+        assert noise_scale_std == 0 and noise_shift_std == 0, "BN noise is not used by the RSLO configurations"
+
+    def forward(self, x):
+        return _pair(super().forward, x)
+
+
 class SPC_BN2d(nn.BatchNorm2d):
     def forward(self, x):
         return _pair(super().forward, x)
@@ -61,6 +91,51 @@ def act_slope_of(m):
     if isinstance(m, nn.ReLU):
         return 0.0
     return None
+
+
+class SparseConv(nn.Module):
+    """2-D mask-normalised convolution (reference: rslo/layers/SparseConv.py:222-302; conv_type "sparse_conv", not the
+    shipped "mask_conv"): y = conv(x * m) / conv_ones(m) + b where the window holds any mask weight (0 elsewhere), and
+    the mask is max-pooled (max_pool_mask) or sum-pooled and renormalised by the per-sample maximum of the INPUT mask.
+    A (feature, mask) pair goes in and comes out; a bare tensor gets the mask `sum over channels != 0`."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, padding=0, bias=True, max_pool_mask=True,
+                 **kwargs):
+        super().__init__()
+        assert kernel_size % 2 == 1
+        self.out_channels, self.use_bias, self.max_pool_mask = out_channels, bias, max_pool_mask
+        self.conv1 = nn.Conv2d(in_channels, out_channels, kernel_size=kernel_size, stride=stride, bias=False,
+                               padding=padding)
+        self.sum_conv = nn.Conv2d(1, 1, kernel_size, stride, bias=False, padding=padding)
+        self.sum_conv.weight.requires_grad_(False)
+        nn.init.constant_(self.sum_conv.weight, 1)
+        if max_pool_mask:
+            self.mask_pool = nn.MaxPool2d(kernel_size, stride=stride, padding=padding)
+        else:
+            self.mask_pool = nn.Conv2d(1, 1, kernel_size, stride, bias=False, padding=padding)
+            self.mask_pool.weight.requires_grad_(False)
+            nn.init.constant_(self.mask_pool.weight, 1)
+        self.b = nn.ParameterList([nn.Parameter(torch.zeros(out_channels, 1, 1))]) if bias else [0]
+
+    def sparse_conv(self, tensor, mask):
+        if mask is None:
+            mask = torch.ones_like(tensor[:, :1])
+        mask = mask.detach()
+        features = self.conv1(tensor * mask)
+        norm = self.sum_conv(mask)
+        norm = torch.where(norm == 0, torch.zeros_like(norm), 1.0 / (norm + 1e-12))
+        feature = features * norm + self.b[0]
+        if self.max_pool_mask:
+            mask = self.mask_pool(mask)
+        else:
+            top = mask.reshape(mask.shape[0], -1).max(dim=-1)[0].view(-1, 1, 1, 1)
+            mask = self.mask_pool(mask) / top
+        return [feature, mask.detach()]
+
+    def forward(self, x):
+        if not isinstance(x, (list, tuple)):
+            x = [x, (torch.sum(x, dim=1, keepdim=True) != 0).float()]
+        return self.sparse_conv(x[0], x[1])
 
 
 class FusedSequential(nn.Sequential):

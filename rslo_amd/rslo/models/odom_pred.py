@@ -59,9 +59,7 @@ class UNOdomPredEncDecSVDTempMaskBase(OdomPredEncDecBase):
         # The MaskConv encoder carries an occupancy mask next to the features (max-pooled per conv, averaged at every
         # residual add); nothing in this head ever reads it (only x[0] leaves the encoder), so by default it is not
         # propagated: ~80 small launches per step that cannot change any output.  True restores the propagation.
-        self.track_masks = False
-        if use_svd:
-            raise NotImplementedError("use_svd=True vote is a 'next' row (SURVEY.md 8f-4)")
+        self.track_masks = getattr(self, "_bn_type", None) == "MaskSyncBN"      # that variant reads the masks
         nuf = list(kwargs.get("num_upsample_filters"))
         conf_type = kwargs.get("conf_type")
         motion, tconf, qconf = [], [], []
@@ -138,6 +136,8 @@ class UNOdomPredEncDecSVDTempMaskBase(OdomPredEncDecBase):
         t_conf, t_logit = self.t_map_conf(x_tail, extra_mask=input_mask, return_logit=True, outside=outside)
         r_conf, r_logit = self.q_map_conf(x_tail, extra_mask=input_mask, return_logit=True, outside=outside)
         tq_map_g, odom = self.vote(tq_map, t_conf, r_conf)
+        if self.use_svd:        # rigid fit over the occupied cells instead of the confidence-weighted mean
+            odom = self.vote_svd(tq_map, input_mask_bool, t_conf)
         odoms = [odom]
 
         with torch.no_grad():   # temperature-20 confidences -> loss masks
@@ -150,10 +150,15 @@ class UNOdomPredEncDecSVDTempMaskBase(OdomPredEncDecBase):
 
         translations, rotations = [], []
         for o in odoms:
-            t, r = o.split([3, 4], dim=1)
+            t, r = o[:, :3], o[:, 3:]
             if self.odom_format == "r(x+t)":
                 t = rotate_vec_by_q(t, r)
-            r = r / (torch.norm(r, dim=1, keepdim=True) + 1e-12)
+            if r.shape[-1] == 4:
+                r = r / (torch.norm(r, dim=1, keepdim=True) + 1e-12)
+            elif not self.training:     # use_svd: a rotation matrix in training, a (w, x, y, z) quaternion in eval
+                import kornia
+                q = kornia.rotation_matrix_to_quaternion(r.reshape(-1, 3, 3).contiguous())
+                r = torch.cat([q[..., 3:], q[..., :3]], dim=-1)
             translations.append(t)
             rotations.append(r)
         return {"translation_preds": translations, "rotation_preds": rotations, "tq_map_g": tq_map_g * input_mask,
@@ -213,8 +218,25 @@ class UNOdomPredEncDecSVDTempMaskBase(OdomPredEncDecBase):
         q = (tq_map_g[:, 3:] * r_conf).sum(dim=(2, 3)) / (r_conf.sum(dim=(2, 3)) + 1e-12)
         return tq_map_g, torch.cat([t, q], dim=-1)
 
+    def vote_svd(self, tq_map, selected_mask, t_conf):
+        """use_svd = True (odom_pred.py:319-346): the per-cell translations are read as a scene flow and ONE rigid
+        motion per sample is fitted to (cell anchor x, x - flow) over the occupied cells by the weighted Kabsch of
+        SVDHead, weights = translation confidences.  Returns [B, 12] = (t, R row-major), like the reference.  All samples
+        in one batched solve (the reference loops over the batch and gathers the selected cells; here the selection is a
+        0/1 factor in the centroids and the cross-covariance: same sums)."""
+        from rslo.core.losses import masked_kabsch
+        from rslo.utils.geometric import gen_voxel_3d_coords
+        B = tq_map.shape[0]
+        xyz = gen_voxel_3d_coords(tq_map, self.point_cloud_range, format="B3HW").permute(0, 2, 3, 1).reshape(B, -1, 3)
+        flow = tq_map[:, :3].permute(0, 2, 3, 1).reshape(B, -1, 3)
+        sel = selected_mask.reshape(B, -1).bool()
+        R, t = masked_kabsch(xyz, xyz - flow, t_conf.reshape(B, -1), sel)
+        return torch.cat([t, R.reshape(B, 9)], dim=1)
+
     def aggregate_tq(self, tq_maps, selected_masks, t_confs, r_confs):
         assert len(tq_maps) == len(selected_masks) == len(t_confs) == len(r_confs)
+        if self.use_svd:
+            return [self.vote_svd(m, sm, tc) for m, sm, tc in zip(tq_maps, selected_masks, t_confs)]
         return [self.vote(m, tc, rc)[1] for m, tc, rc in zip(tq_maps, t_confs, r_confs)]
 
 

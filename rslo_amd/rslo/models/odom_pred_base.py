@@ -13,7 +13,8 @@ from rslo.layers.common import ParameterLayer
 from rslo.layers.confidence import ConfidenceModule
 from rslo.layers.hip_conv2d import Conv2d
 from rslo.layers.MaskConv import MaskConv, MaskConvTranspose2d
-from rslo.layers.SparseConv import SPC_BN2d, SPC_LeakyReLU, SPC_ReLU, SPC_SyncBN2d, FusedSequential
+from rslo.layers.SparseConv import (SPC_BN2d, SPC_LeakyReLU, SPC_MaskSyncBN2d, SPC_ReLU, SPC_SemiGlobalSyncBN2d,
+                                    SPC_SyncBN2d, FusedSequential)
 from torchplus.nn import Empty
 from torchplus.tools import change_default_args
 
@@ -43,7 +44,7 @@ class OdomPredEncDecBase(nn.Module):
         assert conf_type in ["linear", "softmax"]
         if conv_type != "mask_conv":
             raise NotImplementedError("only conv_type='mask_conv' is on the RSLO hot path")
-        if bn_type not in ("None", "BN", "SyncBN") or use_groupnorm:
+        if bn_type == "IN" or use_groupnorm:
             raise NotImplementedError("bn_type %r is outside the RSLO hot path" % bn_type)
         if use_dynamic_mask or use_correlation or dropout_input or use_SPGN or use_se or use_sa:
             raise NotImplementedError("option outside the shipped RSLO configuration")
@@ -63,6 +64,7 @@ class OdomPredEncDecBase(nn.Module):
         self._first_conv_groups = first_conv_groups
         self.use_se = self.use_sa = False
         self.use_svd = use_svd
+        self._bn_type = bn_type
         self._use_correlation = False
         self._enc_use_norm = enc_use_norm
         self._cycle_constraint = cycle_constraint
@@ -74,7 +76,12 @@ class OdomPredEncDecBase(nn.Module):
         if bn_type == "None":
             self.BatchNorm2d = Empty
         else:
-            base = SPC_SyncBN2d if (bn_type == "SyncBN" or sync_bn) else SPC_BN2d
+            # SyncBN is the shipped choice (fused kernels); the two statistics variants of the registry
+            # (odom_pred_base.py:113-131) run on plain torch ops
+            base = {"SemiGlobalSyncBN": SPC_SemiGlobalSyncBN2d, "MaskSyncBN": SPC_MaskSyncBN2d, "BN": SPC_BN2d}.get(
+                bn_type, SPC_SyncBN2d)
+            if sync_bn:
+                base = SPC_SyncBN2d
             self.BatchNorm2d = change_default_args(eps=1e-3, momentum=0.01)(base)
         self.ConvTranspose2d = change_default_args(bias=True)(MaskConvTranspose2d)
 

@@ -70,6 +70,23 @@ def odom_to_abs_pose(odoms):
     return np.concatenate(poses, axis=0)
 
 
+def gen_voxel_3d_coords(tq_map, pc_range, return_seq=False, format="BHW3"):
+    """Cell anchor coordinates of a BEV (or cubic) map (reference: rslo/utils/geometric.py:159-218): x = (j - ox) vx,
+    y = (oy - i) vy, z = (k - oz) vz, no half-cell offset -- the same convention as the local<->global maps
+    (rslo/data/dataset.py).  tq_map [B,H,W,C] ("BHW3") or [B,C,H,W] ("B3HW") only supplies shape / dtype / device.
+    -> [B,H,W,3] / [B,3,H,W] (Z = 1 squeezed), or [B*H*W, 3] with return_seq."""
+    from rslo.data.dataset import _cell_centres, _grid_geometry
+    assert format in ("BHW3", "B3HW") and tq_map.dim() == 4
+    B = tq_map.shape[0]
+    H, W = (tq_map.shape[1:3] if format == "BHW3" else tq_map.shape[2:])
+    _, vs, origin = _grid_geometry([1, int(H), int(W)], pc_range)
+    xyz = _cell_centres(int(W), int(H), 1, origin, vs, tq_map.device, tq_map.dtype)      # [H*W*1, 3], (i, j, k) order
+    if return_seq:
+        return xyz.repeat(B, 1)
+    xyz = xyz.view(1, int(H), int(W), 3).expand(B, int(H), int(W), 3)
+    return xyz.permute(0, 3, 1, 2).contiguous() if format == "B3HW" else xyz.contiguous()
+
+
 from rslo import reference_fallback as _reference_fallback  # noqa: E402
 
 __getattr__ = _reference_fallback(__name__)   # names outside the hot path: the checkout's own file, if one is on the path

@@ -55,7 +55,7 @@ def tiny_net():
 def scripted_grads(net, step):
     for i, p in enumerate(net.parameters()):
         if p.requires_grad:
-            idx = torch.arange(p.numel(), dtype=torch.float32).reshape(p.shape)
+            idx = torch.arange(p.numel(), dtype=torch.float32, device=p.device).reshape(p.shape)
             p.grad = 0.1 * torch.sin(0.37 * idx + 0.11 * step + i) + 0.01 * p.detach()
 
 
@@ -70,7 +70,7 @@ def run(opt_builder, lr_builder, optimizer_cfg, net):
         scripted_grads(net, step)
         opt.step()
         opt.zero_grad()
-        traj.append(torch.cat([p.detach().reshape(-1) for p in net.parameters()]).numpy().copy())
+        traj.append(torch.cat([p.detach().reshape(-1) for p in net.parameters()]).cpu().numpy().copy())
     return opt, np.array(lrs, np.float64), np.array(moms, np.float64), np.stack(traj)
 
 

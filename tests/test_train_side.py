@@ -103,3 +103,48 @@ def test_other_schedules_known_answers():
     s = lsf.LRSchedulerStep(o, 10, [(0, "lambda p: 1.0 + p"), (0.5, "lambda p: 3.0")], [(0, "lambda p: 0.9")])
     s.step(2); assert abs(o.lr - 1.4) < 1e-12 and o.mom == 0.9
     s.step(7); assert o.lr == 3.0
+
+
+@pytest.mark.gpu
+def test_gpu_optimizer_trajectory_matches_reference_vectors(gold, hip):
+    """f1 on the device: the same scripted toy problem as the reference-generated trajectory, run on cuda:0 through the
+    builders (fused multi-tensor Adam behind OptimWrapper + OneCycle).  Learning rates / momenta exact, parameters
+    2e-6 relative of the reference's CPU trajectory."""
+    from rslo.builder import lr_scheduler_builder, optimizer_builder
+    g, _ = gold
+    net = tiny_net().cuda()
+    opt, lrs, moms, traj = run(optimizer_builder, lr_scheduler_builder, shipped_optimizer_cfg(), net)
+    np.testing.assert_allclose(lrs, g["lrs"], rtol=1e-12, atol=0)
+    np.testing.assert_allclose(moms, g["moms"], rtol=1e-12, atol=0)
+    np.testing.assert_allclose(traj, g["traj"], rtol=2e-5, atol=1e-6)
+    assert all(p.is_cuda for grp in opt.param_groups for p in grp["params"])
+
+
+@pytest.mark.gpu
+def test_cpu_checkpoints_of_a_gpu_run_hold_host_tensors(tmp_path, hip):
+    """save_models_cpu (reference: checkpoint.py:178-218): .tckpt files of a GPU run load without map_location."""
+    import torchplus.train as T
+    from rslo.builder import optimizer_builder
+    net = tiny_net().cuda()
+    net.name = "voxelnet"
+    opt = optimizer_builder.build(shipped_optimizer_cfg(), net)
+    x = torch.randn(4, 6, device="cuda")
+    net(x).sum().backward()
+    opt.step()
+    T.save_models_cpu(str(tmp_path), [net, opt], 1)
+
+    def tensors(o):
+        if isinstance(o, torch.Tensor):
+            yield o
+        elif isinstance(o, dict):
+            for v in o.values():
+                yield from tensors(v)
+        elif isinstance(o, (list, tuple)):
+            for v in o:
+                yield from tensors(v)
+    for f in os.listdir(tmp_path):
+        if f.endswith(".tckpt"):
+            sd = torch.load(str(tmp_path / f), weights_only=False)
+            ts = list(tensors(sd))
+            assert ts and all(not t.is_cuda for t in ts), f
+    assert next(net.parameters()).is_cuda                      # the live model stayed on the device
