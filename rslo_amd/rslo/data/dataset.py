@@ -11,6 +11,34 @@ import torch
 
 import rslo.utils.pose_utils as tch_p
 
+REGISTERED_DATASET_CLASSES = {}
+
+
+def register_dataset(cls, name=None):
+    name = cls.__name__ if name is None else name
+    assert name not in REGISTERED_DATASET_CLASSES, f"exist class: {REGISTERED_DATASET_CLASSES}"
+    REGISTERED_DATASET_CLASSES[name] = cls
+    return cls
+
+
+def get_dataset_class(name):
+    assert name in REGISTERED_DATASET_CLASSES, f"available class: {REGISTERED_DATASET_CLASSES}"
+    return REGISTERED_DATASET_CLASSES[name]
+
+
+class Dataset(object):
+    """Interface of the sequence readers (rslo/data/dataset.py:32-50)."""
+    NumPointFeatures = -1
+
+    def __getitem__(self, index):
+        raise NotImplementedError
+
+    def __len__(self):
+        raise NotImplementedError
+
+    def evaluation(self, prediction, output_dir):
+        raise NotImplementedError
+
 
 def _cell_centres(size_x, size_y, size_z, origin_loc, voxel_size, device, dtype):
     i = torch.arange(size_y, device=device, dtype=dtype).view(-1, 1, 1)

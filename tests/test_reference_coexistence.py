@@ -67,8 +67,8 @@ SCRIPT = textwrap.dedent('''
               DistributedGivenIterationSampler, DistributedGivenIterationSamplerEpoch):
         assert isinstance(c, type)
     # a partial mirror module forwards what it lacks to the checkout's namesake
-    from rslo.data.dataset import get_dataset_class
-    assert get_dataset_class.__module__.endswith("__reference__")
+    from rslo.data.preprocess import prep_pointcloud            # not part of the mirror's preprocess.py
+    assert prep_pointcloud.__module__.endswith("__reference__")
     print("resolved")
 ''')
 
@@ -86,7 +86,7 @@ def test_without_a_checkout_missing_names_fail_with_a_clear_message():
     env = dict(os.environ)
     env.pop("PYTHONPATH", None)
     env.pop("RSLO_REFERENCE_ROOT", None)
-    src = ("import sys; sys.path.insert(0, %r); import rslo_amd, rslo.data.dataset as D\n"
-           "try:\n    D.get_dataset_class\nexcept AttributeError as e:\n    assert 'hot path' in str(e); print('clear')\n" % ROOT)
+    src = ("import sys; sys.path.insert(0, %r); import rslo_amd, rslo.data.preprocess as D\n"
+           "try:\n    D.prep_pointcloud\nexcept AttributeError as e:\n    assert 'hot path' in str(e); print('clear')\n" % ROOT)
     out = subprocess.run([sys.executable, "-c", src], capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0 and "clear" in out.stdout, out.stderr[-2000:]
