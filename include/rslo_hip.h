@@ -146,6 +146,10 @@ RSLO_API int rslo_weight_split_many(const RsloWeightSplitDesc *desc_dev, int n_l
 RSLO_API int rslo_spconv_fwd_split(const float *in, int cin, const void *Ws, const float *bias, const int32_t *nbr,
                                    const int32_t *row_order, int64_t n_out, int K, int cout, int flip_k,
                                    float act_slope, float *out, void *stream);
+/*     Experiment knob of rslo_spconv_fwd_split: <= 0 = one 32-row tile per wave (k_spconv_v6, the default);
+ *     2 / 4 = that many tiles per wave with the weight operands reused across them through a wave-private LDS ring
+ *     (k_spconv_v9: bit-identical results, measured slower -- see the kernel header).  Environment: RSLO_SPCONV_V9. */
+RSLO_API void rslo_spconv_set_v9(int mode);
 /*     bf16 feature path (BASELINE config C4: bf16 features, int32 rulebook, fp32 accumulate): in / out are bf16 rows
  *     [N,C], Wb the weights rounded to bf16 in MFMA operand order (rslo_weight_to_bf16, K*cin*cout*2 bytes; transpose
  *     = 1 for the data gradient), bias fp32.  Channel counts 32 / 64. */

@@ -125,7 +125,7 @@ class SparseConvTensor:
         return offs
 
     def dense(self, channels_first=True):
-        feats = self.features if self.features.dtype == torch.float32 else self.features.float()   # bf16 trunk (C4)
+        feats = self.features.float() if self.features.dtype == torch.bfloat16 else self.features   # bf16 trunk (C4)
         out = _DenseFn.apply(feats, self.site_index().coords, self.batch_size, tuple(self.spatial_shape))
         if not channels_first:
             out = out.permute(0, 2, 3, 4, 1).contiguous()
@@ -309,7 +309,7 @@ def _segmented_bn_act(x, bn, slope):
     dev_off = index.batch_offs_dev
     S = x.batch_size
     max_len = max(offs[b + 1] - offs[b] for b in range(S))
-    feats = x.features if x.features.dtype == torch.float32 else x.features.float()
+    feats = x.features.float() if x.features.dtype == torch.bfloat16 else x.features
     y = _SegBNActFn.apply(feats, bn.weight, bn.bias, bn, dev_off, S, max_len, slope)
     if bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(sum(1 for b in range(S) if offs[b + 1] > offs[b]))
