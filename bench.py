@@ -364,6 +364,7 @@ def main():
     # the reference's training step: 8-group Adam behind OptimWrapper (decoupled weight decay) + OneCycle schedule,
     # built from the shipped train_config (train_hdf5.py:408-411,478-480,618,661-674)
     from rslo.builder import lr_scheduler_builder, optimizer_builder
+    from rslo_amd import optim as hip_optim
     from rslo.utils import config_text
     train_cfg = config_text.shipped_config().train_config
     opt = optimizer_builder.build(train_cfg.optimizer, net)
@@ -418,7 +419,7 @@ def main():
             average_gradients(net, mean=True)
         w0, c0 = mark("bwd", w0, c0)
         if not args.no_optim:
-            torch.nn.utils.clip_grad_norm_(params, 10.0)
+            hip_optim.clip_grad_norm_(params, 10.0, optimizer=opt)      # train_hdf5.py:671 on the optimizer's tables
             opt.step()
             net.update_global_step()
         mark("opt", w0, c0)

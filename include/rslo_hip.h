@@ -448,6 +448,37 @@ RSLO_API int rslo_quat_to_rot_bwd(const float *q_wxyz, const float *gR, int B, f
 RSLO_API int rslo_pose_targets(const float *res_r, const float *res_t, const float *R_pred, const float *T_pred, int B,
                                float *rot_targets_wxyz, float *trans_targets, void *stream);
 
+/* f1   optimizer step of the training driver: global gradient-norm clipping (train_hdf5.py:671,
+ *      torch.nn.utils.clip_grad_norm_) and torch.optim.Adam under the fastai OptimWrapper's decoupled weight decay
+ *      (rslo/torchplus/train/fastai_optim.py:176-187; 8 parameter groups, rslo/builder/optimizer_builder.py:49-66) over
+ *      all parameter tensors at once.  tensors_dev: device array, one entry per tensor that has a gradient;
+ *      chunks_dev: device array cutting the tensors into pieces of <= 4096 elements (offsets multiples of 4), one
+ *      workgroup each.  State lives in the caller's tensors (exp_avg, exp_avg_sq, step = torch.optim.Adam's).
+ *      rslo_opt_clip_grad_norm: total_norm[0] = || all grads ||_2 (device scalar, no host read); grads are scaled by
+ *      max_norm / (total_norm + 1e-6) when that is < 1.  partial_ws: n_chunks doubles.
+ *      rslo_opt_adam_step: p *= 1 - wd lr; m, v moment updates; p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+ *      with t = step (the count AFTER this update, >= 1); writes t into every tensor's step scalar. */
+typedef struct {
+  float *param, *grad, *exp_avg, *exp_avg_sq, *step;   /* step may be NULL */
+  int32_t group;                                       /* index into RsloOptHyper.group */
+  int32_t reserved;
+} RsloOptTensor;
+typedef struct {
+  int32_t tensor, count;
+  int64_t offset;
+} RsloOptChunk;
+typedef struct {
+  float lr, beta1, beta2, eps, weight_decay;           /* weight_decay = the wrapper's decoupled wd (0: none) */
+} RsloOptGroup;
+#define RSLO_OPT_MAX_GROUPS 16
+typedef struct {
+  RsloOptGroup group[RSLO_OPT_MAX_GROUPS];
+} RsloOptHyper;
+RSLO_API int rslo_opt_clip_grad_norm(const RsloOptTensor *tensors_dev, const RsloOptChunk *chunks_dev, int n_chunks,
+                                     float max_norm, double *partial_ws, float *total_norm, void *stream);
+RSLO_API int rslo_opt_adam_step(const RsloOptTensor *tensors_dev, const RsloOptChunk *chunks_dev, int n_chunks,
+                                const RsloOptHyper *hyper, float step, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -118,6 +118,8 @@ SIGNATURES = {
     "rslo_pyramid_l2_ws_bytes": (_sz, [_vp, _i, _i]),
     "rslo_pyramid_l2_fwd": (C.c_int, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp]),
     "rslo_pyramid_l2_bwd": (C.c_int, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "rslo_opt_clip_grad_norm": (C.c_int, [_vp, _vp, _i, _f, _vp, _vp, _vp]),
+    "rslo_opt_adam_step": (C.c_int, [_vp, _vp, _i, _vp, _f, _vp]),
 }
 
 

@@ -9,8 +9,10 @@ Contract kept:
   * `true_wd`: decoupled weight decay, p *= 1 - wd * lr BEFORE the inner step, inner weight_decay forced to 0;
   * state_dict / load_state_dict / param_groups are the inner optimizer's (checkpoint format unchanged).
 
-MI355X form: the decoupled decay is one multi-tensor launch per param group (torch._foreach_mul_) instead of one
-launch per parameter tensor (213 tensors); the inner optimizer may be built with fused=True by the builder.
+MI355X form: on contiguous fp32 CUDA parameters under a plain Adam the decay and the update of ALL tensors run in one
+launch (rslo_amd.optim.AdamStepper over csrc/optim.hip; state stays in the inner optimizer's dict).  Otherwise the
+decoupled decay is one multi-tensor launch per param group (torch._foreach_mul_) instead of one launch per parameter
+tensor (213 tensors), and the inner optimizer may be built with fused=True by the builder.
 """
 from collections.abc import Iterable
 
@@ -88,6 +90,8 @@ class OptimWrapper:
 
     @torch.no_grad()
     def step(self):
+        if self._hip_step():
+            return
         if self.true_wd:
             for lr, wd, (plain, bn) in zip(self._lr, self._wd, self._pairs()):
                 for grp in ((plain, bn) if self.bn_wd else (plain,)):
@@ -96,6 +100,21 @@ class OptimWrapper:
                         torch._foreach_mul_(ps, 1 - wd * lr)
             self.set_val("weight_decay", listify(0, self._wd))
         self.opt.step()
+
+    def _hip_step(self):
+        """Decay + Adam over all tensors in one launch (rslo_amd.optim / csrc/optim.hip) when the inner optimizer is a
+        plain Adam over contiguous fp32 CUDA tensors; False -> the torch formulation below runs."""
+        from rslo_amd import optim as hip_optim
+        st = hip_optim.stepper_of(self.opt)
+        if st is None:
+            return False
+        wd = None
+        if self.true_wd:
+            self.set_val("weight_decay", listify(0, self._wd))
+            wd = []
+            for w in self._wd:
+                wd += [w, w if self.bn_wd else 0.0]
+        return st.step(wd)
 
     def zero_grad(self, set_to_none=True):
         self.opt.zero_grad(set_to_none=set_to_none)

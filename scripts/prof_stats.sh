@@ -18,4 +18,4 @@ ls -la gpurun_out | tail
 f=$(find $OUT -name "*kernel_stats.csv" | head -1)
 head -45 "$f" | cut -c1-220
 t=$(find $OUT -name "*kernel_trace.csv" | head -1)
-python scripts/trace_last_steps.py "$t" ${LAST:-1} ${VOX_PER_STEP:-8} gpurun_out/prof_${TAG}_last_step.txt | head -90
+python scripts/trace_last_steps.py "$t" ${LAST:-1} ${VOX_PER_STEP:-8} gpurun_out/prof_${TAG}_last_step.txt | head -${HEAD:-90}

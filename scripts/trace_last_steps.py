@@ -53,9 +53,10 @@ lines.append("## by category (ms/step)")
 for k, v in sorted(cats.items(), key=lambda kv: -kv[1]):
     lines.append("%-32s %9.3f" % (k, v / n_steps))
 lines.append("## top kernels: calls/step, total ms/step, avg us")
-for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:60]:
-    lines.append("%6.1f %9.3f %10.1f  %s" % (c / n_steps, t / 1e6 / n_steps, t / c / 1e3, n[:150]))
 import os
+TOP = int(os.environ.get("TOP", "60"))       # TOP=0: every kernel
+for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:TOP or None]:
+    lines.append("%6.1f %9.3f %10.1f  %s" % (c / n_steps, t / 1e6 / n_steps, t / c / 1e3, n[:150]))
 detail = os.environ.get("DETAIL")        # e.g. DETAIL=miopenSp3AsmConv: every call's duration (us) in launch order
 if detail:
     for key in detail.split(","):

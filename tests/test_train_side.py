@@ -12,7 +12,7 @@ import rslo_amd  # noqa: F401
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 sys.path.insert(0, GOLD)
-from make_golden_train import TOTAL_STEP, run, tiny_net   # noqa: E402  (the scripted toy problem, not reference code)
+from make_golden_train import TOTAL_STEP, run, scripted_grads, tiny_net   # noqa: E402  (the scripted toy problem, not reference code)
 
 
 @pytest.fixture(scope="module")
@@ -128,8 +128,7 @@ def test_cpu_checkpoints_of_a_gpu_run_hold_host_tensors(tmp_path, hip):
     net = tiny_net().cuda()
     net.name = "voxelnet"
     opt = optimizer_builder.build(shipped_optimizer_cfg(), net)
-    x = torch.randn(4, 6, device="cuda")
-    net(x).sum().backward()
+    scripted_grads(net, 0)
     opt.step()
     T.save_models_cpu(str(tmp_path), [net, opt], 1)
 
@@ -148,3 +147,71 @@ def test_cpu_checkpoints_of_a_gpu_run_hold_host_tensors(tmp_path, hip):
             ts = list(tensors(sd))
             assert ts and all(not t.is_cuda for t in ts), f
     assert next(net.parameters()).is_cuda                      # the live model stayed on the device
+
+
+@pytest.mark.gpu
+def test_hip_clip_and_adam_match_torch(hip):
+    """csrc/optim.hip against torch's own formulation on the same tensors: clip_grad_norm_ + decoupled decay + fused
+    Adam, 4 param groups with different hyper-parameters, ragged tensor sizes, tensors without gradients, 6 steps
+    (the first ones clip, the later ones do not), then a state_dict round trip."""
+    from rslo_amd import optim as hip_optim
+    torch.manual_seed(3)
+    shapes = [(7,), (64, 64, 3, 3), (4097,), (5, 13), (1,), (8192,), (33, 3), (16,)]
+    groups_of = [0, 0, 1, 1, 2, 2, 3, 3]
+    hyp = [dict(lr=3e-3, betas=(0.9, 0.99), eps=1e-8), dict(lr=1e-3, betas=(0.85, 0.95), eps=1e-8),
+           dict(lr=5e-4, betas=(0.9, 0.999), eps=1e-6), dict(lr=2e-3, betas=(0.8, 0.9), eps=1e-8)]
+    wds = [0.01, 0.0, 0.001, 0.05]
+
+    def make():
+        ps = [torch.nn.Parameter(torch.randn(*s, device="cuda")) for s in shapes]
+        return ps, torch.optim.Adam([dict(params=[p for p, g in zip(ps, groups_of) if g == gi], **hyp[gi])
+                                     for gi in range(4)], fused=True)
+    torch.manual_seed(5)
+    pa, oa = make()
+    torch.manual_seed(5)
+    pb, ob = make()
+    st = hip_optim.stepper_of(oa)
+    assert st is not None
+    no_grad = {4}                       # a tensor that never gets a gradient
+    for it in range(6):
+        scale = 40.0 if it < 3 else 0.01
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            if i in no_grad:
+                continue
+            g = torch.randn_like(a) * scale
+            a.grad, b.grad = g.clone(), g.clone()
+        ta = hip_optim.clip_grad_norm_(pa, 10.0, optimizer=oa)
+        tb = torch.nn.utils.clip_grad_norm_(pb, 10.0)
+        assert abs(float(ta) - float(tb)) <= 2e-6 * float(tb)
+        for a, b in zip(pa, pb):
+            if a.grad is not None:
+                assert torch.allclose(a.grad, b.grad, rtol=2e-6, atol=0)
+        assert st.step(wds)
+        with torch.no_grad():
+            for gi, grp in enumerate(ob.param_groups):
+                torch._foreach_mul_(list(grp["params"]), 1 - wds[gi] * grp["lr"])
+        ob.step()
+        for a, b in zip(pa, pb):
+            assert torch.allclose(a, b, rtol=2e-6, atol=1e-7), it
+    for a, b in zip(pa, pb):
+        if a.grad is None:
+            assert len(oa.state[a]) == 0
+            continue
+        assert float(oa.state[a]["step"]) == float(ob.state[b]["step"]) == 6.0
+        assert torch.allclose(oa.state[a]["exp_avg"], ob.state[b]["exp_avg"], rtol=1e-5, atol=1e-8)
+        assert torch.allclose(oa.state[a]["exp_avg_sq"], ob.state[b]["exp_avg_sq"], rtol=1e-5, atol=1e-10)
+    # a state_dict round trip replaces the moment tensors: the tables follow
+    oa.load_state_dict(oa.state_dict())
+    for a, b in zip(pa, pb):
+        if a.grad is not None:
+            g = torch.randn_like(a)
+            a.grad, b.grad = g.clone(), g.clone()
+    assert st.step(wds)
+    with torch.no_grad():
+        for gi, grp in enumerate(ob.param_groups):
+            torch._foreach_mul_(list(grp["params"]), 1 - wds[gi] * grp["lr"])
+    ob.step()
+    for a, b in zip(pa, pb):
+        assert torch.allclose(a, b, rtol=2e-6, atol=1e-7)
+        if a.grad is not None:
+            assert float(oa.state[a]["step"]) == 7.0
