@@ -375,6 +375,8 @@ def main():
     clouds = workload.kitti_pairs(args.batch, n_el=args.rings, start=rank * args.batch)
     clouds = [[torch.from_numpy(c).to(dev) for c in pair] for pair in clouds]
     fixed_example = workload.make_example(net, clouds, device=dev) if args.no_voxelize else None
+    if fixed_example is not None and os.environ.get("RSLO_BENCH_FIXED_PLAN") == "1":
+        net.plan_example(fixed_example)      # diagnostic: no structure work at all inside the step (lower bound)
 
     # the next batch is voxelized and its rulebooks planned on a side stream while the current step runs (what the
     # reference's DataLoader workers do on the CPU); every step still voxelizes its own 2 x batch clouds

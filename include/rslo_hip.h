@@ -414,11 +414,25 @@ typedef struct {
   void *ws_fwd;     /* rslo_conv2d_wsplit_bytes(cin, cout) bytes, transpose = 0 */
   void *ws_dgrad;   /* same size, transpose = 1 */
   int32_t cin, cout;
+  int32_t ntap;     /* 9 (or 0): 3x3 weight; 1: 1x1 weight (operand of rslo_conv2d_fwd_s2 / _dgrad_s2 with ksize 1) */
+  int32_t reserved;
 } RsloConv2dSplitDesc;
 RSLO_API int rslo_conv2d_wsplit_many(const RsloConv2dSplitDesc *desc_dev, int n_layers, int64_t max_weight_elems,
                                      void *stream);
 RSLO_API int rslo_conv2d_fwd(const float *in, const void *Ws, const float *bias, int B, int cin, int cout, int H, int W,
                              float *out, void *stream);
+/*      The stride-2 layers of the BEV encoder (first 3x3 convolution and 1x1 downsample of every stage,
+ *      rslo/models/odom_pred.py:398-426): ksize 3 (padding 1) or 1 (padding 0), no bias (the reference builds them
+ *      bias-free in front of a BatchNorm).  in [B,cin,H,W] -> out [B,cout,Ho,Wo], Ho = (H - 1) / 2 + 1.
+ *      rslo_conv2d_wsplit_k: the split operand of a [cout,cin,ksize,ksize] weight (transpose = 1: data gradient);
+ *      rslo_conv2d_dgrad_s2 writes every element of din [B,cin,H,W] (per output parity class: no zero-stuffing,
+ *      no atomics). */
+RSLO_API int rslo_conv2d_s2_supported(int cin, int cout, int ksize);
+RSLO_API int rslo_conv2d_wsplit_k(const float *W, int cin, int cout, int ksize, int transpose, void *Ws, void *stream);
+RSLO_API int rslo_conv2d_fwd_s2(const float *in, const void *Ws, int B, int cin, int cout, int H, int W, int ksize,
+                                float *out, void *stream);
+RSLO_API int rslo_conv2d_dgrad_s2(const float *dout, const void *Ws, int B, int cin, int cout, int H, int W, int ksize,
+                                  float *din, void *stream);
 /*      C4 (bf16 operands, fp32 accumulation and storage): the same kernels issuing only the product of the
  *      round-to-nearest bf16 values of activations and weights (1 MFMA instead of 6).  Ws is the operand block of
  *      rslo_conv2d_wsplit (its first plane IS the bf16-rounded weight); the stride-2 weight gradient keeps the split form. */

@@ -247,6 +247,39 @@ def conv2d_dgrad(dout, w):
     return dx
 
 
+def conv2d_s2_fwd(x, w):
+    """Bias-free stride-2 Conv2d of the BEV stages, float64: 3x3 / padding 1 (BasicBlock.conv1 of a stage's first block,
+    rslo/models/custom_resnet_spc.py:224-260) or 1x1 / padding 0 (its downsample branch, odom_pred.py:404-406).
+    x [B,Cin,H,W], w [Cout,Cin,k,k] -> [B,Cout,(H-1)//2+1,(W-1)//2+1]."""
+    x = np.asarray(x, np.float64)
+    w = np.asarray(w, np.float64)
+    B, Cin, H, W = x.shape
+    k = w.shape[2]
+    pad = (k - 1) // 2
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    xp = np.zeros((B, Cin, H + 2 * pad + 1, W + 2 * pad + 1))
+    xp[:, :, pad:pad + H, pad:pad + W] = x
+    out = np.zeros((B, w.shape[0], Ho, Wo))
+    for ky in range(k):
+        for kx in range(k):
+            out += np.einsum("oi,biyx->boyx", w[:, :, ky, kx], xp[:, :, ky:ky + 2 * Ho:2, kx:kx + 2 * Wo:2], optimize=True)
+    return out
+
+
+def conv2d_s2_dgrad(dout, w, H, W):
+    """Data gradient of conv2d_s2_fwd for an [H, W] input: dx[b,i,2y+ky-pad,2x+kx-pad] += dout[b,o,y,x] w[o,i,ky,kx]."""
+    g = np.asarray(dout, np.float64)
+    w = np.asarray(w, np.float64)
+    B, Cout, Ho, Wo = g.shape
+    k = w.shape[2]
+    pad = (k - 1) // 2
+    dxp = np.zeros((B, w.shape[1], H + 2 * pad + 1, W + 2 * pad + 1))
+    for ky in range(k):
+        for kx in range(k):
+            dxp[:, :, ky:ky + 2 * Ho:2, kx:kx + 2 * Wo:2] += np.einsum("oi,boyx->biyx", w[:, :, ky, kx], g, optimize=True)
+    return dxp[:, :, pad:pad + H, pad:pad + W]
+
+
 def conv1x1_fwd(x, w, bias=None):
     """1x1 Conv2d (torch.nn.Conv2d(c, 7, 1), rslo/models/odom_pred.py:71): out[b,o,y,x] = bias[o] + sum_i w[o,i] x[b,i,y,x]."""
     out = np.einsum("oi,biyx->boyx", np.asarray(w, np.float64)[:, :, 0, 0], np.asarray(x, np.float64))

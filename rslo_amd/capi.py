@@ -101,6 +101,10 @@ SIGNATURES = {
     "rslo_conv2d_fwd_supported": (C.c_int, [_i, _i, _i, _i]),
     "rslo_conv2d_wsplit_bytes": (_sz, [_i, _i]),
     "rslo_conv2d_wsplit": (C.c_int, [_vp, _i, _i, _i, _vp, _vp]),
+    "rslo_conv2d_wsplit_k": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "rslo_conv2d_s2_supported": (C.c_int, [_i, _i, _i]),
+    "rslo_conv2d_fwd_s2": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "rslo_conv2d_dgrad_s2": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "rslo_conv2d_wsplit_many": (C.c_int, [_vp, _i, _i64, _vp]),
     "rslo_conv2d_fwd": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "rslo_conv2d_fwd_bf16": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
@@ -994,14 +998,14 @@ def conv2d_wsplit(w, transpose=False):
 
 class Conv2dSplitDesc(C.Structure):
     _fields_ = [("W", C.c_void_p), ("ws_fwd", C.c_void_p), ("ws_dgrad", C.c_void_p), ("cin", C.c_int32),
-                ("cout", C.c_int32)]
+                ("cout", C.c_int32), ("ntap", C.c_int32), ("reserved", C.c_int32)]
 
 
 def conv2d_wsplit_many(weights):
-    """weights: list of [cout,cin,3,3] fp32 CUDA tensors.  Returns (plan, [(ws_fwd, ws_dgrad) per layer]); call
-    conv2d_wsplit_run(plan) after every weight update: it refreshes all operands in one launch."""
+    """weights: list of [cout,cin,3,3] (or [cout,cin,1,1]) fp32 CUDA tensors.  Returns (plan, [(ws_fwd, ws_dgrad) per
+    layer]); call conv2d_wsplit_run(plan) after every weight update: it refreshes all operands in one launch."""
     dev = weights[0].device
-    sizes = [lib().rslo_conv2d_wsplit_bytes(w.shape[1], w.shape[0]) // 2 for w in weights]
+    sizes = [lib().rslo_conv2d_wsplit_bytes(w.shape[1], w.shape[0]) // 2 * (w.shape[2] * w.shape[3]) // 9 for w in weights]
     pool = torch.empty((2 * sum(sizes),), dtype=torch.int16, device=dev)
     views, off = [], 0
     arr = (Conv2dSplitDesc * len(weights))()
@@ -1009,7 +1013,8 @@ def conv2d_wsplit_many(weights):
         f, t = pool[off:off + n], pool[off + n:off + 2 * n]
         off += 2 * n
         views.append((f, t))
-        arr[i] = Conv2dSplitDesc(_ptr(w, torch.float32, "w").value, f.data_ptr(), t.data_ptr(), w.shape[1], w.shape[0])
+        arr[i] = Conv2dSplitDesc(_ptr(w, torch.float32, "w").value, f.data_ptr(), t.data_ptr(), w.shape[1], w.shape[0],
+                                 w.shape[2] * w.shape[3], 0)
     host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
     table = host.to(dev)
     plan = {"table": table, "n": len(weights), "max": max(int(w.numel()) for w in weights), "pool": pool,
@@ -1019,6 +1024,41 @@ def conv2d_wsplit_many(weights):
 
 def conv2d_wsplit_run(plan):
     _chk(lib().rslo_conv2d_wsplit_many(_ptr(plan["table"]), plan["n"], plan["max"], _stream()), "rslo_conv2d_wsplit_many")
+
+
+def conv2d_s2_supported(cin, cout, ksize):
+    return bool(lib().rslo_conv2d_s2_supported(int(cin), int(cout), int(ksize)))
+
+
+def conv2d_wsplit_k(w, transpose=False):
+    """w [cout,cin,k,k] (k = 1 or 3) fp32 -> split-bf16 operands for conv2d_fwd_s2 (transpose=True: conv2d_dgrad_s2)."""
+    cout, cin, k = w.shape[0], w.shape[1], w.shape[2]
+    ws = torch.empty((3 * k * k * cin * cout,), dtype=torch.int16, device=w.device)
+    _chk(lib().rslo_conv2d_wsplit_k(_ptr(w, torch.float32, "w"), cin, cout, k, 1 if transpose else 0, _ptr(ws), _stream()),
+         "rslo_conv2d_wsplit_k")
+    return ws
+
+
+def conv2d_fwd_s2(x, ws, cout, ksize):
+    """x [B,cin,H,W] contiguous fp32 -> [B,cout,Ho,Wo]: 3x3 / padding 1 or 1x1 / padding 0, stride 2, no bias."""
+    B, cin, H, W = x.shape
+    out = torch.empty((B, cout, (H - 1) // 2 + 1, (W - 1) // 2 + 1), dtype=torch.float32, device=x.device)
+    rc = lib().rslo_conv2d_fwd_s2(_ptr(x, torch.float32, "x"), ws.data_ptr(), B, cin, cout, H, W, ksize, out.data_ptr(),
+                                  _stream())
+    if rc:
+        _chk(rc, "rslo_conv2d_fwd_s2")
+    return out
+
+
+def conv2d_dgrad_s2(dy, ws_t, cin, H, W, ksize):
+    """dy [B,cout,Ho,Wo] -> dx [B,cin,H,W] of the stride-2 layer; ws_t = the transpose=True operand."""
+    B, cout = dy.shape[0], dy.shape[1]
+    dx = torch.empty((B, cin, H, W), dtype=torch.float32, device=dy.device)
+    rc = lib().rslo_conv2d_dgrad_s2(_ptr(dy, torch.float32, "dy"), ws_t.data_ptr(), B, cin, cout, H, W, ksize, dx.data_ptr(),
+                                    _stream())
+    if rc:
+        _chk(rc, "rslo_conv2d_dgrad_s2")
+    return dx
 
 
 def conv2d_fwd(x, ws, bias, cout, lp=False):

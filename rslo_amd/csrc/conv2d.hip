@@ -547,22 +547,27 @@ static int conv2d_wgrad_launch(const float *in, const float *dout, int B, int ci
 
 // Ws [cin_k / 32][9][n_m / 16][3][64][8] bf16 from W [cout][cin][3][3]; transpose = 0: m = cout, k = cin (forward);
 // transpose = 1: m = cin, k = cout, taps flipped (data gradient)
-__global__ void k_conv2d_wsplit(const float *__restrict__ W, int cin, int cout, int transpose,
-                                unsigned short *__restrict__ Ws) {
+// element i of the operand block of a [cout][cin][T] weight, T = ntap taps (9: 3x3, 1: 1x1)
+__device__ __forceinline__ void conv2d_wsplit_elem(const float *__restrict__ W, int cin, int cout, int ntap, int transpose,
+                                                   unsigned short *__restrict__ Ws, int64_t i) {
   const int n_m = transpose ? cin : cout, n_k = transpose ? cout : cin;
   const int n_mt = n_m / 16;
-  const int64_t n = (int64_t)n_k * 9 * n_m;
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t n = (int64_t)n_k * ntap * n_m;
   if (i >= n) return;
   const int e = (int)(i & 7), lane = (int)((i >> 3) & 63);
   int64_t r = i >> 9;
   const int mt = (int)(r % n_mt); r /= n_mt;
-  const int tap = (int)(r % 9);
-  const int chunk = (int)(r / 9);
+  const int tap = (int)(r % ntap);
+  const int chunk = (int)(r / ntap);
   const int m = mt * 16 + (lane & 15), k = chunk * 32 + 8 * (lane >> 4) + e;
-  const float x = transpose ? W[((int64_t)k * cin + m) * 9 + (8 - tap)] : W[((int64_t)m * cin + k) * 9 + tap];
-  const int64_t base = ((((int64_t)chunk * 9 + tap) * n_mt + mt) * 3) * 512 + lane * 8 + e;
+  const float x = transpose ? W[((int64_t)k * cin + m) * ntap + (ntap - 1 - tap)] : W[((int64_t)m * cin + k) * ntap + tap];
+  const int64_t base = ((((int64_t)chunk * ntap + tap) * n_mt + mt) * 3) * 512 + lane * 8 + e;
   rslo_split1(x, Ws[base], Ws[base + 512], Ws[base + 1024]);
+}
+
+__global__ void k_conv2d_wsplit(const float *__restrict__ W, int cin, int cout, int ntap, int transpose,
+                                unsigned short *__restrict__ Ws) {
+  conv2d_wsplit_elem(W, cin, cout, ntap, transpose, Ws, (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 // all layers of a model in one launch: grid (ceil(max_n / 256), 2 * n_layers); row 2 l + t splits layer l with
@@ -570,23 +575,8 @@ __global__ void k_conv2d_wsplit(const float *__restrict__ W, int cin, int cout, 
 __global__ void k_conv2d_wsplit_many(const RsloConv2dSplitDesc *__restrict__ desc) {
   const RsloConv2dSplitDesc d = desc[blockIdx.y >> 1];
   const int transpose = blockIdx.y & 1;
-  const int cin = d.cin, cout = d.cout;
-  const float *__restrict__ W = d.W;
-  unsigned short *__restrict__ Ws = (unsigned short *)(transpose ? d.ws_dgrad : d.ws_fwd);
-  const int n_m = transpose ? cin : cout, n_k = transpose ? cout : cin;
-  const int n_mt = n_m / 16;
-  const int64_t n = (int64_t)n_k * 9 * n_m;
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int e = (int)(i & 7), lane = (int)((i >> 3) & 63);
-  int64_t r = i >> 9;
-  const int mt = (int)(r % n_mt); r /= n_mt;
-  const int tap = (int)(r % 9);
-  const int chunk = (int)(r / 9);
-  const int m = mt * 16 + (lane & 15), k = chunk * 32 + 8 * (lane >> 4) + e;
-  const float x = transpose ? W[((int64_t)k * cin + m) * 9 + (8 - tap)] : W[((int64_t)m * cin + k) * 9 + tap];
-  const int64_t base = ((((int64_t)chunk * 9 + tap) * n_mt + mt) * 3) * 512 + lane * 8 + e;
-  rslo_split1(x, Ws[base], Ws[base + 512], Ws[base + 1024]);
+  conv2d_wsplit_elem(d.W, d.cin, d.cout, d.ntap == 1 ? 1 : 9, transpose,
+                     (unsigned short *)(transpose ? d.ws_dgrad : d.ws_fwd), (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 struct Conv2dFwdGeom {
@@ -788,13 +778,18 @@ extern "C" int rslo_conv2d_fwd_supported(int cin, int cout, int H, int W) {
 
 extern "C" size_t rslo_conv2d_wsplit_bytes(int cin, int cout) { return (size_t)3 * 9 * cin * cout * sizeof(unsigned short); }
 
-extern "C" int rslo_conv2d_wsplit(const float *W, int cin, int cout, int transpose, void *Ws, void *stream) {
+extern "C" int rslo_conv2d_wsplit_k(const float *W, int cin, int cout, int ksize, int transpose, void *Ws, void *stream) {
   RSLO_CHECK_ARG(cin % 32 == 0 && cout % 32 == 0, "rslo_conv2d_wsplit: channels must be multiples of 32 (%d, %d)", cin, cout);
-  const int64_t n = (int64_t)cin * cout * 9;
+  RSLO_CHECK_ARG(ksize == 1 || ksize == 3, "rslo_conv2d_wsplit: kernel size must be 1 or 3");
+  const int64_t n = (int64_t)cin * cout * ksize * ksize;
   hipLaunchKernelGGL(k_conv2d_wsplit, dim3((unsigned)rslo_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, W, cin, cout,
-                     transpose, (unsigned short *)Ws);
+                     ksize * ksize, transpose, (unsigned short *)Ws);
   RSLO_CHECK_LAUNCH("k_conv2d_wsplit");
   return RSLO_OK;
+}
+
+extern "C" int rslo_conv2d_wsplit(const float *W, int cin, int cout, int transpose, void *Ws, void *stream) {
+  return rslo_conv2d_wsplit_k(W, cin, cout, 3, transpose, Ws, stream);
 }
 
 extern "C" int rslo_conv2d_wsplit_many(const RsloConv2dSplitDesc *desc_dev, int n_layers, int64_t max_weight_elems,
@@ -843,6 +838,212 @@ static int conv2d_fwd_launch(const float *in, const void *Ws, const float *bias,
   else if (mtw == 2) hipLaunchKernelGGL((k_conv2d_fwd<4, 2, false>), grid, dim3(256), 0, st, in, ws, bias, gm, out);
   else hipLaunchKernelGGL((k_conv2d_fwd<4, 1, true>), grid, dim3(256), 0, st, in, ws, bias, gm, out);
   RSLO_CHECK_LAUNCH("k_conv2d_fwd");
+  return RSLO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Stride-2 layers of the BEV encoder (the first 3x3 convolution and the 1x1 downsample of every stage:
+// rslo/models/odom_pred.py:398-426 -> custom_resnet_spc.BasicBlock / conv1x1): forward and data gradient on the same
+// staged-halo, split-bf16 structure as k_conv2d_fwd.
+//
+//   forward        out[b][m][y][x]  = sum_{k, taps} A[m][k][tap] in[b][k][2y + ky - P][2x + kx - P]      (P = 1 / 0)
+//   data gradient  din[b][m][Y][X]  = sum_{k, (ky,kx): Y = 2y + ky - P, X = 2x + kx - P} W[k][m][ky][kx] dout[b][k][y][x]
+//
+// The data gradient is computed per output PARITY CLASS (Y mod 2, X mod 2): a class's pixels (2r + py, 2c + px) form a
+// dense grid over which the sum is a small stride-1 convolution of dout with 1, 2 or 4 of the 9 taps (3x3) or with the
+// single tap / nothing (1x1: three of the four classes are zeros, written by the same launch).  No zero-stuffed
+// intermediate, no atomics, no layout transposes (the library path: Winograd "dilation2" kernels + NCHW<->CNHW copies).
+// One kernel: S_IN = sampling stride of the staged plane per class pixel (2 forward, 1 data gradient); a class
+// descriptor gives the halo origin, the taps (LDS offsets + index into the split weight operand) and where the class's
+// pixels land in the output plane.  blockIdx.z = class.
+// ---------------------------------------------------------------------------------------------------------------------
+struct Conv2dStrClass {
+  int py, px;             // output pixel of class pixel (r, c): (s_out r + py, s_out c + px)
+  int by, bx;             // staged plane pixel of halo (0, 0) for the tile at class pixel (r0, c0): (S_IN r0 + by, ..)
+  int ny, nx;             // taps used (0: the class is identically zero)
+  int oy[3], ox[3];       // halo offsets of the taps
+  int wt[9];              // [iy * 3 + ix] -> tap index in the weight operand
+  int rows, cols;         // class pixels per image
+};
+struct Conv2dStrGeom {
+  int B, cin, cout;       // contraction / produced channels of THIS call
+  int Hi, Wi, Ho, Wo;     // staged plane, written plane
+  int s_out, ntap_w;      // output stride of class pixels; taps per chunk in the weight operand (9 or 1)
+  int tiles_x, tiles_y;
+  Conv2dStrClass cls[4];
+};
+
+template <int TR, int S_IN>
+__global__ __launch_bounds__(256, 2) void k_conv2d_str(const float *__restrict__ in, const unsigned short *__restrict__ Ws,
+                                                       Conv2dStrGeom gm, float *__restrict__ out) {
+  constexpr int NTW = TR / 2, HR = S_IN * (TR - 1) + 3, HC = S_IN * 15 + 3, NPX = HR * HC;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[NPX * C2F_PXB];
+  const Conv2dStrClass &cl = gm.cls[blockIdx.z];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int wm = wid & 1, wn = wid >> 1;
+  int bx = blockIdx.x;
+  const int tx = bx % gm.tiles_x; bx /= gm.tiles_x;
+  const int ty = bx % gm.tiles_y;
+  const int b = bx / gm.tiles_y;
+  const int c0 = tx * 16, r0 = ty * TR;
+  if (r0 >= cl.rows || c0 >= cl.cols) return;
+  const int64_t HWi = (int64_t)gm.Hi * gm.Wi, HWo = (int64_t)gm.Ho * gm.Wo;
+  const int n_mt = gm.cout / 16;
+  const int mt0 = blockIdx.y * 2 + wm;          // this wave's 16-channel output block
+
+  f32x4 acc[NTW];
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  if (cl.ny > 0 && cl.nx > 0) {
+    constexpr int NTASK = (NPX * 4 + 255) / 256;
+    const float *tsrc[NTASK];
+    int tdst[NTASK];
+#pragma unroll
+    for (int r = 0; r < NTASK; ++r) {
+      const int task = tid + r * 256;
+      const int o = task / NPX, q = task - o * NPX;
+      const int qy = q / HC, qx = q - qy * HC;
+      const int y = S_IN * r0 + cl.by + qy, x = S_IN * c0 + cl.bx + qx;
+      const bool ok = task < NPX * 4 && y >= 0 && y < gm.Hi && x >= 0 && x < gm.Wi;
+      tsrc[r] = ok ? in + ((int64_t)b * gm.cin + 8 * o) * HWi + (int64_t)y * gm.Wi + x : nullptr;
+      tdst[r] = task < NPX * 4 ? q * C2F_PXB + o * 16 : -1;
+    }
+    float raw[NTASK][8];
+    const int n_chunks = gm.cin / 32;
+#pragma unroll
+    for (int r = 0; r < NTASK; ++r)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) raw[r][j] = tsrc[r] ? tsrc[r][j * HWi] : 0.f;
+    const unsigned short *wbase = Ws + (int64_t)mt0 * 3 * 512 + lane * 8;
+    for (int chunk = 0; chunk < n_chunks; ++chunk) {
+#pragma unroll
+      for (int r = 0; r < NTASK; ++r) {
+        if (tdst[r] >= 0) {
+          const Split3 s = split_masked(raw[r], 0xffu);
+          unsigned char *dst = lds + tdst[r];
+          *(u32x4 *)(dst) = s.h;
+          *(u32x4 *)(dst + 64) = s.m;
+          *(u32x4 *)(dst + 128) = s.l;
+        }
+      }
+      if (chunk + 1 < n_chunks) {
+#pragma unroll
+        for (int r = 0; r < NTASK; ++r)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) raw[r][j] = tsrc[r] ? tsrc[r][((int64_t)(chunk + 1) * 32 + j) * HWi] : 0.f;
+      }
+      __syncthreads();
+      for (int iy = 0; iy < cl.ny; ++iy) {
+        for (int ix = 0; ix < cl.nx; ++ix) {
+          const unsigned short *wp = wbase + ((((int64_t)chunk * gm.ntap_w + cl.wt[iy * 3 + ix]) * n_mt) * 3) * 512;
+          const u32x4 ah = *(const u32x4 *)(wp), am = *(const u32x4 *)(wp + 512), al = *(const u32x4 *)(wp + 1024);
+          u32x4 bh[NTW], bm[NTW], bl[NTW];
+#pragma unroll
+          for (int nt = 0; nt < NTW; ++nt) {
+            const unsigned char *bp = lds + ((S_IN * (wn * NTW + nt) + cl.oy[iy]) * HC + S_IN * li + cl.ox[ix]) * C2F_PXB +
+                                      g * 16;
+            bh[nt] = *(const u32x4 *)(bp);
+            bm[nt] = *(const u32x4 *)(bp + 64);
+            bl[nt] = *(const u32x4 *)(bp + 128);
+          }
+          // six products per block, smallest first
+#pragma unroll
+          for (int nt = 0; nt < NTW; ++nt) acc[nt] = MFMA_BF16(al, bh[nt], acc[nt]);
+#pragma unroll
+          for (int nt = 0; nt < NTW; ++nt) acc[nt] = MFMA_BF16(am, bm[nt], acc[nt]);
+#pragma unroll
+          for (int nt = 0; nt < NTW; ++nt) acc[nt] = MFMA_BF16(ah, bl[nt], acc[nt]);
+#pragma unroll
+          for (int nt = 0; nt < NTW; ++nt) acc[nt] = MFMA_BF16(am, bh[nt], acc[nt]);
+#pragma unroll
+          for (int nt = 0; nt < NTW; ++nt) acc[nt] = MFMA_BF16(ah, bm[nt], acc[nt]);
+#pragma unroll
+          for (int nt = 0; nt < NTW; ++nt) acc[nt] = MFMA_BF16(ah, bh[nt], acc[nt]);
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  const int c = c0 + li;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int m = mt0 * 16 + 4 * g + j;
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+      const int r = r0 + wn * NTW + nt;
+      if (c < cl.cols && r < cl.rows)
+        out[((int64_t)b * gm.cout + m) * HWo + (int64_t)(gm.s_out * r + cl.py) * gm.Wo + gm.s_out * c + cl.px] = acc[nt][j];
+    }
+  }
+}
+
+// ksize 3 (padding 1) or 1 (padding 0), stride 2
+extern "C" int rslo_conv2d_s2_supported(int cin, int cout, int ksize) {
+  return (ksize == 1 || ksize == 3) && cin > 0 && cout > 0 && cin % 32 == 0 && cout % 32 == 0;
+}
+
+// in [B,cin,H,W] -> out [B,cout,Ho,Wo], Ho = (H - 1) / 2 + 1; Ws = rslo_conv2d_wsplit_k(W, cin, cout, ksize, 0)
+extern "C" int rslo_conv2d_fwd_s2(const float *in, const void *Ws, int B, int cin, int cout, int H, int W, int ksize,
+                                  float *out, void *stream) {
+  RSLO_CHECK_ARG(in && Ws && out && B > 0 && H > 0 && W > 0 && rslo_conv2d_s2_supported(cin, cout, ksize),
+                 "rslo_conv2d_fwd_s2: unsupported shape cin=%d cout=%d ksize=%d", cin, cout, ksize);
+  Conv2dStrGeom gm = {};
+  gm.B = B; gm.cin = cin; gm.cout = cout; gm.Hi = H; gm.Wi = W;
+  gm.Ho = (H - 1) / 2 + 1; gm.Wo = (W - 1) / 2 + 1;
+  gm.s_out = 1; gm.ntap_w = ksize * ksize;
+  gm.tiles_x = (int)rslo_cdiv(gm.Wo, 16); gm.tiles_y = (int)rslo_cdiv(gm.Ho, 4);
+  Conv2dStrClass &c = gm.cls[0];
+  c.rows = gm.Ho; c.cols = gm.Wo;
+  if (ksize == 3) {
+    c.by = c.bx = -1; c.ny = c.nx = 3;
+    for (int i = 0; i < 3; ++i) c.oy[i] = c.ox[i] = i;
+    for (int i = 0; i < 9; ++i) c.wt[i] = i;
+  } else {
+    c.ny = c.nx = 1;
+  }
+  hipLaunchKernelGGL((k_conv2d_str<4, 2>), dim3((unsigned)(B * gm.tiles_x * gm.tiles_y), (unsigned)(cout / 32), 1), dim3(256),
+                     0, (hipStream_t)stream, in, (const unsigned short *)Ws, gm, out);
+  RSLO_CHECK_LAUNCH("k_conv2d_str(fwd)");
+  return RSLO_OK;
+}
+
+// dout [B,cout,Ho,Wo] -> din [B,cin,H,W] (every element written); Ws = rslo_conv2d_wsplit_k(W, cin, cout, ksize, 1)
+extern "C" int rslo_conv2d_dgrad_s2(const float *dout, const void *Ws, int B, int cin, int cout, int H, int W, int ksize,
+                                    float *din, void *stream) {
+  RSLO_CHECK_ARG(dout && Ws && din && B > 0 && H > 0 && W > 0 && rslo_conv2d_s2_supported(cin, cout, ksize),
+                 "rslo_conv2d_dgrad_s2: unsupported shape cin=%d cout=%d ksize=%d", cin, cout, ksize);
+  Conv2dStrGeom gm = {};
+  gm.B = B; gm.cin = cout; gm.cout = cin;       // contraction over the forward's output channels
+  gm.Hi = (H - 1) / 2 + 1; gm.Wi = (W - 1) / 2 + 1; gm.Ho = H; gm.Wo = W;
+  gm.s_out = 2; gm.ntap_w = ksize * ksize;
+  const int rmax = (H + 1) / 2, cmax = (W + 1) / 2;
+  gm.tiles_x = (int)rslo_cdiv(cmax, 16); gm.tiles_y = (int)rslo_cdiv(rmax, 4);
+  for (int py = 0; py < 2; ++py)
+    for (int px = 0; px < 2; ++px) {
+      Conv2dStrClass &c = gm.cls[py * 2 + px];
+      c.py = py; c.px = px;
+      c.rows = (H - py + 1) / 2; c.cols = (W - px + 1) / 2;
+      if (ksize == 3) {
+        // Y = 2y + ky - 1 = 2r + py  ->  py = 0: ky = 1, y = r;  py = 1: ky = 0, y = r + 1 and ky = 2, y = r.  The operand
+        // with transpose = 1 stores original tap t at index 8 - t.
+        int kys[2], dys[2], kxs[2], dxs[2];
+        c.ny = py ? 2 : 1; c.nx = px ? 2 : 1;
+        if (py) { kys[0] = 0; dys[0] = 1; kys[1] = 2; dys[1] = 0; } else { kys[0] = 1; dys[0] = 0; }
+        if (px) { kxs[0] = 0; dxs[0] = 1; kxs[1] = 2; dxs[1] = 0; } else { kxs[0] = 1; dxs[0] = 0; }
+        for (int iy = 0; iy < c.ny; ++iy) c.oy[iy] = dys[iy];
+        for (int ix = 0; ix < c.nx; ++ix) c.ox[ix] = dxs[ix];
+        for (int iy = 0; iy < c.ny; ++iy)
+          for (int ix = 0; ix < c.nx; ++ix) c.wt[iy * 3 + ix] = 8 - (3 * kys[iy] + kxs[ix]);
+      } else {
+        c.ny = c.nx = (py == 0 && px == 0) ? 1 : 0;      // din[2y][2x] only; the other classes are zeros
+      }
+    }
+  hipLaunchKernelGGL((k_conv2d_str<4, 1>), dim3((unsigned)(B * gm.tiles_x * gm.tiles_y), (unsigned)(cin / 32), 4), dim3(256), 0,
+                     (hipStream_t)stream, dout, (const unsigned short *)Ws, gm, din);
+  RSLO_CHECK_LAUNCH("k_conv2d_str(dgrad)");
   return RSLO_OK;
 }
 

@@ -18,6 +18,11 @@ import torch.nn.functional as F
 HIP_PASSES = os.environ.get("RSLO_CONV2D_PASSES", "wfd")
 
 
+def _low_precision():
+    from rslo_amd import precision
+    return precision.low_precision() is not None
+
+
 class _Conv3x3Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, stride, hip_fd, hip_w):
@@ -38,8 +43,10 @@ class _Conv3x3Fn(torch.autograd.Function):
             if "d" in HIP_PASSES:
                 ctx.ws_t = ws[1] if ws is not None else capi.conv2d_wsplit(w, True)
             if "f" in HIP_PASSES:
-                return capi.conv2d_fwd(x, ws[0] if ws is not None else capi.conv2d_wsplit(w, False), bias, w.shape[0],
-                                       lp=lp)
+                wf = ws[0] if ws is not None else capi.conv2d_wsplit(w, False)
+                if stride == 2:
+                    return capi.conv2d_fwd_s2(x, wf, w.shape[0], 3)
+                return capi.conv2d_fwd(x, wf, bias, w.shape[0], lp=lp)
         return F.conv2d(x, w, bias, stride, 1)
 
     @staticmethod
@@ -50,7 +57,9 @@ class _Conv3x3Fn(torch.autograd.Function):
         dy = dy.contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            if ctx.ws_t is not None:
+            if ctx.ws_t is not None and s == 2:
+                dx = capi.conv2d_dgrad_s2(dy, ctx.ws_t, w.shape[1], x.shape[2], x.shape[3], 3)
+            elif ctx.ws_t is not None:
                 dx = capi.conv2d_fwd(dy, ctx.ws_t, None, w.shape[1], lp=ctx.lp)
             else:
                 dx = torch.ops.aten.convolution_backward(dy, x, w, None, [s, s], [1, 1], [1, 1], False, [0, 0], 1,
@@ -70,6 +79,36 @@ class _Conv3x3Fn(torch.autograd.Function):
         return dx, dw, db, None, None, None
 
 
+
+
+class _Conv1x1S2Fn(torch.autograd.Function):
+    """Bias-free 1x1 / stride-2 downsample convolution of a BEV stage (custom_resnet_spc.conv1x1, odom_pred.py:404-406):
+    forward and data gradient on rslo_conv2d_fwd_s2 / _dgrad_s2; the weight gradient is a plain [cout x cin] GEMM over
+    the sampled pixels (library bmm on the subsampled input: 1.1 GFLOP, no layout transposes)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        from rslo_amd import capi
+        x = x.contiguous()
+        ctx.save_for_backward(x, w)
+        ws = getattr(w, "_hip_split", None)
+        if ws is not None and (ws[2] != w._version or ws[3] != w.data_ptr()):
+            ws = None
+        ctx.ws_t = ws[1] if ws is not None else capi.conv2d_wsplit_k(w, True)
+        return capi.conv2d_fwd_s2(x, ws[0] if ws is not None else capi.conv2d_wsplit_k(w, False), w.shape[0], 1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        from rslo_amd import capi
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = capi.conv2d_dgrad_s2(dy, ctx.ws_t, w.shape[1], x.shape[2], x.shape[3], 1)
+        if ctx.needs_input_grad[1]:
+            xs = x[:, :, ::2, ::2].flatten(2)                              # [B, cin, P]
+            dw = torch.matmul(dy.flatten(2), xs.transpose(1, 2)).sum(0).reshape(w.shape)
+        return dx, dw
 
 
 class _Conv1x1Fn(torch.autograd.Function):
@@ -105,8 +144,7 @@ def presplit(root):
     ent = root.__dict__.get("_hip_conv2d_plan")        # (plan, weights, views), kept on the module itself
     if ent is None or any(w.data_ptr() != p for w, p in zip(ent[1], ent[0]["ptrs"])):
         ws = [m.weight for m in root.modules()
-              if isinstance(m, Conv2d) and m.hip_wgrad and m.kernel_size == (3, 3) and m.stride == (1, 1)
-              and m.padding == (1, 1) and m.dilation == (1, 1) and m.groups == 1 and m.weight.is_cuda
+              if isinstance(m, Conv2d) and m.hip_wgrad and m._kind() in ("3x3", "1x1s2") and m.weight.is_cuda
               and m.weight.dtype == torch.float32 and m.in_channels % 32 == 0 and m.out_channels % 32 == 0]
         if not ws:
             return
@@ -137,6 +175,9 @@ class Conv2d(nn.Conv2d):
                 kind = "1x1"
             elif self.kernel_size == (3, 3) and self.padding == (1, 1) and self.stride in ((1, 1), (2, 2)):
                 kind = "3x3"
+            elif (self.kernel_size == (1, 1) and self.stride == (2, 2) and self.padding == (0, 0) and self.bias is None
+                  and self.in_channels % 32 == 0 and self.out_channels % 32 == 0):
+                kind = "1x1s2"
         self.__dict__["_hip_kind"] = (key, kind)
         return kind
 
@@ -147,8 +188,9 @@ class Conv2d(nn.Conv2d):
             from rslo_amd import capi
             w_ok = "w" in HIP_PASSES and capi.conv2d_wgrad_supported(self.in_channels, self.out_channels, key[0],
                                                                      key[1], self.stride[0])
-            fd_ok = self.stride == (1, 1) and capi.conv2d_fwd_supported(self.in_channels, self.out_channels, key[0],
-                                                                       key[1]) and ("f" in HIP_PASSES or "d" in HIP_PASSES)
+            fd_ok = ("f" in HIP_PASSES or "d" in HIP_PASSES) and (
+                capi.conv2d_fwd_supported(self.in_channels, self.out_channels, key[0], key[1]) if self.stride == (1, 1)
+                else (self.bias is None and capi.conv2d_s2_supported(self.in_channels, self.out_channels, 3)))
             ok = self._hip_ok = (key, w_ok, fd_ok)
         return ok[1] or ok[2]
 
@@ -158,6 +200,8 @@ class Conv2d(nn.Conv2d):
             kind = self._kind()
             if kind == "1x1" and "w" in HIP_PASSES:
                 return _Conv1x1Fn.apply(input, weight, bias)
+            if kind == "1x1s2" and "f" in HIP_PASSES and "d" in HIP_PASSES and not _low_precision():
+                return _Conv1x1S2Fn.apply(input, weight)
             if kind == "3x3" and self._eligible(input):
                 return _Conv3x3Fn.apply(input, weight, bias, self.stride[0], self._hip_ok[2], self._hip_ok[1])
         return super()._conv_forward(input, weight, bias)

@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 5 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/$c -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-events > $OUT/$c.log 2>&1
 done
-python3 - $OUT $GRAFT_REPO_ROOT/gpurun_out/r01_pmc_traffic_bench.json <<'PY'
+python3 - $OUT $GRAFT_REPO_ROOT/gpurun_out/${ROUND:-r02}_pmc_traffic_bench.json $GRAFT_REPO_ROOT/rslo_amd/librslo_hip.so <<'PY'
 import csv, sys, glob, collections, json, re
 res = collections.defaultdict(dict)
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -16,7 +16,9 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             agg[re.sub(r"^void ", "", n.split("(")[0])].append(float(d["Counter_Value"]))
     for k, v in agg.items():
         res[k][c] = sum(v) / len(v); res[k]["launches"] = len(v)
-out = {"note": "per-launch averages over a 5-step bench.py run; FETCH_SIZE/WRITE_SIZE are reported in KB; "
+import hashlib
+out = {"lib_sha256": hashlib.sha256(open(sys.argv[3], "rb").read()).hexdigest()[:16],
+       "note": "per-launch averages over a 5-step bench.py run; FETCH_SIZE/WRITE_SIZE are reported in KB; "
                "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE counts 128-B requests as 64 B)",
        "kernels": {}}
 for k, v in sorted(res.items()):

@@ -6,7 +6,7 @@ OUT=/tmp/pmc_mf; rm -rf $OUT; mkdir -p $OUT gpurun_out
 cd /tmp && export TMPDIR=/tmp
 timeout -k 5 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-events > $OUT/run.log 2>&1
 echo "rocprof rc=$?"; tail -2 $OUT/run.log | cut -c1-200
-python3 - $OUT $GRAFT_REPO_ROOT/gpurun_out/r01_pmc_mfma_busy.json <<'PY'
+python3 - $OUT $GRAFT_REPO_ROOT/gpurun_out/${ROUND:-r02}_pmc_mfma_busy.json $GRAFT_REPO_ROOT/rslo_amd/librslo_hip.so <<'PY'
 import csv, sys, glob, collections, json, re
 f = glob.glob("%s/**/*counter_collection.csv" % sys.argv[1], recursive=True)[0]
 per = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -14,7 +14,9 @@ for d in csv.DictReader(open(f)):
     n = d["Kernel_Name"]
     if any(k in n for k in ("k_spconv", "k_wgrad", "k_conv2d_fwd", "k_conv2d_wgrad_s1", "k_conv2d_wgrad<", "miopenSp3", "igemm")):
         per[re.sub(r"^void ", "", n.split("(")[0])[:60]][d["Counter_Name"]].append(float(d["Counter_Value"]))
-out = {"note": "per-launch averages over a 5-step bench.py run; mfma_busy_pct = 100 * SQ_VALU_MFMA_BUSY_CYCLES / "
+import hashlib
+out = {"lib_sha256": hashlib.sha256(open(sys.argv[3], "rb").read()).hexdigest()[:16],
+       "note": "per-launch averages over a 5-step bench.py run; mfma_busy_pct = 100 * SQ_VALU_MFMA_BUSY_CYCLES / "
                "(GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs); shader_clock_cycles = GRBM_GUI_ACTIVE / 8", "kernels": {}}
 for k, v in sorted(per.items()):
     mb, ga = v.get("SQ_VALU_MFMA_BUSY_CYCLES", []), v.get("GRBM_GUI_ACTIVE", [])

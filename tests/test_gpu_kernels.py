@@ -880,6 +880,63 @@ def test_conv2d_fwd_and_dgrad_match_float64_oracle(hip, B, cin, cout, H, W, cfg)
         assert err <= 4 * err_lib + 1e-6 * scale, (err, err_lib)
 
 
+@pytest.mark.parametrize("B,cin,cout,H,W,k", [
+    (2, 64, 32, 12, 22, 3), (2, 64, 32, 12, 22, 1),          # small even map
+    (1, 32, 64, 13, 21, 3), (1, 32, 64, 13, 21, 1),          # odd sizes: ragged parity classes
+    (2, 128, 128, 48, 88, 3), (2, 128, 128, 48, 88, 1),      # stage 2 of the BEV encoder
+    (1, 256, 128, 96, 176, 3),                               # stage 1: full-resolution map
+])
+def test_conv2d_stride2_fwd_and_dgrad_match_float64_oracle(hip, B, cin, cout, H, W, k):
+    """The stride-2 layers (3x3 / padding 1 and the 1x1 downsample) through rslo_conv2d_wsplit_k + rslo_conv2d_fwd_s2 /
+    rslo_conv2d_dgrad_s2 against the float64 restatement: |err| <= 2e-5 max|ref| and no further from it than 4x the
+    library's fp32 result; the data gradient writes every element (the buffer is pre-filled with NaN)."""
+    rng = np.random.default_rng(31 + k)
+    x = rng.standard_normal((B, cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((cout, cin, k, k)) / np.sqrt(k * k * cin)).astype(np.float32)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    g = rng.standard_normal((B, cout, Ho, Wo)).astype(np.float32)
+    assert hip.conv2d_s2_supported(cin, cout, k)
+    y = hip.conv2d_fwd_s2(dev(x), hip.conv2d_wsplit_k(dev(w), False), cout, k)
+    assert y.shape == (B, cout, Ho, Wo)
+    dx = hip.conv2d_dgrad_s2(dev(g), hip.conv2d_wsplit_k(dev(w), True), cin, H, W, k)
+    assert dx.shape == (B, cin, H, W) and bool(torch.isfinite(dx).all())
+    ry, rdx = O.conv2d_s2_fwd(x, w), O.conv2d_s2_dgrad(g, w, H, W)
+    tx = dev(x).requires_grad_(True)
+    ty = torch.nn.functional.conv2d(tx, dev(w), None, 2, (k - 1) // 2)
+    ty.backward(dev(g))
+    for got, ref, lib in [(y.cpu().numpy().astype(np.float64), ry, ty.detach().cpu().numpy()),
+                          (dx.cpu().numpy().astype(np.float64), rdx, tx.grad.cpu().numpy())]:
+        scale = np.abs(ref).max()
+        err = np.abs(got - ref).max()
+        err_lib = np.abs(lib.astype(np.float64) - ref).max()
+        assert err <= 2e-5 * scale, (err, scale)
+        assert err <= 4 * err_lib + 1e-6 * scale, (err, err_lib)
+
+
+def test_hip_conv2d_stride2_layers_match_library_through_autograd(hip):
+    """rslo.layers.hip_conv2d.Conv2d on the two stride-2 layer kinds of a BEV stage (3x3 / padding 1 and the bias-free
+    1x1 downsample): outputs, input gradients and weight gradients against torch.nn.functional.conv2d, with the operands
+    coming from the one-launch presplit of the module tree."""
+    from rslo.layers import hip_conv2d
+    torch.manual_seed(4)
+    root = torch.nn.Sequential(hip_conv2d.Conv2d(64, 32, 3, stride=2, padding=1, bias=False),
+                               hip_conv2d.Conv2d(64, 32, 1, stride=2, bias=False)).cuda()
+    hip_conv2d.presplit(root)
+    for m in root:
+        assert getattr(m.weight, "_hip_split", None) is not None
+        x = torch.randn(2, 64, 24, 44, device="cuda", requires_grad=True)
+        y = m(x)
+        assert y.grad_fn is not None and type(y.grad_fn).__name__ in ("_Conv3x3FnBackward", "_Conv1x1S2FnBackward")
+        g = torch.randn_like(y)
+        y.backward(g)
+        xr = x.detach().clone().requires_grad_(True)
+        wr = m.weight.detach().clone().requires_grad_(True)
+        yr = torch.nn.functional.conv2d(xr, wr, None, 2, m.padding)
+        yr.backward(g)
+        for a, b in ((y, yr), (x.grad, xr.grad), (m.weight.grad, wr.grad)):
+            assert float((a - b).abs().max()) <= 3e-5 * float(b.abs().max()), type(y.grad_fn).__name__
+
+
 def test_hip_conv2d_all_passes_with_presplit_match_library(hip, monkeypatch):
     """RSLO_CONV2D_PASSES=wfd: forward and data gradient through rslo_conv2d_fwd with the operands of all layers split
     in one launch (presplit), refreshed after an in-place weight update."""

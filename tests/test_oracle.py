@@ -265,3 +265,20 @@ def test_dense_conv2d_fwd_dgrad_restatement_matches_torch():
     y.backward(torch.from_numpy(g))
     np.testing.assert_allclose(O.conv2d_fwd(x.detach().numpy(), w.numpy(), bias.numpy()), y.detach().numpy(), rtol=1e-12, atol=1e-12)
     np.testing.assert_allclose(O.conv2d_dgrad(g, w.numpy()), x.grad.numpy(), rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("k", [1, 3])
+def test_stride2_conv_restatement_matches_torch_float64(k):
+    """oracle.conv2d_s2_fwd / conv2d_s2_dgrad (the checkers of the stride-2 HIP kernels) against torch's own float64
+    convolution and its autograd, even and odd map sizes."""
+    import torch
+    rng = np.random.default_rng(k)
+    for H, W in ((12, 22), (13, 21)):
+        x = rng.standard_normal((2, 5, H, W))
+        w = rng.standard_normal((4, 5, k, k))
+        tx = torch.from_numpy(x).requires_grad_(True)
+        ty = torch.nn.functional.conv2d(tx, torch.from_numpy(w), None, 2, (k - 1) // 2)
+        g = rng.standard_normal(tuple(ty.shape))
+        ty.backward(torch.from_numpy(g))
+        assert np.abs(O.conv2d_s2_fwd(x, w) - ty.detach().numpy()).max() < 1e-12
+        assert np.abs(O.conv2d_s2_dgrad(g, w, H, W) - tx.grad.numpy()).max() < 1e-12
