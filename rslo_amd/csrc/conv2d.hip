@@ -853,13 +853,13 @@ static int conv2d_fwd_launch(const float *in, const void *Ws, const float *bias,
 // dense grid over which the sum is a small stride-1 convolution of dout with 1, 2 or 4 of the 9 taps (3x3) or with the
 // single tap / nothing (1x1: three of the four classes are zeros, written by the same launch).  No zero-stuffed
 // intermediate, no atomics, no layout transposes (the library path: Winograd "dilation2" kernels + NCHW<->CNHW copies).
-// One kernel: S_IN = sampling stride of the staged plane per class pixel (2 forward, 1 data gradient); a class
-// descriptor gives the halo origin, the taps (LDS offsets + index into the split weight operand) and where the class's
-// pixels land in the output plane.  blockIdx.z = class.
+// One kernel: S_IN = sampling stride of the staged plane per class pixel (2: 3x3 forward; 1: data gradients and the 1x1
+// forward, which stages only the sampled pixels); a class descriptor gives the taps (LDS offsets + index into the split
+// weight operand) and where the class's pixels land in the output plane.  A workgroup stages its halo ONCE per channel
+// chunk and computes all NCLS classes of its tile from it (data gradient: 4 classes, 9 tap products in total).
 // ---------------------------------------------------------------------------------------------------------------------
 struct Conv2dStrClass {
   int py, px;             // output pixel of class pixel (r, c): (s_out r + py, s_out c + px)
-  int by, bx;             // staged plane pixel of halo (0, 0) for the tile at class pixel (r0, c0): (S_IN r0 + by, ..)
   int ny, nx;             // taps used (0: the class is identically zero)
   int oy[3], ox[3];       // halo offsets of the taps
   int wt[9];              // [iy * 3 + ix] -> tap index in the weight operand
@@ -867,18 +867,20 @@ struct Conv2dStrClass {
 };
 struct Conv2dStrGeom {
   int B, cin, cout;       // contraction / produced channels of THIS call
-  int Hi, Wi, Ho, Wo;     // staged plane, written plane
+  int Hi, Wi, Ho, Wo;     // source plane, written plane
+  int src_stride;         // staged pixel (qy, qx) = source pixel src_stride * (S_IN r0 + by + qy, ..) (2: 1x1 forward)
+  int by, bx;             // halo origin offset
   int s_out, ntap_w;      // output stride of class pixels; taps per chunk in the weight operand (9 or 1)
+  int n_class;            // classes computed by every workgroup from ONE staged halo (1 forward, 4 data gradient)
   int tiles_x, tiles_y;
   Conv2dStrClass cls[4];
 };
 
-template <int TR, int S_IN>
+template <int TR, int S_IN, int NCLS>
 __global__ __launch_bounds__(256, 2) void k_conv2d_str(const float *__restrict__ in, const unsigned short *__restrict__ Ws,
                                                        Conv2dStrGeom gm, float *__restrict__ out) {
   constexpr int NTW = TR / 2, HR = S_IN * (TR - 1) + 3, HC = S_IN * 15 + 3, NPX = HR * HC;
   __shared__ __attribute__((aligned(16))) unsigned char lds[NPX * C2F_PXB];
-  const Conv2dStrClass &cl = gm.cls[blockIdx.z];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int li = lane & 15, g = lane >> 4;
   const int wm = wid & 1, wn = wid >> 1;
@@ -887,54 +889,57 @@ __global__ __launch_bounds__(256, 2) void k_conv2d_str(const float *__restrict__
   const int ty = bx % gm.tiles_y;
   const int b = bx / gm.tiles_y;
   const int c0 = tx * 16, r0 = ty * TR;
-  if (r0 >= cl.rows || c0 >= cl.cols) return;
   const int64_t HWi = (int64_t)gm.Hi * gm.Wi, HWo = (int64_t)gm.Ho * gm.Wo;
   const int n_mt = gm.cout / 16;
   const int mt0 = blockIdx.y * 2 + wm;          // this wave's 16-channel output block
 
-  f32x4 acc[NTW];
+  f32x4 acc[NCLS][NTW];
 #pragma unroll
-  for (int nt = 0; nt < NTW; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int c = 0; c < NCLS; ++c)
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) acc[c][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  if (cl.ny > 0 && cl.nx > 0) {
-    constexpr int NTASK = (NPX * 4 + 255) / 256;
-    const float *tsrc[NTASK];
-    int tdst[NTASK];
+  constexpr int NTASK = (NPX * 4 + 255) / 256;
+  const float *tsrc[NTASK];
+  int tdst[NTASK];
+#pragma unroll
+  for (int r = 0; r < NTASK; ++r) {
+    const int task = tid + r * 256;
+    const int o = task / NPX, q = task - o * NPX;
+    const int qy = q / HC, qx = q - qy * HC;
+    const int y = gm.src_stride * (S_IN * r0 + gm.by + qy), x = gm.src_stride * (S_IN * c0 + gm.bx + qx);
+    const bool ok = task < NPX * 4 && y >= 0 && y < gm.Hi && x >= 0 && x < gm.Wi;
+    tsrc[r] = ok ? in + ((int64_t)b * gm.cin + 8 * o) * HWi + (int64_t)y * gm.Wi + x : nullptr;
+    tdst[r] = task < NPX * 4 ? q * C2F_PXB + o * 16 : -1;
+  }
+  float raw[NTASK][8];
+  const int n_chunks = gm.cin / 32;
+#pragma unroll
+  for (int r = 0; r < NTASK; ++r)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) raw[r][j] = tsrc[r] ? tsrc[r][j * HWi] : 0.f;
+  const unsigned short *wbase = Ws + (int64_t)mt0 * 3 * 512 + lane * 8;
+  for (int chunk = 0; chunk < n_chunks; ++chunk) {
 #pragma unroll
     for (int r = 0; r < NTASK; ++r) {
-      const int task = tid + r * 256;
-      const int o = task / NPX, q = task - o * NPX;
-      const int qy = q / HC, qx = q - qy * HC;
-      const int y = S_IN * r0 + cl.by + qy, x = S_IN * c0 + cl.bx + qx;
-      const bool ok = task < NPX * 4 && y >= 0 && y < gm.Hi && x >= 0 && x < gm.Wi;
-      tsrc[r] = ok ? in + ((int64_t)b * gm.cin + 8 * o) * HWi + (int64_t)y * gm.Wi + x : nullptr;
-      tdst[r] = task < NPX * 4 ? q * C2F_PXB + o * 16 : -1;
+      if (tdst[r] >= 0) {
+        const Split3 s = split_masked(raw[r], 0xffu);
+        unsigned char *dst = lds + tdst[r];
+        *(u32x4 *)(dst) = s.h;
+        *(u32x4 *)(dst + 64) = s.m;
+        *(u32x4 *)(dst + 128) = s.l;
+      }
     }
-    float raw[NTASK][8];
-    const int n_chunks = gm.cin / 32;
+    if (chunk + 1 < n_chunks) {
 #pragma unroll
-    for (int r = 0; r < NTASK; ++r)
+      for (int r = 0; r < NTASK; ++r)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) raw[r][j] = tsrc[r] ? tsrc[r][j * HWi] : 0.f;
-    const unsigned short *wbase = Ws + (int64_t)mt0 * 3 * 512 + lane * 8;
-    for (int chunk = 0; chunk < n_chunks; ++chunk) {
+        for (int j = 0; j < 8; ++j) raw[r][j] = tsrc[r] ? tsrc[r][((int64_t)(chunk + 1) * 32 + j) * HWi] : 0.f;
+    }
+    __syncthreads();
 #pragma unroll
-      for (int r = 0; r < NTASK; ++r) {
-        if (tdst[r] >= 0) {
-          const Split3 s = split_masked(raw[r], 0xffu);
-          unsigned char *dst = lds + tdst[r];
-          *(u32x4 *)(dst) = s.h;
-          *(u32x4 *)(dst + 64) = s.m;
-          *(u32x4 *)(dst + 128) = s.l;
-        }
-      }
-      if (chunk + 1 < n_chunks) {
-#pragma unroll
-        for (int r = 0; r < NTASK; ++r)
-#pragma unroll
-          for (int j = 0; j < 8; ++j) raw[r][j] = tsrc[r] ? tsrc[r][((int64_t)(chunk + 1) * 32 + j) * HWi] : 0.f;
-      }
-      __syncthreads();
+    for (int c = 0; c < NCLS; ++c) {
+      const Conv2dStrClass &cl = gm.cls[c];
       for (int iy = 0; iy < cl.ny; ++iy) {
         for (int ix = 0; ix < cl.nx; ++ix) {
           const unsigned short *wp = wbase + ((((int64_t)chunk * gm.ntap_w + cl.wt[iy * 3 + ix]) * n_mt) * 3) * 512;
@@ -950,32 +955,36 @@ __global__ __launch_bounds__(256, 2) void k_conv2d_str(const float *__restrict__
           }
           // six products per block, smallest first
 #pragma unroll
-          for (int nt = 0; nt < NTW; ++nt) acc[nt] = MFMA_BF16(al, bh[nt], acc[nt]);
+          for (int nt = 0; nt < NTW; ++nt) acc[c][nt] = MFMA_BF16(al, bh[nt], acc[c][nt]);
 #pragma unroll
-          for (int nt = 0; nt < NTW; ++nt) acc[nt] = MFMA_BF16(am, bm[nt], acc[nt]);
+          for (int nt = 0; nt < NTW; ++nt) acc[c][nt] = MFMA_BF16(am, bm[nt], acc[c][nt]);
 #pragma unroll
-          for (int nt = 0; nt < NTW; ++nt) acc[nt] = MFMA_BF16(ah, bl[nt], acc[nt]);
+          for (int nt = 0; nt < NTW; ++nt) acc[c][nt] = MFMA_BF16(ah, bl[nt], acc[c][nt]);
 #pragma unroll
-          for (int nt = 0; nt < NTW; ++nt) acc[nt] = MFMA_BF16(am, bh[nt], acc[nt]);
+          for (int nt = 0; nt < NTW; ++nt) acc[c][nt] = MFMA_BF16(am, bh[nt], acc[c][nt]);
 #pragma unroll
-          for (int nt = 0; nt < NTW; ++nt) acc[nt] = MFMA_BF16(ah, bm[nt], acc[nt]);
+          for (int nt = 0; nt < NTW; ++nt) acc[c][nt] = MFMA_BF16(ah, bm[nt], acc[c][nt]);
 #pragma unroll
-          for (int nt = 0; nt < NTW; ++nt) acc[nt] = MFMA_BF16(ah, bh[nt], acc[nt]);
+          for (int nt = 0; nt < NTW; ++nt) acc[c][nt] = MFMA_BF16(ah, bh[nt], acc[c][nt]);
         }
       }
-      __syncthreads();
     }
+    __syncthreads();
   }
 
-  const int c = c0 + li;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int m = mt0 * 16 + 4 * g + j;
+  for (int c = 0; c < NCLS; ++c) {
+    const Conv2dStrClass &cl = gm.cls[c];
+    const int col = c0 + li;
 #pragma unroll
-    for (int nt = 0; nt < NTW; ++nt) {
-      const int r = r0 + wn * NTW + nt;
-      if (c < cl.cols && r < cl.rows)
-        out[((int64_t)b * gm.cout + m) * HWo + (int64_t)(gm.s_out * r + cl.py) * gm.Wo + gm.s_out * c + cl.px] = acc[nt][j];
+    for (int j = 0; j < 4; ++j) {
+      const int m = mt0 * 16 + 4 * g + j;
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) {
+        const int r = r0 + wn * NTW + nt;
+        if (col < cl.cols && r < cl.rows)
+          out[((int64_t)b * gm.cout + m) * HWo + (int64_t)(gm.s_out * r + cl.py) * gm.Wo + gm.s_out * col + cl.px] = acc[c][nt][j];
+      }
     }
   }
 }
@@ -993,19 +1002,20 @@ extern "C" int rslo_conv2d_fwd_s2(const float *in, const void *Ws, int B, int ci
   Conv2dStrGeom gm = {};
   gm.B = B; gm.cin = cin; gm.cout = cout; gm.Hi = H; gm.Wi = W;
   gm.Ho = (H - 1) / 2 + 1; gm.Wo = (W - 1) / 2 + 1;
-  gm.s_out = 1; gm.ntap_w = ksize * ksize;
+  gm.s_out = 1; gm.ntap_w = ksize * ksize; gm.n_class = 1;
   gm.tiles_x = (int)rslo_cdiv(gm.Wo, 16); gm.tiles_y = (int)rslo_cdiv(gm.Ho, 4);
   Conv2dStrClass &c = gm.cls[0];
   c.rows = gm.Ho; c.cols = gm.Wo;
+  const dim3 grid((unsigned)(B * gm.tiles_x * gm.tiles_y), (unsigned)(cout / 32), 1);
   if (ksize == 3) {
-    c.by = c.bx = -1; c.ny = c.nx = 3;
+    gm.src_stride = 1; gm.by = gm.bx = -1; c.ny = c.nx = 3;
     for (int i = 0; i < 3; ++i) c.oy[i] = c.ox[i] = i;
     for (int i = 0; i < 9; ++i) c.wt[i] = i;
-  } else {
-    c.ny = c.nx = 1;
+    hipLaunchKernelGGL((k_conv2d_str<4, 2, 1>), grid, dim3(256), 0, (hipStream_t)stream, in, (const unsigned short *)Ws, gm, out);
+  } else {        // out[y][x] = W in[2y][2x]: stage only the sampled pixels
+    gm.src_stride = 2; c.ny = c.nx = 1;
+    hipLaunchKernelGGL((k_conv2d_str<4, 1, 1>), grid, dim3(256), 0, (hipStream_t)stream, in, (const unsigned short *)Ws, gm, out);
   }
-  hipLaunchKernelGGL((k_conv2d_str<4, 2>), dim3((unsigned)(B * gm.tiles_x * gm.tiles_y), (unsigned)(cout / 32), 1), dim3(256),
-                     0, (hipStream_t)stream, in, (const unsigned short *)Ws, gm, out);
   RSLO_CHECK_LAUNCH("k_conv2d_str(fwd)");
   return RSLO_OK;
 }
@@ -1018,7 +1028,7 @@ extern "C" int rslo_conv2d_dgrad_s2(const float *dout, const void *Ws, int B, in
   Conv2dStrGeom gm = {};
   gm.B = B; gm.cin = cout; gm.cout = cin;       // contraction over the forward's output channels
   gm.Hi = (H - 1) / 2 + 1; gm.Wi = (W - 1) / 2 + 1; gm.Ho = H; gm.Wo = W;
-  gm.s_out = 2; gm.ntap_w = ksize * ksize;
+  gm.s_out = 2; gm.ntap_w = ksize * ksize; gm.n_class = 4; gm.src_stride = 1;
   const int rmax = (H + 1) / 2, cmax = (W + 1) / 2;
   gm.tiles_x = (int)rslo_cdiv(cmax, 16); gm.tiles_y = (int)rslo_cdiv(rmax, 4);
   for (int py = 0; py < 2; ++py)
@@ -1041,7 +1051,8 @@ extern "C" int rslo_conv2d_dgrad_s2(const float *dout, const void *Ws, int B, in
         c.ny = c.nx = (py == 0 && px == 0) ? 1 : 0;      // din[2y][2x] only; the other classes are zeros
       }
     }
-  hipLaunchKernelGGL((k_conv2d_str<4, 1>), dim3((unsigned)(B * gm.tiles_x * gm.tiles_y), (unsigned)(cin / 32), 4), dim3(256), 0,
+  // all four classes of a tile from one staged halo of dout (9 tap products in total for 3x3)
+  hipLaunchKernelGGL((k_conv2d_str<4, 1, 4>), dim3((unsigned)(B * gm.tiles_x * gm.tiles_y), (unsigned)(cin / 32), 1), dim3(256), 0,
                      (hipStream_t)stream, dout, (const unsigned short *)Ws, gm, din);
   RSLO_CHECK_LAUNCH("k_conv2d_str(dgrad)");
   return RSLO_OK;

@@ -3,6 +3,7 @@
 the last one, [start of step -(n+1), start of the last step): the last step's tail would include bench.py's
 post-timing summary work (pair counting for the roofline figures).  Writes a small text summary."""
 import csv
+import os
 import sys
 from collections import defaultdict
 
@@ -14,7 +15,7 @@ with open(path) as f:
     for d in r:
         rows.append((int(d["Start_Timestamp"]), int(d["End_Timestamp"]), d["Kernel_Name"]))
 rows.sort()
-vox = [s for s, e, n in rows if n.startswith("k_vox_insert")]
+vox = [s for s, e, n in rows if n.startswith(os.environ.get("STEP_MARK", "k_vox_insert"))]   # first kernel of a step
 assert len(vox) >= (n_steps + 1) * vox_per_step, (len(vox), n_steps, vox_per_step)
 t0 = vox[-(n_steps + 1) * vox_per_step]
 t1 = vox[-vox_per_step]
