@@ -16,6 +16,8 @@ import torch.nn.functional as F
 # which passes of an eligible layer run on the hand-written kernels: "w" weight gradient, "f" forward, "d" data gradient
 # ("" = everything on the library, for A/B measurements)
 HIP_PASSES = os.environ.get("RSLO_CONV2D_PASSES", "wfd")
+# "0": the stride-2 layers (3x3 and the 1x1 downsample) stay on the library (A/B measurements)
+HIP_STRIDE2 = os.environ.get("RSLO_CONV2D_S2", "1") != "0"
 
 
 def _low_precision():
@@ -175,7 +177,7 @@ class Conv2d(nn.Conv2d):
                 kind = "1x1"
             elif self.kernel_size == (3, 3) and self.padding == (1, 1) and self.stride in ((1, 1), (2, 2)):
                 kind = "3x3"
-            elif (self.kernel_size == (1, 1) and self.stride == (2, 2) and self.padding == (0, 0) and self.bias is None
+            elif (HIP_STRIDE2 and self.kernel_size == (1, 1) and self.stride == (2, 2) and self.padding == (0, 0) and self.bias is None
                   and self.in_channels % 32 == 0 and self.out_channels % 32 == 0):
                 kind = "1x1s2"
         self.__dict__["_hip_kind"] = (key, kind)
@@ -190,7 +192,7 @@ class Conv2d(nn.Conv2d):
                                                                      key[1], self.stride[0])
             fd_ok = ("f" in HIP_PASSES or "d" in HIP_PASSES) and (
                 capi.conv2d_fwd_supported(self.in_channels, self.out_channels, key[0], key[1]) if self.stride == (1, 1)
-                else (self.bias is None and capi.conv2d_s2_supported(self.in_channels, self.out_channels, 3)))
+                else (HIP_STRIDE2 and self.bias is None and capi.conv2d_s2_supported(self.in_channels, self.out_channels, 3)))
             ok = self._hip_ok = (key, w_ok, fd_ok)
         return ok[1] or ok[2]
 

@@ -32,6 +32,97 @@ def SPC_cat(a, b):
     return torch.cat([a, b], dim=1)
 
 
+class c2_probe:
+    """Shape stand-in for conv2's input (conv1's output) so that Conv2d._eligible can be asked before it exists."""
+
+    def __init__(self, x, stride):
+        self.shape = (x.shape[0], x.shape[1], (x.shape[2] - 1) // stride + 1, (x.shape[3] - 1) // stride + 1)
+
+
+def _split_of(w, ksize3):
+    """(forward operand, data-gradient operand) of a conv weight: from the one-launch presplit when still valid."""
+    from rslo_amd import capi
+    ws = getattr(w, "_hip_split", None)
+    if ws is not None and ws[2] == w._version and ws[3] == w.data_ptr():
+        return ws[0], ws[1]
+    if ksize3:
+        return capi.conv2d_wsplit(w, False), capi.conv2d_wsplit(w, True)
+    return capi.conv2d_wsplit_k(w, False), capi.conv2d_wsplit_k(w, True)
+
+
+class _BasicBlockFn(torch.autograd.Function):
+    """One autograd node for a whole BasicBlock on one rank:  y = act(bn2(conv2(act(bn1(conv1(x))))) + shortcut(x)),
+    shortcut = identity or bn_d(conv1x1_s2(x)).  The same kernels in the same order as the layer-by-layer path
+    (rslo_conv2d_fwd / _fwd_s2, rslo_bn2d_fwd_local, their backward counterparts) -- results are bit-identical -- but 1
+    node instead of 4-6: the interpreter / autograd-engine time per block drops by ~70 us per step, and the shortcut
+    gradient is added to the data gradient right here instead of by the engine's accumulation."""
+
+    @staticmethod
+    def forward(ctx, x, w1, g1, b1, w2, g2, b2, wd, gd, bd, blk, hip_w1):
+        from rslo_amd import capi, precision
+        from apex.parallel import count_batch
+        x = x.contiguous()
+        lp = precision.low_precision() is not None
+        slope = act_slope_of(blk.relu)
+        s = blk.stride
+        planes = w1.shape[0]
+
+        def bn_fwd(bn, t, res, g, b, sl):
+            track = bn.track_running_stats and bn.running_mean is not None
+            if track:
+                count_batch(bn)
+            return capi.bn2d_fwd_local(t, res, g, b, bn.running_mean if track else None, bn.running_var if track else None,
+                                       bn.momentum, bn.eps, sl)
+        w1f, w1t = _split_of(w1, True)
+        w2f, w2t = _split_of(w2, True)
+        o1 = capi.conv2d_fwd_s2(x, w1f, planes, 3) if s == 2 else capi.conv2d_fwd(x, w1f, None, planes, lp=lp)
+        y1, m1, i1 = bn_fwd(blk.bn1, o1, None, g1, b1, slope)
+        o2 = capi.conv2d_fwd(y1, w2f, None, planes, lp=lp)
+        wdt = od = md = idd = None
+        if wd is not None:
+            wdf, wdt = _split_of(wd, False)
+            od = capi.conv2d_fwd_s2(x, wdf, planes, 1)
+            res, md, idd = bn_fwd(blk.downsample[1], od, None, gd, bd, 1.0)
+        else:
+            res = x
+        y2, m2, i2 = bn_fwd(blk.bn2, o2, res, g2, b2, slope)
+        ctx.save_for_backward(x, w1, g1, w2, g2, wd, gd, o1, y1, m1, i1, o2, y2, m2, i2, od, md, idd)
+        ctx.ops = (w1t, w2t, wdt)
+        ctx.meta = (slope, s, lp, hip_w1)
+        return y2
+
+    @staticmethod
+    def backward(ctx, gy):
+        from rslo_amd import capi
+        x, w1, g1, w2, g2, wd, gd, o1, y1, m1, i1, o2, y2, m2, i2, od, md, idd = ctx.saved_tensors
+        w1t, w2t, wdt = ctx.ops
+        slope, s, lp, hip_w1 = ctx.meta
+        gy = gy.contiguous()
+        act = slope != 1.0
+        d_o2, d_res, dg2, db2 = capi.bn2d_bwd_local(gy, y2 if act else None, o2, g2, m2, i2, slope, act, True)
+        d_y1 = capi.conv2d_fwd(d_o2, w2t, None, w2.shape[1], lp=lp)
+        dw2 = capi.conv2d_wgrad(y1, d_o2, 1, lp=lp)
+        d_o1, _, dg1, db1 = capi.bn2d_bwd_local(d_y1, y1 if act else None, o1, g1, m1, i1, slope, act, False)
+        if s == 2:
+            dx = capi.conv2d_dgrad_s2(d_o1, w1t, w1.shape[1], x.shape[2], x.shape[3], 3)
+        else:
+            dx = capi.conv2d_fwd(d_o1, w1t, None, w1.shape[1], lp=lp)
+        if hip_w1:
+            dw1 = capi.conv2d_wgrad(x, d_o1, s, lp=lp)
+        else:       # the full-resolution stride-2 layer: the library's weight gradient (see csrc/conv2d.hip conv2d_plan)
+            dw1 = torch.ops.aten.convolution_backward(d_o1, x, w1, None, [s, s], [1, 1], [1, 1], False, [0, 0], 1,
+                                                      [False, True, False])[1]
+        dwd = dgd = dbd = None
+        if wd is not None:
+            d_od, _, dgd, dbd = capi.bn2d_bwd_local(d_res, None, od, gd, md, idd, 1.0, False, False)
+            dx.add_(capi.conv2d_dgrad_s2(d_od, wdt, wd.shape[1], x.shape[2], x.shape[3], 1))
+            xs = x[:, :, ::2, ::2].flatten(2)
+            dwd = torch.matmul(d_od.flatten(2), xs.transpose(1, 2)).sum(0).reshape(wd.shape)
+        else:
+            dx.add_(d_res)
+        return dx, dw1, dg1, db1, dw2, dg2, db2, dwd, dgd, dbd, None, None
+
+
 class BasicBlock(nn.Module):
     expansion = 1
 
@@ -50,7 +141,68 @@ class BasicBlock(nn.Module):
         self.stride = stride
         self.use_se = self.use_sa = False
 
+    def _fused_node_ok(self, x):
+        """The whole block as one autograd node (_BasicBlockFn): single rank, training, every layer on the hand-written
+        kernels.  RSLO_FUSED_BLOCK=0 keeps the layer-by-layer nodes."""
+        key = (tuple(x.shape), x.dtype, x.is_cuda, self.training, torch.is_grad_enabled())
+        cached = self.__dict__.get("_fused_ok")
+        if cached is None or cached[0] != key:
+            cached = self.__dict__["_fused_ok"] = (key, self._fused_node_check(x))
+        return cached[1]
+
+    def _fused_node_check(self, x):
+        import os
+        import torch.distributed as dist
+        from rslo.layers import hip_conv2d
+        if os.environ.get("RSLO_FUSED_BLOCK", "1") == "0" or not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4):
+            return False
+        if not (self.training and torch.is_grad_enabled() and hip_conv2d.HIP_PASSES == "wfd"):
+            return False
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            return False        # SyncBN statistics are exchanged between the kernels of a layer: layer-by-layer nodes
+        c1, c2 = getattr(self.conv1, "conv1", self.conv1), getattr(self.conv2, "conv1", self.conv2)
+        bns = [self.bn1, self.bn2]
+        convs = [c1, c2]
+        if self.downsample is not None:
+            mods = list(self.downsample.children()) if isinstance(self.downsample, nn.Sequential) else []
+            if len(mods) != 2:
+                return False
+            cd = getattr(mods[0], "conv1", mods[0])
+            if not (isinstance(cd, hip_conv2d.Conv2d) and cd._kind() == "1x1s2" and cd.stride == (2, 2)):
+                return False
+            bns.append(mods[1])
+            convs.append(cd)
+        for bn in bns:
+            if not (isinstance(bn, SPC_SyncBN2d) and hasattr(bn, "fusable") and bn.fusable(x) and bn.affine):
+                return False
+        for c in convs[:2]:
+            if not (isinstance(c, hip_conv2d.Conv2d) and c._kind() == "3x3" and c.bias is None and c.weight.requires_grad):
+                return False
+        if self.stride not in (1, 2) or c1.stride != (self.stride, self.stride) or c2.stride != (1, 1):
+            return False
+        if (self.downsample is None) != (self.stride == 1 and c1.in_channels == c1.out_channels):
+            return False
+        if not c1._eligible(x) or not c1._hip_ok[2]:
+            return False
+        if not (c2._eligible(c2_probe(x, self.stride)) and c2._hip_ok[1] and c2._hip_ok[2]):
+            return False
+        self._fused_hip_w1 = bool(c1._hip_ok[1])
+        return True
+
     def forward(self, x):
+        pair = isinstance(x, (list, tuple))
+        if (not pair or x[1] is None) and self._fused_node_ok(x[0] if pair else x):
+            t = x[0] if pair else x
+            c1, c2 = getattr(self.conv1, "conv1", self.conv1), getattr(self.conv2, "conv1", self.conv2)
+            if self.downsample is not None:
+                ds = list(self.downsample.children())
+                cd = getattr(ds[0], "conv1", ds[0])
+                wd, gd, bd = cd.weight, ds[1].weight, ds[1].bias
+            else:
+                wd = gd = bd = None
+            y = _BasicBlockFn.apply(t, c1.weight, self.bn1.weight, self.bn1.bias, c2.weight, self.bn2.weight,
+                                    self.bn2.bias, wd, gd, bd, self, self._fused_hip_w1)
+            return [y, None] if pair else y
         if isinstance(self.bn1, SPC_SyncBN2d) and isinstance(self.bn2, SPC_SyncBN2d):
             # BN + ReLU and BN + residual add + ReLU as fused epilogues of the normalisation kernels
             slope = act_slope_of(self.relu)

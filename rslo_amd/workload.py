@@ -89,7 +89,16 @@ class ExamplePrefetcher:
         # depth = examples prepared ahead of the one in use: submit() `depth` times before the first get().  With 2 the
         # example of step i+1 is already finished when step i ends, so a late helper thread no longer stalls the step.
         self.depth = max(1, int(depth))
-        self.stream = torch.cuda.Stream(self.device)
+        # the side stream runs at the lowest priority the device offers: its small integer kernels fill gaps, the
+        # training stream's kernels win the compute units when both are ready (RSLO_PREFETCH_PRIORITY overrides)
+        import os as _os
+        pr = _os.environ.get("RSLO_PREFETCH_PRIORITY")
+        if pr is None:
+            try:
+                pr = max(torch.cuda.Stream.priority_range())      # (lowest, highest): larger number = lower priority
+            except Exception:
+                pr = 0
+        self.stream = torch.cuda.Stream(self.device, priority=int(pr))
         self._in, self._out = queue.Queue(), queue.Queue()
         self._keep = []
         # Two Python threads issue GPU work here.  With the interpreter's default 5 ms switch interval the helper can

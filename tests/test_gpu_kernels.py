@@ -995,3 +995,43 @@ def test_conv1x1_kernels_match_oracle_and_autograd(hip, B, cin, cout, H, W):
     dW1, _ = hip.conv1x1_wgrad(x.detach(), gy)
     dW2, _ = hip.conv1x1_wgrad(x.detach(), gy)
     assert torch.equal(dW1, dW2)
+
+
+@pytest.mark.parametrize("stride", [1, 2])
+def test_basic_block_as_one_autograd_node_gives_the_same_bits(hip, stride, monkeypatch):
+    """custom_resnet_spc._BasicBlockFn (one autograd node per BasicBlock) against the layer-by-layer nodes
+    (RSLO_FUSED_BLOCK=0) on the same block: outputs, input gradient, every parameter gradient and the BatchNorm running
+    statistics are bit-identical -- same kernels, same order; the shortcut gradient is added in place of the engine's sum."""
+    import copy
+    from rslo.layers import hip_conv2d
+    from rslo.layers.MaskConv import MaskConv
+    from rslo.layers.SparseConv import FusedSequential, SPC_SyncBN2d
+    from rslo.models import custom_resnet_spc as R
+    torch.manual_seed(11 + stride)
+    inp, planes = (64, 64) if stride == 1 else (64, 128)
+    down = None
+    if stride == 2:
+        down = FusedSequential(R.conv1x1(inp, planes, 2, Conv2d=MaskConv), SPC_SyncBN2d(planes))
+    blk = R.BasicBlock(inp, planes, stride, down, BN=SPC_SyncBN2d, Conv2d=MaskConv).cuda().train()
+    for p in blk.parameters():
+        torch.nn.init.normal_(p, 0.0, 0.2)
+    ref = copy.deepcopy(blk)
+    x = torch.randn(2, inp, 24, 44, device="cuda")
+    g = torch.randn(2, planes, 24 // stride, 44 // stride, device="cuda")
+
+    def run(b, fused):
+        monkeypatch.setenv("RSLO_FUSED_BLOCK", "1" if fused else "0")
+        b.__dict__.pop("_fused_ok", None)
+        hip_conv2d.presplit(b)
+        xi = x.clone().requires_grad_(True)
+        y = b([xi, None])[0]
+        assert (type(y.grad_fn).__name__ == "_BasicBlockFnBackward") == fused
+        y.backward(g)
+        return y.detach(), xi.grad
+    ya, ga = run(blk, True)
+    yb, gb = run(ref, False)
+    assert torch.equal(ya, yb) and torch.equal(ga, gb)
+    for (n, p), (_, q) in zip(blk.named_parameters(), ref.named_parameters()):
+        assert p.grad is not None and torch.equal(p.grad, q.grad), n
+    for (n, p), (_, q) in zip(blk.named_buffers(), ref.named_buffers()):
+        assert torch.equal(p, q), n
