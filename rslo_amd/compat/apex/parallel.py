@@ -61,48 +61,57 @@ def _world(group):
     return dist.get_world_size(group) if group is not None else dist.get_world_size()
 
 
+def fused_bn_forward(bn, x, res, weight, bias, slope, group, world):
+    """y = act(BN_train(x) + res) through rslo_bn2d_* (x, res contiguous).  -> y, mean, invstd, cnt_all (the element
+    count over all ranks as a device scalar; None on one rank).  Updates bn's running statistics."""
+    from rslo_amd import capi
+    track = bn.track_running_stats and bn.running_mean is not None
+    mom = bn.momentum          # fusable() leaves momentum=None (cumulative average) to the unfused path
+    if world > 1:
+        stats = capi.bn2d_stats(x)
+        dist.all_reduce(stats, group=group)
+        y, mean, invstd = capi.bn2d_apply(x, res, stats, weight, bias, bn.running_mean if track else None,
+                                          bn.running_var if track else None, mom, bn.eps, slope)
+        return y, mean, invstd, stats[-1:]        # ranks may hold different batch sizes: the all-reduced count
+    # one rank: no exchange, the apply kernel adds the slice partials itself (two launches)
+    y, mean, invstd = capi.bn2d_fwd_local(x, res, weight, bias, bn.running_mean if track else None,
+                                          bn.running_var if track else None, mom, bn.eps, slope)
+    return y, mean, invstd, None
+
+
+def fused_bn_backward(gy, y, x, weight, mean, invstd, cnt_all, slope, has_res, affine, group, world):
+    """-> dx, dres, dgamma, dbeta (dgamma / dbeta are this rank's sums: data parallel averages them afterwards)."""
+    from rslo_amd import capi
+    has_act = slope != 1.0
+    if world == 1:
+        return capi.bn2d_bwd_local(gy, y, x, weight, mean, invstd, slope, has_act, has_res, want_affine=affine)
+    red, dgamma, dbeta = capi.bn2d_bwd_reduce(gy, y, x, mean, invstd, slope, has_act, want_affine=affine)
+    dist.all_reduce(red, group=group)
+    # the count all-reduced in the forward pass, read on the device: exact for uneven per-rank batches, no host sync
+    dx, dres = capi.bn2d_bwd_apply(gy, y, x, weight, mean, invstd, red, 0.0, slope, has_act, has_res, count_dev=cnt_all)
+    return dx, dres, dgamma, dbeta
+
+
 class _FusedBNActFn(torch.autograd.Function):
     """y = act(BN_train(x) + residual) through rslo_bn2d_* (rslo_amd/csrc/bn2d.hip).  Statistics are over all ranks of
     `group`: the per-channel sums are all-reduced between the two kernels of each direction (skipped on one rank)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, residual, bn, slope, group):
-        from rslo_amd import capi
         x = x.contiguous()
         res = None if residual is None else residual.contiguous()
         world = _world(group)
-        track = bn.track_running_stats and bn.running_mean is not None
-        mom = bn.momentum          # fusable() leaves momentum=None (cumulative average) to the unfused path
-        cnt_all = None
-        if world > 1:
-            stats = capi.bn2d_stats(x)
-            dist.all_reduce(stats, group=group)
-            y, mean, invstd = capi.bn2d_apply(x, res, stats, weight, bias, bn.running_mean if track else None,
-                                              bn.running_var if track else None, mom, bn.eps, slope)
-            cnt_all = stats[-1:]        # element count over all ranks (ranks may hold different batch sizes)
-        else:           # one rank: no exchange, the apply kernel adds the slice partials itself (two launches)
-            y, mean, invstd = capi.bn2d_fwd_local(x, res, weight, bias, bn.running_mean if track else None,
-                                                  bn.running_var if track else None, mom, bn.eps, slope)
+        y, mean, invstd, cnt_all = fused_bn_forward(bn, x, res, weight, bias, slope, group, world)
         ctx.save_for_backward(x, y if slope != 1.0 else None, weight, mean, invstd, cnt_all)
         ctx.meta = (slope, group, world, residual is not None, weight is not None)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        from rslo_amd import capi
         x, y, weight, mean, invstd, cnt_all = ctx.saved_tensors
         slope, group, world, has_res, affine = ctx.meta
-        gy = gy.contiguous()
-        has_act = slope != 1.0
-        if world == 1:
-            dx, dres, dgamma, dbeta = capi.bn2d_bwd_local(gy, y, x, weight, mean, invstd, slope, has_act, has_res,
-                                                          want_affine=affine)
-            return dx, dgamma, dbeta, dres, None, None, None
-        red, dgamma, dbeta = capi.bn2d_bwd_reduce(gy, y, x, mean, invstd, slope, has_act, want_affine=affine)
-        dist.all_reduce(red, group=group)
-        # the count all-reduced in the forward pass, read on the device: exact for uneven per-rank batches, no host sync
-        dx, dres = capi.bn2d_bwd_apply(gy, y, x, weight, mean, invstd, red, 0.0, slope, has_act, has_res,
-                                       count_dev=cnt_all)
+        dx, dres, dgamma, dbeta = fused_bn_backward(gy.contiguous(), y, x, weight, mean, invstd, cnt_all, slope, has_res,
+                                                    affine, group, world)
         return dx, dgamma, dbeta, dres, None, None, None
 
 

@@ -51,7 +51,7 @@ def _split_of(w, ksize3):
 
 
 class _BasicBlockFn(torch.autograd.Function):
-    """One autograd node for a whole BasicBlock on one rank:  y = act(bn2(conv2(act(bn1(conv1(x))))) + shortcut(x)),
+    """One autograd node for a whole BasicBlock:  y = act(bn2(conv2(act(bn1(conv1(x))))) + shortcut(x)),
     shortcut = identity or bn_d(conv1x1_s2(x)).  The same kernels in the same order as the layer-by-layer path
     (rslo_conv2d_fwd / _fwd_s2, rslo_bn2d_fwd_local, their backward counterparts) -- results are bit-identical -- but 1
     node instead of 4-6: the interpreter / autograd-engine time per block drops by ~70 us per step, and the shortcut
@@ -60,49 +60,51 @@ class _BasicBlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w1, g1, b1, w2, g2, b2, wd, gd, bd, blk, hip_w1):
         from rslo_amd import capi, precision
-        from apex.parallel import count_batch
+        from apex.parallel import _world, count_batch, fused_bn_forward
         x = x.contiguous()
         lp = precision.low_precision() is not None
         slope = act_slope_of(blk.relu)
         s = blk.stride
         planes = w1.shape[0]
 
+        group = blk.bn1.process_group
+        world = _world(group)
+
         def bn_fwd(bn, t, res, g, b, sl):
-            track = bn.track_running_stats and bn.running_mean is not None
-            if track:
+            if bn.track_running_stats:
                 count_batch(bn)
-            return capi.bn2d_fwd_local(t, res, g, b, bn.running_mean if track else None, bn.running_var if track else None,
-                                       bn.momentum, bn.eps, sl)
+            return fused_bn_forward(bn, t, res, g, b, sl, group, world)
         w1f, w1t = _split_of(w1, True)
         w2f, w2t = _split_of(w2, True)
         o1 = capi.conv2d_fwd_s2(x, w1f, planes, 3) if s == 2 else capi.conv2d_fwd(x, w1f, None, planes, lp=lp)
-        y1, m1, i1 = bn_fwd(blk.bn1, o1, None, g1, b1, slope)
+        y1, m1, i1, n1 = bn_fwd(blk.bn1, o1, None, g1, b1, slope)
         o2 = capi.conv2d_fwd(y1, w2f, None, planes, lp=lp)
-        wdt = od = md = idd = None
+        wdt = od = md = idd = nd = None
         if wd is not None:
             wdf, wdt = _split_of(wd, False)
             od = capi.conv2d_fwd_s2(x, wdf, planes, 1)
-            res, md, idd = bn_fwd(blk.downsample[1], od, None, gd, bd, 1.0)
+            res, md, idd, nd = bn_fwd(blk.downsample[1], od, None, gd, bd, 1.0)
         else:
             res = x
-        y2, m2, i2 = bn_fwd(blk.bn2, o2, res, g2, b2, slope)
-        ctx.save_for_backward(x, w1, g1, w2, g2, wd, gd, o1, y1, m1, i1, o2, y2, m2, i2, od, md, idd)
+        y2, m2, i2, n2 = bn_fwd(blk.bn2, o2, res, g2, b2, slope)
+        ctx.save_for_backward(x, w1, g1, w2, g2, wd, gd, o1, y1, m1, i1, n1, o2, y2, m2, i2, n2, od, md, idd, nd)
         ctx.ops = (w1t, w2t, wdt)
-        ctx.meta = (slope, s, lp, hip_w1)
+        ctx.meta = (slope, s, lp, hip_w1, group, world)
         return y2
 
     @staticmethod
     def backward(ctx, gy):
         from rslo_amd import capi
-        x, w1, g1, w2, g2, wd, gd, o1, y1, m1, i1, o2, y2, m2, i2, od, md, idd = ctx.saved_tensors
+        from apex.parallel import fused_bn_backward
+        x, w1, g1, w2, g2, wd, gd, o1, y1, m1, i1, n1, o2, y2, m2, i2, n2, od, md, idd, nd = ctx.saved_tensors
         w1t, w2t, wdt = ctx.ops
-        slope, s, lp, hip_w1 = ctx.meta
+        slope, s, lp, hip_w1, group, world = ctx.meta
         gy = gy.contiguous()
         act = slope != 1.0
-        d_o2, d_res, dg2, db2 = capi.bn2d_bwd_local(gy, y2 if act else None, o2, g2, m2, i2, slope, act, True)
+        d_o2, d_res, dg2, db2 = fused_bn_backward(gy, y2 if act else None, o2, g2, m2, i2, n2, slope, True, True, group, world)
         d_y1 = capi.conv2d_fwd(d_o2, w2t, None, w2.shape[1], lp=lp)
         dw2 = capi.conv2d_wgrad(y1, d_o2, 1, lp=lp)
-        d_o1, _, dg1, db1 = capi.bn2d_bwd_local(d_y1, y1 if act else None, o1, g1, m1, i1, slope, act, False)
+        d_o1, _, dg1, db1 = fused_bn_backward(d_y1, y1 if act else None, o1, g1, m1, i1, n1, slope, False, True, group, world)
         if s == 2:
             dx = capi.conv2d_dgrad_s2(d_o1, w1t, w1.shape[1], x.shape[2], x.shape[3], 3)
         else:
@@ -114,7 +116,7 @@ class _BasicBlockFn(torch.autograd.Function):
                                                       [False, True, False])[1]
         dwd = dgd = dbd = None
         if wd is not None:
-            d_od, _, dgd, dbd = capi.bn2d_bwd_local(d_res, None, od, gd, md, idd, 1.0, False, False)
+            d_od, _, dgd, dbd = fused_bn_backward(d_res, None, od, gd, md, idd, nd, 1.0, False, True, group, world)
             dx.add_(capi.conv2d_dgrad_s2(d_od, wdt, wd.shape[1], x.shape[2], x.shape[3], 1))
             xs = x[:, :, ::2, ::2].flatten(2)
             dwd = torch.matmul(d_od.flatten(2), xs.transpose(1, 2)).sum(0).reshape(wd.shape)
@@ -142,8 +144,9 @@ class BasicBlock(nn.Module):
         self.use_se = self.use_sa = False
 
     def _fused_node_ok(self, x):
-        """The whole block as one autograd node (_BasicBlockFn): single rank, training, every layer on the hand-written
-        kernels.  RSLO_FUSED_BLOCK=0 keeps the layer-by-layer nodes."""
+        """The whole block as one autograd node (_BasicBlockFn): training, every layer on the hand-written kernels (any
+        number of ranks: the SyncBN statistics exchange happens inside the node, as in _FusedBNActFn).
+        RSLO_FUSED_BLOCK=0 keeps the layer-by-layer nodes."""
         key = (tuple(x.shape), x.dtype, x.is_cuda, self.training, torch.is_grad_enabled())
         cached = self.__dict__.get("_fused_ok")
         if cached is None or cached[0] != key:
@@ -152,14 +155,11 @@ class BasicBlock(nn.Module):
 
     def _fused_node_check(self, x):
         import os
-        import torch.distributed as dist
         from rslo.layers import hip_conv2d
         if os.environ.get("RSLO_FUSED_BLOCK", "1") == "0" or not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4):
             return False
         if not (self.training and torch.is_grad_enabled() and hip_conv2d.HIP_PASSES == "wfd"):
             return False
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            return False        # SyncBN statistics are exchanged between the kernels of a layer: layer-by-layer nodes
         c1, c2 = getattr(self.conv1, "conv1", self.conv1), getattr(self.conv2, "conv1", self.conv2)
         bns = [self.bn1, self.bn2]
         convs = [c1, c2]
@@ -173,7 +173,8 @@ class BasicBlock(nn.Module):
             bns.append(mods[1])
             convs.append(cd)
         for bn in bns:
-            if not (isinstance(bn, SPC_SyncBN2d) and hasattr(bn, "fusable") and bn.fusable(x) and bn.affine):
+            if not (isinstance(bn, SPC_SyncBN2d) and hasattr(bn, "fusable") and bn.fusable(x) and bn.affine
+                    and bn.process_group is bns[0].process_group):
                 return False
         for c in convs[:2]:
             if not (isinstance(c, hip_conv2d.Conv2d) and c._kind() == "3x3" and c.bias is None and c.weight.requires_grad):

@@ -614,6 +614,60 @@ def _syncbn_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _block_worker(rank, world, port, q):
+    import copy
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)     # two ranks on ONE GPU
+    import rslo_amd  # noqa: F401
+    from rslo.layers import hip_conv2d
+    from rslo.layers.MaskConv import MaskConv
+    from rslo.layers.SparseConv import FusedSequential, SPC_SyncBN2d
+    from rslo.models import custom_resnet_spc as R
+    torch.manual_seed(21)
+    down = FusedSequential(R.conv1x1(64, 128, 2, Conv2d=MaskConv), SPC_SyncBN2d(128))
+    blk = R.BasicBlock(64, 128, 2, down, BN=SPC_SyncBN2d, Conv2d=MaskConv).cuda().train()
+    for p in blk.parameters():
+        torch.nn.init.normal_(p, 0.0, 0.2)
+    ref = copy.deepcopy(blk)
+    full = torch.randn(4, 64, 24, 44)
+    g_full = torch.randn(4, 128, 12, 22)
+    sl = slice(2 * rank, 2 * rank + 2)
+    outs = []
+    for b, fused in ((blk, True), (ref, False)):
+        os.environ["RSLO_FUSED_BLOCK"] = "1" if fused else "0"
+        b.__dict__.pop("_fused_ok", None)
+        hip_conv2d.presplit(b)
+        x = full[sl].cuda().requires_grad_(True)
+        y = b([x, None])[0]
+        assert (type(y.grad_fn).__name__ == "_BasicBlockFnBackward") == fused
+        y.backward(g_full[sl].cuda())
+        outs.append([y.detach().cpu(), x.grad.cpu()] + [p.grad.cpu() for p in b.parameters()] + [t.cpu() for t in b.buffers()])
+    same = all(torch.equal(a, c) for a, c in zip(*outs))
+    q.put((rank, same, float(outs[0][0].abs().mean())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_fused_block_node_with_two_ranks_equals_layer_nodes(hip):
+    """_BasicBlockFn under SyncBN with two ranks (gloo, one GPU): the statistics exchanges happen inside the node in the
+    same order as the layer-by-layer nodes issue them -> identical bits on every rank."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_block_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted([q.get(timeout=300) for _ in range(2)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(o[1] for o in out) and all(o[2] > 0 for o in out), out
+
+
 def test_fused_syncbn_two_ranks_equals_full_batch(hip):
     """Two processes (gloo, same GPU) each hold half of a batch: the fused SyncBatchNorm path must reproduce
     BatchNorm over the whole batch -- outputs, input / residual gradients, running statistics; the affine gradients are
