@@ -12,7 +12,7 @@ f = glob.glob("%s/**/*counter_collection.csv" % sys.argv[1], recursive=True)[0]
 per = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in csv.DictReader(open(f)):
     n = d["Kernel_Name"]
-    if any(k in n for k in ("k_spconv", "k_wgrad", "k_conv2d_fwd", "k_conv2d_wgrad_s1", "k_conv2d_wgrad<", "miopenSp3", "igemm")):
+    if any(k in n for k in ("k_spconv", "k_wgrad", "k_conv2d_fwd", "k_conv2d_wgrad_s1", "k_conv2d_wgrad<", "k_conv2d_str", "miopenSp3", "igemm")):
         per[re.sub(r"^void ", "", n.split("(")[0])[:60]][d["Counter_Name"]].append(float(d["Counter_Value"]))
 import hashlib
 out = {"lib_sha256": hashlib.sha256(open(sys.argv[3], "rb").read()).hexdigest()[:16],
