@@ -465,7 +465,8 @@ RSLO_API int rslo_pose_targets(const float *res_r, const float *res_t, const flo
 /* f1   optimizer step of the training driver: global gradient-norm clipping (train_hdf5.py:671,
  *      torch.nn.utils.clip_grad_norm_) and torch.optim.Adam under the fastai OptimWrapper's decoupled weight decay
  *      (rslo/torchplus/train/fastai_optim.py:176-187; 8 parameter groups, rslo/builder/optimizer_builder.py:49-66) over
- *      all parameter tensors at once.  tensors_dev: device array, one entry per tensor that has a gradient;
+ *      all parameter tensors at once.  tensors_dev: device array, one entry per trainable tensor (grad = NULL: no
+ *      gradient this step -- excluded from the norm, decayed but not stepped, like the wrapper does);
  *      chunks_dev: device array cutting the tensors into pieces of <= 4096 elements (offsets multiples of 4), one
  *      workgroup each.  State lives in the caller's tensors (exp_avg, exp_avg_sq, step = torch.optim.Adam's).
  *      rslo_opt_clip_grad_norm: total_norm[0] = || all grads ||_2 (device scalar, no host read); grads are scaled by
@@ -482,7 +483,7 @@ typedef struct {
   int64_t offset;
 } RsloOptChunk;
 typedef struct {
-  float lr, beta1, beta2, eps, weight_decay;           /* weight_decay = the wrapper's decoupled wd (0: none) */
+  double lr, beta1, beta2, eps, weight_decay;          /* weight_decay = the wrapper's decoupled wd (0: none) */
 } RsloOptGroup;
 #define RSLO_OPT_MAX_GROUPS 16
 typedef struct {

@@ -19,7 +19,12 @@ __global__ __launch_bounds__(OPT_THREADS) void k_opt_sqnorm(const RsloOptTensor 
                                                             const RsloOptChunk *__restrict__ chunks,
                                                             double *__restrict__ partial) {
   const RsloOptChunk c = chunks[blockIdx.x];
-  const float *__restrict__ g = tensors[c.tensor].grad + c.offset;
+  const float *__restrict__ g = tensors[c.tensor].grad;
+  if (g == nullptr) {      // no gradient this step (uniform per block)
+    if (threadIdx.x == 0) partial[blockIdx.x] = 0.0;
+    return;
+  }
+  g += c.offset;
   double s = 0.0;
   const int n4 = (c.count / 4) * 4;
   for (int i = threadIdx.x * 4; i < n4; i += OPT_THREADS * 4) {       // chunk offsets are multiples of 4 elements
@@ -59,7 +64,9 @@ __global__ __launch_bounds__(OPT_THREADS) void k_opt_clip(const RsloOptTensor *_
   const float coef = max_norm / (norm + 1e-6f);        // torch: clip_coef = max_norm / (total_norm + 1e-6), clamped to 1
   if (!(coef < 1.0f)) return;
   const RsloOptChunk c = chunks[blockIdx.x];
-  float *__restrict__ g = tensors[c.tensor].grad + c.offset;
+  float *__restrict__ g = tensors[c.tensor].grad;
+  if (g == nullptr) return;
+  g += c.offset;
   const int n4 = (c.count / 4) * 4;
   for (int i = threadIdx.x * 4; i < n4; i += OPT_THREADS * 4) {
     float4 v = *reinterpret_cast<float4 *>(g + i);
@@ -72,13 +79,18 @@ __global__ __launch_bounds__(OPT_THREADS) void k_opt_clip(const RsloOptTensor *_
 // torch.optim.Adam (amsgrad = False, maximize = False, weight_decay = 0) after the wrapper's decoupled decay:
 //   p <- p (1 - wd lr);  m <- b1 m + (1 - b1) g;  v <- b2 v + (1 - b2) g g
 //   p <- p - (lr / (1 - b1^t)) m / (sqrt(v) / sqrt(1 - b2^t) + eps)
-__device__ __forceinline__ void adam_elem(float &p, float g, float &m, float &v, float decay, float b1, float b2,
-                                          float step_size, float sqrt_bc2, float eps) {
+// torch's fused kernel evaluates these with the hyper-parameters as doubles (so 1 - beta2 = 0.001 is not rounded to
+// fp32 first: in fp32, 1 - 0.999f is off by 1.3e-5 relative); the same here -- the kernel is bound by its 28 bytes per
+// element, the fp64 operations are free.
+__device__ __forceinline__ void adam_elem(float &p, float g, float &m, float &v, float decay, double b1, double b2,
+                                          double step_size, double sqrt_bc2, double eps) {
   p *= decay;
-  m = m + (1.0f - b1) * (g - m);      // torch: exp_avg.lerp_(grad, 1 - beta1)
-  v = b2 * v + (1.0f - b2) * g * g;
-  const float denom = sqrtf(v) / sqrt_bc2 + eps;
-  p -= (step_size * m) / denom;
+  const double md = b1 * (double)m + (1.0 - b1) * (double)g;
+  const double vd = b2 * (double)v + (1.0 - b2) * (double)g * (double)g;
+  m = (float)md;
+  v = (float)vd;
+  const double denom = sqrt(vd) / sqrt_bc2 + eps;
+  p = (float)((double)p - step_size * md / denom);
 }
 
 __global__ __launch_bounds__(OPT_THREADS) void k_opt_adam(const RsloOptTensor *__restrict__ tensors,
@@ -87,14 +99,27 @@ __global__ __launch_bounds__(OPT_THREADS) void k_opt_adam(const RsloOptTensor *_
   const RsloOptChunk c = chunks[blockIdx.x];
   const RsloOptTensor t = tensors[c.tensor];
   const RsloOptGroup h = hyper.group[t.group];
-  const double bc1 = 1.0 - pow((double)h.beta1, (double)step), bc2 = 1.0 - pow((double)h.beta2, (double)step);
-  const float step_size = (float)((double)h.lr / bc1), sqrt_bc2 = (float)sqrt(bc2);
-  const float decay = 1.0f - h.weight_decay * h.lr;
+  const double bc1 = 1.0 - pow(h.beta1, (double)step), bc2 = 1.0 - pow(h.beta2, (double)step);
+  const double step_size = h.lr / bc1, sqrt_bc2 = sqrt(bc2);
+  const float decay = (float)(1.0 - h.weight_decay * h.lr);      // torch._foreach_mul_(params, 1 - wd * lr): fp32 product
   float *__restrict__ p = t.param + c.offset;
+  const int n4 = (c.count / 4) * 4;
+  if (t.grad == nullptr) {
+    // no gradient this step: torch.optim.Adam skips the tensor, the wrapper's decoupled decay does not
+    // (fastai_optim.py:176-187 multiplies every requires_grad parameter)
+    if (decay != 1.0f) {
+      for (int i = threadIdx.x * 4; i < n4; i += OPT_THREADS * 4) {
+        float4 pp = *reinterpret_cast<float4 *>(p + i);
+        pp.x *= decay; pp.y *= decay; pp.z *= decay; pp.w *= decay;
+        *reinterpret_cast<float4 *>(p + i) = pp;
+      }
+      for (int i = n4 + threadIdx.x; i < c.count; i += OPT_THREADS) p[i] *= decay;
+    }
+    return;
+  }
   const float *__restrict__ g = t.grad + c.offset;
   float *__restrict__ m = t.exp_avg + c.offset;
   float *__restrict__ v = t.exp_avg_sq + c.offset;
-  const int n4 = (c.count / 4) * 4;
   for (int i = threadIdx.x * 4; i < n4; i += OPT_THREADS * 4) {
     float4 pp = *reinterpret_cast<float4 *>(p + i), mm = *reinterpret_cast<float4 *>(m + i),
            vv = *reinterpret_cast<float4 *>(v + i);

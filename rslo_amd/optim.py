@@ -26,8 +26,8 @@ _CHUNK_DT = np.dtype([("tensor", "<i4"), ("count", "<i4"), ("offset", "<i8")])
 
 
 class _Group(C.Structure):
-    _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
-                ("weight_decay", C.c_float)]
+    _fields_ = [("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
+                ("weight_decay", C.c_double)]
 
 
 class _Hyper(C.Structure):
@@ -39,8 +39,9 @@ def _usable(p):
 
 
 class AdamStepper:
-    """Tables for one torch.optim.Adam instance.  `params` order = param_groups order; a tensor takes part in a step
-    when it has a gradient (77 of the network's 290 tensors never do: SURVEY App-A.2)."""
+    """Tables for one torch.optim.Adam instance over all trainable tensors, param_groups order.  A tensor without a
+    gradient in a step (77 of the network's 290 never get one: SURVEY App-A.2) is left out of the norm and of the moment
+    update but still decays, as under the reference's wrapper."""
 
     def __init__(self, opt):
         self.opt = opt
@@ -67,39 +68,46 @@ class AdamStepper:
         return any(len(g["params"]) for g in opt.param_groups)
 
     # ------------------------------------------------------------------ tables
-    def _active(self):
-        out = []
-        for gi, g in enumerate(self.opt.param_groups):
-            for p in g["params"]:
-                if p.grad is not None:
-                    out.append((gi, p))
-        return out
+    def _all(self):
+        return [(gi, p) for gi, g in enumerate(self.opt.param_groups) for p in g["params"] if p.requires_grad]
 
-    def _build(self, active):
-        dev = active[0][1].device
+    def _init_state(self, p):
+        """What torch.optim.Adam._init_group creates for a fused optimizer."""
+        st = self.opt.state[p]
+        st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
+        st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+
+    def _build(self, tensors):
+        """Tables over ALL trainable tensors (the decoupled decay touches every one of them; the moment update only those
+        that have a gradient in the step at hand)."""
+        dev = tensors[0][1].device
         state = self.opt.state
-        steps = set()
-        for gi, p in active:
+        with_state = []
+        for gi, p in tensors:
             st = state[p]
-            if len(st) == 0:        # what torch.optim.Adam._init_group creates for a fused / capturable optimizer
-                st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
-                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            if len(st) == 0:
+                if p.grad is None:
+                    continue
+                self._init_state(p)
             if not (_usable(st["exp_avg"]) and _usable(st["exp_avg_sq"])):
                 return False
             if not (isinstance(st["step"], torch.Tensor) and st["step"].is_cuda and st["step"].dtype == torch.float32):
                 st["step"] = torch.as_tensor(float(st["step"]), dtype=torch.float32, device=p.device)
-        for s in torch.stack([state[p]["step"] for _, p in active]).tolist():      # one host read, at (re)build time only
-            steps.add(int(s))
-        if len(steps) != 1:
+            with_state.append(p)
+        steps = set()
+        if with_state:      # one host read, at (re)build time only
+            steps = {int(v) for v in torch.stack([state[p]["step"] for p in with_state]).tolist()}
+        if len(steps) > 1:
             return False            # tensors that joined later carry their own count: leave those to torch
-        self.step_count = steps.pop()
-        n = len(active)
-        host = np.zeros(n, _TENSOR_DT)
+        self.step_count = steps.pop() if steps else 0
+        host = np.zeros(len(tensors), _TENSOR_DT)
         chunks = []
-        for i, (gi, p) in enumerate(active):
+        for i, (gi, p) in enumerate(tensors):
             st = state[p]
-            host[i] = (p.data_ptr(), 0, st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), st["step"].data_ptr(), gi, 0)
+            has = len(st) > 0
+            host[i] = (p.data_ptr(), 0, st["exp_avg"].data_ptr() if has else 0, st["exp_avg_sq"].data_ptr() if has else 0,
+                       st["step"].data_ptr() if has else 0, gi, 0)
             numel = p.numel()
             for off in range(0, numel, CHUNK):
                 chunks.append((i, min(CHUNK, numel - off), off))
@@ -112,30 +120,48 @@ class AdamStepper:
         self.total_norm = torch.zeros((), dtype=torch.float32, device=dev)
         self._ring = [torch.empty(host.nbytes, dtype=torch.uint8).pin_memory() for _ in range(4)]
         self.grad_ptrs = None
-        self.active = active
-        self.key = tuple(id(p) for _, p in active)
+        self.tensors = tensors
+        self.has_state = np.array([len(state[p]) > 0 for _, p in tensors])
+        self.key = tuple(id(p) for _, p in tensors)
         return True
 
     def _refresh(self):
-        """Tables for the tensors that have a gradient now; False if this step has to go through torch."""
-        active = self._active()
-        if not active:
+        """Tables with this step's gradient pointers; False if this step has to go through torch."""
+        tensors = self._all()
+        if not tensors:
             return False
         if self.key is not None:      # cheap staleness probe (someone replaced opt.state behind our back)
-            st0 = self.opt.state.get(self.active[0][1], {})
-            if "exp_avg" not in st0 or st0["exp_avg"].data_ptr() != int(self.host["exp_avg"][0]):
-                self.key = None
-        if self.key != tuple(id(p) for _, p in active):
-            if not self._build(active):
+            probe = int(np.argmax(self.has_state)) if self.has_state.any() else None
+            if probe is not None:
+                st0 = self.opt.state.get(self.tensors[probe][1], {})
+                if "exp_avg" not in st0 or st0["exp_avg"].data_ptr() != int(self.host["exp_avg"][probe]):
+                    self.key = None
+        if self.key != tuple(id(p) for _, p in tensors):
+            if not self._build(tensors):
                 self.key = None
                 return False
-        ptrs = np.fromiter((p.grad.data_ptr() for _, p in active), dtype=np.uint64, count=len(active))
-        for _, p in active:
+        ptrs = np.zeros(len(tensors), dtype=np.uint64)
+        for i, (_, p) in enumerate(tensors):
             g = p.grad
+            if g is None:
+                continue
             if g.dtype != torch.float32 or not g.is_contiguous() or not g.is_cuda:
                 return False
+            ptrs[i] = g.data_ptr()
         if (ptrs % 16).any():
             return False
+        late = (ptrs != 0) & ~self.has_state
+        if late.any():
+            if self.step_count > 0:
+                return False        # a tensor receives its first gradient after others were stepped: torch keeps per-tensor counts
+            for i in np.nonzero(late)[0]:
+                p = self.tensors[i][1]
+                self._init_state(p)
+                st = self.opt.state[p]
+                self.host["exp_avg"][i], self.host["exp_avg_sq"][i] = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+                self.host["step"][i] = st["step"].data_ptr()
+                self.has_state[i] = True
+            self.grad_ptrs = None
         if self.grad_ptrs is None or not np.array_equal(ptrs, self.grad_ptrs):
             self.host["grad"] = ptrs
             pin = self._ring[self._ring_pos]
@@ -143,7 +169,7 @@ class AdamStepper:
             pin.numpy()[:] = self.host.view(np.uint8)
             self.tensors_dev.copy_(pin, non_blocking=True)
             self.grad_ptrs = ptrs
-        return True
+        return bool(ptrs.any())
 
     # ------------------------------------------------------------------ the two operations
     def clip_grad_norm_(self, max_norm):
