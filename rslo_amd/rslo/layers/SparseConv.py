@@ -138,6 +138,64 @@ class SparseConv(nn.Module):
         return self.sparse_conv(x[0], x[1])
 
 
+class _ConvBNActFn(torch.autograd.Function):
+    """y = act(bn(conv3x3_s1(x) + bias)) as ONE autograd node (the skip / deblock / prediction trunks of the BEV head:
+    Conv2d -> SyncBN -> ReLU triples outside the BasicBlocks).  Same kernels in the same order as the two nodes it
+    replaces (rslo_conv2d_fwd, rslo_bn2d_*, rslo_conv2d_wgrad with the bias gradient from the same pass): bit-identical."""
+
+    @staticmethod
+    def forward(ctx, x, w, cb, g, b, conv, bn, slope):
+        from rslo_amd import capi, precision
+        from apex.parallel import _world, count_batch, fused_bn_forward
+        x = x.contiguous()
+        lp = precision.low_precision() is not None
+        ws = getattr(w, "_hip_split", None)
+        if ws is not None and (ws[2] != w._version or ws[3] != w.data_ptr()):
+            ws = None
+        wf, wt = (ws[0], ws[1]) if ws is not None else (capi.conv2d_wsplit(w, False), capi.conv2d_wsplit(w, True))
+        group = bn.process_group
+        world = _world(group)
+        o = capi.conv2d_fwd(x, wf, cb, w.shape[0], lp=lp)
+        if bn.track_running_stats:
+            count_batch(bn)
+        y, mean, invstd, cnt = fused_bn_forward(bn, o, None, g, b, slope, group, world)
+        ctx.save_for_backward(x, w, g, o, y if slope != 1.0 else None, mean, invstd, cnt)
+        ctx.meta = (wt, slope, lp, cb is not None, group, world)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        from rslo_amd import capi
+        from apex.parallel import fused_bn_backward
+        x, w, g, o, y, mean, invstd, cnt = ctx.saved_tensors
+        wt, slope, lp, has_bias, group, world = ctx.meta
+        d_o, _, dg, db = fused_bn_backward(gy.contiguous(), y, o, g, mean, invstd, cnt, slope, False, True, group, world)
+        dx = capi.conv2d_fwd(d_o, wt, None, w.shape[1], lp=lp) if ctx.needs_input_grad[0] else None
+        dcb = None
+        if has_bias:
+            dw, dcb = capi.conv2d_wgrad(x, d_o, 1, want_bias=True, lp=lp)
+        else:
+            dw = capi.conv2d_wgrad(x, d_o, 1, lp=lp)
+        return dx, dw, dcb, dg, db, None, None, None
+
+
+def _conv_bn_fusable(conv, bn, x):
+    """Static + shape-dependent eligibility of a (Conv2d, SyncBN) pair for _ConvBNActFn, cached on the conv module."""
+    import os
+    from rslo.layers import hip_conv2d
+    key = (tuple(x.shape), x.dtype, x.is_cuda, conv.training, bn.training, torch.is_grad_enabled())
+    cached = conv.__dict__.get("_convbn_ok")
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    ok = (os.environ.get("RSLO_FUSED_BLOCK", "1") != "0" and isinstance(conv, hip_conv2d.Conv2d) and x.is_cuda
+          and x.dtype == torch.float32 and x.dim() == 4 and bn.training and torch.is_grad_enabled()
+          and hip_conv2d.HIP_PASSES == "wfd" and conv._kind() == "3x3" and conv.stride == (1, 1)
+          and conv.weight.requires_grad and hasattr(bn, "fusable") and bn.fusable(x) and bn.affine
+          and conv._eligible(x) and conv._hip_ok[1] and conv._hip_ok[2])
+    conv.__dict__["_convbn_ok"] = (key, bool(ok))
+    return bool(ok)
+
+
 class FusedSequential(nn.Sequential):
     """nn.Sequential that hands a following (Leaky)ReLU to a normalisation layer able to fuse it (the ROCm
     SyncBatchNorm stand-in: one kernel pair per direction for BN + activation).  Same children, same state-dict keys,
@@ -150,10 +208,15 @@ class FusedSequential(nn.Sequential):
             return steps
         mods = list(self._modules.values())
         steps, i = [], 0
+        from rslo.layers import hip_conv2d
         while i < len(mods):
             m = mods[i]
             slope = act_slope_of(mods[i + 1]) if i + 1 < len(mods) else None
-            if slope is not None and isinstance(m, SPC_SyncBN2d):
+            if (isinstance(m, hip_conv2d.Conv2d) and i + 2 < len(mods) and isinstance(mods[i + 1], SPC_SyncBN2d)
+                    and act_slope_of(mods[i + 2]) is not None):
+                steps.append(((m, mods[i + 1]), act_slope_of(mods[i + 2])))       # conv -> BN -> act: one node when eligible
+                i += 3
+            elif slope is not None and isinstance(m, SPC_SyncBN2d):
                 steps.append((m, slope))
                 i += 2
             else:
@@ -181,5 +244,12 @@ class FusedSequential(nn.Sequential):
 
     def forward(self, x):
         for m, slope in self._steps():
-            x = m(x) if slope is None else m(x, act_slope=slope)
+            if isinstance(m, tuple):
+                conv, bn = m
+                if isinstance(x, torch.Tensor) and _conv_bn_fusable(conv, bn, x):
+                    x = _ConvBNActFn.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, conv, bn, slope)
+                else:
+                    x = bn(conv(x), act_slope=slope)
+            else:
+                x = m(x) if slope is None else m(x, act_slope=slope)
         return x

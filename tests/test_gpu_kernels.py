@@ -1089,3 +1089,42 @@ def test_basic_block_as_one_autograd_node_gives_the_same_bits(hip, stride, monke
         assert p.grad is not None and torch.equal(p.grad, q.grad), n
     for (n, p), (_, q) in zip(blk.named_buffers(), ref.named_buffers()):
         assert torch.equal(p, q), n
+
+
+def test_conv_bn_act_as_one_autograd_node_gives_the_same_bits(hip, monkeypatch):
+    """FusedSequential(Conv2d 3x3 (+bias), SyncBN, ReLU) -- the skip / deblock / prediction trunks of the BEV head --
+    as one autograd node (_ConvBNActFn) against the two nodes it replaces: identical outputs, gradients, statistics."""
+    import copy
+    from rslo.layers import hip_conv2d
+    from rslo.layers.SparseConv import FusedSequential, SPC_ReLU, SPC_SyncBN2d
+    torch.manual_seed(5)
+    seq = FusedSequential(hip_conv2d.Conv2d(64, 32, kernel_size=3, padding=1), SPC_SyncBN2d(32), SPC_ReLU(),
+                          hip_conv2d.Conv2d(32, 7, 1)).cuda().train()
+    ref = copy.deepcopy(seq)
+    x = torch.randn(2, 64, 24, 44, device="cuda")
+    g = torch.randn(2, 7, 24, 44, device="cuda")
+
+    def run(m, fused):
+        monkeypatch.setenv("RSLO_FUSED_BLOCK", "1" if fused else "0")
+        m[0].__dict__.pop("_convbn_ok", None)
+        hip_conv2d.presplit(m)
+        xi = x.clone().requires_grad_(True)
+        y = m(xi)
+        y.backward(g)
+        names = set()
+        fn, todo = y.grad_fn, [y.grad_fn]
+        while todo:
+            f = todo.pop()
+            if f is None:
+                continue
+            names.add(type(f).__name__)
+            todo += [n for n, _ in f.next_functions]
+        assert ("_ConvBNActFnBackward" in names) == fused
+        return y.detach(), xi.grad
+    ya, ga = run(seq, True)
+    yb, gb = run(ref, False)
+    assert torch.equal(ya, yb) and torch.equal(ga, gb)
+    for (n, p), (_, q) in zip(seq.named_parameters(), ref.named_parameters()):
+        assert torch.equal(p.grad, q.grad), n
+    for (n, p), (_, q) in zip(seq.named_buffers(), ref.named_buffers()):
+        assert torch.equal(p, q), n
