@@ -354,8 +354,14 @@ def main():
         # Data parallel without the DDP wrapper: identical initial weights (broadcast), and after backward ONE flat
         # 48 MB all-reduce of the gradients over RCCL (rslo.utils.distributed_utils.average_gradients).  torch DDP with
         # find_unused_parameters=True (77 of 290 tensors never get a gradient) costs ~8 ms of host time per step here.
-        from rslo.utils.distributed_utils import average_gradients, broadcast_params
+        from rslo.utils.distributed_utils import OverlappedGradientExchange, average_gradients, broadcast_params
         broadcast_params(net, 0)
+        # the head's ~11 M gradients leave as one asynchronous all-reduce when the head's backward is done, overlapped
+        # with the encoder's backward; the rest follows after backward (RSLO_OVERLAP_GRADS=0: one bucket after backward)
+        grad_exchange = None
+        if os.environ.get("RSLO_OVERLAP_GRADS", "1") != "0":
+            grad_exchange = OverlappedGradientExchange(net, net.odom_predictor, mean=True, module_hook=False)
+            net.__dict__["_grad_exchange"] = grad_exchange
         # RCCL writes its version banner (NCCL_DEBUG=VERSION on this pool) through C stdio, which would otherwise be
         # flushed at process exit, AFTER the JSON line: push it out now, on every rank
         torch.cuda.synchronize()
@@ -418,7 +424,10 @@ def main():
         with amp.scale_loss(ret["loss"].mean(), opt) as scaled_loss:       # train_hdf5.py:663
             scaled_loss.backward()
         if dist_on:
-            average_gradients(net, mean=True)
+            if grad_exchange is not None:
+                grad_exchange.finish()
+            else:
+                average_gradients(net, mean=True)
         w0, c0 = mark("bwd", w0, c0)
         if not args.no_optim:
             hip_optim.clip_grad_norm_(params, 10.0, optimizer=opt)      # train_hdf5.py:671 on the optimizer's tables

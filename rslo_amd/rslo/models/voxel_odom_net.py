@@ -244,6 +244,9 @@ class UnVoxelOdomNetICP3(nn.Module):
         if plan is None:
             plan = self.middle_feature_extractor.plan(self._merge_coords(coors, batch_size), T * batch_size)
         bev, cov = self.middle_feature_extractor(torch.cat(voxel_features, 0), plan.indices, T * batch_size, plan=plan)
+        exchange = self.__dict__.get("_grad_exchange")      # data parallel: the head's gradient bucket leaves when the
+        if exchange is not None:                            # gradient of the BEV map is complete (distributed_utils)
+            exchange.watch(bev)
         spatial_features = list(bev.split(batch_size, dim=0))
         middle_conf_preds = list(cov.split([f.shape[0] for f in voxel_features], dim=0))
         self.end_timer("middle forward")

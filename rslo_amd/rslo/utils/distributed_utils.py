@@ -92,6 +92,91 @@ def average_gradients(model, bucket=True, mean=False):
             p.grad = g
 
 
+class OverlappedGradientExchange:
+    """average_gradients in two pieces, the first one overlapped with the rest of backward.
+
+    The network's backward runs loss -> BEV head -> encoder; the head holds ~11 M of the 12 M parameters and its
+    gradients are complete when the gradient w.r.t. the head's input (the BEV map) has been produced, while ~3 ms of
+    encoder backward are still to run.  `install(model, early)` puts a backward hook on the module `early`
+    (`net.odom_predictor`): when it fires, the gradients of that module's parameters (the agreed subset) go out as ONE
+    flat asynchronous all-reduce; `finish()` -- called where the driver calls average_gradients -- waits for it and
+    reduces the remaining tensors as a second flat bucket.  Same sums as average_gradients (bit-identical on two ranks:
+    each element is still the sum of the same two numbers).  xGMI rings are per-link bound: two large messages, not 213."""
+
+    def __init__(self, model, early, mean=False, module_hook=True):
+        """module_hook=False: the caller marks the boundary itself with watch(tensor) every forward (modules whose inputs
+        or outputs are lists / dicts, like the BEV head: the hook sits on the BEV tensor the head consumes)."""
+        self.model, self.mean = model, mean
+        self.early_ids = {id(p) for p in early.parameters() if p.requires_grad}
+        self.pending = None
+        self.handle = early.register_full_backward_hook(self._on_early_done) if module_hook else None
+
+    def remove(self):
+        if self.handle is not None:
+            self.handle.remove()
+
+    def watch(self, tensor):
+        """The gradient w.r.t. `tensor` is complete exactly when the early module's backward is: launch the bucket then."""
+        if tensor.requires_grad and _active():
+            tensor.register_hook(lambda g: self._on_early_done(None, None, None))
+        return tensor
+
+    def _bucket(self, params):
+        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in params]
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        return grads, flat
+
+    def _on_early_done(self, module, grad_input, grad_output):
+        if not _active() or self.pending is not None:
+            return None
+        params = [p for p in self.model.parameters() if p.requires_grad]
+        # only a set agreed by an earlier finish() is used here: at this point of backward the later modules have no
+        # gradients yet, so an agreement taken now would be wrong (the first step goes out in one piece at finish())
+        st = self.model.__dict__.get("_rslo_grad_set")
+        if not st or st.get("idx") is None or st.get("n") != len(params) or st["calls"] % _GRAD_SET_RECHECK == 0:
+            return None
+        sel = [params[i] for i in st["idx"] if id(params[i]) in self.early_ids]
+        if not sel or any(p.grad is None for p in sel):
+            return None         # a gradient of this module is still to come (or absent on this rank): all at finish()
+        grads, flat = self._bucket(sel)
+        work = dist.all_reduce(flat, async_op=True)
+        self.pending = (sel, grads, flat, work)
+        return None
+
+    def finish(self):
+        """The rest of average_gradients(model, mean=self.mean)."""
+        if not _active():
+            return
+        params = [p for p in self.model.parameters() if p.requires_grad]
+        idx = _agreed_grad_set(self.model, params)
+        chosen = set(idx)
+        stray = [i for i, p in enumerate(params) if p.grad is not None and i not in chosen]
+        if stray:
+            raise RuntimeError("OverlappedGradientExchange: %d parameter(s) received a gradient outside the agreed set"
+                               % len(stray))
+        world = dist.get_world_size()
+        done = set()
+        pend, self.pending = self.pending, None
+        if pend is not None:
+            done = {id(p) for p in pend[0]}
+        rest = [params[i] for i in idx if id(params[i]) not in done]
+        buckets = []
+        if rest:
+            grads, flat = self._bucket(rest)
+            dist.all_reduce(flat)
+            buckets.append((rest, grads, flat))
+        if pend is not None:
+            pend[3].wait()
+            buckets.append(pend[:3])
+        for sel, grads, flat in buckets:
+            if self.mean:
+                flat.div_(world)
+            torch._foreach_copy_(grads, [c.view_as(g) for c, g in zip(flat.split([g.numel() for g in grads]), grads)])
+            for p, g in zip(sel, grads):
+                if p.grad is None:
+                    p.grad = g
+
+
 def broadcast_params(model, src=0):
     """Rank `src` -> all: parameters and buffers, one flattened broadcast per dtype."""
     if not _active():

@@ -4,6 +4,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -203,3 +204,58 @@ def test_gradient_bucket_keeps_its_size_when_one_rank_skips_a_branch():
     np.testing.assert_array_equal(r0["s2_b"], r1["s2_b"])
     np.testing.assert_allclose(r0["s2_b"], np.full((2, 3), 1.0))         # only rank 0 (x = 1) used the branch
     assert r0["s3"] == "raised"
+
+
+def _overlap_worker(rank, world, port, q, rank_mode):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import copy
+    from rslo.utils.distributed_utils import OverlappedGradientExchange, average_gradients
+    torch.manual_seed(3)
+    # "encoder" -> "head": the head's backward finishes first, the hook fires while the encoder's is still to run
+    net = torch.nn.Module()
+    net.encoder = torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.Tanh(), torch.nn.Linear(8, 8))
+    net.head = torch.nn.Sequential(torch.nn.Linear(8, 8), torch.nn.Tanh(), torch.nn.Linear(8, 3))
+    net.unused = torch.nn.Linear(3, 3)                      # never receives a gradient (like 77 tensors of the model)
+    net.forward = lambda x: net.head(net.encoder(x))
+    ref = copy.deepcopy(net)
+    ref.forward = lambda x: ref.head(ref.encoder(x))
+    ex = OverlappedGradientExchange(net, net.head, mean=True, module_hook=(rank_mode == "module"))
+    if rank_mode == "tensor":       # the boundary marked on the tensor the head consumes (what the network does)
+        net.forward = lambda x: net.head(ex.watch(net.encoder(x)))
+    out = []
+    for step in range(3):
+        x = torch.randn(5, 6, generator=torch.Generator().manual_seed(100 * step + rank))
+        for m in (net, ref):
+            m.zero_grad(set_to_none=True)
+            m.forward(x).square().sum().backward()
+        fired = ex.pending is not None
+        ex.finish()
+        average_gradients(ref, mean=True)
+        same = all((a.grad is None and b.grad is None) or torch.equal(a.grad, b.grad)
+                   for a, b in zip(net.parameters(), ref.parameters()))
+        out.append((fired, same, ex.pending is None))
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["module", "tensor"])
+def test_overlapped_gradient_exchange_equals_average_gradients(mode):
+    """Two gloo ranks: the head's bucket leaves from the backward hook (asynchronously, while the encoder's backward is
+    still to run), the rest at finish(); every gradient equals average_gradients' bit for bit, step after step."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, world, port, q, mode)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, out in res:
+        assert all(same and cleared for _, same, cleared in out), out
+        assert [fired for fired, _, _ in out] == [False, True, True], out     # step 0 agrees on the set, then it overlaps
