@@ -15,6 +15,8 @@
 // 4 waves of a workgroup take interleaved chunks of one pixel slab and are added in LDS in wave order; slab partials go
 // to a workspace and are added in slab order by k_conv2d_wgrad_reduce (which also writes the OIHW layout): fixed
 // summation order, no atomics, bit-reproducible run to run (MIOpen's split-K kernels for these shapes use atomics).
+#include <stdlib.h>
+
 #include "rslo_common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -876,7 +878,7 @@ struct Conv2dStrGeom {
   Conv2dStrClass cls[4];
 };
 
-template <int TR, int S_IN, int NCLS>
+template <int TR, int S_IN, int NCLS, int MTW>
 __global__ __launch_bounds__(256, 2) void k_conv2d_str(const float *__restrict__ in, const unsigned short *__restrict__ Ws,
                                                        Conv2dStrGeom gm, float *__restrict__ out) {
   constexpr int NTW = TR / 2, HR = S_IN * (TR - 1) + 3, HC = S_IN * 15 + 3, NPX = HR * HC;
@@ -891,13 +893,15 @@ __global__ __launch_bounds__(256, 2) void k_conv2d_str(const float *__restrict__
   const int c0 = tx * 16, r0 = ty * TR;
   const int64_t HWi = (int64_t)gm.Hi * gm.Wi, HWo = (int64_t)gm.Ho * gm.Wo;
   const int n_mt = gm.cout / 16;
-  const int mt0 = blockIdx.y * 2 + wm;          // this wave's 16-channel output block
+  const int mt0 = (blockIdx.y * 2 + wm) * MTW;          // this wave's first 16-channel output block (MTW of them)
 
-  f32x4 acc[NCLS][NTW];
+  f32x4 acc[NCLS][MTW][NTW];
 #pragma unroll
   for (int c = 0; c < NCLS; ++c)
 #pragma unroll
-    for (int nt = 0; nt < NTW; ++nt) acc[c][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) acc[c][mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   constexpr int NTASK = (NPX * 4 + 255) / 256;
   const float *tsrc[NTASK];
@@ -942,8 +946,6 @@ __global__ __launch_bounds__(256, 2) void k_conv2d_str(const float *__restrict__
       const Conv2dStrClass &cl = gm.cls[c];
       for (int iy = 0; iy < cl.ny; ++iy) {
         for (int ix = 0; ix < cl.nx; ++ix) {
-          const unsigned short *wp = wbase + ((((int64_t)chunk * gm.ntap_w + cl.wt[iy * 3 + ix]) * n_mt) * 3) * 512;
-          const u32x4 ah = *(const u32x4 *)(wp), am = *(const u32x4 *)(wp + 512), al = *(const u32x4 *)(wp + 1024);
           u32x4 bh[NTW], bm[NTW], bl[NTW];
 #pragma unroll
           for (int nt = 0; nt < NTW; ++nt) {
@@ -953,19 +955,24 @@ __global__ __launch_bounds__(256, 2) void k_conv2d_str(const float *__restrict__
             bm[nt] = *(const u32x4 *)(bp + 64);
             bl[nt] = *(const u32x4 *)(bp + 128);
           }
-          // six products per block, smallest first
 #pragma unroll
-          for (int nt = 0; nt < NTW; ++nt) acc[c][nt] = MFMA_BF16(al, bh[nt], acc[c][nt]);
+          for (int mt = 0; mt < MTW; ++mt) {
+            const unsigned short *wp = wbase + ((((int64_t)chunk * gm.ntap_w + cl.wt[iy * 3 + ix]) * n_mt + mt) * 3) * 512;
+            const u32x4 ah = *(const u32x4 *)(wp), am = *(const u32x4 *)(wp + 512), al = *(const u32x4 *)(wp + 1024);
+            // six products per block, smallest first
 #pragma unroll
-          for (int nt = 0; nt < NTW; ++nt) acc[c][nt] = MFMA_BF16(am, bm[nt], acc[c][nt]);
+            for (int nt = 0; nt < NTW; ++nt) acc[c][mt][nt] = MFMA_BF16(al, bh[nt], acc[c][mt][nt]);
 #pragma unroll
-          for (int nt = 0; nt < NTW; ++nt) acc[c][nt] = MFMA_BF16(ah, bl[nt], acc[c][nt]);
+            for (int nt = 0; nt < NTW; ++nt) acc[c][mt][nt] = MFMA_BF16(am, bm[nt], acc[c][mt][nt]);
 #pragma unroll
-          for (int nt = 0; nt < NTW; ++nt) acc[c][nt] = MFMA_BF16(am, bh[nt], acc[c][nt]);
+            for (int nt = 0; nt < NTW; ++nt) acc[c][mt][nt] = MFMA_BF16(ah, bl[nt], acc[c][mt][nt]);
 #pragma unroll
-          for (int nt = 0; nt < NTW; ++nt) acc[c][nt] = MFMA_BF16(ah, bm[nt], acc[c][nt]);
+            for (int nt = 0; nt < NTW; ++nt) acc[c][mt][nt] = MFMA_BF16(am, bh[nt], acc[c][mt][nt]);
 #pragma unroll
-          for (int nt = 0; nt < NTW; ++nt) acc[c][nt] = MFMA_BF16(ah, bh[nt], acc[c][nt]);
+            for (int nt = 0; nt < NTW; ++nt) acc[c][mt][nt] = MFMA_BF16(ah, bm[nt], acc[c][mt][nt]);
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) acc[c][mt][nt] = MFMA_BF16(ah, bh[nt], acc[c][mt][nt]);
+          }
         }
       }
     }
@@ -977,15 +984,18 @@ __global__ __launch_bounds__(256, 2) void k_conv2d_str(const float *__restrict__
     const Conv2dStrClass &cl = gm.cls[c];
     const int col = c0 + li;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int m = mt0 * 16 + 4 * g + j;
+    for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
-      for (int nt = 0; nt < NTW; ++nt) {
-        const int r = r0 + wn * NTW + nt;
-        if (col < cl.cols && r < cl.rows)
-          out[((int64_t)b * gm.cout + m) * HWo + (int64_t)(gm.s_out * r + cl.py) * gm.Wo + gm.s_out * col + cl.px] = acc[c][nt][j];
+      for (int j = 0; j < 4; ++j) {
+        const int m = (mt0 + mt) * 16 + 4 * g + j;
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+          const int r = r0 + wn * NTW + nt;
+          if (col < cl.cols && r < cl.rows)
+            out[((int64_t)b * gm.cout + m) * HWo + (int64_t)(gm.s_out * r + cl.py) * gm.Wo + gm.s_out * col + cl.px] =
+                acc[c][mt][nt][j];
+        }
       }
-    }
   }
 }
 
@@ -1006,15 +1016,25 @@ extern "C" int rslo_conv2d_fwd_s2(const float *in, const void *Ws, int B, int ci
   gm.tiles_x = (int)rslo_cdiv(gm.Wo, 16); gm.tiles_y = (int)rslo_cdiv(gm.Ho, 4);
   Conv2dStrClass &c = gm.cls[0];
   c.rows = gm.Ho; c.cols = gm.Wo;
-  const dim3 grid((unsigned)(B * gm.tiles_x * gm.tiles_y), (unsigned)(cout / 32), 1);
+  // two 16-channel blocks per wave (64 output channels per workgroup) when the launch still fills the chip: the staged
+  // halo and its operand split are shared by twice the MFMAs (256 -> 128 at 96x176: 237 -> 218 us, its 1x1: 41 -> 31 us;
+  // the smaller stages lose, 44 -> 62 us, and keep 32 channels)
+  static const int mtw_env = getenv("RSLO_CONV2D_S2_MTW") ? atoi(getenv("RSLO_CONV2D_S2_MTW")) : 0;
+  const int64_t wgs32 = (int64_t)B * gm.tiles_x * gm.tiles_y * (cout / 32);
+  const int mtw = (cout % 64 == 0 && (mtw_env ? mtw_env == 2 : wgs32 >= 1024)) ? 2 : 1;
+  const dim3 grid((unsigned)(B * gm.tiles_x * gm.tiles_y), (unsigned)(cout / (32 * mtw)), 1);
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned short *ws = (const unsigned short *)Ws;
   if (ksize == 3) {
     gm.src_stride = 1; gm.by = gm.bx = -1; c.ny = c.nx = 3;
     for (int i = 0; i < 3; ++i) c.oy[i] = c.ox[i] = i;
     for (int i = 0; i < 9; ++i) c.wt[i] = i;
-    hipLaunchKernelGGL((k_conv2d_str<4, 2, 1>), grid, dim3(256), 0, (hipStream_t)stream, in, (const unsigned short *)Ws, gm, out);
+    if (mtw == 2) hipLaunchKernelGGL((k_conv2d_str<4, 2, 1, 2>), grid, dim3(256), 0, st, in, ws, gm, out);
+    else hipLaunchKernelGGL((k_conv2d_str<4, 2, 1, 1>), grid, dim3(256), 0, st, in, ws, gm, out);
   } else {        // out[y][x] = W in[2y][2x]: stage only the sampled pixels
     gm.src_stride = 2; c.ny = c.nx = 1;
-    hipLaunchKernelGGL((k_conv2d_str<4, 1, 1>), grid, dim3(256), 0, (hipStream_t)stream, in, (const unsigned short *)Ws, gm, out);
+    if (mtw == 2) hipLaunchKernelGGL((k_conv2d_str<4, 1, 1, 2>), grid, dim3(256), 0, st, in, ws, gm, out);
+    else hipLaunchKernelGGL((k_conv2d_str<4, 1, 1, 1>), grid, dim3(256), 0, st, in, ws, gm, out);
   }
   RSLO_CHECK_LAUNCH("k_conv2d_str(fwd)");
   return RSLO_OK;
@@ -1052,8 +1072,16 @@ extern "C" int rslo_conv2d_dgrad_s2(const float *dout, const void *Ws, int B, in
       }
     }
   // all four classes of a tile from one staged halo of dout (9 tap products in total for 3x3)
-  hipLaunchKernelGGL((k_conv2d_str<4, 1, 4>), dim3((unsigned)(B * gm.tiles_x * gm.tiles_y), (unsigned)(cin / 32), 1), dim3(256), 0,
-                     (hipStream_t)stream, dout, (const unsigned short *)Ws, gm, din);
+  static const int mtw_env = getenv("RSLO_CONV2D_S2_MTW") ? atoi(getenv("RSLO_CONV2D_S2_MTW")) : 0;
+  const int64_t wgs32 = (int64_t)B * gm.tiles_x * gm.tiles_y * (cin / 32);
+  (void)wgs32;      // measured: 64 channels per workgroup loses on the four-class data gradient (138 vs 100 us on the
+                    // largest layer: 4 x 2 x 2 accumulator tiles per wave), so it is opt-in here
+  const int mtw = (cin % 64 == 0 && mtw_env == 2) ? 2 : 1;
+  const dim3 grid((unsigned)(B * gm.tiles_x * gm.tiles_y), (unsigned)(cin / (32 * mtw)), 1);
+  if (mtw == 2)
+    hipLaunchKernelGGL((k_conv2d_str<4, 1, 4, 2>), grid, dim3(256), 0, (hipStream_t)stream, dout, (const unsigned short *)Ws, gm, din);
+  else
+    hipLaunchKernelGGL((k_conv2d_str<4, 1, 4, 1>), grid, dim3(256), 0, (hipStream_t)stream, dout, (const unsigned short *)Ws, gm, din);
   RSLO_CHECK_LAUNCH("k_conv2d_str(dgrad)");
   return RSLO_OK;
 }
