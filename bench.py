@@ -181,19 +181,23 @@ class ConvProbe:
             setattr(self.capi, k, f)
 
     def summarize(self, steps):
-        """-> (per-kernel dict, dominant kernel roofline dict).  Needs the LAST step recorded with
-        keep_tables so pair counts can be read; launches are identical every step (fixed inputs)."""
+        """-> (per-kernel dict, dominant kernel roofline dict).  The probed steps are recorded with keep_tables so that
+        every launch's own pair count is read (the tables stay alive until this summary)."""
         torch.cuda.synchronize()
-        per_step = len(self.records) // max(steps, 1)
-        last = self.records[-per_step:]
-        pairs = [int((m[5] >= 0).sum().item()) if m[0] != "dense" else 0 for (m, _, _) in last]
+        counted = {}      # pair count per table (the probed steps run DIFFERENT batches: every record has its own table)
+
+        def n_pairs(t):
+            k = (t.data_ptr(), tuple(t.shape))
+            if k not in counted:
+                counted[k] = int((t >= 0).sum().item())
+            return counted[k]
         groups = {}
         for i, (m, e0, e1) in enumerate(self.records):
             if m[0] == "dense":
                 _, flops, byts, name = m
             else:
-                kind, cin, cout, K, n_out, _, name = m
-                P = pairs[i % per_step]
+                kind, cin, cout, K, n_out, table, name = m
+                P = n_pairs(table)
                 sz = 2 if kind == "bf16" else 4          # bytes per feature / weight element
                 byts = P * cin * sz + n_out * cout * sz + 8 * P + K * cin * cout * sz
                 flops = 2 * P * cin * cout
@@ -378,8 +382,19 @@ def main():
     from apex import amp        # the real package if installed, else rslo_amd/compat/apex
     net, opt = amp.initialize(net, opt, opt_level="O1" if args.dtype == "bf16" else "O0")   # train_hdf5.py:456-461
 
-    clouds = workload.kitti_pairs(args.batch, n_el=args.rings, start=rank * args.batch)
-    clouds = [[torch.from_numpy(c).to(dev) for c in pair] for pair in clouds]
+    # RSLO_BENCH_BATCHES distinct resident batches (default 3), used round-robin: consecutive steps voxelize and plan
+    # DIFFERENT scans (different voxel counts, tables, pair lists), not one cache-warm batch over and over
+    n_sets = max(1, int(os.environ.get("RSLO_BENCH_BATCHES", "3")))
+    cloud_sets = []
+    for k in range(n_sets):
+        cs = workload.kitti_pairs(args.batch, n_el=args.rings, start=(rank * n_sets + k) * args.batch)
+        cloud_sets.append([[torch.from_numpy(c).to(dev) for c in pair] for pair in cs])
+    clouds = cloud_sets[0]
+    submitted = [0]
+
+    def next_clouds():
+        submitted[0] += 1
+        return cloud_sets[submitted[0] % n_sets]
     fixed_example = workload.make_example(net, clouds, device=dev) if args.no_voxelize else None
     if fixed_example is not None and os.environ.get("RSLO_BENCH_FIXED_PLAN") == "1":
         net.plan_example(fixed_example)      # diagnostic: no structure work at all inside the step (lower bound)
@@ -391,7 +406,7 @@ def main():
         depth = int(os.environ.get("RSLO_PREFETCH_DEPTH", "2"))
         prefetch = workload.ExamplePrefetcher(net, device=dev, depth=depth)
         for _ in range(depth):
-            prefetch.submit(clouds)
+            prefetch.submit(next_clouds())
 
     wait = [0.0]
 
@@ -413,13 +428,13 @@ def main():
         elif fixed_example is not None:
             ex = dict(fixed_example)
         else:
-            ex = workload.make_example(net, clouds, device=dev)
+            ex = workload.make_example(net, next_clouds(), device=dev)
         w0, c0 = mark("get", w0, c0)
         sched.step(net.get_global_step())
         opt.zero_grad()
         ret = model(ex)
         if prefetch is not None:
-            prefetch.submit(clouds)
+            prefetch.submit(next_clouds())
         w0, c0 = mark("fwd", w0, c0)
         with amp.scale_loss(ret["loss"].mean(), opt) as scaled_loss:       # train_hdf5.py:663
             scaled_loss.backward()
@@ -462,7 +477,6 @@ def main():
     for i in range(args.steps):
         if use_probe and i == args.steps - probe_steps:
             probe.enabled = True
-        if use_probe and i == args.steps - 1:
             probe.keep_tables = True
         ret = step()
         marks[i + 1].record()
@@ -489,7 +503,7 @@ def main():
                     json.dump({k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()}
                                for k, v in groups.items()}, f, indent=1)
             probe.uninstall()
-        n_points = int(np.mean([c.shape[0] for pair in clouds for c in pair]))
+        n_points = int(np.mean([c.shape[0] for cs in cloud_sets for pair in cs for c in pair]))
         line = {
             "metric": "frame-pairs/sec fwd+bwd (synthetic KITTI-shaped ~%dk-pt scans)" % (n_points // 1000),
             "value": round(args.batch * world * args.steps / elapsed, 3),
@@ -511,6 +525,7 @@ def main():
                        "lib_sha256": lib_hash(),
                        "frame_pairs_per_gpu": args.batch, "points_per_frame": n_points,
                        "voxelize_in_step": not args.no_voxelize, "voxelize_prefetch_stream": prefetch is not None,
+                       "distinct_batches": n_sets,
                        "optimizer_in_step": not args.no_optim,
                        "host_issue_ms_per_step": round(1e3 * cpu_issue / args.steps, 3),
                        "prefetch_wait_ms_per_step": round(1e3 * wait[0] / args.steps, 3),
