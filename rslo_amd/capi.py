@@ -194,10 +194,13 @@ def voxelize(points, pc_range, voxel_size, grid_xyz, max_points, max_voxels):
     d_nvox [1] int32 on device).  Rows >= nvox are zero; the caller slices after reading nvox."""
     P, F = points.shape
     dev = points.device
-    voxels = torch.empty((max_voxels, max_points, F), dtype=torch.float32, device=dev)
-    coords = torch.empty((max_voxels, 3), dtype=torch.int32, device=dev)
-    num = torch.empty((max_voxels,), dtype=torch.int32, device=dev)
-    nvox = torch.empty((1,), dtype=torch.int32, device=dev)
+    # one block, laid out voxels | num | coords | nvox: the library zero-fills it with a single memset
+    nv, nn, nc = max_voxels * max_points * F, max_voxels, max_voxels * 3
+    block = torch.empty((nv + nn + nc + 4,), dtype=torch.int32, device=dev)
+    voxels = block[:nv].view(torch.float32).view(max_voxels, max_points, F)
+    num = block[nv:nv + nn]
+    coords = block[nv + nn:nv + nn + nc].view(max_voxels, 3)
+    nvox = block[nv + nn + nc:nv + nn + nc + 1]
     wsb = lib().rslo_voxelize_ws_bytes(P)
     ws = _ws(wsb, dev)
     r = _F6(*[float(v) for v in pc_range])

@@ -389,10 +389,13 @@ static size_t vox_ws_layout(int64_t P, void *base, VoxWs *w) {
     off += align256(bytes);
     return p;
   };
-  void *keys = take(cap * 4), *first = take(cap * 4), *head = take(cap * 4), *vid = take(cap * 4);
+  // keys | head are filled with 0xFF and first | cutoff with 0x7F: adjacent, so each pair is ONE memset (cap * 4 is a
+  // multiple of 256: no padding in between)
+  void *keys = take(cap * 4), *head = take(cap * 4), *first = take(cap * 4);
+  void *cutoff = take(256);
+  void *vid = take(cap * 4);
   void *next = take((size_t)P * 4), *slot = take((size_t)P * 4), *pos = take((size_t)P * 4),
        *flags = take((size_t)P * 4);
-  void *cutoff = take(256);
   size_t sb = rslo_scan_ws_bytes(P);
   void *sws = take(sb);
   if (w) {
@@ -512,10 +515,21 @@ extern "C" int rslo_voxelize(const float *points, int64_t P, int F, const float 
     int32_t d[3] = {grid_xyz[2], grid_xyz[1], grid_xyz[0]};
     if (int rc = check_volume(1, d)) return rc;
   }
-  RSLO_HIP(hipMemsetAsync(voxels, 0, (size_t)max_voxels * T * F * sizeof(float), st));
-  RSLO_HIP(hipMemsetAsync(num_points, 0, (size_t)max_voxels * sizeof(int32_t), st));
-  RSLO_HIP(hipMemsetAsync(coords, 0, (size_t)max_voxels * 3 * sizeof(int32_t), st));
-  RSLO_HIP(hipMemsetAsync(d_nvox, 0, sizeof(int32_t), st));
+  {
+    // the four outputs are zero-filled; a caller that lays them out back to back (voxels | num_points | coords | d_nvox,
+    // as rslo_amd.capi does) gets ONE fill instead of four
+    const size_t bv = (size_t)max_voxels * T * F * sizeof(float), bn = (size_t)max_voxels * sizeof(int32_t),
+                 bc = (size_t)max_voxels * 3 * sizeof(int32_t);
+    char *v0 = (char *)voxels;
+    if ((char *)num_points == v0 + bv && (char *)coords == v0 + bv + bn && (char *)d_nvox == v0 + bv + bn + bc) {
+      RSLO_HIP(hipMemsetAsync(voxels, 0, bv + bn + bc + sizeof(int32_t), st));
+    } else {
+      RSLO_HIP(hipMemsetAsync(voxels, 0, bv, st));
+      RSLO_HIP(hipMemsetAsync(num_points, 0, bn, st));
+      RSLO_HIP(hipMemsetAsync(coords, 0, bc, st));
+      RSLO_HIP(hipMemsetAsync(d_nvox, 0, sizeof(int32_t), st));
+    }
+  }
   if (P == 0) return RSLO_OK;
   if (ws_bytes < rslo_voxelize_ws_bytes(P)) {
     rslo_set_error("voxelize: workspace too small (%zu < %zu)", ws_bytes, rslo_voxelize_ws_bytes(P));
@@ -529,10 +543,8 @@ extern "C" int rslo_voxelize(const float *points, int64_t P, int F, const float 
     G.vs[j] = vsize3[j];
     G.g[j] = grid_xyz[j];
   }
-  RSLO_HIP(hipMemsetAsync(w.keys, 0xFF, (size_t)w.cap * 4, st));
-  RSLO_HIP(hipMemsetAsync(w.head, 0xFF, (size_t)w.cap * 4, st));
-  RSLO_HIP(hipMemsetAsync(w.first, 0x7F, (size_t)w.cap * 4, st));
-  RSLO_HIP(hipMemsetAsync(w.cutoff, 0x7F, sizeof(int32_t), st));
+  RSLO_HIP(hipMemsetAsync(w.keys, 0xFF, (size_t)w.cap * 8, st));                 // keys | head
+  RSLO_HIP(hipMemsetAsync(w.first, 0x7F, (size_t)w.cap * 4 + sizeof(int32_t), st));    // first | cutoff
   const unsigned nb = (unsigned)rslo_cdiv(P, 256);
   const int shift = 32 - rslo_log2_i64(w.cap);
   hipLaunchKernelGGL(k_vox_insert, dim3(nb), dim3(256), 0, st, points, P, F, G, w.keys, w.first, w.head,
