@@ -403,8 +403,11 @@ def main():
     # reference's DataLoader workers do on the CPU); every step still voxelizes its own 2 x batch clouds
     prefetch = None
     if fixed_example is None and not args.no_prefetch:
-        depth = int(os.environ.get("RSLO_PREFETCH_DEPTH", "2"))
-        prefetch = workload.ExamplePrefetcher(net, device=dev, depth=depth)
+        # one helper is enough: with 2-3 the wait for the next example goes to zero but backward stretches by the same
+        # amount (14.9 / 14.8 / 15.3 ms per step with 1 / 2 / 3 helpers) -- the GPU, shared by both streams, is the bound
+        workers = int(os.environ.get("RSLO_PREFETCH_WORKERS", "1"))
+        depth = int(os.environ.get("RSLO_PREFETCH_DEPTH", str(max(2, workers + 1))))
+        prefetch = workload.ExamplePrefetcher(net, device=dev, depth=depth, workers=workers)
         for _ in range(depth):
             prefetch.submit(next_clouds())
 
@@ -470,6 +473,9 @@ def main():
     wait[0] = 0.0
     for v in ph.values():
         v[0] = v[1] = 0.0
+    alloc0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)      # hipMalloc calls so far (caching allocator misses)
+    live0 = torch.cuda.memory_allocated(dev)
+    gc_every = int(os.environ.get("RSLO_BENCH_GC", "0"))                  # diagnostic: cyclic GC every n timed steps
     t0 = time.perf_counter()
     cpu0 = time.thread_time()           # CPU time of the issuing thread: close to the wall time = host-bound step
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # one event per step: spread of the
@@ -480,6 +486,9 @@ def main():
             probe.keep_tables = True
         ret = step()
         marks[i + 1].record()
+        if gc_every and (i + 1) % gc_every == 0:
+            import gc
+            gc.collect()
     cpu_issue = time.thread_time() - cpu0
     barrier()
     elapsed = time.perf_counter() - t0
@@ -490,6 +499,10 @@ def main():
         elapsed = float(t.item())
 
     if phases and rank == 0:
+        st = torch.cuda.memory_stats(dev)
+        print("allocator: %d hipMalloc calls during the %d timed steps, %d MB reserved, %d MB peak allocated, live %d -> %d MB" % (
+            st.get("num_device_alloc", 0) - alloc0, args.steps, st.get("reserved_bytes.all.current", 0) >> 20,
+            st.get("allocated_bytes.all.peak", 0) >> 20, live0 >> 20, torch.cuda.memory_allocated(dev) >> 20), file=sys.stderr)
         print("phases (wall ms, cpu ms per step): " + ", ".join(
             "%s %.2f/%.2f" % (k, 1e3 * v[0] / args.steps, 1e3 * v[1] / args.steps) for k, v in ph.items()), file=sys.stderr)
     loss_val = float(ret["loss"].detach().mean().item())

@@ -368,7 +368,11 @@ class SparseConvolution(SparseModule):
             rb = index.subm_cache.get(key)
             if rb is None:
                 nbr = capi.rulebook_subm(index, self.kernel_size)
-                rb = Rulebook("subm", nbr, None, index, index, self.kernel_size, [1, 1, 1], None)
+                # no back-reference to `index`: the cache entry would close a reference cycle (index -> cache -> rulebook
+                # -> index) and every batch's tables (~200 MB) would then wait for the cyclic garbage collector instead of
+                # being freed when the example goes out of scope -- measured: live memory 3.6 -> 8.9 GB over 100 steps and
+                # two hipMalloc calls per step; a SubM layer never reads these fields
+                rb = Rulebook("subm", nbr, None, None, None, self.kernel_size, [1, 1, 1], None)
                 index.subm_cache[key] = rb
         else:
             out_index, nbr, nbrT = capi.rulebook_conv(index, self.kernel_size, self.stride, self.padding)

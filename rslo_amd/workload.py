@@ -79,7 +79,7 @@ class ExamplePrefetcher:
     the C++ autograd engine.  The depth + 1 most recent examples are kept alive so memory handed to the training stream
     is not recycled by the side stream while still in use."""
 
-    def __init__(self, net, max_voxels=synthetic.MAX_VOXELS, device="cuda", plan=True, depth=1):
+    def __init__(self, net, max_voxels=synthetic.MAX_VOXELS, device="cuda", plan=True, depth=1, workers=1):
         import queue
         import threading
         device = torch.device(device)
@@ -88,73 +88,90 @@ class ExamplePrefetcher:
         self.net, self.max_voxels, self.device, self.plan = net, max_voxels, device, plan
         # depth = examples prepared ahead of the one in use: submit() `depth` times before the first get().  With 2 the
         # example of step i+1 is already finished when step i ends, so a late helper thread no longer stalls the step.
+        # workers = helper threads, each with its own side stream: one job is a chain of ~7 host reads of data-dependent
+        # sizes, each waiting for small kernels that share the GPU with the training stream, so its LATENCY (10-14 ms)
+        # can exceed a training step even though its work is 2-3 ms; two jobs in flight hide that (results are handed
+        # out in submission order).
         self.depth = max(1, int(depth))
-        # the side stream runs at the lowest priority the device offers: its small integer kernels fill gaps, the
-        # training stream's kernels win the compute units when both are ready (RSLO_PREFETCH_PRIORITY overrides)
-        import os as _os
-        pr = _os.environ.get("RSLO_PREFETCH_PRIORITY")
+        self.workers = max(1, int(workers))
+        self._in = queue.Queue()
+        self._cv = threading.Condition()
+        self._results = {}          # seq -> (example, ready event, error)
+        self._keep = {}             # seq -> example, until the training stream is done with it
+        self._next_submit = self._next_get = 0
+        self.cpu_seconds, self.jobs = 0.0, 0
+        # Several Python threads issue GPU work here.  With the interpreter's default 5 ms switch interval a helper can
+        # hold the lock for a third of a step while the training thread's queue runs dry; 0.2 ms keeps all streams
+        # fed (measured: 238 -> 257 frame-pairs/s on the same box, back-to-back runs).
+        import os
+        import sys
+        sys.setswitchinterval(float(os.environ.get("RSLO_SWITCH_INTERVAL", "0.0002")))
+        pr = os.environ.get("RSLO_PREFETCH_PRIORITY")
         if pr is None:
             try:
                 pr = max(torch.cuda.Stream.priority_range())      # (lowest, highest): larger number = lower priority
             except Exception:
                 pr = 0
-        self.stream = torch.cuda.Stream(self.device, priority=int(pr))
-        self._in, self._out = queue.Queue(), queue.Queue()
-        self._keep = []
-        # Two Python threads issue GPU work here.  With the interpreter's default 5 ms switch interval the helper can
-        # hold the lock for a third of a step while the training thread's queue runs dry; 0.2 ms keeps both streams
-        # fed (measured: 238 -> 257 frame-pairs/s on the same box, back-to-back runs).
-        import os
-        import sys
-        sys.setswitchinterval(float(os.environ.get("RSLO_SWITCH_INTERVAL", "0.0002")))
-        self._thread = threading.Thread(target=self._work, daemon=True)
-        self._thread.start()
+        self.streams = [torch.cuda.Stream(self.device, priority=int(pr)) for _ in range(self.workers)]
+        self.stream = self.streams[0]
+        self._threads = [threading.Thread(target=self._work, args=(w,), daemon=True) for w in range(self.workers)]
+        for t in self._threads:
+            t.start()
 
-    def _work(self):
+    def _work(self, w):
+        import time
         torch.cuda.set_device(self.device)
+        stream = self.streams[w]
         while True:
             job = self._in.get()
             if job is None:
                 return
-            clouds, prev_done = job
-            import time
+            seq, clouds, prev_done = job
             c0 = time.thread_time()
             try:
                 if prev_done is not None:
-                    prev_done.synchronize()          # everything older than the previous step has left the GPU
-                del self._keep[:-self.depth]
-                with torch.cuda.stream(self.stream):
+                    prev_done.synchronize()      # the training stream has issued (and finished) everything up to the
+                with self._cv:                   # forward of step seq - depth: older examples are no longer read
+                    for old in [k for k in self._keep if k <= seq - self.depth - 1]:
+                        del self._keep[old]
+                with torch.cuda.stream(stream):
                     ex = make_example(self.net, clouds, self.max_voxels, self.device)
                     if self.plan:
                         self.net.plan_example(ex)
                     ready = torch.cuda.Event()
-                    ready.record(self.stream)
-                self._keep.append(ex)
-                self.cpu_seconds = getattr(self, "cpu_seconds", 0.0) + (time.thread_time() - c0)
-                self.jobs = getattr(self, "jobs", 0) + 1
-                self._out.put((ex, ready, None))
+                    ready.record(stream)
+                res = (ex, ready, None)
             except Exception as e:      # surface in get()
-                self._out.put((None, None, e))
+                ex, res = None, (None, None, e)
+            with self._cv:
+                if ex is not None:
+                    self._keep[seq] = ex
+                self._results[seq] = res
+                self.cpu_seconds += time.thread_time() - c0
+                self.jobs += 1
+                self._cv.notify_all()
 
     def submit(self, clouds):
         done = torch.cuda.Event()
         done.record(torch.cuda.current_stream(self.device))
-        self._in.put((clouds, done))
+        self._in.put((self._next_submit, clouds, done))
+        self._next_submit += 1
 
     def get(self):
-        import queue
-        while True:
-            try:
-                ex, ready, err = self._out.get(timeout=5.0)
-                break
-            except queue.Empty:
-                if not self._thread.is_alive():
-                    raise RuntimeError("ExamplePrefetcher: the helper thread died")
+        seq = self._next_get
+        self._next_get += 1
+        with self._cv:
+            while seq not in self._results:
+                if not self._cv.wait(timeout=5.0) and not any(t.is_alive() for t in self._threads):
+                    raise RuntimeError("ExamplePrefetcher: the helper threads died")
+            ex, ready, err = self._results.pop(seq)
         if err is not None:
             raise err
         torch.cuda.current_stream(self.device).wait_event(ready)
         return ex
 
     def close(self):
-        self._in.put(None)
-        self._thread.join(timeout=10)
+        for _ in self._threads:
+            self._in.put(None)
+        for t in self._threads:
+            t.join(timeout=10)
