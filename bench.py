@@ -65,11 +65,55 @@ def parse():
     ap.add_argument("--no-prefetch", action="store_true", help="voxelize / plan inside the step on the training stream")
     ap.add_argument("--no-voxelize", action="store_true", help="voxelize once outside the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP events (roofline=null)")
     ap.add_argument("--kernel-report", default="", help="write the per-kernel roofline table to this JSON file")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="f32 = C3 (the headline line); bf16 = the single-GPU half of C4: apex.amp O1, bf16 conv operands")
     return ap.parse_args()
+
+
+def pin_to_quiet_cores(n=8, part=(0, 1)):
+    """The step is bound by how fast two Python threads issue ~1000 launches; on the shared boxes of the pool the
+    scheduler migrates them between busy cores (same binary, same box: 14.8 ... 17.4 ms per step).  Pick the block of n
+    consecutive allowed CPUs that was idlest over a 100 ms sample of /proc/stat and keep the process there
+    (RSLO_BENCH_PIN=0 turns it off; measured on one box, alternating runs: 14.68-14.77 ms per step pinned against
+    14.9 / 15.9 / 16.6 / 18.4 ms free, host issue 5.1 vs 7-8.6 ms).  part = (local rank, ranks on the node): rank r only
+    considers every ranks-th block, so the ranks of a node never share cores.  Returns the chosen CPUs or None."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+        if len(allowed) <= n:
+            return None
+
+        def sample():
+            out = {}
+            with open("/proc/stat") as f:
+                for line in f:
+                    if line.startswith("cpu") and line[3].isdigit():
+                        p = line.split()
+                        v = [int(x) for x in p[1:9]]
+                        out[int(p[0][3:])] = (sum(v), v[3] + v[4])      # total, idle + iowait
+            return out
+        a = sample()
+        time.sleep(0.1)
+        b = sample()
+        busy = {c: 1.0 - (b[c][1] - a[c][1]) / max(b[c][0] - a[c][0], 1) for c in allowed if c in a and c in b}
+        best, best_load = None, None
+        for i in range(0, len(allowed) - n + 1):
+            blk = allowed[i:i + n]
+            if blk[-1] - blk[0] != n - 1 or blk[0] % n:      # aligned blocks of consecutive ids: one core complex
+                continue
+            if (blk[0] // n) % max(part[1], 1) != part[0] % max(part[1], 1):
+                continue
+            load = sum(busy.get(c, 1.0) for c in blk)
+            if best is None or load < best_load:
+                best, best_load = blk, load
+        if best is None:
+            return None
+        os.sched_setaffinity(0, set(best))
+        return best
+    except (AttributeError, OSError, ValueError):
+        return None
 
 
 def _flush_c_stdio():
@@ -317,6 +361,11 @@ def cpu_baseline(args):
 # --------------------------------------------------------------------------------------------- main
 def main():
     args = parse()
+    if args.cpu_baseline_only:          # child of a pinned run: the CPU baseline on the host's full affinity mask
+        sys.path.insert(0, ROOT) if ROOT not in sys.path else None
+        import rslo_amd  # noqa: F401
+        print(json.dumps(cpu_baseline(args)))
+        return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -341,6 +390,11 @@ def main():
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if dist_on else 0)
+
+    pinned = None
+    orig_affinity = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
+    if os.environ.get("RSLO_BENCH_PIN", "1") != "0":
+        pinned = pin_to_quiet_cores(8, (local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world))))
 
     import rslo_amd  # noqa: F401
     from rslo_amd import capi, workload
@@ -538,7 +592,7 @@ def main():
                        "lib_sha256": lib_hash(),
                        "frame_pairs_per_gpu": args.batch, "points_per_frame": n_points,
                        "voxelize_in_step": not args.no_voxelize, "voxelize_prefetch_stream": prefetch is not None,
-                       "distinct_batches": n_sets,
+                       "distinct_batches": n_sets, "pinned_cpus": pinned,
                        "optimizer_in_step": not args.no_optim,
                        "host_issue_ms_per_step": round(1e3 * cpu_issue / args.steps, 3),
                        "prefetch_wait_ms_per_step": round(1e3 * wait[0] / args.steps, 3),
@@ -550,7 +604,16 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
-                line["cpu_baseline"] = cpu_baseline(args)
+                if pinned is not None:
+                    # the GPU run is pinned to 8 cores; the CPU baseline gets the whole host: a child process with the
+                    # original affinity mask (OpenMP pools created under the pinned mask would stay on those cores)
+                    import subprocess
+                    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--rings",
+                                        str(args.rings)], capture_output=True, text=True, timeout=600,
+                                       preexec_fn=lambda: os.sched_setaffinity(0, orig_affinity))
+                    line["cpu_baseline"] = json.loads(r.stdout.strip().splitlines()[-1])
+                else:
+                    line["cpu_baseline"] = cpu_baseline(args)
             except Exception as e:   # the baseline is informational; never lose the measurement over it
                 line["cpu_baseline"] = {"error": repr(e)}
     if dist_on:
