@@ -147,8 +147,9 @@ class ConvProbe:
         rbw = 2 if n_out >= 256 * 32 * 8 else 1
         if bf16:
             return "k_spconv_bf16<%d, %d, %d>" % (cin_op, cout_op, rbw)
-        if split:
-            return "k_spconv_v6<%d, %d, %d>" % (cin_op, cout_op, rbw)
+        if split:      # rslo_spconv_fwd_split: two waves per 32-row tile except for 32 -> 32
+            ks = 1 if (cin_op == 32 and cout_op == 32) else 2
+            return "k_spconv_v6<%d, %d, %d, %d>" % (cin_op, cout_op, 2 if ks == 2 else rbw, ks)
         if cin_op % 16 == 0 and cout_op % 16 == 0:
             return "k_spconv_v3<%d, %d, %d, %s>" % (cin_op, cout_op, rbw, t)
         ci = 8 if cin_op <= 8 else (16 if cin_op <= 16 else (32 if cin_op <= 32 else 64))
@@ -245,11 +246,17 @@ class ConvProbe:
                 sz = 2 if kind == "bf16" else 4          # bytes per feature / weight element
                 byts = P * cin * sz + n_out * cout * sz + 8 * P + K * cin * cout * sz
                 flops = 2 * P * cin * cout
-            g = groups.setdefault(name, {"launches": 0, "ms": 0.0, "bytes": 0, "flops": 0})
+            g = groups.setdefault(name, {"launches": 0, "ms": 0.0, "bytes": 0, "flops": 0,
+                                         "big": {"launches": 0, "ms": 0.0, "flops": 0}})
+            dt = e0.elapsed_time(e1)
             g["launches"] += 1
-            g["ms"] += e0.elapsed_time(e1)
+            g["ms"] += dt
             g["bytes"] += byts
             g["flops"] += flops
+            if m[0] != "dense" and n_out >= 256 * 32 * 8:      # the launches the round-1 / round-2 lines called <.., 2>
+                g["big"]["launches"] += 1
+                g["big"]["ms"] += dt
+                g["big"]["flops"] += flops
         for g in groups.values():
             g["avg_us"] = 1e3 * g["ms"] / g["launches"]
             g["GBps"] = g["bytes"] / (g["ms"] * 1e-3) / 1e9
@@ -304,6 +311,15 @@ class ConvProbe:
             # with rocprofv3 on this same command (scripts/pmc_bench_traffic.sh) and committed under profiles/
             if gname != name:
                 r["layer_shape"] = gname.split(" [")[1].rstrip("]")
+            big = g.get("big")
+            if big and 0 < big["launches"] < g["launches"] and r["bound"] == "mfma":
+                # one kernel name now serves every 64-channel layer; the subset with >= 65536 output rows is the set of
+                # launches earlier lines reported as k_spconv_v6<64, 64, 2> (comparable round over round)
+                tf = big["flops"] / (big["ms"] * 1e-3) / 1e12
+                r["launches_with_65536_rows_or_more"] = {
+                    "launches_per_step": big["launches"] // max(steps, 1),
+                    "avg_launch_us": round(1e3 * big["ms"] / big["launches"], 2), "achieved": round(tf, 2),
+                    "frac": round(tf / r["peak"], 4)}
             if name in pmc_busy:       # matrix-core busy cycles / (shader cycles x 1024 SIMDs), scripts/pmc_mfma_busy.sh
                 r["mfma_busy_pct"] = pmc_busy[name]["mfma_busy_pct"]
                 r["mfma_busy_source"] = "profiles/" + PMC_BUSY

@@ -150,6 +150,11 @@ RSLO_API int rslo_spconv_fwd_split(const float *in, int cin, const void *Ws, con
  *     2 / 4 = that many tiles per wave with the weight operands reused across them through a wave-private LDS ring
  *     (k_spconv_v9: bit-identical results, measured slower -- see the kernel header).  Environment: RSLO_SPCONV_V9. */
 RSLO_API void rslo_spconv_set_v9(int mode);
+/*     Tiling of k_spconv_v6 behind rslo_spconv_fwd_split: a tile is 16*rbw rows (rbw 1, 2, 4) and ks waves (1, 2, 4) share
+ *     it, each walking 1/ks of the tile's active kernel offsets; their accumulators are added through LDS in wave order
+ *     (a fixed summation order, results within fp32 rounding of the one-wave form).  0 = the library chooses per layer
+ *     shape (default: 32 rows and two waves except for 32 -> 32 channels).  Environment: RSLO_SPCONV_RBW / _KS. */
+RSLO_API void rslo_spconv_set_tiling(int rbw, int ks);
 /*     bf16 feature path (BASELINE config C4: bf16 features, int32 rulebook, fp32 accumulate): in / out are bf16 rows
  *     [N,C], Wb the weights rounded to bf16 in MFMA operand order (rslo_weight_to_bf16, K*cin*cout*2 bytes; transpose
  *     = 1 for the data gradient), bias fp32.  Channel counts 32 / 64. */

@@ -569,8 +569,22 @@ __device__ __forceinline__ f32x4 fake_mfma(u32x4 a, u32x4 b, f32x4 c) {
 #define MFMA_BF16(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), C, 0, 0, 0)
 #endif
 
-template <int CIN_T, int COUT_T, int RBW>
-__global__ __launch_bounds__(SPC_THREADS) void k_spconv_v6(const float *__restrict__ in,
+// KS = 2: the active offsets of a tile are divided between TWO waves (lowest half of the set bits / the rest), whose
+// accumulators are added through LDS before the epilogue (first half + second half: a fixed order).  A launch of the
+// level-2 / level-3 layers is ONE generation of waves (about 100k rows = 3.1 tiles of 32 rows per SIMD): each SIMD holds
+// 3 or 4 waves from start to end, the kernel's time is the gather latency chain of the SIMDs that got 4, and nothing
+// else is in flight to hide it.  Half-length chains in twice as many waves put 6.2 waves on a SIMD (quantisation 6.2 vs
+// 7 instead of 3.1 vs 4) at the same weight and row traffic per product.
+#ifndef SPC6_WPE
+#define SPC6_WPE 0      // > 0: register budget for that many waves per SIMD (experiment)
+#endif
+#if SPC6_WPE > 0
+#define SPC6_ATTR __attribute__((amdgpu_waves_per_eu(SPC6_WPE, SPC6_WPE)))
+#else
+#define SPC6_ATTR
+#endif
+template <int CIN_T, int COUT_T, int RBW, int KS = 1>
+__global__ __launch_bounds__(SPC_THREADS) SPC6_ATTR void k_spconv_v6(const float *__restrict__ in,
                                                            const unsigned short *__restrict__ Ws,
                                                            const float *__restrict__ bias,
                                                            const int32_t *__restrict__ nbr,
@@ -580,30 +594,42 @@ __global__ __launch_bounds__(SPC_THREADS) void k_spconv_v6(const float *__restri
   constexpr int NS = CIN_T / 32;       // K-steps of 32 input channels
   constexpr int NB = COUT_T / 16;      // 16-column blocks: column li of block nb = output channel NB li + nb
   constexpr int ROWS = 16 * RBW;
-  __shared__ int32_t nbl[SPC_WAVES][ROWS * SPC_MAXK];
-  __shared__ int32_t orow[SPC_WAVES][ROWS];
+  constexpr int TPB = SPC_WAVES / KS;  // tiles per workgroup
+  __shared__ int32_t nbl[TPB][ROWS * SPC_MAXK];
+  __shared__ int32_t orow[TPB][ROWS];
+  __shared__ __attribute__((aligned(16))) VecF<NB> part[KS > 1 ? TPB * (KS - 1) * RBW * 4 * 64 : 1];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int li = lane & 15, g = lane >> 4;
+  const int tw = wid / KS, half = wid % KS;
   const int64_t n_tiles = (n_out + ROWS - 1) / ROWS;
-  const int64_t n_blocks = (n_tiles + SPC_WAVES - 1) / SPC_WAVES;
+  const int64_t n_blocks = (n_tiles + TPB - 1) / TPB;
   const int64_t vb = xcd_tile(n_blocks);
-  const int64_t tile = vb * SPC_WAVES + wid;
+  const int64_t tile = vb * TPB + tw;
   const bool active = vb < n_blocks && tile < n_tiles;
   const int64_t row0 = tile * ROWS;
 
-  if (active) spc_load_tile<ROWS>(nbr, order, row0, n_out, K, lane, nbl[wid], orow[wid]);
+  if (active && half == 0) spc_load_tile<ROWS>(nbr, order, row0, n_out, K, lane, nbl[tw], orow[tw]);
   __syncthreads();
-  if (!active) return;
+  if (KS == 1 && !active) return;
 
   unsigned mask = 0;
-  for (int k = 0; k < K; ++k) {
-    bool any = false;
+  if (active) {
+    for (int k = 0; k < K; ++k) {
+      bool any = false;
 #pragma unroll
-    for (int rb = 0; rb < RBW; ++rb) any |= nbl[wid][(rb * 16 + li) * K + k] >= 0;
-    if (__ballot(any) != 0ull) mask |= 1u << k;
+      for (int rb = 0; rb < RBW; ++rb) any |= nbl[tw][(rb * 16 + li) * K + k] >= 0;
+      if (__ballot(any) != 0ull) mask |= 1u << k;
+    }
   }
   mask = __builtin_amdgcn_readfirstlane(mask);
+  if constexpr (KS > 1) {
+    // part `half` owns the FIXED offsets k = half (mod KS): a row's sum is ((part 0's offsets in order) + (part 1's) ..)
+    // whatever tile the row order puts it in -- results do not depend on the row order.  Interleaved, not ranges: the
+    // mask-sorted order makes tiles of rows that lack the same side of the neighbourhood (a contiguous range of
+    // offsets), which ranges would hand to one wave (measured: 161 vs 149 us on the 64 -> 64 level-2 layer)
+    mask &= (KS == 2 ? 0x55555555u : 0x11111111u) << half;
+  }
 
   f32x4 acc[RBW][NB];
 #pragma unroll
@@ -620,7 +646,7 @@ __global__ __launch_bounds__(SPC_THREADS) void k_spconv_v6(const float *__restri
     bool ok[RBW];
 #pragma unroll
     for (int rb = 0; rb < RBW; ++rb) {
-      const int32_t r = nbl[wid][(rb * 16 + li) * K + k];
+      const int32_t r = nbl[tw][(rb * 16 + li) * K + k];
       ok[rb] = r >= 0;
       ap[rb] = in + (int64_t)(ok[rb] ? r : 0) * CIN_T + 8 * g;
     }
@@ -671,6 +697,32 @@ __global__ __launch_bounds__(SPC_THREADS) void k_spconv_v6(const float *__restri
     }
   }
 
+  if constexpr (KS > 1) {      // parts 1 .. KS-1 -> LDS -> added to part 0 in part order (same lane, same registers)
+    VecF<NB> *slot = part + tw * ((KS - 1) * RBW * 4 * 64);
+    if (half > 0 && active) {
+#pragma unroll
+      for (int rb = 0; rb < RBW; ++rb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          VecF<NB> v;
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) v.v[nb] = acc[rb][nb][j];
+          slot[((half - 1) * RBW * 4 + rb * 4 + j) * 64 + lane] = v;
+        }
+    }
+    __syncthreads();
+    if (half > 0 || !active) return;
+#pragma unroll
+    for (int h = 1; h < KS; ++h)
+#pragma unroll
+      for (int rb = 0; rb < RBW; ++rb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const VecF<NB> v = slot[((h - 1) * RBW * 4 + rb * 4 + j) * 64 + lane];
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) acc[rb][nb][j] += v.v[nb];
+        }
+  }
   // epilogue: lane (g, li) holds rows 4g+j, output channels NB*li .. NB*li+NB-1
   VecF<NB> bv;
 #pragma unroll
@@ -679,7 +731,7 @@ __global__ __launch_bounds__(SPC_THREADS) void k_spconv_v6(const float *__restri
   for (int rb = 0; rb < RBW; ++rb)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int64_t row = orow[wid][rb * 16 + 4 * g + j];
+      const int64_t row = orow[tw][rb * 16 + 4 * g + j];
       if (row < 0) continue;
       float o[NB];
 #pragma unroll
@@ -1143,6 +1195,14 @@ extern "C" int rslo_weight_split_many(const RsloWeightSplitDesc *desc_dev, int n
 static int spc_v9_mode = getenv("RSLO_SPCONV_V9") ? atoi(getenv("RSLO_SPCONV_V9")) : -1;
 extern "C" void rslo_spconv_set_v9(int mode) { spc_v9_mode = mode; }
 
+// k_spconv_v6 tiling: rows per tile = 16 rbw (1, 2, 4), waves per tile ks (1, 2, 4; rbw 4 only with ks 1); 0 = choose
+static int spc_force_rbw = getenv("RSLO_SPCONV_RBW") ? atoi(getenv("RSLO_SPCONV_RBW")) : 0;
+static int spc_force_ks = getenv("RSLO_SPCONV_KS") ? atoi(getenv("RSLO_SPCONV_KS")) : 0;
+extern "C" void rslo_spconv_set_tiling(int rbw, int ks) {
+  spc_force_rbw = (rbw == 1 || rbw == 2 || rbw == 4) ? rbw : 0;
+  spc_force_ks = (ks == 1 || ks == 2 || ks == 4) ? ks : 0;
+}
+
 extern "C" int rslo_spconv_fwd_split(const float *in, int cin, const void *Ws, const float *bias, const int32_t *nbr,
                                      const int32_t *row_order, int64_t n_out, int K, int cout, int flip_k,
                                      float act_slope, float *out, void *stream) {
@@ -1179,19 +1239,28 @@ extern "C" int rslo_spconv_fwd_split(const float *in, int cin, const void *Ws, c
     RSLO_CHECK_LAUNCH("spconv_v9");
     return RSLO_OK;
   }
-  static const int force_rbw = getenv("RSLO_SPCONV_RBW") ? atoi(getenv("RSLO_SPCONV_RBW")) : 0;
-  const int rbw = force_rbw ? force_rbw : ((n_out >= 256 * 32 * 8) ? 2 : 1);
+  const int force_rbw = spc_force_rbw, force_ks = spc_force_ks;
+  int rbw = force_rbw ? force_rbw : ((n_out >= 256 * 32 * 8) ? 2 : 1);
+  // measured per layer shape (profiles/r02_spconv_offset_split.txt): two waves per 32-row tile win everywhere except
+  // 32 -> 32 (the cheapest products per gathered row: the LDS hand-over costs more than the shorter chain saves)
+  const int ks = force_ks ? force_ks : ((cin == 32 && cout == 32) ? 1 : 2);
+  if (!force_rbw && ks == 2) rbw = 2;
+#define SPC6_LAUNCH(CI, CO, RB, KSv)                                                                        \
+  hipLaunchKernelGGL((k_spconv_v6<CI, CO, RB, KSv>), dim3(xcd_grid(rslo_cdiv(rslo_cdiv(n_out, 16 * RB), 4 / KSv))), \
+                     dim3(SPC_THREADS), 0, st, in, ws, bias, nbr, row_order, n_out, K, flip_k, act_slope, out)
 #define SPC6_CASE(CI, CO)                                                                                    \
   if (cin == CI && cout == CO) {                                                                             \
-    if (rbw == 2)                                                                                            \
-      hipLaunchKernelGGL((k_spconv_v6<CI, CO, 2>), dim3(xcd_grid(rslo_cdiv(rslo_cdiv(n_out, 32), 4))),       \
-                         dim3(SPC_THREADS), 0, st, in, ws, bias, nbr, row_order, n_out, K, flip_k, act_slope, out);     \
-    else                                                                                                     \
-      hipLaunchKernelGGL((k_spconv_v6<CI, CO, 1>), dim3(xcd_grid(rslo_cdiv(rslo_cdiv(n_out, 16), 4))),       \
-                         dim3(SPC_THREADS), 0, st, in, ws, bias, nbr, row_order, n_out, K, flip_k, act_slope, out);     \
+    if (rbw == 4) SPC6_LAUNCH(CI, CO, 4, 1);                                                                 \
+    else if (rbw == 2 && ks == 4) SPC6_LAUNCH(CI, CO, 2, 4);                                                 \
+    else if (rbw == 2 && ks == 2) SPC6_LAUNCH(CI, CO, 2, 2);                                                 \
+    else if (rbw == 2) SPC6_LAUNCH(CI, CO, 2, 1);                                                            \
+    else if (ks == 4) SPC6_LAUNCH(CI, CO, 1, 4);                                                             \
+    else if (ks == 2) SPC6_LAUNCH(CI, CO, 1, 2);                                                             \
+    else SPC6_LAUNCH(CI, CO, 1, 1);                                                                          \
   }
   SPC6_CASE(32, 32) SPC6_CASE(32, 64) SPC6_CASE(64, 32) SPC6_CASE(64, 64)
 #undef SPC6_CASE
+#undef SPC6_LAUNCH
   RSLO_CHECK_LAUNCH("spconv_v6");
   return RSLO_OK;
 }
@@ -1475,7 +1544,9 @@ extern "C" int rslo_spconv_wgrad(const float *in, int cin, const float *dout, in
 // contraction dimension.  Wave partials are summed through LDS in a fixed order, chunk partials by a second
 // kernel in chunk order: deterministic, no atomics.
 // ---------------------------------------------------------------------------------------
+#ifndef WG2_CHUNK
 #define WG2_CHUNK 2048
+#endif
 
 template <int CIN_T, int COUT_T, bool EXACT>
 __global__ __launch_bounds__(SPC_THREADS) void k_wgrad2(const float *__restrict__ in, int cin,

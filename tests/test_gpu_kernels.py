@@ -177,6 +177,7 @@ def test_multi_tile_wave_form_gives_the_same_bits(hip, cin, cout):
             g = torch.randn(len(coords), cout, device="cuda")
             order = hip.rulebook_row_order(nbr)
             L.rslo_spconv_set_v9(0)
+            L.rslo_spconv_set_tiling(2, 1)       # the one-wave-per-tile form v9 mirrors
             ref = [hip.spconv_fwd(x, W, b, nbr, act_slope=0.01), hip.spconv_dgrad(g, W, nbr, flip_k=True),
                    hip.spconv_fwd(x, W, b, nbr, act_slope=0.01, order=order)]
             for mode in (2, 4):
@@ -187,6 +188,42 @@ def test_multi_tile_wave_form_gives_the_same_bits(hip, cin, cout):
                     assert torch.equal(a, r), (mode, n)
     finally:
         L.rslo_spconv_set_v9(-1)
+        L.rslo_spconv_set_tiling(0, 0)
+
+
+@pytest.mark.parametrize("cin,cout", [(32, 32), (64, 64), (32, 64), (64, 32)])
+def test_offset_split_tilings_agree(hip, cin, cout):
+    """rslo_spconv_set_tiling: every (rows per tile, waves per tile) form of k_spconv_v6 computes the same products; only
+    the order in which the per-offset sums meet differs (ks waves are added through LDS in wave order).  All forms
+    against float64 within the fp32 bar of the kernel, each form run-to-run identical, ragged and tiny sizes included."""
+    rng = np.random.default_rng(cin * 5 + cout)
+    dims = [9, 60, 70]
+    L = hip.lib()
+    try:
+        for n in (1, 31, 5000, 8200 + 17):
+            coords = rand_sites(rng, 2, dims, n)
+            idx = hip.SiteIndex(dev(coords), 2, dims)
+            nbr = hip.rulebook_subm(idx, [3, 3, 3])
+            x = torch.randn(len(coords), cin, device="cuda")
+            W = torch.randn(27, cin, cout, device="cuda") * 0.1
+            b = torch.randn(cout, device="cuda")
+            order = hip.rulebook_row_order(nbr)
+            # float64 reference: gather-matmul per offset
+            nb = nbr.long()
+            xz = torch.cat([x.double(), torch.zeros(1, cin, dtype=torch.float64, device="cuda")])
+            ref = b.double()[None].repeat(len(coords), 1)
+            for k in range(27):
+                ref += xz[torch.where(nb[:, k] >= 0, nb[:, k], torch.full_like(nb[:, k], len(coords)))] @ W[k].double()
+            scale = ref.abs().max().item() + 1e-30
+            for rbw, ks in ((1, 1), (1, 2), (1, 4), (2, 1), (2, 2), (2, 4), (4, 1), (0, 0)):
+                L.rslo_spconv_set_tiling(rbw, ks)
+                y = hip.spconv_fwd(x, W, b, nbr)
+                assert (y.double() - ref).abs().max().item() <= 2e-6 * scale, (rbw, ks, n)
+                assert torch.equal(hip.spconv_fwd(x, W, b, nbr), y), (rbw, ks, n)
+                yo = hip.spconv_fwd(x, W, b, nbr, order=order)
+                assert (yo.double() - ref).abs().max().item() <= 2e-6 * scale, (rbw, ks, n, "order")
+    finally:
+        L.rslo_spconv_set_tiling(0, 0)
 
 
 def test_rulebook_empty_input(hip):
