@@ -146,7 +146,7 @@ class ConvProbe:
         t = "true" if trans else "false"
         rbw = 2 if n_out >= 256 * 32 * 8 else 1
         if bf16:
-            return "k_spconv_bf16<%d, %d, %d>" % (cin_op, cout_op, rbw)
+            return "k_spconv_bf16<%d, %d, %d, %d>" % (cin_op, cout_op, rbw, 1 if (cin_op == 32 and cout_op == 32) else 2)
         if split:      # rslo_spconv_fwd_split: two waves per 32-row tile except for 32 -> 32
             ks = 1 if (cin_op == 32 and cout_op == 32) else 2
             return "k_spconv_v6<%d, %d, %d, %d>" % (cin_op, cout_op, 2 if ks == 2 else rbw, ks)

@@ -1039,7 +1039,8 @@ __global__ void k_weight_bf16(const float *__restrict__ W, int K, int cin_op, in
   Wb[i] = f32_to_bf16_rne(w);
 }
 
-template <int CIN_T, int COUT_T, int RBW>
+// KS waves per tile as in k_spconv_v6 (offsets k = wave (mod KS), fp32 accumulators added through LDS in wave order)
+template <int CIN_T, int COUT_T, int RBW, int KS = 1>
 __global__ __launch_bounds__(SPC_THREADS) void k_spconv_bf16(const unsigned short *__restrict__ in,
                                                              const unsigned short *__restrict__ Wb,
                                                              const float *__restrict__ bias,
@@ -1049,30 +1050,36 @@ __global__ __launch_bounds__(SPC_THREADS) void k_spconv_bf16(const unsigned shor
   constexpr int NS = CIN_T / 32;
   constexpr int NB = COUT_T / 16;
   constexpr int ROWS = 16 * RBW;
-  __shared__ int32_t nbl[SPC_WAVES][ROWS * SPC_MAXK];
-  __shared__ int32_t orow[SPC_WAVES][ROWS];
+  constexpr int TPB = SPC_WAVES / KS;  // tiles per workgroup
+  __shared__ int32_t nbl[TPB][ROWS * SPC_MAXK];
+  __shared__ int32_t orow[TPB][ROWS];
+  __shared__ __attribute__((aligned(16))) VecF<NB> part[KS > 1 ? TPB * (KS - 1) * RBW * 4 * 64 : 1];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int li = lane & 15, g = lane >> 4;
   const int64_t n_tiles = (n_out + ROWS - 1) / ROWS;
-  const int64_t n_blocks = (n_tiles + SPC_WAVES - 1) / SPC_WAVES;
+  const int tw = wid / KS, half = wid % KS;
+  const int64_t n_blocks = (n_tiles + TPB - 1) / TPB;
   const int64_t vb = xcd_tile(n_blocks);
-  const int64_t tile = vb * SPC_WAVES + wid;
+  const int64_t tile = vb * TPB + tw;
   const bool active = vb < n_blocks && tile < n_tiles;
   const int64_t row0 = tile * ROWS;
 
-  if (active) spc_load_tile<ROWS>(nbr, order, row0, n_out, K, lane, nbl[wid], orow[wid]);
+  if (active && half == 0) spc_load_tile<ROWS>(nbr, order, row0, n_out, K, lane, nbl[tw], orow[tw]);
   __syncthreads();
-  if (!active) return;
+  if (KS == 1 && !active) return;
 
   unsigned mask = 0;
-  for (int k = 0; k < K; ++k) {
-    bool any = false;
+  if (active) {
+    for (int k = 0; k < K; ++k) {
+      bool any = false;
 #pragma unroll
-    for (int rb = 0; rb < RBW; ++rb) any |= nbl[wid][(rb * 16 + li) * K + k] >= 0;
-    if (__ballot(any) != 0ull) mask |= 1u << k;
+      for (int rb = 0; rb < RBW; ++rb) any |= nbl[tw][(rb * 16 + li) * K + k] >= 0;
+      if (__ballot(any) != 0ull) mask |= 1u << k;
+    }
   }
   mask = __builtin_amdgcn_readfirstlane(mask);
+  if constexpr (KS > 1) mask &= (KS == 2 ? 0x55555555u : 0x11111111u) << half;
 
   f32x4 acc[RBW][NB];
 #pragma unroll
@@ -1088,7 +1095,7 @@ __global__ __launch_bounds__(SPC_THREADS) void k_spconv_bf16(const unsigned shor
     bool ok[RBW];
 #pragma unroll
     for (int rb = 0; rb < RBW; ++rb) {
-      const int32_t r = nbl[wid][(rb * 16 + li) * K + k];
+      const int32_t r = nbl[tw][(rb * 16 + li) * K + k];
       ok[rb] = r >= 0;
       ap[rb] = in + (int64_t)(ok[rb] ? r : 0) * CIN_T + 8 * g;
     }
@@ -1110,6 +1117,32 @@ __global__ __launch_bounds__(SPC_THREADS) void k_spconv_bf16(const unsigned shor
     }
   }
 
+  if constexpr (KS > 1) {
+    VecF<NB> *slot = part + tw * ((KS - 1) * RBW * 4 * 64);
+    if (half > 0 && active) {
+#pragma unroll
+      for (int rb = 0; rb < RBW; ++rb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          VecF<NB> v;
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) v.v[nb] = acc[rb][nb][j];
+          slot[((half - 1) * RBW * 4 + rb * 4 + j) * 64 + lane] = v;
+        }
+    }
+    __syncthreads();
+    if (half > 0 || !active) return;
+#pragma unroll
+    for (int h = 1; h < KS; ++h)
+#pragma unroll
+      for (int rb = 0; rb < RBW; ++rb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const VecF<NB> v = slot[((h - 1) * RBW * 4 + rb * 4 + j) * 64 + lane];
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) acc[rb][nb][j] += v.v[nb];
+        }
+  }
   VecF<NB> bv;
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) bv.v[nb] = bias ? bias[NB * li + nb] : 0.f;
@@ -1117,7 +1150,7 @@ __global__ __launch_bounds__(SPC_THREADS) void k_spconv_bf16(const unsigned shor
   for (int rb = 0; rb < RBW; ++rb)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int64_t row = orow[wid][rb * 16 + 4 * g + j];
+      const int64_t row = orow[tw][rb * 16 + 4 * g + j];
       if (row < 0) continue;
       unsigned short o[NB];
 #pragma unroll
@@ -1132,6 +1165,10 @@ __global__ __launch_bounds__(SPC_THREADS) void k_spconv_bf16(const unsigned shor
         *reinterpret_cast<unsigned *>(dst) = (unsigned)o[0] | ((unsigned)o[1] << 16);
     }
 }
+
+// k_spconv_v6 tiling: rows per tile = 16 rbw (1, 2, 4), waves per tile ks (1, 2, 4; rbw 4 only with ks 1); 0 = choose
+static int spc_force_rbw = getenv("RSLO_SPCONV_RBW") ? atoi(getenv("RSLO_SPCONV_RBW")) : 0;
+static int spc_force_ks = getenv("RSLO_SPCONV_KS") ? atoi(getenv("RSLO_SPCONV_KS")) : 0;
 
 extern "C" int rslo_weight_to_bf16(const float *W, int K, int cin_op, int cout_op, int transpose, void *Wb, void *stream) {
   RSLO_CHECK_ARG(W && Wb && K >= 1, "rslo_weight_to_bf16: bad arguments");
@@ -1153,17 +1190,25 @@ extern "C" int rslo_spconv_fwd_bf16(const void *in, int cin, const void *Wb, con
   if (n_out == 0) return RSLO_OK;
   const unsigned short *x = (const unsigned short *)in, *w = (const unsigned short *)Wb;
   unsigned short *o = (unsigned short *)out;
-  const int rbw = (n_out >= 256 * 32 * 8) ? 2 : 1;
+  // rslo_spconv_set_tiling applies here too.  Measured (profiles/r02_spconv_offset_split.txt): the bf16 kernel moves half
+  // the bytes per product and gains less from a second wave per tile -- 64 -> 64 level 3 35.9 -> 32.0 us (16-row tiles),
+  // level 2 67.0 -> 65.8 us (32-row tiles), 32 -> 32 loses (27.4 -> 29.7 us)
+  const int rbw = spc_force_rbw == 1 || spc_force_rbw == 2 ? spc_force_rbw : ((n_out >= 256 * 32 * 8) ? 2 : 1);
+  const int ks = spc_force_ks ? spc_force_ks : ((cin == 32 && cout == 32) ? 1 : 2);
+#define SPCB_LAUNCH(CI, CO, RB, KSv)                                                                           \
+  hipLaunchKernelGGL((k_spconv_bf16<CI, CO, RB, KSv>), dim3(xcd_grid(rslo_cdiv(rslo_cdiv(n_out, 16 * RB), 4 / KSv))), \
+                     dim3(SPC_THREADS), 0, st, x, w, bias, nbr, row_order, n_out, K, flip_k, act_slope, o)
 #define SPCB_CASE(CI, CO)                                                                                   \
   if (cin == CI && cout == CO) {                                                                            \
-    if (rbw == 2)                                                                                           \
-      hipLaunchKernelGGL((k_spconv_bf16<CI, CO, 2>), dim3(xcd_grid(rslo_cdiv(rslo_cdiv(n_out, 32), 4))),    \
-                         dim3(SPC_THREADS), 0, st, x, w, bias, nbr, row_order, n_out, K, flip_k, act_slope, o);        \
-    else                                                                                                    \
-      hipLaunchKernelGGL((k_spconv_bf16<CI, CO, 1>), dim3(xcd_grid(rslo_cdiv(rslo_cdiv(n_out, 16), 4))),    \
-                         dim3(SPC_THREADS), 0, st, x, w, bias, nbr, row_order, n_out, K, flip_k, act_slope, o);        \
+    if (rbw == 2 && ks == 4) SPCB_LAUNCH(CI, CO, 2, 4);                                                     \
+    else if (rbw == 2 && ks == 2) SPCB_LAUNCH(CI, CO, 2, 2);                                                \
+    else if (rbw == 2) SPCB_LAUNCH(CI, CO, 2, 1);                                                           \
+    else if (ks == 4) SPCB_LAUNCH(CI, CO, 1, 4);                                                            \
+    else if (ks == 2) SPCB_LAUNCH(CI, CO, 1, 2);                                                            \
+    else SPCB_LAUNCH(CI, CO, 1, 1);                                                                         \
   }
   SPCB_CASE(32, 32) SPCB_CASE(32, 64) SPCB_CASE(64, 32) SPCB_CASE(64, 64)
+#undef SPCB_LAUNCH
 #undef SPCB_CASE
   RSLO_CHECK_LAUNCH("spconv_bf16");
   return RSLO_OK;
@@ -1195,9 +1240,6 @@ extern "C" int rslo_weight_split_many(const RsloWeightSplitDesc *desc_dev, int n
 static int spc_v9_mode = getenv("RSLO_SPCONV_V9") ? atoi(getenv("RSLO_SPCONV_V9")) : -1;
 extern "C" void rslo_spconv_set_v9(int mode) { spc_v9_mode = mode; }
 
-// k_spconv_v6 tiling: rows per tile = 16 rbw (1, 2, 4), waves per tile ks (1, 2, 4; rbw 4 only with ks 1); 0 = choose
-static int spc_force_rbw = getenv("RSLO_SPCONV_RBW") ? atoi(getenv("RSLO_SPCONV_RBW")) : 0;
-static int spc_force_ks = getenv("RSLO_SPCONV_KS") ? atoi(getenv("RSLO_SPCONV_KS")) : 0;
 extern "C" void rslo_spconv_set_tiling(int rbw, int ks) {
   spc_force_rbw = (rbw == 1 || rbw == 2 || rbw == 4) ? rbw : 0;
   spc_force_ks = (ks == 1 || ks == 2 || ks == 4) ? ks : 0;

@@ -215,6 +215,7 @@ def test_offset_split_tilings_agree(hip, cin, cout):
             for k in range(27):
                 ref += xz[torch.where(nb[:, k] >= 0, nb[:, k], torch.full_like(nb[:, k], len(coords)))] @ W[k].double()
             scale = ref.abs().max().item() + 1e-30
+            bf16_ref = None
             for rbw, ks in ((1, 1), (1, 2), (1, 4), (2, 1), (2, 2), (2, 4), (4, 1), (0, 0)):
                 L.rslo_spconv_set_tiling(rbw, ks)
                 y = hip.spconv_fwd(x, W, b, nbr)
@@ -222,6 +223,14 @@ def test_offset_split_tilings_agree(hip, cin, cout):
                 assert torch.equal(hip.spconv_fwd(x, W, b, nbr), y), (rbw, ks, n)
                 yo = hip.spconv_fwd(x, W, b, nbr, order=order)
                 assert (yo.double() - ref).abs().max().item() <= 2e-6 * scale, (rbw, ks, n, "order")
+                if rbw != 4:       # the bf16 feature kernel (C4) takes the same tilings: bf16 rows, fp32 accumulation
+                    xb = x.to(torch.bfloat16)
+                    yb = hip.spconv_fwd_bf16(xb, W, b, nbr)
+                    if bf16_ref is None:
+                        bf16_ref = yb
+                    # the partial sums meet in a different order: one bf16 ulp of the rounded output at most
+                    assert (yb.float() - bf16_ref.float()).abs().max().item() <= 2 ** -7 * scale, (rbw, ks, n, "bf16")
+                    assert torch.equal(hip.spconv_fwd_bf16(xb, W, b, nbr), yb)
     finally:
         L.rslo_spconv_set_tiling(0, 0)
 
