@@ -586,13 +586,19 @@ struct Conv2dFwdGeom {
   int tiles_x, tiles_y;
 };
 
-template <int TR, int MTW, bool FULLA, bool LP = false>
-__global__ __launch_bounds__(256, 2) void k_conv2d_fwd(const float *__restrict__ in, const unsigned short *__restrict__ Ws,
+// KC = 2 (small maps): a second set of four waves takes every other channel chunk with its own staging buffer and the two
+// accumulator sets meet through LDS (set 0 + set 1, a fixed order).  On the 12x22 / 24x44 maps a launch is less than one
+// workgroup per CU and lasts as long as ONE workgroup's chain of n_chunks x (global load -> split -> LDS -> 9 taps),
+// 2.7 us per chunk against 0.7 us of MFMAs: two half-length chains side by side on the CU halve it.
+template <int TR, int MTW, bool FULLA, bool LP = false, int KC = 1>
+__global__ __launch_bounds__(256 * KC, 2 / KC) void k_conv2d_fwd(const float *__restrict__ in, const unsigned short *__restrict__ Ws,
                                                     const float *__restrict__ bias, Conv2dFwdGeom gm,
                                                     float *__restrict__ out) {
   constexpr int NTW = TR / 2, HR = TR + 2, NPX = HR * 18;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[NPX * C2F_PXB];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  __shared__ __attribute__((aligned(16))) unsigned char lds_all[KC][NPX * C2F_PXB];
+  const int grp = KC == 1 ? 0 : (int)(threadIdx.x >> 8);       // wave set (wave-uniform)
+  unsigned char *lds = lds_all[grp];
+  const int tid = threadIdx.x & 255, lane = tid & 63, wid = tid >> 6;
   const int li = lane & 15, g = lane >> 4;
   const int wm = wid & 1, wn = wid >> 1;
   int bx = blockIdx.x;
@@ -630,7 +636,7 @@ __global__ __launch_bounds__(256, 2) void k_conv2d_fwd(const float *__restrict__
 #pragma unroll
   for (int r = 0; r < NTASK; ++r)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) raw[r][j] = tsrc[r] ? tsrc[r][j * HW] : 0.f;
+    for (int j = 0; j < 8; ++j) raw[r][j] = (tsrc[r] && grp < n_chunks) ? tsrc[r][((int64_t)grp * 32 + j) * HW] : 0.f;
   // weight operands are fetched one tap ahead (they come from L2 / Infinity Cache: the split weights of a whole model do
   // not stay in one XCD's L2 between layers); tap 0 of a chunk is requested before the staging barrier
   // FULLA (small maps, few MFMAs per tap): all 9 taps of a chunk are held in registers and each tap's registers are
@@ -647,13 +653,17 @@ __global__ __launch_bounds__(256, 2) void k_conv2d_fwd(const float *__restrict__
       L_[mt] = *(const u32x4 *)(wp + 1024);                                                               \
     }                                                                                                     \
   }
-  if (FULLA) {
+  if (grp < n_chunks) {
+    if (FULLA) {
 #pragma unroll
-    for (int t = 0; t < NA; ++t) { C2F_LOAD_A(0, t, ah[t], am[t], al[t]) }
-  } else {
-    C2F_LOAD_A(0, 0, ah[0], am[0], al[0])
+      for (int t = 0; t < NA; ++t) { C2F_LOAD_A(grp, t, ah[t], am[t], al[t]) }
+    } else {
+      C2F_LOAD_A(grp, 0, ah[0], am[0], al[0])
+    }
   }
-  for (int chunk = 0; chunk < n_chunks; ++chunk) {
+  for (int chunk = grp; chunk < n_chunks + grp; chunk += KC) {      // both wave sets pass the same number of barriers
+    const bool live = chunk < n_chunks;
+    if (live) {
     // split the prefetched values of this chunk into LDS, then prefetch the next chunk's (in flight during the MFMAs)
 #pragma unroll
     for (int r = 0; r < NTASK; ++r) {
@@ -667,13 +677,15 @@ __global__ __launch_bounds__(256, 2) void k_conv2d_fwd(const float *__restrict__
         }
       }
     }
-    if (chunk + 1 < n_chunks) {
+    if (chunk + KC < n_chunks) {
 #pragma unroll
       for (int r = 0; r < NTASK; ++r)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) raw[r][j] = tsrc[r] ? tsrc[r][((int64_t)(chunk + 1) * 32 + j) * HW] : 0.f;
+        for (int j = 0; j < 8; ++j) raw[r][j] = tsrc[r] ? tsrc[r][((int64_t)(chunk + KC) * 32 + j) * HW] : 0.f;
+    }
     }
     __syncthreads();
+    if (live) {
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
 #pragma unroll
@@ -684,8 +696,8 @@ __global__ __launch_bounds__(256, 2) void k_conv2d_fwd(const float *__restrict__
         if (!FULLA) {
           if (tap < 8) {
             C2F_LOAD_A(chunk, tap + 1, nh, nm, nl)
-          } else if (chunk + 1 < n_chunks) {
-            C2F_LOAD_A(chunk + 1, 0, nh, nm, nl)
+          } else if (chunk + KC < n_chunks) {
+            C2F_LOAD_A(chunk + KC, 0, nh, nm, nl)
           }
         }
         u32x4 bh[NTW], bm[NTW], bl[NTW];
@@ -726,7 +738,7 @@ __global__ __launch_bounds__(256, 2) void k_conv2d_fwd(const float *__restrict__
 #pragma unroll
           for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = MFMA_BF16(ah[ia][mt], bh[nt], acc[mt][nt]);
         if (FULLA) {
-          if (chunk + 1 < n_chunks) { C2F_LOAD_A(chunk + 1, tap, ah[ia], am[ia], al[ia]) }
+          if (chunk + KC < n_chunks) { C2F_LOAD_A(chunk + KC, tap, ah[ia], am[ia], al[ia]) }
         } else {
 #pragma unroll
           for (int mt = 0; mt < MTW; ++mt) {
@@ -736,9 +748,29 @@ __global__ __launch_bounds__(256, 2) void k_conv2d_fwd(const float *__restrict__
         }
       }
     }
+    }
     __syncthreads();
   }
 #undef C2F_LOAD_A
+  if constexpr (KC == 2) {      // set 1 -> LDS (its own staging buffer, free after the last barrier) -> set 0
+    float *slot = reinterpret_cast<float *>(lds_all[1]);
+    if (grp == 1) {
+#pragma unroll
+      for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) slot[((mt * NTW + nt) * 4 + j) * 256 + tid] = acc[mt][nt][j];
+    }
+    __syncthreads();
+    if (grp == 1) return;
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[mt][nt][j] += slot[((mt * NTW + nt) * 4 + j) * 256 + tid];
+  }
 
   const int x = x0 + li;
 #pragma unroll
@@ -828,16 +860,26 @@ static int conv2d_fwd_launch(const float *in, const void *Ws, const float *bias,
   const dim3 grid((unsigned)(B * gm.tiles_x * gm.tiles_y), (unsigned)(cout / (32 * mtw)));
   hipStream_t st = (hipStream_t)stream;
   const unsigned short *ws = (const unsigned short *)Ws;
+  // two wave sets per workgroup (channel chunks alternate between them) when the launch leaves CUs empty and the chain
+  // is long (RSLO_CONV2D_FWD_KC = 1 | 2 forces it).  Measured (scripts/bench_conv2d_fwd.py): 256 -> 256 at 12x22 (192
+  // workgroups, 8 chunks) 23.7 -> 19.0 us; 128 -> 128 at 24x44 (288 workgroups, 4 chunks) 17.1 -> 21.4 us, 512 -> 128 at
+  // 24x44 50.9 -> 61.0 us, 48x88 and larger 44 -> 62 us: every wave streams its own weight operands (27 KB per chunk)
+  // through the CU's vector L1, and a second wave set doubles that traffic wherever the CUs are already occupied
+  static const int kc_env = getenv("RSLO_CONV2D_FWD_KC") ? atoi(getenv("RSLO_CONV2D_FWD_KC")) : 0;
+  const int64_t wgs4 = (int64_t)B * gm.tiles_x * rslo_cdiv(H, 4) * (cout / 32);
+  const bool kc2 = cin >= 64 && (kc_env ? kc_env == 2 : (cin >= 256 && wgs4 <= 200));
   if (lp) {       // bf16 operands (C4): the default tile configuration only
     const dim3 grid1((unsigned)(B * gm.tiles_x * (int)rslo_cdiv(H, 4)), (unsigned)(cout / 32));
     gm.tiles_y = (int)rslo_cdiv(H, 4);
-    hipLaunchKernelGGL((k_conv2d_fwd<4, 1, true, true>), grid1, dim3(256), 0, st, in, ws, bias, gm, out);
+    if (kc2) hipLaunchKernelGGL((k_conv2d_fwd<4, 1, true, true, 2>), grid1, dim3(512), 0, st, in, ws, bias, gm, out);
+    else hipLaunchKernelGGL((k_conv2d_fwd<4, 1, true, true>), grid1, dim3(256), 0, st, in, ws, bias, gm, out);
     RSLO_CHECK_LAUNCH("k_conv2d_fwd(bf16)");
     return RSLO_OK;
   }
   if (tr == 8 && mtw == 2) hipLaunchKernelGGL((k_conv2d_fwd<8, 2, false>), grid, dim3(256), 0, st, in, ws, bias, gm, out);
   else if (tr == 8) hipLaunchKernelGGL((k_conv2d_fwd<8, 1, false>), grid, dim3(256), 0, st, in, ws, bias, gm, out);
   else if (mtw == 2) hipLaunchKernelGGL((k_conv2d_fwd<4, 2, false>), grid, dim3(256), 0, st, in, ws, bias, gm, out);
+  else if (kc2) hipLaunchKernelGGL((k_conv2d_fwd<4, 1, true, false, 2>), grid, dim3(512), 0, st, in, ws, bias, gm, out);
   else hipLaunchKernelGGL((k_conv2d_fwd<4, 1, true>), grid, dim3(256), 0, st, in, ws, bias, gm, out);
   RSLO_CHECK_LAUNCH("k_conv2d_fwd");
   return RSLO_OK;

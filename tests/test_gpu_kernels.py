@@ -941,6 +941,9 @@ def test_hip_conv2d_module_gradients_match_library(hip):
     (2, 96, 64, 25, 23, None),       # odd sizes: ragged tiles in both directions
     (1, 64, 64, 96, 176, None),      # full-resolution BEV map
     (2, 64, 128, 16, 40, "8,2"), (2, 64, 128, 16, 40, "8,1"), (2, 64, 128, 16, 40, "4,2"), (2, 64, 128, 16, 40, "4,1"),
+    (1, 256, 256, 12, 22, None),     # the library's own choice here: two wave sets per workgroup (forward and gradient)
+    (2, 96, 64, 25, 23, "kc=2"),     # two wave sets forced on an ODD number of channel chunks and ragged tiles
+    (1, 64, 32, 9, 17, "kc=2"),      # ... and on one chunk per set
 ])
 def test_conv2d_fwd_and_dgrad_match_float64_oracle(hip, B, cin, cout, H, W, cfg):
     """Forward (with bias) and data gradient through rslo_conv2d_wsplit + rslo_conv2d_fwd against the float64
@@ -956,7 +959,7 @@ def test_conv2d_fwd_and_dgrad_match_float64_oracle(hip, B, cin, cout, H, W, cfg)
                 "y = capi.conv2d_fwd(torch.from_numpy(x).cuda(), capi.conv2d_wsplit(torch.from_numpy(w).cuda(), False), None, %d).cpu().numpy();"
                 "r = O.conv2d_fwd(x, w); e = np.abs(y - r).max() / np.abs(r).max(); print(e); sys.exit(0 if e < 2e-5 else 1)"
                 % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), B, cin, H, W, cout, cin, cout))
-        env = dict(os.environ, RSLO_CONV2D_FWD_CFG=cfg)
+        env = dict(os.environ, RSLO_CONV2D_FWD_KC="2") if cfg == "kc=2" else dict(os.environ, RSLO_CONV2D_FWD_CFG=cfg)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, (r.stdout, r.stderr[-2000:])
         return
