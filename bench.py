@@ -202,14 +202,17 @@ class ConvProbe:
         # output (+ split weights / + weight gradient), each touched once
         def c2f_meta(x, ws, bias, cout, lp=False):
             B, cin, H, W = x.shape
+            # the instantiation conv2d_fwd_launch picks (csrc/conv2d.hip): second wave set on long chains / empty CUs
+            wgs = B * ((W + 15) // 16) * ((H + 3) // 4) * (cout // 32)
+            kc = 2 if (cin >= 256 and wgs <= 200) else 1
             return ("dense", 2 * B * H * W * cin * cout * 9, 4 * B * H * W * (cin + cout) + 54 * cin * cout,
-                    "k_conv2d_fwd<4, 1, true%s> [%d->%d %dx%d]" % (", true" if lp else "", cin, cout, H, W))
+                    "k_conv2d_fwd<4, 1, true, %s, %d> [%d->%d %dx%d]" % ("true" if lp else "false", kc, cin, cout, H, W))
 
         def c2w_meta(x, dout, stride=1, want_bias=False, lp=False):
             B, cin, H, W = x.shape
             cout, Ho, Wo = dout.shape[1], dout.shape[2], dout.shape[3]
             return ("dense", 2 * B * Ho * Wo * cin * cout * 9, 4 * B * (H * W * cin + Ho * Wo * cout) + 36 * cin * cout,
-                    ("k_conv2d_wgrad_s1<2%s>" % (", true" if lp else "") if stride == 1 else "k_conv2d_wgrad<2, 2>")
+                    ("k_conv2d_wgrad_s1<2, %s>" % ("true" if lp else "false") if stride == 1 else "k_conv2d_wgrad<2, 2>")
                     + " [%d->%d %dx%d]" % (cin, cout, H, W))
 
         if os.environ.get("RSLO_CONV2D_FWD_CFG") is None and os.environ.get("RSLO_CONV2D_NB") is None:
@@ -283,7 +286,8 @@ class ConvProbe:
             name = gname.split(" [")[0]          # dense groups are keyed kernel + layer shape
             # which roof bounds it: arithmetic intensity vs the fp32 ridge (157.3 TF / 8 TB/s = 19.7 flop/B)
             ai = g["flops"] / g["bytes"]
-            lowp = "k_spconv_bf16" in name or name.endswith(", true>")      # bf16 operands (C4)
+            lowp = ("k_spconv_bf16" in name or (name.startswith("k_conv2d_wgrad_s1") and name.endswith(", true>"))
+                    or (name.startswith("k_conv2d_fwd") and name.split(", ")[3] == "true"))      # bf16 operands (C4)
             if lowp and ai >= MFMA_BF16_PEAK_TF * 1e3 / HBM_PEAK_GBS:
                 r = {"bound": "mfma", "kernel": name, "achieved": round(g["TFLOPs"], 2), "peak": MFMA_BF16_PEAK_TF,
                      "unit": "TFLOP/s", "frac": round(g["TFLOPs"] / MFMA_BF16_PEAK_TF, 4), "traffic": None}
