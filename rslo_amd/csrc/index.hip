@@ -164,21 +164,55 @@ extern "C" int rslo_hash_build(const int32_t *coords, int64_t N, int B, const in
   return RSLO_OK;
 }
 
+// (row, kz, ky, kx) of thread t = row * K + (kz * ks.b + ky) * ks.c + kx.  The generic form is one 64-bit and four 32-bit
+// divisions by run-time values (~200 instructions on this ISA, more than the rest of these kernels); every layer of the
+// path has 3x3x3 kernels, for which FAST decomposes with constant divisors in 32 bits (launchers check row * 27 < 2^31).
+template <bool FAST>
+__device__ __forceinline__ void rb_decompose(int64_t t, Int3 ks, int64_t &row, int &kz, int &ky, int &kx) {
+  if (FAST) {
+    const unsigned u = (unsigned)t, r = u / 27u, k = u - r * 27u;
+    row = r;
+    kz = (int)(k / 9u);
+    ky = (int)((k / 3u) % 3u);
+    kx = (int)(k % 3u);
+  } else {
+    const int K = ks.a * ks.b * ks.c;
+    row = t / K;
+    int k = (int)(t - row * K);
+    kx = k % ks.c;
+    k /= ks.c;
+    ky = k % ks.b;
+    kz = k / ks.b;
+  }
+}
+// t / s and t % s == 0 for a stride component (FAST2: every stride is 2)
+template <bool FAST2>
+__device__ __forceinline__ bool rb_unstride(int t, int s, int &q) {
+  if (FAST2) {
+    q = t >> 1;
+    return (t & 1) == 0;
+  }
+  q = t / s;
+  return t - q * s == 0;
+}
+static inline bool rb_fast_k(const int32_t *ks, int64_t rows) {
+  return ks[0] == 3 && ks[1] == 3 && ks[2] == 3 && rows * 27 < ((int64_t)1 << 31);
+}
+static inline bool rb_fast_s(const int32_t *st) { return st[0] == 2 && st[1] == 2 && st[2] == 2; }
+
 // ---------------------------------------------------------------------------------------
 // SubM rulebook: one thread per (row, offset)
 // ---------------------------------------------------------------------------------------
+template <bool FAST>
 __global__ void k_rulebook_subm(const int32_t *__restrict__ coords, int64_t N, Dims3 s, Int3 ks,
                                 const uint32_t *__restrict__ keys, const int32_t *__restrict__ vals,
                                 uint32_t mask, int shift, int32_t *__restrict__ nbr) {
   const int K = ks.a * ks.b * ks.c;
   int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= N * K) return;
-  const int64_t o = t / K;
-  int k = (int)(t - o * K);
-  const int kx = k % ks.c;
-  k /= ks.c;
-  const int ky = k % ks.b;
-  const int kz = k / ks.b;
+  int64_t o;
+  int kz, ky, kx;
+  rb_decompose<FAST>(t, ks, o, kz, ky, kx);
   const int4 c = reinterpret_cast<const int4 *>(coords)[o];
   const int z = c.y + kz - ks.a / 2, y = c.z + ky - ks.b / 2, x = c.w + kx - ks.c / 2;
   int32_t r = -1;
@@ -195,9 +229,12 @@ extern "C" int rslo_rulebook_subm(const int32_t *coords, int64_t N, int B, const
   if (N == 0) return RSLO_OK;
   const int K = ks[0] * ks[1] * ks[2];
   const int shift = 32 - rslo_log2_i64(cap);
-  hipLaunchKernelGGL(k_rulebook_subm, dim3((unsigned)rslo_cdiv(N * K, 256)), dim3(256), 0, st, coords, N,
-                     Dims3{d[0], d[1], d[2]}, Int3{ks[0], ks[1], ks[2]}, keys, vals,
-                     (uint32_t)(cap - 1), shift, nbr);
+  if (rb_fast_k(ks, N))
+    hipLaunchKernelGGL(k_rulebook_subm<true>, dim3((unsigned)rslo_cdiv(N * K, 256)), dim3(256), 0, st, coords, N,
+                       Dims3{d[0], d[1], d[2]}, Int3{ks[0], ks[1], ks[2]}, keys, vals, (uint32_t)(cap - 1), shift, nbr);
+  else
+    hipLaunchKernelGGL(k_rulebook_subm<false>, dim3((unsigned)rslo_cdiv(N * K, 256)), dim3(256), 0, st, coords, N,
+                       Dims3{d[0], d[1], d[2]}, Int3{ks[0], ks[1], ks[2]}, keys, vals, (uint32_t)(cap - 1), shift, nbr);
   RSLO_CHECK_LAUNCH("rulebook_subm");
   return RSLO_OK;
 }
@@ -211,22 +248,20 @@ extern "C" int64_t rslo_conv_bitmap_words(int B, const int32_t *od) {
   return (vol + 31) / 32;
 }
 
+template <bool FAST, bool FAST2>
 __global__ void k_conv_mark(const int32_t *__restrict__ coords, int64_t N, Int3 ks, Int3 st, Int3 pd,
                             Dims3 od, uint32_t *__restrict__ bitmap) {
   const int K = ks.a * ks.b * ks.c;
   int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= N * K) return;
-  const int64_t i = t / K;
-  int k = (int)(t - i * K);
-  const int kx = k % ks.c;
-  k /= ks.c;
-  const int ky = k % ks.b;
-  const int kz = k / ks.b;
+  int64_t i;
+  int kz, ky, kx;
+  rb_decompose<FAST>(t, ks, i, kz, ky, kx);
   const int4 c = reinterpret_cast<const int4 *>(coords)[i];
   const int tz = c.y + pd.a - kz, ty = c.z + pd.b - ky, tx = c.w + pd.c - kx;
   if (tz < 0 || ty < 0 || tx < 0) return;
-  if (tz % st.a || ty % st.b || tx % st.c) return;
-  const int z = tz / st.a, y = ty / st.b, x = tx / st.c;
+  int z, y, x;
+  if (!rb_unstride<FAST2>(tz, st.a, z) || !rb_unstride<FAST2>(ty, st.b, y) || !rb_unstride<FAST2>(tx, st.c, x)) return;
   if (z >= od.d || y >= od.h || x >= od.w) return;
   const uint32_t lin = rslo_lin(c.x, z, y, x, od);
   atomicOr(&bitmap[lin >> 5], 1u << (lin & 31));
@@ -242,9 +277,13 @@ extern "C" int rslo_conv_out_count(const int32_t *coords_in, int64_t N, int B, c
   RSLO_HIP(hipMemsetAsync(bitmap, 0, (size_t)words * sizeof(uint32_t), st));
   const int K = ks[0] * ks[1] * ks[2];
   if (N > 0) {
-    hipLaunchKernelGGL(k_conv_mark, dim3((unsigned)rslo_cdiv(N * K, 256)), dim3(256), 0, st, coords_in, N,
-                       Int3{ks[0], ks[1], ks[2]}, Int3{stride[0], stride[1], stride[2]},
-                       Int3{pad[0], pad[1], pad[2]}, Dims3{od[0], od[1], od[2]}, bitmap);
+#define RB_MARK(F, F2)                                                                                     \
+    hipLaunchKernelGGL((k_conv_mark<F, F2>), dim3((unsigned)rslo_cdiv(N * K, 256)), dim3(256), 0, st, coords_in, N, \
+                       Int3{ks[0], ks[1], ks[2]}, Int3{stride[0], stride[1], stride[2]},                    \
+                       Int3{pad[0], pad[1], pad[2]}, Dims3{od[0], od[1], od[2]}, bitmap)
+    if (rb_fast_k(ks, N) && rb_fast_s(stride)) RB_MARK(true, true);
+    else RB_MARK(false, false);
+#undef RB_MARK
     RSLO_CHECK_LAUNCH("conv_mark");
   }
   return scan_exclusive<true>(bitmap, word_prefix, words, scan_ws, scan_ws_bytes, d_count, st);
@@ -284,6 +323,7 @@ extern "C" int rslo_conv_out_coords(const uint32_t *bitmap, const int32_t *word_
   return RSLO_OK;
 }
 
+template <bool FAST>
 __global__ void k_rulebook_conv(const int32_t *__restrict__ coords_out, int64_t M, Dims3 id, Int3 ks,
                                 Int3 st, Int3 pd, const uint32_t *__restrict__ keys,
                                 const int32_t *__restrict__ vals, uint32_t mask, int shift,
@@ -291,12 +331,9 @@ __global__ void k_rulebook_conv(const int32_t *__restrict__ coords_out, int64_t 
   const int K = ks.a * ks.b * ks.c;
   int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= M * K) return;
-  const int64_t o = t / K;
-  int k = (int)(t - o * K);
-  const int kx = k % ks.c;
-  k /= ks.c;
-  const int ky = k % ks.b;
-  const int kz = k / ks.b;
+  int64_t o;
+  int kz, ky, kx;
+  rb_decompose<FAST>(t, ks, o, kz, ky, kx);
   const int4 c = reinterpret_cast<const int4 *>(coords_out)[o];
   const int z = c.y * st.a - pd.a + kz, y = c.z * st.b - pd.b + ky, x = c.w * st.c - pd.c + kx;
   int32_t r = -1;
@@ -314,14 +351,19 @@ extern "C" int rslo_rulebook_conv(const int32_t *coords_out, int64_t M, int B, c
   if (M == 0) return RSLO_OK;
   const int K = ks[0] * ks[1] * ks[2];
   const int shift = 32 - rslo_log2_i64(in_cap);
-  hipLaunchKernelGGL(k_rulebook_conv, dim3((unsigned)rslo_cdiv(M * K, 256)), dim3(256), 0, st, coords_out,
-                     M, Dims3{id[0], id[1], id[2]}, Int3{ks[0], ks[1], ks[2]},
-                     Int3{stride[0], stride[1], stride[2]}, Int3{pad[0], pad[1], pad[2]}, in_keys,
-                     in_vals, (uint32_t)(in_cap - 1), shift, nbr);
+#define RB_CONV(F)                                                                                            \
+  hipLaunchKernelGGL(k_rulebook_conv<F>, dim3((unsigned)rslo_cdiv(M * K, 256)), dim3(256), 0, st, coords_out,  \
+                     M, Dims3{id[0], id[1], id[2]}, Int3{ks[0], ks[1], ks[2]},                                 \
+                     Int3{stride[0], stride[1], stride[2]}, Int3{pad[0], pad[1], pad[2]}, in_keys,             \
+                     in_vals, (uint32_t)(in_cap - 1), shift, nbr)
+  if (rb_fast_k(ks, M)) RB_CONV(true);
+  else RB_CONV(false);
+#undef RB_CONV
   RSLO_CHECK_LAUNCH("rulebook_conv");
   return RSLO_OK;
 }
 
+template <bool FAST, bool FAST2>
 __global__ void k_rulebook_conv_T(const int32_t *__restrict__ coords_in, int64_t N, Dims3 od, Int3 ks,
                                   Int3 st, Int3 pd, const uint32_t *__restrict__ keys,
                                   const int32_t *__restrict__ vals, uint32_t mask, int shift,
@@ -329,17 +371,15 @@ __global__ void k_rulebook_conv_T(const int32_t *__restrict__ coords_in, int64_t
   const int K = ks.a * ks.b * ks.c;
   int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= N * K) return;
-  const int64_t i = t / K;
-  int k = (int)(t - i * K);
-  const int kx = k % ks.c;
-  k /= ks.c;
-  const int ky = k % ks.b;
-  const int kz = k / ks.b;
+  int64_t i;
+  int kz, ky, kx;
+  rb_decompose<FAST>(t, ks, i, kz, ky, kx);
   const int4 c = reinterpret_cast<const int4 *>(coords_in)[i];
   const int tz = c.y + pd.a - kz, ty = c.z + pd.b - ky, tx = c.w + pd.c - kx;
   int32_t r = -1;
-  if (tz >= 0 && ty >= 0 && tx >= 0 && tz % st.a == 0 && ty % st.b == 0 && tx % st.c == 0) {
-    const int z = tz / st.a, y = ty / st.b, x = tx / st.c;
+  int z, y, x;
+  if (tz >= 0 && ty >= 0 && tx >= 0 && rb_unstride<FAST2>(tz, st.a, z) && rb_unstride<FAST2>(ty, st.b, y) &&
+      rb_unstride<FAST2>(tx, st.c, x)) {
     if (z < od.d && y < od.h && x < od.w)
       r = rslo_hfind(keys, vals, mask, shift, rslo_lin(c.x, z, y, x, od));
   }
@@ -355,10 +395,14 @@ extern "C" int rslo_rulebook_conv_T(const int32_t *coords_in, int64_t N, int B, 
   if (N == 0) return RSLO_OK;
   const int K = ks[0] * ks[1] * ks[2];
   const int shift = 32 - rslo_log2_i64(out_cap);
-  hipLaunchKernelGGL(k_rulebook_conv_T, dim3((unsigned)rslo_cdiv(N * K, 256)), dim3(256), 0, st, coords_in,
-                     N, Dims3{od[0], od[1], od[2]}, Int3{ks[0], ks[1], ks[2]},
-                     Int3{stride[0], stride[1], stride[2]}, Int3{pad[0], pad[1], pad[2]}, out_keys,
-                     out_vals, (uint32_t)(out_cap - 1), shift, nbrT);
+#define RB_CONVT(F, F2)                                                                                       \
+  hipLaunchKernelGGL((k_rulebook_conv_T<F, F2>), dim3((unsigned)rslo_cdiv(N * K, 256)), dim3(256), 0, st, coords_in, \
+                     N, Dims3{od[0], od[1], od[2]}, Int3{ks[0], ks[1], ks[2]},                                 \
+                     Int3{stride[0], stride[1], stride[2]}, Int3{pad[0], pad[1], pad[2]}, out_keys,            \
+                     out_vals, (uint32_t)(out_cap - 1), shift, nbrT)
+  if (rb_fast_k(ks, N) && rb_fast_s(stride)) RB_CONVT(true, true);
+  else RB_CONVT(false, false);
+#undef RB_CONVT
   RSLO_CHECK_LAUNCH("rulebook_conv_T");
   return RSLO_OK;
 }
@@ -638,55 +682,105 @@ extern "C" int rslo_dense_gather(const float *dense, const int32_t *coords, int6
 // ---------------------------------------------------------------------------------------
 // neighbour table -> spconv-style pair lists (for the weight-gradient kernels)
 // ---------------------------------------------------------------------------------------
-__global__ void k_pair_flags(const int32_t *__restrict__ nbr, int64_t N, int K, uint32_t *__restrict__ flags) {
-  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= N * K) return;
-  const int64_t o = t / K;
-  const int k = (int)(t - o * K);
-  flags[(int64_t)k * N + o] = nbr[t] >= 0 ? 1u : 0u;
+// Pairs of offset k come in ascending row order, offsets in ascending k (the order spconv's indice_pairs have and the
+// fixed summation order of the weight-gradient kernels).  Three launches over row blocks of 256:
+//   k_pair_count : per (offset, row block) the number of present neighbours (wave ballots; the block's table rows are
+//                  staged through LDS so the global reads are coalesced: a thread's K entries are K * 4 bytes apart)
+//   k_pair_scan  : exclusive scan of the [K][blocks] counts in offset-major order (one workgroup) + koff
+//   k_pair_emit  : position = block offset + waves before + ballot rank; writes (input row, output row)
+// The table is read twice and the lists written once (~70 MB for 250 k rows) where the flag / scan / emit form moved
+// ~250 MB through five launches.
+#define PR_ROWS 256
+
+template <bool EMIT>
+__global__ __launch_bounds__(PR_ROWS) void k_pair_pass(const int32_t *__restrict__ nbr, int64_t N, int K, int nblk,
+                                                       int32_t *__restrict__ counts,
+                                                       const int32_t *__restrict__ offsets,
+                                                       int32_t *__restrict__ pin, int32_t *__restrict__ pout) {
+  __shared__ int32_t tab[PR_ROWS * 27];
+  __shared__ int32_t wcnt[PR_ROWS / 64][27];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int64_t row0 = (int64_t)blockIdx.x * PR_ROWS;
+  const int64_t lim = (N - row0 < PR_ROWS ? N - row0 : PR_ROWS) * K;      // table entries of this block
+  for (int e = tid; e < PR_ROWS * K; e += PR_ROWS) tab[e] = e < lim ? nbr[row0 * K + e] : -1;
+  __syncthreads();
+  const int32_t *mine = tab + tid * K;       // stride K = 27 words: conflict-free for odd K
+  for (int k = 0; k < K; ++k) {
+    const unsigned long long m = __ballot(mine[k] >= 0);
+    if (lane == 0) wcnt[wid][k] = __popcll(m);
+  }
+  __syncthreads();
+  if (!EMIT) {
+    if (tid < K) {
+      int32_t c = 0;
+#pragma unroll
+      for (int w = 0; w < PR_ROWS / 64; ++w) c += wcnt[w][tid];
+      counts[(int64_t)tid * nblk + blockIdx.x] = c;
+    }
+    return;
+  }
+  const int64_t row = row0 + tid;
+  for (int k = 0; k < K; ++k) {
+    const int32_t r = mine[k];
+    const unsigned long long m = __ballot(r >= 0);
+    if (r >= 0) {
+      int32_t pos = offsets[(int64_t)k * nblk + blockIdx.x] + __popcll(m & ((1ull << lane) - 1ull));
+      for (int w = 0; w < wid; ++w) pos += wcnt[w][k];
+      pin[pos] = r;
+      pout[pos] = (int32_t)row;
+    }
+  }
 }
 
-__global__ void k_pair_emit(const int32_t *__restrict__ nbr, const int32_t *__restrict__ pos, int64_t N, int K,
-                            int32_t total_unused, int32_t *__restrict__ pin, int32_t *__restrict__ pout,
-                            int32_t *__restrict__ koff, const int32_t *__restrict__ d_total) {
-  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= N * K) return;
-  const int64_t o = t / K;
-  const int k = (int)(t - o * K);
-  const int64_t f = (int64_t)k * N + o;
-  if (o == 0) koff[k] = pos[f];
-  if (t == 0) koff[K] = *d_total;
-  const int32_t r = nbr[t];
-  if (r >= 0) {
-    const int32_t p = pos[f];
-    pin[p] = r;
-    pout[p] = (int32_t)o;
+// exclusive scan of n values in place by ONE workgroup (n = K * blocks, a few 10^4); koff[k] = offset of (k, block 0)
+__global__ __launch_bounds__(1024) void k_pair_scan(int32_t *__restrict__ v, int n, int K, int nblk,
+                                                    int32_t *__restrict__ koff) {
+  __shared__ int32_t wsum[16];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int per = (n + 1023) / 1024;
+  const int i0 = tid * per, i1 = (i0 + per < n) ? i0 + per : n;
+  int32_t s = 0;
+  for (int i = i0; i < i1; ++i) s += v[i];
+  int32_t inc = s;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int32_t t = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += t;
   }
+  if (lane == 63) wsum[wid] = inc;
+  __syncthreads();
+  int32_t run = inc - s;
+  for (int w = 0; w < wid; ++w) run += wsum[w];
+  for (int i = i0; i < i1; ++i) {
+    const int32_t x = v[i];
+    v[i] = run;
+    if (i % nblk == 0) koff[i / nblk] = run;
+    run += x;
+  }
+  if (tid == 1023) koff[K] = run;        // the last thread's running sum ends at the total (empty chunks carry it)
 }
 
 extern "C" int rslo_rulebook_pairs(const int32_t *nbr, int64_t n_rows, int K, void *ws, size_t ws_bytes,
                                    int32_t *pairs_in, int32_t *pairs_out, int32_t *koff, void *stream) {
   hipStream_t st = (hipStream_t)stream;
+  RSLO_CHECK_ARG(K >= 1 && K <= 27, "rulebook_pairs: K must be in 1..27");
   if (n_rows == 0) {
     RSLO_HIP(hipMemsetAsync(koff, 0, (size_t)(K + 1) * sizeof(int32_t), st));
     return RSLO_OK;
   }
   const int64_t n = n_rows * K;
   RSLO_CHECK_ARG(n < (int64_t)2000000000, "rulebook_pairs: table too large");
-  const size_t need = (size_t)n * 8 + rslo_scan_ws_bytes(n) + 512;
-  if (ws_bytes < need) {
+  const int nblk = (int)rslo_cdiv(n_rows, PR_ROWS);
+  if (ws_bytes < (size_t)K * nblk * sizeof(int32_t)) {
     rslo_set_error("rulebook_pairs: workspace too small");
     return RSLO_EWS;
   }
-  uint32_t *flags = (uint32_t *)ws;
-  int32_t *pos = (int32_t *)ws + n;
-  int32_t *d_total = (int32_t *)((char *)ws + (size_t)n * 8);
-  void *sws = (char *)ws + (size_t)n * 8 + 256;
-  const unsigned nb = (unsigned)rslo_cdiv(n, 256);
-  hipLaunchKernelGGL(k_pair_flags, dim3(nb), dim3(256), 0, st, nbr, n_rows, K, flags);
-  if (int rc = scan_exclusive<false>(flags, pos, n, sws, ws_bytes - (size_t)n * 8 - 256, d_total, st)) return rc;
-  hipLaunchKernelGGL(k_pair_emit, dim3(nb), dim3(256), 0, st, nbr, pos, n_rows, K, 0, pairs_in, pairs_out, koff,
-                     d_total);
+  int32_t *counts = (int32_t *)ws;
+  hipLaunchKernelGGL(k_pair_pass<false>, dim3((unsigned)nblk), dim3(PR_ROWS), 0, st, nbr, n_rows, K, nblk, counts,
+                     (const int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
+  hipLaunchKernelGGL(k_pair_scan, dim3(1), dim3(1024), 0, st, counts, K * nblk, K, nblk, koff);
+  hipLaunchKernelGGL(k_pair_pass<true>, dim3((unsigned)nblk), dim3(PR_ROWS), 0, st, nbr, n_rows, K, nblk,
+                     (int32_t *)nullptr, (const int32_t *)counts, pairs_in, pairs_out);
   RSLO_CHECK_LAUNCH("rulebook_pairs");
   return RSLO_OK;
 }
@@ -700,7 +794,10 @@ extern "C" int rslo_rulebook_pairs(const int32_t *nbr, int64_t n_rows, int K, vo
 // One workgroup per window: key = mask << 11 | local row, bitonic sort in LDS (unique keys -> deterministic).
 // flip = 1 reverses the bit order (the mask a SubM data-gradient call walks with flip_k).
 // ---------------------------------------------------------------------------------------
-#define RO_WINDOW 2048
+#ifndef RO_BITS
+#define RO_BITS 11
+#endif
+#define RO_WINDOW (1 << RO_BITS)
 #define RO_THREADS 256
 
 __global__ __launch_bounds__(RO_THREADS) void k_row_order(const int32_t *__restrict__ nbr, int64_t n, int K, int flip,
@@ -714,7 +811,7 @@ __global__ __launch_bounds__(RO_THREADS) void k_row_order(const int32_t *__restr
       unsigned m = 0;
       for (int k = 0; k < K; ++k)
         if (nbr[row * K + k] >= 0) m |= 1u << (flip ? (K - 1 - k) : k);
-      kv = ((unsigned long long)m << 11) | (unsigned)r;
+      kv = ((unsigned long long)m << RO_BITS) | (unsigned)r;
     }
     key[r] = kv;
   }
@@ -736,7 +833,7 @@ __global__ __launch_bounds__(RO_THREADS) void k_row_order(const int32_t *__restr
   }
   for (int r = threadIdx.x; r < RO_WINDOW; r += RO_THREADS) {
     const int64_t row = base + r;
-    if (row < n) order[row] = (int32_t)(base + (int64_t)(key[r] & 2047ull));
+    if (row < n) order[row] = (int32_t)(base + (int64_t)(key[r] & (unsigned long long)(RO_WINDOW - 1)));
   }
 }
 
