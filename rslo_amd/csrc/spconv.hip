@@ -1579,7 +1579,8 @@ extern "C" int rslo_spconv_wgrad(const float *in, int cin, const float *dout, in
 // ---------------------------------------------------------------------------------------
 // wgrad v2 on explicit pair lists.  rslo_rulebook_pairs() turns a neighbour table into the spconv-style
 // rulebook once per indice_key (pairs of offset k contiguous, ascending output row; koff[K+1] on the device),
-// so the gradient kernels do no compaction.  Grid (pair chunk, offset): the 4 waves of a workgroup split a
+// so the gradient kernels do no compaction.  One workgroup per (pair chunk, offset), dealt to the XCDs by wg2_assign()
+// below: the 4 waves of a workgroup split a
 // chunk of WG2_CHUNK pairs; lane (li, g) loads CB contiguous input channels of pair g and NB contiguous output
 // channels (16-byte loads for 64 channels, the same column-permutation trick as the forward kernel) and
 // v_mfma_f32_16x16x4_f32 accumulates dW[ci = CB*i + cb][co = NB*li + nb] with the pair index as the
@@ -1587,8 +1588,47 @@ extern "C" int rslo_spconv_wgrad(const float *in, int cin, const float *dout, in
 // kernel in chunk order: deterministic, no atomics.
 // ---------------------------------------------------------------------------------------
 #ifndef WG2_CHUNK
-#define WG2_CHUNK 2048
+#define WG2_CHUNK 2048      /* pairs per workgroup, fp32-MFMA kernel (16-channel layers) */
 #endif
+#ifndef WG3_CHUNK
+#define WG3_CHUNK 1024      /* split-bf16 / bf16 kernels (32 / 64 channels): 55 vs 61 us (32->32), 64-66 vs 71 us (64->64, 40 k rows) */
+#endif
+#define WG_MIN_CHUNK (WG2_CHUNK < WG3_CHUNK ? WG2_CHUNK : WG3_CHUNK)
+
+// Which (offset k, pair chunk c) a workgroup of the weight-gradient kernels takes.  The grid is one-dimensional and
+// workgroups are dealt to the 8 XCDs round-robin (id & 7), each XCD with its own L2.  XCD x takes, of EVERY offset, the
+// chunks c in [x n_k / 8, (x + 1) n_k / 8) (n_k = chunks of offset k): pair lists ascend in the output row, so these are
+// the pairs of the same eighth of the rows for all 27 offsets -- a row of `in` / `dout` is pulled into ONE L2 and serves
+// its ~15 pairs from there, where the (chunk, offset) grid spread the 27 readers of a row over all XCDs (353 MB through
+// L2 misses per 64->64 launch for 46 MB of distinct rows).  The chunks themselves and the slot a partial is written to
+// are unchanged, so the results keep their bits.  wg2_grid() is the matching launch size (slots per XCD >= what any
+// XCD can be dealt: sum_k (n_k / 8 + 1)).
+template <int CHUNK>
+__device__ __forceinline__ bool wg2_assign(const int32_t *__restrict__ koff, int K, int legacy_nch, int &k, int &c) {
+  if (legacy_nch > 0) {          // the (chunk, offset) order of the earlier grid, kept for A/B runs (RSLO_WGRAD_XCD=0)
+    k = (int)blockIdx.x / legacy_nch;
+    c = (int)blockIdx.x - k * legacy_nch;
+    return k < K && c * CHUNK < koff[k + 1] - koff[k];
+  }
+  const int x = blockIdx.x & 7;
+  int j = blockIdx.x >> 3;
+  for (int kk = 0; kk < K; ++kk) {
+    const int n = (koff[kk + 1] - koff[kk] + CHUNK - 1) / CHUNK;
+    const int c0 = (x * n) >> 3, c1 = ((x + 1) * n) >> 3;
+    if (j < c1 - c0) {
+      k = kk;
+      c = c0 + j;
+      return true;
+    }
+    j -= c1 - c0;
+  }
+  return false;
+}
+static const bool wg2_xcd = !(getenv("RSLO_WGRAD_XCD") && getenv("RSLO_WGRAD_XCD")[0] == '0');
+static inline unsigned wg2_grid(int nch, int K) {
+  return wg2_xcd ? 8u * (unsigned)((nch * K + 7) / 8 + K) : (unsigned)(nch * K);
+}
+static inline int wg2_legacy(int nch) { return wg2_xcd ? 0 : nch; }
 
 template <int CIN_T, int COUT_T, bool EXACT>
 __global__ __launch_bounds__(SPC_THREADS) void k_wgrad2(const float *__restrict__ in, int cin,
@@ -1596,15 +1636,15 @@ __global__ __launch_bounds__(SPC_THREADS) void k_wgrad2(const float *__restrict_
                                                         const int32_t *__restrict__ pin,
                                                         const int32_t *__restrict__ pout,
                                                         const int32_t *__restrict__ koff, int K,
-                                                        float *__restrict__ ws) {
+                                                        int legacy_nch, float *__restrict__ ws) {
   constexpr int CB = CIN_T / 16, NB = COUT_T / 16;
   __shared__ __attribute__((aligned(16))) float red[CIN_T * COUT_T];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int li = lane & 15, g = lane >> 4;
-  const int k = blockIdx.y;
+  int k, chunk;
+  if (!wg2_assign<WG2_CHUNK>(koff, K, legacy_nch, k, chunk)) return;
   const int pk0 = koff[k], pk1 = koff[k + 1];
-  const int p0 = pk0 + (int)blockIdx.x * WG2_CHUNK;
-  if (p0 >= pk1) return;
+  const int p0 = pk0 + chunk * WG2_CHUNK;
   const int p1 = (p0 + WG2_CHUNK < pk1) ? p0 + WG2_CHUNK : pk1;
 
   f32x4 acc[CB][NB];
@@ -1677,7 +1717,7 @@ __global__ __launch_bounds__(SPC_THREADS) void k_wgrad2(const float *__restrict_
     }
     __syncthreads();
   }
-  float *dst = ws + ((int64_t)blockIdx.x * K + k) * cin * cout;
+  float *dst = ws + ((int64_t)chunk * K + k) * cin * cout;
   for (int e = tid; e < cin * cout; e += SPC_THREADS) {
     const int ci = e / cout, co = e - ci * cout;
     dst[e] = red[ci * COUT_T + co];
@@ -1690,21 +1730,24 @@ __global__ __launch_bounds__(SPC_THREADS) void k_wgrad2(const float *__restrict_
 // (one float4 / float2 of its own channels per pair), so no transposition is needed: the 8 gathered values of a
 // channel are split (hi + mid + lo) and packed straight into the A / B operands.  6 MFMAs per 16x16 block and 32 pairs
 // instead of 8 fp32 MFMAs: 2.5x fewer matrix-core cycles, same fixed-order reductions as k_wgrad2.
+#ifndef WG3_WPE
+#define WG3_WPE 2      /* 3 fits 64->64 into 168 registers with 19 spilled: 142 vs 130 us */
+#endif
 template <int CIN_T, int COUT_T>
-__global__ __launch_bounds__(SPC_THREADS) void k_wgrad3(const float *__restrict__ in, const float *__restrict__ dout,
+__global__ __launch_bounds__(SPC_THREADS) __attribute__((amdgpu_waves_per_eu(WG3_WPE))) void k_wgrad3(const float *__restrict__ in, const float *__restrict__ dout,
                                                         const int32_t *__restrict__ pin,
                                                         const int32_t *__restrict__ pout,
                                                         const int32_t *__restrict__ koff, int K,
-                                                        float *__restrict__ ws) {
+                                                        int legacy_nch, float *__restrict__ ws) {
   constexpr int CB = CIN_T / 16, NB = COUT_T / 16;
   __shared__ __attribute__((aligned(16))) float red[CIN_T * COUT_T];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int li = lane & 15, g = lane >> 4;
-  const int k = blockIdx.y;
+  int k, chunk;
+  if (!wg2_assign<WG3_CHUNK>(koff, K, legacy_nch, k, chunk)) return;
   const int pk0 = koff[k], pk1 = koff[k + 1];
-  const int p0 = pk0 + (int)blockIdx.x * WG2_CHUNK;
-  if (p0 >= pk1) return;
-  const int p1 = (p0 + WG2_CHUNK < pk1) ? p0 + WG2_CHUNK : pk1;
+  const int p0 = pk0 + chunk * WG3_CHUNK;
+  const int p1 = (p0 + WG3_CHUNK < pk1) ? p0 + WG3_CHUNK : pk1;
 
   f32x4 acc[CB][NB];
 #pragma unroll
@@ -1712,8 +1755,8 @@ __global__ __launch_bounds__(SPC_THREADS) void k_wgrad3(const float *__restrict_
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) acc[cb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int w0 = p0 + wid * (WG2_CHUNK / SPC_WAVES);
-  const int w1 = (w0 + WG2_CHUNK / SPC_WAVES < p1) ? w0 + WG2_CHUNK / SPC_WAVES : p1;
+  const int w0 = p0 + wid * (WG3_CHUNK / SPC_WAVES);
+  const int w1 = (w0 + WG3_CHUNK / SPC_WAVES < p1) ? w0 + WG3_CHUNK / SPC_WAVES : p1;
   for (int q = w0; q < w1; q += 64) {
     const int myp = q + lane;
     const int32_t my_i = (myp < w1) ? pin[myp] : -1;
@@ -1792,7 +1835,7 @@ __global__ __launch_bounds__(SPC_THREADS) void k_wgrad3(const float *__restrict_
     }
     __syncthreads();
   }
-  float *dst = ws + ((int64_t)blockIdx.x * K + k) * CIN_T * COUT_T;
+  float *dst = ws + ((int64_t)chunk * K + k) * CIN_T * COUT_T;
   for (int e = tid; e < CIN_T * COUT_T; e += SPC_THREADS) dst[e] = red[e];
 }
 
@@ -1833,16 +1876,16 @@ __global__ __launch_bounds__(SPC_THREADS) void k_wgrad3_bf16(const unsigned shor
                                                              const int32_t *__restrict__ pin,
                                                              const int32_t *__restrict__ pout,
                                                              const int32_t *__restrict__ koff, int K,
-                                                             float *__restrict__ ws) {
+                                                             int legacy_nch, float *__restrict__ ws) {
   constexpr int CB = CIN_T / 16, NB = COUT_T / 16;
   __shared__ __attribute__((aligned(16))) float red[CIN_T * COUT_T];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int li = lane & 15, g = lane >> 4;
-  const int k = blockIdx.y;
+  int k, chunk;
+  if (!wg2_assign<WG3_CHUNK>(koff, K, legacy_nch, k, chunk)) return;
   const int pk0 = koff[k], pk1 = koff[k + 1];
-  const int p0 = pk0 + (int)blockIdx.x * WG2_CHUNK;
-  if (p0 >= pk1) return;
-  const int p1 = (p0 + WG2_CHUNK < pk1) ? p0 + WG2_CHUNK : pk1;
+  const int p0 = pk0 + chunk * WG3_CHUNK;
+  const int p1 = (p0 + WG3_CHUNK < pk1) ? p0 + WG3_CHUNK : pk1;
 
   f32x4 acc[CB][NB];
 #pragma unroll
@@ -1850,8 +1893,8 @@ __global__ __launch_bounds__(SPC_THREADS) void k_wgrad3_bf16(const unsigned shor
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) acc[cb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int w0 = p0 + wid * (WG2_CHUNK / SPC_WAVES);
-  const int w1 = (w0 + WG2_CHUNK / SPC_WAVES < p1) ? w0 + WG2_CHUNK / SPC_WAVES : p1;
+  const int w0 = p0 + wid * (WG3_CHUNK / SPC_WAVES);
+  const int w1 = (w0 + WG3_CHUNK / SPC_WAVES < p1) ? w0 + WG3_CHUNK / SPC_WAVES : p1;
   for (int q = w0; q < w1; q += 64) {
     const int myp = q + lane;
     const int32_t my_i = (myp < w1) ? pin[myp] : -1;
@@ -1906,13 +1949,13 @@ __global__ __launch_bounds__(SPC_THREADS) void k_wgrad3_bf16(const unsigned shor
     }
     __syncthreads();
   }
-  float *dst = ws + ((int64_t)blockIdx.x * K + k) * CIN_T * COUT_T;
+  float *dst = ws + ((int64_t)chunk * K + k) * CIN_T * COUT_T;
   for (int e = tid; e < CIN_T * COUT_T; e += SPC_THREADS) dst[e] = red[e];
 }
 
 // grid (ceil(cc / 256), K [+ 1]): row k < K adds the chunk partials of offset k in chunk order; the optional row K adds
 // the bias-gradient partial rows bpart [n_bpart][cout] in row order (8 independent loads in flight, ordered adds).
-__global__ void k_wgrad2_reduce(const float *__restrict__ ws, const int32_t *__restrict__ koff, int K, int cc,
+__global__ void k_wgrad2_reduce(const float *__restrict__ ws, const int32_t *__restrict__ koff, int K, int chunk, int cc,
                                 float *__restrict__ dW, const float *__restrict__ bpart, int n_bpart, int cout,
                                 float *__restrict__ dbias) {
   const int k = blockIdx.y;
@@ -1949,7 +1992,7 @@ __global__ void k_wgrad2_reduce(const float *__restrict__ ws, const int32_t *__r
   const int se = threadIdx.x & 31, sg = threadIdx.x >> 5;
   const int e = blockIdx.x * 32 + se;
   const int n = koff[k + 1] - koff[k];
-  const int nch = (n + WG2_CHUNK - 1) / WG2_CHUNK;
+  const int nch = (n + chunk - 1) / chunk;
   float s = 0.f;
   if (e < cc) {
     int c = sg;
@@ -2006,7 +2049,7 @@ extern "C" size_t rslo_rulebook_pairs_ws_bytes(int64_t n_rows, int K) {
 }
 
 extern "C" size_t rslo_spconv_wgrad_pairs_ws_bytes(int64_t n_out, int K, int cin, int cout) {
-  const int64_t nch = rslo_cdiv(n_out > 0 ? n_out : 1, WG2_CHUNK);
+  const int64_t nch = rslo_cdiv(n_out > 0 ? n_out : 1, WG_MIN_CHUNK);
   return ((size_t)nch * (size_t)K * cin * cout + (size_t)(CS1_MAXBLK + 8) * cout) * sizeof(float);
 }
 
@@ -2027,16 +2070,18 @@ extern "C" int rslo_spconv_wgrad_pairs(const float *in, int cin, const float *do
     rslo_set_error("wgrad_pairs: workspace too small");
     return RSLO_EWS;
   }
-  const int nch = (int)rslo_cdiv(n_out, WG2_CHUNK);   // P_k <= n_out: upper bound on chunks per offset
   const int ci = cin <= 16 ? 16 : (cin <= 32 ? 32 : 64), co = pad_cout(cout);
   const bool exact = (ci == cin && co == cout);
-  dim3 grid((unsigned)nch, (unsigned)K);
   static const bool split_on = !(getenv("RSLO_SPCONV_SPLIT") && getenv("RSLO_SPCONV_SPLIT")[0] == '0');
-  if (split_on && exact && (cin == 32 || cin == 64) && (cout == 32 || cout == 64)) {
+  const bool use3 = split_on && exact && (cin == 32 || cin == 64) && (cout == 32 || cout == 64);
+  const int chunk = use3 ? WG3_CHUNK : WG2_CHUNK;
+  const int nch = (int)rslo_cdiv(n_out, chunk);   // P_k <= n_out: upper bound on chunks per offset
+  dim3 grid(wg2_grid(nch, K));
+  if (use3) {
 #define WG3_CASE(CI, CO)                                                                                  \
     if (cin == CI && cout == CO)                                                                          \
       hipLaunchKernelGGL((k_wgrad3<CI, CO>), grid, dim3(SPC_THREADS), 0, st, in, dout, pairs_in, pairs_out, koff, K, \
-                         (float *)ws);
+                         wg2_legacy(nch), (float *)ws);
     WG3_CASE(32, 32) WG3_CASE(32, 64) WG3_CASE(64, 32) WG3_CASE(64, 64)
 #undef WG3_CASE
   } else {
@@ -2044,10 +2089,10 @@ extern "C" int rslo_spconv_wgrad_pairs(const float *in, int cin, const float *do
   if (ci == CI && co == CO) {                                                                             \
     if (exact)                                                                                            \
       hipLaunchKernelGGL((k_wgrad2<CI, CO, true>), grid, dim3(SPC_THREADS), 0, st, in, cin, dout, cout,   \
-                         pairs_in, pairs_out, koff, K, (float *)ws);                                      \
+                         pairs_in, pairs_out, koff, K, wg2_legacy(nch), (float *)ws);                                      \
     else                                                                                                  \
       hipLaunchKernelGGL((k_wgrad2<CI, CO, false>), grid, dim3(SPC_THREADS), 0, st, in, cin, dout, cout,  \
-                         pairs_in, pairs_out, koff, K, (float *)ws);                                      \
+                         pairs_in, pairs_out, koff, K, wg2_legacy(nch), (float *)ws);                                      \
   }
   WG2_CASE(16, 16) WG2_CASE(16, 32) WG2_CASE(16, 64)
   WG2_CASE(32, 16) WG2_CASE(32, 32) WG2_CASE(32, 64)
@@ -2071,7 +2116,7 @@ extern "C" int rslo_spconv_wgrad_pairs(const float *in, int cin, const float *do
     }
   }
   hipLaunchKernelGGL(k_wgrad2_reduce, dim3((unsigned)rslo_cdiv(cc, 32), (unsigned)(K + (dbias ? 1 : 0))), dim3(256), 0, st,
-                     (const float *)ws, koff, K, cc, dW, bpart, n_bpart, cout, dbias);
+                     (const float *)ws, koff, K, chunk, cc, dW, bpart, n_bpart, cout, dbias);
   RSLO_CHECK_LAUNCH("wgrad_pairs");
   return RSLO_OK;
 }
@@ -2095,18 +2140,18 @@ extern "C" int rslo_spconv_wgrad_pairs_bf16(const void *in, int cin, const void 
     rslo_set_error("wgrad_pairs_bf16: workspace too small");
     return RSLO_EWS;
   }
-  const int nch = (int)rslo_cdiv(n_out, WG2_CHUNK);
-  dim3 grid((unsigned)nch, (unsigned)K);
+  const int nch = (int)rslo_cdiv(n_out, WG3_CHUNK);
+  dim3 grid(wg2_grid(nch, K));
   const unsigned short *x = (const unsigned short *)in, *g = (const unsigned short *)dout;
 #define WG3B_CASE(CI, CO)                                                                                      \
   if (cin == CI && cout == CO)                                                                                 \
     hipLaunchKernelGGL((k_wgrad3_bf16<CI, CO>), grid, dim3(SPC_THREADS), 0, st, x, g, pairs_in, pairs_out, koff, K, \
-                       (float *)ws);
+                       wg2_legacy(nch), (float *)ws);
   WG3B_CASE(32, 32) WG3B_CASE(32, 64) WG3B_CASE(64, 32) WG3B_CASE(64, 64)
 #undef WG3B_CASE
   const int cc = cin * cout;
   hipLaunchKernelGGL(k_wgrad2_reduce, dim3((unsigned)rslo_cdiv(cc, 32), (unsigned)(K + (dbias ? 1 : 0))), dim3(256), 0, st,
-                     (const float *)ws, koff, K, cc, dW, bias_partial, dbias ? n_bias_partial : 0, cout, dbias);
+                     (const float *)ws, koff, K, WG3_CHUNK, cc, dW, bias_partial, dbias ? n_bias_partial : 0, cout, dbias);
   RSLO_CHECK_LAUNCH("wgrad_pairs_bf16");
   return RSLO_OK;
 }
