@@ -378,7 +378,10 @@ class UnVoxelOdomNetICP3(nn.Module):
         res_r = res_t = None
         if consistency_loss is not None:
             if len(preds_dict["middle_conf_preds"]) == 0:
-                raise NotImplementedError("hier_points supervision without a covariance head (SURVEY.md 8f-4)")
+                # the reference has no working behaviour here: it keeps point_confs = None (voxel_odom_net.py:628) and
+                # indexes it in the consistency_loss call (:702-703) -> TypeError on the first step
+                raise NotImplementedError("hier_points supervision without a covariance head (SURVEY.md 8f-4): the "
+                                          "reference itself fails in this branch (point_confs is None)")
             feats = preds_dict["voxel_features"]
             # xyz + normal columns (intensity dropped); slices, not an index list (no host->device index upload)
             if feats[0].shape[1] > 6:
