@@ -1624,11 +1624,12 @@ __device__ __forceinline__ bool wg2_assign(const int32_t *__restrict__ koff, int
   }
   return false;
 }
-static const bool wg2_xcd = !(getenv("RSLO_WGRAD_XCD") && getenv("RSLO_WGRAD_XCD")[0] == '0');
-static inline unsigned wg2_grid(int nch, int K) {
-  return wg2_xcd ? 8u * (unsigned)((nch * K + 7) / 8 + K) : (unsigned)(nch * K);
+// read per call (not cached) so that a test can compare the two orders inside one process
+static inline bool wg2_xcd() { const char *e = getenv("RSLO_WGRAD_XCD"); return !(e && e[0] == '0'); }
+static inline unsigned wg2_grid(int nch, int K, bool xcd) {
+  return xcd ? 8u * (unsigned)((nch * K + 7) / 8 + K) : (unsigned)(nch * K);
 }
-static inline int wg2_legacy(int nch) { return wg2_xcd ? 0 : nch; }
+static inline int wg2_legacy(int nch, bool xcd) { return xcd ? 0 : nch; }
 
 template <int CIN_T, int COUT_T, bool EXACT>
 __global__ __launch_bounds__(SPC_THREADS) void k_wgrad2(const float *__restrict__ in, int cin,
@@ -2076,12 +2077,13 @@ extern "C" int rslo_spconv_wgrad_pairs(const float *in, int cin, const float *do
   const bool use3 = split_on && exact && (cin == 32 || cin == 64) && (cout == 32 || cout == 64);
   const int chunk = use3 ? WG3_CHUNK : WG2_CHUNK;
   const int nch = (int)rslo_cdiv(n_out, chunk);   // P_k <= n_out: upper bound on chunks per offset
-  dim3 grid(wg2_grid(nch, K));
+  const bool xcd = wg2_xcd();
+  dim3 grid(wg2_grid(nch, K, xcd));
   if (use3) {
 #define WG3_CASE(CI, CO)                                                                                  \
     if (cin == CI && cout == CO)                                                                          \
       hipLaunchKernelGGL((k_wgrad3<CI, CO>), grid, dim3(SPC_THREADS), 0, st, in, dout, pairs_in, pairs_out, koff, K, \
-                         wg2_legacy(nch), (float *)ws);
+                         wg2_legacy(nch, xcd), (float *)ws);
     WG3_CASE(32, 32) WG3_CASE(32, 64) WG3_CASE(64, 32) WG3_CASE(64, 64)
 #undef WG3_CASE
   } else {
@@ -2089,10 +2091,10 @@ extern "C" int rslo_spconv_wgrad_pairs(const float *in, int cin, const float *do
   if (ci == CI && co == CO) {                                                                             \
     if (exact)                                                                                            \
       hipLaunchKernelGGL((k_wgrad2<CI, CO, true>), grid, dim3(SPC_THREADS), 0, st, in, cin, dout, cout,   \
-                         pairs_in, pairs_out, koff, K, wg2_legacy(nch), (float *)ws);                                      \
+                         pairs_in, pairs_out, koff, K, wg2_legacy(nch, xcd), (float *)ws);                                      \
     else                                                                                                  \
       hipLaunchKernelGGL((k_wgrad2<CI, CO, false>), grid, dim3(SPC_THREADS), 0, st, in, cin, dout, cout,  \
-                         pairs_in, pairs_out, koff, K, wg2_legacy(nch), (float *)ws);                                      \
+                         pairs_in, pairs_out, koff, K, wg2_legacy(nch, xcd), (float *)ws);                                      \
   }
   WG2_CASE(16, 16) WG2_CASE(16, 32) WG2_CASE(16, 64)
   WG2_CASE(32, 16) WG2_CASE(32, 32) WG2_CASE(32, 64)
@@ -2141,12 +2143,13 @@ extern "C" int rslo_spconv_wgrad_pairs_bf16(const void *in, int cin, const void 
     return RSLO_EWS;
   }
   const int nch = (int)rslo_cdiv(n_out, WG3_CHUNK);
-  dim3 grid(wg2_grid(nch, K));
+  const bool xcd = wg2_xcd();
+  dim3 grid(wg2_grid(nch, K, xcd));
   const unsigned short *x = (const unsigned short *)in, *g = (const unsigned short *)dout;
 #define WG3B_CASE(CI, CO)                                                                                      \
   if (cin == CI && cout == CO)                                                                                 \
     hipLaunchKernelGGL((k_wgrad3_bf16<CI, CO>), grid, dim3(SPC_THREADS), 0, st, x, g, pairs_in, pairs_out, koff, K, \
-                       wg2_legacy(nch), (float *)ws);
+                       wg2_legacy(nch, xcd), (float *)ws);
   WG3B_CASE(32, 32) WG3B_CASE(32, 64) WG3B_CASE(64, 32) WG3B_CASE(64, 64)
 #undef WG3B_CASE
   const int cc = cin * cout;

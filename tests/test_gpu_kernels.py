@@ -1177,3 +1177,98 @@ def test_conv_bn_act_as_one_autograd_node_gives_the_same_bits(hip, monkeypatch):
         assert torch.equal(p.grad, q.grad), n
     for (n, p), (_, q) in zip(seq.named_buffers(), ref.named_buffers()):
         assert torch.equal(p, q), n
+
+
+class _Env:
+    """Sets / clears one environment variable for the C library's per-call getenv (A/B switches of the workgroup orders)."""
+
+    def __init__(self, name, value):
+        self.name, self.value = name, value
+
+    def __enter__(self):
+        self.old = os.environ.get(self.name)
+        if self.value is None:
+            os.environ.pop(self.name, None)
+        else:
+            os.environ[self.name] = str(self.value)
+
+    def __exit__(self, *a):
+        if self.old is None:
+            os.environ.pop(self.name, None)
+        else:
+            os.environ[self.name] = self.old
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout", [(16, 16), (32, 32), (64, 64), (32, 64), (7, 16)])
+def test_sparse_wgrad_xcd_order_keeps_the_bits(hip, cin, cout):
+    """The XCD-aware deal of (pair chunk, offset) workgroups (wg2_assign, spconv.hip) only changes WHICH workgroup id
+    computes a chunk: dW and dbias are bit-identical to the plain (chunk, offset) grid, fp32 and bf16 rows, also when an
+    offset has fewer chunks than XCDs and when the row count is not a multiple of the chunk."""
+    rng = np.random.default_rng(77)
+    dims, B = [9, 40, 44], 2
+    coords = rand_sites(rng, B, dims, 5300)
+    n = len(coords)
+    x = dev(rng.normal(size=(n, cin)).astype(np.float32))
+    gy = dev(rng.normal(size=(n, cout)).astype(np.float32))
+    pairs = hip.rulebook_pairs(dev(O.rulebook_subm(coords, B, dims)))
+    res = {}
+    for mode in ("0", "1"):
+        with _Env("RSLO_WGRAD_XCD", mode):
+            gw, gb = hip.spconv_wgrad_pairs(x, gy, pairs, n, 27, cin, cout)
+            res[mode] = [gw.clone(), gb.clone()]
+            if cin in (32, 64) and cout in (32, 64):
+                gwb, _ = hip.spconv_wgrad_pairs_bf16(x.bfloat16(), gy.bfloat16(), pairs, n, 27, cin, cout)
+                res[mode].append(gwb.clone())
+    for a, b in zip(res["0"], res["1"]):
+        assert torch.equal(a, b)
+    assert float(res["1"][0].abs().max()) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,cin,cout,H,W", [(4, 128, 128, 24, 44), (4, 256, 256, 12, 22), (2, 64, 32, 20, 37),
+                                             (1, 32, 64, 9, 16), (3, 128, 64, 13, 50)])
+def test_conv2d_fwd_xcd_orders_keep_the_bits(hip, B, cin, cout, H, W):
+    """conv2d_xcd_tile (conv2d.hip) arranges the 8 XCDs as channel classes x pixel ranges; every arrangement (forced
+    through RSLO_CONV2D_FWD_XSC = 1, 2, 4, 8 where it divides the channel groups, 0 = automatic) computes the same
+    tiles as the plain grid (-1): identical bits, forward operand and data-gradient operand, fp32 and bf16 operands,
+    maps whose tile count is not a multiple of the pixel ranges."""
+    torch.manual_seed(5)
+    x = torch.randn(B, cin, H, W, device="cuda")
+    g = torch.randn(B, cout, H, W, device="cuda")
+    w = torch.randn(cout, cin, 3, 3, device="cuda") / (3 * cin ** 0.5)
+    bias = torch.randn(cout, device="cuda")
+    ws, wst = hip.conv2d_wsplit(w, False), hip.conv2d_wsplit(w, True)
+
+    def run():
+        return [hip.conv2d_fwd(x, ws, bias, cout).clone(), hip.conv2d_fwd(g, wst, None, cin).clone(),
+                hip.conv2d_fwd(x, ws, bias, cout, lp=True).clone()]
+    with _Env("RSLO_CONV2D_FWD_XSC", -1):
+        ref = run()
+    for xsc in (None, 0, 1, 2, 4, 8):
+        with _Env("RSLO_CONV2D_FWD_XSC", xsc):
+            for a, b in zip(ref, run()):
+                assert torch.equal(a, b), xsc
+    lib = torch.nn.functional.conv2d(x, w, bias, 1, 1)
+    assert float((ref[0] - lib).abs().max()) <= 2e-4 * float(lib.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,cin,cout,H,W,k", [(4, 128, 128, 48, 88, 3), (2, 64, 128, 21, 37, 3), (4, 128, 256, 24, 44, 1),
+                                               (1, 256, 128, 96, 176, 3)])
+def test_conv2d_stride2_xcd_orders_keep_the_bits(hip, B, cin, cout, H, W, k):
+    """Same statement for the stride-2 kernels (forward and the four-class data gradient), RSLO_CONV2D_S2_XSC."""
+    torch.manual_seed(6)
+    x = torch.randn(B, cin, H, W, device="cuda")
+    g = torch.randn(B, cout, (H - 1) // 2 + 1, (W - 1) // 2 + 1, device="cuda")
+    w = torch.randn(cout, cin, k, k, device="cuda") / (k * cin ** 0.5)
+    ws, wst = hip.conv2d_wsplit_k(w, False), hip.conv2d_wsplit_k(w, True)
+
+    def run():
+        return [hip.conv2d_fwd_s2(x, ws, cout, k).clone(), hip.conv2d_dgrad_s2(g, wst, cin, H, W, k).clone()]
+    with _Env("RSLO_CONV2D_S2_XSC", -1):
+        ref = run()
+    for xsc in (None, 1, 2, 4, 8):
+        with _Env("RSLO_CONV2D_S2_XSC", xsc):
+            for a, b in zip(ref, run()):
+                assert torch.equal(a, b), xsc
