@@ -165,17 +165,9 @@ typedef unsigned long long u64;
 #define CG_KEY_INIT ((u64)0x7f800000u << 32)
 
 // all 64 lanes against the 64 points of one target tile, staged in the wave's LDS slot (broadcast reads)
-__device__ __forceinline__ void cg_eval_points(const float4 mine, float4 *slot, int lane, float qx, float qy, float qz,
-                                               u64 &best);
 __device__ __forceinline__ void cg_eval_tile(const float4 *__restrict__ tile, float4 *slot, int lane, float qx, float qy,
                                              float qz, u64 &best) {
-  cg_eval_points(tile[lane], slot, lane, qx, qy, qz, best);
-}
-// the same with the tile's points already in registers (lane l holds point l): the search loop requests the next tile of
-// a group before it evaluates the current one
-__device__ __forceinline__ void cg_eval_points(const float4 mine, float4 *slot, int lane, float qx, float qy, float qz,
-                                               u64 &best) {
-  slot[lane] = mine;
+  slot[lane] = tile[lane];
   __builtin_amdgcn_wave_barrier();
 #pragma unroll 16
   for (int j = 0; j < CG_TILE; ++j) {
@@ -196,9 +188,6 @@ __device__ __forceinline__ float cg_box_lb(const float *bx, float qx, float qy, 
 }
 
 #define CG_GROUP 8      /* target tiles per group box */
-#ifndef CG_PREFETCH
-#define CG_PREFETCH 1
-#endif
 // grid: (query tiles / 4, segments S, pairs B).  Segment s scans target tiles [s * seg_tiles, (s+1) * seg_tiles) after
 // seeding from the lanes' own key-rank tiles (anywhere in the cloud); partial keys go to pkey[b][s][sorted query].
 __global__ __launch_bounds__(256) void k_cg_search(const float4 *__restrict__ sq, const float4 *__restrict__ st,
@@ -254,25 +243,11 @@ __global__ __launch_bounds__(256) void k_cg_search(const float4 *__restrict__ sq
       float bd = __int_as_float((int)(best >> 32));
       if (__ballot(on && !(cg_box_lb(gb + g * 6, q.x, q.y, q.z) > bd)) == 0ull) continue;
       const int t1 = (g + 1) * CG_GROUP < nt ? (g + 1) * CG_GROUP : nt;
-#if CG_PREFETCH
-      // the points of tile t + 1 are requested (unconditionally: 1 KB from L2, no branch around the load) before tile t
-      // is tested and evaluated, so a surviving tile's load latency hides behind the previous tile's 64-point loop
-      float4 nxt = tb[(t0 + g * CG_GROUP) * CG_TILE + lane];
-      for (int t = g * CG_GROUP; t < t1; ++t) {
-        const float4 cur = nxt;
-        const int tn = t + 1 < t1 ? t + 1 : t;
-        nxt = tb[(t0 + tn) * CG_TILE + lane];
-        bd = __int_as_float((int)(best >> 32));
-        if (__ballot(on && !(cg_box_lb(sb + t * 6, q.x, q.y, q.z) > bd)) == 0ull) continue;
-        cg_eval_points(cur, slots[wid], lane, q.x, q.y, q.z, best);
-      }
-#else
       for (int t = g * CG_GROUP; t < t1; ++t) {
         bd = __int_as_float((int)(best >> 32));
         if (__ballot(on && !(cg_box_lb(sb + t * 6, q.x, q.y, q.z) > bd)) == 0ull) continue;
         cg_eval_tile(tb + (t0 + t) * CG_TILE, slots[wid], lane, q.x, q.y, q.z, best);
       }
-#endif
     }
   }
   if (wave_on) pkey[((int64_t)b * S + seg) * Npad + qt * CG_TILE + lane] = best;
