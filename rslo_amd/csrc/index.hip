@@ -628,10 +628,61 @@ __global__ void k_vfe_mean(const float *__restrict__ voxels, const int32_t *__re
   for (int f = 0; f < F; ++f) out[v * F + f] = m[f];
 }
 
+// The same arithmetic with coalesced reads: a wave copies the T*F floats of its 64 voxels (one contiguous run of the
+// voxel tensor) into its LDS slab with 16-byte loads and every lane then sums its own voxel from there in the same t
+// order (identical bits).  One thread per voxel straight from memory walks 64 cache lines per load instruction:
+// 50 us for 125 k voxels of 10 x 7 floats (0.7 TB/s).
+__global__ __launch_bounds__(256) void k_vfe_mean_lds(const float *__restrict__ voxels, const int32_t *__restrict__ num,
+                                                      int64_t M, int T, int F, float *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float vfe_sm[];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int TF = T * F;
+  float *my = vfe_sm + (size_t)wid * 64 * TF;
+  const int64_t v0 = ((int64_t)blockIdx.x * 4 + wid) * 64;
+  if (v0 >= M) return;
+  const int nv = (int)((M - v0 < 64) ? (M - v0) : 64);
+  const int nfl = nv * TF, n4 = nfl >> 2;
+  const float *src = voxels + v0 * TF;            // 64 * TF floats per wave: 16-byte aligned whenever `voxels` is
+  for (int i = lane; i < n4; i += 64) reinterpret_cast<float4 *>(my)[i] = reinterpret_cast<const float4 *>(src)[i];
+  for (int i = (n4 << 2) + lane; i < nfl; i += 64) my[i] = src[i];
+  __builtin_amdgcn_wave_barrier();                // LDS operations of one wave complete in order
+  if (lane >= nv) return;
+  const int64_t v = v0 + lane;
+  const float inv_n = (float)num[v];
+  const float *p = my + lane * TF;
+  float m[16];
+  for (int f = 0; f < F; ++f) {
+    float s = 0.f;
+    for (int t = 0; t < T; ++t) s = __fadd_rn(s, p[t * F + f]);
+    m[f] = __fdiv_rn(s, inv_n);
+  }
+  if (F >= 7) {
+    const float n2 = __fadd_rn(__fadd_rn(__fmul_rn(m[4], m[4]), __fmul_rn(m[5], m[5])), __fmul_rn(m[6], m[6]));
+    const float d = __fadd_rn(__fsqrt_rn(n2), 1e-12f);
+    m[4] = __fdiv_rn(m[4], d);
+    m[5] = __fdiv_rn(m[5], d);
+    m[6] = __fdiv_rn(m[6], d);
+  }
+  for (int f = 0; f < F; ++f) out[v * F + f] = m[f];
+}
+
 extern "C" int rslo_vfe_mean(const float *voxels, const int32_t *num_points, int64_t M, int T, int F,
                              float *out, void *stream) {
   RSLO_CHECK_ARG(F <= 16, "vfe_mean: F > 16 unsupported");
   if (M == 0) return RSLO_OK;
+  const size_t lds = (size_t)4 * 64 * T * F * sizeof(float);
+  static const bool lds_on = !(getenv("RSLO_VFE_LDS") && getenv("RSLO_VFE_LDS")[0] == '0');
+  if (lds_on && lds <= 80 * 1024 && ((uintptr_t)voxels & 15) == 0) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      RSLO_HIP(hipFuncSetAttribute((const void *)k_vfe_mean_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(k_vfe_mean_lds, dim3((unsigned)rslo_cdiv(M, 256)), dim3(256), lds, (hipStream_t)stream, voxels,
+                       num_points, M, T, F, out);
+    RSLO_CHECK_LAUNCH("vfe_mean");
+    return RSLO_OK;
+  }
   hipLaunchKernelGGL(k_vfe_mean, dim3((unsigned)rslo_cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, voxels,
                      num_points, M, T, F, out);
   RSLO_CHECK_LAUNCH("vfe_mean");

@@ -1272,3 +1272,17 @@ def test_conv2d_stride2_xcd_orders_keep_the_bits(hip, B, cin, cout, H, W, k):
         with _Env("RSLO_CONV2D_S2_XSC", xsc):
             for a, b in zip(ref, run()):
                 assert torch.equal(a, b), xsc
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M", [1, 63, 64, 65, 300, 4097])
+def test_vfe_mean_wave_tail_sizes_match_oracle(hip, M):
+    """k_vfe_mean_lds stages the rows of 64 voxels per wave through LDS: voxel counts around the wave / block boundaries
+    (last wave partly filled, last block with idle waves) against the oracle's sequential sums."""
+    rng = np.random.default_rng(M)
+    T, F = 10, 7
+    num = rng.integers(1, T + 1, size=M).astype(np.int32)
+    vox = (rng.normal(size=(M, T, F)) * 10).astype(np.float32)
+    vox *= (np.arange(T)[None, :, None] < num[:, None, None])
+    got = hip.vfe_mean(dev(vox), dev(num)).cpu().numpy()
+    np.testing.assert_allclose(got, O.vfe_mean(vox, num), rtol=2e-6, atol=2e-6)
