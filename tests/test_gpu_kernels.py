@@ -846,6 +846,15 @@ def test_roi_threshold_radix_select_is_exact(hip):
         assert torch.equal(got, want), (ratio, got, want)
     want = losses.roi_threshold(d[:1], 0.97).reshape(-1)
     assert torch.equal(hip.roi_threshold(d[:1].cuda().contiguous(), None, 0.97).cpu(), want)
+    # the kernel keeps 40 values per thread (40960 per pair) in registers and reads any further ones from memory in every
+    # pass: counts at the step's size, exactly at the register capacity, one past it and well past it
+    d = torch.rand(4, 45000, generator=g) ** 2 * 9
+    cnt = torch.tensor([31000, 40960, 40961, 45000], dtype=torch.int32)
+    for b in range(4):
+        d[b, cnt[b]:] = float("inf")
+    for ratio in (0.97, 0.3):
+        want = losses.roi_threshold_ragged(d, cnt, ratio).reshape(-1)
+        assert torch.equal(hip.roi_threshold(d.cuda(), cnt.cuda(), ratio).cpu(), want), ratio
 
 
 def test_pose_algebra_kernels_match_kornia_restatement(hip):
