@@ -21,5 +21,7 @@ for k, v in sorted(per.items()):
     row["waves"] = round(a.get("SQ_WAVES", 0))
     out["kernels"][k] = row
     print("%-30s" % k, row)
+import hashlib, os
+out["lib_sha256"] = hashlib.sha256(open(os.path.join(os.environ["GRAFT_REPO_ROOT"], "rslo_amd/librslo_hip.so"), "rb").read()).hexdigest()[:16]
 json.dump(out, open(sys.argv[2], "w"), indent=1)
 PY
