@@ -528,6 +528,14 @@ def main():
         mark("opt", w0, c0)
         return ret
 
+    # The training stream runs at HIGH priority, the structure work of the coming batches (side stream) at normal
+    # priority: its ~250 small integer kernels then take the CU slots the training kernels leave free instead of an
+    # equal share of the machine (streams of one priority alternate).  RSLO_TRAIN_PRIORITY=0: both normal (A/B runs).
+    if os.environ.get("RSLO_TRAIN_PRIORITY", "1") != "0":
+        train_stream = torch.cuda.Stream(dev, priority=min(torch.cuda.Stream.priority_range()))
+        train_stream.wait_stream(torch.cuda.current_stream(dev))
+        torch.cuda.set_stream(train_stream)
+
     probe = ConvProbe(capi)
     use_probe = (not args.no_kernel_events) and rank == 0
     if use_probe:
@@ -545,6 +553,8 @@ def main():
     # per-launch HIP events on the last PROBE_STEPS timed steps only (the events themselves cost host time)
     probe_steps = min(3, args.steps)
     wait[0] = 0.0
+    if prefetch is not None:
+        prefetch.lead_wait_seconds = prefetch.plan_wait_seconds = 0.0
     for v in ph.values():
         v[0] = v[1] = 0.0
     alloc0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)      # hipMalloc calls so far (caching allocator misses)
@@ -614,8 +624,16 @@ def main():
                        "voxelize_in_step": not args.no_voxelize, "voxelize_prefetch_stream": prefetch is not None,
                        "distinct_batches": n_sets, "pinned_cpus": pinned,
                        "optimizer_in_step": not args.no_optim,
-                       "host_issue_ms_per_step": round(1e3 * cpu_issue / args.steps, 3),
-                       "prefetch_wait_ms_per_step": round(1e3 * wait[0] / args.steps, 3),
+                       # CPU time of the issuing thread minus the time it was HELD BACK behind the GPU (a spinning wait)
+                       "host_issue_ms_per_step": round(1e3 * (cpu_issue - (prefetch.lead_wait_seconds if prefetch else 0.0))
+                                                       / args.steps, 3),
+                       # get(): waiting for the helper's result / the plan's event + assembling the example from the arena
+                       "prefetch_wait_ms_per_step": round(1e3 * (wait[0] - (prefetch.lead_wait_seconds if prefetch else 0.0))
+                                                          / args.steps, 3),
+                       # get(): the issuing thread sleeping until the GPU is within RSLO_HOST_LEAD forward passes (slack of a
+                       # GPU-bound step; an unbounded lead fills the launch queue and costs ~0.4 ms per step)
+                       "host_held_back_ms_per_step": (round(1e3 * prefetch.lead_wait_seconds / args.steps, 3)
+                                                      if prefetch else None),
                        "prefetch_thread_cpu_ms_per_step": (round(1e3 * prefetch.cpu_seconds / max(prefetch.jobs, 1), 3)
                                                            if prefetch is not None and hasattr(prefetch, "jobs") else None),
                        "final_loss": round(loss_val, 4)},

@@ -191,6 +191,69 @@ RSLO_API int rslo_rulebook_row_order(const int32_t *nbr, int64_t n_rows, int K, 
 RSLO_API size_t rslo_rulebook_pairs_ws_bytes(int64_t n_rows, int K);
 RSLO_API int rslo_rulebook_pairs(const int32_t *nbr, int64_t n_rows, int K, void *ws, size_t ws_bytes,
                         int32_t *pairs_in, int32_t *pairs_out, int32_t *koff /*[K+1]*/, void *stream);
+/* ------------------------------------------------------------------------------------
+ * a1 + a2 + a5 in ONE call: voxelization of all clouds of a step (frames x samples) and the complete rulebook chain
+ * of a chain-structured sparse encoder -- site hashes, SubM tables, strided-conv output sets + both tables, tile row
+ * orders, weight-gradient pair lists -- without a host read.  Replaces, for a whole training step, the DataLoader-side
+ * VoxelGenerator.generate calls + merge_second_batch coordinate padding (rslo/data/preprocess.py:493,75-89) and the
+ * implicit indice-pair builds of SpMiddleFHDWithCov2_3 (rslo/models/middle.py:119-213, keys subm0 .. dsubm1).
+ *
+ * Levels: level 0 = the voxel grid (dims0 = sparse_shape, z y x); level l+1 = output of the strided conv l
+ * (conv_ks/stride/pad[l]); subm_ks[l] != 0 asks for the SubM table of level l.  Batch index of cloud c in the batched
+ * encoder tensor = c (clouds are given frame-major: c = t * clouds_per_frame + b); its index inside its frame = b.
+ * Everything lives in ONE caller-owned arena (rslo_plan_encoder_layout gives the offsets; capacities instead of exact
+ * sizes: level 0 = min(n_clouds * max_voxels, sum P), level l+1 = capacity of level l unless cap_rows[] says otherwise).
+ * Actual sizes are device words in the counts block, copied asynchronously to h_counts (pinned host memory, may be
+ * NULL) at the end; the caller reads them after synchronising with an event recorded behind the call:
+ *   counts[RSLO_PLAN_CNT_OVERFLOW]      bit l set: level l had more sites than its capacity (rows past it dropped:
+ *                                       the plan is unusable, re-plan with larger cap_rows)
+ *   counts[RSLO_PLAN_CNT_ROWS + l]      active sites of level l
+ *   counts[RSLO_PLAN_CNT_NVOX + c]      voxels of cloud c
+ *   counts[RSLO_PLAN_CNT_BOFF + l*(RSLO_PLAN_MAX_CLOUDS+1) + j]   first row of batch element j on level l (j = 0..n)
+ * Results equal the stand-alone entry points above bit for bit (same kernels, row counts read from the device).
+ * ------------------------------------------------------------------------------------ */
+#define RSLO_PLAN_MAX_LEVELS 8
+#define RSLO_PLAN_MAX_CLOUDS 64
+#define RSLO_PLAN_CNT_OVERFLOW 0
+#define RSLO_PLAN_CNT_ROWS 1
+#define RSLO_PLAN_CNT_RAW 9
+#define RSLO_PLAN_CNT_NVOX 32
+#define RSLO_PLAN_CNT_BASE 96
+#define RSLO_PLAN_CNT_BOFF 176
+#define RSLO_PLAN_CNT_WORDS (176 + RSLO_PLAN_MAX_LEVELS * (RSLO_PLAN_MAX_CLOUDS + 1))
+typedef struct {
+  int32_t n_levels;
+  int32_t dims0[3];                              /* sparse_shape (z, y, x) of level 0 */
+  int32_t subm_ks[RSLO_PLAN_MAX_LEVELS][3];      /* 0,0,0: no SubM table on this level */
+  int32_t conv_ks[RSLO_PLAN_MAX_LEVELS][3], conv_stride[RSLO_PLAN_MAX_LEVELS][3], conv_pad[RSLO_PLAN_MAX_LEVELS][3];
+  int32_t want_pairs, want_orders;
+  float range6[6], vsize3[3];                    /* voxelizer geometry (rslo_voxelize) */
+  int32_t grid_xyz[3], max_points, max_voxels, n_features;
+  int64_t cap_rows[RSLO_PLAN_MAX_LEVELS];        /* 0 = default capacity */
+} RsloEncoderSpec;
+typedef struct {
+  uint64_t total_bytes;
+  int32_t dims[RSLO_PLAN_MAX_LEVELS][3];
+  int64_t cap_rows[RSLO_PLAN_MAX_LEVELS], hash_cap[RSLO_PLAN_MAX_LEVELS];
+  uint64_t counts_off;                           /* int32 [RSLO_PLAN_CNT_WORDS] */
+  uint64_t voxels_off, num_points_off;           /* fp32 [cap0, T, F], int32 [cap0]: all clouds, frame-major */
+  uint64_t coords_frame_off;                     /* int32 [cap0, 4]: (index inside the frame, z, y, x) */
+  uint64_t coords_off[RSLO_PLAN_MAX_LEVELS];     /* int32 [cap_l, 4]: (batch, z, y, x); level 0 = all clouds */
+  uint64_t keys_off[RSLO_PLAN_MAX_LEVELS], vals_off[RSLO_PLAN_MAX_LEVELS];
+  uint64_t subm_nbr_off[RSLO_PLAN_MAX_LEVELS], subm_pin_off[RSLO_PLAN_MAX_LEVELS], subm_pout_off[RSLO_PLAN_MAX_LEVELS],
+      subm_koff_off[RSLO_PLAN_MAX_LEVELS];
+  uint64_t conv_nbr_off[RSLO_PLAN_MAX_LEVELS], conv_nbrT_off[RSLO_PLAN_MAX_LEVELS], conv_order_off[RSLO_PLAN_MAX_LEVELS],
+      conv_pin_off[RSLO_PLAN_MAX_LEVELS], conv_pout_off[RSLO_PLAN_MAX_LEVELS], conv_koff_off[RSLO_PLAN_MAX_LEVELS];
+  int64_t scratch_words;
+  uint64_t vox_ws_off, bitmap_off, prefix_off, scan_ws_off, pair_ws_off;
+} RsloPlanLayout;
+RSLO_API int rslo_plan_encoder_layout(const RsloEncoderSpec *h_spec, int n_clouds, const int64_t *h_n_points,
+                                      RsloPlanLayout *h_layout);
+RSLO_API int rslo_plan_encoder(const RsloEncoderSpec *h_spec, const RsloPlanLayout *h_layout, int n_clouds,
+                               int clouds_per_frame, const float *const *h_points /*n_clouds device pointers [P,F]*/,
+                               const int64_t *h_n_points, void *arena, size_t arena_bytes,
+                               int32_t *h_counts /*pinned, [RSLO_PLAN_CNT_WORDS] or NULL*/, void *stream);
+
 /* wgrad over pair lists: dW[k] = sum_{p in [koff[k],koff[k+1])} in[pairs_in[p]]^T dout[pairs_out[p]];
  * dbias = column sums of dout (all n_out rows).  Deterministic (fixed-order two-stage reduction). */
 RSLO_API size_t rslo_spconv_wgrad_pairs_ws_bytes(int64_t n_out, int K, int cin, int cout);
@@ -481,7 +544,8 @@ RSLO_API int rslo_pose_targets(const float *res_r, const float *res_t, const flo
 typedef struct {
   float *param, *grad, *exp_avg, *exp_avg_sq, *step;   /* step may be NULL */
   int32_t group;                                       /* index into RsloOptHyper.group */
-  int32_t reserved;
+  int32_t step_offset;  /* this tensor's own step count = `step` + step_offset (torch.optim.Adam counts per tensor: one
+                           that got its first gradient late, or skipped steps, lags the others) */
 } RsloOptTensor;
 typedef struct {
   int32_t tensor, count;

@@ -57,5 +57,23 @@ def build(force=False, verbose=True):
     return LIB
 
 
+HOST_SRC = os.path.join(CSRC, "host", "voxelize_host.c")
+HOST_LIB = os.path.join(HERE, "librslo_host.so")
+HOST_FLAGS = ["-O2", "-fPIC", "-shared", "-ffp-contract=off", "-fvisibility=hidden", "-Wall", "-Wextra"]
+
+
+def build_host(force=False, verbose=True):
+    """librslo_host.so (include/rslo_host.h): the host-memory face of VoxelGenerator for forked DataLoader workers.
+    Plain C through gcc, no HIP."""
+    if not force and os.path.exists(HOST_LIB) and os.path.getmtime(HOST_LIB) >= os.path.getmtime(HOST_SRC):
+        return HOST_LIB
+    cmd = [os.environ.get("CC", "gcc")] + HOST_FLAGS + ["-o", HOST_LIB, HOST_SRC, "-lm"]
+    if verbose:
+        print("[rslo_amd.build]", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return HOST_LIB
+
+
 if __name__ == "__main__":
     print(build(force=True))
+    print(build_host(force=True))

@@ -123,6 +123,8 @@ SIGNATURES = {
     "rslo_pyramid_l2_ws_bytes": (_sz, [_vp, _i, _i]),
     "rslo_pyramid_l2_fwd": (C.c_int, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp]),
     "rslo_pyramid_l2_bwd": (C.c_int, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "rslo_plan_encoder_layout": (C.c_int, [_vp, _i, _vp, _vp]),
+    "rslo_plan_encoder": (C.c_int, [_vp, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp, _vp]),
     "rslo_opt_clip_grad_norm": (C.c_int, [_vp, _vp, _i, _f, _vp, _vp, _vp]),
     "rslo_opt_adam_step": (C.c_int, [_vp, _vp, _i, _vp, _f, _vp]),
 }
@@ -237,6 +239,61 @@ class SiteIndex:
         self.vals = torch.empty((self.cap,), dtype=torch.int32, device=coords.device)
         _chk(lib().rslo_hash_build(_ptr(coords, torch.int32, "coords"), N, self.batch, _i3(self.dims),
                                    _ptr(self.keys), _ptr(self.vals), self.cap, _stream()), "rslo_hash_build")
+
+
+    @classmethod
+    def from_parts(cls, coords, batch, dims, keys, vals, cap):
+        """A site index whose hash already exists (built inside rslo_plan_encoder)."""
+        self = cls.__new__(cls)
+        self.coords, self.batch, self.dims = coords, int(batch), [int(d) for d in dims]
+        self.keys, self.vals, self.cap = keys, vals, int(cap)
+        return self
+
+
+# -- rslo_plan_encoder: the structures of include/rslo_hip.h -------------------------------------------------------
+PLAN_MAX_LEVELS, PLAN_MAX_CLOUDS = 8, 64
+PLAN_CNT_OVERFLOW, PLAN_CNT_ROWS, PLAN_CNT_NVOX, PLAN_CNT_BOFF = 0, 1, 32, 176
+PLAN_CNT_WORDS = 176 + PLAN_MAX_LEVELS * (PLAN_MAX_CLOUDS + 1)
+_L3 = (C.c_int32 * 3) * PLAN_MAX_LEVELS
+_LU64 = C.c_uint64 * PLAN_MAX_LEVELS
+_LI64 = C.c_int64 * PLAN_MAX_LEVELS
+
+
+class EncoderSpec(C.Structure):
+    _fields_ = [("n_levels", C.c_int32), ("dims0", C.c_int32 * 3), ("subm_ks", _L3), ("conv_ks", _L3),
+                ("conv_stride", _L3), ("conv_pad", _L3), ("want_pairs", C.c_int32), ("want_orders", C.c_int32),
+                ("range6", C.c_float * 6), ("vsize3", C.c_float * 3), ("grid_xyz", C.c_int32 * 3),
+                ("max_points", C.c_int32), ("max_voxels", C.c_int32), ("n_features", C.c_int32), ("cap_rows", _LI64)]
+
+
+class PlanLayout(C.Structure):
+    _fields_ = [("total_bytes", C.c_uint64), ("dims", _L3), ("cap_rows", _LI64), ("hash_cap", _LI64),
+                ("counts_off", C.c_uint64), ("voxels_off", C.c_uint64), ("num_points_off", C.c_uint64),
+                ("coords_frame_off", C.c_uint64), ("coords_off", _LU64), ("keys_off", _LU64), ("vals_off", _LU64),
+                ("subm_nbr_off", _LU64), ("subm_pin_off", _LU64), ("subm_pout_off", _LU64), ("subm_koff_off", _LU64),
+                ("conv_nbr_off", _LU64), ("conv_nbrT_off", _LU64), ("conv_order_off", _LU64), ("conv_pin_off", _LU64),
+                ("conv_pout_off", _LU64), ("conv_koff_off", _LU64), ("scratch_words", C.c_int64),
+                ("vox_ws_off", C.c_uint64), ("bitmap_off", C.c_uint64), ("prefix_off", C.c_uint64),
+                ("scan_ws_off", C.c_uint64), ("pair_ws_off", C.c_uint64)]
+
+
+def plan_encoder_layout(spec, n_points):
+    """spec: EncoderSpec, n_points: per-cloud point counts -> PlanLayout (offsets into one arena, capacities)."""
+    lay = PlanLayout()
+    arr = (C.c_int64 * len(n_points))(*[int(n) for n in n_points])
+    _chk(lib().rslo_plan_encoder_layout(C.byref(spec), len(n_points), arr, C.byref(lay)), "rslo_plan_encoder_layout")
+    return lay
+
+
+def plan_encoder(spec, lay, clouds, clouds_per_frame, arena, h_counts):
+    """Enqueue voxelization + the whole rulebook chain for `clouds` (CUDA fp32 [P,F] tensors, frame-major) on the current
+    stream: ONE foreign call, no host read.  arena: uint8 CUDA tensor of >= lay.total_bytes; h_counts: pinned int32
+    tensor [PLAN_CNT_WORDS] that receives the counts block (valid once an event recorded after this call has passed)."""
+    n = len(clouds)
+    ptrs = (C.c_void_p * n)(*[_ptr(c, torch.float32, "cloud").value if c.shape[0] else None for c in clouds])
+    cnts = (C.c_int64 * n)(*[int(c.shape[0]) for c in clouds])
+    _chk(lib().rslo_plan_encoder(C.byref(spec), C.byref(lay), n, int(clouds_per_frame), ptrs, cnts, _ptr(arena),
+                                 arena.numel(), C.c_void_p(h_counts.data_ptr()), _stream()), "rslo_plan_encoder")
 
 
 def rulebook_subm(index, ks):

@@ -2,6 +2,7 @@
 // All kernels are HBM/L2-bound integer work: one thread per (site, kernel-offset) with the
 // offset fastest so table writes are coalesced; the hash tables (<= a few MB) live in L2.
 #include <stdarg.h>
+#include <string.h>
 
 #include "rslo_common.h"
 
@@ -123,21 +124,36 @@ extern "C" int64_t rslo_hash_capacity(int64_t n) {
   return c;
 }
 
-__global__ void k_hash_insert(const int32_t *__restrict__ coords, int64_t N, Dims3 s,
+// Row counts of the structure kernels come either from the host (N) or, inside rslo_plan_encoder, from a device word
+// (d_n != NULL: the count an earlier kernel of the same stream produced -- no host read in between).  Every kernel
+// walks its work items in a grid-stride loop, so a launch sized for the CAPACITY of a level does the work of its
+// actual size.
+__device__ __forceinline__ int64_t rslo_rows(int64_t N, const int32_t *__restrict__ d_n) {
+  return d_n ? (int64_t)*d_n : N;
+}
+#define RSLO_GRID_STRIDE(i, total) \
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (total); i += (int64_t)gridDim.x * blockDim.x)
+static inline unsigned rb_grid(int64_t items) {
+  const int64_t b = rslo_cdiv(items > 0 ? items : 1, 256);
+  return (unsigned)(b < 65536 ? b : 65536);
+}
+
+__global__ void k_hash_insert(const int32_t *__restrict__ coords, int64_t N, const int32_t *__restrict__ d_n, Dims3 s,
                               uint32_t *__restrict__ keys, int32_t *__restrict__ vals, uint32_t mask,
                               int shift) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N) return;
-  const int4 c = reinterpret_cast<const int4 *>(coords)[i];
-  const uint32_t key = rslo_lin(c.x, c.y, c.z, c.w, s);
-  uint32_t p = rslo_hslot(key, shift);
-  while (true) {
-    uint32_t prev = atomicCAS(&keys[p], RSLO_EMPTY_KEY, key);
-    if (prev == RSLO_EMPTY_KEY || prev == key) {
-      vals[p] = (int32_t)i;
-      return;
+  const int64_t n = rslo_rows(N, d_n);
+  RSLO_GRID_STRIDE(i, n) {
+    const int4 c = reinterpret_cast<const int4 *>(coords)[i];
+    const uint32_t key = rslo_lin(c.x, c.y, c.z, c.w, s);
+    uint32_t p = rslo_hslot(key, shift);
+    while (true) {
+      uint32_t prev = atomicCAS(&keys[p], RSLO_EMPTY_KEY, key);
+      if (prev == RSLO_EMPTY_KEY || prev == key) {
+        vals[p] = (int32_t)i;
+        break;
+      }
+      p = (p + 1) & mask;
     }
-    p = (p + 1) & mask;
   }
 }
 
@@ -158,7 +174,7 @@ extern "C" int rslo_hash_build(const int32_t *coords, int64_t N, int B, const in
   RSLO_HIP(hipMemsetAsync(keys, 0xFF, (size_t)cap * sizeof(uint32_t), st));
   if (N == 0) return RSLO_OK;
   const int shift = 32 - rslo_log2_i64(cap);
-  hipLaunchKernelGGL(k_hash_insert, dim3((unsigned)rslo_cdiv(N, 256)), dim3(256), 0, st, coords, N,
+  hipLaunchKernelGGL(k_hash_insert, dim3(rb_grid(N)), dim3(256), 0, st, coords, N, (const int32_t *)nullptr,
                      Dims3{d[0], d[1], d[2]}, keys, vals, (uint32_t)(cap - 1), shift);
   RSLO_CHECK_LAUNCH("hash_insert");
   return RSLO_OK;
@@ -204,21 +220,23 @@ static inline bool rb_fast_s(const int32_t *st) { return st[0] == 2 && st[1] == 
 // SubM rulebook: one thread per (row, offset)
 // ---------------------------------------------------------------------------------------
 template <bool FAST>
-__global__ void k_rulebook_subm(const int32_t *__restrict__ coords, int64_t N, Dims3 s, Int3 ks,
-                                const uint32_t *__restrict__ keys, const int32_t *__restrict__ vals,
-                                uint32_t mask, int shift, int32_t *__restrict__ nbr) {
+__global__ void k_rulebook_subm(const int32_t *__restrict__ coords, int64_t N, const int32_t *__restrict__ d_n,
+                                Dims3 s, Int3 ks, const uint32_t *__restrict__ keys,
+                                const int32_t *__restrict__ vals, uint32_t mask, int shift,
+                                int32_t *__restrict__ nbr) {
   const int K = ks.a * ks.b * ks.c;
-  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= N * K) return;
-  int64_t o;
-  int kz, ky, kx;
-  rb_decompose<FAST>(t, ks, o, kz, ky, kx);
-  const int4 c = reinterpret_cast<const int4 *>(coords)[o];
-  const int z = c.y + kz - ks.a / 2, y = c.z + ky - ks.b / 2, x = c.w + kx - ks.c / 2;
-  int32_t r = -1;
-  if (z >= 0 && z < s.d && y >= 0 && y < s.h && x >= 0 && x < s.w)
-    r = rslo_hfind(keys, vals, mask, shift, rslo_lin(c.x, z, y, x, s));
-  nbr[t] = r;
+  const int64_t total = rslo_rows(N, d_n) * K;
+  RSLO_GRID_STRIDE(t, total) {
+    int64_t o;
+    int kz, ky, kx;
+    rb_decompose<FAST>(t, ks, o, kz, ky, kx);
+    const int4 c = reinterpret_cast<const int4 *>(coords)[o];
+    const int z = c.y + kz - ks.a / 2, y = c.z + ky - ks.b / 2, x = c.w + kx - ks.c / 2;
+    int32_t r = -1;
+    if (z >= 0 && z < s.d && y >= 0 && y < s.h && x >= 0 && x < s.w)
+      r = rslo_hfind(keys, vals, mask, shift, rslo_lin(c.x, z, y, x, s));
+    nbr[t] = r;
+  }
 }
 
 extern "C" int rslo_rulebook_subm(const int32_t *coords, int64_t N, int B, const int32_t *d,
@@ -230,10 +248,10 @@ extern "C" int rslo_rulebook_subm(const int32_t *coords, int64_t N, int B, const
   const int K = ks[0] * ks[1] * ks[2];
   const int shift = 32 - rslo_log2_i64(cap);
   if (rb_fast_k(ks, N))
-    hipLaunchKernelGGL(k_rulebook_subm<true>, dim3((unsigned)rslo_cdiv(N * K, 256)), dim3(256), 0, st, coords, N,
+    hipLaunchKernelGGL(k_rulebook_subm<true>, dim3(rb_grid(N * K)), dim3(256), 0, st, coords, N, (const int32_t *)nullptr,
                        Dims3{d[0], d[1], d[2]}, Int3{ks[0], ks[1], ks[2]}, keys, vals, (uint32_t)(cap - 1), shift, nbr);
   else
-    hipLaunchKernelGGL(k_rulebook_subm<false>, dim3((unsigned)rslo_cdiv(N * K, 256)), dim3(256), 0, st, coords, N,
+    hipLaunchKernelGGL(k_rulebook_subm<false>, dim3(rb_grid(N * K)), dim3(256), 0, st, coords, N, (const int32_t *)nullptr,
                        Dims3{d[0], d[1], d[2]}, Int3{ks[0], ks[1], ks[2]}, keys, vals, (uint32_t)(cap - 1), shift, nbr);
   RSLO_CHECK_LAUNCH("rulebook_subm");
   return RSLO_OK;
@@ -249,22 +267,24 @@ extern "C" int64_t rslo_conv_bitmap_words(int B, const int32_t *od) {
 }
 
 template <bool FAST, bool FAST2>
-__global__ void k_conv_mark(const int32_t *__restrict__ coords, int64_t N, Int3 ks, Int3 st, Int3 pd,
-                            Dims3 od, uint32_t *__restrict__ bitmap) {
+__global__ void k_conv_mark(const int32_t *__restrict__ coords, int64_t N, const int32_t *__restrict__ d_n, Int3 ks,
+                            Int3 st, Int3 pd, Dims3 od, uint32_t *__restrict__ bitmap) {
   const int K = ks.a * ks.b * ks.c;
-  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= N * K) return;
-  int64_t i;
-  int kz, ky, kx;
-  rb_decompose<FAST>(t, ks, i, kz, ky, kx);
-  const int4 c = reinterpret_cast<const int4 *>(coords)[i];
-  const int tz = c.y + pd.a - kz, ty = c.z + pd.b - ky, tx = c.w + pd.c - kx;
-  if (tz < 0 || ty < 0 || tx < 0) return;
-  int z, y, x;
-  if (!rb_unstride<FAST2>(tz, st.a, z) || !rb_unstride<FAST2>(ty, st.b, y) || !rb_unstride<FAST2>(tx, st.c, x)) return;
-  if (z >= od.d || y >= od.h || x >= od.w) return;
-  const uint32_t lin = rslo_lin(c.x, z, y, x, od);
-  atomicOr(&bitmap[lin >> 5], 1u << (lin & 31));
+  const int64_t total = rslo_rows(N, d_n) * K;
+  RSLO_GRID_STRIDE(t, total) {
+    int64_t i;
+    int kz, ky, kx;
+    rb_decompose<FAST>(t, ks, i, kz, ky, kx);
+    const int4 c = reinterpret_cast<const int4 *>(coords)[i];
+    const int tz = c.y + pd.a - kz, ty = c.z + pd.b - ky, tx = c.w + pd.c - kx;
+    if (tz < 0 || ty < 0 || tx < 0) continue;
+    int z, y, x;
+    if (!rb_unstride<FAST2>(tz, st.a, z) || !rb_unstride<FAST2>(ty, st.b, y) || !rb_unstride<FAST2>(tx, st.c, x))
+      continue;
+    if (z >= od.d || y >= od.h || x >= od.w) continue;
+    const uint32_t lin = rslo_lin(c.x, z, y, x, od);
+    atomicOr(&bitmap[lin >> 5], 1u << (lin & 31));
+  }
 }
 
 extern "C" int rslo_conv_out_count(const int32_t *coords_in, int64_t N, int B, const int32_t *ks,
@@ -278,8 +298,8 @@ extern "C" int rslo_conv_out_count(const int32_t *coords_in, int64_t N, int B, c
   const int K = ks[0] * ks[1] * ks[2];
   if (N > 0) {
 #define RB_MARK(F, F2)                                                                                     \
-    hipLaunchKernelGGL((k_conv_mark<F, F2>), dim3((unsigned)rslo_cdiv(N * K, 256)), dim3(256), 0, st, coords_in, N, \
-                       Int3{ks[0], ks[1], ks[2]}, Int3{stride[0], stride[1], stride[2]},                    \
+    hipLaunchKernelGGL((k_conv_mark<F, F2>), dim3(rb_grid(N * K)), dim3(256), 0, st, coords_in, N,           \
+                       (const int32_t *)nullptr, Int3{ks[0], ks[1], ks[2]}, Int3{stride[0], stride[1], stride[2]}, \
                        Int3{pad[0], pad[1], pad[2]}, Dims3{od[0], od[1], od[2]}, bitmap)
     if (rb_fast_k(ks, N) && rb_fast_s(stride)) RB_MARK(true, true);
     else RB_MARK(false, false);
@@ -296,6 +316,7 @@ __global__ void k_conv_emit(const uint32_t *__restrict__ bitmap, const int32_t *
   uint32_t bits = bitmap[w];
   if (!bits) return;
   int32_t r = prefix[w];
+  if (r >= M) return;          // rslo_plan_encoder: M is the level's capacity, rows past it are dropped (and flagged)
   while (bits) {
     const int b = __ffs(bits) - 1;
     bits &= bits - 1;
@@ -324,22 +345,23 @@ extern "C" int rslo_conv_out_coords(const uint32_t *bitmap, const int32_t *word_
 }
 
 template <bool FAST>
-__global__ void k_rulebook_conv(const int32_t *__restrict__ coords_out, int64_t M, Dims3 id, Int3 ks,
-                                Int3 st, Int3 pd, const uint32_t *__restrict__ keys,
+__global__ void k_rulebook_conv(const int32_t *__restrict__ coords_out, int64_t M, const int32_t *__restrict__ d_m,
+                                Dims3 id, Int3 ks, Int3 st, Int3 pd, const uint32_t *__restrict__ keys,
                                 const int32_t *__restrict__ vals, uint32_t mask, int shift,
                                 int32_t *__restrict__ nbr) {
   const int K = ks.a * ks.b * ks.c;
-  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= M * K) return;
-  int64_t o;
-  int kz, ky, kx;
-  rb_decompose<FAST>(t, ks, o, kz, ky, kx);
-  const int4 c = reinterpret_cast<const int4 *>(coords_out)[o];
-  const int z = c.y * st.a - pd.a + kz, y = c.z * st.b - pd.b + ky, x = c.w * st.c - pd.c + kx;
-  int32_t r = -1;
-  if (z >= 0 && z < id.d && y >= 0 && y < id.h && x >= 0 && x < id.w)
-    r = rslo_hfind(keys, vals, mask, shift, rslo_lin(c.x, z, y, x, id));
-  nbr[t] = r;
+  const int64_t total = rslo_rows(M, d_m) * K;
+  RSLO_GRID_STRIDE(t, total) {
+    int64_t o;
+    int kz, ky, kx;
+    rb_decompose<FAST>(t, ks, o, kz, ky, kx);
+    const int4 c = reinterpret_cast<const int4 *>(coords_out)[o];
+    const int z = c.y * st.a - pd.a + kz, y = c.z * st.b - pd.b + ky, x = c.w * st.c - pd.c + kx;
+    int32_t r = -1;
+    if (z >= 0 && z < id.d && y >= 0 && y < id.h && x >= 0 && x < id.w)
+      r = rslo_hfind(keys, vals, mask, shift, rslo_lin(c.x, z, y, x, id));
+    nbr[t] = r;
+  }
 }
 
 extern "C" int rslo_rulebook_conv(const int32_t *coords_out, int64_t M, int B, const int32_t *id,
@@ -352,8 +374,8 @@ extern "C" int rslo_rulebook_conv(const int32_t *coords_out, int64_t M, int B, c
   const int K = ks[0] * ks[1] * ks[2];
   const int shift = 32 - rslo_log2_i64(in_cap);
 #define RB_CONV(F)                                                                                            \
-  hipLaunchKernelGGL(k_rulebook_conv<F>, dim3((unsigned)rslo_cdiv(M * K, 256)), dim3(256), 0, st, coords_out,  \
-                     M, Dims3{id[0], id[1], id[2]}, Int3{ks[0], ks[1], ks[2]},                                 \
+  hipLaunchKernelGGL(k_rulebook_conv<F>, dim3(rb_grid(M * K)), dim3(256), 0, st, coords_out,                  \
+                     M, (const int32_t *)nullptr, Dims3{id[0], id[1], id[2]}, Int3{ks[0], ks[1], ks[2]},       \
                      Int3{stride[0], stride[1], stride[2]}, Int3{pad[0], pad[1], pad[2]}, in_keys,             \
                      in_vals, (uint32_t)(in_cap - 1), shift, nbr)
   if (rb_fast_k(ks, M)) RB_CONV(true);
@@ -364,26 +386,27 @@ extern "C" int rslo_rulebook_conv(const int32_t *coords_out, int64_t M, int B, c
 }
 
 template <bool FAST, bool FAST2>
-__global__ void k_rulebook_conv_T(const int32_t *__restrict__ coords_in, int64_t N, Dims3 od, Int3 ks,
-                                  Int3 st, Int3 pd, const uint32_t *__restrict__ keys,
+__global__ void k_rulebook_conv_T(const int32_t *__restrict__ coords_in, int64_t N, const int32_t *__restrict__ d_n,
+                                  Dims3 od, Int3 ks, Int3 st, Int3 pd, const uint32_t *__restrict__ keys,
                                   const int32_t *__restrict__ vals, uint32_t mask, int shift,
                                   int32_t *__restrict__ nbrT) {
   const int K = ks.a * ks.b * ks.c;
-  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= N * K) return;
-  int64_t i;
-  int kz, ky, kx;
-  rb_decompose<FAST>(t, ks, i, kz, ky, kx);
-  const int4 c = reinterpret_cast<const int4 *>(coords_in)[i];
-  const int tz = c.y + pd.a - kz, ty = c.z + pd.b - ky, tx = c.w + pd.c - kx;
-  int32_t r = -1;
-  int z, y, x;
-  if (tz >= 0 && ty >= 0 && tx >= 0 && rb_unstride<FAST2>(tz, st.a, z) && rb_unstride<FAST2>(ty, st.b, y) &&
-      rb_unstride<FAST2>(tx, st.c, x)) {
-    if (z < od.d && y < od.h && x < od.w)
-      r = rslo_hfind(keys, vals, mask, shift, rslo_lin(c.x, z, y, x, od));
+  const int64_t total = rslo_rows(N, d_n) * K;
+  RSLO_GRID_STRIDE(t, total) {
+    int64_t i;
+    int kz, ky, kx;
+    rb_decompose<FAST>(t, ks, i, kz, ky, kx);
+    const int4 c = reinterpret_cast<const int4 *>(coords_in)[i];
+    const int tz = c.y + pd.a - kz, ty = c.z + pd.b - ky, tx = c.w + pd.c - kx;
+    int32_t r = -1;
+    int z, y, x;
+    if (tz >= 0 && ty >= 0 && tx >= 0 && rb_unstride<FAST2>(tz, st.a, z) && rb_unstride<FAST2>(ty, st.b, y) &&
+        rb_unstride<FAST2>(tx, st.c, x)) {
+      if (z < od.d && y < od.h && x < od.w)
+        r = rslo_hfind(keys, vals, mask, shift, rslo_lin(c.x, z, y, x, od));
+    }
+    nbrT[t] = r;
   }
-  nbrT[t] = r;
 }
 
 extern "C" int rslo_rulebook_conv_T(const int32_t *coords_in, int64_t N, int B, const int32_t *od,
@@ -396,8 +419,8 @@ extern "C" int rslo_rulebook_conv_T(const int32_t *coords_in, int64_t N, int B, 
   const int K = ks[0] * ks[1] * ks[2];
   const int shift = 32 - rslo_log2_i64(out_cap);
 #define RB_CONVT(F, F2)                                                                                       \
-  hipLaunchKernelGGL((k_rulebook_conv_T<F, F2>), dim3((unsigned)rslo_cdiv(N * K, 256)), dim3(256), 0, st, coords_in, \
-                     N, Dims3{od[0], od[1], od[2]}, Int3{ks[0], ks[1], ks[2]},                                 \
+  hipLaunchKernelGGL((k_rulebook_conv_T<F, F2>), dim3(rb_grid(N * K)), dim3(256), 0, st, coords_in,           \
+                     N, (const int32_t *)nullptr, Dims3{od[0], od[1], od[2]}, Int3{ks[0], ks[1], ks[2]},       \
                      Int3{stride[0], stride[1], stride[2]}, Int3{pad[0], pad[1], pad[2]}, out_keys,            \
                      out_vals, (uint32_t)(out_cap - 1), shift, nbrT)
   if (rb_fast_k(ks, N) && rb_fast_s(stride)) RB_CONVT(true, true);
@@ -500,16 +523,30 @@ __global__ void k_vox_flags(const int32_t *__restrict__ slot, const int32_t *__r
   flags[i] = (s >= 0 && first[s] == (int32_t)i) ? 1u : 0u;
 }
 
+// Plan mode (rslo_plan_encoder): the clouds of a step are voxelized one after the other into ONE row space; cloud c
+// starts at row *d_base (the running total the previous cloud left), writes (b, z, y, x) coordinates twice -- with its
+// index inside the frame (the example dict's `coordinates[t]`, rslo/data/preprocess.py:75-89) and with its index in the
+// batched encoder tensor (t * B + b) -- and leaves the next cloud's base.  d_base == NULL: the stand-alone entry point.
+struct VoxPlan {
+  const int32_t *d_base;
+  int32_t *d_base_next;
+  int32_t *coords_frame, *coords_all;   // [cap, 4]
+  int b_frame, b_all;
+};
+
 __global__ void k_vox_assign(const uint32_t *__restrict__ keys, const int32_t *__restrict__ slot,
                              const uint32_t *__restrict__ flags, const int32_t *__restrict__ pos, int64_t P,
                              VoxGeom G, int max_voxels, int32_t *__restrict__ vid,
                              int32_t *__restrict__ coords, int32_t *__restrict__ cutoff,
-                             int32_t *__restrict__ d_nvox) {
+                             int32_t *__restrict__ d_nvox, VoxPlan pl) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P) return;
+  const int32_t base = pl.d_base ? *pl.d_base : 0;
   if (i == P - 1) {
     const int32_t tot = pos[i] + (int32_t)flags[i];
-    *d_nvox = tot < max_voxels ? tot : max_voxels;
+    const int32_t nv = tot < max_voxels ? tot : max_voxels;
+    *d_nvox = nv;
+    if (pl.d_base_next) *pl.d_base_next = base + nv;
   }
   if (!flags[i]) return;
   const int32_t s = slot[i];
@@ -521,9 +558,14 @@ __global__ void k_vox_assign(const uint32_t *__restrict__ keys, const int32_t *_
     key /= G.g[0];
     const int y = key % G.g[1];
     const int z = key / G.g[1];
-    coords[v * 3 + 0] = z;
-    coords[v * 3 + 1] = y;
-    coords[v * 3 + 2] = x;
+    if (pl.d_base) {
+      reinterpret_cast<int4 *>(pl.coords_frame)[base + v] = make_int4(pl.b_frame, z, y, x);
+      reinterpret_cast<int4 *>(pl.coords_all)[base + v] = make_int4(pl.b_all, z, y, x);
+    } else {
+      coords[v * 3 + 0] = z;
+      coords[v * 3 + 1] = y;
+      coords[v * 3 + 2] = x;
+    }
   } else if (v == max_voxels) {
     *cutoff = (int32_t)i;  // the reference loop `break`s here
   }
@@ -533,7 +575,7 @@ __global__ void k_vox_fill(const float *__restrict__ pts, int64_t P, int F, int 
                            const int32_t *__restrict__ slot, const int32_t *__restrict__ head,
                            const int32_t *__restrict__ next, const int32_t *__restrict__ vid,
                            const int32_t *__restrict__ cutoff, float *__restrict__ voxels,
-                           int32_t *__restrict__ num_points) {
+                           int32_t *__restrict__ num_points, const int32_t *__restrict__ d_base) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P) return;
   const int32_t s = slot[i];
@@ -541,11 +583,33 @@ __global__ void k_vox_fill(const float *__restrict__ pts, int64_t P, int F, int 
   int rank = 0;
   for (int32_t j = head[s]; j >= 0; j = next[j]) rank += (j < (int32_t)i);
   if (rank >= T) return;
-  const int32_t v = vid[s];
+  const int32_t v = vid[s] + (d_base ? *d_base : 0);
   float *dst = voxels + ((int64_t)v * T + rank) * F;
   const float *src = pts + i * F;
   for (int f = 0; f < F; ++f) dst[f] = src[f];
   atomicAdd(&num_points[v], 1);
+}
+
+// the voxelizer's launches for one cloud (outputs already zero-filled by the caller)
+static int vox_run(const float *points, int64_t P, int F, const VoxGeom &G, int T, int max_voxels, void *ws,
+                   float *voxels, int32_t *coords, int32_t *num_points, int32_t *d_nvox, VoxPlan pl, hipStream_t st) {
+  VoxWs w;
+  vox_ws_layout(P, ws, &w);
+  RSLO_HIP(hipMemsetAsync(w.keys, 0xFF, (size_t)w.cap * 8, st));                 // keys | head
+  RSLO_HIP(hipMemsetAsync(w.first, 0x7F, (size_t)w.cap * 4 + sizeof(int32_t), st));    // first | cutoff
+  const unsigned nb = (unsigned)rslo_cdiv(P, 256);
+  const int shift = 32 - rslo_log2_i64(w.cap);
+  hipLaunchKernelGGL(k_vox_insert, dim3(nb), dim3(256), 0, st, points, P, F, G, w.keys, w.first, w.head,
+                     w.next, w.slot, (uint32_t)(w.cap - 1), shift);
+  hipLaunchKernelGGL(k_vox_flags, dim3(nb), dim3(256), 0, st, w.slot, w.first, P, w.flags);
+  RSLO_CHECK_LAUNCH("vox_insert");
+  if (int rc = scan_exclusive<false>(w.flags, w.pos, P, w.scan_ws, w.scan_bytes, nullptr, st)) return rc;
+  hipLaunchKernelGGL(k_vox_assign, dim3(nb), dim3(256), 0, st, w.keys, w.slot, w.flags, w.pos, P, G,
+                     max_voxels, w.vid, coords, w.cutoff, d_nvox, pl);
+  hipLaunchKernelGGL(k_vox_fill, dim3(nb), dim3(256), 0, st, points, P, F, T, w.slot, w.head, w.next,
+                     w.vid, w.cutoff, voxels, num_points, pl.d_base);
+  RSLO_CHECK_LAUNCH("vox_fill");
+  return RSLO_OK;
 }
 
 extern "C" int rslo_voxelize(const float *points, int64_t P, int F, const float *range6,
@@ -579,29 +643,13 @@ extern "C" int rslo_voxelize(const float *points, int64_t P, int F, const float 
     rslo_set_error("voxelize: workspace too small (%zu < %zu)", ws_bytes, rslo_voxelize_ws_bytes(P));
     return RSLO_EWS;
   }
-  VoxWs w;
-  vox_ws_layout(P, ws, &w);
   VoxGeom G;
   for (int j = 0; j < 3; ++j) {
     G.lo[j] = range6[j];
     G.vs[j] = vsize3[j];
     G.g[j] = grid_xyz[j];
   }
-  RSLO_HIP(hipMemsetAsync(w.keys, 0xFF, (size_t)w.cap * 8, st));                 // keys | head
-  RSLO_HIP(hipMemsetAsync(w.first, 0x7F, (size_t)w.cap * 4 + sizeof(int32_t), st));    // first | cutoff
-  const unsigned nb = (unsigned)rslo_cdiv(P, 256);
-  const int shift = 32 - rslo_log2_i64(w.cap);
-  hipLaunchKernelGGL(k_vox_insert, dim3(nb), dim3(256), 0, st, points, P, F, G, w.keys, w.first, w.head,
-                     w.next, w.slot, (uint32_t)(w.cap - 1), shift);
-  hipLaunchKernelGGL(k_vox_flags, dim3(nb), dim3(256), 0, st, w.slot, w.first, P, w.flags);
-  RSLO_CHECK_LAUNCH("vox_insert");
-  if (int rc = scan_exclusive<false>(w.flags, w.pos, P, w.scan_ws, w.scan_bytes, nullptr, st)) return rc;
-  hipLaunchKernelGGL(k_vox_assign, dim3(nb), dim3(256), 0, st, w.keys, w.slot, w.flags, w.pos, P, G,
-                     max_voxels, w.vid, coords, w.cutoff, d_nvox);
-  hipLaunchKernelGGL(k_vox_fill, dim3(nb), dim3(256), 0, st, points, P, F, T, w.slot, w.head, w.next,
-                     w.vid, w.cutoff, voxels, num_points);
-  RSLO_CHECK_LAUNCH("vox_fill");
-  return RSLO_OK;
+  return vox_run(points, P, F, G, T, max_voxels, ws, voxels, coords, num_points, d_nvox, VoxPlan{}, st);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -744,13 +792,19 @@ extern "C" int rslo_dense_gather(const float *dense, const int32_t *coords, int6
 #define PR_ROWS 256
 
 template <bool EMIT>
-__global__ __launch_bounds__(PR_ROWS) void k_pair_pass(const int32_t *__restrict__ nbr, int64_t N, int K, int nblk,
+__global__ __launch_bounds__(PR_ROWS) void k_pair_pass(const int32_t *__restrict__ nbr, int64_t N_host,
+                                                       const int32_t *__restrict__ d_n, int K, int nblk,
                                                        int32_t *__restrict__ counts,
                                                        const int32_t *__restrict__ offsets,
                                                        int32_t *__restrict__ pin, int32_t *__restrict__ pout) {
   __shared__ int32_t tab[PR_ROWS * 27];
   __shared__ int32_t wcnt[PR_ROWS / 64][27];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int64_t N = rslo_rows(N_host, d_n);
+  if (d_n) {      // capacity-sized launch: the counts are laid out for the ACTUAL number of row blocks, the rest exit
+    nblk = (int)((N + PR_ROWS - 1) / PR_ROWS);
+    if ((int)blockIdx.x >= nblk) return;
+  }
   const int64_t row0 = (int64_t)blockIdx.x * PR_ROWS;
   const int64_t lim = (N - row0 < PR_ROWS ? N - row0 : PR_ROWS) * K;      // table entries of this block
   for (int e = tid; e < PR_ROWS * K; e += PR_ROWS) tab[e] = e < lim ? nbr[row0 * K + e] : -1;
@@ -785,9 +839,17 @@ __global__ __launch_bounds__(PR_ROWS) void k_pair_pass(const int32_t *__restrict
 
 // exclusive scan of n values in place by ONE workgroup (n = K * blocks, a few 10^4); koff[k] = offset of (k, block 0)
 __global__ __launch_bounds__(1024) void k_pair_scan(int32_t *__restrict__ v, int n, int K, int nblk,
-                                                    int32_t *__restrict__ koff) {
+                                                    const int32_t *__restrict__ d_n, int32_t *__restrict__ koff) {
   __shared__ int32_t wsum[16];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  if (d_n) {
+    nblk = (*d_n + PR_ROWS - 1) / PR_ROWS;
+    n = K * nblk;
+    if (nblk == 0) {
+      if (tid <= K) koff[tid] = 0;
+      return;
+    }
+  }
   const int per = (n + 1023) / 1024;
   const int i0 = tid * per, i1 = (i0 + per < n) ? i0 + per : n;
   int32_t s = 0;
@@ -811,6 +873,21 @@ __global__ __launch_bounds__(1024) void k_pair_scan(int32_t *__restrict__ v, int
   if (tid == 1023) koff[K] = run;        // the last thread's running sum ends at the total (empty chunks carry it)
 }
 
+static int pairs_run(const int32_t *nbr, int64_t n_rows, const int32_t *d_n, int K, int nblk, int32_t *counts,
+                     int32_t *pairs_in, int32_t *pairs_out, int32_t *koff, hipStream_t st) {
+  hipLaunchKernelGGL(k_pair_pass<false>, dim3((unsigned)nblk), dim3(PR_ROWS), 0, st, nbr, n_rows, d_n, K, nblk, counts,
+                     (const int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
+  hipLaunchKernelGGL(k_pair_scan, dim3(1), dim3(1024), 0, st, counts, K * nblk, K, nblk, d_n, koff);
+  hipLaunchKernelGGL(k_pair_pass<true>, dim3((unsigned)nblk), dim3(PR_ROWS), 0, st, nbr, n_rows, d_n, K, nblk,
+                     (int32_t *)nullptr, (const int32_t *)counts, pairs_in, pairs_out);
+  RSLO_CHECK_LAUNCH("rulebook_pairs");
+  return RSLO_OK;
+}
+
+extern "C" size_t rslo_rulebook_pairs_ws_bytes(int64_t n_rows, int K) {
+  return align256((size_t)K * (size_t)rslo_cdiv(n_rows > 0 ? n_rows : 1, PR_ROWS) * sizeof(int32_t));
+}
+
 extern "C" int rslo_rulebook_pairs(const int32_t *nbr, int64_t n_rows, int K, void *ws, size_t ws_bytes,
                                    int32_t *pairs_in, int32_t *pairs_out, int32_t *koff, void *stream) {
   hipStream_t st = (hipStream_t)stream;
@@ -827,13 +904,7 @@ extern "C" int rslo_rulebook_pairs(const int32_t *nbr, int64_t n_rows, int K, vo
     return RSLO_EWS;
   }
   int32_t *counts = (int32_t *)ws;
-  hipLaunchKernelGGL(k_pair_pass<false>, dim3((unsigned)nblk), dim3(PR_ROWS), 0, st, nbr, n_rows, K, nblk, counts,
-                     (const int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
-  hipLaunchKernelGGL(k_pair_scan, dim3(1), dim3(1024), 0, st, counts, K * nblk, K, nblk, koff);
-  hipLaunchKernelGGL(k_pair_pass<true>, dim3((unsigned)nblk), dim3(PR_ROWS), 0, st, nbr, n_rows, K, nblk,
-                     (int32_t *)nullptr, (const int32_t *)counts, pairs_in, pairs_out);
-  RSLO_CHECK_LAUNCH("rulebook_pairs");
-  return RSLO_OK;
+  return pairs_run(nbr, n_rows, nullptr, K, nblk, counts, pairs_in, pairs_out, koff, st);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -851,10 +922,13 @@ extern "C" int rslo_rulebook_pairs(const int32_t *nbr, int64_t n_rows, int K, vo
 #define RO_WINDOW (1 << RO_BITS)
 #define RO_THREADS 256
 
-__global__ __launch_bounds__(RO_THREADS) void k_row_order(const int32_t *__restrict__ nbr, int64_t n, int K, int flip,
+__global__ __launch_bounds__(RO_THREADS) void k_row_order(const int32_t *__restrict__ nbr, int64_t n_host,
+                                                          const int32_t *__restrict__ d_n, int K, int flip,
                                                           int32_t *__restrict__ order) {
   __shared__ unsigned long long key[RO_WINDOW];
+  const int64_t n = rslo_rows(n_host, d_n);
   const int64_t base = (int64_t)blockIdx.x * RO_WINDOW;
+  if (base >= n) return;       // capacity-sized launch (rslo_plan_encoder): windows past the actual rows
   for (int r = threadIdx.x; r < RO_WINDOW; r += RO_THREADS) {
     const int64_t row = base + r;
     unsigned long long kv = ~0ull;
@@ -894,7 +968,291 @@ extern "C" int rslo_rulebook_row_order(const int32_t *nbr, int64_t n_rows, int K
   if (n_rows == 0) return RSLO_OK;
   RSLO_CHECK_ARG(nbr && order, "rslo_rulebook_row_order: null pointer");
   hipLaunchKernelGGL(k_row_order, dim3((unsigned)rslo_cdiv(n_rows, RO_WINDOW)), dim3(RO_THREADS), 0,
-                     (hipStream_t)stream, nbr, n_rows, K, flip_k, order);
+                     (hipStream_t)stream, nbr, n_rows, (const int32_t *)nullptr, K, flip_k, order);
   RSLO_CHECK_LAUNCH("k_row_order");
+  return RSLO_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// rslo_plan_encoder: voxelization of all clouds of a step + the whole rulebook chain of a chain-structured sparse
+// encoder in ONE call without a single host read.  Every data-dependent size stays on the device: the kernels above
+// take their row counts from the counts block (d_n), launches are sized for the capacity of a level, and the counts
+// reach the host through one asynchronous copy into pinned memory that the caller reads when it picks the plan up
+// (a step later, in rslo_amd.workload.ExamplePrefetcher).  The Python-issued form of the same work was ~230 launches
+// and 7 blocking reads per step on a helper thread.
+// ---------------------------------------------------------------------------------------
+static size_t plan_take(size_t &off, size_t bytes) {
+  const size_t o = off;
+  off += align256(bytes > 0 ? bytes : 1);
+  return o;
+}
+
+static void plan_out_dims(const int32_t *in, const int32_t *ks, const int32_t *st, const int32_t *pd, int32_t *out) {
+  for (int j = 0; j < 3; ++j) out[j] = (in[j] + 2 * pd[j] - ks[j]) / st[j] + 1;
+}
+
+extern "C" int rslo_plan_encoder_layout(const RsloEncoderSpec *spec, int n_clouds, const int64_t *h_n_points,
+                                        RsloPlanLayout *lay) {
+  RSLO_CHECK_ARG(spec && lay && h_n_points, "plan_encoder_layout: null argument");
+  RSLO_CHECK_ARG(spec->n_levels >= 1 && spec->n_levels <= RSLO_PLAN_MAX_LEVELS, "plan_encoder_layout: 1..8 levels");
+  RSLO_CHECK_ARG(n_clouds >= 1 && n_clouds <= RSLO_PLAN_MAX_CLOUDS, "plan_encoder_layout: 1..64 clouds");
+  RSLO_CHECK_ARG(spec->max_points >= 1 && spec->max_voxels >= 1 && spec->n_features >= 3 && spec->n_features <= 16,
+                 "plan_encoder_layout: bad voxelizer parameters");
+  memset(lay, 0, sizeof(*lay));
+  const int L = spec->n_levels, T = spec->max_points, F = spec->n_features;
+  int64_t sumP = 0, maxP = 1;
+  for (int c = 0; c < n_clouds; ++c) {
+    RSLO_CHECK_ARG(h_n_points[c] >= 0 && h_n_points[c] < (int64_t)2000000000, "plan_encoder_layout: bad point count");
+    sumP += h_n_points[c];
+    if (h_n_points[c] > maxP) maxP = h_n_points[c];
+  }
+  for (int j = 0; j < 3; ++j) lay->dims[0][j] = spec->dims0[j];
+  for (int l = 0; l + 1 < L; ++l)
+    plan_out_dims(lay->dims[l], spec->conv_ks[l], spec->conv_stride[l], spec->conv_pad[l], lay->dims[l + 1]);
+  for (int l = 0; l < L; ++l) {
+    RSLO_CHECK_ARG(lay->dims[l][0] >= 1 && lay->dims[l][1] >= 1 && lay->dims[l][2] >= 1, "plan_encoder_layout: empty level");
+    if (int rc = check_volume(n_clouds, lay->dims[l])) return rc;
+    int64_t cap = spec->cap_rows[l];
+    if (l == 0) {      // every cloud adds at most min(max_voxels, P) rows: a smaller capacity could be overrun
+      int64_t need = (int64_t)n_clouds * spec->max_voxels;
+      if (sumP < need) need = sumP;
+      RSLO_CHECK_ARG(cap <= 0 || cap >= need, "plan_encoder_layout: level-0 capacity below n_clouds * max_voxels");
+      if (cap <= 0) cap = need;
+    } else if (cap <= 0) {
+      {
+        cap = lay->cap_rows[l - 1];      // LiDAR surfaces thin out under stride 2; an overflow is flagged, never silent
+      }
+    }
+    const int64_t vol = (int64_t)n_clouds * lay->dims[l][0] * lay->dims[l][1] * lay->dims[l][2];
+    if (cap > vol) cap = vol;
+    if (cap < 1) cap = 1;
+    RSLO_CHECK_ARG(cap * 27 < ((int64_t)1 << 31), "plan_encoder_layout: level capacity too large");
+    lay->cap_rows[l] = cap;
+    lay->hash_cap[l] = rslo_hash_capacity(cap);
+  }
+  size_t off = 0;
+  lay->counts_off = plan_take(off, RSLO_PLAN_CNT_WORDS * sizeof(int32_t));
+  const int64_t c0 = lay->cap_rows[0];
+  // voxels | num_points back to back: one zero fill
+  lay->voxels_off = plan_take(off, (size_t)c0 * T * F * sizeof(float));
+  lay->num_points_off = plan_take(off, (size_t)c0 * sizeof(int32_t));
+  lay->coords_frame_off = plan_take(off, (size_t)c0 * 16);
+  for (int l = 0; l < L; ++l) {
+    const int64_t cap = lay->cap_rows[l];
+    lay->coords_off[l] = plan_take(off, (size_t)cap * 16);
+    lay->keys_off[l] = plan_take(off, (size_t)lay->hash_cap[l] * 4);
+    lay->vals_off[l] = plan_take(off, (size_t)lay->hash_cap[l] * 4);
+    const int Ks = spec->subm_ks[l][0] * spec->subm_ks[l][1] * spec->subm_ks[l][2];
+    if (Ks > 0) {
+      RSLO_CHECK_ARG(Ks <= 27, "plan_encoder_layout: SubM kernel volume > 27");
+      lay->subm_nbr_off[l] = plan_take(off, (size_t)cap * Ks * 4);
+      if (spec->want_pairs) {
+        lay->subm_pin_off[l] = plan_take(off, (size_t)cap * Ks * 4);
+        lay->subm_pout_off[l] = plan_take(off, (size_t)cap * Ks * 4);
+        lay->subm_koff_off[l] = plan_take(off, (size_t)(Ks + 1) * 4);
+      }
+    }
+    if (l + 1 < L) {
+      const int K = spec->conv_ks[l][0] * spec->conv_ks[l][1] * spec->conv_ks[l][2];
+      RSLO_CHECK_ARG(K >= 1 && K <= 27, "plan_encoder_layout: conv kernel volume must be in 1..27");
+      const int64_t capo = lay->cap_rows[l + 1];
+      lay->conv_nbr_off[l] = plan_take(off, (size_t)capo * K * 4);
+      lay->conv_nbrT_off[l] = plan_take(off, (size_t)cap * K * 4);
+      if (spec->want_orders) lay->conv_order_off[l] = plan_take(off, (size_t)cap * 4);
+      if (spec->want_pairs) {
+        lay->conv_pin_off[l] = plan_take(off, (size_t)capo * K * 4);
+        lay->conv_pout_off[l] = plan_take(off, (size_t)capo * K * 4);
+        lay->conv_koff_off[l] = plan_take(off, (size_t)(K + 1) * 4);
+      }
+    }
+  }
+  // scratch shared by the stages (stream order): voxelizer workspace, bitmap + word prefix + scan sums, pair counts
+  int64_t words = 1, pair_ws = 256;
+  for (int l = 0; l + 1 < L; ++l) {
+    const int64_t w = rslo_conv_bitmap_words(n_clouds, lay->dims[l + 1]);
+    if (w > words) words = w;
+  }
+  for (int l = 0; l < L; ++l) {
+    const int64_t b = (int64_t)rslo_rulebook_pairs_ws_bytes(lay->cap_rows[l], 27);
+    if (b > pair_ws) pair_ws = b;
+  }
+  lay->scratch_words = words;
+  lay->vox_ws_off = plan_take(off, rslo_voxelize_ws_bytes(maxP));
+  lay->bitmap_off = plan_take(off, (size_t)words * 4);
+  lay->prefix_off = plan_take(off, (size_t)words * 4);
+  lay->scan_ws_off = plan_take(off, rslo_scan_ws_bytes(words));
+  lay->pair_ws_off = plan_take(off, (size_t)pair_ws);
+  lay->total_bytes = off;
+  return RSLO_OK;
+}
+
+__global__ void kp_carry(int32_t *__restrict__ cnt, int c) {      // a cloud without points
+  cnt[RSLO_PLAN_CNT_NVOX + c] = 0;
+  cnt[RSLO_PLAN_CNT_BASE + c + 1] = cnt[RSLO_PLAN_CNT_BASE + c];
+}
+
+__global__ void kp_level0(int32_t *__restrict__ cnt, int n_clouds) {
+  const int j = threadIdx.x;
+  if (j <= n_clouds) cnt[RSLO_PLAN_CNT_BOFF + j] = cnt[RSLO_PLAN_CNT_BASE + j];
+  if (j == 0) cnt[RSLO_PLAN_CNT_ROWS] = cnt[RSLO_PLAN_CNT_BASE + n_clouds];
+}
+
+__global__ void kp_level_finish(int32_t *__restrict__ cnt, int level, int cap) {
+  const int32_t raw = cnt[RSLO_PLAN_CNT_RAW + level];
+  cnt[RSLO_PLAN_CNT_ROWS + level] = raw < cap ? raw : cap;
+  if (raw > cap) atomicOr((unsigned *)&cnt[RSLO_PLAN_CNT_OVERFLOW], 1u << level);
+}
+
+// rows are grouped by ascending batch index on every level: first row with batch >= j, j = 0..nb
+__global__ void kp_batch_offsets(const int32_t *__restrict__ coords, const int32_t *__restrict__ d_n, int nb,
+                                 int32_t *__restrict__ out) {
+  const int j = threadIdx.x;
+  if (j > nb) return;
+  int lo = 0, hi = *d_n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (coords[(int64_t)mid * 4] < j) lo = mid + 1;
+    else hi = mid;
+  }
+  out[j] = lo;
+}
+
+extern "C" int rslo_plan_encoder(const RsloEncoderSpec *spec, const RsloPlanLayout *lay, int n_clouds,
+                                 int clouds_per_frame, const float *const *h_points, const int64_t *h_n_points,
+                                 void *arena, size_t arena_bytes, int32_t *h_counts, void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  RSLO_CHECK_ARG(spec && lay && h_points && h_n_points && arena, "plan_encoder: null argument");
+  RSLO_CHECK_ARG(arena_bytes >= lay->total_bytes, "plan_encoder: arena too small");
+  RSLO_CHECK_ARG(clouds_per_frame >= 1 && n_clouds % clouds_per_frame == 0, "plan_encoder: clouds must fill whole frames");
+  RSLO_CHECK_ARG(((uintptr_t)arena & 255) == 0, "plan_encoder: arena must be 256-byte aligned");
+  char *A = (char *)arena;
+  const int L = spec->n_levels, T = spec->max_points, F = spec->n_features;
+  int32_t *cnt = (int32_t *)(A + lay->counts_off);
+  RSLO_HIP(hipMemsetAsync(cnt, 0, RSLO_PLAN_CNT_WORDS * sizeof(int32_t), st));
+  const int64_t c0 = lay->cap_rows[0];
+  float *voxels = (float *)(A + lay->voxels_off);
+  int32_t *num = (int32_t *)(A + lay->num_points_off);
+  RSLO_HIP(hipMemsetAsync(voxels, 0, (size_t)(lay->num_points_off - lay->voxels_off) + (size_t)c0 * 4, st));
+  int32_t *coords_frame = (int32_t *)(A + lay->coords_frame_off), *coords0 = (int32_t *)(A + lay->coords_off[0]);
+  VoxGeom G;
+  for (int j = 0; j < 3; ++j) {
+    G.lo[j] = spec->range6[j];
+    G.vs[j] = spec->vsize3[j];
+    G.g[j] = spec->grid_xyz[j];
+  }
+  for (int c = 0; c < n_clouds; ++c) {
+    const int64_t P = h_n_points[c];
+    if (P == 0) {
+      hipLaunchKernelGGL(kp_carry, dim3(1), dim3(1), 0, st, cnt, c);
+      continue;
+    }
+    // a cloud cannot add more voxels than the level-0 capacity has left: the reference's max_voxels bound per cloud
+    // sums to at most the capacity (layout), so base + nvox <= capacity by construction
+    VoxPlan pl{cnt + RSLO_PLAN_CNT_BASE + c, cnt + RSLO_PLAN_CNT_BASE + c + 1, coords_frame, coords0,
+               c % clouds_per_frame, c};
+    if (int rc = vox_run(h_points[c], P, F, G, T, spec->max_voxels, A + lay->vox_ws_off, voxels, nullptr, num,
+                         cnt + RSLO_PLAN_CNT_NVOX + c, pl, st))
+      return rc;
+  }
+  hipLaunchKernelGGL(kp_level0, dim3(1), dim3(RSLO_PLAN_MAX_CLOUDS + 1), 0, st, cnt, n_clouds);
+  RSLO_CHECK_LAUNCH("plan level 0");
+
+  auto hash_level = [&](int l) -> int {
+    const int64_t hc = lay->hash_cap[l];
+    RSLO_HIP(hipMemsetAsync(A + lay->keys_off[l], 0xFF, (size_t)hc * 4, st));
+    hipLaunchKernelGGL(k_hash_insert, dim3(rb_grid(lay->cap_rows[l])), dim3(256), 0, st,
+                       (const int32_t *)(A + lay->coords_off[l]), (int64_t)0, (const int32_t *)(cnt + RSLO_PLAN_CNT_ROWS + l),
+                       Dims3{lay->dims[l][0], lay->dims[l][1], lay->dims[l][2]}, (uint32_t *)(A + lay->keys_off[l]),
+                       (int32_t *)(A + lay->vals_off[l]), (uint32_t)(hc - 1), 32 - rslo_log2_i64(hc));
+    RSLO_CHECK_LAUNCH("plan hash");
+    return RSLO_OK;
+  };
+  auto pairs_of = [&](const int32_t *nbr, int l_rows, int K, size_t pin, size_t pout, size_t koff) -> int {
+    const int nblk = (int)rslo_cdiv(lay->cap_rows[l_rows], PR_ROWS);
+    return pairs_run(nbr, 0, cnt + RSLO_PLAN_CNT_ROWS + l_rows, K, nblk, (int32_t *)(A + lay->pair_ws_off),
+                     (int32_t *)(A + pin), (int32_t *)(A + pout), (int32_t *)(A + koff), st);
+  };
+
+  if (int rc = hash_level(0)) return rc;
+  for (int l = 0; l < L; ++l) {
+    const int64_t cap = lay->cap_rows[l];
+    const int32_t *d_n = cnt + RSLO_PLAN_CNT_ROWS + l;
+    const int32_t *coords = (const int32_t *)(A + lay->coords_off[l]);
+    const Dims3 dl{lay->dims[l][0], lay->dims[l][1], lay->dims[l][2]};
+    const uint32_t *keys = (const uint32_t *)(A + lay->keys_off[l]);
+    const int32_t *vals = (const int32_t *)(A + lay->vals_off[l]);
+    const int64_t hc = lay->hash_cap[l];
+    const int32_t *sk = spec->subm_ks[l];
+    const int Ks = sk[0] * sk[1] * sk[2];
+    if (Ks > 0) {
+      int32_t *nbr = (int32_t *)(A + lay->subm_nbr_off[l]);
+      if (rb_fast_k(sk, cap))
+        hipLaunchKernelGGL(k_rulebook_subm<true>, dim3(rb_grid(cap * Ks)), dim3(256), 0, st, coords, (int64_t)0, d_n, dl,
+                           Int3{sk[0], sk[1], sk[2]}, keys, vals, (uint32_t)(hc - 1), 32 - rslo_log2_i64(hc), nbr);
+      else
+        hipLaunchKernelGGL(k_rulebook_subm<false>, dim3(rb_grid(cap * Ks)), dim3(256), 0, st, coords, (int64_t)0, d_n, dl,
+                           Int3{sk[0], sk[1], sk[2]}, keys, vals, (uint32_t)(hc - 1), 32 - rslo_log2_i64(hc), nbr);
+      RSLO_CHECK_LAUNCH("plan subm");
+      if (spec->want_pairs)
+        if (int rc = pairs_of(nbr, l, Ks, lay->subm_pin_off[l], lay->subm_pout_off[l], lay->subm_koff_off[l])) return rc;
+    }
+    if (l + 1 >= L) break;
+    const int32_t *ks = spec->conv_ks[l], *sd = spec->conv_stride[l], *pd = spec->conv_pad[l];
+    const int K = ks[0] * ks[1] * ks[2];
+    const int64_t capo = lay->cap_rows[l + 1];
+    const Dims3 od{lay->dims[l + 1][0], lay->dims[l + 1][1], lay->dims[l + 1][2]};
+    const int64_t words = rslo_conv_bitmap_words(n_clouds, lay->dims[l + 1]);
+    uint32_t *bitmap = (uint32_t *)(A + lay->bitmap_off);
+    int32_t *prefix = (int32_t *)(A + lay->prefix_off);
+    RSLO_HIP(hipMemsetAsync(bitmap, 0, (size_t)words * 4, st));
+    const bool fk = rb_fast_k(ks, cap > capo ? cap : capo), fs = rb_fast_s(sd);
+#define PLAN_MARK(F, F2)                                                                                         \
+    hipLaunchKernelGGL((k_conv_mark<F, F2>), dim3(rb_grid(cap * K)), dim3(256), 0, st, coords, (int64_t)0, d_n,  \
+                       Int3{ks[0], ks[1], ks[2]}, Int3{sd[0], sd[1], sd[2]}, Int3{pd[0], pd[1], pd[2]}, od, bitmap)
+    if (fk && fs) PLAN_MARK(true, true);
+    else PLAN_MARK(false, false);
+#undef PLAN_MARK
+    RSLO_CHECK_LAUNCH("plan conv_mark");
+    if (int rc = scan_exclusive<true>(bitmap, prefix, words, A + lay->scan_ws_off, rslo_scan_ws_bytes(lay->scratch_words),
+                                      cnt + RSLO_PLAN_CNT_RAW + l + 1, st))
+      return rc;
+    hipLaunchKernelGGL(kp_level_finish, dim3(1), dim3(1), 0, st, cnt, l + 1, (int)capo);
+    int32_t *coords_o = (int32_t *)(A + lay->coords_off[l + 1]);
+    hipLaunchKernelGGL(k_conv_emit, dim3((unsigned)rslo_cdiv(words, 256)), dim3(256), 0, st, bitmap, prefix, words, od,
+                       coords_o, capo);
+    const int32_t *d_m = cnt + RSLO_PLAN_CNT_ROWS + l + 1;
+    hipLaunchKernelGGL(kp_batch_offsets, dim3(1), dim3(RSLO_PLAN_MAX_CLOUDS + 1), 0, st, coords_o, d_m, n_clouds,
+                       cnt + RSLO_PLAN_CNT_BOFF + (l + 1) * (RSLO_PLAN_MAX_CLOUDS + 1));
+    RSLO_CHECK_LAUNCH("plan conv_emit");
+    if (int rc = hash_level(l + 1)) return rc;
+    int32_t *nbr = (int32_t *)(A + lay->conv_nbr_off[l]), *nbrT = (int32_t *)(A + lay->conv_nbrT_off[l]);
+    const uint32_t *okeys = (const uint32_t *)(A + lay->keys_off[l + 1]);
+    const int32_t *ovals = (const int32_t *)(A + lay->vals_off[l + 1]);
+    const int64_t ohc = lay->hash_cap[l + 1];
+#define PLAN_CONV(F)                                                                                             \
+    hipLaunchKernelGGL(k_rulebook_conv<F>, dim3(rb_grid(capo * K)), dim3(256), 0, st, coords_o, (int64_t)0, d_m, dl, \
+                       Int3{ks[0], ks[1], ks[2]}, Int3{sd[0], sd[1], sd[2]}, Int3{pd[0], pd[1], pd[2]}, keys, vals, \
+                       (uint32_t)(hc - 1), 32 - rslo_log2_i64(hc), nbr)
+    if (fk) PLAN_CONV(true);
+    else PLAN_CONV(false);
+#undef PLAN_CONV
+#define PLAN_CONVT(F, F2)                                                                                        \
+    hipLaunchKernelGGL((k_rulebook_conv_T<F, F2>), dim3(rb_grid(cap * K)), dim3(256), 0, st, coords, (int64_t)0, d_n, \
+                       od, Int3{ks[0], ks[1], ks[2]}, Int3{sd[0], sd[1], sd[2]}, Int3{pd[0], pd[1], pd[2]}, okeys, \
+                       ovals, (uint32_t)(ohc - 1), 32 - rslo_log2_i64(ohc), nbrT)
+    if (fk && fs) PLAN_CONVT(true, true);
+    else PLAN_CONVT(false, false);
+#undef PLAN_CONVT
+    RSLO_CHECK_LAUNCH("plan rulebook_conv");
+    if (spec->want_orders) {
+      hipLaunchKernelGGL(k_row_order, dim3((unsigned)rslo_cdiv(cap, RO_WINDOW)), dim3(RO_THREADS), 0, st,
+                         (const int32_t *)nbrT, (int64_t)0, d_n, K, 0, (int32_t *)(A + lay->conv_order_off[l]));
+      RSLO_CHECK_LAUNCH("plan row_order");
+    }
+    if (spec->want_pairs)
+      if (int rc = pairs_of(nbr, l + 1, K, lay->conv_pin_off[l], lay->conv_pout_off[l], lay->conv_koff_off[l])) return rc;
+  }
+  if (h_counts)
+    RSLO_HIP(hipMemcpyAsync(h_counts, cnt, RSLO_PLAN_CNT_WORDS * sizeof(int32_t), hipMemcpyDeviceToHost, st));
   return RSLO_OK;
 }

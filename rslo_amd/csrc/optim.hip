@@ -99,7 +99,8 @@ __global__ __launch_bounds__(OPT_THREADS) void k_opt_adam(const RsloOptTensor *_
   const RsloOptChunk c = chunks[blockIdx.x];
   const RsloOptTensor t = tensors[c.tensor];
   const RsloOptGroup h = hyper.group[t.group];
-  const double bc1 = 1.0 - pow(h.beta1, (double)step), bc2 = 1.0 - pow(h.beta2, (double)step);
+  const float tstep = step + (float)t.step_offset;      // torch.optim.Adam keeps one count per tensor
+  const double bc1 = 1.0 - pow(h.beta1, (double)tstep), bc2 = 1.0 - pow(h.beta2, (double)tstep);
   const double step_size = h.lr / bc1, sqrt_bc2 = sqrt(bc2);
   const float decay = (float)(1.0 - h.weight_decay * h.lr);      // torch._foreach_mul_(params, 1 - wd * lr): fp32 product
   float *__restrict__ p = t.param + c.offset;
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(OPT_THREADS) void k_opt_adam(const RsloOptTensor *_
   }
   for (int i = n4 + threadIdx.x; i < c.count; i += OPT_THREADS)
     adam_elem(p[i], g[i], m[i], v[i], decay, h.beta1, h.beta2, step_size, sqrt_bc2, h.eps);
-  if (c.offset == 0 && threadIdx.x == 0 && t.step) *t.step = step;      // torch keeps the count as a float tensor
+  if (c.offset == 0 && threadIdx.x == 0 && t.step) *t.step = tstep;     // torch keeps the count as a float tensor
 }
 
 extern "C" int rslo_opt_clip_grad_norm(const RsloOptTensor *tensors_dev, const RsloOptChunk *chunks_dev, int n_chunks,

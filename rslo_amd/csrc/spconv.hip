@@ -2044,11 +2044,6 @@ __global__ __launch_bounds__(256) void k_colsum_partial(const float *__restrict_
   }
 }
 
-extern "C" size_t rslo_rulebook_pairs_ws_bytes(int64_t n_rows, int K) {
-  const int64_t n = (n_rows > 0 ? n_rows : 1) * K;
-  return (size_t)n * 8 + rslo_scan_ws_bytes(n) + 512;
-}
-
 extern "C" size_t rslo_spconv_wgrad_pairs_ws_bytes(int64_t n_out, int K, int cin, int cout) {
   const int64_t nch = rslo_cdiv(n_out > 0 ? n_out : 1, WG_MIN_CHUNK);
   return ((size_t)nch * (size_t)K * cin * cout + (size_t)(CS1_MAXBLK + 8) * cout) * sizeof(float);

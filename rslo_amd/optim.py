@@ -21,7 +21,7 @@ CHUNK = 4096            # elements per workgroup (multiple of 4: 16-byte accesse
 MAX_GROUPS = 16
 
 _TENSOR_DT = np.dtype([("param", "<u8"), ("grad", "<u8"), ("exp_avg", "<u8"), ("exp_avg_sq", "<u8"), ("step", "<u8"),
-                       ("group", "<i4"), ("reserved", "<i4")])
+                       ("group", "<i4"), ("step_offset", "<i4")])
 _CHUNK_DT = np.dtype([("tensor", "<i4"), ("count", "<i4"), ("offset", "<i8")])
 
 
@@ -82,32 +82,34 @@ class AdamStepper:
         """Tables over ALL trainable tensors (the decoupled decay touches every one of them; the moment update only those
         that have a gradient in the step at hand)."""
         dev = tensors[0][1].device
-        state = self.opt.state
+        state = self.opt.state      # a defaultdict: read it with .get(), or never-stepped parameters gain empty entries
         with_state = []
         for gi, p in tensors:
-            st = state[p]
-            if len(st) == 0:
+            st = state.get(p)
+            if not st:
                 if p.grad is None:
                     continue
                 self._init_state(p)
+                st = state[p]
             if not (_usable(st["exp_avg"]) and _usable(st["exp_avg_sq"])):
                 return False
             if not (isinstance(st["step"], torch.Tensor) and st["step"].is_cuda and st["step"].dtype == torch.float32):
                 st["step"] = torch.as_tensor(float(st["step"]), dtype=torch.float32, device=p.device)
             with_state.append(p)
-        steps = set()
+        steps = {}
         if with_state:      # one host read, at (re)build time only
-            steps = {int(v) for v in torch.stack([state[p]["step"] for p in with_state]).tolist()}
-        if len(steps) > 1:
-            return False            # tensors that joined later carry their own count: leave those to torch
-        self.step_count = steps.pop() if steps else 0
+            steps = dict(zip((id(p) for p in with_state),
+                             (int(v) for v in torch.stack([state[p]["step"] for p in with_state]).tolist())))
+        # torch counts steps per tensor; the kernel takes ONE count plus a per-tensor offset (tensors that joined later
+        # or skipped steps lag behind)
+        self.step_count = max(steps.values()) if steps else 0
         host = np.zeros(len(tensors), _TENSOR_DT)
         chunks = []
         for i, (gi, p) in enumerate(tensors):
-            st = state[p]
+            st = state.get(p) or {}
             has = len(st) > 0
             host[i] = (p.data_ptr(), 0, st["exp_avg"].data_ptr() if has else 0, st["exp_avg_sq"].data_ptr() if has else 0,
-                       st["step"].data_ptr() if has else 0, gi, 0)
+                       st["step"].data_ptr() if has else 0, gi, steps[id(p)] - self.step_count if has else 0)
             numel = p.numel()
             for off in range(0, numel, CHUNK):
                 chunks.append((i, min(CHUNK, numel - off), off))
@@ -121,7 +123,7 @@ class AdamStepper:
         self._ring = [torch.empty(host.nbytes, dtype=torch.uint8).pin_memory() for _ in range(4)]
         self.grad_ptrs = None
         self.tensors = tensors
-        self.has_state = np.array([len(state[p]) > 0 for _, p in tensors])
+        self.has_state = np.array([bool(state.get(p)) for _, p in tensors])
         self.key = tuple(id(p) for _, p in tensors)
         return True
 
@@ -151,15 +153,14 @@ class AdamStepper:
         if (ptrs % 16).any():
             return False
         late = (ptrs != 0) & ~self.has_state
-        if late.any():
-            if self.step_count > 0:
-                return False        # a tensor receives its first gradient after others were stepped: torch keeps per-tensor counts
+        if late.any():      # first gradient of a tensor: torch starts ITS count at 1 whatever the others have reached
             for i in np.nonzero(late)[0]:
                 p = self.tensors[i][1]
                 self._init_state(p)
                 st = self.opt.state[p]
                 self.host["exp_avg"][i], self.host["exp_avg_sq"][i] = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
                 self.host["step"][i] = st["step"].data_ptr()
+                self.host["step_offset"][i] = -self.step_count
                 self.has_state[i] = True
             self.grad_ptrs = None
         if self.grad_ptrs is None or not np.array_equal(ptrs, self.grad_ptrs):
@@ -187,10 +188,12 @@ class AdamStepper:
         Returns False (nothing done) when this step has to go through torch."""
         from rslo_amd import capi
         if not self._refresh():
+            self.key = None             # torch steps instead and advances the device-side counts: re-read them next time
             return False
         hyper = _Hyper()
         for gi, g in enumerate(self.opt.param_groups):
             if g["weight_decay"] != 0:
+                self.key = None
                 return False            # L2-style decay (grad += wd p) is torch's
             b1, b2 = g["betas"]
             hyper.group[gi] = _Group(float(g["lr"]), float(b1), float(b2), float(g["eps"]),
@@ -199,6 +202,11 @@ class AdamStepper:
         capi._chk(capi.lib().rslo_opt_adam_step(self.tensors_dev.data_ptr(), self.chunks_dev.data_ptr(), self.n_chunks,
                                                 C.byref(hyper), float(self.step_count), capi._stream()),
                   "rslo_opt_adam_step")
+        # a tensor with state but no gradient in this step keeps its count (torch skips it): it lags one more from now
+        # on; the table is re-uploaded when it gets a gradient again (its gradient pointer changes then)
+        skipped = self.has_state & (self.grad_ptrs == 0)
+        if skipped.any():
+            self.host["step_offset"][skipped] -= 1
         return True
 
 

@@ -1,0 +1,243 @@
+"""Host side of rslo_plan_encoder (include/rslo_hip.h): voxelization of all clouds of a step and every rulebook of the
+sparse encoder in ONE foreign call without a host read.
+
+The reference splits this work between its DataLoader workers (spconv VoxelGenerator.generate + merge_second_batch's
+coordinate padding, rslo/data/preprocess.py:493,75-89) and the implicit indice-pair builds inside the first forward
+of SpMiddleFHDWithCov2_3 (rslo/models/middle.py:119-213).  Here both are GPU kernels; issued from Python they were
+~230 launches and 7 blocking reads of data-dependent sizes per step on a helper thread (14-15 ms of thread time per
+step, 3-4 ms of it exposed as a wait in the training loop).  EncoderPlanner issues them through one C call into an
+arena sized by CAPACITIES; the actual sizes arrive through an asynchronous copy into pinned memory and are read when
+the example is picked up, one step later:
+
+    planner = EncoderPlanner(net)                        # derives the level structure from the encoder's modules
+    job = planner.submit(clouds_per_sample)              # one foreign call on the current stream + an event
+    example = planner.finish(job)                        # reads the counts, wraps arena views: example dict + plan
+
+finish() returns the same `example` dict workload.make_example + net.plan_example build (same tensors bit for bit:
+tests/test_gpu_model.py::test_native_plan_equals_python_plan); per-frame tensors are views of one frame-major block,
+so the concatenations of make_example / network_forward disappear as well.
+"""
+import numpy as np
+import torch
+
+from rslo_amd import capi
+
+
+def encoder_levels(middle):
+    """Walk the encoder's SparseSequentials the way their plan() would and return (levels, keys):
+    levels[l] = {"dims", "subm": ks or None, "conv": (ks, stride, pad) or None}; keys[indice_key] = ("subm"|"conv", l).
+    None when the encoder is not a chain (a level with two different strided convs / SubM kernel sizes)."""
+    import spconv
+    levels = [{"dims": [int(d) for d in middle.sparse_shape], "subm": None, "conv": None}]
+    keys = {}
+
+    def walk(seq, lvl):
+        for m in seq._modules.values():
+            if isinstance(m, spconv.SparseSequential):
+                lvl = walk(m, lvl)
+            elif isinstance(m, spconv.SparseConvolution):
+                if lvl is None:
+                    return None
+                if m.inverse:
+                    ent = keys.get(m.indice_key)
+                    if ent is None or ent[0] != "conv":
+                        return None
+                    lvl = ent[1]
+                elif m.subm:
+                    ks = list(m.kernel_size)
+                    if levels[lvl]["subm"] not in (None, ks):
+                        return None
+                    levels[lvl]["subm"] = ks
+                    if m.indice_key is not None:
+                        if keys.get(m.indice_key, ("subm", lvl)) != ("subm", lvl):
+                            return None
+                        keys[m.indice_key] = ("subm", lvl)
+                else:
+                    conv = (list(m.kernel_size), list(m.stride), list(m.padding))
+                    ent = keys.get(m.indice_key) if m.indice_key is not None else None
+                    if ent is not None:
+                        if ent != ("conv", lvl) or levels[lvl]["conv"] != conv:
+                            return None
+                    else:
+                        if levels[lvl]["conv"] is not None:
+                            return None
+                        levels[lvl]["conv"] = conv
+                        if lvl + 1 == len(levels):
+                            levels.append({"dims": capi.conv_out_dims(levels[lvl]["dims"], *conv), "subm": None,
+                                           "conv": None})
+                        if m.indice_key is not None:
+                            keys[m.indice_key] = ("conv", lvl)
+                    lvl = lvl + 1
+        return lvl
+
+    p0 = walk(middle.middle_conv, 0)
+    if p0 is None or walk(middle.middle_conv_tail, p0) is None or walk(middle.middle_cov_deconv, p0) is None:
+        return None
+    if len(levels) > capi.PLAN_MAX_LEVELS:
+        return None
+    return levels, keys
+
+
+class _Job:
+    __slots__ = ("arena", "counts", "lay", "ready", "B", "T", "n_clouds", "with_pairs", "clouds")
+
+
+class EncoderPlanner:
+    def __init__(self, net, max_voxels=None, arenas=4):
+        self.net = net
+        vg = net.voxel_generator
+        self.middle = net.middle_feature_extractor
+        st = encoder_levels(self.middle)
+        if st is None:
+            raise capi.RsloHipError("EncoderPlanner: the encoder is not a chain of levels (use net.plan_example)")
+        self.levels, self.keys = st
+        self.max_voxels = int(max_voxels or vg._max_voxels)
+        self.vg = vg
+        self.n_arenas = int(arenas)
+        self._arenas = []         # [(uint8 CUDA tensor, pinned int32 counts)], handed out round-robin
+        self._next = 0
+        self.fallbacks = 0
+
+    def _spec(self, n_features, with_pairs):
+        sp = capi.EncoderSpec()
+        sp.n_levels = len(self.levels)
+        for j in range(3):
+            sp.dims0[j] = self.levels[0]["dims"][j]
+        for l, lv in enumerate(self.levels):
+            if lv["subm"] is not None:
+                for j in range(3):
+                    sp.subm_ks[l][j] = lv["subm"][j]
+            if lv["conv"] is not None:
+                ks, stv, pd = lv["conv"]
+                for j in range(3):
+                    sp.conv_ks[l][j], sp.conv_stride[l][j], sp.conv_pad[l][j] = ks[j], stv[j], pd[j]
+        sp.want_pairs, sp.want_orders = int(with_pairs), int(capi.ROW_ORDER)
+        vg = self.vg
+        for j in range(6):
+            sp.range6[j] = float(vg._point_cloud_range[j])
+        for j in range(3):
+            sp.vsize3[j] = float(vg._voxel_size[j])
+            sp.grid_xyz[j] = int(vg._grid_size[j])
+        sp.max_points, sp.max_voxels, sp.n_features = vg._max_num_points, self.max_voxels, int(n_features)
+        return sp
+
+    def _arena(self, nbytes, device):
+        """Arenas are reused round-robin: a job's arena is free again after `arenas` further submits (the prefetcher
+        keeps depth + 1 examples alive; 4 arenas cover depth 2)."""
+        if len(self._arenas) < self.n_arenas:
+            ent = [torch.empty((nbytes,), dtype=torch.uint8, device=device),
+                   torch.empty((capi.PLAN_CNT_WORDS,), dtype=torch.int32).pin_memory()]
+            self._arenas.append(ent)
+            return ent
+        ent = self._arenas[self._next % self.n_arenas]
+        self._next += 1
+        if ent[0].numel() < nbytes or ent[0].device != device:
+            ent[0] = torch.empty((nbytes,), dtype=torch.uint8, device=device)
+        return ent
+
+    def submit(self, clouds_per_sample, with_pairs=None):
+        """clouds_per_sample: list (batch) of lists (frames) of CUDA fp32 [P,F] tensors.  Enqueues everything on the
+        current stream and records the `ready` event; no host read."""
+        B, T = len(clouds_per_sample), len(clouds_per_sample[0])
+        flat = [clouds_per_sample[b][t] for t in range(T) for b in range(B)]
+        for p in flat:
+            if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
+                raise capi.RsloHipError("EncoderPlanner.submit: clouds must be contiguous fp32 CUDA tensors")
+        if with_pairs is None:
+            with_pairs = self.net.training
+        spec = self._spec(flat[0].shape[1], with_pairs)
+        lay = capi.plan_encoder_layout(spec, [p.shape[0] for p in flat])
+        arena, counts = self._arena(int(lay.total_bytes), flat[0].device)
+        capi.plan_encoder(spec, lay, flat, B, arena, counts)
+        job = _Job()
+        job.arena, job.counts, job.lay, job.B, job.T, job.n_clouds = arena, counts, lay, B, T, len(flat)
+        job.with_pairs, job.clouds = bool(with_pairs), clouds_per_sample
+        job.ready = torch.cuda.Event()
+        job.ready.record(torch.cuda.current_stream(flat[0].device))
+        return job
+
+    # ------------------------------------------------------------------------------------------------------------
+    def finish(self, job):
+        """Wait for the job's event (host side: it was recorded a step ago), read the counts and wrap the arena:
+        returns the example dict with "sparse_plan" attached.  A capacity overflow (a strided level with more sites
+        than its input level: not a LiDAR-shaped cloud) falls back to the exact-size Python planner."""
+        import spconv
+        job.ready.synchronize()
+        cnt = job.counts.numpy()
+        if int(cnt[capi.PLAN_CNT_OVERFLOW]) != 0:
+            self.fallbacks += 1
+            from rslo_amd import workload
+            ex = workload.make_example(self.net, [[c for c in s] for s in job.clouds], self.max_voxels,
+                                       job.arena.device)
+            return self.net.plan_example(ex)
+        lay, A, B, T, n = job.lay, job.arena, job.B, job.T, job.n_clouds
+        L = len(self.levels)
+        rows = [int(cnt[capi.PLAN_CNT_ROWS + l]) for l in range(L)]
+        boff = [[int(v) for v in cnt[capi.PLAN_CNT_BOFF + l * (capi.PLAN_MAX_CLOUDS + 1):
+                                     capi.PLAN_CNT_BOFF + l * (capi.PLAN_MAX_CLOUDS + 1) + n + 1]] for l in range(L)]
+        vg = self.vg
+        Tp, F = vg._max_num_points, job.clouds[0][0].shape[1]
+        N0 = rows[0]
+
+        def i32(off, count, shape=None):
+            t = A[int(off):int(off) + 4 * int(count)].view(torch.int32)
+            return t if shape is None else t.view(shape)
+
+        voxels = A[int(lay.voxels_off):int(lay.voxels_off) + 4 * N0 * Tp * F].view(torch.float32).view(N0, Tp, F)
+        num = i32(lay.num_points_off, N0)
+        cframe = i32(lay.coords_frame_off, N0 * 4, (N0, 4))
+        ex = {"voxels": [], "num_points": [], "coordinates": [], "num_voxels": []}
+        nvox = [int(v) for v in cnt[capi.PLAN_CNT_NVOX:capi.PLAN_CNT_NVOX + n]]
+        for t in range(T):
+            r0, r1 = boff[0][t * B], boff[0][(t + 1) * B]
+            ex["voxels"].append(voxels[r0:r1])
+            ex["num_points"].append(num[r0:r1])
+            ex["coordinates"].append(cframe[r0:r1])
+            ex["num_voxels"].append(torch.tensor(nvox[t * B:(t + 1) * B], dtype=torch.int64).reshape(B, 1))
+        npairs = T * (T - 1) // 2
+        dev = A.device
+        ex["icp_odometry"] = torch.zeros(B * npairs, 7, device=dev)
+        ex["tq_maps"] = [torch.zeros(B * npairs, 7, 96, 176, device=dev)]
+        ex["_frame_major"] = (voxels, num)          # all frames in one block: one VFE launch, no concatenation
+
+        # ---- the plan: site indices, rulebooks, orders, pair lists as arena views
+        idx = []
+        for l in range(L):
+            coords = i32(lay.coords_off[l], rows[l] * 4, (rows[l], 4))
+            hc = int(lay.hash_cap[l])
+            si = capi.SiteIndex.from_parts(coords, n, list(lay.dims[l]), i32(lay.keys_off[l], hc), i32(lay.vals_off[l], hc),
+                                           hc)
+            si.subm_cache = {}
+            si.batch_offs = boff[l]
+            si.batch_offs_dev = i32(lay.counts_off + 4 * (capi.PLAN_CNT_BOFF + l * (capi.PLAN_MAX_CLOUDS + 1)), n + 1)
+            idx.append(si)
+        x = spconv.SparseConvTensor(None, idx[0].coords, self.middle.sparse_shape, n, index=idx[0])
+        rbs_conv = {}
+        for l, lv in enumerate(self.levels):
+            if lv["subm"] is not None:
+                ks = lv["subm"]
+                K = ks[0] * ks[1] * ks[2]
+                nbr = i32(lay.subm_nbr_off[l], rows[l] * K, (rows[l], K))
+                rb = spconv.Rulebook("subm", nbr, None, None, None, ks, [1, 1, 1], None)
+                if job.with_pairs:
+                    cap = int(lay.cap_rows[l]) * K
+                    rb._pairs = (i32(lay.subm_pin_off[l], cap), i32(lay.subm_pout_off[l], cap),
+                                 i32(lay.subm_koff_off[l], K + 1))
+                idx[l].subm_cache[tuple(ks)] = rb
+            if lv["conv"] is not None:
+                ks, stv, pd = lv["conv"]
+                K = ks[0] * ks[1] * ks[2]
+                nbr = i32(lay.conv_nbr_off[l], rows[l + 1] * K, (rows[l + 1], K))
+                nbrT = i32(lay.conv_nbrT_off[l], rows[l] * K, (rows[l], K))
+                rb = spconv.Rulebook("conv", nbr, nbrT, idx[l], idx[l + 1], ks, stv, pd)
+                rb._orders["nbrT"] = i32(lay.conv_order_off[l], rows[l]) if capi.ROW_ORDER else None
+                if job.with_pairs:
+                    cap = int(lay.cap_rows[l + 1]) * K
+                    rb._pairs = (i32(lay.conv_pin_off[l], cap), i32(lay.conv_pout_off[l], cap),
+                                 i32(lay.conv_koff_off[l], K + 1))
+                rbs_conv[l] = rb
+        for key, (kind, l) in self.keys.items():
+            x.indice_dict[key] = rbs_conv[l] if kind == "conv" else idx[l].subm_cache[tuple(self.levels[l]["subm"])]
+        ex["sparse_plan"] = x
+        ex["_plan_job"] = job            # keeps the arena referenced while the example is alive
+        return ex

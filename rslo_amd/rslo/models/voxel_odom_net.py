@@ -235,7 +235,13 @@ class UnVoxelOdomNetICP3(nn.Module):
         assert len(voxels) == len(num_points) == len(coors), "The lengths should be same."
         T = len(voxels)
         self.start_timer("voxel_feature_extractor")
-        voxel_features = [self.voxel_feature_extractor(voxels[t], num_points[t], coors[t]) for t in range(T)]
+        fm = example.get("_frame_major") if example is not None and voxels is example.get("voxels") else None
+        if fm is not None:      # rslo_amd.plan.EncoderPlanner: the frames are views of one block -> one launch, no cat
+            vf_all = self.voxel_feature_extractor(fm[0], fm[1], None)
+            voxel_features = list(vf_all.split([v.shape[0] for v in voxels], dim=0))
+        else:
+            voxel_features = [self.voxel_feature_extractor(voxels[t], num_points[t], coors[t]) for t in range(T)]
+            vf_all = None
         self.end_timer("voxel_feature_extractor")
 
         self.start_timer("middle forward")
@@ -243,7 +249,8 @@ class UnVoxelOdomNetICP3(nn.Module):
         plan = example.get("sparse_plan") if example is not None else None
         if plan is None:
             plan = self.middle_feature_extractor.plan(self._merge_coords(coors, batch_size), T * batch_size)
-        bev, cov = self.middle_feature_extractor(torch.cat(voxel_features, 0), plan.indices, T * batch_size, plan=plan)
+        bev, cov = self.middle_feature_extractor(torch.cat(voxel_features, 0) if vf_all is None else vf_all, plan.indices,
+                                                 T * batch_size, plan=plan)
         exchange = self.__dict__.get("_grad_exchange")      # data parallel: the head's gradient bucket leaves when the
         if exchange is not None:                            # gradient of the BEV map is complete (distributed_utils)
             exchange.watch(bev)

@@ -32,64 +32,102 @@ def gradients_multiply(model, multiplier=1):
         torch._foreach_mul_(grads, multiplier)
 
 
-_GRAD_SET_RECHECK = 100      # calls between two agreements on the set of parameters that carry gradients
+_HOST_GROUP = {}
+
+
+def _host_group():
+    """Group for HOST-side agreements (one flag per call, a presence vector when the flag is up).  Decisions that shape
+    a collective -- which tensors a bucket holds -- must be identical on every rank and are taken on the host, so they
+    travel over a CPU backend: the default group itself when it is gloo, else a gloo group created next to it on first
+    use (all ranks reach this point together: they call average_gradients / finish() the same number of times).  A GPU
+    all-reduce of the flag would have to be READ on the host, i.e. drain the training stream every step.  Returns
+    None when no CPU group can be had; the agreement then falls back to the default group plus a host read."""
+    if dist.get_backend() == "gloo":
+        return dist.group.WORLD
+    if "g" not in _HOST_GROUP:
+        try:
+            _HOST_GROUP["g"] = dist.new_group(backend="gloo")
+        except Exception:
+            _HOST_GROUP["g"] = None
+    return _HOST_GROUP["g"]
+
+
+def _host_max(values, device):
+    """Element-wise MAX of a small int list over all ranks, result on the host."""
+    g = _host_group()
+    if g is not None:
+        t = torch.tensor(values, dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=g)
+        return t.tolist()
+    t = torch.tensor(values, dtype=torch.int32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return t.tolist()
 
 
 def _agreed_grad_set(model, params):
-    """Indices (into `params`) of the parameters that receive a gradient on ANY rank, agreed by one small MAX
-    all-reduce on the first call and every _GRAD_SET_RECHECK calls after it (all ranks count calls alike).  The
-    reference's per-parameter loop (distributed_utils.py:62-75) stays aligned because its frozen torch zero-fills
-    gradients; here `zero_grad(set_to_none=True)` recomputes the non-None set from each step's graph, and a
-    data-dependent branch (an empty mask on one rank) would otherwise change the bucket size on that rank only and
-    hang the collective."""
-    st = model.__dict__.setdefault("_rslo_grad_set", {"calls": 0, "idx": None})
-    if st["idx"] is None or st["calls"] % _GRAD_SET_RECHECK == 0 or st.get("n") != len(params):
-        dev = params[0].device
-        have = torch.tensor([0.0 if p.grad is None else 1.0 for p in params], device=dev)
-        dist.all_reduce(have, op=dist.ReduceOp.MAX)
-        st["idx"] = [i for i, h in enumerate(have.tolist()) if h > 0]
+    """Indices (into `params`) of the parameters that take part in the gradient exchange: every parameter that has
+    received a gradient on ANY rank so far.  The set only grows.  Each call exchanges ONE flag over the host group
+    ("I hold a gradient outside the set" / "I have no set yet"); when any rank raises it, all ranks re-agree in the
+    same call through a presence vector -- so a parameter that first gets a gradient late (a loss branch that switches
+    on with global_step, a mask that was empty on every rank when the set was first agreed) joins the bucket on all
+    ranks at once instead of hanging the collective or being dropped.  The reference's per-parameter loop
+    (distributed_utils.py:62-75) stays aligned because its frozen torch zero-fills gradients; here
+    `zero_grad(set_to_none=True)` recomputes the non-None set from each step's graph, and a rank whose graph skips a
+    parameter of the set contributes zeros."""
+    st = model.__dict__.setdefault("_rslo_grad_set", {"idx": None, "n": None})
+    fresh = st["idx"] is None or st["n"] != len(params)
+    chosen = set() if fresh else set(st["idx"])
+    stray = any(p.grad is not None and i not in chosen for i, p in enumerate(params))
+    dev = params[0].device
+    if _host_max([1 if (fresh or stray) else 0], dev)[0]:
+        have = _host_max([1 if (p.grad is not None or i in chosen) else 0 for i, p in enumerate(params)], dev)
+        st["idx"] = [i for i, h in enumerate(have) if h > 0]
         st["n"] = len(params)
-    st["calls"] += 1
     return st["idx"]
+
+
+def _reduce_bucket(sel, mean, async_op=False):
+    """Flat all-reduce of the gradients of `sel` (zeros where this rank has none)."""
+    grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in sel]
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    work = dist.all_reduce(flat, async_op=async_op)
+    return grads, flat, work
+
+
+def _scatter_bucket(sel, grads, flat, mean):
+    if mean:
+        flat.div_(dist.get_world_size())
+    torch._foreach_copy_(grads, [c.view_as(g) for c, g in zip(flat.split([g.numel() for g in grads]), grads)])
+    for p, g in zip(sel, grads):
+        if p.grad is None:
+            p.grad = g
 
 
 def average_gradients(model, bucket=True, mean=False):
     """All-reduce the gradients of `model` across ranks as one flat fp32 bucket (sum; mean=True divides by the
     world size).  The bucket covers the agreed set of gradient-carrying parameters (same size on every rank by
-    construction); a rank whose graph skipped one of them this step contributes zeros and receives the sum; a gradient
-    OUTSIDE the agreed set raises instead of being dropped silently."""
+    construction, see _agreed_grad_set); a rank whose graph skipped one of them this step contributes zeros and
+    receives the sum."""
     if not _active():
         return
     params = [p for p in model.parameters() if p.requires_grad]
     if not params:
         return
     idx = _agreed_grad_set(model, params)
-    chosen = set(idx)
-    stray = [i for i, p in enumerate(params) if p.grad is not None and i not in chosen]
-    if stray:
-        raise RuntimeError("average_gradients: %d parameter(s) received a gradient on this rank that no rank had when the "
-                           "gradient set was agreed (data-dependent graph?); call again after "
-                           "model.__dict__.pop('_rslo_grad_set')" % len(stray))
     if not idx:
         return
-    world = dist.get_world_size()
     sel = [params[i] for i in idx]
-    grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in sel]
     if not bucket:
-        for p, g in zip(sel, grads):
+        world = dist.get_world_size()
+        for p in sel:
+            g = p.grad if p.grad is not None else torch.zeros_like(p)
             dist.all_reduce(g)
             if mean:
                 g.div_(world)
             p.grad = g
         return
-    flat = torch.cat([g.reshape(-1) for g in grads])
-    dist.all_reduce(flat)
-    if mean:
-        flat.div_(world)
-    torch._foreach_copy_(grads, [c.view_as(g) for c, g in zip(flat.split([g.numel() for g in grads]), grads)])
-    for p, g in zip(sel, grads):
-        if p.grad is None:
-            p.grad = g
+    grads, flat, _ = _reduce_bucket(sel, mean)
+    _scatter_bucket(sel, grads, flat, mean)
 
 
 class OverlappedGradientExchange:
@@ -101,7 +139,11 @@ class OverlappedGradientExchange:
     (`net.odom_predictor`): when it fires, the gradients of that module's parameters (the agreed subset) go out as ONE
     flat asynchronous all-reduce; `finish()` -- called where the driver calls average_gradients -- waits for it and
     reduces the remaining tensors as a second flat bucket.  Same sums as average_gradients (bit-identical on two ranks:
-    each element is still the sum of the same two numbers).  xGMI rings are per-link bound: two large messages, not 213."""
+    each element is still the sum of the same two numbers).  xGMI rings are per-link bound: two large messages, not 213.
+
+    The SEQUENCE of collectives is a function of the agreed set alone, never of one rank's graph: whenever a set
+    exists, every rank sends [early subset, rest] -- from the hook if it fires, else from finish() -- with zeros for
+    gradients that rank does not hold (a branch of the head skipped on one rank, a loss that did not reach the head)."""
 
     def __init__(self, model, early, mean=False, module_hook=True):
         """module_hook=False: the caller marks the boundary itself with watch(tensor) every forward (modules whose inputs
@@ -121,26 +163,26 @@ class OverlappedGradientExchange:
             tensor.register_hook(lambda g: self._on_early_done(None, None, None))
         return tensor
 
-    def _bucket(self, params):
-        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in params]
-        flat = torch.cat([g.reshape(-1) for g in grads])
-        return grads, flat
+    def _early_subset(self, params):
+        """The early bucket's tensors under the set agreed by EARLIER finish() calls (identical on every rank); empty
+        before the first agreement -- at hook time the later modules have no gradients yet, so an agreement taken
+        there would be wrong, and the first step goes out in one piece at finish()."""
+        st = self.model.__dict__.get("_rslo_grad_set")
+        if not st or st.get("idx") is None or st.get("n") != len(params):
+            return []
+        return [params[i] for i in st["idx"] if id(params[i]) in self.early_ids]
+
+    def _launch_early(self, params):
+        sel = self._early_subset(params)
+        if sel:
+            # the engine runs AccumulateGrad nodes ahead of everything else that is ready, so at the hook every gradient
+            # this rank will produce for the early module exists; a missing one is absent on this rank: zeros
+            grads, flat, work = _reduce_bucket(sel, self.mean, async_op=True)
+            self.pending = (sel, grads, flat, work)
 
     def _on_early_done(self, module, grad_input, grad_output):
-        if not _active() or self.pending is not None:
-            return None
-        params = [p for p in self.model.parameters() if p.requires_grad]
-        # only a set agreed by an earlier finish() is used here: at this point of backward the later modules have no
-        # gradients yet, so an agreement taken now would be wrong (the first step goes out in one piece at finish())
-        st = self.model.__dict__.get("_rslo_grad_set")
-        if not st or st.get("idx") is None or st.get("n") != len(params) or st["calls"] % _GRAD_SET_RECHECK == 0:
-            return None
-        sel = [params[i] for i in st["idx"] if id(params[i]) in self.early_ids]
-        if not sel or any(p.grad is None for p in sel):
-            return None         # a gradient of this module is still to come (or absent on this rank): all at finish()
-        grads, flat = self._bucket(sel)
-        work = dist.all_reduce(flat, async_op=True)
-        self.pending = (sel, grads, flat, work)
+        if _active() and self.pending is None:
+            self._launch_early([p for p in self.model.parameters() if p.requires_grad])
         return None
 
     def finish(self):
@@ -148,33 +190,18 @@ class OverlappedGradientExchange:
         if not _active():
             return
         params = [p for p in self.model.parameters() if p.requires_grad]
-        idx = _agreed_grad_set(self.model, params)
-        chosen = set(idx)
-        stray = [i for i, p in enumerate(params) if p.grad is not None and i not in chosen]
-        if stray:
-            raise RuntimeError("OverlappedGradientExchange: %d parameter(s) received a gradient outside the agreed set"
-                               % len(stray))
-        world = dist.get_world_size()
-        done = set()
+        if self.pending is None:        # the hook did not fire on this rank (its loss never reached the early module):
+            self._launch_early(params)  # the other ranks sent the early bucket, this one joins it now
         pend, self.pending = self.pending, None
-        if pend is not None:
-            done = {id(p) for p in pend[0]}
+        idx = _agreed_grad_set(self.model, params)
+        done = {id(p) for p in pend[0]} if pend is not None else set()
         rest = [params[i] for i in idx if id(params[i]) not in done]
-        buckets = []
         if rest:
-            grads, flat = self._bucket(rest)
-            dist.all_reduce(flat)
-            buckets.append((rest, grads, flat))
+            grads, flat, _ = _reduce_bucket(rest, self.mean)
+            _scatter_bucket(rest, grads, flat, self.mean)
         if pend is not None:
             pend[3].wait()
-            buckets.append(pend[:3])
-        for sel, grads, flat in buckets:
-            if self.mean:
-                flat.div_(world)
-            torch._foreach_copy_(grads, [c.view_as(g) for c, g in zip(flat.split([g.numel() for g in grads]), grads)])
-            for p, g in zip(sel, grads):
-                if p.grad is None:
-                    p.grad = g
+            _scatter_bucket(pend[0], pend[1], pend[2], self.mean)
 
 
 def broadcast_params(model, src=0):

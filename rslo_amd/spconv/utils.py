@@ -5,15 +5,15 @@ rslo/builder/voxel_builder.py:83-94 (extra block-filtering kwargs accepted; with
 height_threshold = -1 the filter keeps everything, which is the only mode implemented).
 
 `generate(points, max_voxels)` takes
-  * a CUDA tensor [P,F]  -> returns CUDA tensors (the fast path: voxelization stays on the GPU), or
-  * a numpy array [P,F]  -> round-trips through the GPU and returns numpy arrays like the reference.
-There is no CPU implementation here.
+  * a CUDA tensor [P,F]  -> voxelized by rslo_voxelize on the GPU, returns CUDA tensors (the training path:
+                            rslo_amd.workload.ExamplePrefetcher / rslo_plan_encoder keep the clouds resident), or
+  * a numpy array [P,F]  -> voxelized in HOST memory by librslo_host.so (include/rslo_host.h), returns numpy arrays.
 
-Worker processes.  The reference voxelizes on the CPU inside forked DataLoader workers (rslo/data/preprocess.py:493).
-A forked child of a process that has already initialised HIP cannot use the device, so the numpy path REFUSES there
-with an explanatory error instead of hanging in the runtime.  Supported arrangements: (a) hand the raw points to the
-training process and voxelize there on a side stream (rslo_amd.workload.ExamplePrefetcher -- what bench.py does);
-(b) DataLoader(..., multiprocessing_context="spawn"), each worker then owns a HIP context of its own.
+Where an input lives decides where it is voxelized; nothing is moved behind the caller's back.  The numpy face is what
+the reference's DataLoader workers call (rslo/data/preprocess.py:493): they are forked (train_hdf5.py:549-553), and a
+forked child of a process that has initialised HIP cannot use the device -- so that face is plain C without HIP /
+torch, re-entrant and fork-safe, and train_hdf5.py's loaders run unchanged.  Both faces give the same bits
+(tests/test_gpu_kernels.py::test_host_voxelizer_equals_device_voxelizer).
 """
 import numpy as np
 import torch
@@ -41,24 +41,15 @@ class VoxelGenerator:
 
     def generate(self, points, max_voxels=None):
         maxv = int(max_voxels or self._max_voxels)
-        as_numpy = isinstance(points, np.ndarray)
-        if as_numpy:
-            if torch.cuda._is_in_bad_fork():
-                raise RuntimeError(
-                    "VoxelGenerator.generate(numpy) was called in a forked child of a process that had already "
-                    "initialised the GPU; HIP cannot be used there.  Start DataLoader workers with "
-                    "multiprocessing_context='spawn', or pass the points to the training process and voxelize there "
-                    "(rslo_amd.workload.ExamplePrefetcher).")
-            pts = torch.from_numpy(np.ascontiguousarray(points, dtype=np.float32)).cuda()
-        else:
-            pts = points.contiguous().float()
+        if isinstance(points, np.ndarray):
+            from rslo_amd import hostlib
+            return hostlib.voxelize(points, self._point_cloud_range, self._voxel_size, self._grid_size,
+                                    self._max_num_points, maxv)
+        pts = points.contiguous().float()
         vox, coords, num, nvox = capi.voxelize(pts, self._point_cloud_range, self._voxel_size, self._grid_size,
                                                self._max_num_points, maxv)
         M = int(nvox.item())
-        vox, coords, num = vox[:M], coords[:M], num[:M]
-        if as_numpy:
-            return vox.cpu().numpy(), coords.cpu().numpy(), num.cpu().numpy()
-        return vox, coords, num
+        return vox[:M], coords[:M], num[:M]
 
     def generate_many(self, clouds, max_voxels=None):
         """Voxelize several CUDA clouds with ONE host read of the voxel counts (generate() syncs per cloud).

@@ -70,7 +70,11 @@ def _to_host(obj):
     if isinstance(obj, torch.Tensor):
         return obj.detach().cpu()
     if isinstance(obj, dict):
-        return type(obj)((k, _to_host(v)) for k, v in obj.items())
+        out = type(obj)((k, _to_host(v)) for k, v in obj.items())
+        meta = getattr(obj, "_metadata", None)      # module.state_dict(): per-module version info, an ATTRIBUTE of the
+        if meta is not None:                        # OrderedDict -- the reference saves model.cpu().state_dict() with it
+            out._metadata = meta
+        return out
     if isinstance(obj, (list, tuple)):
         return type(obj)(_to_host(v) for v in obj)
     return obj

@@ -80,12 +80,22 @@ class ExamplePrefetcher:
     is not recycled by the side stream while still in use."""
 
     def __init__(self, net, max_voxels=synthetic.MAX_VOXELS, device="cuda", plan=True, depth=1, workers=1):
+        import os
         import queue
         import threading
         device = torch.device(device)
         if device.index is None:
             device = torch.device("cuda", torch.cuda.current_device())
         self.net, self.max_voxels, self.device, self.plan = net, max_voxels, device, plan
+        # native planner (rslo_plan_encoder): voxelization + all rulebooks in one foreign call without a host read; the
+        # example is assembled from the arena in get().  RSLO_NATIVE_PLAN=0 keeps the Python-issued form (A/B runs).
+        self.planner = None
+        if plan and os.environ.get("RSLO_NATIVE_PLAN", "1") != "0":
+            from rslo_amd import plan as native_plan
+            try:
+                self.planner = native_plan.EncoderPlanner(net, max_voxels, arenas=max(4, int(depth) + 3))
+            except Exception:      # an encoder that is not a chain of levels: the Python planner handles it
+                self.planner = None
         # depth = examples prepared ahead of the one in use: submit() `depth` times before the first get().  With 2 the
         # example of step i+1 is already finished when step i ends, so a late helper thread no longer stalls the step.
         # workers = helper threads, each with its own side stream: one job is a chain of ~7 host reads of data-dependent
@@ -99,6 +109,13 @@ class ExamplePrefetcher:
         self._results = {}          # seq -> (example, ready event, error)
         self._keep = {}             # seq -> example, until the training stream is done with it
         self._next_submit = self._next_get = 0
+        self._done_ring = []
+        # get() lets the issuing thread run at most `host_lead` forward passes ahead of the GPU (a SLEEPING wait on the
+        # event submit() recorded behind an earlier forward).  Nothing else bounds it once the plan needs no host read,
+        # and a host that fills the launch queue spins inside hipLaunchKernel instead.  0 = unbounded.
+        self.host_lead = int(os.environ.get("RSLO_HOST_LEAD", "1"))
+        self._lead_ring = []
+        self.lead_wait_seconds = self.plan_wait_seconds = 0.0
         self.cpu_seconds, self.jobs = 0.0, 0
         # Several Python threads issue GPU work here.  With the interpreter's default 5 ms switch interval a helper can
         # hold the lock for a third of a step while the training thread's queue runs dry; 0.2 ms keeps all streams
@@ -129,22 +146,31 @@ class ExamplePrefetcher:
             seq, clouds, prev_done = job
             c0 = time.thread_time()
             try:
-                if prev_done is not None:
-                    prev_done.synchronize()      # the training stream has issued (and finished) everything up to the
-                with self._cv:                   # forward of step seq - depth: older examples are no longer read
-                    for old in [k for k in self._keep if k <= seq - self.depth - 1]:
-                        del self._keep[old]
-                with torch.cuda.stream(stream):
-                    ex = make_example(self.net, clouds, self.max_voxels, self.device)
-                    if self.plan:
-                        self.net.plan_example(ex)
-                    ready = torch.cuda.Event()
-                    ready.record(stream)
+                if self.planner is not None:
+                    with torch.cuda.stream(stream):
+                        if prev_done is not None:     # arena reuse: ordered behind the training stream on the GPU
+                            stream.wait_event(prev_done)
+                        cl = [[c if torch.is_tensor(c) else torch.from_numpy(c) for c in s] for s in clouds]
+                        cl = [[c.to(self.device, torch.float32).contiguous() for c in s] for s in cl]
+                        ex = self.planner.submit(cl)          # a job: becomes the example in get()
+                    ready = ex.ready
+                else:
+                    if prev_done is not None:
+                        prev_done.synchronize()  # the training stream has issued (and finished) everything up to the
+                    with self._cv:               # forward of step seq - depth: older examples are no longer read
+                        for old in [k for k in self._keep if k <= seq - self.depth - 1]:
+                            del self._keep[old]
+                    with torch.cuda.stream(stream):
+                        ex = make_example(self.net, clouds, self.max_voxels, self.device)
+                        if self.plan:
+                            self.net.plan_example(ex)
+                        ready = torch.cuda.Event()
+                        ready.record(stream)
                 res = (ex, ready, None)
             except Exception as e:      # surface in get()
                 ex, res = None, (None, None, e)
             with self._cv:
-                if ex is not None:
+                if ex is not None and self.planner is None:
                     self._keep[seq] = ex
                 self._results[seq] = res
                 self.cpu_seconds += time.thread_time() - c0
@@ -152,8 +178,20 @@ class ExamplePrefetcher:
                 self._cv.notify_all()
 
     def submit(self, clouds):
-        done = torch.cuda.Event()
+        done = torch.cuda.Event(blocking=True)
         done.record(torch.cuda.current_stream(self.device))
+        self._lead_ring.append(done)
+        del self._lead_ring[:-(self.host_lead + 2)]
+        if self.planner is not None:
+            # Arena reuse is the only thing a native-plan job has to wait for.  Job j writes arena j mod A, last read by
+            # the step that consumed job j - A; the event of submit j - (A - 1 - depth) was recorded behind the forward
+            # of the step AFTER that one, so it covers its backward -- and it is `A - 1 - depth` (= 2) steps old: the
+            # GPU has passed it, the job starts at once and has depth steps of GPU time before anyone needs it.
+            # (Waiting on the event of THIS submit holds every job back until the current forward has drained on the GPU.)
+            self._done_ring.append(done)
+            lag = self.planner.n_arenas - 1 - self.depth
+            done = self._done_ring[-1 - lag] if len(self._done_ring) > lag else None
+            del self._done_ring[:-(lag + 1)]
         self._in.put((self._next_submit, clouds, done))
         self._next_submit += 1
 
@@ -167,6 +205,15 @@ class ExamplePrefetcher:
             ex, ready, err = self._results.pop(seq)
         if err is not None:
             raise err
+        import time
+        t0 = time.perf_counter()
+        if self.host_lead > 0 and len(self._lead_ring) >= self.host_lead:
+            self._lead_ring[-self.host_lead].synchronize()
+        t1 = time.perf_counter()
+        self.lead_wait_seconds += t1 - t0        # the issuing thread held back behind the GPU: slack, not a stall
+        if self.planner is not None:
+            ex = self.planner.finish(ex)        # host wait on an event recorded a step ago, then arena views
+        self.plan_wait_seconds += time.perf_counter() - t1   # the plan itself was late / assembling the example
         torch.cuda.current_stream(self.device).wait_event(ready)
         return ex
 

@@ -171,14 +171,18 @@ def _uneven_worker(rank, world, port, q):
     average_gradients(net)
     out["s2_a"] = net.a.weight.grad.clone().numpy()
     out["s2_b"] = net.b.weight.grad.clone().numpy()
-    # step 3: a gradient outside the agreed set must raise on the rank that has it, not hang / be dropped
+    # step 3: a parameter outside the agreed set receives its FIRST gradient, on one rank only: both ranks re-agree in
+    # the same call (one flag over the host group) and reduce it -- no raise, no hang, nothing dropped
     net.zero_grad(set_to_none=True)
     (net(x, True).sum() + (net.never(x).sum() if rank == 0 else 0.0)).backward()
-    try:
-        average_gradients(net)
-        out["s3"] = "ok"
-    except RuntimeError as e:
-        out["s3"] = "raised" if "agreed" in str(e) else str(e)
+    average_gradients(net)
+    out["s3_never"] = net.never.weight.grad.clone().numpy()
+    out["s3_a"] = net.a.weight.grad.clone().numpy()
+    # step 4: the set is sticky -- `never` stays in the bucket although no rank uses it now (zeros, not None)
+    net.zero_grad(set_to_none=True)
+    net(x, True).sum().backward()
+    average_gradients(net)
+    out["s4_never"] = net.never.weight.grad.clone().numpy()
     q.put((rank, out))
     dist.destroy_process_group()
 
@@ -203,7 +207,10 @@ def test_gradient_bucket_keeps_its_size_when_one_rank_skips_a_branch():
     np.testing.assert_allclose(r0["s2_a"], np.full((2, 3), 3.0))
     np.testing.assert_array_equal(r0["s2_b"], r1["s2_b"])
     np.testing.assert_allclose(r0["s2_b"], np.full((2, 3), 1.0))         # only rank 0 (x = 1) used the branch
-    assert r0["s3"] == "raised"
+    np.testing.assert_array_equal(r0["s3_never"], r1["s3_never"])
+    np.testing.assert_allclose(r0["s3_never"], np.full((2, 3), 1.0))     # rank 0's gradient (x = 1) + rank 1's zeros
+    np.testing.assert_allclose(r0["s3_a"], np.full((2, 3), 3.0))
+    np.testing.assert_allclose(r1["s4_never"], np.zeros((2, 3)))
 
 
 def _overlap_worker(rank, world, port, q, rank_mode):
@@ -259,3 +266,74 @@ def test_overlapped_gradient_exchange_equals_average_gradients(mode):
     for _, out in res:
         assert all(same and cleared for _, same, cleared in out), out
         assert [fired for fired, _, _ in out] == [False, True, True], out     # step 0 agrees on the set, then it overlaps
+
+
+def _asym_overlap_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import copy
+    from rslo.utils.distributed_utils import OverlappedGradientExchange, average_gradients
+    torch.manual_seed(5)
+    net = torch.nn.Module()
+    net.encoder = torch.nn.Linear(6, 8)
+    net.head = torch.nn.Module()
+    net.head.main, net.head.side = torch.nn.Linear(8, 3), torch.nn.Linear(8, 3)
+    ref = copy.deepcopy(net)
+    ex = OverlappedGradientExchange(net, net.head, mean=True, module_hook=False)
+
+    def fwd(m, x, mode, watch):
+        f = m.encoder(x)
+        if mode == "no_head":                  # this rank's loss never reaches the watched tensor: its hook does not fire
+            if watch:
+                ex.watch(m.encoder(x))
+            return f.square().sum()
+        if watch:
+            f = ex.watch(f)
+        y = m.head.main(f)
+        if mode == "both":
+            y = y + m.head.side(f)
+        return y.square().sum()
+
+    # step 0 agrees on the set (both branches everywhere); step 1: rank 1 skips head.side (rank 0 sent
+    # [early, rest], rank 1 one bucket); step 2: rank 1's loss skips the head altogether; step 3: everything again
+    plan = [("both", "both"), ("both", "main"), ("both", "no_head"), ("both", "both")]
+    out = []
+    for step, modes in enumerate(plan):
+        x = torch.randn(5, 6, generator=torch.Generator().manual_seed(100 * step + rank))
+        for m in (net, ref):
+            m.zero_grad(set_to_none=True)
+            fwd(m, x, modes[rank], m is net).backward()
+        fired = ex.pending is not None
+        ex.finish()
+        average_gradients(ref, mean=True)
+        same = all((a.grad is None and b.grad is None) or (a.grad is not None and b.grad is not None
+                                                           and torch.equal(a.grad, b.grad))
+                   for a, b in zip(net.parameters(), ref.parameters()))
+        out.append((fired, same, float(net.head.side.weight.grad.abs().sum())))
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overlapped_exchange_is_rank_symmetric_when_one_rank_skips_part_of_the_early_module():
+    """the early bucket's launch must not depend on one rank's graph.  A rank that lacks a gradient of
+    the early module (or whose backward never reaches it) still takes part in the same two collectives with zeros;
+    results equal average_gradients on both ranks and the two ranks hold identical gradients."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=_asym_overlap_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, out in res:
+        assert all(same for _, same, _ in out), (rank, out)
+    # the hook fired wherever the loss reached the head; rank 1 joined the early bucket from finish() at step 2
+    assert [f for f, _, _ in res[0][1]] == [False, True, True, True]
+    assert [f for f, _, _ in res[1][1]] == [False, True, False, True]
+    assert [g for _, _, g in res[0][1]] == [g for _, _, g in res[1][1]]

@@ -65,6 +65,22 @@ def test_voxelize_kitti_shaped_scan_and_vfe(hip):
     _vox_both(hip, pts, S.PC_RANGE, S.VOXEL_SIZE, S.MAX_POINTS_PER_VOXEL, 20000)
 
 
+def test_host_voxelizer_equals_device_voxelizer(hip):
+    """The two faces of spconv.utils.VoxelGenerator.generate -- numpy in (librslo_host.so, what forked DataLoader
+    workers call) and CUDA tensor in (rslo_voxelize) -- return the same bits on full scans: 64-ring scan, the 20000-voxel
+    cap (the loop's break), the dense 128-ring scan at 0.1 m voxels (C5)."""
+    from spconv.utils import VoxelGenerator
+    for pts, vs, maxv in ((S.scan(), S.VOXEL_SIZE, S.MAX_VOXELS), (S.scan(), S.VOXEL_SIZE, 20000),
+                          (S.scan(n_el=128), [0.1, 0.1, 0.1], 1 << 18)):
+        vg = VoxelGenerator(vs, S.PC_RANGE, S.MAX_POINTS_PER_VOXEL, maxv)
+        hv, hc, hn = vg.generate(pts, maxv)
+        assert isinstance(hv, np.ndarray)
+        dv, dc, dn = vg.generate(torch.from_numpy(pts).cuda(), maxv)
+        assert dv.is_cuda
+        assert hv.shape == tuple(dv.shape) and len(hc) > 19000
+        assert (hv == dv.cpu().numpy()).all() and (hc == dc.cpu().numpy()).all() and (hn == dn.cpu().numpy()).all()
+
+
 # ------------------------------------------------------------------------------- rulebooks
 def _encoder_levels(hip, coords, batch, dims):
     """Runs the rulebook chain of SpMiddleFHDWithCov2_3 on both sides; yields per-level data."""

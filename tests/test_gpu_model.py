@@ -488,6 +488,90 @@ def test_prefetched_example_equals_inline(hip):
     pf.close()
 
 
+def _plan_tables(plan):
+    """Every table of a planned SparseConvTensor, keyed by indice_key."""
+    out = {"coords": plan.indices}
+    for key, rb in plan.indice_dict.items():
+        out[key + ".nbr"] = rb.nbr
+        if rb.nbrT is not None:
+            out[key + ".nbrT"] = rb.nbrT
+            out[key + ".out_coords"] = rb.out_index.coords
+            o = rb.order("nbrT")
+            if o is not None:
+                out[key + ".order"] = o
+        pin, pout, koff = rb.pairs()
+        npairs = int(koff[-1])
+        out[key + ".pin"], out[key + ".pout"], out[key + ".koff"] = pin[:npairs], pout[:npairs], koff
+    return out
+
+
+@pytest.mark.parametrize("case", ["pair", "bs2_ragged", "empty_cloud"])
+def test_native_plan_equals_python_plan(hip, case):
+    """rslo_plan_encoder (one foreign call, row counts on the device, capacity-sized arena) produces the example dict
+    and EVERY table of the Python-issued plan bit for bit: voxels / coordinates / point counts per frame, site order of
+    every level, SubM and strided tables, transposed tables, tile orders, pair lists, per-level batch offsets."""
+    from rslo_amd import plan as native_plan
+    torch.manual_seed(3)
+    net, _ = workload.build_network()
+    net.train()
+    if case == "pair":
+        pairs = [reduced_pair(7, rings=32)]
+    elif case == "bs2_ragged":
+        pairs = [reduced_pair(8), reduced_pair(9, rings=32)]
+    else:      # a sample whose second frame has no point inside the range
+        p = reduced_pair(10)
+        far = p[1].copy()
+        far[:, :3] += 1000.0
+        pairs = [reduced_pair(11), (p[0], far)]
+    clouds = [[torch.from_numpy(c).cuda() for c in pr[:2]] for pr in pairs]
+    ref = net.plan_example(workload.make_example(net, clouds))
+    planner = native_plan.EncoderPlanner(net, synthetic.MAX_VOXELS)
+    for _ in range(2):          # second round: the arena ring hands out fresh memory, results must not depend on it
+        ex = planner.finish(planner.submit(clouds))
+    assert planner.fallbacks == 0
+    for key in ("voxels", "coordinates", "num_points", "num_voxels"):
+        assert len(ex[key]) == len(ref[key])
+        for a, b in zip(ex[key], ref[key]):
+            assert a.shape == b.shape and a.dtype == b.dtype and torch.equal(a.cpu(), b.cpu()), key
+    ta, tb = _plan_tables(ex["sparse_plan"]), _plan_tables(ref["sparse_plan"])
+    assert sorted(ta) == sorted(tb)
+    for k in ta:
+        assert ta[k].shape == tb[k].shape and torch.equal(ta[k], tb[k]), k
+    pa, pb = ex["sparse_plan"], ref["sparse_plan"]
+    assert pa.batch_offsets() == pb.batch_offsets()
+    assert torch.equal(pa.site_index().batch_offs_dev, pb.site_index().batch_offs_dev)
+    if case == "empty_cloud":       # the loss has no defined value for a frame without voxels
+        return
+    # and the step on it: same loss / poses as on the Python plan
+    net.global_step.fill_(2000)
+    r0 = net(ref)
+    r1 = net(ex)
+    assert rel(r1["loss"], r0["loss"]) < 5e-4 and rel(r1["translation_preds"], r0["translation_preds"]) < 5e-4
+    r1["loss"].mean().backward()
+
+
+def test_native_plan_overflow_falls_back_to_exact_sizes(hip):
+    """A strided level with MORE sites than its input (isolated voxels: each feeds up to 8 outputs of a k3 s2 conv)
+    overruns the default capacity; the planner sees the flag and re-plans with exact sizes instead of truncating."""
+    from rslo_amd import plan as native_plan
+    net, _ = workload.build_network()
+    g = np.random.default_rng(0)
+    n = 3000       # isolated points with odd voxel coordinates on a coarse lattice
+    ix, iy, iz = g.integers(0, 700, n) * 2 + 1, g.integers(0, 380, n) * 2 + 1, g.integers(0, 19, n) * 2 + 1
+    xyz = np.stack([ix * 0.1 - 70.4 + 0.05, iy * 0.1 - 38.4 + 0.05, iz * 0.2 - 3 + 0.1], 1).astype(np.float32)
+    pts = np.concatenate([xyz, np.zeros((n, 4), np.float32)], 1)
+    pts[:, 6] = 1.0
+    clouds = [[torch.from_numpy(pts).cuda(), torch.from_numpy(pts[::2].copy()).cuda()]]
+    planner = native_plan.EncoderPlanner(net, synthetic.MAX_VOXELS)
+    ex = planner.finish(planner.submit(clouds))
+    assert planner.fallbacks == 1
+    ref = net.plan_example(workload.make_example(net, clouds))
+    ta, tb = _plan_tables(ex["sparse_plan"]), _plan_tables(ref["sparse_plan"])
+    for k in ta:
+        assert torch.equal(ta[k], tb[k]), k
+    assert ref["sparse_plan"].indice_dict["conv3d2"].nbr.shape[0] > ref["sparse_plan"].indices.shape[0]
+
+
 def test_short_training_run_stays_finite(hip):
     """End-to-end behaviour of the assembled step (encoder + head + loss + the reference's optimizer wrapper and
     OneCycle schedule): 25 optimizer steps on one reduced synthetic pair keep the loss and every parameter finite and

@@ -70,12 +70,70 @@ def test_flip_y_augmentation_matches_matrix_conjugation():
     assert random_flip_y(d, [ref.copy()], rng=Always()) and d["odometry"][0][1] == -2.0
 
 
-def test_numpy_voxel_generator_refuses_in_a_forked_gpu_child(monkeypatch):
-    """spconv.utils.VoxelGenerator.generate(numpy) inside a forked child of a GPU process: clear error, no hang."""
-    import pytest
+def _kitti_like(n, seed):
+    g = np.random.default_rng(seed)
+    pts = np.concatenate([g.uniform(-75, 75, (n, 1)), g.uniform(-42, 42, (n, 1)), g.uniform(-3.5, 5.5, (n, 1)),
+                          g.uniform(0, 1, (n, 4))], 1).astype(np.float32)
+    k = len(pts[1::7])
+    pts[::7][:k] = pts[1::7]                       # repeated points: several per voxel
+    return pts
+
+
+def test_host_voxelizer_matches_the_oracle():
+    """librslo_host.so (the numpy face of VoxelGenerator, plain C, hash-indexed) against the oracle's restatement of
+    the classic SECOND loop (dense lookup table): same voxels / coordinates / counts, incl. T truncation, the break at
+    max_voxels, an empty cloud and points outside the range."""
+    import oracle as O
+    from spconv.utils import VoxelGenerator
+    rng, vs = [-70.4, -38.4, -3, 70.4, 38.4, 5], [0.1, 0.1, 0.2]
+    for n, T, maxv in ((20000, 10, 40000), (20000, 2, 40000), (20000, 10, 1500), (0, 10, 100), (5, 10, 100)):
+        pts = _kitti_like(n, n + T)
+        if n == 5:
+            pts[:, 0] = 500.0                      # nothing inside the range
+        vg = VoxelGenerator(vs, rng, T, maxv)
+        v, c, m = vg.generate(pts, maxv)
+        ov, oc, on = O.voxelize(pts, np.array(rng, np.float32), np.array(vs, np.float32), T, maxv)
+        assert v.dtype == np.float32 and c.dtype == np.int32 and m.dtype == np.int32
+        assert v.shape == ov.shape and (v == ov).all() and (c == oc).all() and (m == on).all(), (n, T, maxv)
+    # hand-made: first-come numbering, (z, y, x) order, slots beyond the count are zero
+    pts = np.zeros((4, 7), np.float32)
+    pts[:, :3] = [[0.05, 0.05, -2.9], [10.0, 0.05, -2.9], [0.06, 0.06, -2.9], [500, 0, 0]]
+    v, c, m = VoxelGenerator(vs, rng, 3, 10).generate(pts)
+    assert c.tolist() == [[0, 384, 704], [0, 384, 804]] and m.tolist() == [2, 1]
+    assert (v[0, 0] == pts[0]).all() and (v[0, 1] == pts[2]).all() and (v[0, 2] == 0).all() and (v[1, 1:] == 0).all()
+
+
+def _fork_child(q):
+    import rslo_amd  # noqa: F401
+    from spconv.utils import VoxelGenerator
+    pts = _kitti_like(3000, 1)
+    v, c, m = VoxelGenerator([0.1, 0.1, 0.2], [-70.4, -38.4, -3, 70.4, 38.4, 5], 10, 20000).generate(pts, 40000)
+    q.put((v.shape, int(c.sum()), int(m.sum())))
+
+
+def test_numpy_voxel_generator_works_in_forked_workers(monkeypatch):
+    """The reference's DataLoader workers are forked (train_hdf5.py:549-553) and call VoxelGenerator.generate on numpy
+    arrays (preprocess.py:493).  The numpy face never touches HIP, so it runs in a forked child -- also one whose
+    parent has initialised the GPU (simulated: torch.cuda._is_in_bad_fork) -- and gives the parent's result."""
+    import multiprocessing as mp
     import torch
     from spconv.utils import VoxelGenerator
-    vg = VoxelGenerator([0.1, 0.1, 0.2], [-70.4, -38.4, -3, 70.4, 38.4, 5], 10, 20000)
+    pts = _kitti_like(3000, 1)
+    v, c, m = VoxelGenerator([0.1, 0.1, 0.2], [-70.4, -38.4, -3, 70.4, 38.4, 5], 10, 20000).generate(pts, 40000)
     monkeypatch.setattr(torch.cuda, "_is_in_bad_fork", lambda: True)
-    with pytest.raises(RuntimeError, match="spawn"):
-        vg.generate(np.zeros((10, 7), np.float32))
+    ctx = mp.get_context("fork")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_fork_child, args=(q,)) for _ in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    assert res[0] == res[1] == (v.shape, int(c.sum()), int(m.sum()))
+    # the voxel_builder surface the data layer uses: a dict of numpy arrays (voxel_builder.py:48-54)
+    from rslo.builder import voxel_builder
+    from rslo.utils import config_text
+    vg = voxel_builder.build(config_text.shipped_config().model.second.voxel_generator)
+    out = vg.generate(pts, 40000)
+    assert (out["voxels"] == v).all() and (out["coordinates"] == c).all() and (out["num_points_per_voxel"] == m).all()
