@@ -229,4 +229,4 @@ def test_hip_clip_and_adam_match_torch(hip):
     for a, b in zip(pa, pb):
         assert torch.allclose(a, b, rtol=2e-6, atol=1e-7)
         if a.grad is not None:
-            assert float(oa.state[a]["step"]) == 7.0
+            assert float(oa.state[a]["step"]) == float(ob.state[b]["step"])      # 7; 4 (late tensor); 6 (skipped once)
