@@ -150,6 +150,8 @@ def leaky_bwd(y, dout, slope, colsum=False):
 
 
 def dense_scatter(feat, coords, batch, dims):
+    if result_dtype == torch.float64 and feat.dtype == torch.float32:
+        feat = feat.double()      # C4 arbiter: the bf16 trunk leaves through `.float()`; the double head takes it from here
     if _is64(feat):
         out = torch.zeros(batch, *[int(d) for d in dims], feat.shape[1], dtype=feat.dtype)
         c = coords.long()
@@ -207,18 +209,107 @@ def chamfer_grad(xyz1, xyz2, graddist1, idx1, g1=None, g2=None):
     return a, b
 
 
-_NAMES = ["SiteIndex", "voxelize", "vfe_mean", "rulebook_subm", "conv_out_dims", "rulebook_conv", "spconv_fwd",
+# ---------------------------------------------------------------------------------------------------------------
+# C4 (bf16 operands): the same rounding points as the HIP path, accumulation in float64.
+#   sparse trunk (rslo_spconv_fwd_bf16 / rslo_leaky_bwd_colsum_bf16 / rslo_spconv_wgrad_pairs_bf16): rows ARE bfloat16
+#   tensors, master weights rounded to bf16 per call, bias / accumulation wide, outputs rounded to bf16;
+#   dense 3x3 stride-1 layers (rslo_conv2d_fwd_bf16 / rslo_conv2d_wgrad_bf16): activations, output gradients and
+#   weights rounded to bf16 as operands, accumulation and storage wide.
+# `result_dtype` = dtype of the master weights of the network being run (float32 path or float64 arbiter): the dtype
+# weight / bias gradients are returned in.
+# ---------------------------------------------------------------------------------------------------------------
+result_dtype = torch.float32
+
+
+def _bf(t):
+    """value rounded to bfloat16 (round to nearest even, like v_cvt_pk_bf16_f32), kept in t's dtype"""
+    return t.float().to(torch.bfloat16).to(t.dtype)
+
+
+def spconv_fwd_bf16(x, W, bias, nbr, flip_k=False, act_slope=1.0, transpose=False, order=None):
+    Wn = _np(_bf(W.float()).double())
+    if flip_k:
+        Wn = Wn[::-1].copy()
+    y = _conv64(_np(x.double()), Wn, _np(nbr), transpose)
+    if bias is not None:
+        y = y + _np(bias.double())
+    if act_slope != 1.0:
+        y = np.where(y > 0, y, y * act_slope)
+    return torch.from_numpy(y).float().to(torch.bfloat16)       # fp32 accumulator -> bf16 row, as the kernel stores it
+
+
+def leaky_bwd_bf16(y, dout, slope, colsum=False):
+    g = torch.where(y.float() > 0, dout.float(), dout.float() * slope).to(torch.bfloat16)
+    return (g, g.double().sum(0, keepdim=True).float()) if colsum else g
+
+
+def spconv_wgrad_pairs_bf16(x, dout, pairs, n_out, K, cin, cout, bias_partial=None):
+    pin, pout, koff = (_np(p) for p in pairs)
+    xd, gd = _np(x.double()), _np(dout.double())
+    dW = np.zeros((K, cin, cout), np.float64)
+    for k in range(K):
+        a, b = int(koff[k]), int(koff[k + 1])
+        if b > a:
+            dW[k] = xd[pin[a:b]].T @ gd[pout[a:b]]
+    db = None if bias_partial is None else bias_partial.double().sum(0).to(result_dtype)
+    return torch.from_numpy(dW).to(result_dtype), db
+
+
+class _LpConv3x3Fn(torch.autograd.Function):
+    """3x3 / stride-1 / padding-1 convolution with bf16-rounded operands in all three passes (what rslo_conv2d_fwd_bf16
+    and rslo_conv2d_wgrad_bf16 compute), accumulated in float64."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        y = torch.nn.functional.conv2d(_bf(x).double(), _bf(w).double(), None if bias is None else bias.double(), 1, 1)
+        return y.to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        g = _bf(dy).double()
+        dx = torch.nn.grad.conv2d_input(x.shape, _bf(w).double(), g, 1, 1).to(x.dtype)
+        dw = torch.nn.grad.conv2d_weight(_bf(x).double(), w.shape, g, 1, 1).to(w.dtype)
+        db = g.sum((0, 2, 3)).to(w.dtype) if ctx.has_bias else None     # the kernel sums its (rounded) dout operands
+        return dx, dw, db
+
+
+def _lp_conv_forward(orig):
+    def fwd(self, input, weight, bias):
+        from rslo_amd import capi, precision
+        if (precision.low_precision() is not None and not input.is_cuda and input.dim() == 4
+                and self.kernel_size == (3, 3) and self.stride == (1, 1) and self.padding == (1, 1)
+                and self.dilation == (1, 1) and self.groups == 1
+                and capi.conv2d_fwd_supported(self.in_channels, self.out_channels, input.shape[2], input.shape[3])
+                and capi.conv2d_wgrad_supported(self.in_channels, self.out_channels, input.shape[2], input.shape[3], 1)):
+            return _LpConv3x3Fn.apply(input, weight, bias)
+        return orig(self, input, weight, bias)
+    return fwd
+
+
+_NAMES = ["spconv_fwd_bf16", "leaky_bwd_bf16", "spconv_wgrad_pairs_bf16", "SiteIndex", "voxelize", "vfe_mean", "rulebook_subm", "conv_out_dims", "rulebook_conv", "spconv_fwd",
           "spconv_dgrad", "spconv_wgrad", "rulebook_row_order", "rulebook_pairs", "spconv_wgrad_pairs", "leaky_bwd", "dense_scatter", "dense_gather", "chamfer_nn", "chamfer_grad"]
 
 
 @contextlib.contextmanager
 def patched():
-    from rslo_amd import capi
+    import spconv
+    from rslo.layers import hip_conv2d
+    from rslo_amd import capi, precision
     saved = {n: getattr(capi, n) for n in _NAMES}
+    lowp, convf = spconv.SparseConvolution._low_precision, hip_conv2d.Conv2d._conv_forward
     try:
         for n in _NAMES:
             setattr(capi, n, globals()[n])
+        # C4 on CPU tensors: the product gates its bf16 paths on `is_cuda`; the emulation takes the same layers
+        spconv.SparseConvolution._low_precision = lambda self, feats: (
+            precision.low_precision() is not None and self.allow_low_precision
+            and self.in_channels in (32, 64) and self.out_channels in (32, 64))
+        hip_conv2d.Conv2d._conv_forward = _lp_conv_forward(convf)
         yield
     finally:
         for n, f in saved.items():
             setattr(capi, n, f)
+        spconv.SparseConvolution._low_precision, hip_conv2d.Conv2d._conv_forward = lowp, convf
