@@ -21,7 +21,7 @@
  *                            functions restate the published spconv-1.x /
  *                            SECOND contract and are pinned instead by the
  *                            dense F.conv3d / conv_transpose3d equivalence
- *                            (tests/test_oracle_spconv.py) and hand-made KATs.
+ *                            (tests/test_oracle.py) and hand-made KATs.
  *
  * Conventions: coordinates are (b, z, y, x) int32; weights are
  * [K = kz*ky*kx, Cin, Cout] row-major with k = (kz*KY + ky)*KX + kx

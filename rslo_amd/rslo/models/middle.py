@@ -109,7 +109,12 @@ class SpMiddleFHDWithCov2_3(nn.Module):
                 rb.pairs()
         return x
 
-    def forward(self, voxel_features, coors, batch_size, plan=None):
+    def forward(self, voxel_features, coors, batch_size, plan=None, defer_cov=False):
+        """defer_cov=True: returns (bev, cov_fn); cov_fn() runs the covariance branch.  The caller can then issue it on
+        a second stream behind the BEV head (voxel_odom_net.network_forward): the branch only meets the rest of the
+        network again in the loss, so its six level-1 / level-0 layers -- launches that fill the GPU -- run beside the
+        head's 12 x 22 / 24 x 44 layers, which leave most CUs idle, forward AND backward (autograd replays every node
+        on the stream of its forward).  Same kernels on the same inputs: identical results."""
         # all rulebooks first (they depend on coordinates only): the host reads of output-site counts happen
         # before any convolution is queued, then the ~20 conv launches run without a sync in between
         if plan is None:
@@ -121,14 +126,25 @@ class SpMiddleFHDWithCov2_3(nn.Module):
             spconv.presplit(self)
         x = plan._like(voxel_features)
         ret0 = self.middle_conv(x)
+        ready = None
+        if defer_cov and voxel_features.is_cuda:
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(voxel_features.device))       # ret0 exists from here on
+
+        def cov_branch():
+            cov = self.middle_cov_deconv(ret0).features
+            # eigenvalue increments > 0 (middle.py:237), out of place
+            lam, rest = cov.split([3, cov.shape[1] - 3], dim=1)
+            return torch.cat([F.elu(lam) + 1 + 1e-6, rest], dim=1)
+
         ret = self.middle_conv_tail(ret0)
-        cov = self.middle_cov_deconv(ret0).features
-        # eigenvalue increments > 0 (middle.py:237), out of place
-        lam, rest = cov.split([3, cov.shape[1] - 3], dim=1)
-        cov = torch.cat([F.elu(lam) + 1 + 1e-6, rest], dim=1)
         dense = ret.dense()
         N, Cc, D, H, W = dense.shape
-        return dense.view(N, Cc * D, H, W), cov
+        bev = dense.view(N, Cc * D, H, W)
+        if defer_cov:
+            cov_branch.ready, cov_branch.source = ready, ret0.features
+            return bev, cov_branch
+        return bev, cov_branch()
 
 
 from rslo import reference_fallback as _reference_fallback  # noqa: E402

@@ -13,6 +13,7 @@ MI355X re-design inside that contract:
     step, voxel_odom_net.py:519-539).
 """
 import contextlib
+import os
 import time
 
 import apex.amp as amp
@@ -249,16 +250,35 @@ class UnVoxelOdomNetICP3(nn.Module):
         plan = example.get("sparse_plan") if example is not None else None
         if plan is None:
             plan = self.middle_feature_extractor.plan(self._merge_coords(coors, batch_size), T * batch_size)
-        bev, cov = self.middle_feature_extractor(torch.cat(voxel_features, 0) if vf_all is None else vf_all, plan.indices,
-                                                 T * batch_size, plan=plan)
+        feats_all = torch.cat(voxel_features, 0) if vf_all is None else vf_all
+        two_streams = feats_all.is_cuda and os.environ.get("RSLO_COV_STREAM", "1") != "0"
+        bev, cov = self.middle_feature_extractor(feats_all, plan.indices, T * batch_size, plan=plan,
+                                                 defer_cov=two_streams)
+        cov_fn = cov if two_streams else None
         exchange = self.__dict__.get("_grad_exchange")      # data parallel: the head's gradient bucket leaves when the
         if exchange is not None:                            # gradient of the BEV map is complete (distributed_utils)
             exchange.watch(bev)
         spatial_features = list(bev.split(batch_size, dim=0))
-        middle_conf_preds = list(cov.split([f.shape[0] for f in voxel_features], dim=0))
+        if cov_fn is None:
+            middle_conf_preds = list(cov.split([f.shape[0] for f in voxel_features], dim=0))
         self.end_timer("middle forward")
 
         preds_dict = self.odom_predictor(spatial_features, tq_map_gt=example.get("tq_maps", [None])[0])
+        if cov_fn is not None:
+            # the covariance branch on its own stream, issued BEHIND the head: it starts as soon as the level-2 tensor
+            # exists (event), so it runs beside the tail + head in forward, and -- created last, hence first in the
+            # engine's queue -- beside the head's backward
+            cur = torch.cuda.current_stream(feats_all.device)
+            side = self.__dict__.get("_cov_stream")
+            if side is None or side.device != feats_all.device:
+                side = self.__dict__["_cov_stream"] = torch.cuda.Stream(feats_all.device)
+            side.wait_event(cov_fn.ready)
+            cov_fn.source.record_stream(side)
+            with torch.cuda.stream(side):
+                cov = cov_fn()
+            cur.wait_stream(side)
+            cov.record_stream(cur)
+            middle_conf_preds = list(cov.split([f.shape[0] for f in voxel_features], dim=0))
         with torch.no_grad():
             preds_dict["feature_mask"] = (torch.cat(spatial_features, dim=1).sum(dim=1, keepdim=True) != 0).float()
             disp = [f.mean(dim=1, keepdim=True) for f in spatial_features]

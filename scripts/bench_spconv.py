@@ -59,8 +59,21 @@ def make_order(nbr, coords):
     return torch.sort(key, stable=True)[1].int()
 
 
+LOCALIZE = os.environ.get("LOCALIZE", "0") == "1"   # upper bound of ANY row re-ordering: same masks (same MFMA work), but
+# the neighbour of row o at offset k is row o + k - K/2: a tile's 27 neighbour sets are 27 overlapping contiguous runs
+
+
+def localize(nbr):
+    n, K = nbr.shape
+    loc = (torch.arange(n, device=nbr.device, dtype=torch.int32)[:, None]
+           + torch.arange(K, device=nbr.device, dtype=torch.int32)[None] - K // 2).clamp_(0, n - 1)
+    return torch.where(nbr >= 0, loc, torch.full_like(nbr, -1)).contiguous()
+
+
 def run(name, x, W, nbr, fn, check=True, coords=None):
-    if ONLY and ONLY not in name: return
+    if ONLY and not any(o in name for o in ONLY.split(",")): return
+    if LOCALIZE:
+        nbr = localize(nbr)
     order = make_order(nbr, coords)
     P = int((nbr >= 0).sum()); n_out, K = nbr.shape; cin, cout = W.shape[1], W.shape[2]
     if fn == "dgrad":

@@ -295,36 +295,39 @@ def test_use_svd_vote_matches_reference():
     check_vote_svd("cpu")
 
 
-@pytest.mark.parametrize("mode", [1, 0])
-def test_sparse_conv_2d_layer_matches_reference(mode):
+def check_sparse_conv_2d(mode, device):
     from rslo.layers.SparseConv import SparseConv
     g = _variants()
     tag = "spc%d_" % mode
-    m = SparseConv(6, 8, kernel_size=3, stride=2, padding=1, bias=True, max_pool_mask=bool(mode))
+    m = SparseConv(6, 8, kernel_size=3, stride=2, padding=1, bias=True, max_pool_mask=bool(mode)).to(device)
     with torch.no_grad():
         m.conv1.weight.copy_(torch.from_numpy(g[tag + "w"]))
         m.b[0].copy_(torch.from_numpy(g[tag + "b"]))
-    x = torch.from_numpy(g[tag + "x"]).requires_grad_(True)
-    y, mo = m([x, torch.from_numpy(g[tag + "mask"])])
-    (y * torch.linspace(-1, 1, y.numel()).reshape(y.shape)).sum().backward()
+    x = torch.from_numpy(g[tag + "x"]).to(device).requires_grad_(True)
+    y, mo = m([x, torch.from_numpy(g[tag + "mask"]).to(device)])
+    (y * torch.linspace(-1, 1, y.numel(), device=device).reshape(y.shape)).sum().backward()
     tol = dict(rtol=1e-5, atol=1e-6)
-    np.testing.assert_allclose(y.detach().numpy(), g[tag + "y"], **tol)
-    np.testing.assert_allclose(mo.numpy(), g[tag + "mask_out"], **tol)
-    np.testing.assert_allclose(x.grad.numpy(), g[tag + "gx"], **tol)
-    np.testing.assert_allclose(m.conv1.weight.grad.numpy(), g[tag + "gw"], rtol=1e-4, atol=1e-5)
-    np.testing.assert_allclose(m.b[0].grad.numpy(), g[tag + "gb"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), g[tag + "y"], **tol)
+    np.testing.assert_allclose(mo.cpu().numpy(), g[tag + "mask_out"], **tol)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), g[tag + "gx"], **tol)
+    np.testing.assert_allclose(m.conv1.weight.grad.cpu().numpy(), g[tag + "gw"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(m.b[0].grad.cpu().numpy(), g[tag + "gb"], rtol=1e-4, atol=1e-5)
     want = ["b.0", "conv1.weight", "sum_conv.weight"] + ([] if mode else ["mask_pool.weight"])
     assert sorted(k for k, _ in m.named_parameters()) == sorted(want)          # the reference's state-dict keys
 
 
-@pytest.mark.parametrize("name", ["mask", "semi"])
-def test_normalisation_variants_match_reference_statistics(name):
+@pytest.mark.parametrize("mode", [1, 0])
+def test_sparse_conv_2d_layer_matches_reference(mode):
+    check_sparse_conv_2d(mode, "cpu")
+
+
+def check_normalisation_variant(name, device):
     """MaskSyncBatchNorm / SemiGlobalSyncBatchNorm: two training steps (outputs, gradients, every buffer incl. the
     drift-adapted momenta) and one eval call against the reference's classes (apex's normalisation function restated
     on both sides, see make_golden_variants.py)."""
     from rslo.layers.normalization import MaskSyncBatchNorm, SemiGlobalSyncBatchNorm
     g = _variants()
-    bn = (MaskSyncBatchNorm if name == "mask" else SemiGlobalSyncBatchNorm)(5, eps=1e-3, momentum=0.01)
+    bn = (MaskSyncBatchNorm if name == "mask" else SemiGlobalSyncBatchNorm)(5, eps=1e-3, momentum=0.01).to(device)
     with torch.no_grad():
         bn.weight.copy_(torch.linspace(0.5, 1.5, 5))
         bn.bias.copy_(torch.linspace(-0.2, 0.2, 5))
@@ -332,41 +335,46 @@ def test_normalisation_variants_match_reference_statistics(name):
     tol = dict(rtol=2e-5, atol=2e-6)
     for step in range(2):
         tag = "%s%d_" % (name, step)
-        x = torch.from_numpy(g[tag + "x"]).requires_grad_(True)
-        mk = torch.from_numpy(g[tag + "m"])
+        x = torch.from_numpy(g[tag + "x"]).to(device).requires_grad_(True)
+        mk = torch.from_numpy(g[tag + "m"]).to(device)
         y = bn([x * 1.0, mk]) if name == "mask" else bn(x * 1.0)
-        (y * torch.linspace(-1, 1, y.numel()).reshape(y.shape)).sum().backward()
-        np.testing.assert_allclose(y.detach().numpy(), g[tag + "y"], **tol)
-        np.testing.assert_allclose(x.grad.numpy(), g[tag + "gx"], rtol=1e-4, atol=1e-5)
-        np.testing.assert_allclose(bn.weight.grad.numpy(), g[tag + "gw"], rtol=1e-4, atol=1e-5)
-        np.testing.assert_allclose(bn.bias.grad.numpy(), g[tag + "gb"], rtol=1e-4, atol=1e-5)
+        (y * torch.linspace(-1, 1, y.numel(), device=device).reshape(y.shape)).sum().backward()
+        np.testing.assert_allclose(y.detach().cpu().numpy(), g[tag + "y"], **tol)
+        np.testing.assert_allclose(x.grad.cpu().numpy(), g[tag + "gx"], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(bn.weight.grad.cpu().numpy(), g[tag + "gw"], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(bn.bias.grad.cpu().numpy(), g[tag + "gb"], rtol=1e-4, atol=1e-5)
         bn.zero_grad()
         sd = bn.state_dict()
         keys = [k[len(tag) + 3:] for k in g.files if k.startswith(tag + "sd/")]
         assert sorted(keys) == sorted(k for k in sd if k not in ("weight", "bias"))
         for k in keys:
-            np.testing.assert_allclose(sd[k].numpy(), g[tag + "sd/" + k], **tol)
+            np.testing.assert_allclose(sd[k].cpu().numpy(), g[tag + "sd/" + k], **tol)
     bn.eval()
-    x, mk = torch.from_numpy(g[name + "E_x"]), torch.from_numpy(g[name + "E_m"])
+    x, mk = torch.from_numpy(g[name + "E_x"]).to(device), torch.from_numpy(g[name + "E_m"]).to(device)
     y = bn([x.clone(), mk]) if name == "mask" else bn(x)
-    np.testing.assert_allclose(y.detach().numpy(), g[name + "E_y"], **tol)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), g[name + "E_y"], **tol)
 
 
-@pytest.mark.parametrize("bn_type,use_svd", [("MaskSyncBN", False), ("SemiGlobalSyncBN", False), ("SyncBN", True)])
-def test_head_builds_and_steps_with_registry_variants(bn_type, use_svd):
+@pytest.mark.parametrize("name", ["mask", "semi"])
+def test_normalisation_variants_match_reference_statistics(name):
+    check_normalisation_variant(name, "cpu")
+
+
+def check_head_variant(bn_type, use_svd, device, widths=(8, 8, 16), up=8, cin=4, hw=(16, 24)):
     """The BEV head with the statistics variants / the SVD vote selected: forward + backward run, outputs finite, the
     SVD vote returns a rotation matrix in training and a unit (w, x, y, z) quaternion in eval."""
     import rslo.models.odom_pred as OP
     torch.manual_seed(3)
     head = OP.get_odom_class("UNRResNetOdomPredEncDecSVDTempMask")(
         bn_type=bn_type, enc_use_norm=True, conv_type="mask_conv", layer_nums=[1, 1, 1], layer_strides=[2, 2, 2],
-        num_filters=[8, 8, 16], upsample_strides=[2, 2, 2], num_upsample_filters=[8, 8, 8], num_input_features=8,
-        pooling_type="avg_pool", pooling_size=1, dropout=1e-22, cycle_constraint=True, pred_pyramid_motion=True,
-        use_deep_supervision=True, odom_format="rx+t", point_cloud_range=PC_RANGE, dense_predict=True,
-        conf_type="softmax", use_svd=use_svd, cubic_pred_height=0)
+        num_filters=list(widths), upsample_strides=[2, 2, 2], num_upsample_filters=[up, up, up],
+        num_input_features=2 * cin, pooling_type="avg_pool", pooling_size=1, dropout=1e-22, cycle_constraint=True,
+        pred_pyramid_motion=True, use_deep_supervision=True, odom_format="rx+t", point_cloud_range=PC_RANGE,
+        dense_predict=True, conf_type="softmax", use_svd=use_svd, cubic_pred_height=0).to(device)
     head.train()
     g = torch.Generator().manual_seed(0)
-    xs = [torch.randn(2, 4, 16, 24, generator=g) * (torch.rand(2, 1, 16, 24, generator=g) > 0.5) for _ in range(2)]
+    xs = [(torch.randn(2, cin, *hw, generator=g) * (torch.rand(2, 1, *hw, generator=g) > 0.5)).to(device)
+          for _ in range(2)]
     out = head([x.clone() for x in xs])
     t, r = out["translation_preds"][0], out["rotation_preds"][0]
     assert t.shape == (2, 3) and r.shape == (2, 9 if use_svd else 4)
@@ -374,8 +382,14 @@ def test_head_builds_and_steps_with_registry_variants(bn_type, use_svd):
     assert all(torch.isfinite(p.grad).all() for p in head.parameters() if p.grad is not None)
     if use_svd:
         R = r.reshape(2, 3, 3)
-        assert float((R @ R.transpose(1, 2) - torch.eye(3)).abs().max()) < 1e-4
+        assert float((R @ R.transpose(1, 2) - torch.eye(3, device=device)).abs().max()) < 1e-4
         head.eval()
         with torch.no_grad():
             q = head([x.clone() for x in xs])["rotation_preds"][0]
         assert q.shape == (2, 4) and float((q.norm(dim=1) - 1).abs().max()) < 1e-4
+    return head, xs, out
+
+
+@pytest.mark.parametrize("bn_type,use_svd", [("MaskSyncBN", False), ("SemiGlobalSyncBN", False), ("SyncBN", True)])
+def test_head_builds_and_steps_with_registry_variants(bn_type, use_svd):
+    check_head_variant(bn_type, use_svd, "cpu")

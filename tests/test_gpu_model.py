@@ -14,7 +14,8 @@ import rslo_amd  # noqa: F401
 from oracle import cpu_backend
 from rslo_amd import synthetic, workload
 
-from test_golden_host import (check_closs, check_create_loss, check_head, load_small_head, make_closs)
+from test_golden_host import (check_closs, check_create_loss, check_head, check_head_variant, check_normalisation_variant,
+                              check_sparse_conv_2d, check_vote_svd, load_small_head, make_closs)
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
@@ -822,3 +823,35 @@ def test_three_frame_samples_batched_equals_per_sample(hip):
     assert rel(both["rotation_preds"], torch.cat([ra["rotation_preds"], rb["rotation_preds"]])) < 1e-4
     assert rel(both["C_loss"], (ra["C_loss"] + rb["C_loss"]) / 2) < 2e-4
     both["loss"].mean().backward()
+
+
+# ------------------------------------------------------------------------------ registry variants on the device
+def test_registry_variants_match_reference_vectors_on_the_gpu(hip):
+    """The variants one config flag away from the shipped one (rslo/models/odom_pred.py:319-346 `use_svd` vote,
+    rslo/layers/SparseConv.py:222-302 2-D SparseConv, rslo/layers/normalization.py:11-251 MaskSyncBN /
+    SemiGlobalSyncBN) against the vectors generated from the reference's own classes (variants_ref.npz), on cuda."""
+    check_vote_svd("cuda")
+    for mode in (1, 0):
+        check_sparse_conv_2d(mode, "cuda")
+    for name in ("mask", "semi"):
+        check_normalisation_variant(name, "cuda")
+
+
+@pytest.mark.parametrize("bn_type,use_svd", [("MaskSyncBN", False), ("SemiGlobalSyncBN", False), ("SyncBN", True)])
+def test_head_with_registry_variants_steps_on_the_gpu_and_equals_the_cpu_run(hip, bn_type, use_svd):
+    """The BEV head with a variant selected, at widths the hand-written dense kernels take (32 / 32 / 64 filters on
+    48 x 64 maps: rslo_conv2d_fwd / _wgrad / _s2 underneath), forward + backward on cuda against the SAME head on the
+    CPU (plain torch): poses 1e-4, gradient direction of every tensor (cosine > 0.999)."""
+    head, xs, out = check_head_variant(bn_type, use_svd, "cuda", widths=(32, 32, 64), up=64, cin=32, hw=(48, 64))
+    head_c, xs_c, out_c = check_head_variant(bn_type, use_svd, "cpu", widths=(32, 32, 64), up=64, cin=32, hw=(48, 64))
+    for k in ("translation_preds", "rotation_preds"):
+        assert rel(out[k][0], out_c[k][0]) < 1e-4, k
+    n = 0
+    skip = bias_before_bn(head)          # analytically zero gradients: rounding noise on both sides
+    for (name, p), (_, q) in zip(head.named_parameters(), head_c.named_parameters()):
+        if name in skip or q.grad is None or float(q.grad.abs().max()) < 1e-7:
+            continue
+        cos = float(torch.nn.functional.cosine_similarity(p.grad.flatten().cpu().double(), q.grad.flatten().double(), dim=0))
+        assert cos > 0.999, (name, cos)
+        n += 1
+    assert n > 40
