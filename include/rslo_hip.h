@@ -146,10 +146,6 @@ RSLO_API int rslo_weight_split_many(const RsloWeightSplitDesc *desc_dev, int n_l
 RSLO_API int rslo_spconv_fwd_split(const float *in, int cin, const void *Ws, const float *bias, const int32_t *nbr,
                                    const int32_t *row_order, int64_t n_out, int K, int cout, int flip_k,
                                    float act_slope, float *out, void *stream);
-/*     Experiment knob of rslo_spconv_fwd_split: <= 0 = one 32-row tile per wave (k_spconv_v6, the default);
- *     2 / 4 = that many tiles per wave with the weight operands reused across them through a wave-private LDS ring
- *     (k_spconv_v9: bit-identical results, measured slower -- see the kernel header).  Environment: RSLO_SPCONV_V9. */
-RSLO_API void rslo_spconv_set_v9(int mode);
 /*     Tiling of k_spconv_v6 behind rslo_spconv_fwd_split: a tile is 16*rbw rows (rbw 1, 2, 4) and ks waves (1, 2, 4) share
  *     it, each walking 1/ks of the tile's active kernel offsets; their accumulators are added through LDS in wave order
  *     (a fixed summation order, results within fp32 rounding of the one-wave form).  0 = the library chooses per layer

@@ -41,7 +41,6 @@ SIGNATURES = {
     "rslo_weight_split": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "rslo_weight_split_many": (C.c_int, [_vp, _i, _i64, _vp]),
     "rslo_spconv_fwd_split": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, C.c_float, _vp, _vp]),
-    "rslo_spconv_set_v9": (None, [_i]),
     "rslo_spconv_set_tiling": (None, [_i, _i]),
     "rslo_weight_to_bf16": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "rslo_spconv_fwd_bf16": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, C.c_float, _vp, _vp]),

@@ -547,27 +547,8 @@ __device__ __forceinline__ Split8 split8(const float4 a, const float4 b, bool ok
   return o;
 }
 
-#ifndef SPC_WNT
-#define SPC_WNT 0       // 1: weight-fragment loads carry the non-temporal hint (experiment: keep them out of the vector L1)
-#endif
-#if SPC_WNT
-#define SPC_WLOAD(p) __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p))
-#else
 #define SPC_WLOAD(p) (*reinterpret_cast<const u32x4 *>(p))
-#endif
-#ifndef SPC_ABLATE
-#define SPC_ABLATE 0      // bit 1: no weight loads, 2: no row gathers, 4: no MFMAs, 8: no operand split (scripts/ablate_spconv.sh)
-#endif
-#if SPC_ABLATE & 4
-__device__ __forceinline__ f32x4 fake_mfma(u32x4 a, u32x4 b, f32x4 c) {
-  c[0] += __uint_as_float((a[0] ^ b[0]) & 0x3fffffffu); c[1] += __uint_as_float((a[1] ^ b[1]) & 0x3fffffffu);
-  c[2] += __uint_as_float((a[2] ^ b[2]) & 0x3fffffffu); c[3] += __uint_as_float((a[3] ^ b[3]) & 0x3fffffffu);
-  return c;
-}
-#define MFMA_BF16(A, B, C) fake_mfma(A, B, C)
-#else
 #define MFMA_BF16(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), C, 0, 0, 0)
-#endif
 
 // KS = 2: the active offsets of a tile are divided between TWO waves (lowest half of the set bits / the rest), whose
 // accumulators are added through LDS before the epilogue (first half + second half: a fixed order).  A launch of the
@@ -575,16 +556,8 @@ __device__ __forceinline__ f32x4 fake_mfma(u32x4 a, u32x4 b, f32x4 c) {
 // 3 or 4 waves from start to end, the kernel's time is the gather latency chain of the SIMDs that got 4, and nothing
 // else is in flight to hide it.  Half-length chains in twice as many waves put 6.2 waves on a SIMD (quantisation 6.2 vs
 // 7 instead of 3.1 vs 4) at the same weight and row traffic per product.
-#ifndef SPC6_WPE
-#define SPC6_WPE 0      // > 0: register budget for that many waves per SIMD (experiment)
-#endif
-#if SPC6_WPE > 0
-#define SPC6_ATTR __attribute__((amdgpu_waves_per_eu(SPC6_WPE, SPC6_WPE)))
-#else
-#define SPC6_ATTR
-#endif
 template <int CIN_T, int COUT_T, int RBW, int KS = 1>
-__global__ __launch_bounds__(SPC_THREADS) SPC6_ATTR void k_spconv_v6(const float *__restrict__ in,
+__global__ __launch_bounds__(SPC_THREADS) void k_spconv_v6(const float *__restrict__ in,
                                                            const unsigned short *__restrict__ Ws,
                                                            const float *__restrict__ bias,
                                                            const int32_t *__restrict__ nbr,
@@ -655,31 +628,17 @@ __global__ __launch_bounds__(SPC_THREADS) SPC6_ATTR void k_spconv_v6(const float
       Split8 a[RBW];
 #pragma unroll
       for (int rb = 0; rb < RBW; ++rb) {
-#if SPC_ABLATE & 2      // no row gathers
-        const float t = __int_as_float(0x3f800000 + lane + k + sk);
-        const float4 x0 = make_float4(t, t, t, t), x1 = x0;
-#else
         const float4 x0 = *reinterpret_cast<const float4 *>(ap[rb] + 32 * sk);
         const float4 x1 = *reinterpret_cast<const float4 *>(ap[rb] + 32 * sk + 4);
-#endif
-#if SPC_ABLATE & 8      // no operand split
-        a[rb].h = __builtin_bit_cast(u32x4, x0); a[rb].m = __builtin_bit_cast(u32x4, x1); a[rb].l = a[rb].h ^ a[rb].m;
-#else
         a[rb] = split8(x0, x1, ok[rb]);
-#endif
       }
       // Ws[plane][kk][sk][g][co][8]: 16 bytes per lane, consecutive li -> consecutive 16 bytes
       const unsigned short *wb = Ws + ((((int64_t)kk * NS + sk) * 4 + g) * COUT_T + li) * 8;
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
-#if SPC_ABLATE & 1      // no weight loads
-        const unsigned t0 = 0x3f803f80u + lane * 65537u + kk * 3 + sk + nb;
-        const u32x4 bh = {t0, t0 + 1, t0 + 2, t0 + 3}, bm = {t0 + 4, t0 + 5, t0 + 6, t0 + 7}, bl = {t0 + 8, t0 + 9, t0, t0};
-#else
         const u32x4 bh = SPC_WLOAD(wb + nb * 16 * 8);
         const u32x4 bm = SPC_WLOAD(wb + plane + nb * 16 * 8);
         const u32x4 bl = SPC_WLOAD(wb + 2 * plane + nb * 16 * 8);
-#endif
         // smallest terms first; consecutive MFMAs alternate between the row blocks' accumulators
 #pragma unroll
         for (int rb = 0; rb < RBW; ++rb) acc[rb][nb] = MFMA_BF16(a[rb].l, bh, acc[rb][nb]);
@@ -745,219 +704,6 @@ __global__ __launch_bounds__(SPC_THREADS) SPC6_ATTR void k_spconv_v6(const float
       else
         *reinterpret_cast<float2 *>(dst) = make_float2(o[0], o[1]);
     }
-}
-
-// ---------------------------------------------------------------------------------------
-// v9: the same arithmetic as v6 (same products, same order per accumulator -> bit-identical results), restructured so
-// that a wave re-uses every weight fragment it fetches.  v6 runs one 32-row tile per wave and walks the tile's active
-// offsets: per tile and offset it pulls 24 KB of split weights (64 -> 64) and 8 KB of rows through the CU's vector L1
-// for 1536 matrix-core cycles -- four such waves per CU saturate the 64 B/clk L1 path.  v9 gives a wave T tiles
-// (accumulators of all T tiles stay in registers, one wave per SIMD) and turns the loops inside out: the outer loop
-// walks (offset, 32-channel K-step) GROUPS, the inner loop the tiles that have that offset.  A group's weight operand
-// (12 KB) is fetched ONCE per wave into a wave-private two-slot LDS ring -- global loads issued at the start of the
-// last item of group g for group g+2, written to the slot group g just finished with at the end of that item, so the
-// loads are older than the row gathers the item waits for and never cost a wait of their own -- and read back as MFMA
-// B operands with conflict-free ds_read_b128 (256 B/clk, off the L1 path).  Rows of the next (tile, group) item are
-// gathered before the current item's MFMAs and split to bf16 pieces after them.  No workgroup barriers in the loop:
-// waves never wait for each other (the LDS ring of the removed v8 coupled four waves with different offset sets).
-// MEASURED (round 2, scripts/check_v9.py, profiles/r02_spconv_v9_experiment.txt): bit-identical to v6 on every shape,
-// but not faster -- T = 2 (one ring slot, 2 waves per SIMD) 159-165 us vs 156-158 us on the 64 -> 64 level-2 layer,
-// T = 4 (1 wave per SIMD) 210-240 us.  The vector-L1 traffic does drop as designed; what takes over is issue: a lone
-// wave issues one VALU instruction per 4 cycles, the operand split is ~2.4 VALU instructions per MFMA plus whatever
-// AGPR<->VGPR moves the register allocator adds, and hipcc places s_waitcnt vmcnt right behind the loads unless every
-// item is fenced with sched_barrier(0) (SQ counters: waves parked 34-46 % of their cycles, issue-stalled 15-30 %).
-// Kept as an opt-in form (rslo_spconv_set_v9 / RSLO_SPCONV_V9 = 2 | 4) with its parity test; v6 stays the default.
-// ---------------------------------------------------------------------------------------
-__device__ float spc_zero_row[64];      // all zeros (never written): the row an absent neighbour reads
-
-template <int CIN_T, int COUT_T, int T>
-struct Spc9Lds {            // per wave
-  static constexpr int SLOTS = T >= 4 ? 2 : 1;    // T = 2: one slot, 20 KB per wave -> two waves per SIMD
-  u32x4 bslot[SLOTS][12 * COUT_T];                // [slot][plane 3][g 4][co] 16-byte units = one group's B operand
-  int32_t nbl[T * 32 * SPC_MAXK];
-  int32_t orow[T * 32];
-  unsigned char glist[64];
-};
-
-template <int CIN_T, int COUT_T, int T>
-__global__ __launch_bounds__(SPC_THREADS) void k_spconv_v9(const float *__restrict__ in,
-                                                           const unsigned short *__restrict__ Ws,
-                                                           const float *__restrict__ bias,
-                                                           const int32_t *__restrict__ nbr,
-                                                           const int32_t *__restrict__ order, int64_t n_out,
-                                                           int K, int flip_k, float slope,
-                                                           float *__restrict__ out) {
-  constexpr int NS = CIN_T / 32;       // K-steps of 32 input channels
-  constexpr int NB = COUT_T / 16;      // 16-column blocks: column li of block nb = output channel NB li + nb
-  constexpr int SROWS = 32 * T;        // rows of a wave: T tiles of 2 x 16
-  constexpr int PU = 4 * COUT_T;       // 16-byte units per plane of a group operand
-  constexpr int NLD = 3 * PU / 64;     // 16-byte loads per lane that stage one group
-  using Lds = Spc9Lds<CIN_T, COUT_T, T>;
-  extern __shared__ __align__(16) unsigned char spc9_smem[];
-
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int li = lane & 15, g = lane >> 4;
-  Lds &S = reinterpret_cast<Lds *>(spc9_smem)[wid];
-  const int64_t n_st = (n_out + SROWS - 1) / SROWS;
-  const int64_t n_blocks = (n_st + SPC_WAVES - 1) / SPC_WAVES;
-  const int64_t vb = xcd_tile(n_blocks);
-  const int64_t st = vb * SPC_WAVES + wid;
-  const bool active = vb < n_blocks && st < n_st;
-  const int64_t row0 = st * SROWS;
-
-  if (active) spc_load_tile<SROWS>(nbr, order, row0, n_out, K, lane, S.nbl, S.orow);
-  __syncthreads();
-  if (!active) return;
-
-  // per tile: which offsets any of its 32 rows has
-  unsigned tmask[T], uni = 0;
-#pragma unroll
-  for (int t = 0; t < T; ++t) {
-    unsigned m = 0;
-    for (int k = 0; k < K; ++k) {
-      const bool has = lane < 32 && S.nbl[(t * 32 + lane) * K + k] >= 0;
-      if (__ballot(has) != 0ull) m |= 1u << k;
-    }
-    tmask[t] = __builtin_amdgcn_readfirstlane(m);
-    uni |= tmask[t];
-  }
-  // groups = (offset any of the T tiles has, K-step) in ascending order
-  const int n_groups = __popc(uni) * NS;
-  if (lane < K && ((uni >> lane) & 1u)) {
-    const int pos = __popc(uni & ((1u << lane) - 1u));
-#pragma unroll
-    for (int sk = 0; sk < NS; ++sk) S.glist[pos * NS + sk] = (unsigned char)(lane * NS + sk);
-  }
-  const int64_t plane = (int64_t)K * CIN_T * COUT_T;          // bf16 elements per plane
-  // 16-byte unit j*64 + lane of group ks = (k, sk): plane p = (j*64) / PU, position within the plane (j*64) % PU + lane
-  auto bsrc = [&](int ks, int j) -> const u32x4 * {
-    const int k = ks / NS, sk = ks % NS;
-    const int kk = flip_k ? (K - 1 - k) : k;
-    const int p = (j * 64) / PU, w = (j * 64) % PU + lane;
-    return reinterpret_cast<const u32x4 *>(Ws + p * plane + (int64_t)(kk * NS + sk) * PU * 8) + w;
-  };
-  static_assert(T % 2 == 0, "the row double buffer alternates with the tile index");
-  f32x4 acc[T][2][NB];
-#pragma unroll
-  for (int t = 0; t < T; ++t)
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb) acc[t][rb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  // rows of item (tile t, offset k, K-step sk): lane (li, g) takes channels 32 sk + 8 g .. + 7 of rows li and 16 + li;
-  // an absent neighbour reads the all-zero row (no select on the values)
-  auto gather = [&](int t, int k, int sk, float4 (&x0)[2], float4 (&x1)[2]) {
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb) {
-      const int32_t r = S.nbl[(t * 32 + rb * 16 + li) * K + k];
-      const float *ap = (r >= 0 ? in + (int64_t)r * CIN_T : spc_zero_row) + 32 * sk + 8 * g;
-      x0[rb] = *reinterpret_cast<const float4 *>(ap);
-      x1[rb] = *reinterpret_cast<const float4 *>(ap + 4);
-    }
-  };
-
-  // software pipeline over items j = (group, tile), tile fastest:  item j's MFMAs run on A(j) while the rows of item
-  // j + 2 are fetched and the rows of item j + 1 (fetched during item j - 1) are split into A(j + 1).  The weight
-  // operand of group gi + 1 is fetched during tile 0 of group gi and stored to the other ring slot during tile 1.
-  // A tile runs every group of the wave (an offset only its neighbours have contributes exact zeros): the loop body
-  // is one straight-line block, so the compiler can interleave the VALU work with the MFMAs and count its waits.
-  const int ksfirst = __builtin_amdgcn_readfirstlane((int)S.glist[0]);
-#pragma unroll
-  for (int j = 0; j < NLD; ++j) S.bslot[0][j * 64 + lane] = *bsrc(ksfirst, j);
-  float4 x0[2][2], x1[2][2];       // [buffer = item parity][row block]
-  gather(0, ksfirst / NS, ksfirst % NS, x0[0], x1[0]);
-  gather(1, ksfirst / NS, ksfirst % NS, x0[1], x1[1]);
-  Split8 acur[2];
-#pragma unroll
-  for (int rb = 0; rb < 2; ++rb) acur[rb] = split8(x0[0][rb], x1[0][rb], true);
-
-  for (int gi = 0; gi < n_groups; ++gi) {
-    const int ks = __builtin_amdgcn_readfirstlane((int)S.glist[gi]);
-    const int ksn = __builtin_amdgcn_readfirstlane((int)S.glist[gi + 1 < n_groups ? gi + 1 : n_groups - 1]);
-    constexpr int SLOTS = Lds::SLOTS;
-    const u32x4 *bs = S.bslot[SLOTS == 2 ? (gi & 1) : 0];
-    u32x4 *bsn = S.bslot[SLOTS == 2 ? ((gi + 1) & 1) : 0];
-    u32x4 btmp[NLD];
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-      Split8 anext[2];
-      if (t == 0) {
-#pragma unroll
-        for (int j = 0; j < NLD; ++j) btmp[j] = *bsrc(ksn, j);
-      }
-      const int ksx = (t + 2 < T) ? ks : ksn;
-      gather((t + 2) % T, ksx / NS, ksx % NS, x0[t & 1], x1[t & 1]);
-      // the scheduler models a load as ~100 cycles away; keep the issue (above) and the consumers (next item) in
-      // separate scheduling regions so the rows are in flight for a whole item
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {
-        const int u = g * COUT_T + nb * 16 + li;
-        const u32x4 bh = bs[u], bm = bs[PU + u], bl = bs[2 * PU + u];
-        // smallest terms first; consecutive MFMAs alternate between the row blocks' accumulators
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb) acc[t][rb][nb] = MFMA_BF16(acur[rb].l, bh, acc[t][rb][nb]);
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb) acc[t][rb][nb] = MFMA_BF16(acur[rb].m, bm, acc[t][rb][nb]);
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb) acc[t][rb][nb] = MFMA_BF16(acur[rb].h, bl, acc[t][rb][nb]);
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb) acc[t][rb][nb] = MFMA_BF16(acur[rb].m, bh, acc[t][rb][nb]);
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb) acc[t][rb][nb] = MFMA_BF16(acur[rb].h, bm, acc[t][rb][nb]);
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb) acc[t][rb][nb] = MFMA_BF16(acur[rb].h, bh, acc[t][rb][nb]);
-      }
-#pragma unroll
-      for (int rb = 0; rb < 2; ++rb) anext[rb] = split8(x0[(t + 1) & 1][rb], x1[(t + 1) & 1][rb], true);
-#pragma unroll
-      for (int rb = 0; rb < 2; ++rb) acur[rb] = anext[rb];
-      // one wave per SIMD: nothing else hides this wave's VALU / LDS work, so prescribe the interleave -- every MFMA
-      // (16 cycles of matrix-core time) is followed by SPC9_VPM other instructions of the split / address work
-#ifndef SPC9_VPM
-#define SPC9_VPM 3
-#endif
-#if SPC9_VPM > 0
-#pragma unroll
-      for (int i = 0; i < 6 * 2 * NB; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);             // 1 MFMA
-        if (i % 4 == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read (3 B fragments per 12 MFMAs)
-        __builtin_amdgcn_sched_group_barrier(0x002, SPC9_VPM, 0);      // VALU
-      }
-#endif
-      __builtin_amdgcn_sched_barrier(0);
-      if (SLOTS == 2 ? t == 1 : t == T - 1) {     // one slot: after the group's last read of it (LDS is in order)
-#pragma unroll
-        for (int j = 0; j < NLD; ++j) bsn[j * 64 + lane] = btmp[j];
-      }
-    }
-  }
-
-  // epilogue: lane (g, li) holds rows 4g+j, output channels NB*li .. NB*li+NB-1
-  VecF<NB> bv;
-#pragma unroll
-  for (int nb = 0; nb < NB; ++nb) bv.v[nb] = bias ? bias[NB * li + nb] : 0.f;
-#pragma unroll
-  for (int t = 0; t < T; ++t)
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int64_t row = S.orow[t * 32 + rb * 16 + 4 * g + j];
-        if (row < 0) continue;
-        float o[NB];
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-          float v = acc[t][rb][nb][j] + bv.v[nb];
-          o[nb] = v > 0.f ? v : v * slope;
-        }
-        float *dst = out + row * COUT_T + NB * li;
-        if constexpr (NB == 4)
-          *reinterpret_cast<float4 *>(dst) = make_float4(o[0], o[1], o[2], o[3]);
-        else
-          *reinterpret_cast<float2 *>(dst) = make_float2(o[0], o[1]);
-      }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1236,10 +982,6 @@ extern "C" int rslo_weight_split_many(const RsloWeightSplitDesc *desc_dev, int n
   return RSLO_OK;
 }
 
-// -1: choose by size; 0: always v6; 2 / 4: v9 with that many 32-row tiles per wave (tuning / A-B knob)
-static int spc_v9_mode = getenv("RSLO_SPCONV_V9") ? atoi(getenv("RSLO_SPCONV_V9")) : -1;
-extern "C" void rslo_spconv_set_v9(int mode) { spc_v9_mode = mode; }
-
 extern "C" void rslo_spconv_set_tiling(int rbw, int ks) {
   spc_force_rbw = (rbw == 1 || rbw == 2 || rbw == 4) ? rbw : 0;
   spc_force_ks = (ks == 1 || ks == 2 || ks == 4) ? ks : 0;
@@ -1253,40 +995,21 @@ extern "C" int rslo_spconv_fwd_split(const float *in, int cin, const void *Ws, c
   RSLO_CHECK_ARG(K >= 1 && K <= SPC_MAXK, "spconv_fwd_split: K must be in 1..27");
   if (n_out == 0) return RSLO_OK;
   const unsigned short *ws = (const unsigned short *)Ws;
-  // v9 (T tiles of 32 rows per wave, weights reused across them): RSLO_SPCONV_V9 = T forces it, 0 disables it
-  const int64_t tiles32 = rslo_cdiv(n_out, 32);
-  (void)tiles32;
-  const int v9_t = spc_v9_mode > 0 ? spc_v9_mode : 0;      // measured slower than v6 on every layer shape: opt-in only
-  if (v9_t > 0) {
-#define SPC9_LAUNCH(CI, CO, TT)                                                                              \
-    {                                                                                                        \
-      static bool attr_set = false;                                                                          \
-      const size_t lds = SPC_WAVES * sizeof(Spc9Lds<CI, CO, TT>);                                            \
-      if (!attr_set) {                                                                                       \
-        RSLO_HIP(hipFuncSetAttribute((const void *)k_spconv_v9<CI, CO, TT>,                                  \
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                 \
-        attr_set = true;                                                                                     \
-      }                                                                                                      \
-      hipLaunchKernelGGL((k_spconv_v9<CI, CO, TT>), dim3(xcd_grid(rslo_cdiv(rslo_cdiv(n_out, 32 * TT), 4))), \
-                         dim3(SPC_THREADS), lds, st, in, ws, bias, nbr, row_order, n_out, K, flip_k, act_slope, out); \
-    }
-#define SPC9_CASE(CI, CO)                                                                                    \
-    if (cin == CI && cout == CO) {                                                                           \
-      if (v9_t >= 4) SPC9_LAUNCH(CI, CO, 4)                                                                  \
-      else SPC9_LAUNCH(CI, CO, 2)                                                                            \
-    }
-    SPC9_CASE(32, 32) SPC9_CASE(32, 64) SPC9_CASE(64, 32) SPC9_CASE(64, 64)
-#undef SPC9_CASE
-#undef SPC9_LAUNCH
-    RSLO_CHECK_LAUNCH("spconv_v9");
-    return RSLO_OK;
-  }
   const int force_rbw = spc_force_rbw, force_ks = spc_force_ks;
   int rbw = force_rbw ? force_rbw : ((n_out >= 256 * 32 * 8) ? 2 : 1);
   // measured per layer shape (profiles/r02_spconv_offset_split.txt): two waves per 32-row tile win everywhere except
   // 32 -> 32 (the cheapest products per gathered row: the LDS hand-over costs more than the shorter chain saves)
-  const int ks = force_ks ? force_ks : ((cin == 32 && cout == 32) ? 1 : 2);
+  int ks = force_ks ? force_ks : ((cin == 32 && cout == 32) ? 1 : 2);
   if (!force_rbw && ks == 2) rbw = 2;
+  // Small problems (a single frame: BASELINE config C2, levels of 2.6 k .. 18 k rows): even with two waves per tile most
+  // SIMDs hold no wave at all and a launch lasts as long as ONE tile's chain of ~11 offsets x (weights + gather ->
+  // split -> MFMA).  16-row tiles shared by four waves quarter the chain: whole forward pass of one frame 0.83 ->
+  // 0.68 ms (scripts/bench_encoder.py c2; R1K2 0.69, R2K4 0.67, R1K1 0.96).  Above ~20 k rows the LDS hand-over of four
+  // waves costs more than the shorter chain returns (profiles/r02_spconv_offset_split.txt).
+  if (!force_rbw && !force_ks && n_out < 20000) {
+    rbw = 1;
+    ks = 4;
+  }
 #define SPC6_LAUNCH(CI, CO, RB, KSv)                                                                        \
   hipLaunchKernelGGL((k_spconv_v6<CI, CO, RB, KSv>), dim3(xcd_grid(rslo_cdiv(rslo_cdiv(n_out, 16 * RB), 4 / KSv))), \
                      dim3(SPC_THREADS), 0, st, in, ws, bias, nbr, row_order, n_out, K, flip_k, act_slope, out)

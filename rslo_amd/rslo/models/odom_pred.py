@@ -100,10 +100,15 @@ class UNOdomPredEncDecSVDTempMaskBase(OdomPredEncDecBase):
         if not self.track_masks:
             x = [x, None]
         ups = []
-        for blk, skip in zip(self.blocks, self.skip_blocks):
+        side_work = self.__dict__.pop("_side_work", None)      # (mark, launch) of work for a second stream, see
+        for i, (blk, skip) in enumerate(zip(self.blocks, self.skip_blocks)):   # voxel_odom_net.network_forward
+            if i == 1 and side_work is not None:
+                side_work[0]()      # the half- / quarter-resolution stages start here: launches of ~1 workgroup per CU
             x = blk(x)
             ups.append(skip(x[0]))
         x = x[0]
+        if side_work is not None:
+            side_work[1]()          # created HERE in the graph: in backward it is issued right before the stages above
 
         py_masks = []
         if self.pred_pyramid_motion:

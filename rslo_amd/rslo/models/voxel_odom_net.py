@@ -29,6 +29,8 @@ from rslo.data.dataset import _grid_geometry as _tq_map_geometry
 from rslo.data.dataset import generate_pointwise_local_transformation_tch
 from rslo.models import middle, odom_pred, voxel_encoder
 
+_SIDE_STREAMS = {}
+
 REGISTERED_NETWORK_CLASSES = {}
 
 
@@ -263,19 +265,37 @@ class UnVoxelOdomNetICP3(nn.Module):
             middle_conf_preds = list(cov.split([f.shape[0] for f in voxel_features], dim=0))
         self.end_timer("middle forward")
 
+        if cov_fn is not None:
+            # The covariance branch on its own stream.  It meets the rest of the network again only in the loss, and its
+            # six level-1 / level-0 layers fill the GPU, while the head's half- and quarter-resolution stages (10 residual
+            # blocks on 24 x 44 / 12 x 22 maps) launch about one workgroup per CU.  It is issued from INSIDE the head's
+            # forward, after the encoder stages: the stream waits for the event recorded where those stages begin, so it
+            # runs beside them in forward, and -- its graph nodes being created at that point -- autograd issues its
+            # backward right before theirs (every node replays on the stream of its forward).
+            cur = torch.cuda.current_stream(feats_all.device)
+            side = _SIDE_STREAMS.get(feats_all.device)       # per device, outside the module: deepcopy / pickle of a
+            if side is None:                                 # network must not meet a stream object
+                side = _SIDE_STREAMS[feats_all.device] = torch.cuda.Stream(feats_all.device)
+            box = {}
+            gate = torch.cuda.Event()
+
+            def mark():
+                gate.record(cur)
+
+            def launch():
+                side.wait_event(cov_fn.ready)
+                side.wait_event(gate)
+                cov_fn.source.record_stream(side)
+                with torch.cuda.stream(side):
+                    box["cov"] = cov_fn()
+            if os.environ.get("RSLO_COV_STREAM", "1") != "2":      # "2": issued behind the whole head, no gate (A/B runs)
+                self.odom_predictor.__dict__["_side_work"] = (mark, launch)
         preds_dict = self.odom_predictor(spatial_features, tq_map_gt=example.get("tq_maps", [None])[0])
         if cov_fn is not None:
-            # the covariance branch on its own stream, issued BEHIND the head: it starts as soon as the level-2 tensor
-            # exists (event), so it runs beside the tail + head in forward, and -- created last, hence first in the
-            # engine's queue -- beside the head's backward
-            cur = torch.cuda.current_stream(feats_all.device)
-            side = self.__dict__.get("_cov_stream")
-            if side is None or side.device != feats_all.device:
-                side = self.__dict__["_cov_stream"] = torch.cuda.Stream(feats_all.device)
-            side.wait_event(cov_fn.ready)
-            cov_fn.source.record_stream(side)
-            with torch.cuda.stream(side):
-                cov = cov_fn()
+            if "cov" not in box:        # a head without the hook points (registry variant): run the branch now
+                self.odom_predictor.__dict__.pop("_side_work", None)
+                launch()
+            cov = box["cov"]
             cur.wait_stream(side)
             cov.record_stream(cur)
             middle_conf_preds = list(cov.split([f.shape[0] for f in voxel_features], dim=0))

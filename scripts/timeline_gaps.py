@@ -1,0 +1,40 @@
+"""Post-process a rocprofv3 kernel-trace CSV: for the last steady-state step (window between two k_conv2d_wsplit_many
+launches) print per queue: busy time, idle gaps, and how the busy time splits by launch size (workgroups per launch)."""
+import csv, sys, collections
+path = sys.argv[1]
+rows = []
+with open(path) as f:
+    for d in csv.DictReader(f):
+        wg = max(1, int(d.get("Workgroup_Size_X", d.get("Workgroup_Size", "1")) or 1))
+        grid = int(d.get("Grid_Size_X", d.get("Grid_Size", "0")) or 0) * max(1, int(d.get("Grid_Size_Y", "1") or 1))
+        wgy = max(1, int(d.get("Workgroup_Size_Y", "1") or 1))
+        rows.append((int(d["Start_Timestamp"]), int(d["End_Timestamp"]), d["Kernel_Name"], d.get("Queue_Id", "0"),
+                     grid // (wg * wgy) if grid else 0))
+rows.sort()
+marks = [s for s, e, n, q, g in rows if n.startswith("k_conv2d_wsplit_many")]
+t0, t1 = marks[-3], marks[-2]
+sel = [r for r in rows if t0 <= r[0] < t1]
+print("window %.3f ms, %d dispatches" % ((t1 - t0) / 1e6, len(sel)))
+byq = collections.defaultdict(list)
+for r in sel:
+    byq[r[3]].append(r)
+for q, rs in sorted(byq.items(), key=lambda kv: -len(kv[1])):
+    busy = sum(e - s for s, e, *_ in rs) / 1e6
+    gaps = [(rs[i + 1][0] - rs[i][1]) for i in range(len(rs) - 1)]
+    gap_pos = sum(g for g in gaps if g > 0) / 1e6
+    print("queue %s: %d launches, busy %.3f ms, idle between launches %.3f ms (gaps > 5 us: %d, sum %.3f ms)" % (
+        q, len(rs), busy, gap_pos, sum(1 for g in gaps if g > 5000), sum(g for g in gaps if g > 5000) / 1e6))
+    buckets = collections.OrderedDict([("<64 wg", 0.0), ("64-255", 0.0), ("256-1023", 0.0), ("1024-4095", 0.0), (">=4096", 0.0)])
+    cnt = collections.Counter()
+    for s, e, n, _, g in rs:
+        k = "<64 wg" if g < 64 else "64-255" if g < 256 else "256-1023" if g < 1024 else "1024-4095" if g < 4096 else ">=4096"
+        buckets[k] += (e - s) / 1e6
+        cnt[k] += 1
+    print("   busy by launch size:", {k: (cnt[k], round(v, 3)) for k, v in buckets.items()})
+    small = collections.defaultdict(lambda: [0, 0.0])
+    for s, e, n, _, g in rs:
+        if g < 256:
+            small[n[:60]][0] += 1
+            small[n[:60]][1] += (e - s) / 1e6
+    for n, (c, t) in sorted(small.items(), key=lambda kv: -kv[1][1])[:14]:
+        print("      %4d %7.3f ms  %s" % (c, t, n))

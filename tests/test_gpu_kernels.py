@@ -175,39 +175,6 @@ def test_conv_results_do_not_depend_on_row_order(hip, cin, cout):
 
 
 @pytest.mark.parametrize("cin,cout", [(32, 32), (64, 64), (32, 64), (64, 32)])
-def test_multi_tile_wave_form_gives_the_same_bits(hip, cin, cout):
-    """rslo_spconv_set_v9: T tiles per wave with the weight operands reused through the wave's LDS ring (k_spconv_v9)
-    issues the same products in the same order per accumulator as the default one-tile form -> identical bits, for
-    forward, data gradient (flip_k), with a row order, and at ragged / tiny sizes."""
-    rng = np.random.default_rng(cin * 3 + cout)
-    dims = [9, 60, 70]
-    L = hip.lib()
-    try:
-        for n in (1, 33, 5000, 8200 + 17):
-            coords = rand_sites(rng, 2, dims, n)
-            idx = hip.SiteIndex(dev(coords), 2, dims)
-            nbr = hip.rulebook_subm(idx, [3, 3, 3])
-            x = torch.randn(len(coords), cin, device="cuda")
-            W = torch.randn(27, cin, cout, device="cuda") * 0.1
-            b = torch.randn(cout, device="cuda")
-            g = torch.randn(len(coords), cout, device="cuda")
-            order = hip.rulebook_row_order(nbr)
-            L.rslo_spconv_set_v9(0)
-            L.rslo_spconv_set_tiling(2, 1)       # the one-wave-per-tile form v9 mirrors
-            ref = [hip.spconv_fwd(x, W, b, nbr, act_slope=0.01), hip.spconv_dgrad(g, W, nbr, flip_k=True),
-                   hip.spconv_fwd(x, W, b, nbr, act_slope=0.01, order=order)]
-            for mode in (2, 4):
-                L.rslo_spconv_set_v9(mode)
-                got = [hip.spconv_fwd(x, W, b, nbr, act_slope=0.01), hip.spconv_dgrad(g, W, nbr, flip_k=True),
-                       hip.spconv_fwd(x, W, b, nbr, act_slope=0.01, order=order)]
-                for a, r in zip(got, ref):
-                    assert torch.equal(a, r), (mode, n)
-    finally:
-        L.rslo_spconv_set_v9(-1)
-        L.rslo_spconv_set_tiling(0, 0)
-
-
-@pytest.mark.parametrize("cin,cout", [(32, 32), (64, 64), (32, 64), (64, 32)])
 def test_offset_split_tilings_agree(hip, cin, cout):
     """rslo_spconv_set_tiling: every (rows per tile, waves per tile) form of k_spconv_v6 computes the same products; only
     the order in which the per-offset sums meet differs (ks waves are added through LDS in wave order).  All forms
