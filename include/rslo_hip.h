@@ -288,6 +288,16 @@ RSLO_API int rslo_dense_scatter(const float *feat, const int32_t *coords, int64_
                        const int32_t *h_dims3, float *out, void *stream);
 RSLO_API int rslo_dense_gather(const float *dense, const int32_t *coords, int64_t M, int C, int B,
                       const int32_t *h_dims3, float *dfeat, void *stream);
+/*     The same with the frames of a sample side by side: the batch holds frame t of sample b at index t * (B / frames) + b
+ *     and the dense tensor is [B / frames, frames, C, D, H, W] = the channel concatenation the BEV head builds from a
+ *     pair's frames (rslo/models/odom_pred.py:170, odom_pred_base.py:305-324), produced without a copy. */
+RSLO_API int rslo_dense_scatter_frames(const float *feat, const int32_t *coords, int64_t M, int C, int B, int frames,
+                                       const int32_t *h_dims3, float *out, void *stream);
+RSLO_API int rslo_dense_gather_frames(const float *dense, const int32_t *coords, int64_t M, int C, int B, int frames,
+                                      const int32_t *h_dims3, float *dfeat, void *stream);
+/*     Per-cell sums over each of the G channel groups of a BEV tensor [B, G*Cg, HW] -> [B, G, HW] in one pass: feeds the
+ *     occupancy masks (odom_pred.py:165-168; voxel_odom_net.py:519-527) and the logged channel means. */
+RSLO_API int rslo_bev_channel_sums(const float *in, int B, int G, int Cg, int64_t HW, float *out, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * a17  Chamfer nearest neighbour.  Replaces cd.forward_cuda_one_direction /

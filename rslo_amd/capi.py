@@ -63,6 +63,9 @@ SIGNATURES = {
     "rslo_segbn_bwd": (C.c_int, [_vp, _vp, _vp, _i, _vp, _i, _i64, _vp, _vp, _vp, _f, _vp, _sz, _vp, _vp, _vp, _vp]),
     "rslo_dense_scatter": (C.c_int, [_vp, _vp, _i64, _i, _i, _vp, _vp, _vp]),
     "rslo_dense_gather": (C.c_int, [_vp, _vp, _i64, _i, _i, _vp, _vp, _vp]),
+    "rslo_dense_scatter_frames": (C.c_int, [_vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp]),
+    "rslo_dense_gather_frames": (C.c_int, [_vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp]),
+    "rslo_bev_channel_sums": (C.c_int, [_vp, _i, _i, _i, _i64, _vp, _vp]),
     "rslo_chamfer_ws_bytes": (_sz, [_i, _i, _i]),
     "rslo_chamfer_nn": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "rslo_chamfer_nn_ragged": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -627,19 +630,31 @@ def segbn_bwd(x, y, gy, seg_off, S, max_len, gamma, mean, invstd, act_slope):
     return gx, dgamma, dbeta
 
 
-def dense_scatter(feat, coords, batch, dims):
+def dense_scatter(feat, coords, batch, dims, frames=1):
+    """[M,C] rows -> [batch, C, D, H, W]; frames > 1: [batch / frames, frames, C, D, H, W] (rows of frame t of sample b
+    carry the batch index t * (batch / frames) + b)."""
     M, Cc = feat.shape
-    out = torch.empty((batch, Cc, dims[0], dims[1], dims[2]), dtype=torch.float32, device=feat.device)
-    _chk(lib().rslo_dense_scatter(_ptr(feat, torch.float32, "feat"), _ptr(coords, torch.int32, "coords"), M, Cc,
-                                  int(batch), _i3(dims), _ptr(out), _stream()), "rslo_dense_scatter")
+    shape = (batch, Cc, dims[0], dims[1], dims[2]) if frames == 1 else (batch // frames, frames, Cc, dims[0], dims[1], dims[2])
+    out = torch.empty(shape, dtype=torch.float32, device=feat.device)
+    _chk(lib().rslo_dense_scatter_frames(_ptr(feat, torch.float32, "feat"), _ptr(coords, torch.int32, "coords"), M, Cc,
+                                         int(batch), int(frames), _i3(dims), _ptr(out), _stream()), "rslo_dense_scatter")
     return out
 
 
-def dense_gather(dense, coords, C_, batch, dims):
+def dense_gather(dense, coords, C_, batch, dims, frames=1):
     M = coords.shape[0]
     out = torch.empty((M, C_), dtype=torch.float32, device=dense.device)
-    _chk(lib().rslo_dense_gather(_ptr(dense, torch.float32, "dense"), _ptr(coords, torch.int32, "coords"), M, C_,
-                                 int(batch), _i3(dims), _ptr(out), _stream()), "rslo_dense_gather")
+    _chk(lib().rslo_dense_gather_frames(_ptr(dense, torch.float32, "dense"), _ptr(coords, torch.int32, "coords"), M, C_,
+                                        int(batch), int(frames), _i3(dims), _ptr(out), _stream()), "rslo_dense_gather")
+    return out
+
+
+def bev_channel_sums(bev, groups):
+    """bev [B, groups * Cg, H, W] fp32 -> [B, groups, H, W]: per-cell sum over each channel group, one pass."""
+    B, Ct, H, W = bev.shape
+    out = torch.empty((B, groups, H, W), dtype=torch.float32, device=bev.device)
+    _chk(lib().rslo_bev_channel_sums(_ptr(bev, torch.float32, "bev"), B, int(groups), Ct // int(groups), H * W, _ptr(out),
+                                     _stream()), "rslo_bev_channel_sums")
     return out
 
 

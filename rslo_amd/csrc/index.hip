@@ -740,14 +740,18 @@ extern "C" int rslo_vfe_mean(const float *voxels, const int32_t *num_points, int
 // ---------------------------------------------------------------------------------------
 // dense scatter / gather (a8)
 // ---------------------------------------------------------------------------------------
+// frames > 1: the batched encoder tensor holds frame t of sample b at batch index t * B + b, and the dense tensor is laid
+// out [B, frames, C, D, H, W] -- viewed [B, frames * C * D, H, W] it IS the channel concatenation of a sample's frames that
+// the BEV head builds (rslo/models/odom_pred.py:170 `torch.cat(xs, dim=1)`), with no copy.
 template <bool GATHER>
 __global__ void k_dense(float *__restrict__ feat, const int32_t *__restrict__ coords, int64_t M, int C,
-                        Dims3 s, float *__restrict__ dense) {
+                        Dims3 s, float *__restrict__ dense, int B, int frames) {
   int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= M * C) return;
   const int64_t r = t % M;
   const int ch = (int)(t / M);
-  const int4 c = reinterpret_cast<const int4 *>(coords)[r];
+  int4 c = reinterpret_cast<const int4 *>(coords)[r];
+  if (frames > 1) c.x = (c.x % B) * frames + c.x / B;
   const int64_t vol = (int64_t)s.d * s.h * s.w;
   const int64_t off = ((int64_t)c.x * C + ch) * vol + ((int64_t)c.y * s.h + c.z) * s.w + c.w;
   if (GATHER)
@@ -756,25 +760,63 @@ __global__ void k_dense(float *__restrict__ feat, const int32_t *__restrict__ co
     dense[off] = feat[r * C + ch];
 }
 
+static int dense_run(bool gather, float *feat, const int32_t *coords, int64_t M, int C, int B, int frames,
+                     const int32_t *d, float *dense, hipStream_t st) {
+  RSLO_CHECK_ARG(frames >= 1 && B >= 1 && B % frames == 0, "dense: the batch must hold whole frames");
+  if (!gather) RSLO_HIP(hipMemsetAsync(dense, 0, (size_t)B * C * d[0] * d[1] * d[2] * sizeof(float), st));
+  if (M == 0) return RSLO_OK;
+  const unsigned nb = (unsigned)rslo_cdiv(M * C, 256);
+  if (gather)
+    hipLaunchKernelGGL(k_dense<true>, dim3(nb), dim3(256), 0, st, feat, coords, M, C, Dims3{d[0], d[1], d[2]}, dense,
+                       B / frames, frames);
+  else
+    hipLaunchKernelGGL(k_dense<false>, dim3(nb), dim3(256), 0, st, feat, coords, M, C, Dims3{d[0], d[1], d[2]}, dense,
+                       B / frames, frames);
+  RSLO_CHECK_LAUNCH("dense");
+  return RSLO_OK;
+}
+
 extern "C" int rslo_dense_scatter(const float *feat, const int32_t *coords, int64_t M, int C, int B,
                                   const int32_t *d, float *out, void *stream) {
-  hipStream_t st = (hipStream_t)stream;
-  RSLO_HIP(hipMemsetAsync(out, 0, (size_t)B * C * d[0] * d[1] * d[2] * sizeof(float), st));
-  if (M == 0) return RSLO_OK;
-  hipLaunchKernelGGL(k_dense<false>, dim3((unsigned)rslo_cdiv(M * C, 256)), dim3(256), 0, st,
-                     const_cast<float *>(feat), coords, M, C, Dims3{d[0], d[1], d[2]}, out);
-  RSLO_CHECK_LAUNCH("dense_scatter");
-  return RSLO_OK;
+  return dense_run(false, const_cast<float *>(feat), coords, M, C, B, 1, d, out, (hipStream_t)stream);
 }
 
 extern "C" int rslo_dense_gather(const float *dense, const int32_t *coords, int64_t M, int C, int B,
                                  const int32_t *d, float *dfeat, void *stream) {
-  (void)B;
-  if (M == 0) return RSLO_OK;
-  hipLaunchKernelGGL(k_dense<true>, dim3((unsigned)rslo_cdiv(M * C, 256)), dim3(256), 0,
-                     (hipStream_t)stream, dfeat, coords, M, C, Dims3{d[0], d[1], d[2]},
-                     const_cast<float *>(dense));
-  RSLO_CHECK_LAUNCH("dense_gather");
+  return dense_run(true, dfeat, coords, M, C, B, 1, d, const_cast<float *>(dense), (hipStream_t)stream);
+}
+
+extern "C" int rslo_dense_scatter_frames(const float *feat, const int32_t *coords, int64_t M, int C, int B, int frames,
+                                         const int32_t *d, float *out, void *stream) {
+  return dense_run(false, const_cast<float *>(feat), coords, M, C, B, frames, d, out, (hipStream_t)stream);
+}
+
+extern "C" int rslo_dense_gather_frames(const float *dense, const int32_t *coords, int64_t M, int C, int B, int frames,
+                                        const int32_t *d, float *dfeat, void *stream) {
+  return dense_run(true, dfeat, coords, M, C, B, frames, d, const_cast<float *>(dense), (hipStream_t)stream);
+}
+
+// Per-cell channel sums of a BEV tensor [B, G * Cg, HW] over each of its G channel groups -> [B, G, HW] in ONE pass.
+// The head and the logging extras of the training forward need, per frame of a sample, "is any channel non-zero"
+// (odom_pred.py:165-168 input mask, voxel_odom_net.py:519-527 feature mask) and the channel mean (middle_feature): four
+// torch reductions over 35-70 MB plus a 70 MB concatenation; here the tensor is read once.  Channels are added in
+// ascending order by one thread per cell (coalesced across cells).
+__global__ void k_bev_channel_sums(const float *__restrict__ in, int G, int Cg, int64_t HW, float *__restrict__ out) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= HW) return;
+  const int g = blockIdx.y, b = blockIdx.z;
+  const float *src = in + ((int64_t)(b * G + g) * Cg) * HW + p;
+  float s = 0.f;
+  for (int c = 0; c < Cg; ++c) s = __fadd_rn(s, src[(int64_t)c * HW]);
+  out[(int64_t)(b * G + g) * HW + p] = s;
+}
+
+extern "C" int rslo_bev_channel_sums(const float *in, int B, int G, int Cg, int64_t HW, float *out, void *stream) {
+  RSLO_CHECK_ARG(in && out && B >= 1 && G >= 1 && Cg >= 1 && HW >= 1 && B < 65536 && G < 65536,
+                 "rslo_bev_channel_sums: bad arguments");
+  hipLaunchKernelGGL(k_bev_channel_sums, dim3((unsigned)rslo_cdiv(HW, 256), (unsigned)G, (unsigned)B), dim3(256), 0,
+                     (hipStream_t)stream, in, G, Cg, HW, out);
+  RSLO_CHECK_LAUNCH("k_bev_channel_sums");
   return RSLO_OK;
 }
 

@@ -90,11 +90,23 @@ class UNOdomPredEncDecSVDTempMaskBase(OdomPredEncDecBase):
             hip_conv2d.presplit(self)       # split-bf16 operands of all 3x3 layers for this step, one launch
         if self._cycle_constraint:
             xs = self.create_cycle_constraint_data(xs)
+        # two frames whose maps are channel slices of ONE tensor (voxel_odom_net.network_forward / rslo_dense_scatter_frames):
+        # that tensor is the concatenation, and one pass over it gives the per-frame channel sums
+        base = getattr(xs[0], "_pair_base", None) if len(xs) == 2 else None
+        if base is not None and not (base.is_cuda and base.shape[1] == xs[0].shape[1] + xs[1].shape[1]
+                                     and xs[0].data_ptr() == base.data_ptr()):
+            base = None
+        bev_sums = None
         with torch.no_grad():   # occupancy of the FIRST frame of each pair only (odom_pred.py:165-168)
-            input_mask_bool = xs[0].sum(dim=1, keepdim=True) != 0
+            if base is not None and base.dtype == torch.float32:
+                from rslo_amd import capi
+                bev_sums = capi.bev_channel_sums(base.detach(), 2)
+                input_mask_bool = bev_sums[:, 0:1] != 0
+            else:
+                input_mask_bool = xs[0].sum(dim=1, keepdim=True) != 0
             input_mask = input_mask_bool.to(dtype=xs[0].dtype)
 
-        x = torch.cat(xs, dim=1)
+        x = base if base is not None else torch.cat(xs, dim=1)
         if getattr(self, "channels_last", False):     # experiment switch (bench.py RSLO_HEAD_NHWC=1), see DESIGN.md
             x = x.contiguous(memory_format=torch.channels_last)
         if not self.track_masks:
@@ -166,7 +178,8 @@ class UNOdomPredEncDecSVDTempMaskBase(OdomPredEncDecBase):
                 r = torch.cat([q[..., 3:], q[..., :3]], dim=-1)
             translations.append(t)
             rotations.append(r)
-        return {"translation_preds": translations, "rotation_preds": rotations, "tq_map_g": tq_map_g * input_mask,
+        extra = {} if bev_sums is None else {"_bev_sums": bev_sums}
+        return {**extra, "translation_preds": translations, "rotation_preds": rotations, "tq_map_g": tq_map_g * input_mask,
                 "pyramid_motion": pyramid_motion, "transformed_inputs": None, "t_conf": t_conf, "r_conf": r_conf}
 
     def _snapshot_bn(self, modules):

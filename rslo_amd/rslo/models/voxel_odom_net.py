@@ -254,13 +254,21 @@ class UnVoxelOdomNetICP3(nn.Module):
             plan = self.middle_feature_extractor.plan(self._merge_coords(coors, batch_size), T * batch_size)
         feats_all = torch.cat(voxel_features, 0) if vf_all is None else vf_all
         two_streams = feats_all.is_cuda and os.environ.get("RSLO_COV_STREAM", "1") != "0"
+        # two frames per sample on the GPU: the encoder writes its BEV map with a sample's frames side by side, which IS the
+        # tensor the head would build with torch.cat (70 MB per step and the same again for the gradient's split)
+        pair_bev = T == 2 and feats_all.is_cuda and os.environ.get("RSLO_PAIR_BEV", "1") != "0"
         bev, cov = self.middle_feature_extractor(feats_all, plan.indices, T * batch_size, plan=plan,
-                                                 defer_cov=two_streams)
+                                                 defer_cov=two_streams, bev_frames=T if pair_bev else 1)
         cov_fn = cov if two_streams else None
         exchange = self.__dict__.get("_grad_exchange")      # data parallel: the head's gradient bucket leaves when the
         if exchange is not None:                            # gradient of the BEV map is complete (distributed_utils)
             exchange.watch(bev)
-        spatial_features = list(bev.split(batch_size, dim=0))
+        if pair_bev:
+            spatial_features = list(bev.split(bev.shape[1] // T, dim=1))         # channel-slice views, one per frame
+            for f in spatial_features:
+                f._pair_base = bev
+        else:
+            spatial_features = list(bev.split(batch_size, dim=0))
         if cov_fn is None:
             middle_conf_preds = list(cov.split([f.shape[0] for f in voxel_features], dim=0))
         self.end_timer("middle forward")
@@ -300,8 +308,13 @@ class UnVoxelOdomNetICP3(nn.Module):
             cov.record_stream(cur)
             middle_conf_preds = list(cov.split([f.shape[0] for f in voxel_features], dim=0))
         with torch.no_grad():
-            preds_dict["feature_mask"] = (torch.cat(spatial_features, dim=1).sum(dim=1, keepdim=True) != 0).float()
-            disp = [f.mean(dim=1, keepdim=True) for f in spatial_features]
+            sums = preds_dict.pop("_bev_sums", None)       # [B, T, H, W] per-frame channel sums the head already made
+            if sums is not None:
+                preds_dict["feature_mask"] = (sums.sum(dim=1, keepdim=True) != 0).float()
+                disp = [sums[:, t:t + 1] / float(spatial_features[t].shape[1]) for t in range(T)]
+            else:
+                preds_dict["feature_mask"] = (torch.cat(spatial_features, dim=1).sum(dim=1, keepdim=True) != 0).float()
+                disp = [f.mean(dim=1, keepdim=True) for f in spatial_features]
             preds_dict["middle_feature"] = [(d - d.min()) / (d.max() - d.min() + 1e-12) for d in disp]
         preds_dict["middle_conf_preds"] = middle_conf_preds
         preds_dict["voxel_features"] = voxel_features

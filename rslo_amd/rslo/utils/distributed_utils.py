@@ -46,6 +46,9 @@ def _host_group():
         return dist.group.WORLD
     if "g" not in _HOST_GROUP:
         try:
+            if os.environ.get("MASTER_ADDR", "") in ("127.0.0.1", "localhost"):
+                # single-node launch: gloo would look its interface up through the host NAME, which need not resolve
+                os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
             _HOST_GROUP["g"] = dist.new_group(backend="gloo")
         except Exception:
             _HOST_GROUP["g"] = None
