@@ -187,6 +187,31 @@ RSLO_API int rslo_rulebook_row_order(const int32_t *nbr, int64_t n_rows, int K, 
 RSLO_API size_t rslo_rulebook_pairs_ws_bytes(int64_t n_rows, int K);
 RSLO_API int rslo_rulebook_pairs(const int32_t *nbr, int64_t n_rows, int K, void *ws, size_t ws_bytes,
                         int32_t *pairs_in, int32_t *pairs_out, int32_t *koff /*[K+1]*/, void *stream);
+/* a21  Loss assembly in one launch each way: AdaptiveWeightedL2Loss of the voted pose against the ICP pseudo-targets
+ *      (rslo/core/losses.py:144-197; mask = ones, focal_gamma = 0), the same reduction of the pyramid levels' per-sample
+ *      terms (rslo/models/voxel_odom_net.py:743-798; loss_b from rslo_pyramid_l2_fwd), the consistency loss's reduce over
+ *      the per-pair terms (losses.py:496-506) and the weighted total (voxel_odom_net.py:324-376).
+ *      out5 = (total, T, R, pyramid, C).  Pointers are device pointers; alpha_* point at the modules' log-variance
+ *      parameters (they may alias: the shipped configuration uses the SAME modules for pose and pyramid terms). */
+#define RSLO_LOSS_TAIL_MAX_LEVELS 8
+typedef struct {
+  const float *t_pred, *t_tgt;        /* [B,3] */
+  const float *q_pred, *q_tgt;        /* [B,4] (w,x,y,z) */
+  const float *alpha_T, *alpha_R;     /* [1] each */
+  const float *pyr_loss_b;            /* [L,B,2] or NULL */
+  const float *alpha_pT, *alpha_pR;
+  const float *pair_loss;             /* [n_pairs] or NULL */
+  const float *alpha_C;
+  int32_t B, L, n_pairs, reserved;
+  float w_T, w_R, w_pT, w_pR;         /* the modules' _loss_weight */
+  float c_scale;                      /* (1 - warm_weight) * prediction weight * consistency _loss_weight */
+  float level_w[RSLO_LOSS_TAIL_MAX_LEVELS];   /* pyloss_exp_w_base ** (L - l) */
+} RsloLossTail;
+RSLO_API int rslo_loss_tail_fwd(const RsloLossTail *h_p, float *out5, void *stream);
+RSLO_API int rslo_loss_tail_bwd(const RsloLossTail *h_p, const float *grad_out /*[1]*/, float *d_t /*[B,3]*/,
+                                float *d_q /*[B,4]*/, float *d_pyr /*[L,B,2]*/, float *d_pair /*[n_pairs]*/,
+                                float *d_alpha5 /*(T, R, pT, pR, C)*/, void *stream);
+
 /* ------------------------------------------------------------------------------------
  * a1 + a2 + a5 in ONE call: voxelization of all clouds of a step (frames x samples) and the complete rulebook chain
  * of a chain-structured sparse encoder -- site hashes, SubM tables, strided-conv output sets + both tables, tile row

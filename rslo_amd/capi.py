@@ -127,6 +127,8 @@ SIGNATURES = {
     "rslo_pyramid_l2_bwd": (C.c_int, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "rslo_plan_encoder_layout": (C.c_int, [_vp, _i, _vp, _vp]),
     "rslo_plan_encoder": (C.c_int, [_vp, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp, _vp]),
+    "rslo_loss_tail_fwd": (C.c_int, [_vp, _vp, _vp]),
+    "rslo_loss_tail_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rslo_opt_clip_grad_norm": (C.c_int, [_vp, _vp, _i, _f, _vp, _vp, _vp]),
     "rslo_opt_adam_step": (C.c_int, [_vp, _vp, _i, _vp, _f, _vp]),
 }
@@ -803,6 +805,32 @@ def pyramid_l2_bwd(preds, masks, tq, H0, W0, origin, vsize, grad_loss_b, den):
                                    _ptr(grad_loss_b, torch.float32, "grad"), _ptr(den, torch.float32, "den"),
                                    _stream()), "rslo_pyramid_l2_bwd")
     return dpreds
+
+
+class LossTail(C.Structure):
+    _fields_ = [("t_pred", C.c_void_p), ("t_tgt", C.c_void_p), ("q_pred", C.c_void_p), ("q_tgt", C.c_void_p),
+                ("alpha_T", C.c_void_p), ("alpha_R", C.c_void_p), ("pyr_loss_b", C.c_void_p), ("alpha_pT", C.c_void_p),
+                ("alpha_pR", C.c_void_p), ("pair_loss", C.c_void_p), ("alpha_C", C.c_void_p), ("B", C.c_int32),
+                ("L", C.c_int32), ("n_pairs", C.c_int32), ("reserved", C.c_int32), ("w_T", C.c_float), ("w_R", C.c_float),
+                ("w_pT", C.c_float), ("w_pR", C.c_float), ("c_scale", C.c_float), ("level_w", C.c_float * 8)]
+
+
+def loss_tail_fwd(desc, device):
+    out = torch.empty((5,), dtype=torch.float32, device=device)
+    _chk(lib().rslo_loss_tail_fwd(C.byref(desc), _ptr(out), _stream()), "rslo_loss_tail_fwd")
+    return out
+
+
+def loss_tail_bwd(desc, grad_out, B, L, n_pairs):
+    dev = grad_out.device
+    d_t = torch.empty((B, 3), dtype=torch.float32, device=dev)
+    d_q = torch.empty((B, 4), dtype=torch.float32, device=dev)
+    d_pyr = torch.empty((L, B, 2), dtype=torch.float32, device=dev) if L else None
+    d_pair = torch.empty((n_pairs,), dtype=torch.float32, device=dev) if n_pairs else None
+    d_alpha = torch.empty((5,), dtype=torch.float32, device=dev)
+    _chk(lib().rslo_loss_tail_bwd(C.byref(desc), _ptr(grad_out, torch.float32, "grad"), _ptr(d_t), _ptr(d_q), _ptr(d_pyr),
+                                  _ptr(d_pair), _ptr(d_alpha), _stream()), "rslo_loss_tail_bwd")
+    return d_t, d_q, d_pyr, d_pair, d_alpha
 
 
 def pad_rows_fwd(src, off, length, Lmax):

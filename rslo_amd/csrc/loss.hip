@@ -803,3 +803,152 @@ extern "C" int rslo_pad_rows_bwd(const float *dout, int64_t N, int C, const int3
   RSLO_CHECK_LAUNCH("k_pad_rows_bwd");
   return RSLO_OK;
 }
+
+// ---------------------------------------------------------------------------------------
+// Loss assembly (a21): everything between the per-pair / per-level partial losses and the scalar the step
+// differentiates -- AdaptiveWeightedL2Loss of the voted pose against the ICP pseudo-targets (rslo/core/losses.py:144-197),
+// the same reduction of the pyramid levels (voxel_odom_net.py:743-798), the consistency loss's reduce (losses.py:496-506)
+// and the weighted total (voxel_odom_net.py:324-376).  All operands are a few dozen floats; issued as torch ops this was
+// ~50 launches forward and ~70 backward per step.  One thread does it, in the torch formulation's operation order.
+//   pose:     l_b = sum_i d_bi^2 / (n + 1e-12), n = 3 | 4;   L = w (exp(-a) sum_b l_b / (B + 1e-12) + a)
+//   pyramid:  P   = sum_l cw_l (w_pT (exp(-a_pT) sum_b l_lb0 / (B + 1e-12) + a_pT) + w_pR (exp(-a_pR) ... + a_pR))
+//   consist.: C   = c_scale (exp(-a_C) mean_b lb_b + a_C)            (focal_gamma = 0 everywhere: the shipped configuration)
+// out[0] = T + R + P + C, out[1..4] = T, R, P, C.
+// ---------------------------------------------------------------------------------------
+__global__ void k_loss_tail_fwd(RsloLossTail p, float *__restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const float inv_b = 1.0f / ((float)p.B + 1e-12f);
+  float st = 0.f, sr = 0.f;
+  for (int b = 0; b < p.B; ++b) {
+    float a = 0.f, c = 0.f;
+    for (int i = 0; i < 3; ++i) {
+      const float d = p.t_pred[b * 3 + i] - p.t_tgt[b * 3 + i];
+      a += d * d;
+    }
+    for (int i = 0; i < 4; ++i) {
+      const float d = p.q_pred[b * 4 + i] - p.q_tgt[b * 4 + i];
+      c += d * d;
+    }
+    st += a / (3.0f + 1e-12f);
+    sr += c / (4.0f + 1e-12f);
+  }
+  const float aT = *p.alpha_T, aR = *p.alpha_R;
+  const float T = p.w_T * (expf(-aT) * st * inv_b + aT), R = p.w_R * (expf(-aR) * sr * inv_b + aR);
+  float P = 0.f;
+  if (p.L > 0) {
+    const float apT = *p.alpha_pT, apR = *p.alpha_pR;
+    for (int l = 0; l < p.L; ++l) {
+      float s0 = 0.f, s1 = 0.f;
+      for (int b = 0; b < p.B; ++b) {
+        s0 += p.pyr_loss_b[(l * p.B + b) * 2 + 0];
+        s1 += p.pyr_loss_b[(l * p.B + b) * 2 + 1];
+      }
+      P += p.level_w[l] * (p.w_pT * (expf(-apT) * s0 * inv_b + apT) + p.w_pR * (expf(-apR) * s1 * inv_b + apR));
+    }
+  }
+  float Cl = 0.f;
+  if (p.n_pairs > 0) {
+    float s = 0.f;
+    for (int b = 0; b < p.n_pairs; ++b) s += p.pair_loss[b];
+    const float aC = *p.alpha_C;
+    Cl = p.c_scale * (expf(-aC) * (s / (float)p.n_pairs) + aC);
+  }
+  out[0] = T + R + P + Cl;
+  out[1] = T;
+  out[2] = R;
+  out[3] = P;
+  out[4] = Cl;
+}
+
+// gradients of out[0] scaled by *g: d_t [B,3], d_q [B,4], d_pyr [L,B,2], d_pair [n_pairs], d_alpha[5] = (T, R, pT, pR, C)
+// (a module used for both the pose and the pyramid terms gets the SUM of its two entries from the caller)
+__global__ void k_loss_tail_bwd(RsloLossTail p, const float *__restrict__ g, float *__restrict__ d_t,
+                                float *__restrict__ d_q, float *__restrict__ d_pyr, float *__restrict__ d_pair,
+                                float *__restrict__ d_alpha) {
+  const float go = *g, inv_b = 1.0f / ((float)p.B + 1e-12f);
+  const float aT = *p.alpha_T, aR = *p.alpha_R;
+  const float eT = expf(-aT), eR = expf(-aR);
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+  const float kt = go * p.w_T * eT * inv_b * 2.0f / (3.0f + 1e-12f), kq = go * p.w_R * eR * inv_b * 2.0f / (4.0f + 1e-12f);
+  for (int i = tid; i < p.B * 3; i += nth) d_t[i] = kt * (p.t_pred[i] - p.t_tgt[i]);
+  for (int i = tid; i < p.B * 4; i += nth) d_q[i] = kq * (p.q_pred[i] - p.q_tgt[i]);
+  if (p.L > 0) {
+    const float epT = expf(-*p.alpha_pT), epR = expf(-*p.alpha_pR);
+    for (int i = tid; i < p.L * p.B * 2; i += nth) {
+      const int l = i / (p.B * 2);
+      d_pyr[i] = go * p.level_w[l] * ((i & 1) ? p.w_pR * epR : p.w_pT * epT) * inv_b;
+    }
+  }
+  if (p.n_pairs > 0) {
+    const float kc = go * p.c_scale * expf(-*p.alpha_C) / (float)p.n_pairs;
+    for (int i = tid; i < p.n_pairs; i += nth) d_pair[i] = kc;
+  }
+  if (tid == 0) {
+    float st = 0.f, sr = 0.f;
+    for (int b = 0; b < p.B; ++b) {
+      float a = 0.f, c = 0.f;
+      for (int i = 0; i < 3; ++i) {
+        const float d = p.t_pred[b * 3 + i] - p.t_tgt[b * 3 + i];
+        a += d * d;
+      }
+      for (int i = 0; i < 4; ++i) {
+        const float d = p.q_pred[b * 4 + i] - p.q_tgt[b * 4 + i];
+        c += d * d;
+      }
+      st += a / (3.0f + 1e-12f);
+      sr += c / (4.0f + 1e-12f);
+    }
+    d_alpha[0] = go * p.w_T * (1.0f - eT * st * inv_b);
+    d_alpha[1] = go * p.w_R * (1.0f - eR * sr * inv_b);
+    float dpT = 0.f, dpR = 0.f;
+    if (p.L > 0) {
+      const float epT = expf(-*p.alpha_pT), epR = expf(-*p.alpha_pR);
+      for (int l = 0; l < p.L; ++l) {
+        float s0 = 0.f, s1 = 0.f;
+        for (int b = 0; b < p.B; ++b) {
+          s0 += p.pyr_loss_b[(l * p.B + b) * 2 + 0];
+          s1 += p.pyr_loss_b[(l * p.B + b) * 2 + 1];
+        }
+        dpT += p.level_w[l] * p.w_pT * (1.0f - epT * s0 * inv_b);
+        dpR += p.level_w[l] * p.w_pR * (1.0f - epR * s1 * inv_b);
+      }
+    }
+    d_alpha[2] = go * dpT;
+    d_alpha[3] = go * dpR;
+    float dc = 0.f;
+    if (p.n_pairs > 0) {
+      float s = 0.f;
+      for (int b = 0; b < p.n_pairs; ++b) s += p.pair_loss[b];
+      dc = go * p.c_scale * (1.0f - expf(-*p.alpha_C) * (s / (float)p.n_pairs));
+    }
+    d_alpha[4] = dc;
+  }
+}
+
+static int loss_tail_check(const RsloLossTail *p) {
+  RSLO_CHECK_ARG(p && p->B >= 1 && p->B <= 4096 && p->L >= 0 && p->L <= RSLO_LOSS_TAIL_MAX_LEVELS && p->n_pairs >= 0,
+                 "rslo_loss_tail: bad sizes");
+  RSLO_CHECK_ARG(p->t_pred && p->t_tgt && p->q_pred && p->q_tgt && p->alpha_T && p->alpha_R, "rslo_loss_tail: null pose operand");
+  RSLO_CHECK_ARG(p->L == 0 || (p->pyr_loss_b && p->alpha_pT && p->alpha_pR), "rslo_loss_tail: null pyramid operand");
+  RSLO_CHECK_ARG(p->n_pairs == 0 || (p->pair_loss && p->alpha_C), "rslo_loss_tail: null consistency operand");
+  return RSLO_OK;
+}
+
+extern "C" int rslo_loss_tail_fwd(const RsloLossTail *h_p, float *out5, void *stream) {
+  if (int rc = loss_tail_check(h_p)) return rc;
+  RSLO_CHECK_ARG(out5, "rslo_loss_tail_fwd: null output");
+  hipLaunchKernelGGL(k_loss_tail_fwd, dim3(1), dim3(64), 0, (hipStream_t)stream, *h_p, out5);
+  RSLO_CHECK_LAUNCH("k_loss_tail_fwd");
+  return RSLO_OK;
+}
+
+extern "C" int rslo_loss_tail_bwd(const RsloLossTail *h_p, const float *grad_out, float *d_t, float *d_q, float *d_pyr,
+                                  float *d_pair, float *d_alpha5, void *stream) {
+  if (int rc = loss_tail_check(h_p)) return rc;
+  RSLO_CHECK_ARG(grad_out && d_t && d_q && d_alpha5 && (h_p->L == 0 || d_pyr) && (h_p->n_pairs == 0 || d_pair),
+                 "rslo_loss_tail_bwd: null output");
+  hipLaunchKernelGGL(k_loss_tail_bwd, dim3(1), dim3(256), 0, (hipStream_t)stream, *h_p, grad_out, d_t, d_q, d_pyr,
+                     d_pair, d_alpha5);
+  RSLO_CHECK_LAUNCH("k_loss_tail_bwd");
+  return RSLO_OK;
+}

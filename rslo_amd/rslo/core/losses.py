@@ -86,6 +86,54 @@ class _PyramidL2Fn(torch.autograd.Function):
         return (None, None, None, *dpreds)
 
 
+class _LossTailFn(torch.autograd.Function):
+    """(total, T, R, pyramid, C) from the per-pair / per-level partial losses in one launch (rslo_loss_tail_fwd / _bwd);
+    only out[0] carries a gradient.  alphas: the log-variance parameters of the five loss modules in the order
+    (translation, rotation, pyramid translation, pyramid rotation, consistency) -- the same tensor may appear twice."""
+
+    @staticmethod
+    def _desc(t_pred, q_pred, pyr, pair, alphas, meta):
+        d = capi.LossTail()
+        d.t_pred, d.q_pred = t_pred.data_ptr(), q_pred.data_ptr()
+        d.t_tgt, d.q_tgt = meta["t_tgt"].data_ptr(), meta["q_tgt"].data_ptr()
+        d.alpha_T, d.alpha_R, d.alpha_pT, d.alpha_pR, d.alpha_C = [a.data_ptr() for a in alphas]
+        d.pyr_loss_b = pyr.data_ptr() if pyr is not None else None
+        d.pair_loss = pair.data_ptr() if pair is not None else None
+        d.B, d.L = t_pred.shape[0], (pyr.shape[0] if pyr is not None else 0)
+        d.n_pairs = pair.shape[0] if pair is not None else 0
+        d.w_T, d.w_R, d.w_pT, d.w_pR, d.c_scale = meta["w"]
+        for i, w in enumerate(meta["level_w"]):
+            d.level_w[i] = w
+        return d
+
+    @staticmethod
+    def forward(ctx, t_pred, q_pred, pyr, pair, aT, aR, apT, apR, aC, meta):
+        t_pred, q_pred = t_pred.contiguous(), q_pred.contiguous()
+        pyr = pyr.contiguous() if pyr is not None else None
+        pair = pair.contiguous() if pair is not None else None
+        alphas = (aT, aR, apT, apR, aC)
+        out = capi.loss_tail_fwd(_LossTailFn._desc(t_pred, q_pred, pyr, pair, alphas, meta), t_pred.device)
+        ctx.save_for_backward(t_pred, q_pred, pyr, pair, *alphas, meta["t_tgt"], meta["q_tgt"])
+        ctx.meta = meta
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        t_pred, q_pred, pyr, pair, aT, aR, apT, apR, aC, _, _ = ctx.saved_tensors
+        desc = _LossTailFn._desc(t_pred, q_pred, pyr, pair, (aT, aR, apT, apR, aC), ctx.meta)
+        d_t, d_q, d_pyr, d_pair, d_a = capi.loss_tail_bwd(desc, g[0:1].contiguous(), desc.B, desc.L, desc.n_pairs)
+        need = ctx.needs_input_grad
+        da = [d_a[i:i + 1] if need[4 + i] else None for i in range(5)]
+        return d_t, d_q, d_pyr, d_pair, da[0], da[1], da[2], da[3], da[4], None
+
+
+def loss_tail(raw, level_w):
+    """raw: the ingredients create_loss(..., raw_tail=True) returns -> the [5] tensor (total, T, R, pyramid, C)."""
+    meta = {"t_tgt": raw["t_tgt"].detach().contiguous().float(), "q_tgt": raw["q_tgt"].detach().contiguous().float(),
+            "w": tuple(float(v) for v in raw["w"]), "level_w": [float(v) for v in level_w]}
+    return _LossTailFn.apply(raw["t_pred"], raw["q_pred"], raw["pyr_loss_b"], raw["pair_loss"], *raw["alphas"], meta)
+
+
 class _PadRowsFn(torch.autograd.Function):
     """Ragged rows -> zero-padded batch (rslo_pad_rows_fwd / _bwd)."""
 

@@ -117,6 +117,9 @@ class UnVoxelOdomNetICP3(nn.Module):
         self.measure_time = measure_time
         self.cpu_extras = False
         self.fused_pyramid = True      # pyramid supervision through rslo_pyramid_l2_* (GPU tensors)
+        # reductions + loss weights + total of all loss terms in one launch each way (rslo_loss_tail_*); the torch
+        # formulation op by op (what the golden vectors of the reference pin) runs for CPU tensors / other configurations
+        self.fused_loss_tail = os.environ.get("RSLO_FUSED_LOSS_TAIL", "1") != "0"
 
         self.voxel_feature_extractor = voxel_encoder.get_vfe_class(vfe_class_name)(
             num_input_features, vfe_use_norm, num_filters=vfe_num_filters, with_distance=with_distance,
@@ -391,10 +394,20 @@ class UnVoxelOdomNetICP3(nn.Module):
         if not isinstance(R_preds, (list, tuple)):
             R_preds = [R_preds]
         self.start_timer("create_loss forward")
-        t_loss, r_loss, py_T, py_R, C_loss = self.create_loss(
+        res = self.create_loss(
             preds_dict, example, self._translation_loss, self._rotation_loss,
             pyramid_rotation_loss=self._pyramid_rotation_loss,
-            pyramid_translation_loss=self._pyramid_translation_loss, consistency_loss=self._consistency_loss)
+            pyramid_translation_loss=self._pyramid_translation_loss, consistency_loss=self._consistency_loss,
+            raw_tail=self.fused_loss_tail)
+        if isinstance(res, dict):       # the partial losses: reductions, loss weights and the total in ONE launch
+            n = res["pyr_loss_b"].shape[0] if res["pyr_loss_b"] is not None else 0
+            out = losses.loss_tail(res, [self._pyloss_exp_w_base ** (n - i) for i in range(n)])
+            self.end_timer("create_loss forward")
+            terms = out.detach()
+            return {"loss": out[0:1], "translation_loss": terms[1:2], "rotation_loss": terms[2:3],
+                    "pyramid_loss": terms[3:4], "C_loss": terms[4:5],
+                    "translation_preds": T_preds[0].detach(), "rotation_preds": R_preds[0].detach()}
+        t_loss, r_loss, py_T, py_R, C_loss = res
         n = len(py_T)
         if getattr(self, "_py_scaled", None) is not None:     # fused pyramid path: one weighted sum over [L,2]
             w = losses._const([self._pyloss_exp_w_base ** (n - i) for i in range(n)], T_preds[0].device)
@@ -412,7 +425,9 @@ class UnVoxelOdomNetICP3(nn.Module):
 
     @amp.float_function
     def create_loss(self, preds_dict, example, translation_loss, rotation_loss, pyramid_translation_loss=None,
-                    pyramid_rotation_loss=None, pyramid_preds=None, consistency_loss=None):
+                    pyramid_rotation_loss=None, pyramid_preds=None, consistency_loss=None, raw_tail=False):
+        """raw_tail=True (GPU, shipped loss configuration): returns the partial losses as a dict for
+        losses.loss_tail instead of the five assembled terms."""
         translation_preds, rotation_preds = preds_dict["translation_preds"], preds_dict["rotation_preds"]
         if not isinstance(translation_preds, (list, tuple)):
             translation_preds = [translation_preds]
@@ -436,6 +451,17 @@ class UnVoxelOdomNetICP3(nn.Module):
 
         C_loss = torch.zeros([1], dtype=dtype, device=device)
         res_r = res_t = None
+        raw_pair = None
+        AW = losses.AdaptiveWeightedL2Loss
+        raw_tail = bool(
+            raw_tail and device.type == "cuda" and dtype == torch.float32 and self.fused_pyramid
+            and len(translation_preds) == 1 and len(rotation_preds) == 1 and translation_preds[0].shape[-1] == 3
+            and rotation_preds[0].shape[-1] == 4 and self.odom_predictor._cubic_pred_height == 0
+            and all(isinstance(m, AW) and m.focal_gamma == 0 for m in (translation_loss, rotation_loss))
+            and all(m is None or (isinstance(m, AW) and m.focal_gamma == 0)
+                    for m in (pyramid_translation_loss, pyramid_rotation_loss))
+            and (pyramid_translation_loss is None) == (pyramid_rotation_loss is None)
+            and (consistency_loss is None or getattr(consistency_loss, "focal_gamma", 0) == 0))
         if consistency_loss is not None:
             if len(preds_dict["middle_conf_preds"]) == 0:
                 # the reference has no working behaviour here: it keeps point_confs = None (voxel_odom_net.py:628) and
@@ -502,12 +528,39 @@ class UnVoxelOdomNetICP3(nn.Module):
                     pts1[:, :, :3], p2_moved, cov_pred=cov1, cov_target=cov2, R_pred=R_pred, t_pred=T_pred,
                     normal_pred=pts1[:, :, 3:].detach(), normal_target=n2_moved.detach(), icp_iter=icp_iter,
                     counts=cnt_dev, counts_host=cnt_host)
+                if raw_tail:
+                    raw_pair = (lb, (1 - warm_weight) * weight * consistency_loss._loss_weight)
+                    continue
                 l = consistency_loss._loss_weight * consistency_loss.reduce(lb)
                 C_loss = C_loss + (1 - warm_weight) * weight * l
 
         if res_r is not None and res_t is not None:
             rotation_targets, translation_targets = losses.icp_pose_targets(res_r, res_t, R_pred, T_pred)
 
+        if raw_tail:
+            raw = {"t_pred": translation_preds[0], "q_pred": rotation_preds[0], "t_tgt": translation_targets,
+                   "q_tgt": rotation_targets, "pyr_loss_b": None,
+                   "pair_loss": raw_pair[0] if raw_pair is not None else None,
+                   "alphas": [translation_loss.alpha, rotation_loss.alpha,
+                              (pyramid_translation_loss or translation_loss).alpha,
+                              (pyramid_rotation_loss or rotation_loss).alpha,
+                              consistency_loss.alpha if consistency_loss is not None else translation_loss.alpha],
+                   "w": [translation_loss._loss_weight, rotation_loss._loss_weight,
+                         pyramid_translation_loss._loss_weight if pyramid_translation_loss is not None else 0.0,
+                         pyramid_rotation_loss._loss_weight if pyramid_rotation_loss is not None else 0.0,
+                         raw_pair[1] if raw_pair is not None else 0.0]}
+            levels = [(pp[0], pp[1]) if isinstance(pp, (tuple, list)) else (pp, None) for pp in pyramid_preds]
+            tq_targets = torch.cat([translation_targets, rotation_targets], dim=-1).reshape(-1, 7)
+            example["tq_targets"] = tq_targets
+            if pyramid_translation_loss is not None and len(levels) > 0:
+                if not all(m is not None and p.dim() == 4 for p, m in levels):
+                    raise NotImplementedError("pyramid levels without masks are outside the fused loss assembly")
+                H0, W0 = (int(v) for v in levels[-1][0].shape[2:])
+                _, vs, origin = _tq_map_geometry([1, H0, W0], self.odom_predictor.point_cloud_range)
+                raw["pyr_loss_b"] = losses._PyramidL2Fn.apply(
+                    tq_targets.detach().contiguous().float(), (H0, W0, origin, vs),
+                    [m.detach().contiguous().float() for _, m in levels], *[p.float() for p, _ in levels])
+            return raw
         if (len(translation_preds) == 1 and len(rotation_preds) == 1
                 and isinstance(translation_loss, losses.AdaptiveWeightedL2Loss)
                 and isinstance(rotation_loss, losses.AdaptiveWeightedL2Loss)

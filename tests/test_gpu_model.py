@@ -772,6 +772,41 @@ def test_short_training_run_stays_finite(hip):
     assert float((after - before).abs().max()) > 1e-4
 
 
+@pytest.mark.parametrize("step", [2000, 100])
+def test_fused_loss_tail_matches_torch_formulation(hip, step):
+    """rslo_loss_tail_fwd / _bwd (pose L2 terms, pyramid reduction, consistency reduce, loss weights, total: one launch
+    each way) against the op-by-op torch formulation that the reference-generated goldens pin (check_create_loss): every
+    loss term and every parameter gradient of a training step, after warm-up (step 2000) and inside it (step 100:
+    identity pose in the consistency loss, 5 ICP rounds)."""
+    torch.manual_seed(7)
+    net, _ = workload.build_network()
+    net.train()
+    net.global_step.fill_(step)
+    trained_like_init(net)
+    with torch.no_grad():       # distinct log-variances: their gradients must land on the right modules
+        net._translation_loss.alpha.fill_(0.3)
+        net._rotation_loss.alpha.fill_(-2.1)
+        net._consistency_loss.alpha.fill_(0.7)
+    ex = workload.make_example(net, [list(reduced_pair(1)[:2]), list(reduced_pair(2)[:2])])
+    outs = []
+    for fused in (True, False):
+        net.fused_loss_tail = fused
+        net.zero_grad(set_to_none=True)
+        ret = net(ex)
+        ret["loss"].mean().backward()
+        outs.append((ret, {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}))
+    (ra, ga), (rb, gb) = outs
+    for k in ("loss", "translation_loss", "rotation_loss", "pyramid_loss", "C_loss"):
+        assert ra[k].shape == rb[k].shape == (1,) and rel(ra[k], rb[k]) < 2e-6, (k, float(ra[k]), float(rb[k]))
+    assert sorted(ga) == sorted(gb) and len(ga) >= 200
+    skip = bias_before_bn(net)                  # analytically zero gradients: rounding noise on both sides
+    for n in gb:
+        if n not in skip and float(gb[n].abs().max()) > 1e-5:
+            assert rel(ga[n], gb[n]) < 5e-5, n      # same kernels upstream; the tail's sums are in a different order
+    for n in ("_translation_loss.alpha", "_rotation_loss.alpha"):
+        assert n in ga and float(ga[n].abs().max()) > 0
+
+
 def test_fused_vote_matches_torch_formulation(hip):
     """rslo_vote_fwd/_bwd == from_pointwise_local_transformation_tch + confidence-weighted means (the reference
     formulation, op by op): global map, voted pose, gradients of the local map and of both confidences."""
