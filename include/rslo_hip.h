@@ -187,6 +187,45 @@ RSLO_API int rslo_rulebook_row_order(const int32_t *nbr, int64_t n_rows, int K, 
 RSLO_API size_t rslo_rulebook_pairs_ws_bytes(int64_t n_rows, int K);
 RSLO_API int rslo_rulebook_pairs(const int32_t *nbr, int64_t n_rows, int K, void *ws, size_t ws_bytes,
                         int32_t *pairs_in, int32_t *pairs_out, int32_t *koff /*[K+1]*/, void *stream);
+/* a11 / a12 / a15  The element-wise tail of the BEV head (rslo/models/odom_pred.py:227-264):
+ *   rslo_tq_normalize_*   tq_map = cat(t, q / |q|) per cell (odom_pred.py:229-234), tq [B,7,cells];
+ *   rslo_conf_softmax_*   both ConfidenceModule softmaxes (rslo/layers/confidence.py:26-34): where(outside, -1000, logit) / T,
+ *                         softmax over the cells of a sample; T = 1 -> t_conf, r_conf [B,cells] (with gradient) and
+ *                         T = temperature (20) -> conf_temp [B,2,cells] (no gradient) from one pass; outside: 1 byte per cell;
+ *   rslo_head_masks_*     occupancy pyramid (mask_gen_pools: MaxPool 3/2/1, odom_pred_base.py:228-231), loss weights
+ *                         w_0 = mask * conf_temp, w_{k+1} = occ_{k+1} * AvgPool(3,2,1)(w_k) (hier_weight_gen, odom_pred.py:148,262-264),
+ *                         masked pyramid predictions pred_k * (occ_k > 0), masked pose maps tq * mask, tq_g * mask. */
+RSLO_API int rslo_tq_normalize_fwd(const float *tq, int B, int64_t cells, float *out, void *stream);
+RSLO_API int rslo_tq_normalize_bwd(const float *tq, const float *grad, int B, int64_t cells, float *dtq, void *stream);
+RSLO_API int rslo_conf_softmax_fwd(const float *t_logit, const float *r_logit, const unsigned char *outside, int B,
+                                   int cells, float temperature, float *t_conf, float *r_conf, float *conf_temp,
+                                   void *stream);
+RSLO_API int rslo_conf_softmax_bwd(const float *t_conf, const float *r_conf, const float *g_t, const float *g_r,
+                                   const unsigned char *outside, int B, int cells, float *d_t_logit, float *d_r_logit,
+                                   void *stream);
+typedef struct {
+  const float *mask;        /* [B,1,H,W] 0/1 */
+  const float *conf;        /* [B,2,H,W] */
+  const float *tq, *tq_g;   /* [B,7,H,W] */
+  const float *pred[3];     /* pred[k-1]: [B,7,H>>k,W>>k], k = 1 .. levels-1 */
+  float *w[4];              /* out: w[k] [B,2,H>>k,W>>k] */
+  float *occ[4];            /* out: occ[k], k >= 1: [B,1,H>>k,W>>k] */
+  float *mpred[3];          /* out: masked predictions */
+  float *mtq, *mtq_g;       /* out */
+  int32_t B, H, W, levels;  /* levels = 1 + number of pyramid predictions (<= 4) */
+} RsloHeadMasks;
+typedef struct {
+  const float *mask;
+  const float *occ[4];
+  const float *g_mpred[3];  /* may be NULL */
+  const float *g_mtq;       /* may be NULL */
+  float *d_pred[3];
+  float *d_tq;
+  int32_t B, H, W, levels;
+} RsloHeadMasksBwd;
+RSLO_API int rslo_head_masks_fwd(const RsloHeadMasks *h_a, void *stream);
+RSLO_API int rslo_head_masks_bwd(const RsloHeadMasksBwd *h_a, void *stream);
+
 /* a21  Loss assembly in one launch each way: AdaptiveWeightedL2Loss of the voted pose against the ICP pseudo-targets
  *      (rslo/core/losses.py:144-197; mask = ones, focal_gamma = 0), the same reduction of the pyramid levels' per-sample
  *      terms (rslo/models/voxel_odom_net.py:743-798; loss_b from rslo_pyramid_l2_fwd), the consistency loss's reduce over

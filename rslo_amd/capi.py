@@ -127,6 +127,12 @@ SIGNATURES = {
     "rslo_pyramid_l2_bwd": (C.c_int, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "rslo_plan_encoder_layout": (C.c_int, [_vp, _i, _vp, _vp]),
     "rslo_plan_encoder": (C.c_int, [_vp, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp, _vp]),
+    "rslo_tq_normalize_fwd": (C.c_int, [_vp, _i, _i64, _vp, _vp]),
+    "rslo_tq_normalize_bwd": (C.c_int, [_vp, _vp, _i, _i64, _vp, _vp]),
+    "rslo_conf_softmax_fwd": (C.c_int, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp]),
+    "rslo_conf_softmax_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "rslo_head_masks_fwd": (C.c_int, [_vp, _vp]),
+    "rslo_head_masks_bwd": (C.c_int, [_vp, _vp]),
     "rslo_loss_tail_fwd": (C.c_int, [_vp, _vp, _vp]),
     "rslo_loss_tail_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rslo_opt_clip_grad_norm": (C.c_int, [_vp, _vp, _i, _f, _vp, _vp, _vp]),
@@ -805,6 +811,105 @@ def pyramid_l2_bwd(preds, masks, tq, H0, W0, origin, vsize, grad_loss_b, den):
                                    _ptr(grad_loss_b, torch.float32, "grad"), _ptr(den, torch.float32, "den"),
                                    _stream()), "rslo_pyramid_l2_bwd")
     return dpreds
+
+
+class HeadMasks(C.Structure):
+    _fields_ = [("mask", C.c_void_p), ("conf", C.c_void_p), ("tq", C.c_void_p), ("tq_g", C.c_void_p),
+                ("pred", C.c_void_p * 3), ("w", C.c_void_p * 4), ("occ", C.c_void_p * 4), ("mpred", C.c_void_p * 3),
+                ("mtq", C.c_void_p), ("mtq_g", C.c_void_p), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("levels", C.c_int32)]
+
+
+class HeadMasksBwd(C.Structure):
+    _fields_ = [("mask", C.c_void_p), ("occ", C.c_void_p * 4), ("g_mpred", C.c_void_p * 3), ("g_mtq", C.c_void_p),
+                ("d_pred", C.c_void_p * 3), ("d_tq", C.c_void_p), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("levels", C.c_int32)]
+
+
+def tq_normalize_fwd(tq):
+    B, _, H, W = tq.shape
+    out = torch.empty_like(tq)
+    _chk(lib().rslo_tq_normalize_fwd(_ptr(tq, torch.float32, "tq"), B, H * W, _ptr(out), _stream()), "rslo_tq_normalize_fwd")
+    return out
+
+
+def tq_normalize_bwd(tq, g):
+    B, _, H, W = tq.shape
+    d = torch.empty_like(tq)
+    _chk(lib().rslo_tq_normalize_bwd(_ptr(tq, torch.float32, "tq"), _ptr(g, torch.float32, "grad"), B, H * W, _ptr(d),
+                                     _stream()), "rslo_tq_normalize_bwd")
+    return d
+
+
+def conf_softmax_fwd(t_logit, r_logit, outside, temperature):
+    """t_logit, r_logit [B,1,H,W] fp32, outside [B,1,H,W] bool -> (t_conf, r_conf [B,1,H,W], conf_temp [B,2,H,W])."""
+    B, _, H, W = t_logit.shape
+    t_conf, r_conf = torch.empty_like(t_logit), torch.empty_like(r_logit)
+    ct = torch.empty((B, 2, H, W), dtype=torch.float32, device=t_logit.device)
+    _chk(lib().rslo_conf_softmax_fwd(_ptr(t_logit, torch.float32, "t_logit"), _ptr(r_logit, torch.float32, "r_logit"),
+                                     _ptr(outside, torch.bool, "outside"), B, H * W, float(temperature), _ptr(t_conf),
+                                     _ptr(r_conf), _ptr(ct), _stream()), "rslo_conf_softmax_fwd")
+    return t_conf, r_conf, ct
+
+
+def conf_softmax_bwd(t_conf, r_conf, g_t, g_r, outside):
+    B, _, H, W = t_conf.shape
+    d_t, d_r = torch.empty_like(t_conf), torch.empty_like(r_conf)
+    _chk(lib().rslo_conf_softmax_bwd(_ptr(t_conf, torch.float32, "t_conf"), _ptr(r_conf, torch.float32, "r_conf"),
+                                     _ptr(g_t, torch.float32, "g_t"), _ptr(g_r, torch.float32, "g_r"),
+                                     _ptr(outside, torch.bool, "outside"), B, H * W, _ptr(d_t), _ptr(d_r), _stream()),
+         "rslo_conf_softmax_bwd")
+    return d_t, d_r
+
+
+def head_masks_fwd(mask, conf, tq, tq_g, preds):
+    """mask [B,1,H,W], conf [B,2,H,W], tq / tq_g [B,7,H,W], preds = [pred of level 1, level 2, ...] (finest first)
+    -> (w [levels], occ [levels] (occ[0] = mask), mpreds, mtq, mtq_g)."""
+    B, _, H, W = mask.shape
+    dev = mask.device
+    L = 1 + len(preds)
+    a = HeadMasks()
+    a.mask, a.conf, a.tq, a.tq_g = _ptr(mask, torch.float32, "mask").value, _ptr(conf, torch.float32, "conf").value, \
+        _ptr(tq, torch.float32, "tq").value, _ptr(tq_g, torch.float32, "tq_g").value
+    w, occ, mp = [], [mask], []
+    for k in range(L):
+        wk = torch.empty((B, 2, H >> k, W >> k), dtype=torch.float32, device=dev)
+        w.append(wk)
+        a.w[k] = wk.data_ptr()
+        if k:
+            ok = torch.empty((B, 1, H >> k, W >> k), dtype=torch.float32, device=dev)
+            occ.append(ok)
+            a.occ[k] = ok.data_ptr()
+            a.pred[k - 1] = _ptr(preds[k - 1], torch.float32, "pred").value
+            m = torch.empty_like(preds[k - 1])
+            mp.append(m)
+            a.mpred[k - 1] = m.data_ptr()
+    mtq, mtq_g = torch.empty_like(tq), torch.empty_like(tq_g)
+    a.mtq, a.mtq_g = mtq.data_ptr(), mtq_g.data_ptr()
+    a.B, a.H, a.W, a.levels = B, H, W, L
+    _chk(lib().rslo_head_masks_fwd(C.byref(a), _stream()), "rslo_head_masks_fwd")
+    return w, occ, mp, mtq, mtq_g
+
+
+def head_masks_bwd(mask, occ, g_mpreds, g_mtq, pred_shapes):
+    B, _, H, W = mask.shape
+    dev = mask.device
+    L = len(occ)
+    a = HeadMasksBwd()
+    a.mask = mask.data_ptr()
+    a.g_mtq = _dp(g_mtq)
+    d_tq = torch.empty((B, 7, H, W), dtype=torch.float32, device=dev)
+    a.d_tq = d_tq.data_ptr()
+    d_preds = []
+    for k in range(1, L):
+        a.occ[k] = occ[k].data_ptr()
+        a.g_mpred[k - 1] = _dp(g_mpreds[k - 1])
+        d = torch.empty(pred_shapes[k - 1], dtype=torch.float32, device=dev)
+        d_preds.append(d)
+        a.d_pred[k - 1] = d.data_ptr()
+    a.B, a.H, a.W, a.levels = B, H, W, L
+    _chk(lib().rslo_head_masks_bwd(C.byref(a), _stream()), "rslo_head_masks_bwd")
+    return d_preds, d_tq
 
 
 class LossTail(C.Structure):

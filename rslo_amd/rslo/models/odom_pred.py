@@ -122,48 +122,69 @@ class UNOdomPredEncDecSVDTempMaskBase(OdomPredEncDecBase):
         if side_work is not None:
             side_work[1]()          # created HERE in the graph: in backward it is issued right before the stages above
 
+        fused_tail = self._fused_tail_ok(x, input_mask)
         py_masks = []
-        if self.pred_pyramid_motion:
+        if self.pred_pyramid_motion and not fused_tail:
             m = input_mask
             for i in range(len(self.deblocks) - 1):
                 m = self.mask_gen_pools[-(i + 1)](m)
                 py_masks.append(m)
             py_masks.reverse()
 
-        py_preds = []
+        py_preds, py_raw = [], []
         for i, deblock in enumerate(self.deblocks):
             x = deblock(torch.cat([x, ups[-(i + 1)]], dim=1))
             if self.pred_pyramid_motion and i < len(self.deblocks) - 1:
                 p = self.pyramid_motion_blocks[i](x)
-                py_preds.append([p * (py_masks[i] > 0).to(dtype=p.dtype), py_masks[i]])
+                if fused_tail:
+                    py_raw.append(p)
+                else:
+                    py_preds.append([p * (py_masks[i] > 0).to(dtype=p.dtype), py_masks[i]])
         x_tail = x
-
-        tq_map = self.tq_map_conv(x)
-        t_part, q_part = tq_map.split([3, 4], dim=1)      # one split: its backward is one cat, not 3 x (zeros + copy)
-        tq_map = torch.cat([t_part, q_part / torch.norm(q_part, dim=1, keepdim=True)], dim=1)
 
         if not self.dense_predict:
             raise NotImplementedError("the fc (non-dense) head is outside the RSLO hot path")
+        tq_map = self.tq_map_conv(x)
         # The reference evaluates both confidence heads twice on the same features (T = 1 with gradient, T = 20 on
         # x.detach(), odom_pred.py:242-243,257-258).  The logits of the second pass are identical, so they are reused;
         # its only other effect -- a second running-statistics update of the trunk's BatchNorms with the same batch
         # statistics -- is replayed algebraically.
         bn_before = self._snapshot_bn((self.t_map_conf, self.q_map_conf))
         outside = ~input_mask_bool        # shared by the four masked softmaxes below
-        t_conf, t_logit = self.t_map_conf(x_tail, extra_mask=input_mask, return_logit=True, outside=outside)
-        r_conf, r_logit = self.q_map_conf(x_tail, extra_mask=input_mask, return_logit=True, outside=outside)
+        if fused_tail:
+            # the element-wise tail on csrc/headtail.hip: quaternion normalisation, the four masked softmaxes, the mask /
+            # weight pyramid and the masked maps -- 3 launches forward, 3 backward instead of ~45 each way
+            tq_map = _TqNormFn.apply(tq_map)
+            t_conf, r_conf, temp_tq_conf = _ConfPairFn.apply(self.t_map_conf.conf_model(x_tail),
+                                                              self.q_map_conf.conf_model(x_tail), outside, 20.0)
+        else:
+            t_part, q_part = tq_map.split([3, 4], dim=1)      # one split: its backward is one cat, not 3 x (zeros + copy)
+            tq_map = torch.cat([t_part, q_part / torch.norm(q_part, dim=1, keepdim=True)], dim=1)
+            t_conf, t_logit = self.t_map_conf(x_tail, extra_mask=input_mask, return_logit=True, outside=outside)
+            r_conf, r_logit = self.q_map_conf(x_tail, extra_mask=input_mask, return_logit=True, outside=outside)
         tq_map_g, odom = self.vote(tq_map, t_conf, r_conf)
         if self.use_svd:        # rigid fit over the occupied cells instead of the confidence-weighted mean
             odom = self.vote_svd(tq_map, input_mask_bool, t_conf)
         odoms = [odom]
 
-        with torch.no_grad():   # temperature-20 confidences -> loss masks
-            temp_tq_conf = torch.cat([masked_spatial_softmax(t_logit.detach(), input_mask, 20, outside),
-                                      masked_spatial_softmax(r_logit.detach(), input_mask, 20, outside)], 1)
-            self._replay_bn_update(bn_before)
-        pyramid_motion = py_preds + [[tq_map * input_mask, input_mask * temp_tq_conf]]
-        for p in range(2, len(pyramid_motion) + 1):
-            pyramid_motion[-p][1] = pyramid_motion[-p][1] * self.hier_weight_gen(pyramid_motion[-(p - 1)][1])
+        if fused_tail:
+            with torch.no_grad():
+                self._replay_bn_update(bn_before)
+            # levels finest first: level 1 = the half-resolution prediction (the LAST pyramid block), level 2 the quarter
+            outs = _HeadMasksFn.apply(tq_map, input_mask, temp_tq_conf, tq_map_g, *py_raw[::-1])
+            n_lv = len(py_raw)
+            mtq, tq_map_g_masked = outs[0], outs[1]
+            mpreds, ws = outs[2:2 + n_lv], outs[2 + n_lv:]
+            pyramid_motion = [[mpreds[k - 1], ws[k]] for k in range(n_lv, 0, -1)] + [[mtq, ws[0]]]
+        else:
+            with torch.no_grad():   # temperature-20 confidences -> loss masks
+                temp_tq_conf = torch.cat([masked_spatial_softmax(t_logit.detach(), input_mask, 20, outside),
+                                          masked_spatial_softmax(r_logit.detach(), input_mask, 20, outside)], 1)
+                self._replay_bn_update(bn_before)
+            pyramid_motion = py_preds + [[tq_map * input_mask, input_mask * temp_tq_conf]]
+            for p in range(2, len(pyramid_motion) + 1):
+                pyramid_motion[-p][1] = pyramid_motion[-p][1] * self.hier_weight_gen(pyramid_motion[-(p - 1)][1])
+            tq_map_g_masked = tq_map_g * input_mask
 
         translations, rotations = [], []
         for o in odoms:
@@ -179,8 +200,29 @@ class UNOdomPredEncDecSVDTempMaskBase(OdomPredEncDecBase):
             translations.append(t)
             rotations.append(r)
         extra = {} if bev_sums is None else {"_bev_sums": bev_sums}
-        return {**extra, "translation_preds": translations, "rotation_preds": rotations, "tq_map_g": tq_map_g * input_mask,
+        return {**extra, "translation_preds": translations, "rotation_preds": rotations, "tq_map_g": tq_map_g_masked,
                 "pyramid_motion": pyramid_motion, "transformed_inputs": None, "t_conf": t_conf, "r_conf": r_conf}
+
+    def _fused_tail_ok(self, x, input_mask):
+        """The element-wise tail on csrc/headtail.hip: GPU fp32 tensors, softmax confidences, the pyramid's pooling
+        geometry the kernels implement (MaxPool / AvgPool 3, stride 2, padding 1; at most 3 coarser levels).
+        RSLO_FUSED_HEAD_TAIL=0 keeps the torch ops."""
+        import os
+        ok = self.__dict__.get("_fused_tail_static")
+        if ok is None:
+            n = len(self.deblocks) - 1 if self.pred_pyramid_motion else 0
+            ok = (os.environ.get("RSLO_FUSED_HEAD_TAIL", "1") != "0" and self.fused_vote and self.conf_type == "softmax"
+                  and self.dense_predict and 0 <= n <= 3
+                  and isinstance(self.hier_weight_gen, nn.AvgPool2d)
+                  and (self.hier_weight_gen.kernel_size, self.hier_weight_gen.stride, self.hier_weight_gen.padding) == (3, 2, 1)
+                  and (n == 0 or all(isinstance(mp, nn.MaxPool2d) and (mp.kernel_size, mp.stride, mp.padding) == (3, 2, 1)
+                                     for mp in list(self.mask_gen_pools)[-n:])))
+            self.__dict__["_fused_tail_static"] = ok
+        if not ok or not (x.is_cuda and x.dtype == torch.float32 and input_mask.dim() == 4):
+            return False
+        n = len(self.deblocks) - 1 if self.pred_pyramid_motion else 0
+        H, W = input_mask.shape[2:]
+        return H % (1 << n) == 0 and W % (1 << n) == 0 and H * W <= 32768
 
     def _snapshot_bn(self, modules):
         """Running statistics of the training-mode BatchNorms inside `modules`, before they are updated."""
@@ -256,6 +298,74 @@ class UNOdomPredEncDecSVDTempMaskBase(OdomPredEncDecBase):
         if self.use_svd:
             return [self.vote_svd(m, sm, tc) for m, sm, tc in zip(tq_maps, selected_masks, t_confs)]
         return [self.vote(m, tc, rc)[1] for m, tc, rc in zip(tq_maps, t_confs, r_confs)]
+
+
+class _TqNormFn(torch.autograd.Function):
+    """tq [B,7,H,W] -> cat(t, q / |q|) (rslo_tq_normalize_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, tq):
+        from rslo_amd import capi
+        tq = tq.contiguous()
+        ctx.save_for_backward(tq)
+        return capi.tq_normalize_fwd(tq)
+
+    @staticmethod
+    def backward(ctx, g):
+        from rslo_amd import capi
+        (tq,) = ctx.saved_tensors
+        return capi.tq_normalize_bwd(tq, g.contiguous())
+
+
+class _ConfPairFn(torch.autograd.Function):
+    """Both confidence heads' masked spatial softmaxes in one launch (rslo_conf_softmax_fwd / _bwd):
+    (t_logit, r_logit [B,1,H,W], outside bool) -> t_conf, r_conf at T = 1 (differentiable) and cat(t, r) at T = temperature
+    (no gradient: it only weighs the loss)."""
+
+    @staticmethod
+    def forward(ctx, t_logit, r_logit, outside, temperature):
+        from rslo_amd import capi
+        t_conf, r_conf, ct = capi.conf_softmax_fwd(t_logit.contiguous(), r_logit.contiguous(), outside.contiguous(),
+                                                   temperature)
+        ctx.save_for_backward(t_conf, r_conf, outside)
+        ctx.mark_non_differentiable(ct)
+        return t_conf, r_conf, ct
+
+    @staticmethod
+    def backward(ctx, g_t, g_r, _g):
+        from rslo_amd import capi
+        t_conf, r_conf, outside = ctx.saved_tensors
+        g_t = torch.zeros_like(t_conf) if g_t is None else g_t.contiguous()
+        g_r = torch.zeros_like(r_conf) if g_r is None else g_r.contiguous()
+        d_t, d_r = capi.conf_softmax_bwd(t_conf, r_conf, g_t, g_r, outside.contiguous())
+        return d_t, d_r, None, None
+
+
+class _HeadMasksFn(torch.autograd.Function):
+    """Mask / loss-weight pyramid and the masked maps (rslo_head_masks_fwd / _bwd).
+    (tq_map, input_mask, conf_temp, tq_map_g, *preds finest first) -> (tq_map * mask, tq_map_g * mask,
+    *pred_k * (occ_k > 0), *w_k for k = 0 .. levels-1).  Gradients reach tq_map and the predictions only."""
+
+    @staticmethod
+    def forward(ctx, tq, mask, conf, tq_g, *preds):
+        from rslo_amd import capi
+        preds = [p.contiguous() for p in preds]
+        mask = mask.contiguous()
+        w, occ, mp, mtq, mtq_g = capi.head_masks_fwd(mask, conf.contiguous(), tq.contiguous(), tq_g.contiguous(), preds)
+        ctx.save_for_backward(*occ)
+        ctx.shapes = [tuple(p.shape) for p in preds]
+        ctx.mark_non_differentiable(mtq_g, *w)
+        return (mtq, mtq_g, *mp, *w)
+
+    @staticmethod
+    def backward(ctx, g_mtq, _g_mtqg, *rest):
+        from rslo_amd import capi
+        occ = ctx.saved_tensors
+        n = len(ctx.shapes)
+        g_mp = [g.contiguous() if g is not None else None for g in rest[:n]]
+        d_preds, d_tq = capi.head_masks_bwd(occ[0], list(occ), g_mp, None if g_mtq is None else g_mtq.contiguous(),
+                                            ctx.shapes)
+        return (d_tq, None, None, None, *d_preds)
 
 
 class _VoteFn(torch.autograd.Function):
