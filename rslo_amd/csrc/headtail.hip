@@ -8,7 +8,7 @@
 //              masked pyramid predictions p * (m > 0), masked pose maps
 //
 // As torch ops this is ~45 launches forward and ~45 backward per step on maps of a few 10^4 cells -- each one costs more
-// in launch gap than in work.  Three kernels forward, three backward.
+// in launch gap than in work.  Five small launches forward (three for the mask pyramid's levels), three backward.
 #include "rslo_common.h"
 
 // ----------------------------------------------------------------------------------------- quaternion normalisation
@@ -182,8 +182,8 @@ extern "C" int rslo_conf_softmax_bwd(const float *t_conf, const float *r_conf, c
 // Level 0 = the H x W map; level k + 1 = level k pooled with kernel 3, stride 2, padding 1 (H, W even: half the size).
 //   occ_0 = mask;                 occ_{k+1} = MaxPool(occ_k)            (padding ignored by the max)
 //   w_0   = mask * conf_T [2 ch]; w_{k+1}   = occ_{k+1} * AvgPool(w_k)  (zero padding counted: divisor 9)
-// One thread per (level >= 1, sample, cell) recomputes what it needs from level 0 (a 7 x 7 window at level 2), so the
-// levels need no ordering between them.  Masked maps: pred_k * (occ_k > 0) for the pyramid predictions (k >= 1),
+// One small launch per level (a coarser level reads the one below; recomputing everything from level 0 in ONE launch left
+// a few blocks walking 7 x 7 windows: 70 us).  Masked maps: pred_k * (occ_k > 0) for the pyramid predictions (k >= 1),
 // tq * mask and tq_g * mask at level 0.
 struct HeadMaskArgs {
   const float *mask;        // [B, 1, H, W] float 0/1
@@ -197,57 +197,15 @@ struct HeadMaskArgs {
   int B, H, W, levels;      // levels = 1 + number of pyramid predictions (<= 4)
 };
 
-template <int K>
-__device__ float hm_occ(const float *__restrict__ m0, int H, int W, int y, int x) {
-  // occupancy of cell (y, x) of level K = max of the level-0 mask over its receptive field
-  if constexpr (K == 0) {
-    return m0[y * W + x];
-  } else {
-    float r = -INFINITY;
-    for (int dy = -1; dy <= 1; ++dy)
-      for (int dx = -1; dx <= 1; ++dx) {
-        const int yy = 2 * y + dy, xx = 2 * x + dx;
-        if (yy < 0 || xx < 0 || yy >= (H >> (K - 1)) || xx >= (W >> (K - 1))) continue;
-        r = fmaxf(r, hm_occ<K - 1>(m0, H, W, yy, xx));
-      }
-    return r;
-  }
-}
-
-template <int K>
-__device__ float hm_w(const float *__restrict__ m0, const float *__restrict__ c0, int H, int W, int y, int x) {
-  if constexpr (K == 0) {
-    return m0[y * W + x] * c0[y * W + x];
-  } else {
-    float s = 0.f;
-    for (int dy = -1; dy <= 1; ++dy)
-      for (int dx = -1; dx <= 1; ++dx) {
-        const int yy = 2 * y + dy, xx = 2 * x + dx;
-        if (yy < 0 || xx < 0 || yy >= (H >> (K - 1)) || xx >= (W >> (K - 1))) continue;
-        s += hm_w<K - 1>(m0, c0, H, W, yy, xx);
-      }
-    return hm_occ<K>(m0, H, W, y, x) * (s / 9.0f);
-  }
-}
-
-__device__ __forceinline__ float hm_occ_k(const float *m0, int H, int W, int k, int y, int x) {
-  return k == 1 ? hm_occ<1>(m0, H, W, y, x) : (k == 2 ? hm_occ<2>(m0, H, W, y, x) : hm_occ<3>(m0, H, W, y, x));
-}
-__device__ __forceinline__ float hm_w_k(const float *m0, const float *c0, int H, int W, int k, int y, int x) {
-  return k == 1 ? hm_w<1>(m0, c0, H, W, y, x) : (k == 2 ? hm_w<2>(m0, c0, H, W, y, x) : hm_w<3>(m0, c0, H, W, y, x));
-}
-
-// grid (cells of level 0 / 256, B, levels)
-__global__ void k_head_masks_fwd(HeadMaskArgs a) {
-  const int k = blockIdx.z, b = blockIdx.y;
+// one launch per level, coarser levels read the level below (stream order): grid (cells of level k / 256, B)
+__global__ void k_head_masks_fwd(HeadMaskArgs a, int k) {
+  const int b = blockIdx.y;
   const int h = a.H >> k, w = a.W >> k;
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= h * w) return;
-  const int y = c / w, x = c - y * w;
-  const float *m0 = a.mask + (int64_t)b * a.H * a.W;
   const int64_t cells = (int64_t)h * w;
   if (k == 0) {
-    const float m = m0[c];
+    const float m = a.mask[(int64_t)b * cells + c];
 #pragma unroll
     for (int ch = 0; ch < 2; ++ch) a.w[0][((int64_t)b * 2 + ch) * cells + c] = m * a.conf[((int64_t)b * 2 + ch) * cells + c];
 #pragma unroll
@@ -258,11 +216,24 @@ __global__ void k_head_masks_fwd(HeadMaskArgs a) {
     }
     return;
   }
-  const float o = hm_occ_k(m0, a.H, a.W, k, y, x);
-  a.occ[k][(int64_t)b * cells + c] = o;
+  const int y = c / w, x = c - y * w;
+  const int hp = a.H >> (k - 1), wp = a.W >> (k - 1);
+  const float *occ_p = (k == 1 ? a.mask : a.occ[k - 1]) + (int64_t)b * hp * wp;
+  const float *w_p = a.w[k - 1] + (int64_t)b * 2 * hp * wp;
+  float o = -INFINITY, s0 = 0.f, s1 = 0.f;
 #pragma unroll
-  for (int ch = 0; ch < 2; ++ch)
-    a.w[k][((int64_t)b * 2 + ch) * cells + c] = hm_w_k(m0, a.conf + ((int64_t)b * 2 + ch) * a.H * a.W, a.H, a.W, k, y, x);
+  for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+    for (int dx = -1; dx <= 1; ++dx) {
+      const int yy = 2 * y + dy, xx = 2 * x + dx;
+      if (yy < 0 || xx < 0 || yy >= hp || xx >= wp) continue;      // MaxPool ignores the padding, AvgPool adds zeros
+      o = fmaxf(o, occ_p[yy * wp + xx]);
+      s0 += w_p[yy * wp + xx];
+      s1 += w_p[(int64_t)hp * wp + yy * wp + xx];
+    }
+  a.occ[k][(int64_t)b * cells + c] = o;
+  a.w[k][((int64_t)b * 2 + 0) * cells + c] = o * (s0 / 9.0f);
+  a.w[k][((int64_t)b * 2 + 1) * cells + c] = o * (s1 / 9.0f);
   const float keep = o > 0.f ? 1.f : 0.f;
 #pragma unroll
   for (int ch = 0; ch < 7; ++ch) {
@@ -322,8 +293,9 @@ extern "C" int rslo_head_masks_fwd(const RsloHeadMasks *h_a, void *stream) {
     if (k >= 1 && k < a.levels)
       RSLO_CHECK_ARG(a.w[k] && a.occ[k] && a.pred[k - 1] && a.mpred[k - 1], "rslo_head_masks_fwd: null level pointer");
   }
-  hipLaunchKernelGGL(k_head_masks_fwd, dim3((unsigned)rslo_cdiv((int64_t)a.H * a.W, 256), (unsigned)a.B, (unsigned)a.levels),
-                     dim3(256), 0, (hipStream_t)stream, a);
+  for (int k = 0; k < a.levels; ++k)
+    hipLaunchKernelGGL(k_head_masks_fwd, dim3((unsigned)rslo_cdiv((int64_t)(a.H >> k) * (a.W >> k), 256), (unsigned)a.B),
+                       dim3(256), 0, (hipStream_t)stream, a, k);
   RSLO_CHECK_LAUNCH("k_head_masks_fwd");
   return RSLO_OK;
 }

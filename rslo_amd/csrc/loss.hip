@@ -442,10 +442,13 @@ __global__ void k_icp_solve(const double *__restrict__ partial, int nblk, float 
                             float *__restrict__ res_t, float *__restrict__ step_R, float *__restrict__ step_t) {
   const int b = blockIdx.x;
   __shared__ double mo[ICP_NM];
-  if (threadIdx.x < ICP_NM) {
+  // one wave per moment (4 waves take the moments round-robin), lanes stride over the block partials: a single thread
+  // per moment walked ~120 dependent loads (most of this kernel's 55 us); fixed lane / shuffle order: deterministic
+  for (int m = threadIdx.x >> 6; m < ICP_NM; m += blockDim.x >> 6) {
     double s = 0.0;
-    for (int k = 0; k < nblk; ++k) s += partial[((int64_t)b * nblk + k) * ICP_NM + threadIdx.x];
-    mo[threadIdx.x] = s;
+    for (int k = threadIdx.x & 63; k < nblk; k += 64) s += partial[((int64_t)b * nblk + k) * ICP_NM + m];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if ((threadIdx.x & 63) == 0) mo[m] = s;
   }
   __syncthreads();
   if (threadIdx.x != 0) return;
@@ -507,7 +510,7 @@ extern "C" int rslo_icp_step(const float *p1, const float *n1, const float *tgt,
   const int nblk = (int)rslo_cdiv(N, LS_THREADS);
   hipLaunchKernelGGL(k_icp_moments, dim3(nblk, B), dim3(LS_THREADS), 0, st, p1, n1, tgt, idx, dist, thr, N, M,
                      (double *)ws);
-  hipLaunchKernelGGL(k_icp_solve, dim3(B), dim3(64), 0, st, (const double *)ws, nblk, res_r, res_t, step_R, step_t);
+  hipLaunchKernelGGL(k_icp_solve, dim3(B), dim3(256), 0, st, (const double *)ws, nblk, res_r, res_t, step_R, step_t);
   RSLO_CHECK_LAUNCH("icp_step");
   return RSLO_OK;
 }
@@ -669,27 +672,27 @@ __global__ void k_transform_rows(const float *__restrict__ x, int row_stride, co
 }
 
 #define TR_THREADS 256
+#define TR_MAXBLK 32          // blocks per pair: each thread walks rows j, j + blocks * 256, ... (fp64 sums)
+// Two launches, no fence: a last-block finish behind __threadfence() writes back the XCD's L2, which right after the
+// residual kernels is full of dirty lines (78 us for this 3 MB reduction inside the step).
 __global__ __launch_bounds__(TR_THREADS) void k_transform_rows_bwd(const float *__restrict__ x, int row_stride,
                                                                    const float *__restrict__ g, int M,
-                                                                   double *__restrict__ part, int *__restrict__ done,
-                                                                   float *__restrict__ dR, float *__restrict__ dt) {
+                                                                   double *__restrict__ part) {
   const int b = blockIdx.y;
-  const int j = blockIdx.x * TR_THREADS + threadIdx.x;
   double s[12];
 #pragma unroll
   for (int k = 0; k < 12; ++k) s[k] = 0.0;
-  if (j < M) {
+  for (int j = blockIdx.x * TR_THREADS + threadIdx.x; j < M; j += gridDim.x * TR_THREADS) {
     const float *p = x + ((int64_t)b * M + j) * row_stride;
     const float *q = g + ((int64_t)b * M + j) * 3;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
 #pragma unroll
-      for (int c = 0; c < 3; ++c) s[a * 3 + c] = (double)q[a] * (double)p[c];
-      s[9 + a] = q[a];
+      for (int c = 0; c < 3; ++c) s[a * 3 + c] += (double)q[a] * (double)p[c];
+      s[9 + a] += q[a];
     }
   }
   __shared__ double red[12][TR_THREADS / 64];
-  __shared__ int is_last;
 #pragma unroll
   for (int k = 0; k < 12; ++k) {
     double v = s[k];
@@ -702,23 +705,18 @@ __global__ __launch_bounds__(TR_THREADS) void k_transform_rows_bwd(const float *
     for (int w = 0; w < TR_THREADS / 64; ++w) v += red[threadIdx.x][w];
     part[((int64_t)b * gridDim.x + blockIdx.x) * 12 + threadIdx.x] = v;
   }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence();
-    is_last = atomicAdd(&done[b], 1) == (int)gridDim.x - 1;
-    if (is_last) __threadfence();
-  }
-  __syncthreads();
-  if (!is_last) return;
-  if (threadIdx.x < 12) {
-    double v = 0.0;
-    for (unsigned k = 0; k < gridDim.x; ++k) v += part[((int64_t)b * gridDim.x + k) * 12 + threadIdx.x];
-    if (threadIdx.x < 9)
-      dR[b * 9 + threadIdx.x] = (float)v;
-    else
-      dt[b * 3 + threadIdx.x - 9] = (float)v;
-  }
-  if (threadIdx.x == 0) done[b] = 0;
+}
+
+__global__ void k_transform_rows_bwd_finish(const double *__restrict__ part, int nblk, float *__restrict__ dR,
+                                            float *__restrict__ dt) {
+  const int b = blockIdx.x, k = threadIdx.x;
+  if (k >= 12) return;
+  double v = 0.0;
+  for (int i = 0; i < nblk; ++i) v += part[((int64_t)b * nblk + i) * 12 + k];      // block order: deterministic
+  if (k < 9)
+    dR[b * 9 + k] = (float)v;
+  else
+    dt[b * 3 + k - 9] = (float)v;
 }
 
 extern "C" int rslo_transform_rows(const float *x, int row_stride, const float *R, const float *t, int B, int M,
@@ -731,20 +729,29 @@ extern "C" int rslo_transform_rows(const float *x, int row_stride, const float *
   return RSLO_OK;
 }
 
+static int tr_blocks(int M) {
+  const int64_t n = rslo_cdiv(M > 0 ? M : 1, TR_THREADS * 4);
+  return (int)(n < 1 ? 1 : (n > TR_MAXBLK ? TR_MAXBLK : n));
+}
+
 extern "C" size_t rslo_transform_rows_bwd_ws_bytes(int B, int M) {
-  return (size_t)(B > 0 ? B : 1) * (size_t)rslo_cdiv(M > 0 ? M : 1, TR_THREADS) * 12 * sizeof(double);
+  return (size_t)(B > 0 ? B : 1) * (size_t)tr_blocks(M) * 12 * sizeof(double);
 }
 
 extern "C" int rslo_transform_rows_bwd(const float *x, int row_stride, const float *gout, int B, int M, void *ws,
                                        size_t ws_bytes, int32_t *done, float *dR, float *dt, void *stream) {
-  RSLO_CHECK_ARG(x && gout && done && dR && dt && row_stride >= 3 && M >= 1, "rslo_transform_rows_bwd: bad arguments");
+  (void)done;       // kept in the signature (ABI): the fence-based single-launch finish it served is gone
+  RSLO_CHECK_ARG(x && gout && dR && dt && row_stride >= 3 && M >= 1, "rslo_transform_rows_bwd: bad arguments");
   if (B == 0) return RSLO_OK;
   if (ws_bytes < rslo_transform_rows_bwd_ws_bytes(B, M)) {
     rslo_set_error("transform_rows_bwd: workspace too small");
     return RSLO_EWS;
   }
-  hipLaunchKernelGGL(k_transform_rows_bwd, dim3((unsigned)rslo_cdiv(M, TR_THREADS), B), dim3(TR_THREADS), 0,
-                     (hipStream_t)stream, x, row_stride, gout, M, (double *)ws, (int *)done, dR, dt);
+  const int nblk = tr_blocks(M);
+  hipLaunchKernelGGL(k_transform_rows_bwd, dim3((unsigned)nblk, B), dim3(TR_THREADS), 0, (hipStream_t)stream, x,
+                     row_stride, gout, M, (double *)ws);
+  hipLaunchKernelGGL(k_transform_rows_bwd_finish, dim3(B), dim3(64), 0, (hipStream_t)stream, (const double *)ws, nblk, dR,
+                     dt);
   RSLO_CHECK_LAUNCH("transform_rows_bwd");
   return RSLO_OK;
 }
