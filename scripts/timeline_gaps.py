@@ -38,3 +38,13 @@ for q, rs in sorted(byq.items(), key=lambda kv: -len(kv[1])):
             small[n[:60]][1] += (e - s) / 1e6
     for n, (c, t) in sorted(small.items(), key=lambda kv: -kv[1][1])[:14]:
         print("      %4d %7.3f ms  %s" % (c, t, n))
+
+# launches that hold the stream with very few workgroups (latency-bound chains): candidates for restructuring
+print("== launches with < 64 workgroups lasting > 12 us (all queues), per step")
+agg = collections.defaultdict(lambda: [0, 0.0, 0])
+for s, e, n, q, g in sel:
+    if g < 64 and (e - s) > 12000:
+        a = agg[n[:70]]
+        a[0] += 1; a[1] += (e - s) / 1e3; a[2] = max(a[2], g)
+for n, (c, t, g) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+    print("   %3d x %7.1f us avg (<= %3d wg)  %s" % (c, t / c, g, n))
