@@ -166,6 +166,7 @@ class _ConvBNActFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         from rslo_amd import capi
+        from rslo.layers import hip_conv2d
         from apex.parallel import fused_bn_backward
         x, w, g, o, y, mean, invstd, cnt = ctx.saved_tensors
         wt, slope, lp, has_bias, group, world = ctx.meta
@@ -173,9 +174,9 @@ class _ConvBNActFn(torch.autograd.Function):
         dx = capi.conv2d_fwd(d_o, wt, None, w.shape[1], lp=lp) if ctx.needs_input_grad[0] else None
         dcb = None
         if has_bias:
-            dw, dcb = capi.conv2d_wgrad(x, d_o, 1, want_bias=True, lp=lp)
+            dw, dcb = hip_conv2d.conv2d_wgrad_leaf(x, d_o, 1, want_bias=True, lp=lp)
         else:
-            dw = capi.conv2d_wgrad(x, d_o, 1, lp=lp)
+            dw = hip_conv2d.conv2d_wgrad_leaf(x, d_o, 1, lp=lp)
         return dx, dw, dcb, dg, db, None, None, None
 
 

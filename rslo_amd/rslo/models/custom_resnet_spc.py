@@ -103,14 +103,15 @@ class _BasicBlockFn(torch.autograd.Function):
         act = slope != 1.0
         d_o2, d_res, dg2, db2 = fused_bn_backward(gy, y2 if act else None, o2, g2, m2, i2, n2, slope, True, True, group, world)
         d_y1 = capi.conv2d_fwd(d_o2, w2t, None, w2.shape[1], lp=lp)
-        dw2 = capi.conv2d_wgrad(y1, d_o2, 1, lp=lp)
+        from rslo.layers import hip_conv2d
+        dw2 = hip_conv2d.conv2d_wgrad_leaf(y1, d_o2, 1, lp=lp)
         d_o1, _, dg1, db1 = fused_bn_backward(d_y1, y1 if act else None, o1, g1, m1, i1, n1, slope, False, True, group, world)
         if s == 2:
             dx = capi.conv2d_dgrad_s2(d_o1, w1t, w1.shape[1], x.shape[2], x.shape[3], 3)
         else:
             dx = capi.conv2d_fwd(d_o1, w1t, None, w1.shape[1], lp=lp)
         if hip_w1:
-            dw1 = capi.conv2d_wgrad(x, d_o1, s, lp=lp)
+            dw1 = hip_conv2d.conv2d_wgrad_leaf(x, d_o1, s, lp=lp)
         else:       # the full-resolution stride-2 layer: the library's weight gradient (see csrc/conv2d.hip conv2d_plan)
             dw1 = torch.ops.aten.convolution_backward(d_o1, x, w1, None, [s, s], [1, 1], [1, 1], False, [0, 0], 1,
                                                       [False, True, False])[1]

@@ -178,6 +178,10 @@ class OverlappedGradientExchange:
     def _launch_early(self, params):
         sel = self._early_subset(params)
         if sel:
+            import sys
+            conv = sys.modules.get("rslo.layers.hip_conv2d")
+            if conv is not None:            # weight gradients issued on the leaf stream: this stream waits for them first
+                conv.join_leaf_stream()
             # the engine runs AccumulateGrad nodes ahead of everything else that is ready, so at the hook every gradient
             # this rank will produce for the early module exists; a missing one is absent on this rank: zeros
             grads, flat, work = _reduce_bucket(sel, self.mean, async_op=True)
