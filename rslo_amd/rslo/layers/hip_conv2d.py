@@ -20,48 +20,17 @@ HIP_PASSES = os.environ.get("RSLO_CONV2D_PASSES", "wfd")
 HIP_STRIDE2 = os.environ.get("RSLO_CONV2D_S2", "1") != "0"
 
 
-# The weight-gradient kernels of the dense head run on a second stream (RSLO_WGRAD_STREAM=0: on the issuing stream).  A weight gradient is a LEAF of backward
-# (nothing downstream in the pass reads it), while the data-gradient chain it hangs off is a sequence of dependent launches
-# that leave most CUs idle on the half- / quarter-resolution maps: the leaf work fills them.  Joined once, by an engine
-# callback at the end of the backward pass (and wherever a caller asks: join_leaf_stream()).
-WGRAD_STREAM = os.environ.get("RSLO_WGRAD_STREAM", "1") != "0"
-_leaf = {}          # device -> {"side": stream, "cur": stream of the backward nodes, "pending": bool}
-
-
 def join_leaf_stream(device=None):
-    """Make the streams that issued leaf work wait for it (no-op when nothing is pending)."""
-    for dev, st in _leaf.items():
-        if st["pending"] and (device is None or dev == device):
-            st["cur"].wait_stream(st["side"])
-            st["pending"] = False
+    from rslo_amd import streams
+    streams.join(device)
 
 
 def conv2d_wgrad_leaf(x, dy, stride, want_bias=False, lp=False):
-    from rslo_amd import capi
-    if not (WGRAD_STREAM and x.is_cuda):
-        return capi.conv2d_wgrad(x, dy, stride, want_bias=want_bias, lp=lp) if want_bias else \
-            capi.conv2d_wgrad(x, dy, stride, lp=lp)
-    dev = x.device
-    cur = torch.cuda.current_stream(dev)
-    st = _leaf.get(dev)
-    if st is None:
-        st = _leaf[dev] = {"side": torch.cuda.Stream(dev), "cur": cur, "pending": False}
-    side = st["side"]
-    ev = torch.cuda.Event()
-    ev.record(cur)
-    side.wait_event(ev)
-    with torch.cuda.stream(side):
-        out = capi.conv2d_wgrad(x, dy, stride, want_bias=want_bias, lp=lp) if want_bias else \
-            capi.conv2d_wgrad(x, dy, stride, lp=lp)
-    x.record_stream(side)
-    dy.record_stream(side)
-    for t in (out if isinstance(out, tuple) else (out,)):
-        if t is not None:
-            t.record_stream(cur)
-    if not st["pending"]:
-        st["pending"], st["cur"] = True, cur
-        torch.autograd.Variable._execution_engine.queue_callback(lambda d=dev: join_leaf_stream(d))
-    return out
+    """rslo_conv2d_wgrad as leaf work of the backward pass (rslo_amd.streams)."""
+    from rslo_amd import capi, streams
+    if want_bias:
+        return streams.leaf(lambda: capi.conv2d_wgrad(x, dy, stride, want_bias=True, lp=lp), (x, dy))
+    return streams.leaf(lambda: capi.conv2d_wgrad(x, dy, stride, lp=lp), (x, dy))
 
 
 def _low_precision():

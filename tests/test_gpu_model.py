@@ -847,15 +847,14 @@ def test_fused_head_tail_matches_torch_formulation(hip):
 
 
 def test_weight_gradients_on_the_leaf_stream_are_the_same_gradients(hip):
-    """rslo.layers.hip_conv2d.conv2d_wgrad_leaf: the dense weight-gradient kernels on a second stream, joined by an
+    """rslo_amd.streams.leaf: the dense weight-gradient kernels on a second stream, joined by an
     engine callback at the end of backward.  Same kernels on the same operands: every gradient equals the single-stream
     run to rounding level, over several steps with the optimizer in between (the join must also order the NEXT step's
     writes)."""
-    from rslo.layers import hip_conv2d
-    from rslo_amd import optim as hip_optim
+    from rslo_amd import streams
     grads = []
     for on in (True, False):
-        hip_conv2d.WGRAD_STREAM = on
+        streams.ENABLED = on
         try:
             torch.manual_seed(7)
             net, _ = workload.build_network()
@@ -872,7 +871,7 @@ def test_weight_gradients_on_the_leaf_stream_are_the_same_gradients(hip):
                 opt.step()
             grads.append(per_step)
         finally:
-            hip_conv2d.WGRAD_STREAM = True
+            streams.ENABLED = True
     a, b = grads
     skip = bias_before_bn(net)
     # two runs of one path are not bit-stable (float atomics in the residual backward, the library's atomically reduced
