@@ -962,7 +962,7 @@ extern "C" int rslo_rulebook_pairs(const int32_t *nbr, int64_t n_rows, int K, vo
 #define RO_BITS 11
 #endif
 #define RO_WINDOW (1 << RO_BITS)
-#define RO_THREADS 256
+#define RO_THREADS 1024
 
 __global__ __launch_bounds__(RO_THREADS) void k_row_order(const int32_t *__restrict__ nbr, int64_t n_host,
                                                           const int32_t *__restrict__ d_n, int K, int flip,
