@@ -588,13 +588,15 @@ def main():
     probe_steps = min(3, args.steps)
     wait[0] = 0.0
     if prefetch is not None:
-        prefetch.lead_wait_seconds = prefetch.plan_wait_seconds = 0.0
+        prefetch.plan_wait_seconds = 0.0
     for v in ph.values():
         v[0] = v[1] = 0.0
     alloc0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)      # hipMalloc calls so far (caching allocator misses)
     live0 = torch.cuda.memory_allocated(dev)
     gc_every = int(os.environ.get("RSLO_BENCH_GC", "0"))                  # diagnostic: cyclic GC every n timed steps
     t0 = time.perf_counter()
+    from rslo.models import voxel_odom_net as _von0
+    lead_wait0 = _von0._LEAD_WAIT[0]
     cpu0 = time.thread_time()           # CPU time of the issuing thread: close to the wall time = host-bound step
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # one event per step: spread of the
     marks[0].record()                                                                # step time without extra syncs
@@ -608,6 +610,8 @@ def main():
             import gc
             gc.collect()
     cpu_issue = time.thread_time() - cpu0
+    from rslo.models import voxel_odom_net as _von
+    held_back = _von._LEAD_WAIT[0] - lead_wait0       # seconds the issuing thread was held back behind the GPU (a spinning wait)
     barrier()
     elapsed = time.perf_counter() - t0
     probe.enabled = False
@@ -659,15 +663,12 @@ def main():
                        "distinct_batches": n_sets, "pinned_cpus": pinned,
                        "optimizer_in_step": not args.no_optim,
                        # CPU time of the issuing thread minus the time it was HELD BACK behind the GPU (a spinning wait)
-                       "host_issue_ms_per_step": round(1e3 * (cpu_issue - (prefetch.lead_wait_seconds if prefetch else 0.0))
-                                                       / args.steps, 3),
+                       "host_issue_ms_per_step": round(1e3 * (cpu_issue - held_back) / args.steps, 3),
                        # get(): waiting for the helper's result / the plan's event + assembling the example from the arena
-                       "prefetch_wait_ms_per_step": round(1e3 * (wait[0] - (prefetch.lead_wait_seconds if prefetch else 0.0))
-                                                          / args.steps, 3),
-                       # get(): the issuing thread sleeping until the GPU is within RSLO_HOST_LEAD forward passes (slack of a
+                       "prefetch_wait_ms_per_step": round(1e3 * wait[0] / args.steps, 3),
+                       # the issuing thread sleeping until the GPU is within RSLO_HOST_LEAD forward passes (slack of a
                        # GPU-bound step; an unbounded lead fills the launch queue and costs ~0.4 ms per step)
-                       "host_held_back_ms_per_step": (round(1e3 * prefetch.lead_wait_seconds / args.steps, 3)
-                                                      if prefetch else None),
+                       "host_held_back_ms_per_step": round(1e3 * held_back / args.steps, 3),
                        "prefetch_thread_cpu_ms_per_step": (round(1e3 * prefetch.cpu_seconds / max(prefetch.jobs, 1), 3)
                                                            if prefetch is not None and hasattr(prefetch, "jobs") else None),
                        "final_loss": round(loss_val, 4)},

@@ -30,6 +30,9 @@ from rslo.data.dataset import generate_pointwise_local_transformation_tch
 from rslo.models import middle, odom_pred, voxel_encoder
 
 _SIDE_STREAMS = {}
+_HOST_LEAD = int(os.environ.get("RSLO_HOST_LEAD", "1"))
+_LEAD_EVENTS = {}        # id(network) -> events recorded behind its recent training forwards (kept outside the module)
+_LEAD_WAIT = [0.0]       # seconds the issuing thread was held back (bench.py reports it)
 
 REGISTERED_NETWORK_CLASSES = {}
 
@@ -336,10 +339,26 @@ class UnVoxelOdomNetICP3(nn.Module):
                 cb.append(torch.cat([coors[t][i, :n] for i, n in enumerate(nv)], 0))
             voxels, num_points, coors = vb, nb, cb
         batch_size_dev = example["num_voxels"][0].shape[0]
+        throttle = self.training and voxels[0].is_cuda and _HOST_LEAD > 0
+        if throttle:
+            # The issuing thread runs at most _HOST_LEAD forward passes ahead of the GPU (a sleeping wait on the event
+            # recorded behind an earlier forward).  Nothing else bounds it -- the step has no host read -- and a thread
+            # that fills the launch queue spins inside hipLaunchKernel and costs GPU time: 14.1 vs 13.7 ms per step
+            # measured.  RSLO_HOST_LEAD=0: unbounded.
+            ring = _LEAD_EVENTS.setdefault(id(self), [])
+            if len(ring) >= _HOST_LEAD:
+                t0 = time.perf_counter()
+                ring[-_HOST_LEAD].synchronize()
+                _LEAD_WAIT[0] += time.perf_counter() - t0
         preds_dict = self.network_forward(voxels, num_points, coors, batch_size_dev, example=example)
 
         if self.training:
             ret = self.loss(example, preds_dict)
+            if throttle:
+                ev = torch.cuda.Event(blocking=True)
+                ev.record(torch.cuda.current_stream(voxels[0].device))
+                ring.append(ev)
+                del ring[:-(_HOST_LEAD + 1)]
             extras = {
                 "middle_feature": preds_dict["middle_feature"], "feature_mask": preds_dict["feature_mask"],
                 "t_conf": preds_dict.pop("t_conf", None), "r_conf": preds_dict.pop("r_conf", None),

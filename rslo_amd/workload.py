@@ -110,11 +110,6 @@ class ExamplePrefetcher:
         self._keep = {}             # seq -> example, until the training stream is done with it
         self._next_submit = self._next_get = 0
         self._done_ring = []
-        # get() lets the issuing thread run at most `host_lead` forward passes ahead of the GPU (a SLEEPING wait on the
-        # event submit() recorded behind an earlier forward).  Nothing else bounds it once the plan needs no host read,
-        # and a host that fills the launch queue spins inside hipLaunchKernel instead.  0 = unbounded.
-        self.host_lead = int(os.environ.get("RSLO_HOST_LEAD", "1"))
-        self._lead_ring = []
         self.lead_wait_seconds = self.plan_wait_seconds = 0.0
         self.cpu_seconds, self.jobs = 0.0, 0
         # Several Python threads issue GPU work here.  With the interpreter's default 5 ms switch interval a helper can
@@ -178,10 +173,8 @@ class ExamplePrefetcher:
                 self._cv.notify_all()
 
     def submit(self, clouds):
-        done = torch.cuda.Event(blocking=True)
+        done = torch.cuda.Event()
         done.record(torch.cuda.current_stream(self.device))
-        self._lead_ring.append(done)
-        del self._lead_ring[:-(self.host_lead + 2)]
         if self.planner is not None:
             # Arena reuse is the only thing a native-plan job has to wait for.  Job j writes arena j mod A, last read by
             # the step that consumed job j - A; the event of submit j - (A - 1 - depth) was recorded behind the forward
@@ -207,10 +200,7 @@ class ExamplePrefetcher:
             raise err
         import time
         t0 = time.perf_counter()
-        if self.host_lead > 0 and len(self._lead_ring) >= self.host_lead:
-            self._lead_ring[-self.host_lead].synchronize()
-        t1 = time.perf_counter()
-        self.lead_wait_seconds += t1 - t0        # the issuing thread held back behind the GPU: slack, not a stall
+        t1 = t0         # (the bound on the issuing thread's lead lives in the network's forward: voxel_odom_net.py)
         if self.planner is not None:
             ex = self.planner.finish(ex)        # host wait on an event recorded a step ago, then arena views
         self.plan_wait_seconds += time.perf_counter() - t1   # the plan itself was late / assembling the example
