@@ -306,6 +306,8 @@ typedef struct {
       conv_pin_off[RSLO_PLAN_MAX_LEVELS], conv_pout_off[RSLO_PLAN_MAX_LEVELS], conv_koff_off[RSLO_PLAN_MAX_LEVELS];
   int64_t scratch_words;
   uint64_t vox_ws_off, bitmap_off, prefix_off, scan_ws_off, pair_ws_off;
+  uint64_t keys_end_off;                                 /* keys_off[0] .. keys_end_off: the keys of all levels (one fill) */
+  uint64_t bitmap_level_off[RSLO_PLAN_MAX_LEVELS], bitmap_end_off;   /* output bitmap of conv l, all levels contiguous */
 } RsloPlanLayout;
 RSLO_API int rslo_plan_encoder_layout(const RsloEncoderSpec *h_spec, int n_clouds, const int64_t *h_n_points,
                                       RsloPlanLayout *h_layout);

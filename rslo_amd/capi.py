@@ -284,7 +284,8 @@ class PlanLayout(C.Structure):
                 ("conv_nbr_off", _LU64), ("conv_nbrT_off", _LU64), ("conv_order_off", _LU64), ("conv_pin_off", _LU64),
                 ("conv_pout_off", _LU64), ("conv_koff_off", _LU64), ("scratch_words", C.c_int64),
                 ("vox_ws_off", C.c_uint64), ("bitmap_off", C.c_uint64), ("prefix_off", C.c_uint64),
-                ("scan_ws_off", C.c_uint64), ("pair_ws_off", C.c_uint64)]
+                ("scan_ws_off", C.c_uint64), ("pair_ws_off", C.c_uint64), ("keys_end_off", C.c_uint64),
+                ("bitmap_level_off", _LU64), ("bitmap_end_off", C.c_uint64)]
 
 
 def plan_encoder_layout(spec, n_points):

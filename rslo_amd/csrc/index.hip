@@ -266,24 +266,35 @@ extern "C" int64_t rslo_conv_bitmap_words(int B, const int32_t *od) {
   return (vol + 31) / 32;
 }
 
-template <bool FAST, bool FAST2>
+// One thread per INPUT row: along every axis an input coordinate c feeds the outputs o with o * stride - pad + k = c, i.e.
+// the k of the right parity -- 1 or 2 of 3 for a 3 / 2 / 1 convolution -- so a row marks 1..8 output sites.  (One thread
+// per (row, offset) walked all 27 candidates of which ~3.4 survive: 81 us for 250 k rows, now ~15.)
 __global__ void k_conv_mark(const int32_t *__restrict__ coords, int64_t N, const int32_t *__restrict__ d_n, Int3 ks,
                             Int3 st, Int3 pd, Dims3 od, uint32_t *__restrict__ bitmap) {
-  const int K = ks.a * ks.b * ks.c;
-  const int64_t total = rslo_rows(N, d_n) * K;
-  RSLO_GRID_STRIDE(t, total) {
-    int64_t i;
-    int kz, ky, kx;
-    rb_decompose<FAST>(t, ks, i, kz, ky, kx);
+  const int64_t n = rslo_rows(N, d_n);
+  RSLO_GRID_STRIDE(i, n) {
     const int4 c = reinterpret_cast<const int4 *>(coords)[i];
-    const int tz = c.y + pd.a - kz, ty = c.z + pd.b - ky, tx = c.w + pd.c - kx;
-    if (tz < 0 || ty < 0 || tx < 0) continue;
-    int z, y, x;
-    if (!rb_unstride<FAST2>(tz, st.a, z) || !rb_unstride<FAST2>(ty, st.b, y) || !rb_unstride<FAST2>(tx, st.c, x))
-      continue;
-    if (z >= od.d || y >= od.h || x >= od.w) continue;
-    const uint32_t lin = rslo_lin(c.x, z, y, x, od);
-    atomicOr(&bitmap[lin >> 5], 1u << (lin & 31));
+    int zs[3], ys[3], xs[3], nz = 0, ny = 0, nx = 0;
+    for (int k = 0; k < ks.a && k < 3; ++k) {
+      const int t = c.y + pd.a - k;
+      if (t >= 0 && t % st.a == 0 && t / st.a < od.d) zs[nz++] = t / st.a;
+    }
+    for (int k = 0; k < ks.b && k < 3; ++k) {
+      const int t = c.z + pd.b - k;
+      if (t >= 0 && t % st.b == 0 && t / st.b < od.h) ys[ny++] = t / st.b;
+    }
+    for (int k = 0; k < ks.c && k < 3; ++k) {
+      const int t = c.w + pd.c - k;
+      if (t >= 0 && t % st.c == 0 && t / st.c < od.w) xs[nx++] = t / st.c;
+    }
+    for (int a = 0; a < nz; ++a)
+      for (int b = 0; b < ny; ++b)
+        for (int e = 0; e < nx; ++e) {
+          const uint32_t lin = rslo_lin(c.x, zs[a], ys[b], xs[e], od);
+          const uint32_t bit = 1u << (lin & 31);
+          // an output site has ~6 contributing inputs: skip the atomic when the bit is already there
+          if (!(__builtin_nontemporal_load(&bitmap[lin >> 5]) & bit)) atomicOr(&bitmap[lin >> 5], bit);
+        }
   }
 }
 
@@ -297,13 +308,10 @@ extern "C" int rslo_conv_out_count(const int32_t *coords_in, int64_t N, int B, c
   RSLO_HIP(hipMemsetAsync(bitmap, 0, (size_t)words * sizeof(uint32_t), st));
   const int K = ks[0] * ks[1] * ks[2];
   if (N > 0) {
-#define RB_MARK(F, F2)                                                                                     \
-    hipLaunchKernelGGL((k_conv_mark<F, F2>), dim3(rb_grid(N * K)), dim3(256), 0, st, coords_in, N,           \
-                       (const int32_t *)nullptr, Int3{ks[0], ks[1], ks[2]}, Int3{stride[0], stride[1], stride[2]}, \
-                       Int3{pad[0], pad[1], pad[2]}, Dims3{od[0], od[1], od[2]}, bitmap)
-    if (rb_fast_k(ks, N) && rb_fast_s(stride)) RB_MARK(true, true);
-    else RB_MARK(false, false);
-#undef RB_MARK
+    RSLO_CHECK_ARG(ks[0] <= 3 && ks[1] <= 3 && ks[2] <= 3, "conv_out_count: kernel extent > 3 unsupported");
+    hipLaunchKernelGGL(k_conv_mark, dim3(rb_grid(N)), dim3(256), 0, st, coords_in, N, (const int32_t *)nullptr,
+                       Int3{ks[0], ks[1], ks[2]}, Int3{stride[0], stride[1], stride[2]},
+                       Int3{pad[0], pad[1], pad[2]}, Dims3{od[0], od[1], od[2]}, bitmap);
     RSLO_CHECK_LAUNCH("conv_mark");
   }
   return scan_exclusive<true>(bitmap, word_prefix, words, scan_ws, scan_ws_bytes, d_count, st);
@@ -523,30 +531,16 @@ __global__ void k_vox_flags(const int32_t *__restrict__ slot, const int32_t *__r
   flags[i] = (s >= 0 && first[s] == (int32_t)i) ? 1u : 0u;
 }
 
-// Plan mode (rslo_plan_encoder): the clouds of a step are voxelized one after the other into ONE row space; cloud c
-// starts at row *d_base (the running total the previous cloud left), writes (b, z, y, x) coordinates twice -- with its
-// index inside the frame (the example dict's `coordinates[t]`, rslo/data/preprocess.py:75-89) and with its index in the
-// batched encoder tensor (t * B + b) -- and leaves the next cloud's base.  d_base == NULL: the stand-alone entry point.
-struct VoxPlan {
-  const int32_t *d_base;
-  int32_t *d_base_next;
-  int32_t *coords_frame, *coords_all;   // [cap, 4]
-  int b_frame, b_all;
-};
-
 __global__ void k_vox_assign(const uint32_t *__restrict__ keys, const int32_t *__restrict__ slot,
                              const uint32_t *__restrict__ flags, const int32_t *__restrict__ pos, int64_t P,
                              VoxGeom G, int max_voxels, int32_t *__restrict__ vid,
                              int32_t *__restrict__ coords, int32_t *__restrict__ cutoff,
-                             int32_t *__restrict__ d_nvox, VoxPlan pl) {
+                             int32_t *__restrict__ d_nvox) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P) return;
-  const int32_t base = pl.d_base ? *pl.d_base : 0;
   if (i == P - 1) {
     const int32_t tot = pos[i] + (int32_t)flags[i];
-    const int32_t nv = tot < max_voxels ? tot : max_voxels;
-    *d_nvox = nv;
-    if (pl.d_base_next) *pl.d_base_next = base + nv;
+    *d_nvox = tot < max_voxels ? tot : max_voxels;
   }
   if (!flags[i]) return;
   const int32_t s = slot[i];
@@ -558,14 +552,9 @@ __global__ void k_vox_assign(const uint32_t *__restrict__ keys, const int32_t *_
     key /= G.g[0];
     const int y = key % G.g[1];
     const int z = key / G.g[1];
-    if (pl.d_base) {
-      reinterpret_cast<int4 *>(pl.coords_frame)[base + v] = make_int4(pl.b_frame, z, y, x);
-      reinterpret_cast<int4 *>(pl.coords_all)[base + v] = make_int4(pl.b_all, z, y, x);
-    } else {
-      coords[v * 3 + 0] = z;
-      coords[v * 3 + 1] = y;
-      coords[v * 3 + 2] = x;
-    }
+    coords[v * 3 + 0] = z;
+    coords[v * 3 + 1] = y;
+    coords[v * 3 + 2] = x;
   } else if (v == max_voxels) {
     *cutoff = (int32_t)i;  // the reference loop `break`s here
   }
@@ -575,7 +564,7 @@ __global__ void k_vox_fill(const float *__restrict__ pts, int64_t P, int F, int 
                            const int32_t *__restrict__ slot, const int32_t *__restrict__ head,
                            const int32_t *__restrict__ next, const int32_t *__restrict__ vid,
                            const int32_t *__restrict__ cutoff, float *__restrict__ voxels,
-                           int32_t *__restrict__ num_points, const int32_t *__restrict__ d_base) {
+                           int32_t *__restrict__ num_points) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P) return;
   const int32_t s = slot[i];
@@ -583,7 +572,7 @@ __global__ void k_vox_fill(const float *__restrict__ pts, int64_t P, int F, int 
   int rank = 0;
   for (int32_t j = head[s]; j >= 0; j = next[j]) rank += (j < (int32_t)i);
   if (rank >= T) return;
-  const int32_t v = vid[s] + (d_base ? *d_base : 0);
+  const int32_t v = vid[s];
   float *dst = voxels + ((int64_t)v * T + rank) * F;
   const float *src = pts + i * F;
   for (int f = 0; f < F; ++f) dst[f] = src[f];
@@ -592,7 +581,7 @@ __global__ void k_vox_fill(const float *__restrict__ pts, int64_t P, int F, int 
 
 // the voxelizer's launches for one cloud (outputs already zero-filled by the caller)
 static int vox_run(const float *points, int64_t P, int F, const VoxGeom &G, int T, int max_voxels, void *ws,
-                   float *voxels, int32_t *coords, int32_t *num_points, int32_t *d_nvox, VoxPlan pl, hipStream_t st) {
+                   float *voxels, int32_t *coords, int32_t *num_points, int32_t *d_nvox, hipStream_t st) {
   VoxWs w;
   vox_ws_layout(P, ws, &w);
   RSLO_HIP(hipMemsetAsync(w.keys, 0xFF, (size_t)w.cap * 8, st));                 // keys | head
@@ -605,9 +594,9 @@ static int vox_run(const float *points, int64_t P, int F, const VoxGeom &G, int 
   RSLO_CHECK_LAUNCH("vox_insert");
   if (int rc = scan_exclusive<false>(w.flags, w.pos, P, w.scan_ws, w.scan_bytes, nullptr, st)) return rc;
   hipLaunchKernelGGL(k_vox_assign, dim3(nb), dim3(256), 0, st, w.keys, w.slot, w.flags, w.pos, P, G,
-                     max_voxels, w.vid, coords, w.cutoff, d_nvox, pl);
+                     max_voxels, w.vid, coords, w.cutoff, d_nvox);
   hipLaunchKernelGGL(k_vox_fill, dim3(nb), dim3(256), 0, st, points, P, F, T, w.slot, w.head, w.next,
-                     w.vid, w.cutoff, voxels, num_points, pl.d_base);
+                     w.vid, w.cutoff, voxels, num_points);
   RSLO_CHECK_LAUNCH("vox_fill");
   return RSLO_OK;
 }
@@ -649,7 +638,7 @@ extern "C" int rslo_voxelize(const float *points, int64_t P, int F, const float 
     G.vs[j] = vsize3[j];
     G.g[j] = grid_xyz[j];
   }
-  return vox_run(points, P, F, G, T, max_voxels, ws, voxels, coords, num_points, d_nvox, VoxPlan{}, st);
+  return vox_run(points, P, F, G, T, max_voxels, ws, voxels, coords, num_points, d_nvox, st);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -833,20 +822,32 @@ extern "C" int rslo_bev_channel_sums(const float *in, int B, int G, int Cg, int6
 // ~250 MB through five launches.
 #define PR_ROWS 256
 
+// Several tables per launch (grid.y = table): rslo_plan_encoder builds the pair lists of all its rulebooks in three
+// launches at the end of the plan; the stand-alone entry point is a batch of one.
+#define PR_MAXTAB 16
+struct PairTable {
+  const int32_t *nbr;
+  const int32_t *d_n;      // device row count (NULL: n_rows)
+  int64_t n_rows;
+  int32_t *counts, *pin, *pout, *koff;
+  int K, nblk;
+};
+struct PairBatch {
+  PairTable t[PR_MAXTAB];
+};
+
 template <bool EMIT>
-__global__ __launch_bounds__(PR_ROWS) void k_pair_pass(const int32_t *__restrict__ nbr, int64_t N_host,
-                                                       const int32_t *__restrict__ d_n, int K, int nblk,
-                                                       int32_t *__restrict__ counts,
-                                                       const int32_t *__restrict__ offsets,
-                                                       int32_t *__restrict__ pin, int32_t *__restrict__ pout) {
+__global__ __launch_bounds__(PR_ROWS) void k_pair_pass(PairBatch pb) {
   __shared__ int32_t tab[PR_ROWS * 27];
   __shared__ int32_t wcnt[PR_ROWS / 64][27];
+  const PairTable &T = pb.t[blockIdx.y];
+  const int32_t *__restrict__ nbr = T.nbr;
+  const int K = T.K;
+  int nblk = T.nblk;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int64_t N = rslo_rows(N_host, d_n);
-  if (d_n) {      // capacity-sized launch: the counts are laid out for the ACTUAL number of row blocks, the rest exit
-    nblk = (int)((N + PR_ROWS - 1) / PR_ROWS);
-    if ((int)blockIdx.x >= nblk) return;
-  }
+  const int64_t N = rslo_rows(T.n_rows, T.d_n);
+  if (T.d_n) nblk = (int)((N + PR_ROWS - 1) / PR_ROWS);      // capacity-sized launch: counts are laid out for the ACTUAL blocks
+  if ((int)blockIdx.x >= nblk) return;
   const int64_t row0 = (int64_t)blockIdx.x * PR_ROWS;
   const int64_t lim = (N - row0 < PR_ROWS ? N - row0 : PR_ROWS) * K;      // table entries of this block
   for (int e = tid; e < PR_ROWS * K; e += PR_ROWS) tab[e] = e < lim ? nbr[row0 * K + e] : -1;
@@ -862,7 +863,7 @@ __global__ __launch_bounds__(PR_ROWS) void k_pair_pass(const int32_t *__restrict
       int32_t c = 0;
 #pragma unroll
       for (int w = 0; w < PR_ROWS / 64; ++w) c += wcnt[w][tid];
-      counts[(int64_t)tid * nblk + blockIdx.x] = c;
+      T.counts[(int64_t)tid * nblk + blockIdx.x] = c;
     }
     return;
   }
@@ -871,26 +872,28 @@ __global__ __launch_bounds__(PR_ROWS) void k_pair_pass(const int32_t *__restrict
     const int32_t r = mine[k];
     const unsigned long long m = __ballot(r >= 0);
     if (r >= 0) {
-      int32_t pos = offsets[(int64_t)k * nblk + blockIdx.x] + __popcll(m & ((1ull << lane) - 1ull));
+      int32_t pos = T.counts[(int64_t)k * nblk + blockIdx.x] + __popcll(m & ((1ull << lane) - 1ull));
       for (int w = 0; w < wid; ++w) pos += wcnt[w][k];
-      pin[pos] = r;
-      pout[pos] = (int32_t)row;
+      T.pin[pos] = r;
+      T.pout[pos] = (int32_t)row;
     }
   }
 }
 
-// exclusive scan of n values in place by ONE workgroup (n = K * blocks, a few 10^4); koff[k] = offset of (k, block 0)
-__global__ __launch_bounds__(1024) void k_pair_scan(int32_t *__restrict__ v, int n, int K, int nblk,
-                                                    const int32_t *__restrict__ d_n, int32_t *__restrict__ koff) {
+// exclusive scan of n = K * blocks values in place, ONE workgroup per table; koff[k] = offset of (k, block 0)
+__global__ __launch_bounds__(1024) void k_pair_scan(PairBatch pb) {
   __shared__ int32_t wsum[16];
+  const PairTable &T = pb.t[blockIdx.x];
+  int32_t *__restrict__ v = T.counts;
+  int32_t *__restrict__ koff = T.koff;
+  const int K = T.K;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  if (d_n) {
-    nblk = (*d_n + PR_ROWS - 1) / PR_ROWS;
-    n = K * nblk;
-    if (nblk == 0) {
-      if (tid <= K) koff[tid] = 0;
-      return;
-    }
+  const int64_t N = rslo_rows(T.n_rows, T.d_n);
+  const int nblk = T.d_n ? (int)((N + PR_ROWS - 1) / PR_ROWS) : T.nblk;
+  const int n = K * nblk;
+  if (nblk == 0) {
+    if (tid <= K) koff[tid] = 0;
+    return;
   }
   const int per = (n + 1023) / 1024;
   const int i0 = tid * per, i1 = (i0 + per < n) ? i0 + per : n;
@@ -915,15 +918,24 @@ __global__ __launch_bounds__(1024) void k_pair_scan(int32_t *__restrict__ v, int
   if (tid == 1023) koff[K] = run;        // the last thread's running sum ends at the total (empty chunks carry it)
 }
 
-static int pairs_run(const int32_t *nbr, int64_t n_rows, const int32_t *d_n, int K, int nblk, int32_t *counts,
-                     int32_t *pairs_in, int32_t *pairs_out, int32_t *koff, hipStream_t st) {
-  hipLaunchKernelGGL(k_pair_pass<false>, dim3((unsigned)nblk), dim3(PR_ROWS), 0, st, nbr, n_rows, d_n, K, nblk, counts,
-                     (const int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
-  hipLaunchKernelGGL(k_pair_scan, dim3(1), dim3(1024), 0, st, counts, K * nblk, K, nblk, d_n, koff);
-  hipLaunchKernelGGL(k_pair_pass<true>, dim3((unsigned)nblk), dim3(PR_ROWS), 0, st, nbr, n_rows, d_n, K, nblk,
-                     (int32_t *)nullptr, (const int32_t *)counts, pairs_in, pairs_out);
+static int pairs_run_batch(const PairBatch &pb, int n_tab, hipStream_t st) {
+  if (n_tab == 0) return RSLO_OK;
+  int max_blk = 1;
+  for (int i = 0; i < n_tab; ++i)
+    if (pb.t[i].nblk > max_blk) max_blk = pb.t[i].nblk;
+  hipLaunchKernelGGL(k_pair_pass<false>, dim3((unsigned)max_blk, (unsigned)n_tab), dim3(PR_ROWS), 0, st, pb);
+  hipLaunchKernelGGL(k_pair_scan, dim3((unsigned)n_tab), dim3(1024), 0, st, pb);
+  hipLaunchKernelGGL(k_pair_pass<true>, dim3((unsigned)max_blk, (unsigned)n_tab), dim3(PR_ROWS), 0, st, pb);
   RSLO_CHECK_LAUNCH("rulebook_pairs");
   return RSLO_OK;
+}
+
+static int pairs_run(const int32_t *nbr, int64_t n_rows, const int32_t *d_n, int K, int nblk, int32_t *counts,
+                     int32_t *pairs_in, int32_t *pairs_out, int32_t *koff, hipStream_t st) {
+  PairBatch pb;
+  memset(&pb, 0, sizeof(pb));
+  pb.t[0] = PairTable{nbr, d_n, n_rows, counts, pairs_in, pairs_out, koff, K, nblk};
+  return pairs_run_batch(pb, 1, st);
 }
 
 extern "C" size_t rslo_rulebook_pairs_ws_bytes(int64_t n_rows, int K) {
@@ -1023,6 +1035,170 @@ extern "C" int rslo_rulebook_row_order(const int32_t *nbr, int64_t n_rows, int K
 // (a step later, in rslo_amd.workload.ExamplePrefetcher).  The Python-issued form of the same work was ~230 launches
 // and 7 blocking reads per step on a helper thread.
 // ---------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------
+// The voxelizer for ALL clouds of a step in one set of launches (rslo_plan_encoder): grid (blocks of the largest cloud,
+// cloud).  Same algorithm as vox_run -- per-cloud hash with atomicMin(first point) + linked list, voxel id = rank of the
+// first point, in-voxel rank = list members with a smaller index -- with the per-point arrays of all clouds back to back
+// (ONE scan over all "is first point" flags: a cloud's voxel ids are the global prefix minus the prefix at its first
+// point) and the per-cloud tables back to back (one fill each for keys | head and first | cutoff).  8 clouds: 11
+// launches instead of 80, and launches of ~4000 workgroups instead of ~480.
+// ---------------------------------------------------------------------------------------
+struct VoxBatch {
+  const float *pts[RSLO_PLAN_MAX_CLOUDS];
+  int32_t start[RSLO_PLAN_MAX_CLOUDS + 1];     // first global point index of cloud c (start[n] = total)
+  int32_t tab[RSLO_PLAN_MAX_CLOUDS];           // first table slot of cloud c
+  int8_t shift[RSLO_PLAN_MAX_CLOUDS];          // 32 - log2(table capacity of cloud c)
+  int32_t n, clouds_per_frame;
+};
+
+struct VoxBatchWs {
+  uint32_t *keys;
+  int32_t *head, *first, *cutoff, *vid, *next, *slot, *pos, *pre;      // pre[c] = global prefix at the first point of cloud c
+  uint32_t *flags;
+};
+
+__global__ void kb_vox_insert(VoxBatch B, int F, VoxGeom G, VoxBatchWs w) {
+  const int c = blockIdx.y;
+  const int P = B.start[c + 1] - B.start[c];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  const int gi = B.start[c] + i;
+  int cc[3];
+  if (!vox_coord(B.pts[c] + (int64_t)i * F, G, cc)) {
+    w.slot[gi] = -1;
+    return;
+  }
+  const uint32_t key = ((uint32_t)cc[2] * G.g[1] + cc[1]) * G.g[0] + cc[0];
+  const uint32_t mask = (1u << (32 - B.shift[c])) - 1u;
+  uint32_t *keys = w.keys + B.tab[c];
+  uint32_t s = rslo_hslot(key, B.shift[c]);
+  // plain reads first: 3 of 4 points land in a voxel that already has its slot, and in scan order most of them are not
+  // its first point -- the atomics still decide, the reads only skip those that cannot change anything
+  while (true) {
+    uint32_t prev = __builtin_nontemporal_load(&keys[s]);
+    if (prev == RSLO_EMPTY_KEY) prev = atomicCAS(&keys[s], RSLO_EMPTY_KEY, key);
+    if (prev == RSLO_EMPTY_KEY || prev == key) break;
+    s = (s + 1) & mask;
+  }
+  if (__builtin_nontemporal_load(&w.first[B.tab[c] + s]) > i) atomicMin(&w.first[B.tab[c] + s], i);
+  w.next[gi] = atomicExch(&w.head[B.tab[c] + s], i);
+  w.slot[gi] = (int32_t)s;
+}
+
+__global__ void kb_vox_flags(VoxBatch B, VoxBatchWs w) {
+  const int c = blockIdx.y;
+  const int P = B.start[c + 1] - B.start[c];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  const int gi = B.start[c] + i;
+  const int32_t s = w.slot[gi];
+  w.flags[gi] = (s >= 0 && w.first[B.tab[c] + s] == i) ? 1u : 0u;
+}
+
+// one block: per cloud the number of voxels (capped), the row base of the next cloud, the prefix at its first point
+__global__ void kb_vox_bases(VoxBatch B, VoxBatchWs w, int max_voxels, int32_t *__restrict__ cnt) {
+  if (threadIdx.x != 0) return;
+  const int total_pts = B.start[B.n];
+  const int32_t all = total_pts > 0 ? w.pos[total_pts - 1] + (int32_t)w.flags[total_pts - 1] : 0;
+  int32_t base = 0;
+  cnt[RSLO_PLAN_CNT_BASE] = 0;
+  for (int c = 0; c < B.n; ++c) {
+    const int32_t s0 = B.start[c] < total_pts ? w.pos[B.start[c]] : all;
+    const int32_t s1 = B.start[c + 1] < total_pts ? w.pos[B.start[c + 1]] : all;
+    const int32_t tot = s1 - s0;
+    const int32_t nv = tot < max_voxels ? tot : max_voxels;
+    w.pre[c] = s0;
+    cnt[RSLO_PLAN_CNT_NVOX + c] = nv;
+    base += nv;
+    cnt[RSLO_PLAN_CNT_BASE + c + 1] = base;
+  }
+}
+
+__global__ void kb_vox_assign(VoxBatch B, VoxGeom G, VoxBatchWs w, int max_voxels, const int32_t *__restrict__ cnt,
+                              int32_t *__restrict__ coords_frame, int32_t *__restrict__ coords_all) {
+  const int c = blockIdx.y;
+  const int P = B.start[c + 1] - B.start[c];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  const int gi = B.start[c] + i;
+  if (!w.flags[gi]) return;
+  const int32_t s = w.slot[gi];
+  const int32_t v = w.pos[gi] - w.pre[c];
+  w.vid[B.tab[c] + s] = v;
+  if (v < max_voxels) {
+    uint32_t key = w.keys[B.tab[c] + s];
+    const int x = key % G.g[0];
+    key /= G.g[0];
+    const int y = key % G.g[1];
+    const int z = key / G.g[1];
+    const int32_t row = cnt[RSLO_PLAN_CNT_BASE + c] + v;
+    reinterpret_cast<int4 *>(coords_frame)[row] = make_int4(c % B.clouds_per_frame, z, y, x);
+    reinterpret_cast<int4 *>(coords_all)[row] = make_int4(c, z, y, x);
+  } else if (v == max_voxels) {
+    w.cutoff[c] = i;      // the reference loop `break`s here
+  }
+}
+
+__global__ void kb_vox_fill(VoxBatch B, int F, int T, VoxBatchWs w, const int32_t *__restrict__ cnt,
+                            float *__restrict__ voxels, int32_t *__restrict__ num_points) {
+  const int c = blockIdx.y;
+  const int P = B.start[c + 1] - B.start[c];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  const int gi = B.start[c] + i;
+  const int32_t s = w.slot[gi];
+  if (s < 0 || i >= w.cutoff[c]) return;
+  int rank = 0;
+  for (int32_t j = w.head[B.tab[c] + s]; j >= 0; j = w.next[B.start[c] + j]) rank += (j < i);
+  if (rank >= T) return;
+  const int32_t v = w.vid[B.tab[c] + s] + cnt[RSLO_PLAN_CNT_BASE + c];
+  float *dst = voxels + ((int64_t)v * T + rank) * F;
+  const float *src = B.pts[c] + (int64_t)i * F;
+  for (int f = 0; f < F; ++f) dst[f] = src[f];
+  atomicAdd(&num_points[v], 1);
+}
+
+// workspace of the batched voxelizer: tables (per-cloud capacities back to back) + per-point arrays
+static size_t voxb_ws_layout(int n, const int64_t *h_n_points, void *base, VoxBatchWs *w, VoxBatch *B, void **scan_ws,
+                             size_t *scan_bytes, size_t *fill_ff, size_t *fill_7f) {
+  int64_t caps = 0, pts = 0;
+  for (int c = 0; c < n; ++c) {
+    const int64_t cap = rslo_hash_capacity(h_n_points[c] > 0 ? h_n_points[c] : 1);
+    if (B) {
+      B->tab[c] = (int32_t)caps;
+      B->start[c] = (int32_t)pts;
+      B->shift[c] = (int8_t)(32 - rslo_log2_i64(cap));
+    }
+    caps += cap;
+    pts += h_n_points[c];
+  }
+  if (B) B->start[n] = (int32_t)pts;
+  const int64_t np = pts > 0 ? pts : 1;
+  size_t off = 0;
+  char *b = (char *)base;
+  auto take = [&](size_t bytes) {
+    void *p = b ? (void *)(b + off) : nullptr;
+    off += align256(bytes);
+    return p;
+  };
+  // keys | head: one 0xFF fill; first | cutoff: one 0x7F fill (caps * 4 is a multiple of 256: no padding in between)
+  void *keys = take((size_t)caps * 4), *head = take((size_t)caps * 4), *first = take((size_t)caps * 4);
+  void *cutoff = take(256), *vid = take((size_t)caps * 4), *pre = take(256);
+  void *next = take((size_t)np * 4), *slot = take((size_t)np * 4), *pos = take((size_t)np * 4), *flags = take((size_t)np * 4);
+  const size_t sb = rslo_scan_ws_bytes(np);
+  void *sws = take(sb);
+  if (w) {
+    w->keys = (uint32_t *)keys; w->head = (int32_t *)head; w->first = (int32_t *)first; w->cutoff = (int32_t *)cutoff;
+    w->vid = (int32_t *)vid; w->pre = (int32_t *)pre; w->next = (int32_t *)next; w->slot = (int32_t *)slot;
+    w->pos = (int32_t *)pos; w->flags = (uint32_t *)flags;
+  }
+  if (scan_ws) *scan_ws = sws;
+  if (scan_bytes) *scan_bytes = sb;
+  if (fill_ff) *fill_ff = (size_t)caps * 8;
+  if (fill_7f) *fill_7f = (size_t)caps * 4 + 256;
+  return off;
+}
+
 static size_t plan_take(size_t &off, size_t bytes) {
   const size_t o = off;
   off += align256(bytes > 0 ? bytes : 1);
@@ -1079,10 +1255,15 @@ extern "C" int rslo_plan_encoder_layout(const RsloEncoderSpec *spec, int n_cloud
   lay->voxels_off = plan_take(off, (size_t)c0 * T * F * sizeof(float));
   lay->num_points_off = plan_take(off, (size_t)c0 * sizeof(int32_t));
   lay->coords_frame_off = plan_take(off, (size_t)c0 * 16);
+  // the hash keys of all levels back to back (ONE 0xFF fill), then the output bitmaps of all strided levels (ONE zero fill)
+  for (int l = 0; l < L; ++l) lay->keys_off[l] = plan_take(off, (size_t)lay->hash_cap[l] * 4);
+  lay->keys_end_off = off;
+  for (int l = 0; l + 1 < L; ++l)
+    lay->bitmap_level_off[l] = plan_take(off, (size_t)rslo_conv_bitmap_words(n_clouds, lay->dims[l + 1]) * 4);
+  lay->bitmap_end_off = off;
   for (int l = 0; l < L; ++l) {
     const int64_t cap = lay->cap_rows[l];
     lay->coords_off[l] = plan_take(off, (size_t)cap * 16);
-    lay->keys_off[l] = plan_take(off, (size_t)lay->hash_cap[l] * 4);
     lay->vals_off[l] = plan_take(off, (size_t)lay->hash_cap[l] * 4);
     const int Ks = spec->subm_ks[l][0] * spec->subm_ks[l][1] * spec->subm_ks[l][2];
     if (Ks > 0) {
@@ -1114,23 +1295,20 @@ extern "C" int rslo_plan_encoder_layout(const RsloEncoderSpec *spec, int n_cloud
     const int64_t w = rslo_conv_bitmap_words(n_clouds, lay->dims[l + 1]);
     if (w > words) words = w;
   }
-  for (int l = 0; l < L; ++l) {
-    const int64_t b = (int64_t)rslo_rulebook_pairs_ws_bytes(lay->cap_rows[l], 27);
-    if (b > pair_ws) pair_ws = b;
+  pair_ws = 0;
+  for (int l = 0; l < L; ++l) {      // one counts region per rulebook: the pair lists of all of them are built together
+    if (spec->subm_ks[l][0] > 0) pair_ws += (int64_t)rslo_rulebook_pairs_ws_bytes(lay->cap_rows[l], 27);
+    if (l + 1 < L) pair_ws += (int64_t)rslo_rulebook_pairs_ws_bytes(lay->cap_rows[l + 1], 27);
   }
+  if (pair_ws < 256) pair_ws = 256;
   lay->scratch_words = words;
-  lay->vox_ws_off = plan_take(off, rslo_voxelize_ws_bytes(maxP));
-  lay->bitmap_off = plan_take(off, (size_t)words * 4);
+  lay->vox_ws_off = plan_take(off, voxb_ws_layout(n_clouds, h_n_points, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr));
+  lay->bitmap_off = lay->bitmap_level_off[0];      // (kept in the struct; the per-level bitmaps above are what is used)
   lay->prefix_off = plan_take(off, (size_t)words * 4);
   lay->scan_ws_off = plan_take(off, rslo_scan_ws_bytes(words));
   lay->pair_ws_off = plan_take(off, (size_t)pair_ws);
   lay->total_bytes = off;
   return RSLO_OK;
-}
-
-__global__ void kp_carry(int32_t *__restrict__ cnt, int c) {      // a cloud without points
-  cnt[RSLO_PLAN_CNT_NVOX + c] = 0;
-  cnt[RSLO_PLAN_CNT_BASE + c + 1] = cnt[RSLO_PLAN_CNT_BASE + c];
 }
 
 __global__ void kp_level0(int32_t *__restrict__ cnt, int n_clouds) {
@@ -1182,26 +1360,47 @@ extern "C" int rslo_plan_encoder(const RsloEncoderSpec *spec, const RsloPlanLayo
     G.vs[j] = spec->vsize3[j];
     G.g[j] = spec->grid_xyz[j];
   }
-  for (int c = 0; c < n_clouds; ++c) {
-    const int64_t P = h_n_points[c];
-    if (P == 0) {
-      hipLaunchKernelGGL(kp_carry, dim3(1), dim3(1), 0, st, cnt, c);
-      continue;
+  {
+    VoxBatch VB;
+    VoxBatchWs W;
+    void *sws;
+    size_t sbytes, f_ff, f_7f;
+    memset(&VB, 0, sizeof(VB));
+    voxb_ws_layout(n_clouds, h_n_points, A + lay->vox_ws_off, &W, &VB, &sws, &sbytes, &f_ff, &f_7f);
+    VB.n = n_clouds;
+    VB.clouds_per_frame = clouds_per_frame;
+    int64_t maxP = 0;
+    for (int c = 0; c < n_clouds; ++c) {
+      VB.pts[c] = h_points[c];
+      RSLO_CHECK_ARG(h_n_points[c] == 0 || h_points[c], "plan_encoder: null cloud");
+      if (h_n_points[c] > maxP) maxP = h_n_points[c];
     }
-    // a cloud cannot add more voxels than the level-0 capacity has left: the reference's max_voxels bound per cloud
-    // sums to at most the capacity (layout), so base + nvox <= capacity by construction
-    VoxPlan pl{cnt + RSLO_PLAN_CNT_BASE + c, cnt + RSLO_PLAN_CNT_BASE + c + 1, coords_frame, coords0,
-               c % clouds_per_frame, c};
-    if (int rc = vox_run(h_points[c], P, F, G, T, spec->max_voxels, A + lay->vox_ws_off, voxels, nullptr, num,
-                         cnt + RSLO_PLAN_CNT_NVOX + c, pl, st))
-      return rc;
+    const int64_t total = VB.start[n_clouds];
+    RSLO_CHECK_ARG(total < (int64_t)2000000000, "plan_encoder: too many points");
+    if (total > 0) {
+      RSLO_HIP(hipMemsetAsync(W.keys, 0xFF, f_ff, st));       // keys | head
+      RSLO_HIP(hipMemsetAsync(W.first, 0x7F, f_7f, st));      // first | cutoff
+      const dim3 grid((unsigned)rslo_cdiv(maxP, 256), (unsigned)n_clouds);
+      hipLaunchKernelGGL(kb_vox_insert, grid, dim3(256), 0, st, VB, F, G, W);
+      hipLaunchKernelGGL(kb_vox_flags, grid, dim3(256), 0, st, VB, W);
+      RSLO_CHECK_LAUNCH("plan vox_insert");
+      if (int rc = scan_exclusive<false>(W.flags, W.pos, total, sws, sbytes, nullptr, st)) return rc;
+      // base + nvox <= level-0 capacity by construction: every cloud adds at most min(max_voxels, P) rows (layout)
+      hipLaunchKernelGGL(kb_vox_bases, dim3(1), dim3(64), 0, st, VB, W, spec->max_voxels, cnt);
+      hipLaunchKernelGGL(kb_vox_assign, grid, dim3(256), 0, st, VB, G, W, spec->max_voxels, (const int32_t *)cnt,
+                         coords_frame, coords0);
+      hipLaunchKernelGGL(kb_vox_fill, grid, dim3(256), 0, st, VB, F, T, W, (const int32_t *)cnt, voxels, num);
+      RSLO_CHECK_LAUNCH("plan vox_fill");
+    }
   }
   hipLaunchKernelGGL(kp_level0, dim3(1), dim3(RSLO_PLAN_MAX_CLOUDS + 1), 0, st, cnt, n_clouds);
   RSLO_CHECK_LAUNCH("plan level 0");
 
+  RSLO_HIP(hipMemsetAsync(A + lay->keys_off[0], 0xFF, (size_t)(lay->keys_end_off - lay->keys_off[0]), st));
+  if (L > 1)
+    RSLO_HIP(hipMemsetAsync(A + lay->bitmap_level_off[0], 0, (size_t)(lay->bitmap_end_off - lay->bitmap_level_off[0]), st));
   auto hash_level = [&](int l) -> int {
     const int64_t hc = lay->hash_cap[l];
-    RSLO_HIP(hipMemsetAsync(A + lay->keys_off[l], 0xFF, (size_t)hc * 4, st));
     hipLaunchKernelGGL(k_hash_insert, dim3(rb_grid(lay->cap_rows[l])), dim3(256), 0, st,
                        (const int32_t *)(A + lay->coords_off[l]), (int64_t)0, (const int32_t *)(cnt + RSLO_PLAN_CNT_ROWS + l),
                        Dims3{lay->dims[l][0], lay->dims[l][1], lay->dims[l][2]}, (uint32_t *)(A + lay->keys_off[l]),
@@ -1209,10 +1408,17 @@ extern "C" int rslo_plan_encoder(const RsloEncoderSpec *spec, const RsloPlanLayo
     RSLO_CHECK_LAUNCH("plan hash");
     return RSLO_OK;
   };
+  PairBatch pbatch;
+  memset(&pbatch, 0, sizeof(pbatch));
+  int n_ptab = 0;
+  size_t pws = lay->pair_ws_off;
   auto pairs_of = [&](const int32_t *nbr, int l_rows, int K, size_t pin, size_t pout, size_t koff) -> int {
+    RSLO_CHECK_ARG(n_ptab < PR_MAXTAB, "plan_encoder: too many rulebooks");
     const int nblk = (int)rslo_cdiv(lay->cap_rows[l_rows], PR_ROWS);
-    return pairs_run(nbr, 0, cnt + RSLO_PLAN_CNT_ROWS + l_rows, K, nblk, (int32_t *)(A + lay->pair_ws_off),
-                     (int32_t *)(A + pin), (int32_t *)(A + pout), (int32_t *)(A + koff), st);
+    pbatch.t[n_ptab++] = PairTable{nbr, cnt + RSLO_PLAN_CNT_ROWS + l_rows, 0, (int32_t *)(A + pws), (int32_t *)(A + pin),
+                                   (int32_t *)(A + pout), (int32_t *)(A + koff), K, nblk};
+    pws += rslo_rulebook_pairs_ws_bytes(lay->cap_rows[l_rows], 27);
+    return RSLO_OK;
   };
 
   if (int rc = hash_level(0)) return rc;
@@ -1244,16 +1450,12 @@ extern "C" int rslo_plan_encoder(const RsloEncoderSpec *spec, const RsloPlanLayo
     const int64_t capo = lay->cap_rows[l + 1];
     const Dims3 od{lay->dims[l + 1][0], lay->dims[l + 1][1], lay->dims[l + 1][2]};
     const int64_t words = rslo_conv_bitmap_words(n_clouds, lay->dims[l + 1]);
-    uint32_t *bitmap = (uint32_t *)(A + lay->bitmap_off);
+    uint32_t *bitmap = (uint32_t *)(A + lay->bitmap_level_off[l]);
     int32_t *prefix = (int32_t *)(A + lay->prefix_off);
-    RSLO_HIP(hipMemsetAsync(bitmap, 0, (size_t)words * 4, st));
     const bool fk = rb_fast_k(ks, cap > capo ? cap : capo), fs = rb_fast_s(sd);
-#define PLAN_MARK(F, F2)                                                                                         \
-    hipLaunchKernelGGL((k_conv_mark<F, F2>), dim3(rb_grid(cap * K)), dim3(256), 0, st, coords, (int64_t)0, d_n,  \
-                       Int3{ks[0], ks[1], ks[2]}, Int3{sd[0], sd[1], sd[2]}, Int3{pd[0], pd[1], pd[2]}, od, bitmap)
-    if (fk && fs) PLAN_MARK(true, true);
-    else PLAN_MARK(false, false);
-#undef PLAN_MARK
+    RSLO_CHECK_ARG(ks[0] <= 3 && ks[1] <= 3 && ks[2] <= 3, "plan_encoder: kernel extent > 3 unsupported");
+    hipLaunchKernelGGL(k_conv_mark, dim3(rb_grid(cap)), dim3(256), 0, st, coords, (int64_t)0, d_n,
+                       Int3{ks[0], ks[1], ks[2]}, Int3{sd[0], sd[1], sd[2]}, Int3{pd[0], pd[1], pd[2]}, od, bitmap);
     RSLO_CHECK_LAUNCH("plan conv_mark");
     if (int rc = scan_exclusive<true>(bitmap, prefix, words, A + lay->scan_ws_off, rslo_scan_ws_bytes(lay->scratch_words),
                                       cnt + RSLO_PLAN_CNT_RAW + l + 1, st))
@@ -1294,6 +1496,7 @@ extern "C" int rslo_plan_encoder(const RsloEncoderSpec *spec, const RsloPlanLayo
     if (spec->want_pairs)
       if (int rc = pairs_of(nbr, l + 1, K, lay->conv_pin_off[l], lay->conv_pout_off[l], lay->conv_koff_off[l])) return rc;
   }
+  if (int rc = pairs_run_batch(pbatch, n_ptab, st)) return rc;      // the pair lists of all rulebooks: three launches
   if (h_counts)
     RSLO_HIP(hipMemcpyAsync(h_counts, cnt, RSLO_PLAN_CNT_WORDS * sizeof(int32_t), hipMemcpyDeviceToHost, st));
   return RSLO_OK;

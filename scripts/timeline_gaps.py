@@ -31,6 +31,14 @@ for q, rs in sorted(byq.items(), key=lambda kv: -len(kv[1])):
         buckets[k] += (e - s) / 1e6
         cnt[k] += 1
     print("   busy by launch size:", {k: (cnt[k], round(v, 3)) for k, v in buckets.items()})
+    allk = collections.defaultdict(lambda: [0, 0.0])
+    for s_, e_, n_, _, g_ in rs:
+        allk[n_[:60]][0] += 1
+        allk[n_[:60]][1] += (e_ - s_) / 1e6
+    if len(rs) < 400:      # a side queue: every kernel
+        print("   kernels of this queue:")
+        for n_, (c_, t_) in sorted(allk.items(), key=lambda kv: -kv[1][1])[:30]:
+            print("      %4d %7.3f ms %7.1f us  %s" % (c_, t_, 1e3 * t_ / c_, n_))
     small = collections.defaultdict(lambda: [0, 0.0])
     for s, e, n, _, g in rs:
         if g < 256:
