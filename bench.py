@@ -200,12 +200,13 @@ class ConvProbe:
 
         # dense 3x3 convolutions of the BEV head (csrc/conv2d.hip): algorithmic flops 2 B Ho Wo Cin Cout 9; bytes = input +
         # output (+ split weights / + weight gradient), each touched once
-        def c2f_meta(x, ws, bias, cout, lp=False):
+        def c2f_meta(x, ws, bias, cout, lp=False, residual=None):
             B, cin, H, W = x.shape
             # the instantiation conv2d_fwd_launch picks (csrc/conv2d.hip): second wave set on long chains / empty CUs
             wgs = B * ((W + 15) // 16) * ((H + 3) // 4) * (cout // 32)
             kc = 2 if (cin >= 256 and wgs <= 200) else 1
-            return ("dense", 2 * B * H * W * cin * cout * 9, 4 * B * H * W * (cin + cout) + 54 * cin * cout,
+            res_bytes = 4 * B * H * W * cout if residual is not None else 0      # the epilogue's residual read
+            return ("dense", 2 * B * H * W * cin * cout * 9, 4 * B * H * W * (cin + cout) + 54 * cin * cout + res_bytes,
                     "k_conv2d_fwd<4, 1, true, %s, %d> [%d->%d %dx%d]" % ("true" if lp else "false", kc, cin, cout, H, W))
 
         def c2w_meta(x, dout, stride=1, want_bias=False, lp=False):

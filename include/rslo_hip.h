@@ -225,6 +225,14 @@ typedef struct {
 } RsloHeadMasksBwd;
 RSLO_API int rslo_head_masks_fwd(const RsloHeadMasks *h_a, void *stream);
 RSLO_API int rslo_head_masks_bwd(const RsloHeadMasksBwd *h_a, void *stream);
+/*     Input of a deblock (odom_pred.py:219-221: deblock(cat([x, skip], 1)) with deblock[0] = nn.Upsample(scale)):
+ *     out [B,Ca+Cb,scale*H,scale*W] = nearest-neighbour upsampling of the channel concatenation of a [B,Ca,H,W] and
+ *     b [B,Cb,H,W] in one launch; _bwd: da / db (either may be NULL) = the scale x scale window sums of grad, summed in
+ *     upsample_nearest2d_backward's order. */
+RSLO_API int rslo_cat_upsample_fwd(const float *a, const float *b, int B, int Ca, int Cb, int H, int W, int scale, float *out,
+                                   void *stream);
+RSLO_API int rslo_cat_upsample_bwd(const float *grad, int B, int Ca, int Cb, int H, int W, int scale, float *da, float *db,
+                                   void *stream);
 
 /* a21  Loss assembly in one launch each way: AdaptiveWeightedL2Loss of the voted pose against the ICP pseudo-targets
  *      (rslo/core/losses.py:144-197; mask = ones, focal_gamma = 0), the same reduction of the pyramid levels' per-sample
@@ -364,6 +372,10 @@ RSLO_API int rslo_dense_gather_frames(const float *dense, const int32_t *coords,
 /*     Per-cell sums over each of the G channel groups of a BEV tensor [B, G*Cg, HW] -> [B, G, HW] in one pass: feeds the
  *     occupancy masks (odom_pred.py:165-168; voxel_odom_net.py:519-527) and the logged channel means. */
 RSLO_API int rslo_bev_channel_sums(const float *in, int B, int G, int Cg, int64_t HW, float *out, void *stream);
+/*     The logged extras from those sums [B,T,HW] in one launch (voxel_odom_net.py:455-464): mask [B,HW] = (sum over t) != 0;
+ *     disp [T,B,HW] = the per-frame channel mean sums / Cg, min-max normalised over the frame's batch
+ *     ((d - min) / (max - min + 1e-12)) -- `middle_feature` and `feature_mask` of the training forward. */
+RSLO_API int rslo_bev_display(const float *sums, int B, int T, int Cg, int64_t HW, float *mask, float *disp, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * a17  Chamfer nearest neighbour.  Replaces cd.forward_cuda_one_direction /
@@ -561,6 +573,11 @@ RSLO_API int rslo_conv2d_wsplit_many(const RsloConv2dSplitDesc *desc_dev, int n_
                                      void *stream);
 RSLO_API int rslo_conv2d_fwd(const float *in, const void *Ws, const float *bias, int B, int cin, int cout, int H, int W,
                              float *out, void *stream);
+/*      rslo_conv2d_fwd_add: out = conv + bias + res, res [B,cout,H,W] read in the epilogue -- the data gradient of a
+ *      BasicBlock's first convolution plus the gradient of its identity branch (custom_resnet_spc.py:74-96 backward),
+ *      the same bits as the convolution followed by a separate element-wise add.  res must not alias out. */
+RSLO_API int rslo_conv2d_fwd_add(const float *in, const void *Ws, const float *bias, const float *res, int B, int cin,
+                                 int cout, int H, int W, float *out, void *stream);
 /*      The stride-2 layers of the BEV encoder (first 3x3 convolution and 1x1 downsample of every stage,
  *      rslo/models/odom_pred.py:398-426): ksize 3 (padding 1) or 1 (padding 0), no bias (the reference builds them
  *      bias-free in front of a BatchNorm).  in [B,cin,H,W] -> out [B,cout,Ho,Wo], Ho = (H - 1) / 2 + 1.
@@ -578,6 +595,8 @@ RSLO_API int rslo_conv2d_dgrad_s2(const float *dout, const void *Ws, int B, int 
  *      rslo_conv2d_wsplit (its first plane IS the bf16-rounded weight); the stride-2 weight gradient keeps the split form. */
 RSLO_API int rslo_conv2d_fwd_bf16(const float *in, const void *Ws, const float *bias, int B, int cin, int cout, int H,
                                   int W, float *out, void *stream);
+RSLO_API int rslo_conv2d_fwd_add_bf16(const float *in, const void *Ws, const float *bias, const float *res, int B,
+                                      int cin, int cout, int H, int W, float *out, void *stream);
 RSLO_API int rslo_conv2d_wgrad_bf16(const float *in, const float *dout, int B, int cin, int cout, int H, int W,
                                     int stride, float *dW, float *dbias, void *ws, size_t ws_bytes, void *stream);
 

@@ -111,6 +111,11 @@ SIGNATURES = {
     "rslo_conv2d_wsplit_many": (C.c_int, [_vp, _i, _i64, _vp]),
     "rslo_conv2d_fwd": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "rslo_conv2d_fwd_bf16": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "rslo_cat_upsample_fwd": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "rslo_cat_upsample_bwd": (C.c_int, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "rslo_bev_display": (C.c_int, [_vp, _i, _i, _i, C.c_int64, _vp, _vp, _vp]),
+    "rslo_conv2d_fwd_add": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "rslo_conv2d_fwd_add_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "rslo_conv2d_wgrad_bf16": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "rslo_conv1x1_supported": (C.c_int, [_i, _i]),
     "rslo_conv1x1_fwd": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
@@ -665,6 +670,40 @@ def bev_channel_sums(bev, groups):
     _chk(lib().rslo_bev_channel_sums(_ptr(bev, torch.float32, "bev"), B, int(groups), Ct // int(groups), H * W, _ptr(out),
                                      _stream()), "rslo_bev_channel_sums")
     return out
+
+
+def cat_upsample_fwd(a, b, scale):
+    """a [B,Ca,H,W], b [B,Cb,H,W] contiguous fp32 -> nearest upsampling by `scale` of cat([a, b], 1), one launch."""
+    B, Ca, H, W = a.shape
+    Cb = b.shape[1]
+    if tuple(b.shape) != (B, Cb, H, W):
+        raise ValueError("cat_upsample_fwd: shapes %s / %s" % (tuple(a.shape), tuple(b.shape)))
+    out = torch.empty((B, Ca + Cb, H * scale, W * scale), dtype=torch.float32, device=a.device)
+    _chk(lib().rslo_cat_upsample_fwd(_ptr(a, torch.float32, "a"), _ptr(b, torch.float32, "b"), B, Ca, Cb, H, W, int(scale),
+                                     _ptr(out), _stream()), "rslo_cat_upsample_fwd")
+    return out
+
+
+def cat_upsample_bwd(grad, Ca, Cb, scale, need_a=True, need_b=True):
+    """grad [B,Ca+Cb,s*H,s*W] -> (da [B,Ca,H,W], db [B,Cb,H,W]) (None where not needed)."""
+    B, Ct, Hs, Ws = grad.shape
+    H, W = Hs // scale, Ws // scale
+    da = torch.empty((B, Ca, H, W), dtype=torch.float32, device=grad.device) if need_a else None
+    db = torch.empty((B, Cb, H, W), dtype=torch.float32, device=grad.device) if need_b else None
+    _chk(lib().rslo_cat_upsample_bwd(_ptr(grad, torch.float32, "grad"), B, Ca, Cb, H, W, int(scale), _dp(da), _dp(db),
+                                     _stream()), "rslo_cat_upsample_bwd")
+    return da, db
+
+
+def bev_display(sums, channels):
+    """sums [B, T, H, W] from bev_channel_sums over `channels` channels per frame -> (feature_mask [B,1,H,W],
+    [middle_feature_t [B,1,H,W] for t]) in one launch (see rslo_bev_display)."""
+    B, T, H, W = sums.shape
+    mask = torch.empty((B, 1, H, W), dtype=torch.float32, device=sums.device)
+    disp = torch.empty((T, B, 1, H, W), dtype=torch.float32, device=sums.device)
+    _chk(lib().rslo_bev_display(_ptr(sums, torch.float32, "sums"), B, T, int(channels), H * W, _ptr(mask), _ptr(disp),
+                                _stream()), "rslo_bev_display")
+    return mask, list(disp.unbind(0))
 
 
 # --------------------------------------------------------------------------------------
@@ -1270,11 +1309,20 @@ def conv2d_dgrad_s2(dy, ws_t, cin, H, W, ksize):
     return dx
 
 
-def conv2d_fwd(x, ws, bias, cout, lp=False):
+def conv2d_fwd(x, ws, bias, cout, lp=False, residual=None):
     """x [B,cin,H,W] contiguous fp32, ws from conv2d_wsplit -> [B,cout,H,W] (3x3, stride 1, padding 1).
-    lp: bf16 operands, fp32 accumulation (C4)."""
+    lp: bf16 operands, fp32 accumulation (C4).  residual [B,cout,H,W]: added in the epilogue (rslo_conv2d_fwd_add)."""
     B, cin, H, W = x.shape
     out = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device)
+    if residual is not None:
+        if tuple(residual.shape) != tuple(out.shape) or not residual.is_contiguous():
+            raise ValueError("conv2d_fwd: residual must be a contiguous %s tensor" % (tuple(out.shape),))
+        fn = lib().rslo_conv2d_fwd_add_bf16 if lp else lib().rslo_conv2d_fwd_add
+        rc = fn(_ptr(x, torch.float32, "x"), ws.data_ptr(), _dp(bias), _ptr(residual, torch.float32, "residual"), B, cin,
+                cout, H, W, out.data_ptr(), _stream())
+        if rc:
+            _chk(rc, "rslo_conv2d_fwd_add")
+        return out
     fn = lib().rslo_conv2d_fwd_bf16 if lp else lib().rslo_conv2d_fwd
     rc = fn(_ptr(x, torch.float32, "x"), ws.data_ptr(), _dp(bias), B, cin, cout, H, W, out.data_ptr(),
             _stream())

@@ -24,6 +24,9 @@ class defer_batch_counts:
     def __exit__(self, *exc):
         global _pending_counts
         pending, _pending_counts = _pending_counts, self.prev
+        if self.prev is not None:       # nested: the outermost context applies everything at once
+            self.prev.extend(pending)
+            return False
         by_id = {}
         for t in pending:
             ent = by_id.setdefault(id(t), [t, 0])

@@ -585,6 +585,7 @@ struct Conv2dFwdGeom {
   int B, cin, cout, H, W;      // cin = contraction channels, cout = produced channels of THIS call
   int tiles_x, tiles_y;
   int xsc, npix, ny;           // XCD-aware workgroup order (conv2d_xcd_tile); xsc = 0: plain (pixel tile, channel group) grid
+  const float *res;            // optional [B][cout][H][W] added to the result in the epilogue (out = conv + bias + res), or NULL
 };
 
 // Which (pixel tile bx, output-channel group by) a workgroup takes.  Workgroups of a one-dimensional grid are dealt to the
@@ -829,7 +830,12 @@ __global__ __launch_bounds__(256 * KC, 2 / KC) void k_conv2d_fwd(const float *__
 #pragma unroll
       for (int nt = 0; nt < NTW; ++nt) {
         const int y = y0 + wn * NTW + nt;
-        if (x < W && y < H) out[((int64_t)b * gm.cout + m) * HW + (int64_t)y * W + x] = acc[mt][nt][j] + bv;
+        if (x < W && y < H) {
+          const int64_t o = ((int64_t)b * gm.cout + m) * HW + (int64_t)y * W + x;
+          float v = acc[mt][nt][j] + bv;
+          if (gm.res) v += gm.res[o];      // the residual branch's gradient of a BasicBlock: same bits as a separate add
+          out[o] = v;
+        }
       }
     }
 }
@@ -883,7 +889,7 @@ extern "C" int rslo_conv2d_wsplit_many(const RsloConv2dSplitDesc *desc_dev, int 
 }
 
 static int conv2d_fwd_launch(const float *in, const void *Ws, const float *bias, int B, int cin, int cout, int H, int W,
-                             float *out, void *stream, bool lp);
+                             float *out, void *stream, bool lp, const float *res = nullptr);
 
 extern "C" int rslo_conv2d_fwd(const float *in, const void *Ws, const float *bias, int B, int cin, int cout, int H, int W,
                                float *out, void *stream) {
@@ -895,13 +901,24 @@ extern "C" int rslo_conv2d_fwd_bf16(const float *in, const void *Ws, const float
   return conv2d_fwd_launch(in, Ws, bias, B, cin, cout, H, W, out, stream, true);
 }
 
+extern "C" int rslo_conv2d_fwd_add(const float *in, const void *Ws, const float *bias, const float *res, int B, int cin,
+                                   int cout, int H, int W, float *out, void *stream) {
+  return conv2d_fwd_launch(in, Ws, bias, B, cin, cout, H, W, out, stream, false, res);
+}
+
+extern "C" int rslo_conv2d_fwd_add_bf16(const float *in, const void *Ws, const float *bias, const float *res, int B,
+                                        int cin, int cout, int H, int W, float *out, void *stream) {
+  return conv2d_fwd_launch(in, Ws, bias, B, cin, cout, H, W, out, stream, true, res);
+}
+
 static int conv2d_fwd_launch(const float *in, const void *Ws, const float *bias, int B, int cin, int cout, int H, int W,
-                             float *out, void *stream, bool lp) {
+                             float *out, void *stream, bool lp, const float *res) {
   int tr, mtw;
   RSLO_CHECK_ARG(conv2d_fwd_plan(B, cin, cout, H, W, &tr, &mtw), "rslo_conv2d_fwd: unsupported shape cin=%d cout=%d H=%d W=%d",
                  cin, cout, H, W);
   Conv2dFwdGeom gm;
   gm.B = B; gm.cin = cin; gm.cout = cout; gm.H = H; gm.W = W;
+  gm.res = res;
   gm.tiles_x = (int)rslo_cdiv(W, 16);
   gm.tiles_y = (int)rslo_cdiv(H, tr);
   // input bytes count the halo re-reads of the row tiles ((tr + 2) / tr); bf16-operand weights are one plane of three

@@ -319,3 +319,63 @@ extern "C" int rslo_head_masks_bwd(const RsloHeadMasksBwd *h_a, void *stream) {
   RSLO_CHECK_LAUNCH("k_head_masks_bwd");
   return RSLO_OK;
 }
+
+// ----------------------------------------------------------------------------------------- concatenation + upsampling
+// The input of every deblock (odom_pred.py:219-221 of the reference: x = deblock(cat([x, skip], 1)), deblock =
+// Upsample(s) -> Conv -> BN -> ReLU) is a channel concatenation that is then repeated s x s times: two launches and a
+// (Ca + Cb) x H x W intermediate forward, an s x s window sum, two slices and their copies backward.  One launch each
+// way: a thread takes one SOURCE cell, writes / sums its s x s window (window order = rows, then columns, from zero:
+// the order of upsample_nearest2d_backward, so the sums have the same bits).
+__global__ void k_cat_upsample_fwd(const float *__restrict__ a, const float *__restrict__ b, int Ca, int Cb, int H, int W,
+                                   int s, int64_t n, float *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int x = (int)(i % W);
+  int64_t r = i / W;
+  const int y = (int)(r % H); r /= H;
+  const int c = (int)(r % (Ca + Cb));
+  const int64_t bb = r / (Ca + Cb);
+  const float v = c < Ca ? a[((bb * Ca + c) * H + y) * W + x] : b[((bb * Cb + (c - Ca)) * H + y) * W + x];
+  float *dst = out + (((bb * (Ca + Cb) + c) * H + y) * (int64_t)s) * W * s + (int64_t)x * s;
+  for (int dy = 0; dy < s; ++dy)
+    for (int dx = 0; dx < s; ++dx) dst[(int64_t)dy * W * s + dx] = v;
+}
+
+__global__ void k_cat_upsample_bwd(const float *__restrict__ g, int Ca, int Cb, int H, int W, int s, int64_t n,
+                                   float *__restrict__ da, float *__restrict__ db) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int x = (int)(i % W);
+  int64_t r = i / W;
+  const int y = (int)(r % H); r /= H;
+  const int c = (int)(r % (Ca + Cb));
+  const int64_t bb = r / (Ca + Cb);
+  const float *src = g + (((bb * (Ca + Cb) + c) * H + y) * (int64_t)s) * W * s + (int64_t)x * s;
+  float acc = 0.f;
+  for (int dy = 0; dy < s; ++dy)
+    for (int dx = 0; dx < s; ++dx) acc = __fadd_rn(acc, src[(int64_t)dy * W * s + dx]);
+  if (c < Ca) { if (da) da[((bb * Ca + c) * H + y) * W + x] = acc; }
+  else if (db) db[((bb * Cb + (c - Ca)) * H + y) * W + x] = acc;
+}
+
+extern "C" int rslo_cat_upsample_fwd(const float *a, const float *b, int B, int Ca, int Cb, int H, int W, int scale, float *out,
+                                     void *stream) {
+  RSLO_CHECK_ARG(a && b && out && B >= 1 && Ca >= 1 && Cb >= 1 && H >= 1 && W >= 1 && scale >= 1 && scale <= 8,
+                 "rslo_cat_upsample_fwd: bad arguments");
+  const int64_t n = (int64_t)B * (Ca + Cb) * H * W;
+  hipLaunchKernelGGL(k_cat_upsample_fwd, dim3((unsigned)rslo_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, a, b, Ca, Cb,
+                     H, W, scale, n, out);
+  RSLO_CHECK_LAUNCH("k_cat_upsample_fwd");
+  return RSLO_OK;
+}
+
+extern "C" int rslo_cat_upsample_bwd(const float *grad, int B, int Ca, int Cb, int H, int W, int scale, float *da, float *db,
+                                     void *stream) {
+  RSLO_CHECK_ARG(grad && (da || db) && B >= 1 && Ca >= 1 && Cb >= 1 && H >= 1 && W >= 1 && scale >= 1 && scale <= 8,
+                 "rslo_cat_upsample_bwd: bad arguments");
+  const int64_t n = (int64_t)B * (Ca + Cb) * H * W;
+  hipLaunchKernelGGL(k_cat_upsample_bwd, dim3((unsigned)rslo_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, grad, Ca, Cb,
+                     H, W, scale, n, da, db);
+  RSLO_CHECK_LAUNCH("k_cat_upsample_bwd");
+  return RSLO_OK;
+}

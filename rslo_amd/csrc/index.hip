@@ -809,6 +809,57 @@ extern "C" int rslo_bev_channel_sums(const float *in, int B, int G, int Cg, int6
   return RSLO_OK;
 }
 
+// The logged extras of the training forward from those sums [B, T, HW] (voxel_odom_net.py:455-464 of the reference):
+//   mask[b][p]    = (sum_t sums[b][t][p]) != 0
+//   disp[t][b][p] = (d - min d) / (max d - min d + 1e-12),  d = sums[b][t][p] * (1 / Cg)  (min / max over the frame's
+//                   whole batch), the arithmetic torch does for `mean -> (x - x.min()) / (x.max() - x.min() + 1e-12)`
+// One workgroup per frame t (two passes over 67 k values from L2): one launch instead of ~17 reductions / element-wise ops.
+#define BD_THREADS 1024
+__global__ __launch_bounds__(BD_THREADS) void k_bev_display(const float *__restrict__ sums, int B, int T, int64_t HW,
+                                                            float inv_c, float *__restrict__ mask,
+                                                            float *__restrict__ disp) {
+  // plain operators under the pragma: the __f*_rn device functions are inlined from the HIP headers WITH their
+  // contraction flags (the product below fused into the subtraction: min d - min d != 0)
+#pragma clang fp contract(off)
+  __shared__ float s_mn[BD_THREADS / 64], s_mx[BD_THREADS / 64];
+  const int t = blockIdx.x, tid = threadIdx.x;
+  const int64_t n = (int64_t)B * HW;
+  float mn = INFINITY, mx = -INFINITY;
+  for (int64_t i = tid; i < n; i += BD_THREADS) {
+    const int64_t b = i / HW, p = i - b * HW;
+    const float d = sums[(b * T + t) * HW + p] * inv_c;
+    mn = fminf(mn, d);
+    mx = fmaxf(mx, d);
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    mn = fminf(mn, __shfl_xor(mn, o));
+    mx = fmaxf(mx, __shfl_xor(mx, o));
+  }
+  if ((tid & 63) == 0) { s_mn[tid >> 6] = mn; s_mx[tid >> 6] = mx; }
+  __syncthreads();
+  mn = s_mn[0]; mx = s_mx[0];
+  for (int w = 1; w < BD_THREADS / 64; ++w) { mn = fminf(mn, s_mn[w]); mx = fmaxf(mx, s_mx[w]); }
+  const float den = (mx - mn) + 1e-12f;
+  for (int64_t i = tid; i < n; i += BD_THREADS) {
+    const int64_t b = i / HW, p = i - b * HW;
+    const float d = sums[(b * T + t) * HW + p] * inv_c;
+    disp[(int64_t)t * n + i] = (d - mn) / den;
+    if ((i / BD_THREADS) % T == t) {      // the mask's cells are dealt to the T workgroups
+      float s = 0.f;
+      for (int u = 0; u < T; ++u) s = s + sums[(b * T + u) * HW + p];
+      mask[i] = s != 0.f ? 1.f : 0.f;
+    }
+  }
+}
+
+extern "C" int rslo_bev_display(const float *sums, int B, int T, int Cg, int64_t HW, float *mask, float *disp, void *stream) {
+  RSLO_CHECK_ARG(sums && mask && disp && B >= 1 && T >= 1 && T < 65536 && Cg >= 1 && HW >= 1, "rslo_bev_display: bad arguments");
+  hipLaunchKernelGGL(k_bev_display, dim3((unsigned)T), dim3(BD_THREADS), 0, (hipStream_t)stream, sums, B, T, HW,
+                     1.0f / (float)Cg, mask, disp);
+  RSLO_CHECK_LAUNCH("k_bev_display");
+  return RSLO_OK;
+}
+
 // ---------------------------------------------------------------------------------------
 // neighbour table -> spconv-style pair lists (for the weight-gradient kernels)
 // ---------------------------------------------------------------------------------------

@@ -244,7 +244,18 @@ class FusedSequential(nn.Sequential):
         super().__setattr__(name, value)
 
     def forward(self, x):
+        return self.forward_from(x, 0)
+
+    def forward_from(self, x, first_child):
+        """The children from index `first_child` on (a caller that has already applied the leading ones, e.g. the
+        head's fused concatenation + nn.Upsample in front of a deblock)."""
+        skip = first_child
         for m, slope in self._steps():
+            if skip > 0:      # steps are whole children or (conv, BN, act) / (BN, act) groups: only leading singles are skipped
+                if isinstance(m, tuple) or slope is not None:
+                    raise ValueError("forward_from: child %d is inside a fused group" % first_child)
+                skip -= 1
+                continue
             if isinstance(m, tuple):
                 conv, bn = m
                 if isinstance(x, torch.Tensor) and _conv_bn_fusable(conv, bn, x):

@@ -106,10 +106,12 @@ class _BasicBlockFn(torch.autograd.Function):
         from rslo.layers import hip_conv2d
         dw2 = hip_conv2d.conv2d_wgrad_leaf(y1, d_o2, 1, lp=lp)
         d_o1, _, dg1, db1 = fused_bn_backward(d_y1, y1 if act else None, o1, g1, m1, i1, n1, slope, False, True, group, world)
+        res_joined = False
         if s == 2:
             dx = capi.conv2d_dgrad_s2(d_o1, w1t, w1.shape[1], x.shape[2], x.shape[3], 3)
-        else:
-            dx = capi.conv2d_fwd(d_o1, w1t, None, w1.shape[1], lp=lp)
+        else:       # identity block: the residual branch's gradient joins in the epilogue (same bits as dx.add_(d_res))
+            dx = capi.conv2d_fwd(d_o1, w1t, None, w1.shape[1], lp=lp, residual=d_res if wd is None else None)
+            res_joined = wd is None
         if hip_w1:
             dw1 = hip_conv2d.conv2d_wgrad_leaf(x, d_o1, s, lp=lp)
         else:       # the full-resolution stride-2 layer: the library's weight gradient (see csrc/conv2d.hip conv2d_plan)
@@ -121,7 +123,7 @@ class _BasicBlockFn(torch.autograd.Function):
             dx.add_(capi.conv2d_dgrad_s2(d_od, wdt, wd.shape[1], x.shape[2], x.shape[3], 1))
             xs = x[:, :, ::2, ::2].flatten(2)
             dwd = torch.matmul(d_od.flatten(2), xs.transpose(1, 2)).sum(0).reshape(wd.shape)
-        else:
+        elif not res_joined:
             dx.add_(d_res)
         return dx, dw1, dg1, db1, dw2, dg2, db2, dwd, dgd, dbd, None, None
 

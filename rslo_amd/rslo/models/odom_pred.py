@@ -133,7 +133,7 @@ class UNOdomPredEncDecSVDTempMaskBase(OdomPredEncDecBase):
 
         py_preds, py_raw = [], []
         for i, deblock in enumerate(self.deblocks):
-            x = deblock(torch.cat([x, ups[-(i + 1)]], dim=1))
+            x = _deblock(deblock, x, ups[-(i + 1)])
             if self.pred_pyramid_motion and i < len(self.deblocks) - 1:
                 p = self.pyramid_motion_blocks[i](x)
                 if fused_tail:
@@ -298,6 +298,39 @@ class UNOdomPredEncDecSVDTempMaskBase(OdomPredEncDecBase):
         if self.use_svd:
             return [self.vote_svd(m, sm, tc) for m, sm, tc in zip(tq_maps, selected_masks, t_confs)]
         return [self.vote(m, tc, rc)[1] for m, tc, rc in zip(tq_maps, t_confs, r_confs)]
+
+
+class _CatUpsampleFn(torch.autograd.Function):
+    """nn.Upsample(scale)(torch.cat([a, b], 1)) as one launch each way (csrc/headtail.hip rslo_cat_upsample_*): the input
+    of every deblock (reference odom_pred.py:219-221).  Same bits as the two torch ops, forward and backward."""
+
+    @staticmethod
+    def forward(ctx, a, b, scale):
+        from rslo_amd import capi
+        ctx.meta = (a.shape[1], b.shape[1], scale)
+        return capi.cat_upsample_fwd(a.contiguous(), b.contiguous(), scale)
+
+    @staticmethod
+    def backward(ctx, g):
+        from rslo_amd import capi
+        ca, cb, scale = ctx.meta
+        da, db = capi.cat_upsample_bwd(g.contiguous(), ca, cb, scale, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return da, db, None
+
+
+def _deblock(deblock, x, skip):
+    """deblock(cat([x, skip], 1)); the concatenation and the deblock's leading nn.Upsample in one launch when they are
+    what the shipped head builds (nearest mode, integer scale, fp32 GPU maps).  RSLO_CAT_UPSAMPLE=0: the torch ops."""
+    import os
+    mods = list(deblock.children()) if isinstance(deblock, nn.Sequential) else []
+    up = mods[0] if mods else None
+    if (isinstance(up, nn.Upsample) and up.mode == "nearest" and up.size is None
+            and isinstance(up.scale_factor, (int, float)) and float(up.scale_factor) == int(up.scale_factor)
+            and 1 <= int(up.scale_factor) <= 8 and x.is_cuda and x.dtype == torch.float32 and skip.dtype == torch.float32
+            and x.dim() == 4 and x.shape[0] == skip.shape[0] and x.shape[2:] == skip.shape[2:]
+            and hasattr(deblock, "forward_from") and os.environ.get("RSLO_CAT_UPSAMPLE", "1") != "0"):
+        return deblock.forward_from(_CatUpsampleFn.apply(x, skip, int(up.scale_factor)), 1)
+    return deblock(torch.cat([x, skip], dim=1))
 
 
 class _TqNormFn(torch.autograd.Function):

@@ -17,6 +17,7 @@ import os
 import time
 
 import apex.amp as amp
+import apex.parallel as _apex_parallel
 import kornia
 import numpy as np
 import torch
@@ -315,13 +316,18 @@ class UnVoxelOdomNetICP3(nn.Module):
             middle_conf_preds = list(cov.split([f.shape[0] for f in voxel_features], dim=0))
         with torch.no_grad():
             sums = preds_dict.pop("_bev_sums", None)       # [B, T, H, W] per-frame channel sums the head already made
-            if sums is not None:
-                preds_dict["feature_mask"] = (sums.sum(dim=1, keepdim=True) != 0).float()
-                disp = [sums[:, t:t + 1] / float(spatial_features[t].shape[1]) for t in range(T)]
+            if sums is not None and os.environ.get("RSLO_BEV_DISPLAY", "1") != "0":
+                from rslo_amd import capi       # mask + both normalised maps in one launch (same bits as the lines below)
+                preds_dict["feature_mask"], preds_dict["middle_feature"] = capi.bev_display(
+                    sums, spatial_features[0].shape[1])
             else:
-                preds_dict["feature_mask"] = (torch.cat(spatial_features, dim=1).sum(dim=1, keepdim=True) != 0).float()
-                disp = [f.mean(dim=1, keepdim=True) for f in spatial_features]
-            preds_dict["middle_feature"] = [(d - d.min()) / (d.max() - d.min() + 1e-12) for d in disp]
+                if sums is not None:
+                    preds_dict["feature_mask"] = (sums.sum(dim=1, keepdim=True) != 0).float()
+                    disp = [sums[:, t:t + 1] / float(spatial_features[t].shape[1]) for t in range(T)]
+                else:
+                    preds_dict["feature_mask"] = (torch.cat(spatial_features, dim=1).sum(dim=1, keepdim=True) != 0).float()
+                    disp = [f.mean(dim=1, keepdim=True) for f in spatial_features]
+                preds_dict["middle_feature"] = [(d - d.min()) / (d.max() - d.min() + 1e-12) for d in disp]
         preds_dict["middle_conf_preds"] = middle_conf_preds
         preds_dict["voxel_features"] = voxel_features
         preds_dict["voxel_coords"] = coors
@@ -350,7 +356,9 @@ class UnVoxelOdomNetICP3(nn.Module):
                 t0 = time.perf_counter()
                 ring[-_HOST_LEAD].synchronize()
                 _LEAD_WAIT[0] += time.perf_counter() - t0
-        preds_dict = self.network_forward(voxels, num_points, coors, batch_size_dev, example=example)
+        # one multi-tensor add for the num_batches_tracked buffers of every normalisation layer (ROCm apex stand-in only)
+        with getattr(_apex_parallel, "defer_batch_counts", contextlib.nullcontext)():
+            preds_dict = self.network_forward(voxels, num_points, coors, batch_size_dev, example=example)
 
         if self.training:
             ret = self.loss(example, preds_dict)

@@ -309,6 +309,13 @@ class _SegBNActFn(torch.autograd.Function):
         return gx, dgamma, dbeta, None, None, None, None, None
 
 
+def _pending_batch_counts():
+    """The open defer_batch_counts() list of the ROCm apex stand-in (compat/apex/parallel.py), or None."""
+    import sys
+    mod = sys.modules.get("apex.parallel")
+    return getattr(mod, "_pending_counts", None) if mod is not None else None
+
+
 def _segmented_bn_act(x, bn, slope):
     """Training-mode nn.BatchNorm1d over each frame of the batched tensor, fused with the activation."""
     index = x.site_index()
@@ -319,7 +326,12 @@ def _segmented_bn_act(x, bn, slope):
     feats = x.features.float() if x.features.dtype == torch.bfloat16 else x.features
     y = _SegBNActFn.apply(feats, bn.weight, bn.bias, bn, dev_off, S, max_len, slope)
     if bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(sum(1 for b in range(S) if offs[b + 1] > offs[b]))
+        n_seen = sum(1 for b in range(S) if offs[b + 1] > offs[b])     # one training forward per non-empty frame
+        pending = _pending_batch_counts()
+        if pending is not None:       # inside defer_batch_counts(): one multi-tensor add for the whole network forward
+            pending.extend([bn.num_batches_tracked] * n_seen)
+        else:
+            bn.num_batches_tracked.add_(n_seen)
     return x._like(y)
 
 

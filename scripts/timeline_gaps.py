@@ -39,6 +39,10 @@ for q, rs in sorted(byq.items(), key=lambda kv: -len(kv[1])):
         print("   kernels of this queue:")
         for n_, (c_, t_) in sorted(allk.items(), key=lambda kv: -kv[1][1])[:30]:
             print("      %4d %7.3f ms %7.1f us  %s" % (c_, t_, 1e3 * t_ / c_, n_))
+    else:                  # the training queue: by launch count (each launch also costs a dispatch gap)
+        print("   kernels of this queue by launch count:")
+        for n_, (c_, t_) in sorted(allk.items(), key=lambda kv: -kv[1][0])[:70]:
+            print("      %4d %7.3f ms %7.1f us  %s" % (c_, t_, 1e3 * t_ / c_, n_))
     small = collections.defaultdict(lambda: [0, 0.0])
     for s, e, n, _, g in rs:
         if g < 256:

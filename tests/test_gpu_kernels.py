@@ -339,6 +339,46 @@ def test_dense_scatter_gather(hip):
     assert (back.cpu().numpy() == f).all()
 
 
+@pytest.mark.parametrize("B,T,Cg,H,W", [(4, 2, 128, 96, 176), (1, 2, 48, 7, 5), (3, 1, 100, 33, 17)])
+def test_bev_channel_sums_and_display_match_torch_bits(hip, B, T, Cg, H, W):
+    """rslo_bev_channel_sums + rslo_bev_display = the reference's logged extras (voxel_odom_net.py:455-464: occupancy of the
+    concatenated frames, per-frame channel mean normalised to [0, 1]) with torch's own arithmetic, bit for bit."""
+    g = torch.Generator(device="cuda").manual_seed(3)
+    bev = torch.randn((B, T * Cg, H, W), device="cuda", generator=g)
+    bev = bev * (torch.rand((B, 1, H, W), device="cuda", generator=g) < 0.3)       # mostly empty cells, as a BEV map
+    sums = hip.bev_channel_sums(bev, T)
+    mask, disp = hip.bev_display(sums, Cg)
+    frames = list(bev.split(Cg, dim=1))
+    ref_mask = (sums.sum(dim=1, keepdim=True) != 0).float()
+    assert torch.equal(mask, ref_mask)
+    assert torch.equal(mask, (torch.sum(torch.cat(frames, dim=1), dim=1, keepdim=True) != 0).float())
+    for t in range(T):
+        d = sums[:, t:t + 1] / float(Cg)
+        ref = (d - d.min()) / (d.max() - d.min() + 1e-12)
+        assert torch.equal(disp[t], ref)
+        m = frames[t].mean(dim=1, keepdim=True)       # the reference's expression: same up to the summation order
+        ref2 = (m - m.min()) / (m.max() - m.min() + 1e-12)
+        assert float((disp[t] - ref2).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("B,Ca,Cb,H,W,s", [(2, 5, 3, 7, 9, 2), (1, 64, 128, 24, 44, 2), (2, 3, 4, 5, 6, 1), (1, 2, 2, 4, 5, 3)])
+def test_cat_upsample_matches_torch_bits(hip, B, Ca, Cb, H, W, s):
+    """rslo_cat_upsample_fwd / _bwd = nn.Upsample(scale_factor=s)(torch.cat([a, b], 1)) and its autograd backward
+    (reference odom_pred.py:219-221), bit for bit, including one-sided gradients."""
+    g = torch.Generator(device="cuda").manual_seed(11)
+    a = torch.randn((B, Ca, H, W), device="cuda", generator=g, requires_grad=True)
+    b = torch.randn((B, Cb, H, W), device="cuda", generator=g, requires_grad=True)
+    ref = torch.nn.Upsample(scale_factor=s)(torch.cat([a, b], dim=1))
+    go = torch.randn(ref.shape, device="cuda", generator=g)
+    ref.backward(go)
+    out = hip.cat_upsample_fwd(a.detach(), b.detach(), s)
+    assert torch.equal(out, ref.detach())
+    da, db = hip.cat_upsample_bwd(go, Ca, Cb, s)
+    assert torch.equal(da, a.grad) and torch.equal(db, b.grad)
+    da, db = hip.cat_upsample_bwd(go, Ca, Cb, s, need_a=False)
+    assert da is None and torch.equal(db, b.grad)
+
+
 def test_leaky_bwd(hip):
     y = torch.randn(1001, device="cuda")
     g = torch.randn(1001, device="cuda")
@@ -973,6 +1013,14 @@ def test_conv2d_fwd_and_dgrad_match_float64_oracle(hip, B, cin, cout, H, W, cfg)
         err_lib = np.abs(lib.astype(np.float64) - ref).max()
         assert err <= 2e-5 * scale, (err, scale)
         assert err <= 4 * err_lib + 1e-6 * scale, (err, err_lib)
+    # rslo_conv2d_fwd_add: the residual read in the epilogue = the convolution followed by a separate add, bit for bit
+    res = dev(rng.standard_normal((B, cin, H, W)).astype(np.float32))
+    wt = hip.conv2d_wsplit(dev(w), True)
+    joined = hip.conv2d_fwd(dev(g), wt, None, cin, residual=res)
+    apart = hip.conv2d_fwd(dev(g), wt, None, cin).add_(res)
+    assert torch.equal(joined, apart)
+    joined = hip.conv2d_fwd(dev(g), wt, None, cin, lp=True, residual=res)
+    assert torch.equal(joined, hip.conv2d_fwd(dev(g), wt, None, cin, lp=True).add_(res))
 
 
 @pytest.mark.parametrize("B,cin,cout,H,W,k", [
