@@ -233,6 +233,10 @@ RSLO_API int rslo_cat_upsample_fwd(const float *a, const float *b, int B, int Ca
                                    void *stream);
 RSLO_API int rslo_cat_upsample_bwd(const float *grad, int B, int Ca, int Cb, int H, int W, int scale, float *da, float *db,
                                    void *stream);
+/*     The voted pose odom [B,7] = (t, q) -> t [B,3], r [B,4] = q / (|q| + 1e-12) (odom_pred.py:279-288) and its gradient
+ *     (g_t / g_r may be NULL = zeros), one launch each way. */
+RSLO_API int rslo_pose_tail_fwd(const float *odom, int B, float *t, float *r, void *stream);
+RSLO_API int rslo_pose_tail_bwd(const float *odom, const float *g_t, const float *g_r, int B, float *d_odom, void *stream);
 
 /* a21  Loss assembly in one launch each way: AdaptiveWeightedL2Loss of the voted pose against the ICP pseudo-targets
  *      (rslo/core/losses.py:144-197; mask = ones, focal_gamma = 0), the same reduction of the pyramid levels' per-sample
@@ -372,6 +376,10 @@ RSLO_API int rslo_dense_gather_frames(const float *dense, const int32_t *coords,
 /*     Per-cell sums over each of the G channel groups of a BEV tensor [B, G*Cg, HW] -> [B, G, HW] in one pass: feeds the
  *     occupancy masks (odom_pred.py:165-168; voxel_odom_net.py:519-527) and the logged channel means. */
 RSLO_API int rslo_bev_channel_sums(const float *in, int B, int G, int Cg, int64_t HW, float *out, void *stream);
+/*     The same pass also writing the occupancy of channel group 0 in the three forms the head uses (odom_pred.py:165-168 and
+ *     rslo/layers/confidence.py:26-34): mask_f [B,HW] float 0/1, mask_b [B,HW] bytes 0/1, outside_b = !mask_b.  Any may be NULL. */
+RSLO_API int rslo_bev_channel_sums_masks(const float *in, int B, int G, int Cg, int64_t HW, float *out, float *mask_f,
+                                         unsigned char *mask_b, unsigned char *outside_b, void *stream);
 /*     The logged extras from those sums [B,T,HW] in one launch (voxel_odom_net.py:455-464): mask [B,HW] = (sum over t) != 0;
  *     disp [T,B,HW] = the per-frame channel mean sums / Cg, min-max normalised over the frame's batch
  *     ((d - min) / (max - min + 1e-12)) -- `middle_feature` and `feature_mask` of the training forward. */
@@ -590,6 +598,10 @@ RSLO_API int rslo_conv2d_fwd_s2(const float *in, const void *Ws, int B, int cin,
                                 float *out, void *stream);
 RSLO_API int rslo_conv2d_dgrad_s2(const float *dout, const void *Ws, int B, int cin, int cout, int H, int W, int ksize,
                                   float *din, void *stream);
+/*      din = data gradient + res (res [B,cin,H,W], must not alias din): the input gradients of the two branches of a
+ *      stride-2 BasicBlock (custom_resnet_spc.py:74-96) joined in the second branch's epilogue, same bits as the add. */
+RSLO_API int rslo_conv2d_dgrad_s2_add(const float *dout, const void *Ws, const float *res, int B, int cin, int cout, int H,
+                                      int W, int ksize, float *din, void *stream);
 /*      C4 (bf16 operands, fp32 accumulation and storage): the same kernels issuing only the product of the
  *      round-to-nearest bf16 values of activations and weights (1 MFMA instead of 6).  Ws is the operand block of
  *      rslo_conv2d_wsplit (its first plane IS the bf16-rounded weight); the stride-2 weight gradient keeps the split form. */

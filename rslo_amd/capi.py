@@ -113,7 +113,11 @@ SIGNATURES = {
     "rslo_conv2d_fwd_bf16": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "rslo_cat_upsample_fwd": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "rslo_cat_upsample_bwd": (C.c_int, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "rslo_bev_channel_sums_masks": (C.c_int, [_vp, _i, _i, _i, C.c_int64, _vp, _vp, _vp, _vp, _vp]),
+    "rslo_pose_tail_fwd": (C.c_int, [_vp, _i, _vp, _vp, _vp]),
+    "rslo_pose_tail_bwd": (C.c_int, [_vp, _vp, _vp, _i, _vp, _vp]),
     "rslo_bev_display": (C.c_int, [_vp, _i, _i, _i, C.c_int64, _vp, _vp, _vp]),
+    "rslo_conv2d_dgrad_s2_add": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "rslo_conv2d_fwd_add": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "rslo_conv2d_fwd_add_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "rslo_conv2d_wgrad_bf16": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
@@ -663,13 +667,39 @@ def dense_gather(dense, coords, C_, batch, dims, frames=1):
     return out
 
 
-def bev_channel_sums(bev, groups):
-    """bev [B, groups * Cg, H, W] fp32 -> [B, groups, H, W]: per-cell sum over each channel group, one pass."""
+def bev_channel_sums(bev, groups, masks=False):
+    """bev [B, groups * Cg, H, W] fp32 -> [B, groups, H, W]: per-cell sum over each channel group, one pass.
+    masks=True: also (mask_f float, mask_b bool, outside_b bool) [B,1,H,W] = occupancy of group 0 from the same launch."""
     B, Ct, H, W = bev.shape
     out = torch.empty((B, groups, H, W), dtype=torch.float32, device=bev.device)
+    if masks:
+        mf = torch.empty((B, 1, H, W), dtype=torch.float32, device=bev.device)
+        mb = torch.empty((B, 1, H, W), dtype=torch.bool, device=bev.device)
+        ob = torch.empty((B, 1, H, W), dtype=torch.bool, device=bev.device)
+        _chk(lib().rslo_bev_channel_sums_masks(_ptr(bev, torch.float32, "bev"), B, int(groups), Ct // int(groups), H * W,
+                                               _ptr(out), _ptr(mf), _ptr(mb), _ptr(ob), _stream()),
+             "rslo_bev_channel_sums_masks")
+        return out, mf, mb, ob
     _chk(lib().rslo_bev_channel_sums(_ptr(bev, torch.float32, "bev"), B, int(groups), Ct // int(groups), H * W, _ptr(out),
                                      _stream()), "rslo_bev_channel_sums")
     return out
+
+
+def pose_tail_fwd(odom):
+    """odom [B,7] -> (t [B,3], r [B,4] = q / (|q| + 1e-12))."""
+    B = odom.shape[0]
+    t = torch.empty((B, 3), dtype=torch.float32, device=odom.device)
+    r = torch.empty((B, 4), dtype=torch.float32, device=odom.device)
+    _chk(lib().rslo_pose_tail_fwd(_ptr(odom, torch.float32, "odom"), B, _ptr(t), _ptr(r), _stream()), "rslo_pose_tail_fwd")
+    return t, r
+
+
+def pose_tail_bwd(odom, g_t, g_r):
+    B = odom.shape[0]
+    d = torch.empty((B, 7), dtype=torch.float32, device=odom.device)
+    _chk(lib().rslo_pose_tail_bwd(_ptr(odom, torch.float32, "odom"), _dp(g_t), _dp(g_r), B, _ptr(d), _stream()),
+         "rslo_pose_tail_bwd")
+    return d
 
 
 def cat_upsample_fwd(a, b, scale):
@@ -1298,12 +1328,16 @@ def conv2d_fwd_s2(x, ws, cout, ksize):
     return out
 
 
-def conv2d_dgrad_s2(dy, ws_t, cin, H, W, ksize):
-    """dy [B,cout,Ho,Wo] -> dx [B,cin,H,W] of the stride-2 layer; ws_t = the transpose=True operand."""
+def conv2d_dgrad_s2(dy, ws_t, cin, H, W, ksize, residual=None):
+    """dy [B,cout,Ho,Wo] -> dx [B,cin,H,W] of the stride-2 layer; ws_t = the transpose=True operand.
+    residual [B,cin,H,W]: added in the epilogue (rslo_conv2d_dgrad_s2_add)."""
     B, cout = dy.shape[0], dy.shape[1]
     dx = torch.empty((B, cin, H, W), dtype=torch.float32, device=dy.device)
-    rc = lib().rslo_conv2d_dgrad_s2(_ptr(dy, torch.float32, "dy"), ws_t.data_ptr(), B, cin, cout, H, W, ksize, dx.data_ptr(),
-                                    _stream())
+    if residual is not None and (tuple(residual.shape) != tuple(dx.shape) or not residual.is_contiguous()):
+        raise ValueError("conv2d_dgrad_s2: residual must be a contiguous %s tensor" % (tuple(dx.shape),))
+    rc = lib().rslo_conv2d_dgrad_s2_add(_ptr(dy, torch.float32, "dy"), ws_t.data_ptr(),
+                                        _ptr(residual, torch.float32, "residual") if residual is not None else None,
+                                        B, cin, cout, H, W, ksize, dx.data_ptr(), _stream())
     if rc:
         _chk(rc, "rslo_conv2d_dgrad_s2")
     return dx

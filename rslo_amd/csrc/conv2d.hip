@@ -990,6 +990,7 @@ struct Conv2dStrGeom {
   int n_class;            // classes computed by every workgroup from ONE staged halo (1 forward, 4 data gradient)
   int tiles_x, tiles_y;
   int xsc, npix, ny;      // XCD-aware workgroup order, as in Conv2dFwdGeom
+  const float *res;       // optional [B][cout][Ho][Wo] added in the epilogue (NULL: none)
   Conv2dStrClass cls[4];
 };
 
@@ -1107,9 +1108,10 @@ __global__ __launch_bounds__(256, 2) void k_conv2d_str(const float *__restrict__
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {
           const int r = r0 + wn * NTW + nt;
-          if (col < cl.cols && r < cl.rows)
-            out[((int64_t)b * gm.cout + m) * HWo + (int64_t)(gm.s_out * r + cl.py) * gm.Wo + gm.s_out * col + cl.px] =
-                acc[c][mt][nt][j];
+          if (col < cl.cols && r < cl.rows) {
+            const int64_t o = ((int64_t)b * gm.cout + m) * HWo + (int64_t)(gm.s_out * r + cl.py) * gm.Wo + gm.s_out * col + cl.px;
+            out[o] = gm.res ? acc[c][mt][nt][j] + gm.res[o] : acc[c][mt][nt][j];
+          }
         }
       }
   }
@@ -1160,14 +1162,24 @@ extern "C" int rslo_conv2d_fwd_s2(const float *in, const void *Ws, int B, int ci
 }
 
 // dout [B,cout,Ho,Wo] -> din [B,cin,H,W] (every element written); Ws = rslo_conv2d_wsplit_k(W, cin, cout, ksize, 1)
+extern "C" int rslo_conv2d_dgrad_s2_add(const float *dout, const void *Ws, const float *res, int B, int cin, int cout, int H,
+                                        int W, int ksize, float *din, void *stream);
 extern "C" int rslo_conv2d_dgrad_s2(const float *dout, const void *Ws, int B, int cin, int cout, int H, int W, int ksize,
                                     float *din, void *stream) {
+  return rslo_conv2d_dgrad_s2_add(dout, Ws, nullptr, B, cin, cout, H, W, ksize, din, stream);
+}
+
+// din = data gradient + res (res [B,cin,H,W], not aliasing din): the two input gradients of a stride-2 BasicBlock
+// (3x3 branch + 1x1 downsample branch) meet in the second one's epilogue
+extern "C" int rslo_conv2d_dgrad_s2_add(const float *dout, const void *Ws, const float *res, int B, int cin, int cout, int H,
+                                        int W, int ksize, float *din, void *stream) {
   RSLO_CHECK_ARG(dout && Ws && din && B > 0 && H > 0 && W > 0 && rslo_conv2d_s2_supported(cin, cout, ksize),
                  "rslo_conv2d_dgrad_s2: unsupported shape cin=%d cout=%d ksize=%d", cin, cout, ksize);
   Conv2dStrGeom gm = {};
   gm.B = B; gm.cin = cout; gm.cout = cin;       // contraction over the forward's output channels
   gm.Hi = (H - 1) / 2 + 1; gm.Wi = (W - 1) / 2 + 1; gm.Ho = H; gm.Wo = W;
   gm.s_out = 2; gm.ntap_w = ksize * ksize; gm.n_class = 4; gm.src_stride = 1;
+  gm.res = res;
   const int rmax = (H + 1) / 2, cmax = (W + 1) / 2;
   gm.tiles_x = (int)rslo_cdiv(cmax, 16); gm.tiles_y = (int)rslo_cdiv(rmax, 4);
   for (int py = 0; py < 2; ++py)

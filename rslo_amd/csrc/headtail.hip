@@ -379,3 +379,55 @@ extern "C" int rslo_cat_upsample_bwd(const float *grad, int B, int Ca, int Cb, i
   RSLO_CHECK_LAUNCH("k_cat_upsample_bwd");
   return RSLO_OK;
 }
+
+// ----------------------------------------------------------------------------------------- voted pose -> (t, q / (|q| + eps))
+// odom [B,7] = (t, q) from the vote; the head returns t and the re-normalised quaternion q / (|q| + 1e-12)
+// (odom_pred.py:279-288 of the reference).  As torch ops: 2 slices + norm + add + div forward and ~18 launches of their
+// autograd backward on 28 numbers; here one launch each way (one thread per sample).
+__global__ void k_pose_tail_fwd(const float *__restrict__ odom, int B, float *__restrict__ t, float *__restrict__ r) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float *o = odom + (int64_t)b * 7;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) t[b * 3 + k] = o[k];
+  const float n = sqrtf(o[3] * o[3] + o[4] * o[4] + o[5] * o[5] + o[6] * o[6]);
+  const float den = n + 1e-12f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) r[b * 4 + k] = o[3 + k] / den;
+}
+
+// d_odom[:, :3] = g_t (zeros when NULL); d_odom[:, 3:] = g_r / den - q (q . g_r) / (den^2 |q|)   (the |q| term drops at
+// |q| = 0, where torch.norm's gradient is defined as zero)
+__global__ void k_pose_tail_bwd(const float *__restrict__ odom, const float *__restrict__ g_t,
+                                const float *__restrict__ g_r, int B, float *__restrict__ d_odom) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float *o = odom + (int64_t)b * 7;
+  float *d = d_odom + (int64_t)b * 7;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) d[k] = g_t ? g_t[b * 3 + k] : 0.f;
+  float q[4], g[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { q[k] = o[3 + k]; g[k] = g_r ? g_r[b * 4 + k] : 0.f; }
+  const float n = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  const float den = n + 1e-12f;
+  const float s = q[0] * g[0] + q[1] * g[1] + q[2] * g[2] + q[3] * g[3];
+  const float c = n > 0.f ? s / (den * den * n) : 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) d[3 + k] = g[k] / den - q[k] * c;
+}
+
+extern "C" int rslo_pose_tail_fwd(const float *odom, int B, float *t, float *r, void *stream) {
+  RSLO_CHECK_ARG(odom && t && r && B >= 1, "rslo_pose_tail_fwd: bad arguments");
+  hipLaunchKernelGGL(k_pose_tail_fwd, dim3((unsigned)rslo_cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, odom, B, t, r);
+  RSLO_CHECK_LAUNCH("k_pose_tail_fwd");
+  return RSLO_OK;
+}
+
+extern "C" int rslo_pose_tail_bwd(const float *odom, const float *g_t, const float *g_r, int B, float *d_odom, void *stream) {
+  RSLO_CHECK_ARG(odom && d_odom && B >= 1, "rslo_pose_tail_bwd: bad arguments");
+  hipLaunchKernelGGL(k_pose_tail_bwd, dim3((unsigned)rslo_cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, odom, g_t, g_r, B,
+                     d_odom);
+  RSLO_CHECK_LAUNCH("k_pose_tail_bwd");
+  return RSLO_OK;
+}

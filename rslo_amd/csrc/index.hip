@@ -790,7 +790,9 @@ extern "C" int rslo_dense_gather_frames(const float *dense, const int32_t *coord
 // (odom_pred.py:165-168 input mask, voxel_odom_net.py:519-527 feature mask) and the channel mean (middle_feature): four
 // torch reductions over 35-70 MB plus a 70 MB concatenation; here the tensor is read once.  Channels are added in
 // ascending order by one thread per cell (coalesced across cells).
-__global__ void k_bev_channel_sums(const float *__restrict__ in, int G, int Cg, int64_t HW, float *__restrict__ out) {
+__global__ void k_bev_channel_sums(const float *__restrict__ in, int G, int Cg, int64_t HW, float *__restrict__ out,
+                                   float *__restrict__ mask_f, unsigned char *__restrict__ mask_b,
+                                   unsigned char *__restrict__ outside_b) {
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= HW) return;
   const int g = blockIdx.y, b = blockIdx.z;
@@ -798,15 +800,27 @@ __global__ void k_bev_channel_sums(const float *__restrict__ in, int G, int Cg, 
   float s = 0.f;
   for (int c = 0; c < Cg; ++c) s = __fadd_rn(s, src[(int64_t)c * HW]);
   out[(int64_t)(b * G + g) * HW + p] = s;
+  if (g == 0) {       // occupancy of the first frame of the pair: the head's input mask
+    const bool occ = s != 0.f;
+    const int64_t o = (int64_t)b * HW + p;
+    if (mask_f) mask_f[o] = occ ? 1.f : 0.f;
+    if (mask_b) mask_b[o] = occ ? 1 : 0;
+    if (outside_b) outside_b[o] = occ ? 0 : 1;
+  }
 }
 
-extern "C" int rslo_bev_channel_sums(const float *in, int B, int G, int Cg, int64_t HW, float *out, void *stream) {
+extern "C" int rslo_bev_channel_sums_masks(const float *in, int B, int G, int Cg, int64_t HW, float *out, float *mask_f,
+                                           unsigned char *mask_b, unsigned char *outside_b, void *stream) {
   RSLO_CHECK_ARG(in && out && B >= 1 && G >= 1 && Cg >= 1 && HW >= 1 && B < 65536 && G < 65536,
                  "rslo_bev_channel_sums: bad arguments");
   hipLaunchKernelGGL(k_bev_channel_sums, dim3((unsigned)rslo_cdiv(HW, 256), (unsigned)G, (unsigned)B), dim3(256), 0,
-                     (hipStream_t)stream, in, G, Cg, HW, out);
+                     (hipStream_t)stream, in, G, Cg, HW, out, mask_f, mask_b, outside_b);
   RSLO_CHECK_LAUNCH("k_bev_channel_sums");
   return RSLO_OK;
+}
+
+extern "C" int rslo_bev_channel_sums(const float *in, int B, int G, int Cg, int64_t HW, float *out, void *stream) {
+  return rslo_bev_channel_sums_masks(in, B, G, Cg, HW, out, nullptr, nullptr, nullptr, stream);
 }
 
 // The logged extras of the training forward from those sums [B, T, HW] (voxel_odom_net.py:455-464 of the reference):

@@ -115,14 +115,20 @@ class _BasicBlockFn(torch.autograd.Function):
         if hip_w1:
             dw1 = hip_conv2d.conv2d_wgrad_leaf(x, d_o1, s, lp=lp)
         else:       # the full-resolution stride-2 layer: the library's weight gradient (see csrc/conv2d.hip conv2d_plan)
-            dw1 = torch.ops.aten.convolution_backward(d_o1, x, w1, None, [s, s], [1, 1], [1, 1], False, [0, 0], 1,
-                                                      [False, True, False])[1]
+            from rslo_amd import streams      # leaf work, like the hand-written weight gradients (rslo_amd/streams.py)
+            dw1 = streams.leaf(lambda: torch.ops.aten.convolution_backward(
+                d_o1, x, w1, None, [s, s], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1], (d_o1, x))
         dwd = dgd = dbd = None
         if wd is not None:
+            from rslo_amd import streams
             d_od, _, dgd, dbd = fused_bn_backward(d_res, None, od, gd, md, idd, nd, 1.0, False, True, group, world)
-            dx.add_(capi.conv2d_dgrad_s2(d_od, wdt, wd.shape[1], x.shape[2], x.shape[3], 1))
-            xs = x[:, :, ::2, ::2].flatten(2)
-            dwd = torch.matmul(d_od.flatten(2), xs.transpose(1, 2)).sum(0).reshape(wd.shape)
+            # the downsample branch's input gradient lands on every other pixel: joined with the 3x3 branch's in its epilogue
+            dx = capi.conv2d_dgrad_s2(d_od, wdt, wd.shape[1], x.shape[2], x.shape[3], 1, residual=dx)
+
+            def ds_wgrad():
+                xs = x[:, :, ::2, ::2].flatten(2)
+                return torch.matmul(d_od.flatten(2), xs.transpose(1, 2)).sum(0).reshape(wd.shape)
+            dwd = streams.leaf(ds_wgrad, (d_od, x))
         elif not res_joined:
             dx.add_(d_res)
         return dx, dw1, dg1, db1, dw2, dg2, db2, dwd, dgd, dbd, None, None

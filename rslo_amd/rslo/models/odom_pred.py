@@ -100,11 +100,11 @@ class UNOdomPredEncDecSVDTempMaskBase(OdomPredEncDecBase):
         with torch.no_grad():   # occupancy of the FIRST frame of each pair only (odom_pred.py:165-168)
             if base is not None and base.dtype == torch.float32:
                 from rslo_amd import capi
-                bev_sums = capi.bev_channel_sums(base.detach(), 2)
-                input_mask_bool = bev_sums[:, 0:1] != 0
+                bev_sums, input_mask, input_mask_bool, outside = capi.bev_channel_sums(base.detach(), 2, masks=True)
             else:
                 input_mask_bool = xs[0].sum(dim=1, keepdim=True) != 0
-            input_mask = input_mask_bool.to(dtype=xs[0].dtype)
+                input_mask = input_mask_bool.to(dtype=xs[0].dtype)
+                outside = ~input_mask_bool        # shared by the four masked softmaxes below
 
         x = base if base is not None else torch.cat(xs, dim=1)
         if getattr(self, "channels_last", False):     # experiment switch (bench.py RSLO_HEAD_NHWC=1), see DESIGN.md
@@ -150,7 +150,6 @@ class UNOdomPredEncDecSVDTempMaskBase(OdomPredEncDecBase):
         # its only other effect -- a second running-statistics update of the trunk's BatchNorms with the same batch
         # statistics -- is replayed algebraically.
         bn_before = self._snapshot_bn((self.t_map_conf, self.q_map_conf))
-        outside = ~input_mask_bool        # shared by the four masked softmaxes below
         if fused_tail:
             # the element-wise tail on csrc/headtail.hip: quaternion normalisation, the four masked softmaxes, the mask /
             # weight pyramid and the masked maps -- 3 launches forward, 3 backward instead of ~45 each way
@@ -188,6 +187,12 @@ class UNOdomPredEncDecSVDTempMaskBase(OdomPredEncDecBase):
 
         translations, rotations = [], []
         for o in odoms:
+            if (fused_tail and o.is_cuda and o.dtype == torch.float32 and o.dim() == 2 and o.shape[1] == 7
+                    and self.odom_format != "r(x+t)"):
+                t, r = _PoseTailFn.apply(o)      # (t, q / (|q| + 1e-12)): one launch each way instead of ~20
+                translations.append(t)
+                rotations.append(r)
+                continue
             t, r = o[:, :3], o[:, 3:]
             if self.odom_format == "r(x+t)":
                 t = rotate_vec_by_q(t, r)
@@ -333,6 +338,26 @@ def _deblock(deblock, x, skip):
     return deblock(torch.cat([x, skip], dim=1))
 
 
+class _PoseTailFn(torch.autograd.Function):
+    """odom [B,7] -> (t, q / (|q| + 1e-12)) (rslo_pose_tail_fwd / _bwd; reference odom_pred.py:279-288)."""
+
+    @staticmethod
+    def forward(ctx, odom):
+        from rslo_amd import capi
+        odom = odom.contiguous()
+        ctx.save_for_backward(odom)
+        ctx.set_materialize_grads(False)
+        return capi.pose_tail_fwd(odom)
+
+    @staticmethod
+    def backward(ctx, g_t, g_r):
+        from rslo_amd import capi
+        (odom,) = ctx.saved_tensors
+        if g_t is None and g_r is None:
+            return None
+        return capi.pose_tail_bwd(odom, None if g_t is None else g_t.contiguous(), None if g_r is None else g_r.contiguous())
+
+
 class _TqNormFn(torch.autograd.Function):
     """tq [B,7,H,W] -> cat(t, q / |q|) (rslo_tq_normalize_fwd / _bwd)."""
 
@@ -362,12 +387,15 @@ class _ConfPairFn(torch.autograd.Function):
                                                    temperature)
         ctx.save_for_backward(t_conf, r_conf, outside)
         ctx.mark_non_differentiable(ct)
+        ctx.set_materialize_grads(False)      # no zero-filled stand-ins for the outputs nobody differentiates
         return t_conf, r_conf, ct
 
     @staticmethod
     def backward(ctx, g_t, g_r, _g):
         from rslo_amd import capi
         t_conf, r_conf, outside = ctx.saved_tensors
+        if g_t is None and g_r is None:
+            return None, None, None, None
         g_t = torch.zeros_like(t_conf) if g_t is None else g_t.contiguous()
         g_r = torch.zeros_like(r_conf) if g_r is None else g_r.contiguous()
         d_t, d_r = capi.conf_softmax_bwd(t_conf, r_conf, g_t, g_r, outside.contiguous())
@@ -388,6 +416,7 @@ class _HeadMasksFn(torch.autograd.Function):
         ctx.save_for_backward(*occ)
         ctx.shapes = [tuple(p.shape) for p in preds]
         ctx.mark_non_differentiable(mtq_g, *w)
+        ctx.set_materialize_grads(False)
         return (mtq, mtq_g, *mp, *w)
 
     @staticmethod
@@ -410,12 +439,15 @@ class _VoteFn(torch.autograd.Function):
         ctx.save_for_backward(tq_map, t_conf, r_conf, odom, sums)
         ctx.geom = (origin, vsize)
         ctx.mark_non_differentiable(tq_g)
+        ctx.set_materialize_grads(False)
         return tq_g, odom
 
     @staticmethod
     def backward(ctx, _g_map, g_odom):
         from rslo_amd import capi
         tq_map, t_conf, r_conf, odom, sums = ctx.saved_tensors
+        if g_odom is None:
+            return None, None, None, None, None
         d_tq, d_tc, d_rc = capi.vote_bwd(tq_map, t_conf, r_conf, *ctx.geom, odom, sums, g_odom.contiguous())
         return d_tq, d_tc, d_rc, None, None
 

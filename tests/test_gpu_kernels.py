@@ -347,6 +347,11 @@ def test_bev_channel_sums_and_display_match_torch_bits(hip, B, T, Cg, H, W):
     bev = torch.randn((B, T * Cg, H, W), device="cuda", generator=g)
     bev = bev * (torch.rand((B, 1, H, W), device="cuda", generator=g) < 0.3)       # mostly empty cells, as a BEV map
     sums = hip.bev_channel_sums(bev, T)
+    sums2, mf, mb, ob = hip.bev_channel_sums(bev, T, masks=True)       # the head's input mask from the same launch
+    occ0 = bev[:, :Cg].sum(dim=1, keepdim=True) != 0
+    assert torch.equal(sums2, sums) and mb.dtype == torch.bool and ob.dtype == torch.bool
+    assert torch.equal(mb, sums[:, 0:1] != 0) and torch.equal(ob, ~mb) and torch.equal(mf, mb.float())
+    assert int((mb != occ0).sum()) == 0
     mask, disp = hip.bev_display(sums, Cg)
     frames = list(bev.split(Cg, dim=1))
     ref_mask = (sums.sum(dim=1, keepdim=True) != 0).float()
@@ -377,6 +382,28 @@ def test_cat_upsample_matches_torch_bits(hip, B, Ca, Cb, H, W, s):
     assert torch.equal(da, a.grad) and torch.equal(db, b.grad)
     da, db = hip.cat_upsample_bwd(go, Ca, Cb, s, need_a=False)
     assert da is None and torch.equal(db, b.grad)
+
+
+def test_pose_tail_matches_torch(hip):
+    """rslo_pose_tail_fwd / _bwd = (o[:, :3], o[:, 3:] / (|o[:, 3:]| + 1e-12)) and its autograd gradient (reference
+    odom_pred.py:279-288) to fp32 rounding; one-sided and zero-quaternion rows included."""
+    g = torch.Generator(device="cuda").manual_seed(5)
+    o = torch.randn((6, 7), device="cuda", generator=g)
+    o[2, 3:] = 0                                     # |q| = 0: torch.norm's gradient is zero there
+    o[3, 3:] *= 1e-3
+    o = o.requires_grad_(True)
+    t_ref, q = o[:, :3], o[:, 3:]
+    r_ref = q / (torch.norm(q, dim=1, keepdim=True) + 1e-12)
+    gt, gr = torch.randn((6, 3), device="cuda", generator=g), torch.randn((6, 4), device="cuda", generator=g)
+    (t_ref * gt).sum().add((r_ref * gr).sum()).backward()
+    t, r = hip.pose_tail_fwd(o.detach())
+    assert torch.equal(t, t_ref.detach())
+    assert torch.allclose(r, r_ref.detach(), rtol=2e-6, atol=1e-7)
+    d = hip.pose_tail_bwd(o.detach(), gt, gr)
+    scale = float(o.grad.abs().max())
+    assert float((d - o.grad).abs().max()) <= 2e-6 * scale
+    d_t_only = hip.pose_tail_bwd(o.detach(), gt, None)
+    assert torch.equal(d_t_only[:, :3], gt) and float(d_t_only[:, 3:].abs().max()) == 0.0
 
 
 def test_leaky_bwd(hip):
@@ -1054,6 +1081,10 @@ def test_conv2d_stride2_fwd_and_dgrad_match_float64_oracle(hip, B, cin, cout, H,
         err_lib = np.abs(lib.astype(np.float64) - ref).max()
         assert err <= 2e-5 * scale, (err, scale)
         assert err <= 4 * err_lib + 1e-6 * scale, (err, err_lib)
+    # rslo_conv2d_dgrad_s2_add: the other branch's gradient read in the epilogue = a separate add, bit for bit
+    res = dev(rng.standard_normal((B, cin, H, W)).astype(np.float32))
+    joined = hip.conv2d_dgrad_s2(dev(g), hip.conv2d_wsplit_k(dev(w), True), cin, H, W, k, residual=res)
+    assert torch.equal(joined, res.clone().add_(dx))
 
 
 def test_hip_conv2d_stride2_layers_match_library_through_autograd(hip):
