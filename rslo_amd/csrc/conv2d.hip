@@ -23,6 +23,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef __attribute__((address_space(1))) unsigned char glb_u8;
+typedef __attribute__((address_space(1))) u32x4 glb_u32x4;
+typedef __attribute__((address_space(3))) unsigned char lds_u8;
+typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
 
 #define C2_THREADS 256
 #define C2_WAVES 4
@@ -545,7 +549,17 @@ static int conv2d_wgrad_launch(const float *in, const float *dout, int B, int ci
 // (weights) are split beforehand by k_conv2d_wsplit into the exact MFMA fragment order (16 bytes per lane and plane).
 // Workgroup = 4 waves as 2 (output-channel halves) x 2 (row halves); out tile = 32 MTW channels x TR x 16 pixels.
 // ---------------------------------------------------------------------------------------------------------------------
-#define C2F_PXB 208      // bytes per staged pixel: 3 planes x 32 channels x 2 B + 16 B pad (conflict-free b128 reads)
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope fence + s_barrier and the fence
+// drains vmcnt(0): every global load in flight (the next chunk's values, the next chunk's weight operands) would have
+// to land before any wave passes -- the prefetches this kernel family relies on would be serialised at every barrier.
+#define C2F_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define C2F_PXB 208      // bytes per staged pixel: 3 planes x 32 channels x 2 B + 16 B pad
+// stride-1 kernels: 224 B.  ds_read_b128 is served in lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (+32): with
+// lane = pixel + 16 * octet the 16-byte slots of a group are (S * pixel + octet) mod 16, S = stride / 16 -- S = 13 puts two
+// lanes of every group on one slot (SQ_LDS_BANK_CONFLICT = 44 % of the LDS cycles of the 208-byte layout), S = 14 none
+#ifndef C2F_PXB1
+#define C2F_PXB1 224
+#endif
 
 // Ws [cin_k / 32][9][n_m / 16][3][64][8] bf16 from W [cout][cin][3][3]; transpose = 0: m = cout, k = cin (forward);
 // transpose = 1: m = cin, k = cout, taps flipped (data gradient)
@@ -598,13 +612,18 @@ struct Conv2dFwdGeom {
 // Measured in the step (rocprof, same box): k_conv2d_fwd<4,1,true> 36.4 -> 32.7 us over its 58 launches, -0.2 ms per step.
 // (The same idea on the weight-gradient kernels -- an XCD takes a run of pixel slabs with all their dW tiles -- changed
 // nothing: 28.9 vs 29.4 us, not kept.)
+__device__ __forceinline__ bool conv2d_xcd_tile_id(int id, int xsc, int npix, int ny, int &bx, int &by);
 __device__ __forceinline__ bool conv2d_xcd_tile(int xsc, int npix, int ny, int &bx, int &by) {
   if (xsc == 0) {
     bx = blockIdx.x;
     by = blockIdx.y;
     return true;
   }
-  const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+  return conv2d_xcd_tile_id((int)blockIdx.x, xsc, npix, ny, bx, by);
+}
+// the same mapping for an explicit workgroup slot `id` (id & 7 = the XCD it runs on; xsc >= 1)
+__device__ __forceinline__ bool conv2d_xcd_tile_id(int id, int xsc, int npix, int ny, int &bx, int &by) {
+  const int x = id & 7, j = id >> 3;
   const int sp = 8 / xsc, cg = x % xsc, pg = x / xsc, nyl = ny / xsc;
   const int p0 = (pg * npix) / sp, p1 = ((pg + 1) * npix) / sp;
   const int pl = j / nyl;
@@ -637,12 +656,12 @@ static dim3 conv2d_xcd_grid(int xsc, int npix, int ny) {
 // accumulator sets meet through LDS (set 0 + set 1, a fixed order).  On the 12x22 / 24x44 maps a launch is less than one
 // workgroup per CU and lasts as long as ONE workgroup's chain of n_chunks x (global load -> split -> LDS -> 9 taps),
 // 2.7 us per chunk against 0.7 us of MFMAs: two half-length chains side by side on the CU halve it.
-template <int TR, int MTW, bool FULLA, bool LP = false, int KC = 1>
-__global__ __launch_bounds__(256 * KC, 2 / KC) void k_conv2d_fwd(const float *__restrict__ in, const unsigned short *__restrict__ Ws,
+template <int TR, int MTW, bool FULLA, bool LP = false, int KC = 1, int OCC = 2 / KC>
+__global__ __launch_bounds__(256 * KC, OCC) void k_conv2d_fwd(const float *__restrict__ in, const unsigned short *__restrict__ Ws,
                                                     const float *__restrict__ bias, Conv2dFwdGeom gm,
                                                     float *__restrict__ out) {
   constexpr int NTW = TR / 2, HR = TR + 2, NPX = HR * 18;
-  __shared__ __attribute__((aligned(16))) unsigned char lds_all[KC][NPX * C2F_PXB];
+  __shared__ __attribute__((aligned(16))) unsigned char lds_all[KC][NPX * C2F_PXB1];
   const int grp = KC == 1 ? 0 : (int)(threadIdx.x >> 8);       // wave set (wave-uniform)
   unsigned char *lds = lds_all[grp];
   const int tid = threadIdx.x & 255, lane = tid & 63, wid = tid >> 6;
@@ -677,7 +696,7 @@ __global__ __launch_bounds__(256 * KC, 2 / KC) void k_conv2d_fwd(const float *__
     const int y = y0 - 1 + qy, x = x0 - 1 + qx;
     const bool ok = task < NPX * 4 && y >= 0 && y < H && x >= 0 && x < W;
     tsrc[r] = ok ? in + ((int64_t)b * gm.cin + 8 * o) * HW + (int64_t)y * W + x : nullptr;
-    tdst[r] = task < NPX * 4 ? q * C2F_PXB + o * 16 : -1;
+    tdst[r] = task < NPX * 4 ? q * C2F_PXB1 + o * 16 : -1;
   }
   float raw[NTASK][8];
   const int n_chunks = gm.cin / 32;
@@ -732,8 +751,21 @@ __global__ __launch_bounds__(256 * KC, 2 / KC) void k_conv2d_fwd(const float *__
         for (int j = 0; j < 8; ++j) raw[r][j] = tsrc[r] ? tsrc[r][((int64_t)(chunk + KC) * 32 + j) * HW] : 0.f;
     }
     }
-    __syncthreads();
+    C2F_LDS_BARRIER();      // LDS only: the prefetched global loads stay in flight across it
     if (live) {
+    u32x4 pbh[NTW], pbm[NTW], pbl[NTW];
+#define C2F_LOAD_B(KY, KX)                                                                               \
+  _Pragma("unroll") for (int nt = 0; nt < NTW; ++nt) {                                                    \
+    const lds_u8 *bp = bbase + ((nt + (KY)) * 18 + (KX)) * C2F_PXB1;     /* one address register + immediates */ \
+    pbh[nt] = *(const lds_u32x4 *)(bp);                                                                   \
+    if constexpr (!LP) {                                                                                  \
+      pbm[nt] = *(const lds_u32x4 *)(bp + 64);                                                            \
+      pbl[nt] = *(const lds_u32x4 *)(bp + 128);                                                           \
+    }                                                                                                     \
+  }
+    const lds_u8 *bbase = (const lds_u8 *)lds + (wn * NTW * 18 + li) * C2F_PXB1 + g * 16;
+    constexpr bool BPF = OCC < 5;      // >= 5 waves per SIMD: no second operand set, the other waves cover the LDS latency
+    if constexpr (BPF) { C2F_LOAD_B(0, 0) }
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
 #pragma unroll
@@ -748,15 +780,17 @@ __global__ __launch_bounds__(256 * KC, 2 / KC) void k_conv2d_fwd(const float *__
             C2F_LOAD_A(chunk + KC, 0, nh, nm, nl)
           }
         }
+        // pixel operands one tap ahead: the LDS reads of tap + 1 are in flight during this tap's MFMAs
         u32x4 bh[NTW], bm[NTW], bl[NTW];
+        if constexpr (!BPF) { C2F_LOAD_B(ky, kx) }
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {
-          const unsigned char *bp = lds + ((wn * NTW + nt + ky) * 18 + li + kx) * C2F_PXB + g * 16;
-          bh[nt] = *(const u32x4 *)(bp);
-          if constexpr (!LP) {
-            bm[nt] = *(const u32x4 *)(bp + 64);
-            bl[nt] = *(const u32x4 *)(bp + 128);
-          }
+          bh[nt] = pbh[nt];
+          if constexpr (!LP) { bm[nt] = pbm[nt]; bl[nt] = pbl[nt]; }
+        }
+        if (BPF && tap < 8) {
+          const int ky2 = (tap + 1) / 3, kx2 = (tap + 1) % 3;
+          C2F_LOAD_B(ky2, kx2)
         }
         // six products per block, smallest first; consecutive MFMAs hit different accumulators (LP: the hh product only)
         if constexpr (!LP) {
@@ -797,9 +831,10 @@ __global__ __launch_bounds__(256 * KC, 2 / KC) void k_conv2d_fwd(const float *__
       }
     }
     }
-    __syncthreads();
+    C2F_LDS_BARRIER();      // LDS only: the prefetched global loads stay in flight across it
   }
 #undef C2F_LOAD_A
+#undef C2F_LOAD_B
   if constexpr (KC == 2) {      // set 1 -> LDS (its own staging buffer, free after the last barrier) -> set 0
     float *slot = reinterpret_cast<float *>(lds_all[1]);
     if (grp == 1) {
@@ -840,13 +875,15 @@ __global__ __launch_bounds__(256 * KC, 2 / KC) void k_conv2d_fwd(const float *__
     }
 }
 
+
+static int g_c2f_occ = 0;      // experiments: waves per SIMD the one-tap-ahead variants are compiled for (0: default kernels)
 static int conv2d_fwd_plan(int B, int cin, int cout, int H, int W, int *tr, int *mtw) {
   if (B <= 0 || H <= 0 || W <= 0 || cin % 32 != 0 || cout % 32 != 0) return 0;
   static int cfg_tr = -1, cfg_mtw = -1;
   if (cfg_tr < 0) {
-    const char *e = getenv("RSLO_CONV2D_FWD_CFG");      // "TR,MTW" forces one configuration (experiments)
+    const char *e = getenv("RSLO_CONV2D_FWD_CFG");      // "TR,MTW[,OCC]" forces one configuration (experiments)
     cfg_tr = cfg_mtw = 0;
-    if (e) sscanf(e, "%d,%d", &cfg_tr, &cfg_mtw);
+    if (e) sscanf(e, "%d,%d,%d", &cfg_tr, &cfg_mtw, &g_c2f_occ);
   }
   // measured inside the training step (profiles/README.md): 4-row tiles, one 16-channel block per wave and the whole
   // chunk's weight operands prefetched 9 taps ahead win on every map size of the head (45 vs 67 us on 48x88, 23 vs 54 us
@@ -948,6 +985,26 @@ static int conv2d_fwd_launch(const float *in, const void *Ws, const float *bias,
     RSLO_CHECK_LAUNCH("k_conv2d_fwd(bf16)");
     return RSLO_OK;
   }
+  // large maps (>= 1024 workgroups: 4 or more per CU): the one-tap-ahead variant at 128 registers keeps 4 workgroups
+  // resident per CU instead of 2 (16 waves hide the staging chain; the 9-tap weight prefetch is not needed with them).
+  // Measured (scripts/conv2d_cfgs.sh, B = 4): 128 -> 128 at 48x88 41.6 -> 38.5 us, 64 -> 64 at 96x176 44.1 -> 36.8,
+  // 64 -> 192 at 96x176 114.8 -> 93.3, 192 -> 64 103.8 -> 95.3; 128 -> 128 at 24x44 (288 workgroups) 16.5 -> 17.4 and
+  // 256 -> 256 at 12x22 18.6 -> 25.0 keep the 9-tap kernel.  RSLO_CONV2D_FWD_LEAN=0 / 1 forces it off / on.
+  static const int lean_env = getenv("RSLO_CONV2D_FWD_LEAN") ? atoi(getenv("RSLO_CONV2D_FWD_LEAN")) : -1;
+  if (tr == 4 && mtw == 1 && !kc2 && !g_c2f_occ && (lean_env < 0 ? wgs4 >= 1024 : lean_env == 1)) {
+    hipLaunchKernelGGL((k_conv2d_fwd<4, 1, false, false, 1, 4>), grid, dim3(256), 0, st, in, ws, bias, gm, out);
+    RSLO_CHECK_LAUNCH("k_conv2d_fwd(lean)");
+    return RSLO_OK;
+  }
+  if (tr == 4 && g_c2f_occ) {
+#define C2F_OCC(M, O) hipLaunchKernelGGL((k_conv2d_fwd<4, M, false, false, 1, O>), grid, dim3(256), 0, st, in, ws, bias, gm, out)
+    if (mtw == 1 && g_c2f_occ == 3) C2F_OCC(1, 3);
+    else if (mtw == 1 && g_c2f_occ == 4) C2F_OCC(1, 4);
+    else if (mtw == 1) C2F_OCC(1, 4);
+    else if (g_c2f_occ == 4) C2F_OCC(2, 4);
+    else C2F_OCC(2, 3);
+#undef C2F_OCC
+  } else
   if (tr == 8 && mtw == 2) hipLaunchKernelGGL((k_conv2d_fwd<8, 2, false>), grid, dim3(256), 0, st, in, ws, bias, gm, out);
   else if (tr == 8) hipLaunchKernelGGL((k_conv2d_fwd<8, 1, false>), grid, dim3(256), 0, st, in, ws, bias, gm, out);
   else if (mtw == 2) hipLaunchKernelGGL((k_conv2d_fwd<4, 2, false>), grid, dim3(256), 0, st, in, ws, bias, gm, out);
