@@ -607,6 +607,13 @@ RSLO_API int rslo_conv2d_dgrad_s2_add(const float *dout, const void *Ws, const f
  *      rslo_conv2d_wsplit (its first plane IS the bf16-rounded weight); the stride-2 weight gradient keeps the split form. */
 RSLO_API int rslo_conv2d_fwd_bf16(const float *in, const void *Ws, const float *bias, int B, int cin, int cout, int H,
                                   int W, float *out, void *stream);
+/*      Weight gradient of the 1x1 / stride-2 / padding-0 downsample layers (custom_resnet_spc.py:224-260 `downsample`):
+ *      in [B,cin,H,W], dout [B,cout,Ho,Wo] -> dW [cout,cin,1,1]; the centre tap of the stride-2 3x3 kernel, same fixed-order
+ *      slab reduction (bit-reproducible).  cin % 16 == 0, cout % 32 == 0, W >= 15. */
+RSLO_API int rslo_conv1x1s2_wgrad_supported(int cin, int cout, int H, int W);
+RSLO_API size_t rslo_conv1x1s2_wgrad_ws_bytes(int B, int cin, int cout, int H, int W);
+RSLO_API int rslo_conv1x1s2_wgrad(const float *in, const float *dout, int B, int cin, int cout, int H, int W, float *dW,
+                                  void *ws, size_t ws_bytes, void *stream);
 RSLO_API int rslo_conv2d_fwd_add_bf16(const float *in, const void *Ws, const float *bias, const float *res, int B,
                                       int cin, int cout, int H, int W, float *out, void *stream);
 RSLO_API int rslo_conv2d_wgrad_bf16(const float *in, const float *dout, int B, int cin, int cout, int H, int W,

@@ -100,6 +100,9 @@ SIGNATURES = {
     "rslo_vote_bwd": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rslo_conv2d_wgrad_supported": (C.c_int, [_i, _i, _i, _i, _i]),
     "rslo_conv2d_wgrad_ws_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "rslo_conv1x1s2_wgrad_supported": (C.c_int, [_i, _i, _i, _i]),
+    "rslo_conv1x1s2_wgrad_ws_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "rslo_conv1x1s2_wgrad": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "rslo_conv2d_wgrad": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "rslo_conv2d_fwd_supported": (C.c_int, [_i, _i, _i, _i]),
     "rslo_conv2d_wsplit_bytes": (_sz, [_i, _i]),
@@ -1259,6 +1262,26 @@ def conv2d_wgrad(x, dout, stride=1, want_bias=False, lp=False):
     if rc:
         _chk(rc, "rslo_conv2d_wgrad")
     return (dW, db) if want_bias else dW
+
+
+def conv1x1s2_wgrad(x, dout):
+    """x [B,cin,H,W], dout [B,cout,Ho,Wo] -> dW [cout,cin,1,1] of a 1x1 / stride-2 / padding-0 conv (rslo_conv1x1s2_wgrad);
+    None when the shape is outside the kernel's range (the caller falls back to a batched GEMM)."""
+    B, cin, H, W = x.shape
+    cout = dout.shape[1]
+    key = (B, cin, cout, H, W, "1x1s2")
+    wsb = _c2w_ws_bytes.get(key)
+    if wsb is None:
+        wsb = _c2w_ws_bytes[key] = lib().rslo_conv1x1s2_wgrad_ws_bytes(B, cin, cout, H, W)
+    if wsb == 0:
+        return None
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=x.device)
+    dW = torch.empty((cout, cin, 1, 1), dtype=torch.float32, device=x.device)
+    rc = lib().rslo_conv1x1s2_wgrad(_ptr(x, torch.float32, "x"), _ptr(dout, torch.float32, "dout"), B, cin, cout, H, W,
+                                    dW.data_ptr(), ws.data_ptr(), wsb, _stream())
+    if rc:
+        _chk(rc, "rslo_conv1x1s2_wgrad")
+    return dW
 
 
 def conv2d_fwd_supported(cin, cout, H, W):

@@ -164,18 +164,29 @@ __global__ __launch_bounds__(256) void k_cg_tiles(const float4 *__restrict__ st,
 typedef unsigned long long u64;
 #define CG_KEY_INIT ((u64)0x7f800000u << 32)
 
-// all 64 lanes against the 64 points of one target tile, staged in the wave's LDS slot (broadcast reads)
+// all 64 lanes against the 64 points of one target tile, staged in the wave's LDS slot (broadcast reads).
+// The slot holds the tile as 32 point PAIRS (x0 x1 y0 y1 | z0 z1 w0 w1): two ds_read_b128 deliver the pair's coordinates
+// in adjacent registers, so the three subtractions, three squares and two additions of BOTH points are packed fp32
+// instructions (v_pk_add_f32 / v_pk_mul_f32: same IEEE results per element, no contraction) -- 8 arithmetic issues per
+// pair instead of 16; the key comparisons stay in point order.
+typedef float cg_f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void cg_eval_tile(const float4 *__restrict__ tile, float4 *slot, int lane, float qx, float qy,
                                              float qz, u64 &best) {
-  slot[lane] = tile[lane];
+  const float4 mine = tile[lane];
+  float *sf = reinterpret_cast<float *>(slot) + (lane >> 1) * 8 + (lane & 1);
+  sf[0] = mine.x; sf[2] = mine.y; sf[4] = mine.z; sf[6] = mine.w;
   __builtin_amdgcn_wave_barrier();
-#pragma unroll 16
-  for (int j = 0; j < CG_TILE; ++j) {
-    const float4 P = slot[j];
-    const float dx = P.x - qx, dy = P.y - qy, dz = P.z - qz;
-    const float d = (dx * dx + dy * dy) + dz * dz;
-    const u64 key = ((u64)(unsigned)__float_as_int(d) << 32) | (unsigned)__float_as_int(P.w);
-    best = key < best ? key : best;
+  const cg_f2 qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
+#pragma unroll 8
+  for (int j = 0; j < CG_TILE / 2; ++j) {
+    const float4 A = slot[2 * j], Bv = slot[2 * j + 1];
+    const cg_f2 px = {A.x, A.y}, py = {A.z, A.w}, pz = {Bv.x, Bv.y};
+    const cg_f2 dx = px - qx2, dy = py - qy2, dz = pz - qz2;
+    const cg_f2 d = (dx * dx + dy * dy) + dz * dz;
+    const u64 k0 = ((u64)(unsigned)__float_as_int(d.x) << 32) | (unsigned)__float_as_int(Bv.z);
+    const u64 k1 = ((u64)(unsigned)__float_as_int(d.y) << 32) | (unsigned)__float_as_int(Bv.w);
+    best = k0 < best ? k0 : best;
+    best = k1 < best ? k1 : best;
   }
   __builtin_amdgcn_wave_barrier();
 }

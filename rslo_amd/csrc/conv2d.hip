@@ -89,13 +89,15 @@ struct Conv2dGeom {
   int n_cin_tiles, n_cout_tiles;
 };
 
-// grid (n_cin_tiles * n_cout_tiles, n_slabs); ws [slab][tile][9][16][16 NB]
-template <int NB, int STRIDE>
+// grid (n_cin_tiles * n_cout_tiles, n_slabs); ws [slab][tile][NT][16][16 NB]
+// NT = 9: the 3x3 / padding-1 layer; NT = 1: only the centre tap, which at stride 2 IS the 1x1 / padding-0 downsample layer
+// (out[y][x] = W in[2y][2x]): its weight gradient from the same kernel
+template <int NB, int STRIDE, int NT = 9>
 __global__ __launch_bounds__(C2_THREADS, 2) void k_conv2d_wgrad(const float *__restrict__ in,
                                                              const float *__restrict__ dout, Conv2dGeom gm,
                                                              float *__restrict__ ws) {
   constexpr int CO_T = 16 * NB;
-  __shared__ __attribute__((aligned(16))) float red[9 * 16 * CO_T];
+  __shared__ __attribute__((aligned(16))) float red[NT * 16 * CO_T];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int li = lane & 15, g = lane >> 4;
   const int tile = blockIdx.x;
@@ -108,9 +110,9 @@ __global__ __launch_bounds__(C2_THREADS, 2) void k_conv2d_wgrad(const float *__r
   const int c_begin = blockIdx.y * gm.chunks_per_slab;
   const int c_end = min(c_begin + gm.chunks_per_slab, n_chunks);
 
-  f32x4 acc[9][NB];
+  f32x4 acc[NT][NB];
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) acc[t][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -145,6 +147,7 @@ __global__ __launch_bounds__(C2_THREADS, 2) void k_conv2d_wgrad(const float *__r
     for (int ky = 0; ky < 3; ++ky) {
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) {
+        if (NT == 1 && (ky != 1 || kx != 1)) continue;
         unsigned mask = vp;
         if (ky == 0) mask &= vy0;
         if (ky == 2) mask &= vy2;
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(C2_THREADS, 2) void k_conv2d_wgrad(const float *__r
           }
         }
         const Split3 a = split_masked(v, mask);
-        const int t = ky * 3 + kx;
+        const int t = NT == 1 ? 0 : ky * 3 + kx;
         // six products per block, smallest first; consecutive MFMAs hit different accumulators
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) acc[t][nb] = MFMA_BF16(a.l, bh[nb], acc[t][nb]);
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(C2_THREADS, 2) void k_conv2d_wgrad(const float *__r
   for (int w = 0; w < C2_WAVES; ++w) {
     if (wid == w) {
 #pragma unroll
-      for (int t = 0; t < 9; ++t)
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
@@ -202,8 +205,8 @@ __global__ __launch_bounds__(C2_THREADS, 2) void k_conv2d_wgrad(const float *__r
     }
     __syncthreads();
   }
-  float *dst = ws + ((int64_t)blockIdx.y * gridDim.x + tile) * (9 * 16 * CO_T);
-  for (int e = tid; e < 9 * 16 * CO_T; e += C2_THREADS) dst[e] = red[e];
+  float *dst = ws + ((int64_t)blockIdx.y * gridDim.x + tile) * (NT * 16 * CO_T);
+  for (int e = tid; e < NT * 16 * CO_T; e += C2_THREADS) dst[e] = red[e];
 }
 
 // Stride-1 kernel: the three taps of one kernel row read the same 10-float window r[0..9] = in[p-1 .. p+8] of an input
@@ -390,9 +393,10 @@ __global__ __launch_bounds__(C2_THREADS, NB == 2 ? 3 : 2) void k_conv2d_wgrad_s1
 __global__ __launch_bounds__(256) void k_conv2d_wgrad_reduce(const float *__restrict__ ws, int n_slabs, int n_tiles,
                                                              int n_cout_tiles, int co_t, int cin, int cout,
                                                              float *__restrict__ dW, int n_main_blocks,
-                                                             const float *__restrict__ bws, float *__restrict__ dbias) {
+                                                             const float *__restrict__ bws, float *__restrict__ dbias,
+                                                             int ntap) {
   __shared__ float part[8][32];
-  const int per_tile = 9 * 16 * co_t;
+  const int per_tile = ntap * 16 * co_t;
   const int64_t n = (int64_t)n_tiles * per_tile;
   const int se = threadIdx.x & 31, sg = threadIdx.x >> 5;
   if ((int)blockIdx.x >= n_main_blocks) {          // bias gradient: 32 channels per block, same 8-group slab order
@@ -431,14 +435,18 @@ __global__ __launch_bounds__(256) void k_conv2d_wgrad_reduce(const float *__rest
   const int t = r / (16 * co_t), r2 = r - t * 16 * co_t;
   const int ci = r2 / co_t, co = r2 - ci * co_t;
   const int ct = tile / n_cout_tiles, ot = tile - ct * n_cout_tiles;
-  dW[((int64_t)(ot * co_t + co) * cin + ct * 16 + ci) * 9 + t] = t8;
+  dW[((int64_t)(ot * co_t + co) * cin + ct * 16 + ci) * ntap + t] = t8;
 }
 
 static int conv2d_plan(int B, int cin, int cout, int H, int W, int stride, Conv2dGeom *gm, int *nb, int *n_slabs) {
   if (!(stride == 1 || stride == 2) || B <= 0 || H <= 0 || W < 8 || cin % 16 != 0 || cout % 32 != 0) return 0;
   // measured (scripts/bench_conv2d_wgrad.py): the stride-2 kernel re-reads a 15-float window per tap and loses to the
   // library on the full-resolution map (256->128 at 96x176: 170-210 us vs 131 us); smaller maps win (35-42 vs 49-57 us)
-  if (stride == 2 && (int64_t)H * W >= 96 * 176) return 0;
+  // As leaf work on the weight-gradient stream (rslo_amd/streams.py) the difference no longer shows in the step, and the
+  // hand-written kernel is bit-reproducible where the library's split-K kernels use atomics: it is the default;
+  // RSLO_CONV2D_WGRAD_S2_FULLRES=0 hands the full-resolution layer back to the library.
+  static const int s2_full = getenv("RSLO_CONV2D_WGRAD_S2_FULLRES") ? atoi(getenv("RSLO_CONV2D_WGRAD_S2_FULLRES")) : 1;
+  if (stride == 2 && (int64_t)H * W >= 96 * 176 && !s2_full) return 0;
   static int nb_pref = -1;
   if (nb_pref < 0) {
     const char *e = getenv("RSLO_CONV2D_NB");
@@ -530,8 +538,59 @@ static int conv2d_wgrad_launch(const float *in, const float *dout, int B, int ci
   const int n_main = (int)rslo_cdiv(n, 32);
   hipLaunchKernelGGL(k_conv2d_wgrad_reduce, dim3((unsigned)(n_main + (dbias ? (int)rslo_cdiv(cout, 32) : 0))), dim3(256), 0,
                      st, (const float *)ws, ns, tiles, gm.n_cout_tiles, 16 * nb, cin, cout, dW, n_main,
-                     (const float *)bws, dbias);
+                     (const float *)bws, dbias, 9);
   RSLO_CHECK_LAUNCH("k_conv2d_wgrad_reduce");
+  return RSLO_OK;
+}
+
+// Weight gradient of the 1x1 / stride-2 / padding-0 downsample layers (dW [cout,cin,1,1]): the centre tap of the stride-2
+// kernel.  in [B,cin,H,W], dout [B,cout,Ho,Wo], Ho = (H - 1) / 2 + 1.  Same slab partials + fixed-order reduction.
+static int conv2d_plan_1x1s2(int B, int cin, int cout, int H, int W, Conv2dGeom *gm, int *nb, int *n_slabs) {
+  if (B <= 0 || H <= 0 || W < 15 || cin % 16 != 0 || cout % 32 != 0) return 0;      // 8 or more output columns
+  *nb = 2;
+  gm->B = B; gm->cin = cin; gm->cout = cout; gm->Hin = H; gm->Win = W;
+  gm->H = (H - 1) / 2 + 1; gm->W = (W - 1) / 2 + 1;
+  gm->cpi = (int)rslo_cdiv((int64_t)gm->H * gm->W, 32);
+  gm->n_cin_tiles = cin / 16; gm->n_cout_tiles = cout / 32;
+  const int tiles = gm->n_cin_tiles * gm->n_cout_tiles, n_chunks = B * gm->cpi;
+  int s = (int)rslo_cdiv(768, tiles);
+  const int max_s = n_chunks / 8 > 0 ? n_chunks / 8 : 1;
+  if (s > max_s) s = max_s;
+  if (s < 1) s = 1;
+  gm->chunks_per_slab = (int)rslo_cdiv(n_chunks, s);
+  *n_slabs = (int)rslo_cdiv(n_chunks, gm->chunks_per_slab);
+  return 1;
+}
+
+extern "C" int rslo_conv1x1s2_wgrad_supported(int cin, int cout, int H, int W) {
+  Conv2dGeom gm;
+  int nb, ns;
+  return conv2d_plan_1x1s2(1, cin, cout, H, W, &gm, &nb, &ns);
+}
+
+extern "C" size_t rslo_conv1x1s2_wgrad_ws_bytes(int B, int cin, int cout, int H, int W) {
+  Conv2dGeom gm;
+  int nb, ns;
+  if (!conv2d_plan_1x1s2(B, cin, cout, H, W, &gm, &nb, &ns)) return 0;
+  return (size_t)ns * gm.n_cin_tiles * gm.n_cout_tiles * 16 * 16 * nb * sizeof(float);
+}
+
+extern "C" int rslo_conv1x1s2_wgrad(const float *in, const float *dout, int B, int cin, int cout, int H, int W, float *dW,
+                                    void *ws, size_t ws_bytes, void *stream) {
+  Conv2dGeom gm;
+  int nb, ns;
+  RSLO_CHECK_ARG(in && dout && dW && conv2d_plan_1x1s2(B, cin, cout, H, W, &gm, &nb, &ns),
+                 "rslo_conv1x1s2_wgrad: unsupported shape cin=%d cout=%d H=%d W=%d", cin, cout, H, W);
+  RSLO_CHECK_ARG(ws && ws_bytes >= rslo_conv1x1s2_wgrad_ws_bytes(B, cin, cout, H, W), "rslo_conv1x1s2_wgrad: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int tiles = gm.n_cin_tiles * gm.n_cout_tiles;
+  hipLaunchKernelGGL((k_conv2d_wgrad<2, 2, 1>), dim3(tiles, ns), dim3(C2_THREADS), 0, st, in, dout, gm, (float *)ws);
+  RSLO_CHECK_LAUNCH("k_conv2d_wgrad(1x1)");
+  const int64_t n = (int64_t)tiles * 16 * 16 * nb;
+  const int n_main = (int)rslo_cdiv(n, 32);
+  hipLaunchKernelGGL(k_conv2d_wgrad_reduce, dim3((unsigned)n_main), dim3(256), 0, st, (const float *)ws, ns, tiles,
+                     gm.n_cout_tiles, 16 * nb, cin, cout, dW, n_main, (const float *)nullptr, (float *)nullptr, 1);
+  RSLO_CHECK_LAUNCH("k_conv2d_wgrad_reduce(1x1)");
   return RSLO_OK;
 }
 

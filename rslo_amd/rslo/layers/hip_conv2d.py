@@ -33,6 +33,22 @@ def conv2d_wgrad_leaf(x, dy, stride, want_bias=False, lp=False):
     return streams.leaf(lambda: capi.conv2d_wgrad(x, dy, stride, lp=lp), (x, dy))
 
 
+def conv1x1s2_wgrad_leaf(x, dy, wshape):
+    """Weight gradient of a 1x1 / stride-2 downsample conv as leaf work: rslo_conv1x1s2_wgrad (the centre tap of the
+    stride-2 kernel, fixed summation order), or a batched GEMM over the sampled pixels for shapes outside its range."""
+    from rslo_amd import capi, streams
+
+    def run():
+        x_, dy_ = x.contiguous(), dy.contiguous()
+        if x_.is_cuda and x_.dtype == torch.float32 and dy_.dtype == torch.float32:
+            dw = capi.conv1x1s2_wgrad(x_, dy_)
+            if dw is not None:
+                return dw.reshape(wshape)
+        xs = x_[:, :, ::2, ::2].flatten(2)                              # [B, cin, P]
+        return torch.matmul(dy_.flatten(2), xs.transpose(1, 2)).sum(0).reshape(wshape)
+    return streams.leaf(run, (x, dy))
+
+
 def _low_precision():
     from rslo_amd import precision
     return precision.low_precision() is not None
@@ -121,8 +137,7 @@ class _Conv1x1S2Fn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = capi.conv2d_dgrad_s2(dy, ctx.ws_t, w.shape[1], x.shape[2], x.shape[3], 1)
         if ctx.needs_input_grad[1]:
-            xs = x[:, :, ::2, ::2].flatten(2)                              # [B, cin, P]
-            dw = torch.matmul(dy.flatten(2), xs.transpose(1, 2)).sum(0).reshape(w.shape)
+            dw = conv1x1s2_wgrad_leaf(x, dy, w.shape)
         return dx, dw
 
 

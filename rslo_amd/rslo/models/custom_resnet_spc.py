@@ -124,11 +124,7 @@ class _BasicBlockFn(torch.autograd.Function):
             d_od, _, dgd, dbd = fused_bn_backward(d_res, None, od, gd, md, idd, nd, 1.0, False, True, group, world)
             # the downsample branch's input gradient lands on every other pixel: joined with the 3x3 branch's in its epilogue
             dx = capi.conv2d_dgrad_s2(d_od, wdt, wd.shape[1], x.shape[2], x.shape[3], 1, residual=dx)
-
-            def ds_wgrad():
-                xs = x[:, :, ::2, ::2].flatten(2)
-                return torch.matmul(d_od.flatten(2), xs.transpose(1, 2)).sum(0).reshape(wd.shape)
-            dwd = streams.leaf(ds_wgrad, (d_od, x))
+            dwd = hip_conv2d.conv1x1s2_wgrad_leaf(x, d_od, wd.shape)
         elif not res_joined:
             dx.add_(d_res)
         return dx, dw1, dg1, db1, dw2, dg2, db2, dwd, dgd, dbd, None, None

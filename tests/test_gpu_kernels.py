@@ -945,6 +945,7 @@ def test_pose_algebra_kernels_match_kornia_restatement(hip):
     (2, 48, 64, 25, 23, 2),      # stride 2, odd input
     (2, 32, 128, 24, 44, 2),     # stride 2, even input (last input column / row never read by kx = ky = 2 ... by the pad)
     (1, 64, 64, 96, 176, 1),     # full-resolution BEV map
+    (1, 256, 128, 96, 176, 2),   # the full-resolution stride-2 layer (the library's until round 3)
 ])
 def test_conv2d_wgrad_matches_float64_oracle(hip, B, cin, cout, H, W, stride):
     """fp32 tolerance: |err| <= 2e-5 * max|dW| against the float64 restatement (the split-bf16 products are exact to
@@ -972,6 +973,28 @@ def test_conv2d_wgrad_matches_float64_oracle(hip, B, cin, cout, H, W, stride):
         assert np.array_equal(dw2.cpu().numpy().astype(np.float64), got)
         ref_b = g.astype(np.float64).sum((0, 2, 3))
         assert np.abs(db.cpu().numpy() - ref_b).max() <= 2e-5 * max(np.abs(ref_b).max(), np.sqrt(g[:, 0].size))
+
+
+@pytest.mark.parametrize("B,cin,cout,H,W", [(2, 64, 32, 12, 30), (1, 32, 64, 13, 21), (4, 256, 128, 96, 176), (2, 128, 128, 48, 88)])
+def test_conv1x1s2_wgrad_matches_float64_oracle(hip, B, cin, cout, H, W):
+    """rslo_conv1x1s2_wgrad (weight gradient of the 1x1 / stride-2 downsample layers, the centre tap of the stride-2 kernel):
+    |err| <= 2e-5 * max|dW| against float64, no further than 4x the library's fp32 result, bit-reproducible."""
+    rng = np.random.default_rng(17)
+    x = rng.standard_normal((B, cin, H, W)).astype(np.float32)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    g = rng.standard_normal((B, cout, Ho, Wo)).astype(np.float32)
+    got_t = hip.conv1x1s2_wgrad(dev(x), dev(g))
+    assert got_t is not None and tuple(got_t.shape) == (cout, cin, 1, 1)
+    got = got_t.cpu().numpy().astype(np.float64).reshape(cout, cin)
+    ref = np.einsum("bopq,bipq->oi", g.astype(np.float64), x[:, :, ::2, ::2].astype(np.float64))
+    scale = np.abs(ref).max()
+    err = np.abs(got - ref).max()
+    assert err <= 2e-5 * scale, (err, scale)
+    tw = torch.zeros((cout, cin, 1, 1), device="cuda", requires_grad=True)
+    torch.nn.functional.conv2d(dev(x), tw, None, 2, 0).backward(dev(g))
+    err_lib = np.abs(tw.grad.cpu().numpy().astype(np.float64).reshape(cout, cin) - ref).max()
+    assert err <= 4 * err_lib + 1e-6 * scale, (err, err_lib)
+    assert torch.equal(hip.conv1x1s2_wgrad(dev(x), dev(g)), got_t)
 
 
 def test_hip_conv2d_module_gradients_match_library(hip):
