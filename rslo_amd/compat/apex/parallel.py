@@ -64,6 +64,27 @@ def _world(group):
     return dist.get_world_size(group) if group is not None else dist.get_world_size()
 
 
+_HP_GROUP = {"tried": False, "group": None}
+
+
+def exchange_group(group):
+    """The process group the SyncBN statistics exchanges run on.  A step issues ~90 of them (one per normalisation layer
+    and direction), each a latency-bound all-reduce of a few hundred bytes between two dependent kernels while three other
+    HIP streams (structure plan, covariance branch, weight gradients) keep the GPU's queues busy.  With the default group
+    (`process_group=None`, what convert_syncbn_model passes) and the NCCL / RCCL backend they go to a dedicated group whose
+    communication stream has HIGH priority, so the exchange kernel is not queued behind the side streams' work; the group
+    is created on first use (a collective call: every rank reaches its first SyncBN forward at the same point).
+    RSLO_SYNCBN_HP_GROUP=0, another backend, or an explicit process_group: unchanged."""
+    if group is not None or os.environ.get("RSLO_SYNCBN_HP_GROUP", "1") == "0":
+        return group
+    if not _HP_GROUP["tried"]:
+        _HP_GROUP["tried"] = True
+        if dist.get_backend() == "nccl":
+            opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+            _HP_GROUP["group"] = dist.new_group(backend="nccl", pg_options=opts)
+    return _HP_GROUP["group"]
+
+
 def fused_bn_forward(bn, x, res, weight, bias, slope, group, world):
     """y = act(BN_train(x) + res) through rslo_bn2d_* (x, res contiguous).  -> y, mean, invstd, cnt_all (the element
     count over all ranks as a device scalar; None on one rank).  Updates bn's running statistics."""
@@ -72,7 +93,7 @@ def fused_bn_forward(bn, x, res, weight, bias, slope, group, world):
     mom = bn.momentum          # fusable() leaves momentum=None (cumulative average) to the unfused path
     if world > 1:
         stats = capi.bn2d_stats(x)
-        dist.all_reduce(stats, group=group)
+        dist.all_reduce(stats, group=exchange_group(group))
         y, mean, invstd = capi.bn2d_apply(x, res, stats, weight, bias, bn.running_mean if track else None,
                                           bn.running_var if track else None, mom, bn.eps, slope)
         return y, mean, invstd, stats[-1:]        # ranks may hold different batch sizes: the all-reduced count
@@ -89,7 +110,7 @@ def fused_bn_backward(gy, y, x, weight, mean, invstd, cnt_all, slope, has_res, a
     if world == 1:
         return capi.bn2d_bwd_local(gy, y, x, weight, mean, invstd, slope, has_act, has_res, want_affine=affine)
     red, dgamma, dbeta = capi.bn2d_bwd_reduce(gy, y, x, mean, invstd, slope, has_act, want_affine=affine)
-    dist.all_reduce(red, group=group)
+    dist.all_reduce(red, group=exchange_group(group))
     # the count all-reduced in the forward pass, read on the device: exact for uneven per-rank batches, no host sync
     dx, dres = capi.bn2d_bwd_apply(gy, y, x, weight, mean, invstd, red, 0.0, slope, has_act, has_res, count_dev=cnt_all)
     return dx, dres, dgamma, dbeta

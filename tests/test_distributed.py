@@ -337,3 +337,46 @@ def test_overlapped_exchange_is_rank_symmetric_when_one_rank_skips_part_of_the_e
     assert [f for f, _, _ in res[0][1]] == [False, True, True, True]
     assert [f for f, _, _ in res[1][1]] == [False, True, False, True]
     assert [g for _, _, g in res[0][1]] == [g for _, _, g in res[1][1]]
+
+
+def test_syncbn_exchange_group_is_unchanged_off_nccl():
+    """exchange_group(): explicit groups and non-NCCL backends pass through (the gloo tests above run on the default group)."""
+    import socket
+    import torch.distributed as dist
+    from apex import parallel
+    if not hasattr(parallel, "exchange_group"):
+        pytest.skip("real apex installed")
+    sentinel = object()
+    assert parallel.exchange_group(sentinel) is sentinel
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group("gloo", rank=0, world_size=1, init_method="tcp://127.0.0.1:%d" % port)
+    try:
+        parallel._HP_GROUP.update(tried=False, group=None)
+        assert parallel.exchange_group(None) is None
+    finally:
+        parallel._HP_GROUP.update(tried=False, group=None)
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_syncbn_exchange_group_on_rccl_single_rank():
+    """On the NCCL / RCCL backend the SyncBN exchanges get their own high-priority group (created on first use) and an
+    all-reduce through it works; run in a child process (its own process-group state).  Multi-rank behaviour is the
+    backend's: no second GPU on the test box."""
+    import subprocess, sys
+    code = (
+        "import os, sys, socket; sys.path.insert(0, %r); import torch, rslo_amd; import torch.distributed as dist\n"
+        "from apex import parallel\n"
+        "s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', rank=0, world_size=1, init_method='tcp://127.0.0.1:%%d' %% port)\n"
+        "g = parallel.exchange_group(None)\n"
+        "assert g is not None and g is not dist.group.WORLD and parallel.exchange_group(None) is g\n"
+        "t = torch.arange(8, dtype=torch.float64, device='cuda'); dist.all_reduce(t, group=g); torch.cuda.synchronize()\n"
+        "assert t.tolist() == list(range(8)); dist.destroy_process_group(); print('ok')\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
