@@ -18,5 +18,6 @@ cp $G/${R}_kernel_stats.csv $P/${R}_kernel_stats.csv
 cp $G/prof_${R}_last_step.txt $P/${R}_step_breakdown.txt
 cp $G/prof_${R}fix_last_step.txt $P/${R}_step_breakdown_fixed_plan.txt
 for f in pmc_mfma_busy pmc_sq_waits pmc_traffic_bench; do cp $G/${R}_$f.json $P/${R}_$f.json; done
+for f in timeline_gaps.txt torch_launch_sites.txt nccl_n1.log; do [ -f $G/${R}_$f ] && cp $G/${R}_$f $P/${R}_$f; done
 for f in encoder_c2 encoder_c5; do [ -f $G/${R}_$f.json ] && cp $G/${R}_$f.json $P/${R}_$f.json; done
 grep -h lib_sha256 $P/${R}_pmc_*.json | sort | uniq -c
