@@ -380,10 +380,12 @@ RSLO_API int rslo_bev_channel_sums(const float *in, int B, int G, int Cg, int64_
  *     rslo/layers/confidence.py:26-34): mask_f [B,HW] float 0/1, mask_b [B,HW] bytes 0/1, outside_b = !mask_b.  Any may be NULL. */
 RSLO_API int rslo_bev_channel_sums_masks(const float *in, int B, int G, int Cg, int64_t HW, float *out, float *mask_f,
                                          unsigned char *mask_b, unsigned char *outside_b, void *stream);
-/*     The logged extras from those sums [B,T,HW] in one launch (voxel_odom_net.py:455-464): mask [B,HW] = (sum over t) != 0;
+/*     The logged extras from those sums [B,T,HW] in two launches (voxel_odom_net.py:455-464; ws: rslo_bev_display_ws_bytes(T) bytes of partial extrema): mask [B,HW] = (sum over t) != 0;
  *     disp [T,B,HW] = the per-frame channel mean sums / Cg, min-max normalised over the frame's batch
  *     ((d - min) / (max - min + 1e-12)) -- `middle_feature` and `feature_mask` of the training forward. */
-RSLO_API int rslo_bev_display(const float *sums, int B, int T, int Cg, int64_t HW, float *mask, float *disp, void *stream);
+RSLO_API size_t rslo_bev_display_ws_bytes(int T);
+RSLO_API int rslo_bev_display(const float *sums, int B, int T, int Cg, int64_t HW, float *mask, float *disp, void *ws,
+                              size_t ws_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * a17  Chamfer nearest neighbour.  Replaces cd.forward_cuda_one_direction /

@@ -119,7 +119,8 @@ SIGNATURES = {
     "rslo_bev_channel_sums_masks": (C.c_int, [_vp, _i, _i, _i, C.c_int64, _vp, _vp, _vp, _vp, _vp]),
     "rslo_pose_tail_fwd": (C.c_int, [_vp, _i, _vp, _vp, _vp]),
     "rslo_pose_tail_bwd": (C.c_int, [_vp, _vp, _vp, _i, _vp, _vp]),
-    "rslo_bev_display": (C.c_int, [_vp, _i, _i, _i, C.c_int64, _vp, _vp, _vp]),
+    "rslo_bev_display_ws_bytes": (_sz, [_i]),
+    "rslo_bev_display": (C.c_int, [_vp, _i, _i, _i, C.c_int64, _vp, _vp, _vp, _sz, _vp]),
     "rslo_conv2d_dgrad_s2_add": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "rslo_conv2d_fwd_add": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "rslo_conv2d_fwd_add_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
@@ -730,12 +731,14 @@ def cat_upsample_bwd(grad, Ca, Cb, scale, need_a=True, need_b=True):
 
 def bev_display(sums, channels):
     """sums [B, T, H, W] from bev_channel_sums over `channels` channels per frame -> (feature_mask [B,1,H,W],
-    [middle_feature_t [B,1,H,W] for t]) in one launch (see rslo_bev_display)."""
+    [middle_feature_t [B,1,H,W] for t]) in two launches (see rslo_bev_display)."""
     B, T, H, W = sums.shape
     mask = torch.empty((B, 1, H, W), dtype=torch.float32, device=sums.device)
     disp = torch.empty((T, B, 1, H, W), dtype=torch.float32, device=sums.device)
+    wsb = lib().rslo_bev_display_ws_bytes(T)
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=sums.device)
     _chk(lib().rslo_bev_display(_ptr(sums, torch.float32, "sums"), B, T, int(channels), H * W, _ptr(mask), _ptr(disp),
-                                _stream()), "rslo_bev_display")
+                                ws.data_ptr(), wsb, _stream()), "rslo_bev_display")
     return mask, list(disp.unbind(0))
 
 

@@ -798,7 +798,15 @@ __global__ void k_bev_channel_sums(const float *__restrict__ in, int G, int Cg, 
   const int g = blockIdx.y, b = blockIdx.z;
   const float *src = in + ((int64_t)(b * G + g) * Cg) * HW + p;
   float s = 0.f;
-  for (int c = 0; c < Cg; ++c) s = __fadd_rn(s, src[(int64_t)c * HW]);
+  int c = 0;
+  for (; c + 8 <= Cg; c += 8) {      // 8 independent loads in flight, added in channel order
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(c + u) * HW];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s = __fadd_rn(s, v[u]);
+  }
+  for (; c < Cg; ++c) s = __fadd_rn(s, src[(int64_t)c * HW]);
   out[(int64_t)(b * G + g) * HW + p] = s;
   if (g == 0) {       // occupancy of the first frame of the pair: the head's input mask
     const bool occ = s != 0.f;
@@ -827,19 +835,21 @@ extern "C" int rslo_bev_channel_sums(const float *in, int B, int G, int Cg, int6
 //   mask[b][p]    = (sum_t sums[b][t][p]) != 0
 //   disp[t][b][p] = (d - min d) / (max d - min d + 1e-12),  d = sums[b][t][p] * (1 / Cg)  (min / max over the frame's
 //                   whole batch), the arithmetic torch does for `mean -> (x - x.min()) / (x.max() - x.min() + 1e-12)`
-// One workgroup per frame t (two passes over 67 k values from L2): one launch instead of ~17 reductions / element-wise ops.
-#define BD_THREADS 1024
-__global__ __launch_bounds__(BD_THREADS) void k_bev_display(const float *__restrict__ sums, int B, int T, int64_t HW,
-                                                            float inv_c, float *__restrict__ mask,
-                                                            float *__restrict__ disp) {
+// Two launches instead of ~17 reductions / element-wise ops: BD_PARTS workgroups per frame leave partial extrema, the
+// apply launch folds them (64 values) and writes the maps.  (One workgroup per frame doing both passes was a 94 us
+// latency chain on the training stream.)
+#define BD_THREADS 256
+#define BD_PARTS 64
+__global__ __launch_bounds__(BD_THREADS) void k_bev_display_minmax(const float *__restrict__ sums, int B, int T, int64_t HW,
+                                                                   float inv_c, float *__restrict__ part) {
   // plain operators under the pragma: the __f*_rn device functions are inlined from the HIP headers WITH their
-  // contraction flags (the product below fused into the subtraction: min d - min d != 0)
+  // contraction flags
 #pragma clang fp contract(off)
   __shared__ float s_mn[BD_THREADS / 64], s_mx[BD_THREADS / 64];
-  const int t = blockIdx.x, tid = threadIdx.x;
+  const int t = blockIdx.y, tid = threadIdx.x;
   const int64_t n = (int64_t)B * HW;
   float mn = INFINITY, mx = -INFINITY;
-  for (int64_t i = tid; i < n; i += BD_THREADS) {
+  for (int64_t i = (int64_t)blockIdx.x * BD_THREADS + tid; i < n; i += (int64_t)BD_PARTS * BD_THREADS) {
     const int64_t b = i / HW, p = i - b * HW;
     const float d = sums[(b * T + t) * HW + p] * inv_c;
     mn = fminf(mn, d);
@@ -851,26 +861,50 @@ __global__ __launch_bounds__(BD_THREADS) void k_bev_display(const float *__restr
   }
   if ((tid & 63) == 0) { s_mn[tid >> 6] = mn; s_mx[tid >> 6] = mx; }
   __syncthreads();
-  mn = s_mn[0]; mx = s_mx[0];
-  for (int w = 1; w < BD_THREADS / 64; ++w) { mn = fminf(mn, s_mn[w]); mx = fmaxf(mx, s_mx[w]); }
-  const float den = (mx - mn) + 1e-12f;
-  for (int64_t i = tid; i < n; i += BD_THREADS) {
-    const int64_t b = i / HW, p = i - b * HW;
-    const float d = sums[(b * T + t) * HW + p] * inv_c;
-    disp[(int64_t)t * n + i] = (d - mn) / den;
-    if ((i / BD_THREADS) % T == t) {      // the mask's cells are dealt to the T workgroups
-      float s = 0.f;
-      for (int u = 0; u < T; ++u) s = s + sums[(b * T + u) * HW + p];
-      mask[i] = s != 0.f ? 1.f : 0.f;
-    }
+  if (tid == 0) {
+    for (int w = 1; w < BD_THREADS / 64; ++w) { mn = fminf(mn, s_mn[w]); mx = fmaxf(mx, s_mx[w]); }
+    part[(t * BD_PARTS + blockIdx.x) * 2] = mn;
+    part[(t * BD_PARTS + blockIdx.x) * 2 + 1] = mx;
   }
 }
 
-extern "C" int rslo_bev_display(const float *sums, int B, int T, int Cg, int64_t HW, float *mask, float *disp, void *stream) {
-  RSLO_CHECK_ARG(sums && mask && disp && B >= 1 && T >= 1 && T < 65536 && Cg >= 1 && HW >= 1, "rslo_bev_display: bad arguments");
-  hipLaunchKernelGGL(k_bev_display, dim3((unsigned)T), dim3(BD_THREADS), 0, (hipStream_t)stream, sums, B, T, HW,
-                     1.0f / (float)Cg, mask, disp);
-  RSLO_CHECK_LAUNCH("k_bev_display");
+__global__ __launch_bounds__(BD_THREADS) void k_bev_display_apply(const float *__restrict__ sums, int B, int T, int64_t HW,
+                                                                  float inv_c, const float *__restrict__ part,
+                                                                  float *__restrict__ mask, float *__restrict__ disp) {
+#pragma clang fp contract(off)
+  const int t = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+  float mn = part[(t * BD_PARTS + lane) * 2], mx = part[(t * BD_PARTS + lane) * 2 + 1];      // BD_PARTS = 64 = one wave
+  for (int o = 32; o > 0; o >>= 1) {
+    mn = fminf(mn, __shfl_xor(mn, o));
+    mx = fmaxf(mx, __shfl_xor(mx, o));
+  }
+  const float den = (mx - mn) + 1e-12f;
+  const int64_t n = (int64_t)B * HW;
+  const int64_t i = (int64_t)blockIdx.x * BD_THREADS + tid;
+  if (i >= n) return;
+  const int64_t b = i / HW, p = i - b * HW;
+  const float d = sums[(b * T + t) * HW + p] * inv_c;
+  disp[(int64_t)t * n + i] = (d - mn) / den;
+  if (t == 0) {
+    float s = 0.f;
+    for (int u = 0; u < T; ++u) s = s + sums[(b * T + u) * HW + p];
+    mask[i] = s != 0.f ? 1.f : 0.f;
+  }
+}
+
+extern "C" size_t rslo_bev_display_ws_bytes(int T) { return (size_t)(T > 0 ? T : 1) * BD_PARTS * 2 * sizeof(float); }
+
+extern "C" int rslo_bev_display(const float *sums, int B, int T, int Cg, int64_t HW, float *mask, float *disp, void *ws,
+                                size_t ws_bytes, void *stream) {
+  RSLO_CHECK_ARG(sums && mask && disp && ws && B >= 1 && T >= 1 && T < 65536 && Cg >= 1 && HW >= 1, "rslo_bev_display: bad arguments");
+  RSLO_CHECK_ARG(ws_bytes >= rslo_bev_display_ws_bytes(T), "rslo_bev_display: workspace too small");
+  const float inv_c = 1.0f / (float)Cg;
+  hipLaunchKernelGGL(k_bev_display_minmax, dim3(BD_PARTS, (unsigned)T), dim3(BD_THREADS), 0, (hipStream_t)stream, sums, B, T,
+                     HW, inv_c, (float *)ws);
+  RSLO_CHECK_LAUNCH("k_bev_display_minmax");
+  hipLaunchKernelGGL(k_bev_display_apply, dim3((unsigned)rslo_cdiv((int64_t)B * HW, BD_THREADS), (unsigned)T),
+                     dim3(BD_THREADS), 0, (hipStream_t)stream, sums, B, T, HW, inv_c, (const float *)ws, mask, disp);
+  RSLO_CHECK_LAUNCH("k_bev_display_apply");
   return RSLO_OK;
 }
 

@@ -317,7 +317,7 @@ class UnVoxelOdomNetICP3(nn.Module):
         with torch.no_grad():
             sums = preds_dict.pop("_bev_sums", None)       # [B, T, H, W] per-frame channel sums the head already made
             if sums is not None and os.environ.get("RSLO_BEV_DISPLAY", "1") != "0":
-                from rslo_amd import capi       # mask + both normalised maps in one launch (same bits as the lines below)
+                from rslo_amd import capi       # mask + both normalised maps in two launches (same bits as the lines below)
                 preds_dict["feature_mask"], preds_dict["middle_feature"] = capi.bev_display(
                     sums, spatial_features[0].shape[1])
             else:

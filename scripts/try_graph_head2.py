@@ -30,6 +30,15 @@ with torch.cuda.stream(s):
 torch.cuda.current_stream().wait_stream(s)
 torch.cuda.synchronize()
 print("warmup done", flush=True)
+if stage != "fwd":      # the same work issued eagerly (what the step does today)
+    def eager():
+        head.zero_grad(set_to_none=True)
+        for x in xs: x.grad = None
+        outs = fwd(); loss = sum((o ** 2).mean() for o in outs if o.requires_grad); loss.backward()
+    for _ in range(3): eager()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(10): eager()
+    torch.cuda.synchronize(); print("eager %.2f ms" % ((time.perf_counter() - t0) / 10 * 1e3), flush=True)
 g = torch.cuda.CUDAGraph()
 if stage == "fwd":
     with torch.no_grad():
