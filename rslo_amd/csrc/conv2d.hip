@@ -1358,7 +1358,18 @@ __global__ __launch_bounds__(256) void k_conv1x1_fwd(const float *__restrict__ x
 #pragma unroll
   for (int co = 0; co < C11_MAXCO; ++co) acc[co] = (bias && co < cout) ? bias[co] : 0.f;
   const float *xp = x + (int64_t)b * cin * HW + p;
-  for (int ci = 0; ci < cin; ++ci) {
+  int ci = 0;
+  for (; ci + 8 <= cin; ci += 8) {      // 8 channel loads in flight (a serial chain of cin loads was 34 us on a 24x44 map),
+    float xv[8];                         // accumulated in channel order: same bits
+#pragma unroll
+    for (int u = 0; u < 8; ++u) xv[u] = xp[(int64_t)(ci + u) * HW];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int co = 0; co < C11_MAXCO; ++co)
+        if (co < cout) acc[co] += w[co * cin + ci + u] * xv[u];
+  }
+  for (; ci < cin; ++ci) {
     const float xv = xp[(int64_t)ci * HW];
 #pragma unroll
     for (int co = 0; co < C11_MAXCO; ++co)
