@@ -52,6 +52,8 @@ def get_odom_class(name):
 
 
 class UNOdomPredEncDecSVDTempMaskBase(OdomPredEncDecBase):
+    consumes_presplit_event = True      # _forward waits for hip_conv2d.presplit_early's event instead of splitting itself
+
     def __init__(self, use_svd=True, *args, **kwargs):
         super().__init__(*args, **kwargs)
         self.use_svd = use_svd
@@ -87,7 +89,11 @@ class UNOdomPredEncDecSVDTempMaskBase(OdomPredEncDecBase):
         if not isinstance(xs, list):
             xs = [xs]
         if xs[0].is_cuda and self.training and torch.is_grad_enabled():
-            hip_conv2d.presplit(self)       # split-bf16 operands of all 3x3 layers for this step, one launch
+            ev = self.__dict__.pop("_presplit_event", None)      # issued at the start of the network forward, on a side stream
+            if ev is not None:
+                torch.cuda.current_stream(xs[0].device).wait_event(ev)
+            else:
+                hip_conv2d.presplit(self)       # split-bf16 operands of all 3x3 layers for this step, one launch
         if self._cycle_constraint:
             xs = self.create_cycle_constraint_data(xs)
         # two frames whose maps are channel slices of ONE tensor (voxel_odom_net.network_forward / rslo_dense_scatter_frames):
