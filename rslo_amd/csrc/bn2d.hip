@@ -9,6 +9,8 @@
 // and across ranks ONE small collective per direction instead of torch SyncBatchNorm's gather / reduce sequences.
 // Sums are accumulated in double; partial sums are added in block order by the last block of a channel: deterministic.
 // HBM-bound elementwise work: forward reads x twice (+ residual) and writes y; backward reads dy, y, x twice, writes dx.
+#include <stdlib.h>
+
 #include "rslo_common.h"
 
 #define BN_THREADS 256
@@ -392,6 +394,107 @@ __global__ __launch_bounds__(T) void k_bn2d_bwd_small(const float *__restrict__ 
   }
 }
 
+// Register-cached forms for channels of at most 8 T elements (the 24x44 and 12x22 maps at bs 4: 4.1 elements per thread):
+// every element is loaded ONCE, all of a thread's loads are in flight together, and the second pass works from
+// registers -- the two-pass loops above are two serial rounds of dependent-latency loads (12.5 us per launch for 17 KB
+// per channel).  Element e = tid + i T of the channel's N * HW values (n = e / HW).
+#define BN_RC 8
+template <int T>
+__global__ __launch_bounds__(T) void k_bn2d_fwd_small_rc(const float *__restrict__ x, const float *__restrict__ res,
+                                                         const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                         int N, int C, int HW, float eps, float momentum, float slope,
+                                                         float *__restrict__ run_mean, float *__restrict__ run_var,
+                                                         float *__restrict__ save_mean, float *__restrict__ save_invstd,
+                                                         float *__restrict__ y) {
+  const int c = blockIdx.x, total = N * HW;
+  float v[BN_RC], r[BN_RC];
+  int64_t off[BN_RC];
+#pragma unroll
+  for (int i = 0; i < BN_RC; ++i) {
+    const int e = threadIdx.x + i * T;
+    const int n = e / HW, k = e - n * HW;
+    off[i] = e < total ? ((int64_t)n * C + c) * HW + k : -1;
+    v[i] = off[i] >= 0 ? x[off[i]] : 0.f;
+    r[i] = (res && off[i] >= 0) ? res[off[i]] : 0.f;
+  }
+  double s = 0.0, q = 0.0;
+#pragma unroll
+  for (int i = 0; i < BN_RC; ++i) {
+    s += v[i];
+    q += (double)v[i] * v[i];
+  }
+  __shared__ double tot[2];
+  bn_block_sum2_t<T>(s, q, tot);
+  const double cnt = (double)N * HW;
+  const double m = tot[0] / cnt;
+  double var = tot[1] / cnt - m * m;
+  var = var > 0.0 ? var : 0.0;
+  const float mean = (float)m, invstd = (float)(1.0 / sqrt(var + (double)eps));
+  if (threadIdx.x == 0) {
+    save_mean[c] = mean;
+    save_invstd[c] = invstd;
+    if (run_mean) {
+      const double unbiased = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
+      run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mean;
+      run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)unbiased;
+    }
+  }
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  const float a1 = g * invstd, a0 = b - mean * a1;
+#pragma unroll
+  for (int i = 0; i < BN_RC; ++i) {
+    if (off[i] < 0) continue;
+    const float o = v[i] * a1 + a0 + r[i];
+    y[off[i]] = o > 0.f ? o : o * slope;
+  }
+}
+
+template <int T>
+__global__ __launch_bounds__(T) void k_bn2d_bwd_small_rc(const float *__restrict__ dy, const float *__restrict__ y,
+                                                         const float *__restrict__ x, const float *__restrict__ gamma,
+                                                         const float *__restrict__ save_mean,
+                                                         const float *__restrict__ save_invstd, int N, int C, int HW,
+                                                         float slope, int has_act, float *__restrict__ dx,
+                                                         float *__restrict__ dres, float *__restrict__ dgamma,
+                                                         float *__restrict__ dbeta) {
+  const int c = blockIdx.x, total = N * HW;
+  const float mean = save_mean[c], invstd = save_invstd[c];
+  float g[BN_RC], xh[BN_RC];
+  int64_t off[BN_RC];
+#pragma unroll
+  for (int i = 0; i < BN_RC; ++i) {
+    const int e = threadIdx.x + i * T;
+    const int n = e / HW, k = e - n * HW;
+    off[i] = e < total ? ((int64_t)n * C + c) * HW + k : -1;
+    const float gv = off[i] >= 0 ? dy[off[i]] : 0.f;
+    const float yv = (has_act && off[i] >= 0) ? y[off[i]] : 1.f;
+    const float xv = off[i] >= 0 ? x[off[i]] : mean;
+    g[i] = yv > 0.f ? gv : gv * slope;
+    xh[i] = (xv - mean) * invstd;
+  }
+  double s = 0.0, q = 0.0;
+#pragma unroll
+  for (int i = 0; i < BN_RC; ++i) {
+    s += g[i];
+    q += (double)g[i] * (double)xh[i];
+  }
+  __shared__ double tot[2];
+  bn_block_sum2_t<T>(s, q, tot);
+  if (threadIdx.x == 0) {
+    if (dbeta) dbeta[c] = (float)tot[0];
+    if (dgamma) dgamma[c] = (float)tot[1];
+  }
+  const double cnt = (double)N * HW;
+  const float k0 = (gamma ? gamma[c] : 1.f) * invstd;
+  const float mg = (float)(tot[0] / cnt), mgx = (float)(tot[1] / cnt);
+#pragma unroll
+  for (int i = 0; i < BN_RC; ++i) {
+    if (off[i] < 0) continue;
+    dx[off[i]] = k0 * (g[i] - mg - xh[i] * mgx);
+    if (dres) dres[off[i]] = g[i];
+  }
+}
+
 // multi-rank forms of the small maps: the channel's sums go straight into the tensor that is all-reduced (no slice
 // partials, no finish launch)
 template <int T>
@@ -504,7 +607,14 @@ extern "C" int rslo_bn2d_fwd_local(const float *x, const float *res, const float
   RSLO_CHECK_ARG(x && ws && save_mean && save_invstd && y && N >= 1 && C >= 1 && HW >= 1, "rslo_bn2d_fwd_local: bad arguments");
   RSLO_CHECK_ARG(ws_bytes >= rslo_bn2d_ws_bytes(N, C, HW), "rslo_bn2d_fwd_local: workspace too small");
   if ((int64_t)N * HW <= BN_SMALL_MAX) {
-    if (HW <= 1024)
+    static const int rc = getenv("RSLO_BN_SMALL_RC") ? atoi(getenv("RSLO_BN_SMALL_RC")) : 1;      // 0: the two-pass loops
+    if (rc && (int64_t)N * HW <= 256 * BN_RC)
+      hipLaunchKernelGGL((k_bn2d_fwd_small_rc<256>), dim3(C), dim3(256), 0, (hipStream_t)stream, x, res, gamma, beta, N, C,
+                         HW, eps, momentum, act_slope, running_mean, running_var, save_mean, save_invstd, y);
+    else if (rc && (int64_t)N * HW <= 1024 * BN_RC)
+      hipLaunchKernelGGL((k_bn2d_fwd_small_rc<1024>), dim3(C), dim3(1024), 0, (hipStream_t)stream, x, res, gamma, beta, N, C,
+                         HW, eps, momentum, act_slope, running_mean, running_var, save_mean, save_invstd, y);
+    else if (HW <= 1024)
       hipLaunchKernelGGL((k_bn2d_fwd_small<256>), dim3(C), dim3(256), 0, (hipStream_t)stream, x, res, gamma, beta, N, C, HW,
                          eps, momentum, act_slope, running_mean, running_var, save_mean, save_invstd, y);
     else
@@ -534,7 +644,14 @@ extern "C" int rslo_bn2d_bwd_local(const float *dy, const float *y, const float 
   RSLO_CHECK_ARG(!has_act || y, "rslo_bn2d_bwd_local: y is needed for the activation mask");
   RSLO_CHECK_ARG(ws_bytes >= rslo_bn2d_ws_bytes(N, C, HW), "rslo_bn2d_bwd_local: workspace too small");
   if ((int64_t)N * HW <= BN_SMALL_MAX) {
-    if (HW <= 1024)
+    static const int rc = getenv("RSLO_BN_SMALL_RC") ? atoi(getenv("RSLO_BN_SMALL_RC")) : 1;
+    if (rc && (int64_t)N * HW <= 256 * BN_RC)
+      hipLaunchKernelGGL((k_bn2d_bwd_small_rc<256>), dim3(C), dim3(256), 0, (hipStream_t)stream, dy, y, x, gamma, save_mean,
+                         save_invstd, N, C, HW, act_slope, has_act, dx, dres, dgamma, dbeta);
+    else if (rc && (int64_t)N * HW <= 1024 * BN_RC)
+      hipLaunchKernelGGL((k_bn2d_bwd_small_rc<1024>), dim3(C), dim3(1024), 0, (hipStream_t)stream, dy, y, x, gamma, save_mean,
+                         save_invstd, N, C, HW, act_slope, has_act, dx, dres, dgamma, dbeta);
+    else if (HW <= 1024)
       hipLaunchKernelGGL((k_bn2d_bwd_small<256>), dim3(C), dim3(256), 0, (hipStream_t)stream, dy, y, x, gamma, save_mean,
                          save_invstd, N, C, HW, act_slope, has_act, dx, dres, dgamma, dbeta);
     else
