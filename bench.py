@@ -21,6 +21,11 @@ import os
 import sys
 import time
 
+# The step keeps five HIP streams busy (training, structure plan, covariance branch, weight gradients, RCCL): with the
+# runtime's default of 4 hardware queues two of them share a queue and serialise -- a sixth stream put the training
+# stream behind a side stream for a 23 ms step.  Must be set before the HIP runtime starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 import torch
 

@@ -74,8 +74,11 @@ def exchange_group(group):
     (`process_group=None`, what convert_syncbn_model passes) and the NCCL / RCCL backend they go to a dedicated group whose
     communication stream has HIGH priority, so the exchange kernel is not queued behind the side streams' work; the group
     is created on first use (a collective call: every rank reaches its first SyncBN forward at the same point).
-    RSLO_SYNCBN_HP_GROUP=0, another backend, or an explicit process_group: unchanged."""
-    if group is not None or os.environ.get("RSLO_SYNCBN_HP_GROUP", "1") == "0":
+    OPT-IN (RSLO_SYNCBN_HP_GROUP=1): a second communicator is one more HIP stream, and the step already runs five on
+    the runtime's 4-8 hardware queues -- one stream too many measurably serialises the training stream behind a side
+    stream (23 ms instead of 12 ms per step on one GPU), and this cannot be checked at N > 1 on a one-GPU box.
+    Default, another backend, or an explicit process_group: unchanged."""
+    if group is not None or os.environ.get("RSLO_SYNCBN_HP_GROUP", "0") != "1":
         return group
     if not _HP_GROUP["tried"]:
         _HP_GROUP["tried"] = True

@@ -186,20 +186,16 @@ def presplit(root):
         w._hip_split = (f, t, w._version, w.data_ptr())
 
 
-_PRESPLIT_STREAMS = {}
-
-
-def presplit_early(root, device):
-    """presplit(root) on a side stream, ordered behind everything issued so far (the optimizer step that changed the
+def presplit_early(root, device, side):
+    """presplit(root) on the side stream `side`, ordered behind everything issued so far (the optimizer step that changed the
     weights, the previous backward's readers of the operands).  The caller's stream waits for the returned event right
     before the first layer that uses the operands: the split (103 us for the BEV head: 190 MB) then runs beside the sparse
     encoder's forward instead of in front of the head.  RSLO_PRESPLIT_EARLY=0: not used."""
     if (os.environ.get("RSLO_PRESPLIT_EARLY", "1") == "0" or torch.device(device).type != "cuda"
             or not getattr(root, "consumes_presplit_event", False)):      # only heads whose forward waits for the event
         return None
-    side = _PRESPLIT_STREAMS.get(device)
-    if side is None:
-        side = _PRESPLIT_STREAMS[device] = torch.cuda.Stream(device)
+    # `side`: a stream the caller already owns.  NOT a new one: HIP maps streams onto a few hardware queues, and one more
+    # stream put the training stream on a queue with a busy side stream in the distributed step (23 ms instead of 12)
     side.wait_stream(torch.cuda.current_stream(device))
     with torch.cuda.stream(side):
         presplit(root)

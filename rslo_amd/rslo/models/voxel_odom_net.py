@@ -358,7 +358,11 @@ class UnVoxelOdomNetICP3(nn.Module):
                 _LEAD_WAIT[0] += time.perf_counter() - t0
         if self.training and torch.is_grad_enabled() and voxels[0].is_cuda:
             from rslo.layers import hip_conv2d      # the head's weight operands: split beside the encoder's forward
-            hip_conv2d.presplit_early(self.odom_predictor, voxels[0].device)
+            dev_ = voxels[0].device
+            side_ = _SIDE_STREAMS.get(dev_)          # the covariance branch's stream (idle until the head starts)
+            if side_ is None:
+                side_ = _SIDE_STREAMS[dev_] = torch.cuda.Stream(dev_)
+            hip_conv2d.presplit_early(self.odom_predictor, dev_, side_)
         # one multi-tensor add for the num_batches_tracked buffers of every normalisation layer (ROCm apex stand-in only)
         with getattr(_apex_parallel, "defer_batch_counts", contextlib.nullcontext)():
             preds_dict = self.network_forward(voxels, num_points, coors, batch_size_dev, example=example)

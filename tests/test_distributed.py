@@ -362,7 +362,7 @@ def test_syncbn_exchange_group_is_unchanged_off_nccl():
 
 @pytest.mark.gpu
 def test_syncbn_exchange_group_on_rccl_single_rank():
-    """On the NCCL / RCCL backend the SyncBN exchanges get their own high-priority group (created on first use) and an
+    """With RSLO_SYNCBN_HP_GROUP=1 on the NCCL / RCCL backend the SyncBN exchanges get their own high-priority group and an
     all-reduce through it works; run in a child process (its own process-group state).  Multi-rank behaviour is the
     backend's: no second GPU on the test box."""
     import subprocess, sys
@@ -378,5 +378,5 @@ def test_syncbn_exchange_group_on_rccl_single_rank():
         "assert t.tolist() == list(range(8)); dist.destroy_process_group(); print('ok')\n"
     ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
-                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", RSLO_SYNCBN_HP_GROUP="1"))
     assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
