@@ -24,7 +24,8 @@ import time
 # The step keeps five HIP streams busy (training, structure plan, covariance branch, weight gradients, RCCL): with the
 # runtime's default of 4 hardware queues two of them share a queue and serialise -- a sixth stream put the training
 # stream behind a side stream for a 23 ms step.  Must be set before the HIP runtime starts.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+if os.environ.get("RSLO_BENCH_ONE_GPU", "0") != "1":      # (two ranks sharing ONE GPU would oversubscribe its queues: 192 vs 53 ms)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np
 import torch
