@@ -283,7 +283,7 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn2d_bwd_apply(const float *__re
 // One block owns a channel: pass 1 accumulates the sums (double, fixed order), pass 2 re-reads the (cache-resident)
 // rows and applies.  One launch per direction instead of two: on this path the step is bound by kernel-launch cost on
 // the host (~7 us per launch), not by the 5 us these kernels run.
-#define BN_SMALL_MAX 9000
+#define BN_SMALL_MAX 17408      /* 17 x 1024: the 48x88 maps at bs 4 (16896 values per channel) included */
 
 template <int T>
 __device__ __forceinline__ void bn_block_sum2_t(double a, double b, double *out2) {
@@ -399,7 +399,8 @@ __global__ __launch_bounds__(T) void k_bn2d_bwd_small(const float *__restrict__ 
 // registers -- the two-pass loops above are two serial rounds of dependent-latency loads (12.5 us per launch for 17 KB
 // per channel).  Element e = tid + i T of the channel's N * HW values (n = e / HW).
 #define BN_RC 8
-template <int T>
+#define BN_RC_BIG 17     /* T = 1024: channels of up to 17408 values (48x88 at bs 4) in one launch instead of reduce + apply */
+template <int T, int E = BN_RC>
 __global__ __launch_bounds__(T) void k_bn2d_fwd_small_rc(const float *__restrict__ x, const float *__restrict__ res,
                                                          const float *__restrict__ gamma, const float *__restrict__ beta,
                                                          int N, int C, int HW, float eps, float momentum, float slope,
@@ -407,10 +408,10 @@ __global__ __launch_bounds__(T) void k_bn2d_fwd_small_rc(const float *__restrict
                                                          float *__restrict__ save_mean, float *__restrict__ save_invstd,
                                                          float *__restrict__ y) {
   const int c = blockIdx.x, total = N * HW;
-  float v[BN_RC], r[BN_RC];
-  int64_t off[BN_RC];
+  float v[E], r[E];
+  int64_t off[E];
 #pragma unroll
-  for (int i = 0; i < BN_RC; ++i) {
+  for (int i = 0; i < E; ++i) {
     const int e = threadIdx.x + i * T;
     const int n = e / HW, k = e - n * HW;
     off[i] = e < total ? ((int64_t)n * C + c) * HW + k : -1;
@@ -419,7 +420,7 @@ __global__ __launch_bounds__(T) void k_bn2d_fwd_small_rc(const float *__restrict
   }
   double s = 0.0, q = 0.0;
 #pragma unroll
-  for (int i = 0; i < BN_RC; ++i) {
+  for (int i = 0; i < E; ++i) {
     s += v[i];
     q += (double)v[i] * v[i];
   }
@@ -442,14 +443,14 @@ __global__ __launch_bounds__(T) void k_bn2d_fwd_small_rc(const float *__restrict
   const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
   const float a1 = g * invstd, a0 = b - mean * a1;
 #pragma unroll
-  for (int i = 0; i < BN_RC; ++i) {
+  for (int i = 0; i < E; ++i) {
     if (off[i] < 0) continue;
     const float o = v[i] * a1 + a0 + r[i];
     y[off[i]] = o > 0.f ? o : o * slope;
   }
 }
 
-template <int T>
+template <int T, int E = BN_RC>
 __global__ __launch_bounds__(T) void k_bn2d_bwd_small_rc(const float *__restrict__ dy, const float *__restrict__ y,
                                                          const float *__restrict__ x, const float *__restrict__ gamma,
                                                          const float *__restrict__ save_mean,
@@ -459,10 +460,10 @@ __global__ __launch_bounds__(T) void k_bn2d_bwd_small_rc(const float *__restrict
                                                          float *__restrict__ dbeta) {
   const int c = blockIdx.x, total = N * HW;
   const float mean = save_mean[c], invstd = save_invstd[c];
-  float g[BN_RC], xh[BN_RC];
-  int64_t off[BN_RC];
+  float g[E], xh[E];
+  int64_t off[E];
 #pragma unroll
-  for (int i = 0; i < BN_RC; ++i) {
+  for (int i = 0; i < E; ++i) {
     const int e = threadIdx.x + i * T;
     const int n = e / HW, k = e - n * HW;
     off[i] = e < total ? ((int64_t)n * C + c) * HW + k : -1;
@@ -474,7 +475,7 @@ __global__ __launch_bounds__(T) void k_bn2d_bwd_small_rc(const float *__restrict
   }
   double s = 0.0, q = 0.0;
 #pragma unroll
-  for (int i = 0; i < BN_RC; ++i) {
+  for (int i = 0; i < E; ++i) {
     s += g[i];
     q += (double)g[i] * (double)xh[i];
   }
@@ -488,7 +489,7 @@ __global__ __launch_bounds__(T) void k_bn2d_bwd_small_rc(const float *__restrict
   const float k0 = (gamma ? gamma[c] : 1.f) * invstd;
   const float mg = (float)(tot[0] / cnt), mgx = (float)(tot[1] / cnt);
 #pragma unroll
-  for (int i = 0; i < BN_RC; ++i) {
+  for (int i = 0; i < E; ++i) {
     if (off[i] < 0) continue;
     dx[off[i]] = k0 * (g[i] - mg - xh[i] * mgx);
     if (dres) dres[off[i]] = g[i];
@@ -614,6 +615,9 @@ extern "C" int rslo_bn2d_fwd_local(const float *x, const float *res, const float
     else if (rc && (int64_t)N * HW <= 1024 * BN_RC)
       hipLaunchKernelGGL((k_bn2d_fwd_small_rc<1024>), dim3(C), dim3(1024), 0, (hipStream_t)stream, x, res, gamma, beta, N, C,
                          HW, eps, momentum, act_slope, running_mean, running_var, save_mean, save_invstd, y);
+    else if (rc && (int64_t)N * HW <= 1024 * BN_RC_BIG)
+      hipLaunchKernelGGL((k_bn2d_fwd_small_rc<1024, BN_RC_BIG>), dim3(C), dim3(1024), 0, (hipStream_t)stream, x, res, gamma,
+                         beta, N, C, HW, eps, momentum, act_slope, running_mean, running_var, save_mean, save_invstd, y);
     else if (HW <= 1024)
       hipLaunchKernelGGL((k_bn2d_fwd_small<256>), dim3(C), dim3(256), 0, (hipStream_t)stream, x, res, gamma, beta, N, C, HW,
                          eps, momentum, act_slope, running_mean, running_var, save_mean, save_invstd, y);
@@ -651,6 +655,9 @@ extern "C" int rslo_bn2d_bwd_local(const float *dy, const float *y, const float 
     else if (rc && (int64_t)N * HW <= 1024 * BN_RC)
       hipLaunchKernelGGL((k_bn2d_bwd_small_rc<1024>), dim3(C), dim3(1024), 0, (hipStream_t)stream, dy, y, x, gamma, save_mean,
                          save_invstd, N, C, HW, act_slope, has_act, dx, dres, dgamma, dbeta);
+    else if (rc && (int64_t)N * HW <= 1024 * BN_RC_BIG)
+      hipLaunchKernelGGL((k_bn2d_bwd_small_rc<1024, BN_RC_BIG>), dim3(C), dim3(1024), 0, (hipStream_t)stream, dy, y, x, gamma,
+                         save_mean, save_invstd, N, C, HW, act_slope, has_act, dx, dres, dgamma, dbeta);
     else if (HW <= 1024)
       hipLaunchKernelGGL((k_bn2d_bwd_small<256>), dim3(C), dim3(256), 0, (hipStream_t)stream, dy, y, x, gamma, save_mean,
                          save_invstd, N, C, HW, act_slope, has_act, dx, dres, dgamma, dbeta);
