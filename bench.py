@@ -212,8 +212,8 @@ class ConvProbe:
             wgs = B * ((W + 15) // 16) * ((H + 3) // 4) * (cout // 32)
             kc = 2 if (cin >= 64 and cin >= 256 and wgs <= 200) else 1
             res_bytes = 4 * B * H * W * cout if residual is not None else 0      # the epilogue's residual read
-            if not lp and kc == 1 and wgs >= 1024:      # >= 4 workgroups per CU: the 128-register one-tap-ahead variant
-                inst = "k_conv2d_fwd<4, 1, false, false, 1, 4>"
+            if not lp and kc == 1 and wgs >= 512:      # >= 2 workgroups per CU: the 96-register one-tap-ahead variant
+                inst = "k_conv2d_fwd<4, 1, false, false, 1, 5>"
             else:
                 inst = "k_conv2d_fwd<4, 1, true, %s, %d, %d>" % ("true" if lp else "false", kc, 2 // kc)
             return ("dense", 2 * B * H * W * cin * cout * 9, 4 * B * H * W * (cin + cout) + 54 * cin * cout + res_bytes,

@@ -25,7 +25,14 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef __attribute__((address_space(1))) unsigned char glb_u8;
 typedef __attribute__((address_space(1))) u32x4 glb_u32x4;
+typedef __attribute__((address_space(1))) float glb_f32;
 typedef __attribute__((address_space(3))) unsigned char lds_u8;
+// a wave-uniform global address, forced into scalar registers
+__device__ __forceinline__ const glb_u8 *c2f_uniform(const glb_u8 *p) {
+  const uint64_t a = (uint64_t)p;
+  return (const glb_u8 *)(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
+                          (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a));
+}
 typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
 
 #define C2_THREADS 256
@@ -745,8 +752,11 @@ __global__ __launch_bounds__(256 * KC, OCC) void k_conv2d_fwd(const float *__res
 
   // staging tasks of this thread: task = (channel octet o, pixel q), q fastest; NTASK rounds of 256 threads
   constexpr int NTASK = (NPX * 4 + 255) / 256;
-  const float *tsrc[NTASK];
+  // A task's 8 channel values of chunk c sit at `in` + (c * 32 + j) * HW floats (uniform) + the task's own byte offset
+  // tsrc[r] (one 32-bit register instead of a 64-bit pointer per task; -1 = outside the image)
+  int tsrc[NTASK];
   int tdst[NTASK];
+  const glb_u8 *const in_b = (const glb_u8 *)in;
 #pragma unroll
   for (int r = 0; r < NTASK; ++r) {
     const int task = tid + r * 256;
@@ -754,15 +764,16 @@ __global__ __launch_bounds__(256 * KC, OCC) void k_conv2d_fwd(const float *__res
     const int qy = q / 18, qx = q - qy * 18;
     const int y = y0 - 1 + qy, x = x0 - 1 + qx;
     const bool ok = task < NPX * 4 && y >= 0 && y < H && x >= 0 && x < W;
-    tsrc[r] = ok ? in + ((int64_t)b * gm.cin + 8 * o) * HW + (int64_t)y * W + x : nullptr;
+    tsrc[r] = ok ? (int)((((int64_t)b * gm.cin + 8 * o) * HW + (int64_t)y * W + x) * 4) : -1;
     tdst[r] = task < NPX * 4 ? q * C2F_PXB1 + o * 16 : -1;
   }
+#define C2F_RAW(CH, J, OFF) (*(const glb_f32 *)(c2f_uniform(in_b + ((int64_t)(CH) * 32 + (J)) * HW * 4) + (unsigned)(OFF)))
   float raw[NTASK][8];
   const int n_chunks = gm.cin / 32;
 #pragma unroll
   for (int r = 0; r < NTASK; ++r)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) raw[r][j] = (tsrc[r] && grp < n_chunks) ? tsrc[r][((int64_t)grp * 32 + j) * HW] : 0.f;
+    for (int j = 0; j < 8; ++j) raw[r][j] = (tsrc[r] >= 0 && grp < n_chunks) ? C2F_RAW(grp, j, tsrc[r]) : 0.f;
   // weight operands are fetched one tap ahead (they come from L2 / Infinity Cache: the split weights of a whole model do
   // not stay in one XCD's L2 between layers); tap 0 of a chunk is requested before the staging barrier
   // FULLA (small maps, few MFMAs per tap): all 9 taps of a chunk are held in registers and each tap's registers are
@@ -807,7 +818,7 @@ __global__ __launch_bounds__(256 * KC, OCC) void k_conv2d_fwd(const float *__res
 #pragma unroll
       for (int r = 0; r < NTASK; ++r)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) raw[r][j] = tsrc[r] ? tsrc[r][((int64_t)(chunk + KC) * 32 + j) * HW] : 0.f;
+        for (int j = 0; j < 8; ++j) raw[r][j] = tsrc[r] >= 0 ? C2F_RAW(chunk + KC, j, tsrc[r]) : 0.f;
     }
     }
     C2F_LDS_BARRIER();      // LDS only: the prefetched global loads stay in flight across it
@@ -894,6 +905,7 @@ __global__ __launch_bounds__(256 * KC, OCC) void k_conv2d_fwd(const float *__res
   }
 #undef C2F_LOAD_A
 #undef C2F_LOAD_B
+#undef C2F_RAW
   if constexpr (KC == 2) {      // set 1 -> LDS (its own staging buffer, free after the last barrier) -> set 0
     float *slot = reinterpret_cast<float *>(lds_all[1]);
     if (grp == 1) {
@@ -938,6 +950,7 @@ __global__ __launch_bounds__(256 * KC, OCC) void k_conv2d_fwd(const float *__res
 static int g_c2f_occ = 0;      // experiments: waves per SIMD the one-tap-ahead variants are compiled for (0: default kernels)
 static int conv2d_fwd_plan(int B, int cin, int cout, int H, int W, int *tr, int *mtw) {
   if (B <= 0 || H <= 0 || W <= 0 || cin % 32 != 0 || cout % 32 != 0) return 0;
+  if ((int64_t)B * cin * H * W * 4 >= ((int64_t)1 << 31)) return 0;      // per-lane input offsets are 31-bit byte offsets
   static int cfg_tr = -1, cfg_mtw = -1;
   if (cfg_tr < 0) {
     const char *e = getenv("RSLO_CONV2D_FWD_CFG");      // "TR,MTW[,OCC]" forces one configuration (experiments)
@@ -1044,14 +1057,16 @@ static int conv2d_fwd_launch(const float *in, const void *Ws, const float *bias,
     RSLO_CHECK_LAUNCH("k_conv2d_fwd(bf16)");
     return RSLO_OK;
   }
-  // large maps (>= 1024 workgroups: 4 or more per CU): the one-tap-ahead variant at 128 registers keeps 4 workgroups
-  // resident per CU instead of 2 (16 waves hide the staging chain; the 9-tap weight prefetch is not needed with them).
-  // Measured (scripts/conv2d_cfgs.sh, B = 4): 128 -> 128 at 48x88 41.6 -> 38.5 us, 64 -> 64 at 96x176 44.1 -> 36.8,
-  // 64 -> 192 at 96x176 114.8 -> 93.3, 192 -> 64 103.8 -> 95.3; 128 -> 128 at 24x44 (288 workgroups) 16.5 -> 17.4 and
-  // 256 -> 256 at 12x22 18.6 -> 25.0 keep the 9-tap kernel.  RSLO_CONV2D_FWD_LEAN=0 / 1 forces it off / on.
+  // maps of >= 512 workgroups (2 or more per CU): the one-tap-ahead variant at 96 registers keeps 5 workgroups resident
+  // per CU instead of 2 (20 waves hide the staging chain; the 9-tap weight prefetch is not needed with them; the 32-bit
+  // input offsets above are what lets it fit with one spilled register).  Measured (scripts/conv2d_cfgs.sh, B = 4, the
+  // 9-tap kernel -> 4 workgroups per CU at 104 registers -> 5): 128 -> 128 at 48x88 41.6 -> 38.0 -> 35.7 us, 64 -> 64 at
+  // 96x176 44.1 -> 36.4 -> 35.2, 64 -> 192 at 96x176 114.8 -> 92.2 -> 87.8, 192 -> 64 103.8 -> 94.1 -> 89.7, 256 -> 64 at
+  // 48x88 (576 workgroups) 47.0 -> 42.1; 128 -> 128 at 24x44 (288 workgroups) 16.5 -> 17.4 and 256 -> 256 at 12x22
+  // 18.6 -> 25.0 keep the 9-tap kernel.  RSLO_CONV2D_FWD_LEAN=0 / 1 forces it off / on.
   static const int lean_env = getenv("RSLO_CONV2D_FWD_LEAN") ? atoi(getenv("RSLO_CONV2D_FWD_LEAN")) : -1;
-  if (tr == 4 && mtw == 1 && !kc2 && !g_c2f_occ && (lean_env < 0 ? wgs4 >= 1024 : lean_env == 1)) {
-    hipLaunchKernelGGL((k_conv2d_fwd<4, 1, false, false, 1, 4>), grid, dim3(256), 0, st, in, ws, bias, gm, out);
+  if (tr == 4 && mtw == 1 && !kc2 && !g_c2f_occ && (lean_env < 0 ? wgs4 >= 512 : lean_env == 1)) {
+    hipLaunchKernelGGL((k_conv2d_fwd<4, 1, false, false, 1, 5>), grid, dim3(256), 0, st, in, ws, bias, gm, out);
     RSLO_CHECK_LAUNCH("k_conv2d_fwd(lean)");
     return RSLO_OK;
   }
@@ -1059,7 +1074,8 @@ static int conv2d_fwd_launch(const float *in, const void *Ws, const float *bias,
 #define C2F_OCC(M, O) hipLaunchKernelGGL((k_conv2d_fwd<4, M, false, false, 1, O>), grid, dim3(256), 0, st, in, ws, bias, gm, out)
     if (mtw == 1 && g_c2f_occ == 3) C2F_OCC(1, 3);
     else if (mtw == 1 && g_c2f_occ == 4) C2F_OCC(1, 4);
-    else if (mtw == 1) C2F_OCC(1, 4);
+    else if (mtw == 1 && g_c2f_occ == 4) C2F_OCC(1, 4);
+    else if (mtw == 1) C2F_OCC(1, 5);
     else if (g_c2f_occ == 4) C2F_OCC(2, 4);
     else C2F_OCC(2, 3);
 #undef C2F_OCC
