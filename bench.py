@@ -474,7 +474,8 @@ def main():
     pinned = None
     orig_affinity = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
     if os.environ.get("RSLO_BENCH_PIN", "1") != "0":
-        pinned = pin_to_quiet_cores(8, (local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world))))
+        pinned = pin_to_quiet_cores(int(os.environ.get("RSLO_BENCH_PIN_N", "8")),
+                                    (local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world))))
 
     import rslo_amd  # noqa: F401
     from rslo_amd import capi, workload
