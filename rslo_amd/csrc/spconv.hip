@@ -625,6 +625,21 @@ __global__ __launch_bounds__(SPC_THREADS) void k_spconv_v6(const float *__restri
     }
 #pragma unroll
     for (int sk = 0; sk < NS; ++sk) {
+      // Ws[plane][kk][sk][g][co][8]: 16 bytes per lane, consecutive li -> consecutive 16 bytes
+      const unsigned short *wb = Ws + ((((int64_t)kk * NS + sk) * 4 + g) * COUT_T + li) * 8;
+      // one-row-block tiles (the small-problem tiling: a launch of a few waves per SIMD, nothing to hide latency behind):
+      // ALL weight operands of the step are requested before the gathered rows are waited for -- one memory round trip
+      // per step instead of one for the rows plus one per column block (C2: 26 -> ... us per 64 -> 64 layer)
+      constexpr bool PREW = RBW == 1;
+      u32x4 pw[PREW ? NB : 1][3];
+      if constexpr (PREW) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          pw[nb][0] = SPC_WLOAD(wb + nb * 16 * 8);
+          pw[nb][1] = SPC_WLOAD(wb + plane + nb * 16 * 8);
+          pw[nb][2] = SPC_WLOAD(wb + 2 * plane + nb * 16 * 8);
+        }
+      }
       Split8 a[RBW];
 #pragma unroll
       for (int rb = 0; rb < RBW; ++rb) {
@@ -632,13 +647,11 @@ __global__ __launch_bounds__(SPC_THREADS) void k_spconv_v6(const float *__restri
         const float4 x1 = *reinterpret_cast<const float4 *>(ap[rb] + 32 * sk + 4);
         a[rb] = split8(x0, x1, ok[rb]);
       }
-      // Ws[plane][kk][sk][g][co][8]: 16 bytes per lane, consecutive li -> consecutive 16 bytes
-      const unsigned short *wb = Ws + ((((int64_t)kk * NS + sk) * 4 + g) * COUT_T + li) * 8;
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
-        const u32x4 bh = SPC_WLOAD(wb + nb * 16 * 8);
-        const u32x4 bm = SPC_WLOAD(wb + plane + nb * 16 * 8);
-        const u32x4 bl = SPC_WLOAD(wb + 2 * plane + nb * 16 * 8);
+        const u32x4 bh = PREW ? pw[PREW ? nb : 0][0] : SPC_WLOAD(wb + nb * 16 * 8);
+        const u32x4 bm = PREW ? pw[PREW ? nb : 0][1] : SPC_WLOAD(wb + plane + nb * 16 * 8);
+        const u32x4 bl = PREW ? pw[PREW ? nb : 0][2] : SPC_WLOAD(wb + 2 * plane + nb * 16 * 8);
         // smallest terms first; consecutive MFMAs alternate between the row blocks' accumulators
 #pragma unroll
         for (int rb = 0; rb < RBW; ++rb) acc[rb][nb] = MFMA_BF16(a[rb].l, bh, acc[rb][nb]);
