@@ -74,6 +74,9 @@ def parse():
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP events (roofline=null)")
     ap.add_argument("--kernel-report", default="", help="write the per-kernel roofline table to this JSON file")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / rendezvous / timing protocol only, over gloo on the CPU with an empty step: what the "
+                         "non-GPU test of `--gpus N` runs (no kernels, value is not a measurement)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="f32 = C3 (the headline line); bf16 = the single-GPU half of C4: apex.amp O1, bf16 conv operands")
     return ap.parse_args()
@@ -438,6 +441,71 @@ def cpu_baseline(args):
                       "oracle C/OpenMP sparse ops + torch-CPU dense head; %.1f s" % (args.rings, dt)}
 
 
+# --------------------------------------------------------------------------------------------- N > 1 launcher
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves, one process per GPU
+    (the reference does the same from its own entry point: train_hdf5.py:190-256 `multi_proc_train` ->
+    `mp.spawn(train_worker, nprocs=gpus_per_node)`, NCCL init at :322-344).  The ranks run this same file under
+    torch.distributed.run on 127.0.0.1; rank 0 prints the JSON line, which passes through this process's stdout."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")          # torch.distributed.run would set 1 and say so on stderr
+    port = env.get("MASTER_PORT") or str(_free_port())
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args, world, rank):
+    """The launcher, rendezvous and timing protocol of the N-rank run without a GPU: gloo on the CPU, an empty step.
+    Checks what a scaling run depends on before any kernel does: every rank started, world == --gpus, the barrier /
+    max-over-ranks timing and the per-rank gather work, rank 0 alone prints the line."""
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    for _ in range(args.warmup):
+        time.sleep(1e-3)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(1e-3)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    per_rank = [elapsed]
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        gathered = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(gathered, t)
+        per_rank = [float(g.item()) for g in gathered]
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({
+            "metric": "frame-pairs/sec fwd+bwd (DRY RUN: no kernels ran)", "value": round(args.batch * world * args.steps / elapsed, 3),
+            "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "none", "dry_run": True,
+            "config": {"workload": "dry run of the launcher / rendezvous / timing protocol (gloo, CPU)", "frame_pairs_per_gpu": args.batch},
+            "ranks": {"world": world, "backend": "gloo",
+                      "ms_per_step_min": round(1e3 * min(per_rank) / args.steps, 3),
+                      "ms_per_step_max": round(1e3 * max(per_rank) / args.steps, 3)},
+            "roofline": None, "cpu_baseline": None}), flush=True)
+
+
 # --------------------------------------------------------------------------------------------- main
 def main():
     args = parse()
@@ -446,9 +514,15 @@ def main():
         import rslo_amd  # noqa: F401
         print(json.dumps(cpu_baseline(args)))
         return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:      # no launcher around us: start the ranks ourselves
+        sys.exit(spawn_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
+    if args.dry_run:
+        return dry_run(args, world, rank)
     dist_on = world > 1 or os.environ.get("RSLO_BENCH_FORCE_DIST", "0") == "1"   # (the latter: DDP smoke test at N=1)
     if dist_on:
         import torch.distributed as dist
@@ -459,6 +533,9 @@ def main():
         one_gpu = os.environ.get("RSLO_BENCH_ONE_GPU", "0") == "1"
         if one_gpu:
             local_rank = 0
+        elif torch.cuda.device_count() < int(os.environ.get("LOCAL_WORLD_SIZE", world)):
+            raise SystemExit("bench.py: %d ranks on this node but only %d GPUs visible (one rank per GPU; RSLO_BENCH_ONE_GPU=1 "
+                             "is the functional two-ranks-on-one-GPU mode)" % (world, torch.cuda.device_count()))
         torch.cuda.set_device(local_rank)
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", str(rank))
@@ -642,8 +719,12 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     probe.enabled = False
+    per_rank = [elapsed]
     if dist_on:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        gathered = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(gathered, t)                      # every rank's own clock around the same K steps
+        per_rank = [float(g.item()) for g in gathered]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -702,6 +783,14 @@ def main():
             "roofline": roof,
             "cpu_baseline": None,
         }
+        if dist_on:
+            try:
+                ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:          # a build without the binding: say so rather than guess
+                ver = None
+            line["rccl"] = {"ranks": world, "version": ver, "backend": dist.get_backend(),
+                            "ms_per_step_min": round(1e3 * min(per_rank) / args.steps, 3),
+                            "ms_per_step_max": round(1e3 * max(per_rank) / args.steps, 3)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 if pinned is not None:

@@ -25,3 +25,44 @@ def test_bench_prints_one_json_line_with_roofline(hip):
     c = line["cpu_baseline"]
     assert c["value"] > 0 and c["cores"] >= 1 and c["kind"] in ("port", "reference")
     assert "workload" in line["config"]
+
+
+def _last_json(stdout):
+    return json.loads([ln for ln in stdout.strip().splitlines() if ln.startswith("{")][-1])
+
+
+def test_bench_gpus_flag_starts_that_many_ranks_by_itself():
+    """`python bench.py --gpus 2` with NO launcher around it (the form the driver uses) must start two ranks itself
+    (the reference: train_hdf5.py:255 mp.spawn) and report n_gpus 2.  --dry-run: launcher + gloo rendezvous + the
+    barrier / max-over-ranks timing protocol on the CPU, no kernels."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--dry-run"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines                       # rank 0 alone prints
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["dry_run"] is True
+    assert line["ranks"]["world"] == 2 and line["ranks"]["ms_per_step_min"] <= line["ranks"]["ms_per_step_max"]
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-run"],
+                         capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert out.returncode != 0 and "WORLD_SIZE=2" in (out.stderr + out.stdout)
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_runs_the_full_two_rank_step(hip):
+    """The complete two-rank step (SyncBN statistics exchange, overlapped gradient all-reduce, per-rank prefetch) started
+    by `bench.py --gpus 2` itself.  The test boxes have ONE GPU: RSLO_BENCH_ONE_GPU=1 puts both ranks on it over gloo --
+    functional, not a performance mode."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["RSLO_BENCH_ONE_GPU"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
+                          "--batch", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=1200, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = _last_json(out.stdout)
+    assert line["n_gpus"] == 2 and line["value"] > 0
+    assert line["rccl"]["ranks"] == 2 and line["rccl"]["ms_per_step_min"] <= line["rccl"]["ms_per_step_max"]
