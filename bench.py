@@ -700,7 +700,7 @@ def main():
     gc_every = int(os.environ.get("RSLO_BENCH_GC", "0"))                  # diagnostic: cyclic GC every n timed steps
     t0 = time.perf_counter()
     from rslo.models import voxel_odom_net as _von0
-    lead_wait0 = _von0._LEAD_WAIT[0]
+    lead_wait0, lead_cpu0 = _von0._LEAD_WAIT[0], _von0._LEAD_WAIT[1]
     cpu0 = time.thread_time()           # CPU time of the issuing thread: close to the wall time = host-bound step
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # one event per step: spread of the
     marks[0].record()                                                                # step time without extra syncs
@@ -715,7 +715,8 @@ def main():
             gc.collect()
     cpu_issue = time.thread_time() - cpu0
     from rslo.models import voxel_odom_net as _von
-    held_back = _von._LEAD_WAIT[0] - lead_wait0       # seconds the issuing thread was held back behind the GPU (a spinning wait)
+    held_back = _von._LEAD_WAIT[0] - lead_wait0       # wall seconds the issuing thread was held back behind the GPU
+    held_back_cpu = _von._LEAD_WAIT[1] - lead_cpu0    # CPU seconds of that wait (a sleeping wait on a blocking-sync event: ~0)
     barrier()
     elapsed = time.perf_counter() - t0
     probe.enabled = False
@@ -770,8 +771,9 @@ def main():
                        "voxelize_in_step": not args.no_voxelize, "voxelize_prefetch_stream": prefetch is not None,
                        "distinct_batches": n_sets, "pinned_cpus": pinned,
                        "optimizer_in_step": not args.no_optim,
-                       # CPU time of the issuing thread minus the time it was HELD BACK behind the GPU (a spinning wait)
-                       "host_issue_ms_per_step": round(1e3 * (cpu_issue - held_back) / args.steps, 3),
+                       # CPU time of the issuing thread minus the CPU time it spent waiting behind the GPU (the wait sleeps:
+                       # its wall time is `host_held_back_ms_per_step`, its CPU time is close to nothing)
+                       "host_issue_ms_per_step": round(1e3 * (cpu_issue - held_back_cpu) / args.steps, 3),
                        # get(): waiting for the helper's result / the plan's event + assembling the example from the arena
                        "prefetch_wait_ms_per_step": round(1e3 * wait[0] / args.steps, 3),
                        # the issuing thread sleeping until the GPU is within RSLO_HOST_LEAD forward passes (slack of a

@@ -80,6 +80,8 @@ def exchange_group(group):
     Default, another backend, or an explicit process_group: unchanged."""
     if group is not None or os.environ.get("RSLO_SYNCBN_HP_GROUP", "0") != "1":
         return group
+    if _HP_GROUP.get("world") is not dist.group.WORLD:          # a re-initialised default group: the cached one is dead
+        _HP_GROUP.update(tried=False, group=None, world=dist.group.WORLD)
     if not _HP_GROUP["tried"]:
         _HP_GROUP["tried"] = True
         if dist.get_backend() == "nccl":

@@ -18,6 +18,8 @@ tests/test_gpu_model.py::test_native_plan_equals_python_plan); per-frame tensors
 so the concatenations of make_example / network_forward disappear as well.
 """
 import numpy as np
+import threading
+
 import torch
 
 from rslo_amd import capi
@@ -96,6 +98,7 @@ class EncoderPlanner:
         self.n_arenas = int(arenas)
         self._arenas = []         # [(uint8 CUDA tensor, pinned int32 counts)], handed out round-robin
         self._next = 0
+        self._lock = threading.Lock()
         self.fallbacks = 0
 
     def _spec(self, n_features, with_pairs):
@@ -121,21 +124,25 @@ class EncoderPlanner:
         sp.max_points, sp.max_voxels, sp.n_features = vg._max_num_points, self.max_voxels, int(n_features)
         return sp
 
-    def _arena(self, nbytes, device):
-        """Arenas are reused round-robin: a job's arena is free again after `arenas` further submits (the prefetcher
-        keeps depth + 1 examples alive; 4 arenas cover depth 2)."""
-        if len(self._arenas) < self.n_arenas:
-            ent = [torch.empty((nbytes,), dtype=torch.uint8, device=device),
-                   torch.empty((capi.PLAN_CNT_WORDS,), dtype=torch.int32).pin_memory()]
-            self._arenas.append(ent)
+    def _arena(self, nbytes, device, slot=None):
+        """Arenas are reused round-robin: job `slot` writes arena slot mod A, free again after A further submits (the
+        prefetcher keeps depth + 1 examples alive; 4 arenas cover depth 2).  The prefetcher passes its job sequence number
+        as `slot` -- with several helper threads the calls arrive in thread order, not job order, and the event a job
+        waits on (ExamplePrefetcher.submit) is derived from the sequence number."""
+        with self._lock:
+            if slot is None:
+                slot = self._next
+                self._next += 1
+            i = int(slot) % self.n_arenas
+            while len(self._arenas) <= i:
+                self._arenas.append([torch.empty((nbytes,), dtype=torch.uint8, device=device),
+                                     torch.empty((capi.PLAN_CNT_WORDS,), dtype=torch.int32).pin_memory()])
+            ent = self._arenas[i]
+            if ent[0].numel() < nbytes or ent[0].device != device:
+                ent[0] = torch.empty((nbytes,), dtype=torch.uint8, device=device)
             return ent
-        ent = self._arenas[self._next % self.n_arenas]
-        self._next += 1
-        if ent[0].numel() < nbytes or ent[0].device != device:
-            ent[0] = torch.empty((nbytes,), dtype=torch.uint8, device=device)
-        return ent
 
-    def submit(self, clouds_per_sample, with_pairs=None):
+    def submit(self, clouds_per_sample, with_pairs=None, slot=None):
         """clouds_per_sample: list (batch) of lists (frames) of CUDA fp32 [P,F] tensors.  Enqueues everything on the
         current stream and records the `ready` event; no host read."""
         B, T = len(clouds_per_sample), len(clouds_per_sample[0])
@@ -147,7 +154,7 @@ class EncoderPlanner:
             with_pairs = self.net.training
         spec = self._spec(flat[0].shape[1], with_pairs)
         lay = capi.plan_encoder_layout(spec, [p.shape[0] for p in flat])
-        arena, counts = self._arena(int(lay.total_bytes), flat[0].device)
+        arena, counts = self._arena(int(lay.total_bytes), flat[0].device, slot)
         capi.plan_encoder(spec, lay, flat, B, arena, counts)
         job = _Job()
         job.arena, job.counts, job.lay, job.B, job.T, job.n_clouds = arena, counts, lay, B, T, len(flat)

@@ -161,6 +161,7 @@ class _ConvBNActFn(torch.autograd.Function):
         y, mean, invstd, cnt = fused_bn_forward(bn, o, None, g, b, slope, group, world)
         ctx.save_for_backward(x, w, g, o, y if slope != 1.0 else None, mean, invstd, cnt)
         ctx.meta = (wt, slope, lp, cb is not None, group, world)
+        ctx.leaf_params = (w,) if cb is None else (w, cb)
         return y
 
     @staticmethod
@@ -174,9 +175,9 @@ class _ConvBNActFn(torch.autograd.Function):
         dx = capi.conv2d_fwd(d_o, wt, None, w.shape[1], lp=lp) if ctx.needs_input_grad[0] else None
         dcb = None
         if has_bias:
-            dw, dcb = hip_conv2d.conv2d_wgrad_leaf(x, d_o, 1, want_bias=True, lp=lp)
+            dw, dcb = hip_conv2d.conv2d_wgrad_leaf(x, d_o, 1, want_bias=True, lp=lp, params=ctx.leaf_params)
         else:
-            dw = hip_conv2d.conv2d_wgrad_leaf(x, d_o, 1, lp=lp)
+            dw = hip_conv2d.conv2d_wgrad_leaf(x, d_o, 1, lp=lp, params=ctx.leaf_params)
         return dx, dw, dcb, dg, db, None, None, None
 
 

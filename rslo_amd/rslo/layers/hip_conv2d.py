@@ -25,15 +25,16 @@ def join_leaf_stream(device=None):
     streams.join(device)
 
 
-def conv2d_wgrad_leaf(x, dy, stride, want_bias=False, lp=False):
-    """rslo_conv2d_wgrad as leaf work of the backward pass (rslo_amd.streams)."""
+def conv2d_wgrad_leaf(x, dy, stride, want_bias=False, lp=False, params=None):
+    """rslo_conv2d_wgrad as leaf work of the backward pass (rslo_amd.streams); params = the parameters the results are
+    the gradients of (weight[, bias]): without them the call cannot be checked and runs on the issuing stream."""
     from rslo_amd import capi, streams
     if want_bias:
-        return streams.leaf(lambda: capi.conv2d_wgrad(x, dy, stride, want_bias=True, lp=lp), (x, dy))
-    return streams.leaf(lambda: capi.conv2d_wgrad(x, dy, stride, lp=lp), (x, dy))
+        return streams.leaf(lambda: capi.conv2d_wgrad(x, dy, stride, want_bias=True, lp=lp), (x, dy), params)
+    return streams.leaf(lambda: capi.conv2d_wgrad(x, dy, stride, lp=lp), (x, dy), params)
 
 
-def conv1x1s2_wgrad_leaf(x, dy, wshape):
+def conv1x1s2_wgrad_leaf(x, dy, wshape, params=None):
     """Weight gradient of a 1x1 / stride-2 downsample conv as leaf work: rslo_conv1x1s2_wgrad (the centre tap of the
     stride-2 kernel, fixed summation order), or a batched GEMM over the sampled pixels for shapes outside its range."""
     from rslo_amd import capi, streams
@@ -46,7 +47,7 @@ def conv1x1s2_wgrad_leaf(x, dy, wshape):
                 return dw.reshape(wshape)
         xs = x_[:, :, ::2, ::2].flatten(2)                              # [B, cin, P]
         return torch.matmul(dy_.flatten(2), xs.transpose(1, 2)).sum(0).reshape(wshape)
-    return streams.leaf(run, (x, dy))
+    return streams.leaf(run, (x, dy), params)
 
 
 def _low_precision():
@@ -62,6 +63,7 @@ class _Conv3x3Fn(torch.autograd.Function):
         ctx.save_for_backward(x, w)
         ctx.stride = stride
         ctx.has_bias = bias is not None
+        ctx.leaf_params = (w,) if bias is None else (w, bias)
         ctx.hip_fd = hip_fd
         ctx.ws_t = None
         from rslo_amd import precision
@@ -98,10 +100,10 @@ class _Conv3x3Fn(torch.autograd.Function):
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             if ctx.hip_w and want_db and s == 1:
-                dw, db = conv2d_wgrad_leaf(x, dy, s, want_bias=True, lp=ctx.lp)     # bias gradient from the same pass
+                dw, db = conv2d_wgrad_leaf(x, dy, s, want_bias=True, lp=ctx.lp, params=ctx.leaf_params)     # bias gradient from the same pass
                 want_db = False
             elif ctx.hip_w:
-                dw = conv2d_wgrad_leaf(x, dy, s, lp=ctx.lp)
+                dw = conv2d_wgrad_leaf(x, dy, s, lp=ctx.lp, params=ctx.leaf_params)
             else:
                 dw = torch.ops.aten.convolution_backward(dy, x, w, None, [s, s], [1, 1], [1, 1], False, [0, 0], 1,
                                                          [False, True, False])[1]
@@ -137,7 +139,7 @@ class _Conv1x1S2Fn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = capi.conv2d_dgrad_s2(dy, ctx.ws_t, w.shape[1], x.shape[2], x.shape[3], 1)
         if ctx.needs_input_grad[1]:
-            dw = conv1x1s2_wgrad_leaf(x, dy, w.shape)
+            dw = conv1x1s2_wgrad_leaf(x, dy, w.shape, params=(w,))
         return dx, dw
 
 

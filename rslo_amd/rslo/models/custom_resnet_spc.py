@@ -104,7 +104,7 @@ class _BasicBlockFn(torch.autograd.Function):
         d_o2, d_res, dg2, db2 = fused_bn_backward(gy, y2 if act else None, o2, g2, m2, i2, n2, slope, True, True, group, world)
         d_y1 = capi.conv2d_fwd(d_o2, w2t, None, w2.shape[1], lp=lp)
         from rslo.layers import hip_conv2d
-        dw2 = hip_conv2d.conv2d_wgrad_leaf(y1, d_o2, 1, lp=lp)
+        dw2 = hip_conv2d.conv2d_wgrad_leaf(y1, d_o2, 1, lp=lp, params=(w2,))
         d_o1, _, dg1, db1 = fused_bn_backward(d_y1, y1 if act else None, o1, g1, m1, i1, n1, slope, False, True, group, world)
         res_joined = False
         if s == 2:
@@ -113,18 +113,18 @@ class _BasicBlockFn(torch.autograd.Function):
             dx = capi.conv2d_fwd(d_o1, w1t, None, w1.shape[1], lp=lp, residual=d_res if wd is None else None)
             res_joined = wd is None
         if hip_w1:
-            dw1 = hip_conv2d.conv2d_wgrad_leaf(x, d_o1, s, lp=lp)
+            dw1 = hip_conv2d.conv2d_wgrad_leaf(x, d_o1, s, lp=lp, params=(w1,))
         else:       # the full-resolution stride-2 layer: the library's weight gradient (see csrc/conv2d.hip conv2d_plan)
             from rslo_amd import streams      # leaf work, like the hand-written weight gradients (rslo_amd/streams.py)
             dw1 = streams.leaf(lambda: torch.ops.aten.convolution_backward(
-                d_o1, x, w1, None, [s, s], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1], (d_o1, x))
+                d_o1, x, w1, None, [s, s], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1], (d_o1, x), (w1,))
         dwd = dgd = dbd = None
         if wd is not None:
             from rslo_amd import streams
             d_od, _, dgd, dbd = fused_bn_backward(d_res, None, od, gd, md, idd, nd, 1.0, False, True, group, world)
             # the downsample branch's input gradient lands on every other pixel: joined with the 3x3 branch's in its epilogue
             dx = capi.conv2d_dgrad_s2(d_od, wdt, wd.shape[1], x.shape[2], x.shape[3], 1, residual=dx)
-            dwd = hip_conv2d.conv1x1s2_wgrad_leaf(x, d_od, wd.shape)
+            dwd = hip_conv2d.conv1x1s2_wgrad_leaf(x, d_od, wd.shape, params=(wd,))
         elif not res_joined:
             dx.add_(d_res)
         return dx, dw1, dg1, db1, dw2, dg2, db2, dwd, dgd, dbd, None, None

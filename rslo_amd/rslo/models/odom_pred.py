@@ -51,6 +51,19 @@ def get_odom_class(name):
     return REGISTERED_ODOM_PRED_CLASSES[name]
 
 
+
+def _avgpool_321(m):
+    """nn.AvgPool2d(3, 2, 1) exactly as k_head_masks_* hard-codes it: divisor 9 everywhere (count_include_pad, no
+    divisor_override), floor output size."""
+    return (isinstance(m, nn.AvgPool2d) and (m.kernel_size, m.stride, m.padding) == (3, 2, 1)
+            and m.count_include_pad and not m.ceil_mode and m.divisor_override is None)
+
+
+def _maxpool_321(m):
+    """nn.MaxPool2d(3, 2, 1) as the kernels implement it: dilation 1, floor output size, no indices."""
+    return (isinstance(m, nn.MaxPool2d) and (m.kernel_size, m.stride, m.padding) == (3, 2, 1)
+            and m.dilation in (1, (1, 1)) and not m.ceil_mode and not m.return_indices)
+
 class UNOdomPredEncDecSVDTempMaskBase(OdomPredEncDecBase):
     consumes_presplit_event = True      # _forward waits for hip_conv2d.presplit_early's event instead of splitting itself
 
@@ -224,10 +237,8 @@ class UNOdomPredEncDecSVDTempMaskBase(OdomPredEncDecBase):
             n = len(self.deblocks) - 1 if self.pred_pyramid_motion else 0
             ok = (os.environ.get("RSLO_FUSED_HEAD_TAIL", "1") != "0" and self.fused_vote and self.conf_type == "softmax"
                   and self.dense_predict and 0 <= n <= 3
-                  and isinstance(self.hier_weight_gen, nn.AvgPool2d)
-                  and (self.hier_weight_gen.kernel_size, self.hier_weight_gen.stride, self.hier_weight_gen.padding) == (3, 2, 1)
-                  and (n == 0 or all(isinstance(mp, nn.MaxPool2d) and (mp.kernel_size, mp.stride, mp.padding) == (3, 2, 1)
-                                     for mp in list(self.mask_gen_pools)[-n:])))
+                  and _avgpool_321(self.hier_weight_gen)
+                  and (n == 0 or all(_maxpool_321(mp) for mp in list(self.mask_gen_pools)[-n:])))
             self.__dict__["_fused_tail_static"] = ok
         if not ok or not (x.is_cuda and x.dtype == torch.float32 and input_mask.dim() == 4):
             return False

@@ -32,8 +32,7 @@ from rslo.models import middle, odom_pred, voxel_encoder
 
 _SIDE_STREAMS = {}
 _HOST_LEAD = int(os.environ.get("RSLO_HOST_LEAD", "1"))
-_LEAD_EVENTS = {}        # id(network) -> events recorded behind its recent training forwards (kept outside the module)
-_LEAD_WAIT = [0.0]       # seconds the issuing thread was held back (bench.py reports it)
+_LEAD_WAIT = [0.0, 0.0]  # wall seconds the issuing thread was held back, CPU seconds it spent in that wait (bench.py)
 
 REGISTERED_NETWORK_CLASSES = {}
 
@@ -351,11 +350,12 @@ class UnVoxelOdomNetICP3(nn.Module):
             # recorded behind an earlier forward).  Nothing else bounds it -- the step has no host read -- and a thread
             # that fills the launch queue spins inside hipLaunchKernel and costs GPU time: 14.1 vs 13.7 ms per step
             # measured.  RSLO_HOST_LEAD=0: unbounded.
-            ring = _LEAD_EVENTS.setdefault(id(self), [])
+            ring = self.__dict__.setdefault("_lead_events", [])       # (not a module attribute: events do not deep-copy)
             if len(ring) >= _HOST_LEAD:
-                t0 = time.perf_counter()
-                ring[-_HOST_LEAD].synchronize()
+                t0, c0 = time.perf_counter(), time.thread_time()
+                ring[-_HOST_LEAD].synchronize()                       # a sleeping wait (blocking-sync events)
                 _LEAD_WAIT[0] += time.perf_counter() - t0
+                _LEAD_WAIT[1] += time.thread_time() - c0
         if self.training and torch.is_grad_enabled() and voxels[0].is_cuda:
             from rslo.layers import hip_conv2d      # the head's weight operands: split beside the encoder's forward
             dev_ = voxels[0].device

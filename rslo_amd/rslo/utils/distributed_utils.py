@@ -44,7 +44,9 @@ def _host_group():
     None when no CPU group can be had; the agreement then falls back to the default group plus a host read."""
     if dist.get_backend() == "gloo":
         return dist.group.WORLD
-    if "g" not in _HOST_GROUP:
+    if _HOST_GROUP.get("world") is not dist.group.WORLD:       # first use, or the process group was destroyed and re-made
+        _HOST_GROUP.clear()
+        _HOST_GROUP["world"] = dist.group.WORLD
         try:
             if os.environ.get("MASTER_ADDR", "") in ("127.0.0.1", "localhost"):
                 # single-node launch: gloo would look its interface up through the host NAME, which need not resolve
@@ -77,16 +79,22 @@ def _agreed_grad_set(model, params):
     (distributed_utils.py:62-75) stays aligned because its frozen torch zero-fills gradients; here
     `zero_grad(set_to_none=True)` recomputes the non-None set from each step's graph, and a rank whose graph skips a
     parameter of the set contributes zeros."""
+    return _agreed_grad_set_and_flag(model, params, 0)[0]
+
+
+def _agreed_grad_set_and_flag(model, params, flag):
+    """_agreed_grad_set + one more per-rank integer riding the same host exchange: -> (indices, max of `flag` over ranks)."""
     st = model.__dict__.setdefault("_rslo_grad_set", {"idx": None, "n": None})
     fresh = st["idx"] is None or st["n"] != len(params)
     chosen = set() if fresh else set(st["idx"])
     stray = any(p.grad is not None and i not in chosen for i, p in enumerate(params))
     dev = params[0].device
-    if _host_max([1 if (fresh or stray) else 0], dev)[0]:
+    redo, flag = _host_max([1 if (fresh or stray) else 0, int(flag)], dev)
+    if redo:
         have = _host_max([1 if (p.grad is not None or i in chosen) else 0 for i, p in enumerate(params)], dev)
         st["idx"] = [i for i, h in enumerate(have) if h > 0]
         st["n"] = len(params)
-    return st["idx"]
+    return st["idx"], flag
 
 
 def _reduce_bucket(sel, mean, async_op=False):
@@ -182,10 +190,13 @@ class OverlappedGradientExchange:
             conv = sys.modules.get("rslo.layers.hip_conv2d")
             if conv is not None:            # weight gradients issued on the leaf stream: this stream waits for them first
                 conv.join_leaf_stream()
-            # the engine runs AccumulateGrad nodes ahead of everything else that is ready, so at the hook every gradient
-            # this rank will produce for the early module exists; a missing one is absent on this rank: zeros
+            # a parameter whose uses all lie behind the watched tensor has its gradient by now (the engine runs a ready
+            # AccumulateGrad ahead of everything else); a missing one goes out as zeros.  A parameter that is ALSO used in
+            # front of the watched tensor gets its one AccumulateGrad after this point: finish() finds and repairs that
             grads, flat, work = _reduce_bucket(sel, self.mean, async_op=True)
-            self.pending = (sel, grads, flat, work)
+            # what left: the tensor and its version per entry, so that finish() can tell a gradient that was produced or
+            # added to AFTER this point (the scheduling property above is the engine's, not a contract)
+            self.pending = (sel, grads, flat, work, [g._version for g in grads])
 
     def _on_early_done(self, module, grad_input, grad_output):
         if _active() and self.pending is None:
@@ -200,15 +211,41 @@ class OverlappedGradientExchange:
         if self.pending is None:        # the hook did not fire on this rank (its loss never reached the early module):
             self._launch_early(params)  # the other ranks sent the early bucket, this one joins it now
         pend, self.pending = self.pending, None
-        idx = _agreed_grad_set(self.model, params)
+        # gradients of early parameters that changed after the early bucket left (a parameter also used outside the watched
+        # boundary, a watch(tensor) that is not a true cut): 1 = produced late (the bucket carried a zeros stand-in: this
+        # rank's contribution is still missing from the sum), 2 = ADDED to in place after the copy was taken (the late
+        # part cannot be separated any more).  The flag rides the host exchange of the set agreement: all ranks act alike.
+        late, flag = [], 0
+        if pend is not None:
+            for k, (p, g, v) in enumerate(zip(pend[0], pend[1], pend[4])):
+                if p.grad is not None and p.grad is not g:
+                    late.append(k)
+                    flag = max(flag, 1)
+                elif p.grad is g and g._version != v:
+                    flag = 2
+        idx, flag = _agreed_grad_set_and_flag(self.model, params, flag)
+        if flag >= 2:
+            if pend is not None:
+                pend[3].wait()
+            raise RuntimeError("OverlappedGradientExchange: a gradient of the early module was accumulated into after the "
+                               "early bucket had left (on some rank) -- the watched tensor is not a cut of the graph; use "
+                               "average_gradients() or watch the right boundary")
         done = {id(p) for p in pend[0]} if pend is not None else set()
         rest = [params[i] for i in idx if id(params[i]) not in done]
         if rest:
             grads, flat, _ = _reduce_bucket(rest, self.mean)
             _scatter_bucket(rest, grads, flat, self.mean)
         if pend is not None:
-            pend[3].wait()
-            _scatter_bucket(pend[0], pend[1], pend[2], self.mean)
+            sel, grads, flat, work = pend[:4]
+            work.wait()
+            if flag == 1:      # some rank holds late gradients: one more flat all-reduce over the same tensors (zeros elsewhere)
+                mine = set(late)
+                extra = torch.cat([(p.grad if k in mine else torch.zeros_like(p)).reshape(-1) for k, p in enumerate(sel)])
+                dist.all_reduce(extra)
+                flat.add_(extra)
+                for k in late:
+                    sel[k].grad = None          # the stand-in takes over with the complete sum
+            _scatter_bucket(sel, grads, flat, self.mean)
 
 
 def broadcast_params(model, src=0):

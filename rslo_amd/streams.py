@@ -5,6 +5,15 @@ off is a sequence of dependent launches that leave most CUs idle on the small ma
 `fn` on a per-device side stream ordered behind the issuing stream's current position, and queues ONE engine callback
 that makes the issuing stream wait for the side stream at the end of the backward pass (`join()` does the same on
 request, e.g. before a gradient bucket leaves mid-backward).  RSLO_WGRAD_STREAM=0 runs everything on the issuing stream.
+Safety at the node boundary (the autograd engine knows nothing about the side stream):
+  * `params` names the parameters the results become gradients of.  AccumulateGrad runs on the ISSUING stream: when it
+    only takes the tensor (`p.grad is None`, the shipped loop: `zero_grad()` to None every step) nothing reads the result
+    before the end-of-pass join.  When it would ADD -- `p.grad` already set (gradient accumulation over several
+    backward() calls, `zero_grad(set_to_none=False)`) or a second result for the same parameter in one pass (a weight
+    shared by two layers) -- the side stream is joined first and `fn` runs on the issuing stream.  A call without
+    `params` cannot be checked and runs on the issuing stream.
+  * the inputs are kept referenced until the join: the engine adds a later gradient IN PLACE into a buffered one only
+    when it is its sole owner (`InputBuffer::add`), so a `dy` the side stream is still reading is never written.
 Used for the dense weight gradients of the BEV head (12.68 -> 12.29 ms per step); the sparse weight gradients were tried
 as well and lost (12.44-12.69 ms: their launches fill the GPU on levels 0-2, so they only take CUs from the data-gradient
 chain they would run beside).
@@ -14,7 +23,7 @@ import os
 import torch
 
 ENABLED = os.environ.get("RSLO_WGRAD_STREAM", "1") != "0"
-_state = {}          # device -> {"side": stream, "cur": stream of the backward nodes, "pending": bool}
+_state = {}          # device -> {"side", "cur": stream of the backward nodes, "pending", "targets": ids, "keep": inputs}
 
 
 def join(device=None):
@@ -23,17 +32,24 @@ def join(device=None):
         if st["pending"] and (device is None or dev == device):
             st["cur"].wait_stream(st["side"])
             st["pending"] = False
+            st["targets"].clear()
+            st["keep"].clear()
 
 
-def leaf(fn, inputs):
-    """fn() -> tensor or tuple of tensors (or None entries); inputs: the CUDA tensors fn reads."""
+def leaf(fn, inputs, params=None):
+    """fn() -> tensor or tuple of tensors (or None entries); inputs: the CUDA tensors fn reads; params: the parameters
+    whose gradients fn's results are (see the module docstring)."""
     dev = inputs[0].device
-    if not (ENABLED and dev.type == "cuda"):
+    if not (ENABLED and dev.type == "cuda") or params is None:
         return fn()
     cur = torch.cuda.current_stream(dev)
     st = _state.get(dev)
     if st is None:
-        st = _state[dev] = {"side": torch.cuda.Stream(dev), "cur": cur, "pending": False}
+        st = _state[dev] = {"side": torch.cuda.Stream(dev), "cur": cur, "pending": False, "targets": set(), "keep": []}
+    # (a non-leaf "parameter", e.g. a cast copy, hands the result to another backward node on the issuing stream)
+    if any((not p.is_leaf) or p.grad is not None or id(p) in st["targets"] for p in params):
+        join(dev)              # everything issued so far is ordered in front of the accumulation that follows
+        return fn()
     side = st["side"]
     ev = torch.cuda.Event()
     ev.record(cur)
@@ -43,9 +59,11 @@ def leaf(fn, inputs):
     for t in inputs:
         if t is not None:
             t.record_stream(side)
+            st["keep"].append(t)
     for t in (out if isinstance(out, (tuple, list)) else (out,)):
         if t is not None:
             t.record_stream(cur)
+    st["targets"].update(id(p) for p in params)
     if not st["pending"]:
         st["pending"], st["cur"] = True, cur
         torch.autograd.Variable._execution_engine.queue_callback(lambda d=dev: join(d))

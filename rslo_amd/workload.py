@@ -147,7 +147,7 @@ class ExamplePrefetcher:
                             stream.wait_event(prev_done)
                         cl = [[c if torch.is_tensor(c) else torch.from_numpy(c) for c in s] for s in clouds]
                         cl = [[c.to(self.device, torch.float32).contiguous() for c in s] for s in cl]
-                        ex = self.planner.submit(cl)          # a job: becomes the example in get()
+                        ex = self.planner.submit(cl, slot=seq)          # a job: becomes the example in get()
                     ready = ex.ready
                 else:
                     if prev_done is not None:

@@ -339,6 +339,83 @@ def test_overlapped_exchange_is_rank_symmetric_when_one_rank_skips_part_of_the_e
     assert [g for _, _, g in res[0][1]] == [g for _, _, g in res[1][1]]
 
 
+def _late_grad_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import copy
+    from rslo.utils.distributed_utils import OverlappedGradientExchange, average_gradients
+    torch.manual_seed(5)
+    net = torch.nn.Module()
+    net.encoder = torch.nn.Linear(6, 8)
+    net.head = torch.nn.Module()
+    net.head.main, net.head.side = torch.nn.Linear(8, 3), torch.nn.Linear(8, 8)
+    ref = copy.deepcopy(net)
+    ex = OverlappedGradientExchange(net, net.head, mean=True, module_hook=False)
+
+    def fwd(m, x, mode, watch):
+        # "late": head.side is applied UPSTREAM of the watched tensor too (only there on this rank) -> its gradient is
+        # produced after the hook has fired and the early bucket (with a zeros stand-in for it) has left
+        h = m.encoder(x)
+        if mode == "late":
+            h = m.head.side(h)
+        f = ex.watch(h) if watch else h
+        y = m.head.main(f)
+        if mode == "both":
+            y = y + m.head.side(f)[:, :3]
+        return y.square().sum()
+
+    plan = [("both", "both"), ("both", "late"), ("both", "both")]
+    out = []
+    for step, modes in enumerate(plan):
+        x = torch.randn(5, 6, generator=torch.Generator().manual_seed(100 * step + rank))
+        for m in (net, ref):
+            m.zero_grad(set_to_none=True)
+            fwd(m, x, modes[rank], m is net).backward()
+        fired = ex.pending is not None
+        ex.finish()
+        average_gradients(ref, mean=True)
+        same = all((a.grad is None and b.grad is None) or (a.grad is not None and b.grad is not None
+                                                           and torch.allclose(a.grad, b.grad, rtol=1e-6, atol=1e-7))
+                   for a, b in zip(net.parameters(), ref.parameters()))
+        out.append((fired, same))
+    # the same with gradients kept across steps (zero_grad(set_to_none=False)): the late gradient is then ADDED IN PLACE to
+    # the tensor whose copy already left -- nothing to separate any more: every rank raises (the flag rides the host
+    # exchange), none hangs in a collective
+    net.zero_grad(set_to_none=False)
+    x = torch.randn(5, 6, generator=torch.Generator().manual_seed(900 + rank))
+    fwd(net, x, "late" if rank == 1 else "both", True).backward()
+    try:
+        ex.finish()
+        raised = False
+    except RuntimeError as e:
+        raised = "early bucket had left" in str(e)
+    q.put((rank, out, raised))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overlapped_exchange_keeps_gradients_produced_after_the_early_bucket_left():
+    """a gradient of the early module that appears after the hook fired must not be dropped (the rank
+    would keep its local un-reduced value and the ranks diverge silently): produced late -> one more symmetric
+    all-reduce, sums equal average_gradients; accumulated in place late -> RuntimeError on EVERY rank."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=_late_grad_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, out, raised in res:
+        assert all(same for _, same in out), (rank, out)
+        assert [f for f, _ in out] == [False, True, True], (rank, out)
+        assert raised, rank
+
+
 def test_syncbn_exchange_group_is_unchanged_off_nccl():
     """exchange_group(): explicit groups and non-NCCL backends pass through (the gloo tests above run on the default group)."""
     import socket

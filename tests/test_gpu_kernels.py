@@ -1017,6 +1017,48 @@ def test_hip_conv2d_module_gradients_match_library(hip):
             assert torch.allclose(a, b, rtol=1e-4, atol=1e-4 * float(b.abs().max()))
 
 
+def test_leaf_stream_weight_gradients_accumulate_and_share_safely(hip):
+    """rslo_amd.streams.leaf: the dense weight gradients run on a side stream the autograd engine knows nothing about.
+    (a) two backward() calls without zero_grad (AccumulateGrad ADDS on the training stream), (b) zero_grad(set_to_none=
+    False), (c) one weight used by two layers in one pass: every case must give the bits of the run with the side stream
+    switched off, on many repetitions with a long-running kernel in front of the leaf work (a race shows as a mismatch)."""
+    from rslo.layers.hip_conv2d import Conv2d
+    from rslo_amd import streams
+    assert streams.ENABLED
+    torch.manual_seed(11)
+    m = Conv2d(64, 64, 3, stride=1, padding=1, bias=True).cuda()
+    m2 = Conv2d(64, 64, 3, stride=1, padding=1, bias=False).cuda()
+    m2.weight = m.weight                                   # (c) shared weight
+    x = torch.randn(4, 64, 96, 176, device="cuda")
+
+    def run(mode):
+        m.zero_grad(set_to_none=True)
+        if mode == "zero_fill":
+            m(x).sum().backward()
+            m.zero_grad(set_to_none=False)
+        xin = x.clone().requires_grad_(True)
+        if mode == "shared":
+            (m2(torch.relu(m(xin))) * 0.5).sum().backward()
+        else:
+            (m(xin) * 0.25).sum().backward()
+            if mode == "twice":
+                (m(xin) * 0.75).sum().backward()
+        torch.cuda.synchronize()
+        return [m.weight.grad.clone(), m.bias.grad.clone(), xin.grad.clone()]
+
+    for mode in ("twice", "zero_fill", "shared"):
+        streams.ENABLED = False
+        try:
+            ref = run(mode)
+        finally:
+            streams.ENABLED = True
+        for _ in range(5):
+            got = run(mode)
+            for a, b in zip(got, ref):
+                assert torch.equal(a, b), mode
+    assert not any(st["pending"] or st["keep"] or st["targets"] for st in streams._state.values())
+
+
 @pytest.mark.parametrize("B,cin,cout,H,W,cfg", [
     (2, 32, 64, 12, 22, None),       # map smaller than one 16-wide tile pair, 4-row tiles
     (1, 64, 32, 24, 44, None),       # 32 output channels: one 16-block per wave
