@@ -74,12 +74,26 @@ def parse():
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP events (roofline=null)")
     ap.add_argument("--kernel-report", default="", help="write the per-kernel roofline table to this JSON file")
+    ap.add_argument("--config", default=None, choices=["c2", "c3", "c4", "c5"],
+                    help="BASELINE.json configs[1..4]: c2 = forward-only GU encoder, one 64-ring scan, bs 1, fp32; c3 = the "
+                         "headline line (default): full fwd+bwd, bs 4, fp32; c4 = the same step with bf16 conv operands / "
+                         "trunk features (per-GPU part at N = 1, the full config with --gpus 8); c5 = 128-ring scans at 0.1 m "
+                         "voxels, bs 2 per GPU, GU encoder fwd+bwd (its 256 BEV channels do not fit the head: SURVEY 8d)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous / timing protocol only, over gloo on the CPU with an empty step: what the "
                          "non-GPU test of `--gpus N` runs (no kernels, value is not a measurement)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="f32 = C3 (the headline line); bf16 = the single-GPU half of C4: apex.amp O1, bf16 conv operands")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.config is None:
+        args.config = "c4" if args.dtype == "bf16" else "c3"
+    if args.config == "c4":
+        args.dtype = "bf16"
+    if args.config == "c5" and args.batch == 4 and "--batch" not in " ".join(sys.argv):
+        args.batch = 2                      # C5: bs 2 frame pairs per GPU
+    if args.config == "c2":
+        args.batch = 1
+    return args
 
 
 def pin_to_quiet_cores(n=8, part=(0, 1)):
@@ -441,6 +455,225 @@ def cpu_baseline(args):
                       "oracle C/OpenMP sparse ops + torch-CPU dense head; %.1f s" % (args.rings, dt)}
 
 
+# --------------------------------------------------------------------------------------------- C2 / C5: GU encoder
+def encoder_setup(cfg, device, frames, seed0=0):
+    """The GU encoder (SpMiddleFHDWithCov2_3 incl. covariance branch) of the shipped config with resident, voxelized
+    inputs (C2 times the encoder on inputs already voxelized on the device).  C5: 128-ring scans, 0.1 m
+    cubic voxels, max_voxels lifted to 2^18."""
+    import spconv
+    from rslo.models import middle
+    from rslo_amd import synthetic as S
+    dev = torch.device(device)
+    if cfg == "c2":
+        n_el, vsize, max_vox = 64, S.VOXEL_SIZE, S.MAX_VOXELS
+    else:
+        n_el, vsize, max_vox = 128, S.VOXEL_SIZE_DENSE, 1 << 18
+    gen = spconv.utils.VoxelGenerator(list(vsize), list(S.PC_RANGE), S.MAX_POINTS_PER_VOXEL, max_vox)
+    grid = gen.grid_size
+    torch.manual_seed(7)
+    enc = middle.get_middle_class("SpMiddleFHDWithCov2_3")(
+        [1] + grid[::-1].tolist() + [7], bn_type="None", use_leakyReLU=True, num_input_features=7, num_filters_down1=[],
+        num_filters_down2=[]).to(dev).train()
+    clouds = [S.scan(n_el=n_el, scan_seed=seed0 + i) for i in range(frames)]
+    return enc, gen, clouds, max_vox
+
+
+def encoder_inputs(gen, clouds, max_vox, dev):
+    from rslo_amd import capi
+    if dev.type == "cuda":
+        res = gen.generate_many([torch.from_numpy(c).to(dev) for c in clouds], max_vox)
+    else:
+        res = []
+        for c in clouds:
+            r = gen.generate(c, max_vox)
+            if isinstance(r, dict):
+                r = tuple(r[k] for k in ("voxels", "coordinates", "num_points_per_voxel"))
+            res.append(tuple(torch.as_tensor(a) for a in r[:3]))
+    feats = torch.cat([capi.vfe_mean(v, n) for v, c, n in res], 0)
+    coords = torch.cat([torch.cat([torch.full((c.shape[0], 1), b, dtype=torch.int32, device=c.device), c], 1)
+                        for b, (v, c, n) in enumerate(res)], 0)
+    return feats, coords
+
+
+def encoder_cpu_baseline(args):
+    """One frame of the same encoder pass over the oracle backend on the host cores."""
+    from oracle import cpu_backend
+    cfg = args.config
+    backward = cfg == "c5"
+    threads = torch.get_num_threads()
+    with cpu_backend.patched():
+        enc, gen, clouds, max_vox = encoder_setup(cfg, "cpu", 1)
+        feats, coords = encoder_inputs(gen, clouds, max_vox, torch.device("cpu"))
+        t0 = time.time()
+        n = 0
+        while n < 12 and (n == 0 or time.time() - t0 < 10.0):       # a bounded sample: >= 10 s or 12 passes
+            x = feats.clone().requires_grad_(backward)
+            bev, cov = enc(x, coords, 1)
+            if backward:
+                (bev.square().mean() + cov.square().mean()).backward()
+                enc.zero_grad(set_to_none=True)
+            n += 1
+        dt = (time.time() - t0) / n
+    return {"value": round(0.5 / dt, 4), "unit": "frame-pairs/s", "cores": int(threads), "cpu_model": cpu_model(),
+            "kind": "port",
+            "sample": "%d passes over 1 frame (%d voxels) = half a frame pair each, rulebooks + 20 sparse convs + dense(), %s, "
+                      "oracle C/OpenMP; %.2f s per pass" % (n, feats.shape[0], "forward + backward" if backward else "forward", dt)}
+
+
+def run_encoder(args, world, rank, local_rank, dist_on, dev):
+    """C2 / C5 (BASELINE.json configs[1], configs[4]) through the same entry point and JSON schema as the C3 line.
+    A step = one pass of the GU encoder over this rank's resident frames: rulebook chain (site index, 11 rulebooks) +
+    20 sparse convolutions + dense(); C5 adds the backward pass (data + weight gradients) and, at N > 1, the flat
+    gradient all-reduce.  Unit of work = frame pairs (2 frames), like every other config."""
+    import torch.distributed as dist
+    import rslo_amd  # noqa: F401
+    from rslo_amd import capi
+    import spconv
+    capi.lib()
+    cfg = args.config
+    backward = cfg == "c5"
+    frames = 1 if cfg == "c2" else 2 * args.batch
+    enc, gen, clouds, max_vox = encoder_setup(cfg, dev, frames, seed0=rank * frames)
+    feats, coords = encoder_inputs(gen, clouds, max_vox, dev)
+    if dist_on:
+        from rslo.utils.distributed_utils import average_gradients, broadcast_params
+        broadcast_params(enc, 0)
+
+    def step():
+        x = feats.detach().requires_grad_(backward)
+        bev, cov = enc(x, coords, frames)
+        if backward:
+            (bev.square().mean() + cov.square().mean()).backward()
+            if dist_on:
+                average_gradients(enc, mean=True)
+            enc.zero_grad(set_to_none=True)
+        return bev
+
+    probe = ConvProbe(capi)
+    use_probe = (not args.no_kernel_events) and rank == 0
+    if use_probe:
+        probe.install()
+    for _ in range(args.warmup):
+        step()
+
+    def barrier():
+        if dist_on:
+            dist.barrier()
+        torch.cuda.synchronize()
+    barrier()
+    probe_steps = min(3, args.steps)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        if use_probe and i == args.steps - probe_steps:
+            probe.enabled = probe.keep_tables = True
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    probe.enabled = False
+    per_rank = [elapsed]
+    if dist_on:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        gathered = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(gathered, t)
+        per_rank = [float(g.item()) for g in gathered]
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    line = None
+    if rank == 0:
+        roof = None
+        if use_probe and probe.records:
+            _, roof = probe.summarize(probe_steps)
+            probe.uninstall()
+        # algorithmic work of the pass: SURVEY.md 8d formula on the measured pair counts (backward = dgrad + wgrad ~ 2x)
+        plan = enc.plan(coords, frames)
+        convs = [m for seq in (enc.middle_conv, enc.middle_conv_tail, enc.middle_cov_deconv) for m in seq
+                 if isinstance(m, spconv.SparseConvolution)]
+        byts = fl = 0
+        for m in convs:
+            rb = plan.indice_dict[m.indice_key]
+            tb = rb.nbrT if m.inverse else rb.nbr
+            P = int((tb >= 0).sum())
+            n_out, K = tb.shape
+            byts += P * m.in_channels * 4 + n_out * m.out_channels * 4 + 8 * P + K * m.in_channels * m.out_channels * 4
+            fl += 2 * P * m.in_channels * m.out_channels
+        mult = 3.0 if backward else 1.0
+        ms = 1e3 * elapsed / args.steps
+        extras = {}
+        if cfg == "c2":       # the same pass on rulebooks planned once, eager and replayed from one hipGraph
+            def planned():
+                return enc(feats, coords, frames, plan=plan)[0]
+            with torch.no_grad():
+                for _ in range(5):
+                    planned()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    planned()
+                torch.cuda.synchronize()
+                extras["ms_per_pass_rulebooks_planned_once"] = round(1e3 * (time.perf_counter() - t1) / args.steps, 4)
+                try:
+                    side = torch.cuda.Stream()
+                    with torch.cuda.stream(side):
+                        for _ in range(3):
+                            planned()
+                    torch.cuda.synchronize()
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph):
+                        out_static = planned()
+                    for _ in range(5):
+                        graph.replay()
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for _ in range(args.steps):
+                        graph.replay()
+                    torch.cuda.synchronize()
+                    extras["ms_per_pass_planned_one_hipgraph"] = round(1e3 * (time.perf_counter() - t1) / args.steps, 4)
+                    extras["hipgraph_equals_eager"] = bool(torch.equal(out_static, planned()))
+                except Exception as e:       # recorded, not fatal
+                    extras["hipgraph_error"] = repr(e)[:200]
+        pairs_per_step = frames / 2.0
+        line = {
+            "metric": "frame-pairs/sec %s GU encoder (synthetic %d-ring scans, ~%dk pts)" % (
+                "fwd+bwd" if backward else "forward-only", 128 if backward else 64, clouds[0].shape[0] // 1000),
+            "value": round(pairs_per_step * world * args.steps / elapsed, 3), "unit": "frame-pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": dict({
+                "workload": ("C2: forward-only GU encoder + covariance branch, 1 x 64-ring scan (%d points -> %d voxels), bs 1, "
+                             "fp32; a step = rulebook chain + 20 sparse convs + dense() on a resident voxelized frame "
+                             "(= half a frame pair)" % (clouds[0].shape[0], feats.shape[0])) if cfg == "c2" else
+                            ("C5: GU encoder + covariance branch fwd+bwd, %d x 128-ring scans (%d points/frame, %d voxels in all), "
+                             "0.1 m voxels, sparse shape %s, bs %d frame pairs/GPU, fp32, dp%d; the 256-channel BEV map does "
+                             "not fit the head (SURVEY 8d): encoder only" % (frames, clouds[0].shape[0], feats.shape[0],
+                                                                            [int(v) for v in enc.sparse_shape], args.batch, world)),
+                "frames_per_step_per_gpu": frames, "voxels": int(feats.shape[0]), "sparse_convs": len(convs),
+                "lib_sha256": lib_hash(),
+                "algorithmic_GB_per_step": round(mult * byts / 1e9, 3), "algorithmic_GFLOP_per_step": round(mult * fl / 1e9, 2),
+                "whole_pass_algorithmic_GBps": round(mult * byts / ms / 1e6, 1),
+                "whole_pass_hbm_roofline_frac": round(mult * byts / ms / 1e6 / HBM_PEAK_GBS, 4),
+                "ideal_ms_at_8TBps": round(mult * byts / 8e9, 4)}, **extras),
+            "roofline": roof, "cpu_baseline": None}
+        if dist_on:
+            try:
+                ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:
+                ver = None
+            line["rccl"] = {"ranks": world, "version": ver, "backend": dist.get_backend(),
+                            "ms_per_step_min": round(1e3 * min(per_rank) / args.steps, 3),
+                            "ms_per_step_max": round(1e3 * max(per_rank) / args.steps, 3)}
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = encoder_cpu_baseline(args)
+            except Exception as e:
+                line["cpu_baseline"] = {"error": repr(e)}
+    if dist_on:
+        dist.barrier()
+        dist.destroy_process_group()
+    _flush_c_stdio()
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+
+
 # --------------------------------------------------------------------------------------------- N > 1 launcher
 def _free_port():
     import socket
@@ -512,7 +745,7 @@ def main():
     if args.cpu_baseline_only:          # child of a pinned run: the CPU baseline on the host's full affinity mask
         sys.path.insert(0, ROOT) if ROOT not in sys.path else None
         import rslo_amd  # noqa: F401
-        print(json.dumps(cpu_baseline(args)))
+        print(json.dumps(encoder_cpu_baseline(args) if args.config in ("c2", "c5") else cpu_baseline(args)))
         return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:      # no launcher around us: start the ranks ourselves
         sys.exit(spawn_ranks(args))
@@ -547,6 +780,9 @@ def main():
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if dist_on else 0)
+
+    if args.config in ("c2", "c5"):
+        return run_encoder(args, world, rank, local_rank, dist_on, dev)
 
     pinned = None
     orig_affinity = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
@@ -758,7 +994,7 @@ def main():
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "%s: full fwd+bwd (voxelize + GU encoder + BEV head/vote + chamfer/ICP loss"
                                    "%s), bs=%d frame pairs/GPU, %s, %d-ring scans (~%d pts/frame), dp%d"
-                                   % ("C3" if args.dtype == "f32" else "C4 (per-GPU part)",
+                                   % ("C3" if args.dtype == "f32" else ("C4" if world == 8 else "C4 (per-GPU part)"),
                                       "" if args.no_optim else " + Adam step", args.batch,
                                       "fp32" if args.dtype == "f32" else
                                       "bf16 conv operands / bf16 encoder trunk features, fp32 accumulate + masters (amp O1)",
