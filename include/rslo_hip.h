@@ -149,8 +149,19 @@ RSLO_API int rslo_spconv_fwd_split(const float *in, int cin, const void *Ws, con
 /*     Tiling of k_spconv_v6 behind rslo_spconv_fwd_split: a tile is 16*rbw rows (rbw 1, 2, 4) and ks waves (1, 2, 4) share
  *     it, each walking 1/ks of the tile's active kernel offsets; their accumulators are added through LDS in wave order
  *     (a fixed summation order, results within fp32 rounding of the one-wave form).  0 = the library chooses per layer
- *     shape (default: 32 rows and two waves except for 32 -> 32 channels).  Environment: RSLO_SPCONV_RBW / _KS. */
+ *     shape (default: 32 rows and two waves except for 32 -> 32 channels).  Same as the switches spconv_rbw / spconv_ks. */
 RSLO_API void rslo_spconv_set_tiling(int rbw, int ks);
+/*     Tuning switches of the launch code.  The library reads NO environment variable: tile shapes and kernel variants that
+ *     exist for A/B measurements and for the parity tests that pin every tiling against the oracle are set through these
+ *     calls (process-wide; the defaults are the measured choices).  Names (rslo_tuning_name(i), i = 0 .. until NULL):
+ *     conv2d_wgrad_s2_fullres, conv2d_wgrad_nb, conv2d_wgrad_wgs, conv2d_fwd_tr, conv2d_fwd_mtw, conv2d_fwd_occ,
+ *     conv2d_fwd_kc, conv2d_fwd_lean, conv2d_fwd_xsc, conv2d_s2_mtw, conv2d_s2_xsc, bn_small_rc, spconv_rbw, spconv_ks,
+ *     spconv_v, spconv_wgrad_split, wgrad_xcd, vfe_lds, chamfer (meanings: csrc/rslo_common.h RsloTune).  Every setting
+ *     computes the same products; only tiling, summation grouping and launch geometry change.  Unknown name -> RSLO_EINVAL.
+ *     (The reference has no counterpart: spconv / cuDNN pick their algorithms internally.) */
+RSLO_API int rslo_tuning_set(const char *name, int value);
+RSLO_API int rslo_tuning_get(const char *name, int *value);
+RSLO_API const char *rslo_tuning_name(int index);
 /*     bf16 feature path (BASELINE config C4: bf16 features, int32 rulebook, fp32 accumulate): in / out are bf16 rows
  *     [N,C], Wb the weights rounded to bf16 in MFMA operand order (rslo_weight_to_bf16, K*cin*cout*2 bytes; transpose
  *     = 1 for the data gradient), bias fp32.  Channel counts 32 / 64. */

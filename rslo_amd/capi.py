@@ -42,6 +42,9 @@ SIGNATURES = {
     "rslo_weight_split_many": (C.c_int, [_vp, _i, _i64, _vp]),
     "rslo_spconv_fwd_split": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, C.c_float, _vp, _vp]),
     "rslo_spconv_set_tiling": (None, [_i, _i]),
+    "rslo_tuning_set": (C.c_int, [C.c_char_p, _i]),
+    "rslo_tuning_get": (C.c_int, [C.c_char_p, _vp]),
+    "rslo_tuning_name": (C.c_char_p, [_i]),
     "rslo_weight_to_bf16": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "rslo_spconv_fwd_bf16": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, C.c_float, _vp, _vp]),
     "rslo_spconv_wgrad_ws_bytes": (_sz, [_i64, _i, _i, _i]),
@@ -172,6 +175,35 @@ def lib():
             fn.argtypes = args
         _lib = l
     return _lib
+
+
+def tuning_set(name, value):
+    """rslo_tuning_set: an explicit switch of the launch code (the library reads no environment variable)."""
+    _chk(lib().rslo_tuning_set(name.encode(), int(value)), "rslo_tuning_set")
+
+
+def tuning_get(name):
+    v = C.c_int(0)
+    _chk(lib().rslo_tuning_get(name.encode(), C.byref(v)), "rslo_tuning_get")
+    return v.value
+
+
+class tuning:
+    """with capi.tuning(conv2d_fwd_kc=2, ...): switches set for the block and restored afterwards (tests, A/B scripts)."""
+
+    def __init__(self, **kw):
+        self.kw, self.old = kw, {}
+
+    def __enter__(self):
+        for k, v in self.kw.items():
+            self.old[k] = tuning_get(k)
+            tuning_set(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            tuning_set(k, v)
+        return False
 
 
 def _chk(rc, name):

@@ -608,7 +608,7 @@ extern "C" int rslo_bn2d_fwd_local(const float *x, const float *res, const float
   RSLO_CHECK_ARG(x && ws && save_mean && save_invstd && y && N >= 1 && C >= 1 && HW >= 1, "rslo_bn2d_fwd_local: bad arguments");
   RSLO_CHECK_ARG(ws_bytes >= rslo_bn2d_ws_bytes(N, C, HW), "rslo_bn2d_fwd_local: workspace too small");
   if ((int64_t)N * HW <= BN_SMALL_MAX) {
-    static const int rc = getenv("RSLO_BN_SMALL_RC") ? atoi(getenv("RSLO_BN_SMALL_RC")) : 1;      // 0: the two-pass loops
+    const int rc = rslo_tune(RSLO_TUNE_BN_SMALL_RC);      // 0: the two-pass loops
     if (rc && (int64_t)N * HW <= 256 * BN_RC)
       hipLaunchKernelGGL((k_bn2d_fwd_small_rc<256>), dim3(C), dim3(256), 0, (hipStream_t)stream, x, res, gamma, beta, N, C,
                          HW, eps, momentum, act_slope, running_mean, running_var, save_mean, save_invstd, y);
@@ -648,7 +648,7 @@ extern "C" int rslo_bn2d_bwd_local(const float *dy, const float *y, const float 
   RSLO_CHECK_ARG(!has_act || y, "rslo_bn2d_bwd_local: y is needed for the activation mask");
   RSLO_CHECK_ARG(ws_bytes >= rslo_bn2d_ws_bytes(N, C, HW), "rslo_bn2d_bwd_local: workspace too small");
   if ((int64_t)N * HW <= BN_SMALL_MAX) {
-    static const int rc = getenv("RSLO_BN_SMALL_RC") ? atoi(getenv("RSLO_BN_SMALL_RC")) : 1;
+    const int rc = rslo_tune(RSLO_TUNE_BN_SMALL_RC);
     if (rc && (int64_t)N * HW <= 256 * BN_RC)
       hipLaunchKernelGGL((k_bn2d_bwd_small_rc<256>), dim3(C), dim3(256), 0, (hipStream_t)stream, dy, y, x, gamma, save_mean,
                          save_invstd, N, C, HW, act_slope, has_act, dx, dres, dgamma, dbeta);

@@ -162,11 +162,11 @@ extern "C" int rslo_chamfer_grid_nn(const float *xyz1, const float *xyz2, int B,
                                     void *stream);
 
 // which search runs behind rslo_chamfer_nn*: the pruned one once the clouds are large enough to amortise its
-// five small launches (same results either way); RSLO_CHAMFER=brute|grid forces one
+// five small launches (same results either way); the `chamfer` switch forces one (1 exhaustive, 2 pruned)
 static bool chamfer_use_grid(int N, int M) {
-  static const char *force = getenv("RSLO_CHAMFER");
-  if (force && force[0] == 'b') return false;
-  if (force && force[0] == 'g') return true;
+  const int force = rslo_tune(RSLO_TUNE_CHAMFER);
+  if (force == 1) return false;
+  if (force == 2) return true;
   return N >= 1024 && M >= 2048;
 }
 

@@ -451,14 +451,9 @@ static int conv2d_plan(int B, int cin, int cout, int H, int W, int stride, Conv2
   // library on the full-resolution map (256->128 at 96x176: 170-210 us vs 131 us); smaller maps win (35-42 vs 49-57 us)
   // As leaf work on the weight-gradient stream (rslo_amd/streams.py) the difference no longer shows in the step, and the
   // hand-written kernel is bit-reproducible where the library's split-K kernels use atomics: it is the default;
-  // RSLO_CONV2D_WGRAD_S2_FULLRES=0 hands the full-resolution layer back to the library.
-  static const int s2_full = getenv("RSLO_CONV2D_WGRAD_S2_FULLRES") ? atoi(getenv("RSLO_CONV2D_WGRAD_S2_FULLRES")) : 1;
-  if (stride == 2 && (int64_t)H * W >= 96 * 176 && !s2_full) return 0;
-  static int nb_pref = -1;
-  if (nb_pref < 0) {
-    const char *e = getenv("RSLO_CONV2D_NB");
-    nb_pref = e ? atoi(e) : 2;
-  }
+  // conv2d_wgrad_s2_fullres = 0 hands the full-resolution layer back to the library.
+  if (stride == 2 && (int64_t)H * W >= 96 * 176 && !rslo_tune(RSLO_TUNE_CONV2D_WGRAD_S2_FULLRES)) return 0;
+  const int nb_pref = rslo_tune(RSLO_TUNE_CONV2D_WGRAD_NB);
   *nb = (cout % 64 == 0 && nb_pref == 4) ? 4 : 2;
   gm->B = B; gm->cin = cin; gm->cout = cout;
   gm->Hin = H; gm->Win = W;
@@ -470,12 +465,8 @@ static int conv2d_plan(int B, int cin, int cout, int H, int W, int stride, Conv2
   gm->n_cout_tiles = cout / (16 * *nb);
   const int tiles = gm->n_cin_tiles * gm->n_cout_tiles;
   const int n_chunks = B * gm->cpi;
-  static int target = -1;
-  if (target < 0) {
-    const char *e = getenv("RSLO_CONV2D_WGS");
-    target = e ? atoi(e) : 768;
-    if (target < 1) target = 768;
-  }
+  int target = rslo_tune(RSLO_TUNE_CONV2D_WGRAD_WGS);
+  if (target < 1) target = 768;
   int s = (int)rslo_cdiv(target, tiles);
   const int max_s = n_chunks / 8 > 0 ? n_chunks / 8 : 1;   // at least 2 chunks per wave
   if (s > max_s) s = max_s;
@@ -699,8 +690,8 @@ __device__ __forceinline__ bool conv2d_xcd_tile_id(int id, int xsc, int npix, in
 }
 // channel-class count for a layer: the divisor of ny (<= 8, power of two) with the least fabric traffic; the environment
 // variable `name` forces it for A/B runs (-1: plain grid)
-static int conv2d_xcd_split(const char *name, int ny, double weight_bytes, double input_bytes) {
-  const int env = getenv(name) ? atoi(getenv(name)) : 0;
+static int conv2d_xcd_split(RsloTune which, int ny, double weight_bytes, double input_bytes) {
+  const int env = rslo_tune(which);
   if (env < 0) return 0;
   int best = 1;
   double best_t = 0;
@@ -947,16 +938,11 @@ __global__ __launch_bounds__(256 * KC, OCC) void k_conv2d_fwd(const float *__res
 }
 
 
-static int g_c2f_occ = 0;      // experiments: waves per SIMD the one-tap-ahead variants are compiled for (0: default kernels)
+#define g_c2f_occ rslo_tune(RSLO_TUNE_CONV2D_FWD_OCC)      // waves per SIMD of the one-tap-ahead variants (0: default kernels)
 static int conv2d_fwd_plan(int B, int cin, int cout, int H, int W, int *tr, int *mtw) {
   if (B <= 0 || H <= 0 || W <= 0 || cin % 32 != 0 || cout % 32 != 0) return 0;
   if ((int64_t)B * cin * H * W * 4 >= ((int64_t)1 << 31)) return 0;      // per-lane input offsets are 31-bit byte offsets
-  static int cfg_tr = -1, cfg_mtw = -1;
-  if (cfg_tr < 0) {
-    const char *e = getenv("RSLO_CONV2D_FWD_CFG");      // "TR,MTW[,OCC]" forces one configuration (experiments)
-    cfg_tr = cfg_mtw = 0;
-    if (e) sscanf(e, "%d,%d,%d", &cfg_tr, &cfg_mtw, &g_c2f_occ);
-  }
+  const int cfg_tr = rslo_tune(RSLO_TUNE_CONV2D_FWD_TR), cfg_mtw = rslo_tune(RSLO_TUNE_CONV2D_FWD_MTW);
   // measured inside the training step (profiles/README.md): 4-row tiles, one 16-channel block per wave and the whole
   // chunk's weight operands prefetched 9 taps ahead win on every map size of the head (45 vs 67 us on 48x88, 23 vs 54 us
   // on 12x22 against the 8-row / one-tap-ahead configurations, which stay selectable for experiments)
@@ -1034,23 +1020,23 @@ static int conv2d_fwd_launch(const float *in, const void *Ws, const float *bias,
   const double w_bytes = (lp ? 1.0 : 3.0) * 18.0 * cin * cout, in_bytes = 4.0 * B * cin * H * W * 1.5;
   gm.npix = B * gm.tiles_x * gm.tiles_y;
   gm.ny = cout / (32 * mtw);
-  gm.xsc = conv2d_xcd_split("RSLO_CONV2D_FWD_XSC", gm.ny, w_bytes, in_bytes);
+  gm.xsc = conv2d_xcd_split(RSLO_TUNE_CONV2D_FWD_XSC, gm.ny, w_bytes, in_bytes);
   const dim3 grid = conv2d_xcd_grid(gm.xsc, gm.npix, gm.ny);
   hipStream_t st = (hipStream_t)stream;
   const unsigned short *ws = (const unsigned short *)Ws;
   // two wave sets per workgroup (channel chunks alternate between them) when the launch leaves CUs empty and the chain
-  // is long (RSLO_CONV2D_FWD_KC = 1 | 2 forces it).  Measured (scripts/bench_conv2d_fwd.py): 256 -> 256 at 12x22 (192
+  // is long (conv2d_fwd_kc = 1 | 2 forces it).  Measured (scripts/bench_conv2d_fwd.py): 256 -> 256 at 12x22 (192
   // workgroups, 8 chunks) 23.7 -> 19.0 us; 128 -> 128 at 24x44 (288 workgroups, 4 chunks) 17.1 -> 21.4 us, 512 -> 128 at
   // 24x44 50.9 -> 61.0 us, 48x88 and larger 44 -> 62 us: every wave streams its own weight operands (27 KB per chunk)
   // through the CU's vector L1, and a second wave set doubles that traffic wherever the CUs are already occupied
-  static const int kc_env = getenv("RSLO_CONV2D_FWD_KC") ? atoi(getenv("RSLO_CONV2D_FWD_KC")) : 0;
+  const int kc_env = rslo_tune(RSLO_TUNE_CONV2D_FWD_KC);
   const int64_t wgs4 = (int64_t)B * gm.tiles_x * rslo_cdiv(H, 4) * (cout / 32);
   const bool kc2 = cin >= 64 && (kc_env ? kc_env == 2 : (cin >= 256 && wgs4 <= 200));
   if (lp) {       // bf16 operands (C4): the default tile configuration only
     gm.tiles_y = (int)rslo_cdiv(H, 4);
     gm.npix = B * gm.tiles_x * gm.tiles_y;
     gm.ny = cout / 32;
-    gm.xsc = conv2d_xcd_split("RSLO_CONV2D_FWD_XSC", gm.ny, w_bytes, in_bytes);
+    gm.xsc = conv2d_xcd_split(RSLO_TUNE_CONV2D_FWD_XSC, gm.ny, w_bytes, in_bytes);
     const dim3 grid1 = conv2d_xcd_grid(gm.xsc, gm.npix, gm.ny);
     if (kc2) hipLaunchKernelGGL((k_conv2d_fwd<4, 1, true, true, 2>), grid1, dim3(512), 0, st, in, ws, bias, gm, out);
     else hipLaunchKernelGGL((k_conv2d_fwd<4, 1, true, true>), grid1, dim3(256), 0, st, in, ws, bias, gm, out);
@@ -1063,8 +1049,8 @@ static int conv2d_fwd_launch(const float *in, const void *Ws, const float *bias,
   // 9-tap kernel -> 4 workgroups per CU at 104 registers -> 5): 128 -> 128 at 48x88 41.6 -> 38.0 -> 35.7 us, 64 -> 64 at
   // 96x176 44.1 -> 36.4 -> 35.2, 64 -> 192 at 96x176 114.8 -> 92.2 -> 87.8, 192 -> 64 103.8 -> 94.1 -> 89.7, 256 -> 64 at
   // 48x88 (576 workgroups) 47.0 -> 42.1; 128 -> 128 at 24x44 (288 workgroups) 16.5 -> 17.4 and 256 -> 256 at 12x22
-  // 18.6 -> 25.0 keep the 9-tap kernel.  RSLO_CONV2D_FWD_LEAN=0 / 1 forces it off / on.
-  static const int lean_env = getenv("RSLO_CONV2D_FWD_LEAN") ? atoi(getenv("RSLO_CONV2D_FWD_LEAN")) : -1;
+  // 18.6 -> 25.0 keep the 9-tap kernel.  conv2d_fwd_lean = 0 / 1 forces it off / on.
+  const int lean_env = rslo_tune(RSLO_TUNE_CONV2D_FWD_LEAN);
   if (tr == 4 && mtw == 1 && !kc2 && !g_c2f_occ && (lean_env < 0 ? wgs4 >= 512 : lean_env == 1)) {
     hipLaunchKernelGGL((k_conv2d_fwd<4, 1, false, false, 1, 5>), grid, dim3(256), 0, st, in, ws, bias, gm, out);
     RSLO_CHECK_LAUNCH("k_conv2d_fwd(lean)");
@@ -1269,12 +1255,12 @@ extern "C" int rslo_conv2d_fwd_s2(const float *in, const void *Ws, int B, int ci
   // two 16-channel blocks per wave (64 output channels per workgroup) when the launch still fills the chip: the staged
   // halo and its operand split are shared by twice the MFMAs (256 -> 128 at 96x176: 237 -> 218 us, its 1x1: 41 -> 31 us;
   // the smaller stages lose, 44 -> 62 us, and keep 32 channels)
-  static const int mtw_env = getenv("RSLO_CONV2D_S2_MTW") ? atoi(getenv("RSLO_CONV2D_S2_MTW")) : 0;
+  const int mtw_env = rslo_tune(RSLO_TUNE_CONV2D_S2_MTW);
   const int64_t wgs32 = (int64_t)B * gm.tiles_x * gm.tiles_y * (cout / 32);
   const int mtw = (cout % 64 == 0 && (mtw_env ? mtw_env == 2 : wgs32 >= 1024)) ? 2 : 1;
   gm.npix = B * gm.tiles_x * gm.tiles_y;
   gm.ny = cout / (32 * mtw);
-  gm.xsc = conv2d_xcd_split("RSLO_CONV2D_S2_XSC", gm.ny, 6.0 * ksize * ksize * cin * cout, 4.0 * B * cin * H * W * (ksize == 3 ? 1.5 : 0.25));
+  gm.xsc = conv2d_xcd_split(RSLO_TUNE_CONV2D_S2_XSC, gm.ny, 6.0 * ksize * ksize * cin * cout, 4.0 * B * cin * H * W * (ksize == 3 ? 1.5 : 0.25));
   const dim3 grid = conv2d_xcd_grid(gm.xsc, gm.npix, gm.ny);
   hipStream_t st = (hipStream_t)stream;
   const unsigned short *ws = (const unsigned short *)Ws;
@@ -1335,14 +1321,14 @@ extern "C" int rslo_conv2d_dgrad_s2_add(const float *dout, const void *Ws, const
       }
     }
   // all four classes of a tile from one staged halo of dout (9 tap products in total for 3x3)
-  static const int mtw_env = getenv("RSLO_CONV2D_S2_MTW") ? atoi(getenv("RSLO_CONV2D_S2_MTW")) : 0;
+  const int mtw_env = rslo_tune(RSLO_TUNE_CONV2D_S2_MTW);
   const int64_t wgs32 = (int64_t)B * gm.tiles_x * gm.tiles_y * (cin / 32);
   (void)wgs32;      // measured: 64 channels per workgroup loses on the four-class data gradient (138 vs 100 us on the
                     // largest layer: 4 x 2 x 2 accumulator tiles per wave), so it is opt-in here
   const int mtw = (cin % 64 == 0 && mtw_env == 2) ? 2 : 1;
   gm.npix = B * gm.tiles_x * gm.tiles_y;
   gm.ny = cin / (32 * mtw);
-  gm.xsc = conv2d_xcd_split("RSLO_CONV2D_S2_XSC", gm.ny, 6.0 * ksize * ksize * cin * cout, 4.0 * B * cout * gm.Hi * gm.Wi * 1.5);
+  gm.xsc = conv2d_xcd_split(RSLO_TUNE_CONV2D_S2_XSC, gm.ny, 6.0 * ksize * ksize * cin * cout, 4.0 * B * cout * gm.Hi * gm.Wi * 1.5);
   const dim3 grid = conv2d_xcd_grid(gm.xsc, gm.npix, gm.ny);
   if (mtw == 2)
     hipLaunchKernelGGL((k_conv2d_str<4, 1, 4, 2>), grid, dim3(256), 0, (hipStream_t)stream, dout, (const unsigned short *)Ws, gm, din);

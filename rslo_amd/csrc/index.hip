@@ -708,7 +708,7 @@ extern "C" int rslo_vfe_mean(const float *voxels, const int32_t *num_points, int
   RSLO_CHECK_ARG(F <= 16, "vfe_mean: F > 16 unsupported");
   if (M == 0) return RSLO_OK;
   const size_t lds = (size_t)4 * 64 * T * F * sizeof(float);
-  static const bool lds_on = !(getenv("RSLO_VFE_LDS") && getenv("RSLO_VFE_LDS")[0] == '0');
+  const bool lds_on = rslo_tune(RSLO_TUNE_VFE_LDS) != 0;
   if (lds_on && lds <= 80 * 1024 && ((uintptr_t)voxels & 15) == 0) {
     static bool attr_set = false;
     if (!attr_set) {

@@ -38,6 +38,34 @@ extern "C" void rslo_set_error(const char *fmt, ...);
 
 static inline int64_t rslo_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Tuning switches of the launch code (rslo_tuning_set / rslo_tuning_get, include/rslo_hip.h).  The library reads NO
+// environment variable: tile shapes and variants that exist for A/B measurements and for the parity tests that pin
+// every tiling against the oracle are set explicitly by the caller; the defaults (tuning.hip) are the measured choices.
+enum RsloTune {
+  RSLO_TUNE_CONV2D_WGRAD_S2_FULLRES,   // 1: full-resolution stride-2 weight gradient on the hand-written kernel
+  RSLO_TUNE_CONV2D_WGRAD_NB,           // 16-channel blocks per wave of the dense weight gradient (2 | 4)
+  RSLO_TUNE_CONV2D_WGRAD_WGS,          // workgroup target of its slab split
+  RSLO_TUNE_CONV2D_FWD_TR,             // dense forward: rows per tile (0 = default 4; 4 | 8)
+  RSLO_TUNE_CONV2D_FWD_MTW,            //   16-channel blocks per wave (0 = default 1; 1 | 2)
+  RSLO_TUNE_CONV2D_FWD_OCC,            //   waves per SIMD the one-tap-ahead variants are compiled for (0 = default kernels)
+  RSLO_TUNE_CONV2D_FWD_KC,             //   wave sets per workgroup (0 = choose; 1 | 2)
+  RSLO_TUNE_CONV2D_FWD_LEAN,           //   96-register one-tap-ahead variant (-1 = choose; 0 | 1)
+  RSLO_TUNE_CONV2D_FWD_XSC,            //   XCD channel classes (0 = choose, -1 = plain grid; 1 | 2 | 4 | 8)
+  RSLO_TUNE_CONV2D_S2_MTW,             // stride-2 kernels: 16-channel blocks per wave (0 = choose; 1 | 2)
+  RSLO_TUNE_CONV2D_S2_XSC,             //   XCD channel classes, as above
+  RSLO_TUNE_BN_SMALL_RC,               // 1: register-cached single-launch BatchNorm on small maps; 0: two-pass loops
+  RSLO_TUNE_SPCONV_RBW,                // k_spconv_v6: 16-row blocks per tile (0 = choose; 1 | 2 | 4)
+  RSLO_TUNE_SPCONV_KS,                 //   waves per tile (0 = choose; 1 | 2 | 4)
+  RSLO_TUNE_SPCONV_V,                  // fp32-MFMA sparse forward: 0 = choose, 100 + RBW forces v3's row blocking, else k_spconv
+  RSLO_TUNE_SPCONV_WGRAD_SPLIT,        // 1: split-bf16 sparse weight gradient (k_wgrad3) on 32/64 channels; 0: fp32 MFMA
+  RSLO_TUNE_WGRAD_XCD,                 // 1: XCD-ordered grid of the sparse weight gradients; 0: (chunk, offset) grid
+  RSLO_TUNE_VFE_LDS,                   // 1: LDS-staged VFE mean; 0: one thread per voxel from memory
+  RSLO_TUNE_CHAMFER,                   // 0: choose by size; 1: exhaustive; 2: pruned grid search
+  RSLO_TUNE_COUNT
+};
+extern int g_rslo_tune[RSLO_TUNE_COUNT];
+static inline int rslo_tune(RsloTune t) { return g_rslo_tune[t]; }
+
 struct Dims3 {
   int d, h, w;
 };

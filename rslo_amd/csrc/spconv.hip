@@ -926,8 +926,8 @@ __global__ __launch_bounds__(SPC_THREADS) void k_spconv_bf16(const unsigned shor
 }
 
 // k_spconv_v6 tiling: rows per tile = 16 rbw (1, 2, 4), waves per tile ks (1, 2, 4; rbw 4 only with ks 1); 0 = choose
-static int spc_force_rbw = getenv("RSLO_SPCONV_RBW") ? atoi(getenv("RSLO_SPCONV_RBW")) : 0;
-static int spc_force_ks = getenv("RSLO_SPCONV_KS") ? atoi(getenv("RSLO_SPCONV_KS")) : 0;
+#define spc_force_rbw rslo_tune(RSLO_TUNE_SPCONV_RBW)
+#define spc_force_ks rslo_tune(RSLO_TUNE_SPCONV_KS)
 
 extern "C" int rslo_weight_to_bf16(const float *W, int K, int cin_op, int cout_op, int transpose, void *Wb, void *stream) {
   RSLO_CHECK_ARG(W && Wb && K >= 1, "rslo_weight_to_bf16: bad arguments");
@@ -996,8 +996,8 @@ extern "C" int rslo_weight_split_many(const RsloWeightSplitDesc *desc_dev, int n
 }
 
 extern "C" void rslo_spconv_set_tiling(int rbw, int ks) {
-  spc_force_rbw = (rbw == 1 || rbw == 2 || rbw == 4) ? rbw : 0;
-  spc_force_ks = (ks == 1 || ks == 2 || ks == 4) ? ks : 0;
+  g_rslo_tune[RSLO_TUNE_SPCONV_RBW] = (rbw == 1 || rbw == 2 || rbw == 4) ? rbw : 0;
+  g_rslo_tune[RSLO_TUNE_SPCONV_KS] = (ks == 1 || ks == 2 || ks == 4) ? ks : 0;
 }
 
 extern "C" int rslo_spconv_fwd_split(const float *in, int cin, const void *Ws, const float *bias, const int32_t *nbr,
@@ -1056,7 +1056,7 @@ static int launch_spconv(const float *in, int cin, const float *W, const float *
   if (n_out == 0) return RSLO_OK;
   const int ci = pad_cin(cin), co = pad_cout(cout);
   RSLO_CHECK_ARG(ci == 8 || ci == cin, "spconv: cin must be <=8, 16, 32 or 64");
-  static const int variant = getenv("RSLO_SPCONV_V") ? atoi(getenv("RSLO_SPCONV_V")) : 0;
+  const int variant = rslo_tune(RSLO_TUNE_SPCONV_V);
   if ((variant == 0 || variant >= 100) && ci == cin && co == cout && cin % 16 == 0 && cout % 16 == 0) {
     // v3 (variant 100 + RBW forces the row blocking; default: 2 row blocks when the launch still fills the chip)
     int rbw = variant >= 100 ? variant - 100 : ((n_out >= 256 * 32 * 8) ? 2 : 1);
@@ -1360,8 +1360,7 @@ __device__ __forceinline__ bool wg2_assign(const int32_t *__restrict__ koff, int
   }
   return false;
 }
-// read per call (not cached) so that a test can compare the two orders inside one process
-static inline bool wg2_xcd() { const char *e = getenv("RSLO_WGRAD_XCD"); return !(e && e[0] == '0'); }
+static inline bool wg2_xcd() { return rslo_tune(RSLO_TUNE_WGRAD_XCD) != 0; }
 static inline unsigned wg2_grid(int nch, int K, bool xcd) {
   return xcd ? 8u * (unsigned)((nch * K + 7) / 8 + K) : (unsigned)(nch * K);
 }
@@ -1804,7 +1803,7 @@ extern "C" int rslo_spconv_wgrad_pairs(const float *in, int cin, const float *do
   }
   const int ci = cin <= 16 ? 16 : (cin <= 32 ? 32 : 64), co = pad_cout(cout);
   const bool exact = (ci == cin && co == cout);
-  static const bool split_on = !(getenv("RSLO_SPCONV_SPLIT") && getenv("RSLO_SPCONV_SPLIT")[0] == '0');
+  const bool split_on = rslo_tune(RSLO_TUNE_SPCONV_WGRAD_SPLIT) != 0;
   const bool use3 = split_on && exact && (cin == 32 || cin == 64) && (cout == 32 || cout == 64);
   const int chunk = use3 ? WG3_CHUNK : WG2_CHUNK;
   const int nch = (int)rslo_cdiv(n_out, chunk);   // P_k <= n_out: upper bound on chunks per offset

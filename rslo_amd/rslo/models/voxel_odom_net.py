@@ -14,6 +14,7 @@ MI355X re-design inside that contract:
 """
 import contextlib
 import os
+import weakref
 import time
 
 import apex.amp as amp
@@ -32,6 +33,7 @@ from rslo.models import middle, odom_pred, voxel_encoder
 
 _SIDE_STREAMS = {}
 _HOST_LEAD = int(os.environ.get("RSLO_HOST_LEAD", "1"))
+_LEAD_EVENTS = weakref.WeakKeyDictionary()   # network -> events recorded behind its recent training forwards
 _LEAD_WAIT = [0.0, 0.0]  # wall seconds the issuing thread was held back, CPU seconds it spent in that wait (bench.py)
 
 REGISTERED_NETWORK_CLASSES = {}
@@ -350,7 +352,9 @@ class UnVoxelOdomNetICP3(nn.Module):
             # recorded behind an earlier forward).  Nothing else bounds it -- the step has no host read -- and a thread
             # that fills the launch queue spins inside hipLaunchKernel and costs GPU time: 14.1 vs 13.7 ms per step
             # measured.  RSLO_HOST_LEAD=0: unbounded.
-            ring = self.__dict__.setdefault("_lead_events", [])       # (not a module attribute: events do not deep-copy)
+            ring = _LEAD_EVENTS.get(self)          # kept outside the module (events do not deep-copy), keyed weakly: no
+            if ring is None:                       # stale ring under a recycled id() once a network is freed
+                ring = _LEAD_EVENTS[self] = []
             if len(ring) >= _HOST_LEAD:
                 t0, c0 = time.perf_counter(), time.thread_time()
                 ring[-_HOST_LEAD].synchronize()                       # a sleeping wait (blocking-sync events)

@@ -1,10 +1,11 @@
 """One shape of rslo_conv2d_fwd, launched N times (for rocprofv3 --kernel-trace / --pmc runs: kernel durations without
-launch overhead).  SHAPE=cin,cout,H,W [B=4] [N=20]; tile configuration through the library's RSLO_CONV2D_FWD_* variables."""
+launch overhead).  SHAPE=cin,cout,H,W [B=4] [N=20]; tile configuration through RSLO_TUNING (scripts/_tuning.py)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import rslo_amd  # noqa: F401
 from rslo_amd import capi
+import _tuning; _tuning.apply_from_env()
 cin, cout, H, W = [int(v) for v in os.environ.get("SHAPE", "128,128,48,88").split(",")]
 B, N = int(os.environ.get("B", "4")), int(os.environ.get("N", "20"))
 x = torch.randn(B, cin, H, W, device="cuda")

@@ -5,6 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import rslo_amd
 from rslo_amd import capi, synthetic, workload
+import _tuning; _tuning.apply_from_env()
 
 FRAMES = int(os.environ.get("FRAMES", "8"))
 REPS = int(os.environ.get("REPS", "20"))

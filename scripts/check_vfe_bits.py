@@ -1,10 +1,11 @@
-"""rslo_vfe_mean on seeded inputs: writes the outputs to a file (RSLO_VFE_LDS=0: one thread per voxel from memory, 1: rows
+"""rslo_vfe_mean on seeded inputs: writes the outputs to a file (RSLO_TUNING=vfe_lds=0: one thread per voxel from memory, 1: rows
 staged through LDS) and compares with another run's file -- the two kernels must agree in every bit.
-usage: RSLO_VFE_LDS=0 python scripts/check_vfe_bits.py a.pt; RSLO_VFE_LDS=1 python scripts/check_vfe_bits.py b.pt a.pt"""
+usage: RSLO_TUNING=vfe_lds=0 python scripts/check_vfe_bits.py a.pt; RSLO_TUNING=vfe_lds=1 python scripts/check_vfe_bits.py b.pt a.pt"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, rslo_amd
 from rslo_amd import capi
+import _tuning; _tuning.apply_from_env()
 g = torch.Generator().manual_seed(11)
 out = []
 for M, T, F in ((125431, 10, 7), (63, 10, 7), (64, 10, 7), (1000, 5, 4), (257, 3, 16), (31496, 10, 7)):

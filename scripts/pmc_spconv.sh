@@ -8,7 +8,7 @@ wc -l $OUT/counters.txt
 grep -E "^(SQ_WAVE_CYCLES|SQ_BUSY_CYCLES|SQ_WAIT_ANY|SQ_WAIT_INST_ANY|SQ_ACTIVE_INST_ANY|SQ_VALU_MFMA_BUSY_CYCLES|SQ_INSTS_VALU_MFMA|SQ_INST_CYCLES_VMEM|SQ_WAIT_INST_LDS|TCC_HIT_sum|TCC_MISS_sum|TCP_TCC_READ_REQ_sum|TCP_TOTAL_CACHE_ACCESSES_sum|TCP_TCC_READ|TCC_EA0_RDREQ_sum|TCC_REQ_sum|TCP_TA_DATA_STALL|TA_BUSY|GRBM_GUI_ACTIVE|SQ_INSTS_VMEM|SQ_WAVES|FETCH_SIZE|MfmaUtil|SQ_LDS_BANK_CONFLICT|TCP_PENDING_STALL_CYCLES_sum|TA_TA_BUSY_sum|TCP_TCP_TA_DATA_STALL_CYCLES_sum)" $OUT/counters.txt | tr '\n' ' '
 run() {  # $1 tag, rest counters
   tag=$1; shift
-  RSLO_SPCONV_V=$V ONLY="${ONLYK:-subm2 64->64 fwd}" REPS=3 timeout -k 5 200 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$tag -o p -- python $GRAFT_REPO_ROOT/scripts/bench_spconv.py > $OUT/$tag.log 2>&1
+  RSLO_TUNING=spconv_v=$V ONLY="${ONLYK:-subm2 64->64 fwd}" REPS=3 timeout -k 5 200 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$tag -o p -- python $GRAFT_REPO_ROOT/scripts/bench_spconv.py > $OUT/$tag.log 2>&1
   f=$(find $OUT/$tag -name "*counter_collection.csv" | head -1)
   python3 - "$f" <<'PY'
 import csv, sys, collections

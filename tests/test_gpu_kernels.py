@@ -1072,20 +1072,17 @@ def test_leaf_stream_weight_gradients_accumulate_and_share_safely(hip):
 def test_conv2d_fwd_and_dgrad_match_float64_oracle(hip, B, cin, cout, H, W, cfg):
     """Forward (with bias) and data gradient through rslo_conv2d_wsplit + rslo_conv2d_fwd against the float64
     restatement: |err| <= 2e-5 * max|ref| (split-bf16 products exact to 2^-24 per term, fp32 accumulation over 9 Cin
-    terms), and no further from it than 4x the library's own fp32 result.  cfg forces each tile configuration (in a
-    subprocess-free way the configuration is read once per process, so forced configurations run via the env of a
-    child interpreter)."""
+    terms), and no further from it than 4x the library's own fp32 result.  cfg forces each tile configuration."""
     if cfg is not None:
-        import subprocess, sys
-        code = ("import os, sys; sys.path.insert(0, %r); import numpy as np, torch, rslo_amd; from rslo_amd import capi; import oracle as O;"
-                "rng = np.random.default_rng(2); x = rng.standard_normal((%d,%d,%d,%d)).astype(np.float32);"
-                "w = rng.standard_normal((%d,%d,3,3)).astype(np.float32);"
-                "y = capi.conv2d_fwd(torch.from_numpy(x).cuda(), capi.conv2d_wsplit(torch.from_numpy(w).cuda(), False), None, %d).cpu().numpy();"
-                "r = O.conv2d_fwd(x, w); e = np.abs(y - r).max() / np.abs(r).max(); print(e); sys.exit(0 if e < 2e-5 else 1)"
-                % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), B, cin, H, W, cout, cin, cout))
-        env = dict(os.environ, RSLO_CONV2D_FWD_KC="2") if cfg == "kc=2" else dict(os.environ, RSLO_CONV2D_FWD_CFG=cfg)
-        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
-        assert r.returncode == 0, (r.stdout, r.stderr[-2000:])
+        # a forced tile configuration: explicit switches of the launch code (rslo_tuning_set), restored afterwards
+        kw = {"conv2d_fwd_kc": 2} if cfg == "kc=2" else dict(zip(("conv2d_fwd_tr", "conv2d_fwd_mtw"), map(int, cfg.split(","))))
+        rng = np.random.default_rng(2)
+        x = rng.standard_normal((B, cin, H, W)).astype(np.float32)
+        w = rng.standard_normal((cout, cin, 3, 3)).astype(np.float32)
+        with hip.tuning(**kw):
+            y = hip.conv2d_fwd(dev(x), hip.conv2d_wsplit(dev(w), False), None, cout).cpu().numpy()
+        r = O.conv2d_fwd(x, w)
+        assert np.abs(y - r).max() / np.abs(r).max() < 2e-5
         return
     rng = np.random.default_rng(12)
     x = rng.standard_normal((B, cin, H, W)).astype(np.float32)
@@ -1315,26 +1312,6 @@ def test_conv_bn_act_as_one_autograd_node_gives_the_same_bits(hip, monkeypatch):
         assert torch.equal(p, q), n
 
 
-class _Env:
-    """Sets / clears one environment variable for the C library's per-call getenv (A/B switches of the workgroup orders)."""
-
-    def __init__(self, name, value):
-        self.name, self.value = name, value
-
-    def __enter__(self):
-        self.old = os.environ.get(self.name)
-        if self.value is None:
-            os.environ.pop(self.name, None)
-        else:
-            os.environ[self.name] = str(self.value)
-
-    def __exit__(self, *a):
-        if self.old is None:
-            os.environ.pop(self.name, None)
-        else:
-            os.environ[self.name] = self.old
-
-
 @pytest.mark.gpu
 @pytest.mark.parametrize("cin,cout", [(16, 16), (32, 32), (64, 64), (32, 64), (7, 16)])
 def test_sparse_wgrad_xcd_order_keeps_the_bits(hip, cin, cout):
@@ -1350,7 +1327,7 @@ def test_sparse_wgrad_xcd_order_keeps_the_bits(hip, cin, cout):
     pairs = hip.rulebook_pairs(dev(O.rulebook_subm(coords, B, dims)))
     res = {}
     for mode in ("0", "1"):
-        with _Env("RSLO_WGRAD_XCD", mode):
+        with hip.tuning(wgrad_xcd=int(mode)):
             gw, gb = hip.spconv_wgrad_pairs(x, gy, pairs, n, 27, cin, cout)
             res[mode] = [gw.clone(), gb.clone()]
             if cin in (32, 64) and cout in (32, 64):
@@ -1366,7 +1343,7 @@ def test_sparse_wgrad_xcd_order_keeps_the_bits(hip, cin, cout):
                                              (1, 32, 64, 9, 16), (3, 128, 64, 13, 50)])
 def test_conv2d_fwd_xcd_orders_keep_the_bits(hip, B, cin, cout, H, W):
     """conv2d_xcd_tile (conv2d.hip) arranges the 8 XCDs as channel classes x pixel ranges; every arrangement (forced
-    through RSLO_CONV2D_FWD_XSC = 1, 2, 4, 8 where it divides the channel groups, 0 = automatic) computes the same
+    through the switch conv2d_fwd_xsc = 1, 2, 4, 8 where it divides the channel groups, 0 = automatic) computes the same
     tiles as the plain grid (-1): identical bits, forward operand and data-gradient operand, fp32 and bf16 operands,
     maps whose tile count is not a multiple of the pixel ranges."""
     torch.manual_seed(5)
@@ -1379,10 +1356,10 @@ def test_conv2d_fwd_xcd_orders_keep_the_bits(hip, B, cin, cout, H, W):
     def run():
         return [hip.conv2d_fwd(x, ws, bias, cout).clone(), hip.conv2d_fwd(g, wst, None, cin).clone(),
                 hip.conv2d_fwd(x, ws, bias, cout, lp=True).clone()]
-    with _Env("RSLO_CONV2D_FWD_XSC", -1):
+    with hip.tuning(conv2d_fwd_xsc=-1):
         ref = run()
-    for xsc in (None, 0, 1, 2, 4, 8):
-        with _Env("RSLO_CONV2D_FWD_XSC", xsc):
+    for xsc in (0, 1, 2, 4, 8):
+        with hip.tuning(conv2d_fwd_xsc=xsc):
             for a, b in zip(ref, run()):
                 assert torch.equal(a, b), xsc
     lib = torch.nn.functional.conv2d(x, w, bias, 1, 1)
@@ -1393,7 +1370,7 @@ def test_conv2d_fwd_xcd_orders_keep_the_bits(hip, B, cin, cout, H, W):
 @pytest.mark.parametrize("B,cin,cout,H,W,k", [(4, 128, 128, 48, 88, 3), (2, 64, 128, 21, 37, 3), (4, 128, 256, 24, 44, 1),
                                                (1, 256, 128, 96, 176, 3)])
 def test_conv2d_stride2_xcd_orders_keep_the_bits(hip, B, cin, cout, H, W, k):
-    """Same statement for the stride-2 kernels (forward and the four-class data gradient), RSLO_CONV2D_S2_XSC."""
+    """Same statement for the stride-2 kernels (forward and the four-class data gradient), switch conv2d_s2_xsc."""
     torch.manual_seed(6)
     x = torch.randn(B, cin, H, W, device="cuda")
     g = torch.randn(B, cout, (H - 1) // 2 + 1, (W - 1) // 2 + 1, device="cuda")
@@ -1402,10 +1379,10 @@ def test_conv2d_stride2_xcd_orders_keep_the_bits(hip, B, cin, cout, H, W, k):
 
     def run():
         return [hip.conv2d_fwd_s2(x, ws, cout, k).clone(), hip.conv2d_dgrad_s2(g, wst, cin, H, W, k).clone()]
-    with _Env("RSLO_CONV2D_S2_XSC", -1):
+    with hip.tuning(conv2d_s2_xsc=-1):
         ref = run()
-    for xsc in (None, 1, 2, 4, 8):
-        with _Env("RSLO_CONV2D_S2_XSC", xsc):
+    for xsc in (0, 1, 2, 4, 8):
+        with hip.tuning(conv2d_s2_xsc=xsc):
             for a, b in zip(ref, run()):
                 assert torch.equal(a, b), xsc
 
