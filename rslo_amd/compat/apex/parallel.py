@@ -198,12 +198,60 @@ def convert_syncbn_model(module, process_group=None, channel_last=False):
     return nn.SyncBatchNorm.convert_sync_batchnorm(module, process_group)
 
 
-class DistributedDataParallel(nn.parallel.DistributedDataParallel):
-    """apex DDP call signature (train_hdf5.py:463) on torch DDP over RCCL.  77 of the 290 parameter
-    tensors never receive a gradient, hence find_unused_parameters."""
+class DistributedDataParallel(nn.Module):
+    """apex.parallel.DistributedDataParallel as the driver uses it (train_hdf5.py:463 `net_parallel =
+    apex.parallel.DistributedDataParallel(net)`; forward through the wrapper, `.module` underneath), on the exchange this
+    path is built around: parameters and buffers broadcast from rank 0 at construction, gradients AVERAGED over the ranks
+    (apex: gradient_average=True) by rslo.utils.distributed_utils -- for the odometry network the BEV head's ~11 M
+    gradients leave as one flat asynchronous all-reduce when the head's backward is done (OverlappedGradientExchange),
+    the rest as a second flat bucket at the end of the pass; any other module: one flat bucket (average_gradients).
+    Like apex, the exchange finishes inside backward(): an autograd-engine callback queued when the first output
+    gradient arrives, so `scaled_loss.backward()` returns with reduced gradients and the driver's next statement
+    (`clip_grad_norm_`, train_hdf5.py:671) sees them.  torch DDP with find_unused_parameters=True (77 of the 290
+    parameter tensors never receive a gradient) would cost ~8 ms of host time per step here; message_size /
+    delay_allreduce are accepted and have nothing to tune."""
 
-    def __init__(self, module, message_size=10000000, delay_allreduce=False, **kwargs):
-        dev = next(module.parameters()).device
-        ids = [dev.index] if dev.type == "cuda" else None
-        super().__init__(module, device_ids=ids, find_unused_parameters=True,
-                         bucket_cap_mb=max(1, int(message_size * 4 / 2 ** 20)))
+    def __init__(self, module, message_size=10000000, delay_allreduce=False, shared_param=None,
+                 allreduce_trigger_params=None, retain_allreduce_buffers=False, allreduce_always_fp32=False,
+                 num_allreduce_streams=1, allreduce_communicators=None, gradient_average=True,
+                 gradient_predivide_factor=1.0, gradient_average_split_factor=None, prof=False):
+        super().__init__()
+        if gradient_predivide_factor != 1.0 or not gradient_average:
+            raise NotImplementedError("apex DDP stand-in: gradients are averaged over the ranks (the reference's setting)")
+        self.module = module
+        self._exchange = None
+        self._queued = False
+        if dist.is_available() and dist.is_initialized():
+            from rslo.utils import distributed_utils as du
+            du.broadcast_params(module, 0)
+            early = getattr(module, "odom_predictor", None)
+            if early is not None and os.environ.get("RSLO_OVERLAP_GRADS", "1") != "0":
+                self._exchange = du.OverlappedGradientExchange(module, early, mean=True, module_hook=False)
+                module.__dict__["_grad_exchange"] = self._exchange       # the network marks the head / encoder boundary
+
+    def _finish(self):
+        from rslo.utils import distributed_utils as du
+        self._queued = False
+        import sys
+        st = sys.modules.get("rslo_amd.streams")
+        if st is not None:        # weight gradients still on the leaf stream (its own end-of-pass callback was queued after
+            st.join()             # this one): the buckets are built on the issuing stream, behind them
+        if self._exchange is not None:
+            self._exchange.finish()
+        else:
+            du.average_gradients(self.module, mean=True)
+
+    def _on_first_grad(self, grad):
+        if not self._queued:
+            self._queued = True
+            torch.autograd.Variable._execution_engine.queue_callback(self._finish)
+        return None
+
+    def forward(self, *inputs, **kwargs):
+        out = self.module(*inputs, **kwargs)
+        if torch.is_grad_enabled() and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            ts = out.values() if isinstance(out, dict) else (out if isinstance(out, (list, tuple)) else (out,))
+            for t in ts:
+                if torch.is_tensor(t) and t.requires_grad:
+                    t.register_hook(self._on_first_grad)
+        return out

@@ -105,7 +105,13 @@ def save(model_dir, model, model_name, global_step, max_to_keep=8, keep_latest=T
 def restore(ckpt_path, model, map_func=None, map_location="cpu"):
     if not Path(ckpt_path).is_file():
         raise ValueError("checkpoint {} not exist.".format(ckpt_path))
-    state = torch.load(ckpt_path, map_location=map_location)
+    # the reference's plain torch.load (checkpoint.py:118-126, torch 1.2): a .tckpt of the OPTIMIZER carries what the
+    # schedule wrote into its param groups (numpy scalars from the OneCycle interpolation), which torch >= 2.6's default
+    # weights_only unpickler refuses; try the restricted loader first, fall back for the user's own checkpoint files
+    try:
+        state = torch.load(ckpt_path, map_location=map_location, weights_only=True)
+    except Exception:
+        state = torch.load(ckpt_path, map_location=map_location, weights_only=False)
     if map_func is not None:
         state = map_func(state)
     model.load_state_dict(state)

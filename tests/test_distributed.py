@@ -457,3 +457,58 @@ def test_syncbn_exchange_group_on_rccl_single_rank():
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
                        env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", RSLO_SYNCBN_HP_GROUP="1"))
     assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+
+
+def _apex_ddp_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import copy
+    from apex.parallel import DistributedDataParallel as ApexDDP
+    from rslo.utils.distributed_utils import average_gradients
+    torch.manual_seed(100 + rank)                 # different initial weights per rank: the wrapper broadcasts rank 0's
+    net = torch.nn.Module()
+    net.encoder = torch.nn.Linear(6, 8)
+    net.odom_predictor = torch.nn.Linear(8, 3)    # the attribute the wrapper takes as the early bucket
+    net.unused = torch.nn.Linear(3, 3)            # never receives a gradient (77 of the real network's 290 tensors)
+    net.forward = lambda x: {"loss": net.odom_predictor(net.__dict__["_grad_exchange"].watch(net.encoder(x))).square().sum(),
+                             "aux": torch.zeros(1)}
+    wrapped = ApexDDP(net)
+    w0 = [p.detach().clone() for p in net.parameters()]
+    gathered = [None] * world
+    dist.all_gather_object(gathered, [w.tolist() for w in w0])
+    same_init = gathered[0] == gathered[1]
+    ref = copy.deepcopy(net)
+    ref.__dict__.pop("_grad_exchange", None)
+    out = []
+    for step in range(3):
+        x = torch.randn(5, 6, generator=torch.Generator().manual_seed(10 * step + rank))
+        net.zero_grad(set_to_none=True)
+        ref.zero_grad(set_to_none=True)
+        wrapped(x)["loss"].mean().backward()               # train_hdf5.py:623-665: reduced gradients when backward returns
+        ref.odom_predictor(ref.encoder(x)).square().sum().backward()
+        average_gradients(ref, mean=True)
+        out.append(all((a.grad is None and b.grad is None) or torch.allclose(a.grad, b.grad, rtol=1e-6, atol=1e-7)
+                       for a, b in zip(net.parameters(), ref.parameters())))
+    q.put((rank, same_init, out, net.unused.weight.grad is None))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_apex_ddp_stand_in_broadcasts_and_averages_inside_backward():
+    """compat apex.parallel.DistributedDataParallel (what train_hdf5.py:463 constructs): rank 0's weights everywhere after
+    construction; after `loss.backward()` every rank holds the rank-averaged gradients (== average_gradients(mean=True)),
+    with the head's bucket overlapped from step 1 on; parameters without a gradient stay without one."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=_apex_ddp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, same_init, out, unused_none in res:
+        assert same_init and all(out) and unused_none, (rank, same_init, out, unused_none)
