@@ -328,10 +328,22 @@ def check_three_way(net, ex, median_bar, max_bar, ratio_bar):
     assert len(rows) >= 170   # 213 of 290 parameter tensors receive gradients
     e_gpu = np.array([r[0] for r in rows])
     e_cpu = np.array([r[1] for r in rows])
-    worst = rows[int(e_gpu.argmax())]
     assert np.median(e_gpu) < median_bar, (np.median(e_gpu), np.median(e_cpu))
-    assert e_gpu.max() < max_bar, worst
     assert np.median(e_gpu) < ratio_bar * np.median(e_cpu), (np.median(e_gpu), np.median(e_cpu))
+    # per tensor: within max_bar of float64 -- or an EXCEPTION that the table below justifies: the CPU fp32 path (the
+    # reference-semantics arithmetic, no HIP kernel involved) is itself at least half as far from float64 on the very same
+    # tensor, i.e. the tensor is ill-conditioned in fp32 (a ReLU / LeakyReLU mask or a BatchNorm statistic next to a
+    # rounding boundary), not mis-computed; nothing may be past 0.1 under any excuse
+    over = sorted((r for r in rows if r[0] >= max_bar), reverse=True)
+    if over:
+        print("tensors past %.0e of float64 (GPU err, CPU-fp32 err, name):" % max_bar)
+        for e_g, e_c, n in over:
+            print("  %.2e  %.2e  %s" % (e_g, e_c, n))
+    print("gradients vs float64: GPU median %.2e max %.2e | CPU fp32 median %.2e max %.2e | %d tensors, %d exceptions" % (
+        np.median(e_gpu), e_gpu.max(), np.median(e_cpu), e_cpu.max(), len(rows), len(over)))
+    for e_g, e_c, n in over:
+        assert e_g < 0.1 and e_g <= 2.0 * e_c, (n, e_g, e_c)
+    assert len(over) <= max(3, len(rows) // 50), over
     return rows
 
 
@@ -345,7 +357,7 @@ def test_full_network_fwd_bwd_matches_cpu_oracle(hip):
     p0, p1, _ = reduced_pair(1)
     ex = workload.make_example(net, [[p0, p1]])
     # measured: median 2.1e-4 (CPU fp32 path: 2.9e-4), max 3.1e-2 (one BatchNorm bias of the rotation-confidence trunk)
-    check_three_way(net, ex, median_bar=1e-3, max_bar=6e-2, ratio_bar=4.0)
+    check_three_way(net, ex, median_bar=1e-3, max_bar=3e-2, ratio_bar=3.0)
 
 
 def test_c3_full_size_step_matches_cpu_oracle(hip):
@@ -362,8 +374,65 @@ def test_c3_full_size_step_matches_cpu_oracle(hip):
     # any one kernel: measured over init seeds 7 / 8 / 9 (scripts/parity_report.py --bs 4 --rings 64 --seed N), GPU
     # medians 6.5e-3 / 3.5e-3 / 1.9e-3 with the hand-written stride-2 kernels and 3.7e-3 / 3.6e-3 / 1.7e-3 with the
     # library's (RSLO_CONV2D_S2=0), the CPU fp32 path's own 3.5e-3 / 1.2e-3 / 1.9e-3, median ratio 1.5 / 1.8 / 3.9,
-    # max 3.8e-2 (poses agree to 2e-7 in every variant).  Bars: 1.5x the largest observed value.
-    check_three_way(net, ex, median_bar=1e-2, max_bar=6e-2, ratio_bar=6.0)
+    # max 3.8e-2 (poses agree to 2e-7 in every variant).  Bars (round 4): median 1e-2 and at most 3x the CPU fp32 path's
+    # own median; per tensor 3e-2, past that only as a printed exception where the CPU fp32 path is equally far off.
+    check_three_way(net, ex, median_bar=1e-2, max_bar=3e-2, ratio_bar=3.0)
+
+
+def real_training_steps(net, n_steps, clouds_of_step):
+    """n_steps of the driver's training step (train_hdf5.py:618-674: OneCycle schedule, backward, clip 10, OptimWrapper /
+    Adam, global step) from the network's current state, on the GPU."""
+    from rslo.builder import lr_scheduler_builder, optimizer_builder
+    from rslo.utils import config_text
+    cfg = config_text.shipped_config().train_config
+    opt = optimizer_builder.build(cfg.optimizer, net)
+    sched = lr_scheduler_builder.build(cfg.optimizer, opt, cfg.steps)
+    losses = []
+    for i in range(n_steps):
+        sched.step(net.get_global_step())
+        opt.zero_grad()
+        ret = net(workload.make_example(net, clouds_of_step(i)))
+        ret["loss"].mean().backward()
+        torch.nn.utils.clip_grad_norm_(net.parameters(), 10.0)
+        opt.step()
+        net.update_global_step()
+        losses.append(float(ret["loss"].mean()))
+    assert all(np.isfinite(losses)), losses
+    return losses
+
+
+def test_parity_on_weights_produced_by_real_optimizer_steps(hip):
+    """Verdict r3 #4a: the three-way comparison NOT on a hand-made state but on weights a real (short) training run
+    produced: seed 7, default init, 50 optimizer steps of the shipped schedule on the GPU from global step 0 (the
+    reference's warm-up regime: identity pose inside the consistency loss and icp_iter = 5 while global_step <= 1500,
+    voxel_odom_net.py:670-690), batches of two reduced pairs drawn round-robin from six.  Then (1) one more step's
+    forward + loss + backward three ways at the state training left (global step 50, running statistics included), and
+    (2) the same weights evaluated past the warm-up (global step 2000: predicted pose inside the loss, icp_iter = 2)."""
+    torch.manual_seed(7)
+    net, _ = workload.build_network()
+    net.train()
+    pool = [list(reduced_pair(i)[:2]) for i in range(6)]
+    w0 = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).clone()
+    losses = real_training_steps(net, 50, lambda i: [pool[(2 * i) % 6], pool[(2 * i + 1) % 6]])
+    assert net.get_global_step() == 50
+    moved = (torch.cat([p.detach().reshape(-1) for p in net.parameters()]) - w0).abs().max()
+    assert float(moved) > 1e-3                      # the optimizer really ran
+    print("50 real steps: loss %.4f -> %.4f, largest weight change %.2e" % (losses[0], losses[-1], float(moved)))
+    ex = workload.make_example(net, [pool[1]])
+    net.zero_grad(set_to_none=True)
+    check_three_way(copy.deepcopy(net), ex, median_bar=5e-3, max_bar=3e-2, ratio_bar=3.0)
+    net.global_step.fill_(2000)
+    net.zero_grad(set_to_none=True)
+    (ret, _), (ret_c, _), (ret_64, _) = three_way(copy.deepcopy(net), ex)
+    # past the warm-up on these weights the voted pose is still metres off (50 steps at lr ~1e-4 do not train a head), so
+    # the ICP rounds start outside their basin: outputs and loss terms must still agree -- that is what a user resuming
+    # from an early checkpoint sees -- while gradients there are chaotic in ANY arithmetic and are not compared
+    for k in ("translation_preds", "rotation_preds"):
+        assert rel(ret[k], ret_c[k]) < 1e-5 and rel(ret[k], ret_64[k]) < 1e-5, k
+    for k in ("loss", "translation_loss", "rotation_loss", "pyramid_loss"):
+        assert rel(ret[k], ret_c[k]) < 1e-4 and rel(ret[k], ret_64[k]) < 1e-4, k
+    print("past warm-up on the trained weights: C_loss gpu %.6f cpu %.6f f64 %.6f" % (
+        float(ret["C_loss"]), float(ret_c["C_loss"]), float(ret_64["C_loss"])))
 
 
 def test_amp_o1_bf16_step_tracks_the_fp32_step(hip):
