@@ -686,6 +686,28 @@ RSLO_API int rslo_opt_clip_grad_norm(const RsloOptTensor *tensors_dev, const Rsl
 RSLO_API int rslo_opt_adam_step(const RsloOptTensor *tensors_dev, const RsloOptChunk *chunks_dev, int n_chunks,
                                 const RsloOptHyper *hyper, float step, void *stream);
 
+/* ---- a22 (SyncBN statistics): sum of a few hundred doubles over the ranks of ONE node, as a kernel on the caller's stream
+ *      Replaces the per-layer all-reduce of apex SyncBatchNorm (rslo/layers/SparseConv.py:96-132 -> apex
+ *      sync_batchnorm: 45 layers x 2 directions per step, train_hdf5.py:463) between rslo_bn2d_stats and rslo_bn2d_apply
+ *      (and rslo_bn2d_bwd_reduce / _bwd_apply).  Every rank owns a slice (4 slots of {flag, payload}) the others can read;
+ *      rslo_peer_allreduce_f64 writes the own payload + flag, waits for every peer's flag of the same exchange number, and
+ *      sums the payloads in rank order (identical bits on every rank) into t, in place.  All ranks must issue the same
+ *      sequence of exchanges.  A peer that does not arrive within the timeout (default 20 s) poisons t with NaN and is
+ *      reported by rslo_peer_status -- the kernel never hangs the GPU.
+ *      Transports:  host   = one POSIX shared-memory segment `name` (every rank passes the same name) registered with the
+ *                            HIP runtime: any GPUs of one host, also several ranks on one GPU;
+ *                   device = each rank's slice in its own HBM, exported as an IPC handle of rslo_peer_ipc_handle_bytes()
+ *                            bytes (begin), the handles of ALL ranks in rank order handed back (finish): peers read it
+ *                            over xGMI.  world <= 16, max_n <= 1024. */
+RSLO_API int rslo_peer_create_host(const char *name, int rank, int world, int max_n, void **comm_out);
+RSLO_API int rslo_peer_ipc_handle_bytes(void);
+RSLO_API int rslo_peer_create_device_begin(int rank, int world, int max_n, void **comm_out, void *handle_out);
+RSLO_API int rslo_peer_create_device_finish(void *comm, const void *all_handles);
+RSLO_API int rslo_peer_set_timeout_ms(void *comm, int ms);
+RSLO_API int rslo_peer_allreduce_f64(void *comm, double *t, int n, void *stream);
+RSLO_API unsigned long long rslo_peer_status(void *comm, int *peer);
+RSLO_API int rslo_peer_destroy(void *comm);
+
 #ifdef __cplusplus
 }
 #endif

@@ -90,6 +90,17 @@ def exchange_group(group):
     return _HP_GROUP["group"]
 
 
+def _sum_over_ranks(t, group):
+    """The SyncBN statistics exchange: a same-stream kernel when all ranks share this host (rslo_amd.peer), else the
+    all-reduce on exchange_group(group)."""
+    from rslo_amd import peer
+    c = peer.comm_for(group) if t.is_cuda else None
+    if c is not None:
+        c.all_reduce_(t)
+    else:
+        dist.all_reduce(t, group=exchange_group(group))
+
+
 def fused_bn_forward(bn, x, res, weight, bias, slope, group, world):
     """y = act(BN_train(x) + res) through rslo_bn2d_* (x, res contiguous).  -> y, mean, invstd, cnt_all (the element
     count over all ranks as a device scalar; None on one rank).  Updates bn's running statistics."""
@@ -98,7 +109,7 @@ def fused_bn_forward(bn, x, res, weight, bias, slope, group, world):
     mom = bn.momentum          # fusable() leaves momentum=None (cumulative average) to the unfused path
     if world > 1:
         stats = capi.bn2d_stats(x)
-        dist.all_reduce(stats, group=exchange_group(group))
+        _sum_over_ranks(stats, group)
         y, mean, invstd = capi.bn2d_apply(x, res, stats, weight, bias, bn.running_mean if track else None,
                                           bn.running_var if track else None, mom, bn.eps, slope)
         return y, mean, invstd, stats[-1:]        # ranks may hold different batch sizes: the all-reduced count
@@ -115,7 +126,7 @@ def fused_bn_backward(gy, y, x, weight, mean, invstd, cnt_all, slope, has_res, a
     if world == 1:
         return capi.bn2d_bwd_local(gy, y, x, weight, mean, invstd, slope, has_act, has_res, want_affine=affine)
     red, dgamma, dbeta = capi.bn2d_bwd_reduce(gy, y, x, mean, invstd, slope, has_act, want_affine=affine)
-    dist.all_reduce(red, group=exchange_group(group))
+    _sum_over_ranks(red, group)
     # the count all-reduced in the forward pass, read on the device: exact for uneven per-rank batches, no host sync
     dx, dres = capi.bn2d_bwd_apply(gy, y, x, weight, mean, invstd, red, 0.0, slope, has_act, has_res, count_dev=cnt_all)
     return dx, dres, dgamma, dbeta

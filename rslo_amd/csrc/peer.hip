@@ -1,0 +1,253 @@
+// Same-stream sum over the ranks of one node for the SyncBN statistics (include/rslo_hip.h: rslo_peer_*).
+//
+// The reference normalises the BEV head with apex SyncBatchNorm (rslo/layers/SparseConv.py:96-132, bn_type "SyncBN",
+// train_hdf5.py:463): 45 layers, i.e. 90 exchanges of 2C(+1) doubles per training step, each BETWEEN two dependent kernels
+// of the same layer.  As RCCL collectives they cost a collective launch plus two stream hand-offs inside
+// ProcessGroupNCCL each, 90 times on the critical path.  Here an exchange is ONE small kernel on the training stream:
+//
+//   every rank owns a SLICE of memory every other rank of the node can read:  [SLOTS] x { flag u64 | payload f64[max_n] }
+//   exchange number q (the same on every rank: they run the same layers in the same order) uses slot q mod SLOTS:
+//     1. write the own payload into the own slice (system-scope stores), release fence, flag = q (system scope)
+//     2. spin until the flag of every peer slice reads q (relaxed system-scope loads, s_sleep, bounded by a timeout)
+//     3. acquire fence; every thread adds its element over the slices IN RANK ORDER -> the same bits on every rank
+//   Slot reuse: a rank can write exchange q + 1 only after it has finished reading q, and nobody can finish q + 1 without
+//   its flag, so no rank is ever more than one exchange ahead of a reader: 2 slots suffice, 4 are used.
+//
+// Two transports behind the same kernel (a table of slice base pointers):
+//   * host:   one POSIX shared-memory segment holding all slices, mapped and hipHostRegister-ed by every rank (fine-grained,
+//             system-coherent host memory; every access is a PCIe transaction).  Works for any set of GPUs of one host --
+//             also for several ranks on ONE GPU, which is how the single-GPU development box tests it.
+//   * device: each rank's slice in its own HBM (hipExtMallocWithFlags fine-grained), exported with hipIpcGetMemHandle and
+//             opened by the peers: polls and pulls are xGMI reads of <= 4 KB per peer.
+// Nothing here is a collective library: one node, <= 16 ranks, <= 1024 doubles per exchange.
+#include <fcntl.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <new>
+
+#include "rslo_common.h"
+
+#define PEER_SLOTS 4
+#define PEER_MAX_WORLD 16
+#define PEER_MAX_N 1024
+
+struct PeerTable {
+  unsigned char *base[PEER_MAX_WORLD];      // slice of every rank, as THIS process addresses it
+};
+
+struct RsloPeerComm {
+  int rank, world, max_n, transport;        // 0 host shm, 1 device ipc
+  size_t slice_bytes, slot_bytes;
+  unsigned long long seq;                   // exchanges issued so far
+  PeerTable tab;
+  unsigned long long *status_host;          // pinned: [0] = first sequence number that timed out (0 = none), [1] = peer
+  unsigned long long *status_dev;
+  long long timeout_ticks;                  // wall_clock64() ticks (100 MHz)
+  // host transport
+  void *shm_ptr;
+  size_t shm_bytes;
+  char shm_name[128];
+  // device transport
+  void *own_slice;
+  void *peer_open[PEER_MAX_WORLD];
+};
+
+static inline size_t peer_slot_bytes(int max_n) { return 64 + (size_t)max_n * sizeof(double); }
+
+__global__ void __launch_bounds__(1024) k_peer_allreduce(double *__restrict__ t, int n, PeerTable tab, int me, int world,
+                                                         unsigned long long seq, size_t slot_off, long long timeout_ticks,
+                                                         unsigned long long *__restrict__ status) {
+  const int tid = threadIdx.x;
+  unsigned char *mine = tab.base[me] + slot_off;
+  unsigned long long *my_flag = (unsigned long long *)mine;
+  double *my_pay = (double *)(mine + 64);
+  for (int i = tid; i < n; i += blockDim.x)
+    __hip_atomic_store(my_pay + i, t[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __syncthreads();
+  if (tid == 0) {
+    __atomic_thread_fence(__ATOMIC_RELEASE);      // system scope: the payload is visible before the flag
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    __hip_atomic_store(my_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  __shared__ int s_bad;
+  if (tid == 0) s_bad = 0;
+  __syncthreads();
+  if (tid < world && tid != me) {
+    const unsigned long long *f = (const unsigned long long *)(tab.base[tid] + slot_off);
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+      __builtin_amdgcn_s_sleep(8);
+      if (wall_clock64() - t0 > timeout_ticks) {
+        s_bad = tid + 1;
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // system scope
+  if (s_bad) {       // a peer never arrived: poison the result and report; never hang the GPU
+    if (tid == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0) {
+      __hip_atomic_store(status + 1, (unsigned long long)(s_bad - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(status, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    for (int i = tid; i < n; i += blockDim.x) t[i] = __builtin_nan("");
+    return;
+  }
+  for (int i = tid; i < n; i += blockDim.x) {
+    double s = 0.0;
+    for (int r = 0; r < world; ++r) {
+      const double *p = (const double *)(tab.base[r] + slot_off + 64);
+      s += __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    t[i] = s;
+  }
+}
+
+static int peer_common_init(RsloPeerComm *c, int rank, int world, int max_n) {
+  c->rank = rank; c->world = world; c->max_n = max_n;
+  c->slot_bytes = peer_slot_bytes(max_n);
+  c->slice_bytes = c->slot_bytes * PEER_SLOTS;
+  c->seq = 0;
+  c->timeout_ticks = (long long)20 * 100000000LL;      // 20 s at 100 MHz
+  RSLO_HIP(hipHostMalloc((void **)&c->status_host, 64, hipHostMallocMapped));
+  memset(c->status_host, 0, 64);
+  RSLO_HIP(hipHostGetDevicePointer((void **)&c->status_dev, c->status_host, 0));
+  return RSLO_OK;
+}
+
+extern "C" int rslo_peer_create_host(const char *name, int rank, int world, int max_n, void **comm_out) {
+  RSLO_CHECK_ARG(name && comm_out && world >= 1 && world <= PEER_MAX_WORLD && rank >= 0 && rank < world && max_n >= 1 &&
+                     max_n <= PEER_MAX_N && strlen(name) < 120,
+                 "rslo_peer_create_host: bad arguments (world <= %d, max_n <= %d)", PEER_MAX_WORLD, PEER_MAX_N);
+  RsloPeerComm *c = new (std::nothrow) RsloPeerComm();
+  RSLO_CHECK_ARG(c, "rslo_peer_create_host: out of memory");
+  memset(c, 0, sizeof(*c));
+  c->transport = 0;
+  int rc = peer_common_init(c, rank, world, max_n);
+  if (rc != RSLO_OK) { delete c; return rc; }
+  snprintf(c->shm_name, sizeof(c->shm_name), "%s", name);
+  c->shm_bytes = ((c->slice_bytes * world + 4095) / 4096) * 4096;
+  // every rank opens-or-creates the same segment; a new segment is zero-filled by the kernel (flags 0 = nothing sent: sequence
+  // numbers start at 1); sizing it twice to the same size is harmless
+  int fd = shm_open(name, O_CREAT | O_RDWR, 0600);
+  if (fd < 0 || ftruncate(fd, (off_t)c->shm_bytes) != 0) {
+    if (fd >= 0) close(fd);
+    delete c;
+    rslo_set_error("rslo_peer_create_host: shm_open/ftruncate(%s) failed", name);
+    return RSLO_EINVAL;
+  }
+  c->shm_ptr = mmap(nullptr, c->shm_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (c->shm_ptr == MAP_FAILED) {
+    delete c;
+    rslo_set_error("rslo_peer_create_host: mmap failed");
+    return RSLO_EINVAL;
+  }
+  hipError_t e = hipHostRegister(c->shm_ptr, c->shm_bytes, hipHostRegisterMapped | hipHostRegisterPortable);
+  void *dptr = nullptr;
+  if (e == hipSuccess) e = hipHostGetDevicePointer(&dptr, c->shm_ptr, 0);
+  if (e != hipSuccess) {
+    munmap(c->shm_ptr, c->shm_bytes);
+    delete c;
+    rslo_set_error("rslo_peer_create_host: hipHostRegister: %s", hipGetErrorString(e));
+    return RSLO_ELAUNCH;
+  }
+  for (int r = 0; r < world; ++r) c->tab.base[r] = (unsigned char *)dptr + (size_t)r * c->slice_bytes;
+  *comm_out = c;
+  return RSLO_OK;
+}
+
+extern "C" int rslo_peer_ipc_handle_bytes(void) { return (int)sizeof(hipIpcMemHandle_t); }
+
+extern "C" int rslo_peer_create_device_begin(int rank, int world, int max_n, void **comm_out, void *handle_out) {
+  RSLO_CHECK_ARG(comm_out && handle_out && world >= 1 && world <= PEER_MAX_WORLD && rank >= 0 && rank < world &&
+                     max_n >= 1 && max_n <= PEER_MAX_N,
+                 "rslo_peer_create_device_begin: bad arguments");
+  RsloPeerComm *c = new (std::nothrow) RsloPeerComm();
+  RSLO_CHECK_ARG(c, "rslo_peer_create_device_begin: out of memory");
+  memset(c, 0, sizeof(*c));
+  c->transport = 1;
+  int rc = peer_common_init(c, rank, world, max_n);
+  if (rc != RSLO_OK) { delete c; return rc; }
+  hipError_t e = hipExtMallocWithFlags(&c->own_slice, c->slice_bytes, hipDeviceMallocFinegrained);
+  if (e == hipSuccess) e = hipMemset(c->own_slice, 0, c->slice_bytes);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipIpcGetMemHandle((hipIpcMemHandle_t *)handle_out, c->own_slice);
+  if (e != hipSuccess) {
+    if (c->own_slice) hipFree(c->own_slice);
+    delete c;
+    rslo_set_error("rslo_peer_create_device_begin: %s", hipGetErrorString(e));
+    return RSLO_ELAUNCH;
+  }
+  c->tab.base[rank] = (unsigned char *)c->own_slice;
+  *comm_out = c;
+  return RSLO_OK;
+}
+
+extern "C" int rslo_peer_create_device_finish(void *comm, const void *all_handles) {
+  RsloPeerComm *c = (RsloPeerComm *)comm;
+  RSLO_CHECK_ARG(c && all_handles && c->transport == 1, "rslo_peer_create_device_finish: bad arguments");
+  const hipIpcMemHandle_t *h = (const hipIpcMemHandle_t *)all_handles;
+  for (int r = 0; r < c->world; ++r) {
+    if (r == c->rank) continue;
+    void *p = nullptr;
+    hipError_t e = hipIpcOpenMemHandle(&p, h[r], hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) {
+      rslo_set_error("rslo_peer_create_device_finish: hipIpcOpenMemHandle(rank %d): %s", r, hipGetErrorString(e));
+      return RSLO_ELAUNCH;
+    }
+    c->peer_open[r] = p;
+    c->tab.base[r] = (unsigned char *)p;
+  }
+  return RSLO_OK;
+}
+
+extern "C" int rslo_peer_set_timeout_ms(void *comm, int ms) {
+  RsloPeerComm *c = (RsloPeerComm *)comm;
+  RSLO_CHECK_ARG(c && ms >= 1, "rslo_peer_set_timeout_ms: bad arguments");
+  c->timeout_ticks = (long long)ms * 100000LL;
+  return RSLO_OK;
+}
+
+extern "C" int rslo_peer_allreduce_f64(void *comm, double *t, int n, void *stream) {
+  RsloPeerComm *c = (RsloPeerComm *)comm;
+  RSLO_CHECK_ARG(c && t && n >= 1 && n <= c->max_n, "rslo_peer_allreduce_f64: n = %d outside 1..%d", n, c ? c->max_n : 0);
+  const unsigned long long seq = ++c->seq;
+  const size_t slot_off = (size_t)(seq % PEER_SLOTS) * c->slot_bytes;
+  const int threads = n >= 512 ? 1024 : (n >= 192 ? 512 : 256);
+  hipLaunchKernelGGL(k_peer_allreduce, dim3(1), dim3(threads), 0, (hipStream_t)stream, t, n, c->tab, c->rank, c->world, seq,
+                     slot_off, c->timeout_ticks, c->status_dev);
+  RSLO_CHECK_LAUNCH("k_peer_allreduce");
+  return RSLO_OK;
+}
+
+// 0 = every exchange so far met all its peers; else the sequence number of the first one that timed out (*peer = the rank
+// that never arrived).  Reads pinned memory: no synchronisation, the answer lags the stream.
+extern "C" unsigned long long rslo_peer_status(void *comm, int *peer) {
+  RsloPeerComm *c = (RsloPeerComm *)comm;
+  if (!c) return ~0ULL;
+  const unsigned long long s = ((volatile unsigned long long *)c->status_host)[0];
+  if (peer) *peer = s ? (int)((volatile unsigned long long *)c->status_host)[1] : -1;
+  return s;
+}
+
+extern "C" int rslo_peer_destroy(void *comm) {
+  RsloPeerComm *c = (RsloPeerComm *)comm;
+  if (!c) return RSLO_OK;
+  hipDeviceSynchronize();
+  if (c->transport == 0) {
+    hipHostUnregister(c->shm_ptr);
+    munmap(c->shm_ptr, c->shm_bytes);
+    if (c->rank == 0) shm_unlink(c->shm_name);
+  } else {
+    for (int r = 0; r < c->world; ++r)
+      if (c->peer_open[r]) hipIpcCloseMemHandle(c->peer_open[r]);
+    if (c->own_slice) hipFree(c->own_slice);
+  }
+  hipHostFree(c->status_host);
+  delete c;
+  return RSLO_OK;
+}

@@ -1,0 +1,138 @@
+"""Same-stream statistics exchange between the ranks of one node (csrc/peer.hip, include/rslo_hip.h rslo_peer_*).
+
+The BEV head's SyncBatchNorm (reference: rslo/layers/SparseConv.py:96-132 over apex SyncBatchNorm, train_hdf5.py:463)
+needs the per-channel sums of every layer summed over the ranks, between two dependent kernels of that layer: 90
+exchanges of <= 513 doubles per training step.  `all_reduce_(t, group)` is that sum.  Where every rank of the group
+lives on this host it is ONE small kernel on the current stream (rslo_peer_allreduce_f64: write own slice, spin on the
+peers' flags, add in rank order) instead of an RCCL collective launch with its two stream hand-offs; anywhere else --
+several hosts, an explicit sub-group, a CPU tensor, RSLO_SYNCBN_EXCHANGE=rccl -- it is `dist.all_reduce`.
+
+Transport (RSLO_SYNCBN_EXCHANGE): "host" = a shared-memory segment registered with the HIP runtime (default: works
+for any GPUs of a host and for several ranks on one GPU), "device" = every rank's slice in its own HBM, opened by the
+peers through HIP IPC (reads over xGMI), "rccl" = the collective, "auto" (default) = host when the group is one host.
+Sums are formed in rank order on every rank: all ranks hold identical bits (an RCCL ring does not promise that)."""
+import ctypes as C
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+
+from rslo_amd import capi
+
+MAX_N = 1024
+_COMMS = {}          # id of the default group object -> PeerComm | False (not eligible)
+
+
+class PeerComm:
+    def __init__(self, handle, rank, world, transport):
+        self.handle, self.rank, self.world, self.transport = handle, rank, world, transport
+
+    def all_reduce_(self, t):
+        assert t.is_cuda and t.dtype == torch.float64 and t.is_contiguous() and t.numel() <= MAX_N
+        capi._chk(capi.lib().rslo_peer_allreduce_f64(self.handle, capi._ptr(t), t.numel(), capi._stream()),
+                  "rslo_peer_allreduce_f64")
+        return t
+
+    def status(self):
+        """(0, -1) while every exchange met its peers, else (sequence number of the first time-out, missing rank);
+        reads pinned memory, lags the stream."""
+        peer = C.c_int(-1)
+        s = capi.lib().rslo_peer_status(self.handle, C.byref(peer))
+        return int(s), int(peer.value)
+
+    def check(self):
+        s, peer = self.status()
+        if s:
+            raise capi.RsloHipError("peer exchange %d timed out waiting for rank %d (results were poisoned with NaN)" % (s, peer))
+
+    def set_timeout_ms(self, ms):
+        capi._chk(capi.lib().rslo_peer_set_timeout_ms(self.handle, int(ms)), "rslo_peer_set_timeout_ms")
+
+    def close(self):
+        if self.handle is not None:
+            capi.lib().rslo_peer_destroy(self.handle)
+            self.handle = None
+
+
+def create(transport="host", group=None):
+    """Collective over `group` (default group): every rank calls it at the same point.  Returns a PeerComm, or None when
+    the ranks are not all on this host or the transport cannot be set up on some rank (the decision is agreed: all ranks
+    get a comm or none does)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    hosts = [None] * world
+    dist.all_gather_object(hosts, socket.gethostname(), group=group)
+    if len(set(hosts)) != 1 or world > 16:
+        return None
+    lib = capi.lib()
+    handle = C.c_void_p()
+    ok, comm = 1, None
+    try:
+        if transport == "host":
+            name = [None]
+            if rank == 0:
+                name[0] = "/rslo_peer_%d_%s" % (os.getpid(), os.urandom(4).hex())
+            dist.broadcast_object_list(name, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            capi._chk(lib.rslo_peer_create_host(name[0].encode(), rank, world, MAX_N, C.byref(handle)), "rslo_peer_create_host")
+        elif transport == "device":
+            nb = lib.rslo_peer_ipc_handle_bytes()
+            buf = C.create_string_buffer(nb)
+            capi._chk(lib.rslo_peer_create_device_begin(rank, world, MAX_N, C.byref(handle), buf), "rslo_peer_create_device_begin")
+            allh = [None] * world
+            dist.all_gather_object(allh, bytes(buf.raw), group=group)
+            capi._chk(lib.rslo_peer_create_device_finish(handle, b"".join(allh)), "rslo_peer_create_device_finish")
+        else:
+            raise ValueError("unknown peer transport %r" % (transport,))
+        comm = PeerComm(handle, rank, world, transport)
+    except Exception as e:      # agreed below: one rank failing turns the exchange off everywhere
+        ok = 0
+        err = e
+    flags = [None] * world
+    dist.all_gather_object(flags, ok, group=group)
+    if not all(flags):
+        if comm is not None:
+            comm.close()
+        if not ok and os.environ.get("RSLO_SYNCBN_EXCHANGE", "auto") not in ("auto", ""):
+            raise err          # an explicitly requested transport that cannot be had is an error, not a silent fallback
+        return None
+    dist.barrier(group=group)   # every rank has the segment mapped before rank 0 may ever unlink it / anyone sends
+    return comm
+
+
+def comm_for(group):
+    """The PeerComm of the default process group (created on first use: a collective call -- every rank reaches its
+    first SyncBN forward at the same point), or None: explicit sub-groups, RSLO_SYNCBN_EXCHANGE=rccl, several hosts."""
+    mode = os.environ.get("RSLO_SYNCBN_EXCHANGE", "auto")
+    if group is not None or mode == "rccl" or not (dist.is_available() and dist.is_initialized()):
+        return None
+    key = id(dist.group.WORLD)
+    ent = _COMMS.get(key)
+    if ent is None or ent[0] is not dist.group.WORLD:
+        for k in list(_COMMS):               # a destroyed / re-made default group: the old comm is dead
+            old = _COMMS.pop(k)
+            if old[1]:
+                old[1].close()
+        if dist.get_world_size() < 2:
+            c = None
+        else:
+            c = create("device" if mode == "device" else "host", None)
+        ent = _COMMS[key] = (dist.group.WORLD, c)
+    return ent[1]
+
+
+def all_reduce_(t, group=None, fallback_group=None):
+    """Sum of t (float64 CUDA, <= 1024 elements) over the ranks, in place, on the current stream."""
+    c = comm_for(group) if (t.is_cuda and t.dtype == torch.float64 and t.numel() <= MAX_N) else None
+    if c is None:
+        dist.all_reduce(t, group=fallback_group if fallback_group is not None else group)
+    else:
+        c.all_reduce_(t)
+    return t
+
+
+def shutdown():
+    for k in list(_COMMS):
+        ent = _COMMS.pop(k)
+        if ent[1]:
+            ent[1].close()

