@@ -24,8 +24,10 @@ import time
 # The step keeps five HIP streams busy (training, structure plan, covariance branch, weight gradients, RCCL): with the
 # runtime's default of 4 hardware queues two of them share a queue and serialise -- a sixth stream put the training
 # stream behind a side stream for a 23 ms step.  Must be set before the HIP runtime starts.
-if os.environ.get("RSLO_BENCH_ONE_GPU", "0") != "1":      # (two ranks sharing ONE GPU would oversubscribe its queues: 192 vs 53 ms)
+if os.environ.get("RSLO_BENCH_ONE_GPU", "0") != "1":
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+else:      # ranks sharing ONE GPU (functional mode): their queues must all stay mapped -- a kernel of the peer exchange spins
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")      # until the other process's kernel runs (unset: 279 ms per step; 2: 40)
 
 import numpy as np
 import torch
@@ -860,6 +862,11 @@ def main():
             prefetch.submit(next_clouds())
 
     wait = [0.0]
+    # diagnostic for the two-ranks-on-one-GPU functional mode, where the gradient exchange runs over gloo / TCP and hides what
+    # the SyncBN exchange costs: ranks then diverge -- never a measurement of the step
+    skip_grad_exchange = os.environ.get("RSLO_BENCH_SKIP_GRAD_EXCHANGE", "0") == "1"
+    if skip_grad_exchange and dist_on and grad_exchange is not None:
+        net.__dict__.pop("_grad_exchange", None)
 
     phases = os.environ.get("RSLO_BENCH_PHASES") == "1"       # wall / CPU time of the issuing thread per phase (stderr)
     ph = {k: [0.0, 0.0] for k in ("get", "fwd", "bwd", "opt")}
@@ -889,7 +896,7 @@ def main():
         w0, c0 = mark("fwd", w0, c0)
         with amp.scale_loss(ret["loss"].mean(), opt) as scaled_loss:       # train_hdf5.py:663
             scaled_loss.backward()
-        if dist_on:
+        if dist_on and not skip_grad_exchange:
             if grad_exchange is not None:
                 grad_exchange.finish()
             else:
