@@ -13,6 +13,15 @@ import torch
 from rslo_amd import capi
 
 
+def _refuse_host(name, *tensors):
+    if any(not t.is_cuda for t in tensors):
+        raise NotImplementedError(
+            "%s: in the reference this entry point computes on the HOST for CPU tensors (chamfer_distance.cpp:147-234, "
+            "chosen at chamfer_distance.py:34,61); rslo_amd serves the chamfer path on the GPU only and has no CPU "
+            "fallback -- move the tensors to the device (same results: the kernel is bit-exact against the reference's "
+            "host code, tests/golden/chamfer_ref.npz)" % name)
+
+
 class _CD:
     """The six `cd.*` entry points (caller-allocated outputs, return None)."""
 
@@ -25,7 +34,13 @@ class _CD:
         capi.chamfer_nn(xyz1, xyz2, dist1, idx1)
         capi.chamfer_nn(xyz2, xyz1, dist2, idx2)
 
-    forward = forward_cuda
+    @staticmethod
+    def forward(xyz1, xyz2, dist1, dist2, idx1, idx2):
+        """The reference's `cd.forward` is its HOST implementation (chamfer_distance.cpp:147-190 `nnsearch` on CPU
+        tensors, selected at chamfer_distance.py:34 when the inputs are not CUDA).  This package has no CPU compute path:
+        device tensors are served (same result as forward_cuda), host tensors are refused with the difference named."""
+        _refuse_host("cd.forward", xyz1, xyz2)
+        _CD.forward_cuda(xyz1, xyz2, dist1, dist2, idx1, idx2)
 
     @staticmethod
     def backward_cuda_one_direction(xyz1, xyz2, gradxyz1, gradxyz2, graddist1, idx1):
@@ -39,7 +54,11 @@ class _CD:
         gradxyz1 += g1b
         gradxyz2 += g2b
 
-    backward = backward_cuda
+    @staticmethod
+    def backward(xyz1, xyz2, gradxyz1, gradxyz2, graddist1, graddist2, idx1, idx2):
+        """Reference: the HOST backward (chamfer_distance.cpp:192-234, chamfer_distance.py:61); see forward."""
+        _refuse_host("cd.backward", xyz1, xyz2)
+        _CD.backward_cuda(xyz1, xyz2, gradxyz1, gradxyz2, graddist1, graddist2, idx1, idx2)
 
 
 cd = _CD()

@@ -137,3 +137,18 @@ def test_numpy_voxel_generator_works_in_forked_workers(monkeypatch):
     vg = voxel_builder.build(config_text.shipped_config().model.second.voxel_generator)
     out = vg.generate(pts, 40000)
     assert (out["voxels"] == v).all() and (out["coordinates"] == c).all() and (out["num_points_per_voxel"] == m).all()
+
+
+def test_chamfer_host_entry_points_are_refused_with_the_difference_named():
+    """The reference's cd.forward / cd.backward are its HOST implementations (chamfer_distance.cpp:147-234); this package
+    has no CPU compute path for chamfer and must say so instead of aliasing silently."""
+    import pytest
+    import torch
+    import rslo_amd  # noqa: F401
+    from thirdparty.chamfer_distance.chamfer_distance import cd
+    a = torch.zeros(1, 4, 3)
+    d, i = torch.zeros(1, 4), torch.zeros(1, 4, dtype=torch.int32)
+    with pytest.raises(NotImplementedError, match="HOST"):
+        cd.forward(a, a, d, d.clone(), i, i.clone())
+    with pytest.raises(NotImplementedError, match="HOST"):
+        cd.backward(a, a, a.clone(), a.clone(), d, d.clone(), i, i.clone())
