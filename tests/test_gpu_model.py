@@ -425,9 +425,30 @@ def test_parity_on_weights_produced_by_real_optimizer_steps(hip):
     print("50 real steps: loss %.4f -> %.4f, largest weight change %.2e" % (losses[0], losses[-1], float(moved)))
     ex = workload.make_example(net, [pool[1]])
     net.zero_grad(set_to_none=True)
-    # pose bar 5e-5 here (north star 1e-4): measured 1.1e-5 / 1.4e-5 in two runs -- these weights put the vote at several
-    # metres, and the run-to-run spread of the atomically accumulated partner gradients already shows in the 50 steps
-    check_three_way(copy.deepcopy(net), ex, median_bar=5e-3, max_bar=3e-2, ratio_bar=3.0, pose_bar=5e-5)
+    # Outputs and loss terms: pose bar 5e-5 (north star 1e-4; measured 1.1e-5 / 1.4e-5 in two runs -- these weights put the vote
+    # at several metres), loss terms 1e-4.
+    (ret, g), (ret_c, c), (ret_64, d) = three_way(copy.deepcopy(net), ex)
+    for k in ("translation_preds", "rotation_preds"):
+        assert rel(ret[k], ret_c[k]) < 5e-5 and rel(ret[k], ret_64[k]) < 5e-5, k
+    for k in ("loss", "translation_loss", "rotation_loss", "pyramid_loss", "C_loss"):
+        assert rel(ret[k], ret_c[k]) < 1e-4 and rel(ret[k], ret_64[k]) < 1e-4, k
+    # Gradients.  In this regime the head's gradient is small (regression terms only) and the float64 arbiter ITSELF is
+    # hypersensitive: with default-initialised trunk weights and a sparse BEV map, BasicBlock blocks.1.1 holds channels of
+    # near-zero variance (invstd ~ 1 / sqrt(eps) = 30) whose activations sit within rounding of the ReLU threshold; moving that
+    # block's INPUT by 2.6e-6 (the GPU's forward rounding) flips two of 135 168 mask bits and moves the arbiter's own input
+    # gradient by 1.1e-2 in L2 -- measured with the block evaluated in float64 on both inputs (scripts/warmup_parity*.py,
+    # profiles/NOTES.md round 4), and everything upstream of that block (stage 0, the encoder tail) inherits it.  Given
+    # IDENTICAL inputs the HIP block equals float64 to 1e-6 (test_basic_blocks_are_exact_on_the_inputs_they_see_in_the_network).
+    # So the bar here is on what is well-posed: every tensor points the same way as the arbiter's and has its size.
+    rows = gradient_errors([g, c, d], bias_before_bn(net))
+    assert len(rows) >= 170
+    l2 = np.array([r[3] for r in rows])
+    print("warm-up regime, trained weights: gradient rel-L2 error vs float64: median %.2e, 90%% %.2e, max %.2e (%s)" % (
+        np.median(l2), np.percentile(l2, 90), l2.max(), max(rows, key=lambda r: r[3])[2]))
+    assert np.median(l2) < 1.5e-2 and l2.max() < 5e-2, (np.median(l2), l2.max())
+    # tensors the flip cannot reach (downstream of blocks.1.1 in backward order: the decoder, the heads, the covariance branch)
+    clean = [r for r in rows if any(t in r[2] for t in ("deblocks", "tq_map_conv", "pyramid_motion", "conf_model", "middle_cov_deconv"))]
+    assert len(clean) >= 40 and np.median([r[0] for r in clean]) < 2e-4, np.median([r[0] for r in clean])
     net.global_step.fill_(2000)
     net.zero_grad(set_to_none=True)
     (ret, _), (ret_c, _), (ret_64, _) = three_way(copy.deepcopy(net), ex)
@@ -440,6 +461,57 @@ def test_parity_on_weights_produced_by_real_optimizer_steps(hip):
         assert rel(ret[k], ret_c[k]) < 1e-4 and rel(ret[k], ret_64[k]) < 1e-4, k
     print("past warm-up on the trained weights: C_loss gpu %.6f cpu %.6f f64 %.6f" % (
         float(ret["C_loss"]), float(ret_c["C_loss"]), float(ret_64["C_loss"])))
+
+
+def test_basic_blocks_are_exact_on_the_inputs_they_see_in_the_network(hip):
+    """The BEV encoder's BasicBlocks, each evaluated STAND-ALONE on the input and output gradient it receives inside the
+    network (default init, sparse reduced-ring BEV map, warm-up regime -- the state in which whole-network gradient
+    comparisons are ill-conditioned, see test_parity_on_weights_produced_by_real_optimizer_steps): the fused HIP node
+    (conv3x3 -> SyncBN -> ReLU -> conv3x3 -> SyncBN -> + x -> ReLU, forward and backward) against the plain torch formulation
+    in float64 on the same inputs.  Input gradient, both weight gradients and the four affine gradients to 2e-5."""
+    import torch.nn.functional as F
+    torch.manual_seed(7)
+    net, _ = workload.build_network()
+    net.train()
+    net.global_step.fill_(50)
+    ex = workload.make_example(net, [list(reduced_pair(1)[:2])])
+    picks = {(0, 1): {}, (1, 1): {}, (1, 2): {}, (2, 2): {}}
+    for (si, bi), cap in picks.items():
+        blk = net.odom_predictor.blocks[si][bi]
+        assert blk.downsample is None
+
+        def fwd(x, _orig=blk.forward, _cap=cap):
+            _cap["x"] = (x[0] if isinstance(x, (list, tuple)) else x).detach().clone()
+            out = _orig(x)
+            t = out[0] if isinstance(out, (list, tuple)) else out
+            t.register_hook(lambda g_: _cap.__setitem__("gy", g_.detach().clone()))
+            return out
+        blk.forward = fwd
+    net(ex)["loss"].backward()
+    for (si, bi), cap in picks.items():
+        blk = net.odom_predictor.blocks[si][bi]
+        del blk.forward
+        x, gy = cap["x"], cap["gy"]
+        c1, c2 = getattr(blk.conv1, "conv1", blk.conv1), getattr(blk.conv2, "conv1", blk.conv2)
+        f = lambda t: t.detach().cpu().double().requires_grad_(True)      # noqa: E731
+        xr, w1, w2, g1, b1, g2, b2 = (f(t) for t in (x, c1.weight, c2.weight, blk.bn1.weight, blk.bn1.bias, blk.bn2.weight,
+                                                     blk.bn2.bias))
+        y1 = F.relu(F.batch_norm(F.conv2d(xr, w1, None, 1, 1), None, None, g1, b1, True, 0.0, blk.bn1.eps))
+        y2 = F.relu(F.batch_norm(F.conv2d(y1, w2, None, 1, 1), None, None, g2, b2, True, 0.0, blk.bn2.eps) + xr)
+        y2.backward(gy.cpu().double())
+        b = copy.deepcopy(blk)
+        b.zero_grad(set_to_none=True)
+        xg = x.clone().requires_grad_(True)
+        out = b([xg, None])
+        yg = out[0] if isinstance(out, (list, tuple)) else out
+        assert type(yg.grad_fn).__name__ == "_BasicBlockFnBackward"
+        yg.backward(gy)
+        got = [yg, xg.grad, getattr(b.conv1, "conv1", b.conv1).weight.grad, getattr(b.conv2, "conv1", b.conv2).weight.grad,
+               b.bn1.weight.grad, b.bn1.bias.grad, b.bn2.weight.grad, b.bn2.bias.grad]
+        want = [y2, xr.grad, w1.grad, w2.grad, g1.grad, b1.grad, g2.grad, b2.grad]
+        errs = [rel(a_, w_) for a_, w_ in zip(got, want)]
+        print("block %d.%d stand-alone vs float64 (y, dx, dw1, dw2, dg1, db1, dg2, db2):" % (si, bi), " ".join("%.1e" % e for e in errs))
+        assert max(errs) < 2e-5, ((si, bi), errs)
 
 
 def test_amp_o1_bf16_step_tracks_the_fp32_step(hip):
