@@ -7,9 +7,10 @@ lives on this host it is ONE small kernel on the current stream (rslo_peer_allre
 peers' flags, add in rank order) instead of an RCCL collective launch with its two stream hand-offs; anywhere else --
 several hosts, an explicit sub-group, a CPU tensor, RSLO_SYNCBN_EXCHANGE=rccl -- it is `dist.all_reduce`.
 
-Transport (RSLO_SYNCBN_EXCHANGE): "host" = a shared-memory segment registered with the HIP runtime (default: works
-for any GPUs of a host and for several ranks on one GPU), "device" = every rank's slice in its own HBM, opened by the
-peers through HIP IPC (reads over xGMI), "rccl" = the collective, "auto" (default) = host when the group is one host.
+Transport (RSLO_SYNCBN_EXCHANGE): "device" = every rank's slice in its own HBM, opened by the peers through HIP IPC
+(polls and pulls are xGMI reads; 5.4 us per exchange between two processes on one GPU), "host" = a shared-memory segment
+registered with the HIP runtime (any GPUs of a host; 9.3 us), "rccl" = the collective, "auto" (default) = device if every
+rank can open every handle, else host, else rccl -- agreed over the group, never a per-rank choice.
 Sums are formed in rank order on every rank: all ranks hold identical bits (an RCCL ring does not promise that)."""
 import ctypes as C
 import os
@@ -93,7 +94,7 @@ def create(transport="host", group=None):
     if not all(flags):
         if comm is not None:
             comm.close()
-        if not ok and os.environ.get("RSLO_SYNCBN_EXCHANGE", "auto") not in ("auto", ""):
+        if not ok and os.environ.get("RSLO_SYNCBN_EXCHANGE", "auto") in ("host", "device"):
             raise err          # an explicitly requested transport that cannot be had is an error, not a silent fallback
         return None
     dist.barrier(group=group)   # every rank has the segment mapped before rank 0 may ever unlink it / anyone sends
@@ -115,8 +116,10 @@ def comm_for(group):
                 old[1].close()
         if dist.get_world_size() < 2:
             c = None
-        else:
-            c = create("device" if mode == "device" else "host", None)
+        elif mode in ("host", "device"):
+            c = create(mode, None)
+        else:      # auto: slices in HBM read over xGMI if HIP IPC can be set up on every rank, else the host segment, else RCCL
+            c = create("device", None) or create("host", None)
         ent = _COMMS[key] = (dist.group.WORLD, c)
     return ent[1]
 
