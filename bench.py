@@ -972,6 +972,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    syncbn_exchange = None
+    if dist_on and world > 1:
+        from rslo_amd import peer as _peer
+        _comm = _peer.comm_for(None)
+        syncbn_exchange = _comm.transport + " (same-stream peer kernel)" if _comm is not None else "collective (all_reduce)"
+        if _comm is not None:
+            _comm.check()          # a peer that missed an exchange poisons the statistics with NaN: fail loudly, never report it
     if phases and rank == 0:
         st = torch.cuda.memory_stats(dev)
         print("allocator: %d hipMalloc calls during the %d timed steps, %d MB reserved, %d MB peak allocated, live %d -> %d MB" % (
@@ -1035,7 +1042,9 @@ def main():
                 ver = None
             line["rccl"] = {"ranks": world, "version": ver, "backend": dist.get_backend(),
                             "ms_per_step_min": round(1e3 * min(per_rank) / args.steps, 3),
-                            "ms_per_step_max": round(1e3 * max(per_rank) / args.steps, 3)}
+                            "ms_per_step_max": round(1e3 * max(per_rank) / args.steps, 3),
+                            # how the 90 SyncBN statistics exchanges per step travelled (rslo_amd/peer.py)
+                            "syncbn_exchange": syncbn_exchange}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 if pinned is not None:
@@ -1052,6 +1061,8 @@ def main():
                 line["cpu_baseline"] = {"error": repr(e)}
     if dist_on:
         dist.barrier()
+        from rslo_amd import peer as _peer
+        _peer.shutdown()             # unmap the peers' slices / unlink the shared segment before the group goes away
         dist.destroy_process_group()
     _flush_c_stdio()                 # anything the collectives library still holds goes out before the result
     if rank == 0:

@@ -282,6 +282,11 @@ __global__ void k_cg_merge(const float4 *__restrict__ sq, const u64 *__restrict_
 }
 
 static int cg_segments(int B, int N, int M) {
+  const int forced = rslo_tune(RSLO_TUNE_CHAMFER_SEGMENTS);
+  if (forced >= 1 && forced <= 8) {
+    const int cap = (int)rslo_cdiv(rslo_cdiv(M > 0 ? M : 1, CG_TILE), CG_GROUP);
+    return forced > cap ? (cap < 1 ? 1 : cap) : forced;
+  }
   const int64_t qwaves = rslo_cdiv(N > 0 ? N : 1, CG_TILE) * (B > 0 ? B : 1);
   int S = (int)rslo_cdiv(8192, qwaves);            // enough waves to balance the heavy (far-query) ones
   const int maxS = (int)rslo_cdiv(rslo_cdiv(M > 0 ? M : 1, CG_TILE), 4 * CG_GROUP);

@@ -61,6 +61,7 @@ enum RsloTune {
   RSLO_TUNE_WGRAD_XCD,                 // 1: XCD-ordered grid of the sparse weight gradients; 0: (chunk, offset) grid
   RSLO_TUNE_VFE_LDS,                   // 1: LDS-staged VFE mean; 0: one thread per voxel from memory
   RSLO_TUNE_CHAMFER,                   // 0: choose by size; 1: exhaustive; 2: pruned grid search
+  RSLO_TUNE_CHAMFER_SEGMENTS,          // pruned search: target segments per query wave (0 = choose; 1..8)
   RSLO_TUNE_COUNT
 };
 extern int g_rslo_tune[RSLO_TUNE_COUNT];

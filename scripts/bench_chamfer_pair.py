@@ -30,3 +30,17 @@ for _ in range(20):
     capi.chamfer_nn(a, b, ncnt=counts, mcnt=counts, method="grid")
 e1.record(); torch.cuda.synchronize()
 print("pruned search 4 x %d x %d: %.1f us per call (all kernels of rslo_chamfer_grid_nn)" % (N, N, 1e3 * e0.elapsed_time(e1) / 20))
+if os.environ.get("SWEEP_SEGMENTS", "0") == "1":
+    # misaligned pairs too: the second cloud moved by a bad pose (what a random-init head predicts)
+    for tag, bb in (("aligned", b), ("shift 9 m / yaw 40 deg", None)):
+        if bb is None:
+            th = np.deg2rad(40.0)
+            R = torch.tensor([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1]], dtype=torch.float32, device="cuda")
+            bb = (b @ R.T + torch.tensor([9.0, -1.8, 1.2], device="cuda")).contiguous()
+        for seg in (0, 1, 2, 4, 8):
+            with capi.tuning(chamfer_segments=seg):
+                for _ in range(3): capi.chamfer_nn(a, bb, ncnt=counts, mcnt=counts, method="grid")
+                e0.record()
+                for _ in range(20): capi.chamfer_nn(a, bb, ncnt=counts, mcnt=counts, method="grid")
+                e1.record(); torch.cuda.synchronize()
+            print("%-24s segments=%d: %.1f us per call" % (tag, seg, 1e3 * e0.elapsed_time(e1) / 20))
