@@ -972,6 +972,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    replicas_identical = None
+    if dist_on and world > 1 and not skip_grad_exchange:
+        # data parallel invariant: identical weights and BatchNorm running statistics on every rank after K steps of averaged
+        # gradients and rank-summed statistics (bit for bit: every rank applies the same update to the same values)
+        import hashlib as _hl
+        blob = torch.cat([t.detach().flatten().float() for t in list(net.parameters()) + [b_ for b_ in net.buffers()
+                                                                                      if b_.is_floating_point()]])
+        digest = _hl.sha256(blob.cpu().numpy().tobytes()).hexdigest()
+        digests = [None] * world
+        dist.all_gather_object(digests, digest)
+        replicas_identical = len(set(digests)) == 1
     syncbn_exchange = None
     if dist_on and world > 1:
         from rslo_amd import peer as _peer
@@ -1044,7 +1055,7 @@ def main():
                             "ms_per_step_min": round(1e3 * min(per_rank) / args.steps, 3),
                             "ms_per_step_max": round(1e3 * max(per_rank) / args.steps, 3),
                             # how the 90 SyncBN statistics exchanges per step travelled (rslo_amd/peer.py)
-                            "syncbn_exchange": syncbn_exchange}
+                            "syncbn_exchange": syncbn_exchange, "replicas_identical": replicas_identical}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 if pinned is not None:

@@ -66,3 +66,6 @@ def test_bench_gpus_2_runs_the_full_two_rank_step(hip):
     line = _last_json(out.stdout)
     assert line["n_gpus"] == 2 and line["value"] > 0
     assert line["rccl"]["ranks"] == 2 and line["rccl"]["ms_per_step_min"] <= line["rccl"]["ms_per_step_max"]
+    # SyncBN statistics travelled through the same-stream peer kernel, and after the steps both ranks hold the same bits
+    assert "peer kernel" in line["rccl"]["syncbn_exchange"], line["rccl"]
+    assert line["rccl"]["replicas_identical"] is True, line["rccl"]
