@@ -976,13 +976,17 @@ def main():
     if dist_on and world > 1 and not skip_grad_exchange:
         # data parallel invariant: identical weights and BatchNorm running statistics on every rank after K steps of averaged
         # gradients and rank-summed statistics (bit for bit: every rank applies the same update to the same values)
+        # (the covariance branch's nn.BatchNorm1d layers are LOCAL BatchNorm in the reference too, rslo/models/middle.py:181-198:
+        # their running statistics legitimately differ between ranks and are not part of the invariant)
         import hashlib as _hl
-        blob = torch.cat([t.detach().flatten().float() for t in list(net.parameters()) + [b_ for b_ in net.buffers()
-                                                                                      if b_.is_floating_point()]])
-        digest = _hl.sha256(blob.cpu().numpy().tobytes()).hexdigest()
-        digests = [None] * world
-        dist.all_gather_object(digests, digest)
-        replicas_identical = len(set(digests)) == 1
+        named = list(net.named_parameters()) + [(n_, b_) for n_, b_ in net.odom_predictor.named_buffers() if b_.is_floating_point()]
+        digs = {n_: _hl.sha256(t_.detach().float().cpu().numpy().tobytes()).hexdigest()[:16] for n_, t_ in named}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, digs)
+        differing = [n_ for n_ in digs if len({g_[n_] for g_ in gathered}) != 1]
+        replicas_identical = not differing
+        if differing and rank == 0:
+            print("replicas differ in %d of %d tensors, e.g. %s" % (len(differing), len(digs), differing[:12]), file=sys.stderr)
     syncbn_exchange = None
     if dist_on and world > 1:
         from rslo_amd import peer as _peer
