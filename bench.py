@@ -231,7 +231,9 @@ class ConvProbe:
             wgs = B * ((W + 15) // 16) * ((H + 3) // 4) * (cout // 32)
             kc = 2 if (cin >= 64 and cin >= 256 and wgs <= 200) else 1
             res_bytes = 4 * B * H * W * cout if residual is not None else 0      # the epilogue's residual read
-            if not lp and kc == 1 and wgs >= 512:      # >= 2 workgroups per CU: the 96-register one-tap-ahead variant
+            if not lp and cin <= 64 and cout >= 192 and cout % 64 == 0 and H * W >= 96 * 176:
+                inst = "k_conv2d_fwd<4, 2, false, false, 1, 2>"      # two channel blocks per wave (conv2d_fwd_plan)
+            elif not lp and kc == 1 and wgs >= 512:      # >= 2 workgroups per CU: the 96-register one-tap-ahead variant
                 inst = "k_conv2d_fwd<4, 1, false, false, 1, 5>"
             else:
                 inst = "k_conv2d_fwd<4, 1, true, %s, %d, %d>" % ("true" if lp else "false", kc, 2 // kc)

@@ -949,6 +949,10 @@ static int conv2d_fwd_plan(int B, int cin, int cout, int H, int W, int *tr, int 
   int t = 4, m = 1;
   if (cfg_tr == 4 || cfg_tr == 8) t = cfg_tr;
   if ((cfg_mtw == 1 || cfg_mtw == 2) && cout % (32 * cfg_mtw) == 0) m = cfg_mtw;
+  // few input channels feeding many output channels on a full-resolution map (the data gradient of the decoder's
+  // 192 -> 64 layer: 64 -> 192 at 96x176): two channel blocks per wave halve the staging per product; measured round 4
+  // (scripts/sweep_conv2d_fwd.py, B = 4): 92.2 -> 83.3 us.  Every other head shape is slower that way.
+  else if (cfg_mtw == 0 && cfg_tr == 0 && cin <= 64 && cout >= 192 && cout % 64 == 0 && (int64_t)H * W >= 96 * 176) m = 2;
   *tr = t; *mtw = m;
   return 1;
 }
