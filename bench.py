@@ -247,10 +247,9 @@ class ConvProbe:
                     ("k_conv2d_wgrad_s1<2, %s>" % ("true" if lp else "false") if stride == 1 else "k_conv2d_wgrad<2, 2>")
                     + " [%d->%d %dx%d]" % (cin, cout, H, W))
 
-        if os.environ.get("RSLO_CONV2D_FWD_CFG") is None and os.environ.get("RSLO_CONV2D_NB") is None:
-            for n, meta in (("conv2d_fwd", c2f_meta), ("conv2d_wgrad", c2w_meta)):
-                self._orig[n] = getattr(capi, n)
-                setattr(capi, n, timed(self._orig[n], meta))
+        for n, meta in (("conv2d_fwd", c2f_meta), ("conv2d_wgrad", c2w_meta)):
+            self._orig[n] = getattr(capi, n)
+            setattr(capi, n, timed(self._orig[n], meta))
         capi.spconv_fwd_direct = timed(self._orig["spconv_fwd_direct"], fwd_meta)
         capi.spconv_fwd_split = timed(self._orig["spconv_fwd_split"], split_meta)
         capi.spconv_dgrad_direct = timed(self._orig["spconv_dgrad_direct"], dgrad_meta)

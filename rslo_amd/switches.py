@@ -1,0 +1,40 @@
+"""Every environment variable the PYTHON host of this package reads, in one place (the C library reads none: its
+launch-code switches are `rslo_tuning_set`).  `tests/test_cabi.py::test_every_environment_switch_is_registered` fails when
+a module reads an `RSLO_*` variable that is not listed here, so this table is the complete list.
+
+Three kinds:
+  location   where things are
+  mode       documented modes of operation a user may want
+  path       "=0" puts one fused / hand-written stage back on its unfused formulation (torch ops or the layer-by-layer
+             nodes): the equivalence tests compare the two; not performance settings
+"""
+
+SWITCHES = {
+    # name: (default, kind, meaning)
+    "RSLO_HIP_LIB": ("", "location", "path of librslo_hip.so (default: next to the package)"),
+    "RSLO_REFERENCE_ROOT": ("", "location", "a reference checkout whose non-hot-path modules (protos, logging, ...) are forwarded to"),
+    "RSLO_SYNCBN_EXCHANGE": ("auto", "mode", "SyncBN statistics exchange: auto | device | host | rccl (rslo_amd/peer.py)"),
+    "RSLO_SYNCBN_HP_GROUP": ("0", "mode", "1: a dedicated high-priority RCCL group for the SyncBN collectives (only when they are collectives)"),
+    "RSLO_OVERLAP_GRADS": ("1", "mode", "0: one gradient bucket after backward instead of the overlapped head bucket"),
+    "RSLO_WGRAD_STREAM": ("1", "mode", "0: dense weight gradients on the issuing stream instead of the leaf stream (rslo_amd/streams.py)"),
+    "RSLO_COV_STREAM": ("1", "mode", "0: covariance branch on the training stream; 2: issued behind the whole head (A/B)"),
+    "RSLO_HOST_LEAD": ("1", "mode", "forward passes the issuing thread may run ahead of the GPU (0: unbounded)"),
+    "RSLO_NATIVE_PLAN": ("1", "mode", "0: Python-issued voxelization + rulebook plan instead of rslo_plan_encoder"),
+    "RSLO_PRESPLIT_EARLY": ("1", "mode", "0: head weight operands split in front of the head instead of beside the encoder"),
+    "RSLO_PREFETCH_PRIORITY": ("", "mode", "HIP stream priority of the structure-plan stream (default: lowest)"),
+    "RSLO_SWITCH_INTERVAL": ("0.0002", "mode", "interpreter switch interval while helper threads issue GPU work"),
+    "RSLO_SPCONV_SPLIT": ("1", "path", "0: 32/64-channel sparse layers on the fp32-MFMA kernels instead of the split-bf16 ones"),
+    "RSLO_ROW_ORDER": ("1", "path", "0: no mask-sorted tile order on the transposed tables"),
+    "RSLO_CONV2D_PASSES": ("wfd", "path", "which passes of the dense 3x3 layers run on conv2d.hip (w, f, d); empty: the library"),
+    "RSLO_CONV2D_S2": ("1", "path", "0: stride-2 layers on the library"),
+    "RSLO_FUSED_BN": ("1", "path", "0: torch BatchNorm / SyncBatchNorm instead of bn2d.hip (auto: only with > 1 rank)"),
+    "RSLO_FUSED_BLOCK": ("1", "path", "0: a BasicBlock as layer-by-layer autograd nodes instead of one node"),
+    "RSLO_FUSED_HEAD_TAIL": ("1", "path", "0: the head's element-wise tail as torch ops instead of headtail.hip"),
+    "RSLO_FUSED_LOSS_TAIL": ("1", "path", "0: loss assembly as torch ops instead of k_loss_tail_*"),
+    "RSLO_FUSED_OPTIM": ("1", "path", "0: torch.optim.Adam without fused=True under the wrapper"),
+    "RSLO_HIP_OPTIM": ("1", "path", "0: torch clip_grad_norm_ + Adam instead of optim.hip"),
+    "RSLO_CAT_UPSAMPLE": ("1", "path", "0: torch cat + Upsample in front of a deblock"),
+    "RSLO_PAIR_BEV": ("1", "path", "0: per-frame BEV maps + torch.cat instead of dense() writing the pair layout"),
+    "RSLO_BEV_DISPLAY": ("1", "path", "0: logged display maps as torch ops"),
+    "RSLO_HEAD_NHWC": ("0", "path", "bench.py only: the dense head in channels-last on the library path (measured slower)"),
+}

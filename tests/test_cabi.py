@@ -93,3 +93,22 @@ def test_plan_encoder_layout_is_consistent():
     assert lay.scratch_words == (8 * 21 * 384 * 704 + 31) // 32
     small = capi.plan_encoder_layout(spec, [100] * 8)            # fewer points than max_voxels: capacity = sum P
     assert small.cap_rows[0] == 800
+
+
+def test_every_environment_switch_is_registered():
+    """rslo_amd/switches.py is the complete list of environment variables the Python host reads; the C sources read none
+    (rslo_tuning_set)."""
+    import glob
+    import re
+    from rslo_amd import switches
+    found = set()
+    for f in glob.glob(os.path.join(ROOT, "rslo_amd", "**", "*.py"), recursive=True):
+        if f.endswith("switches.py"):
+            continue
+        found |= set(re.findall(r"RSLO_[A-Z0-9_]+", open(f).read()))
+    found = {v for v in found if not v.startswith("RSLO_TUNE")}
+    assert found <= set(switches.SWITCHES), sorted(found - set(switches.SWITCHES))
+    assert set(switches.SWITCHES) <= found | {"RSLO_HEAD_NHWC"}, sorted(set(switches.SWITCHES) - found)
+    for f in glob.glob(os.path.join(ROOT, "rslo_amd", "csrc", "**", "*"), recursive=True):
+        if os.path.isfile(f) and f.endswith((".hip", ".h", ".c")):
+            assert "getenv" not in open(f).read(), f
