@@ -149,8 +149,8 @@ def _flush_c_stdio():
         pass
 
 
-PMC_TRAFFIC = "r03_pmc_traffic_bench.json"
-PMC_BUSY = "r03_pmc_mfma_busy.json"
+PMC_TRAFFIC = "r04_pmc_traffic_bench.json"
+PMC_BUSY = "r04_pmc_mfma_busy.json"
 
 
 # --------------------------------------------------------------------------------------------- kernel events

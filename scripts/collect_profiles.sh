@@ -12,12 +12,11 @@ open("profiles/%s_bench_line.json" % R, "w").write(json.dumps(runs[1]) + "\n")
 print("bench line: %.1f frame-pairs/s, %.3f ms per step (runs: %s)" % (runs[1]["value"], runs[1]["ms_per_step"],
       ", ".join("%.3f" % d["ms_per_step"] for d in runs)))
 PY
-cp $G/bench_${R}_bf16.json $P/${R}_bench_line_bf16.json
+for c in c2 c4 c5; do [ -f $G/bench_${R}_$c.json ] && cp $G/bench_${R}_$c.json $P/${R}_bench_line_$c.json; done
 cp $G/bench_${R}_with_cpu.json $P/${R}_bench_line_with_cpu_baseline.json
 cp $G/${R}_kernel_stats.csv $P/${R}_kernel_stats.csv
 cp $G/prof_${R}_last_step.txt $P/${R}_step_breakdown.txt
 cp $G/prof_${R}fix_last_step.txt $P/${R}_step_breakdown_fixed_plan.txt
 for f in pmc_mfma_busy pmc_sq_waits pmc_traffic_bench; do cp $G/${R}_$f.json $P/${R}_$f.json; done
-for f in timeline_gaps.txt torch_launch_sites.txt nccl_n1.log; do [ -f $G/${R}_$f ] && cp $G/${R}_$f $P/${R}_$f; done
-for f in encoder_c2 encoder_c5; do [ -f $G/${R}_$f.json ] && cp $G/${R}_$f.json $P/${R}_$f.json; done
+for f in timeline_gaps.txt torch_launch_sites.txt nccl_n1.log two_rank_one_gpu.log; do [ -f $G/${R}_$f ] && cp $G/${R}_$f $P/${R}_$f; done
 grep -h lib_sha256 $P/${R}_pmc_*.json | sort | uniq -c

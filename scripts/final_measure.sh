@@ -2,7 +2,6 @@
 # breakdowns (whole step and training stream alone), the three PMC passes (stamped with the library hash).
 R=${ROUND:-r02}
 for i in 1 2 3; do timeout 200 python bench.py --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/bench_${R}_$i.json; cut -c100-230 gpurun_out/bench_${R}_$i.json; done
-timeout 200 python bench.py --dtype bf16 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/bench_${R}_bf16.json; cut -c100-230 gpurun_out/bench_${R}_bf16.json
 STEP_MARK=kb_vox_insert VOX_PER_STEP=1 TAG=$R STEPS=5 TOP=70 bash scripts/prof_stats.sh > gpurun_out/prof_$R.log 2>&1; head -9 gpurun_out/prof_${R}_last_step.txt
 ROUND=$R bash scripts/pmc_bench_traffic.sh > gpurun_out/pmc_traffic.log 2>&1; grep "v6<64, 64, 2" gpurun_out/pmc_traffic.log
 ROUND=$R bash scripts/pmc_mfma_busy.sh > gpurun_out/pmc_busy.log 2>&1; grep "v6<64, 64, 2\|conv2d_fwd\|conv2d_str" gpurun_out/pmc_busy.log
@@ -14,7 +13,8 @@ unset RSLO_BENCH_FIXED_PLAN BENCH_ARGS
 # through RCCL at N = 1, and the torch-native launches left in the step
 python scripts/timeline_gaps.py $(find /tmp/prof_$R -name "*kernel_trace.csv" | head -1) > gpurun_out/${R}_timeline_gaps.txt 2>&1
 timeout 900 python bench.py 2>/dev/null | tail -1 > gpurun_out/bench_${R}_with_cpu.json; cut -c100-230 gpurun_out/bench_${R}_with_cpu.json
-timeout 300 python scripts/bench_encoder.py c2 gpurun_out/${R}_encoder_c2.json > gpurun_out/${R}_encoder_c2.log 2>&1; tail -2 gpurun_out/${R}_encoder_c2.log
-timeout 300 python scripts/bench_encoder.py c5 gpurun_out/${R}_encoder_c5.json > gpurun_out/${R}_encoder_c5.log 2>&1; tail -2 gpurun_out/${R}_encoder_c5.log
+for c in c2 c4 c5; do timeout 600 python bench.py --config $c 2>/dev/null | tail -1 > gpurun_out/bench_${R}_$c.json; cut -c1-200 gpurun_out/bench_${R}_$c.json; done
+# the two-rank step on ONE GPU (functional mode): peer SyncBN exchange + overlapped gradient exchange over gloo, replicas compared
+RSLO_BENCH_ONE_GPU=1 timeout 600 python bench.py --gpus 2 --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/${R}_two_rank_one_gpu.log 2>&1; tail -1 gpurun_out/${R}_two_rank_one_gpu.log | cut -c100-230
 RSLO_BENCH_FORCE_DIST=1 timeout 300 python bench.py --no-cpu-baseline > gpurun_out/${R}_nccl_n1.log 2>&1; tail -1 gpurun_out/${R}_nccl_n1.log | cut -c100-230
 timeout 200 python scripts/torch_launch_sites.py > gpurun_out/${R}_torch_launch_sites.txt 2>&1; grep "torch-native" gpurun_out/${R}_torch_launch_sites.txt
