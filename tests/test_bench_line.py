@@ -69,3 +69,22 @@ def test_bench_gpus_2_runs_the_full_two_rank_step(hip):
     # SyncBN statistics travelled through the same-stream peer kernel, and after the steps both ranks hold the same bits
     assert "peer kernel" in line["rccl"]["syncbn_exchange"], line["rccl"]
     assert line["rccl"]["replicas_identical"] is True, line["rccl"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", ["c2", "c5"])
+def test_bench_encoder_configs_print_the_same_schema(hip, cfg):
+    """BASELINE configs[1] / configs[4] through the entry point the driver calls: same JSON schema as the C3 line, roofline from
+    the launch probe, CPU baseline over the oracle backend."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", cfg, "--steps", "5", "--warmup", "3"],
+                         capture_output=True, text=True, timeout=1200, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = _last_json(out.stdout)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["unit"] == "frame-pairs/s"
+    assert line["config"]["workload"].startswith(cfg.upper()) and line["config"]["voxelize_and_plan_on_side_stream"] is True
+    r = line["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and 0 < r["frac"] < 1 and "k_spconv" in r["kernel"]
+    assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["kind"] == "port"
