@@ -177,7 +177,7 @@ extern "C" int rslo_peer_create_device_begin(int rank, int world, int max_n, voi
   if (e == hipSuccess) e = hipDeviceSynchronize();
   if (e == hipSuccess) e = hipIpcGetMemHandle((hipIpcMemHandle_t *)handle_out, c->own_slice);
   if (e != hipSuccess) {
-    if (c->own_slice) hipFree(c->own_slice);
+    if (c->own_slice) (void)hipFree(c->own_slice);
     delete c;
     rslo_set_error("rslo_peer_create_device_begin: %s", hipGetErrorString(e));
     return RSLO_ELAUNCH;
@@ -237,17 +237,17 @@ extern "C" unsigned long long rslo_peer_status(void *comm, int *peer) {
 extern "C" int rslo_peer_destroy(void *comm) {
   RsloPeerComm *c = (RsloPeerComm *)comm;
   if (!c) return RSLO_OK;
-  hipDeviceSynchronize();
+  (void)hipDeviceSynchronize();
   if (c->transport == 0) {
-    hipHostUnregister(c->shm_ptr);
+    (void)hipHostUnregister(c->shm_ptr);
     munmap(c->shm_ptr, c->shm_bytes);
     if (c->rank == 0) shm_unlink(c->shm_name);
   } else {
     for (int r = 0; r < c->world; ++r)
-      if (c->peer_open[r]) hipIpcCloseMemHandle(c->peer_open[r]);
-    if (c->own_slice) hipFree(c->own_slice);
+      if (c->peer_open[r]) (void)hipIpcCloseMemHandle(c->peer_open[r]);
+    if (c->own_slice) (void)hipFree(c->own_slice);
   }
-  hipHostFree(c->status_host);
+  (void)hipHostFree(c->status_host);
   delete c;
   return RSLO_OK;
 }

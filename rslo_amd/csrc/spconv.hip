@@ -614,7 +614,11 @@ __global__ __launch_bounds__(SPC_THREADS) void k_spconv_v6(const float *__restri
   while (mask) {
     const int k = __builtin_ctz(mask);
     mask &= mask - 1;
+#ifdef SPC_EXPERIMENT_ALIAS_W      // scripts/variant_spconv.sh only: every offset reads offset 0's 24 KB slice (L1-resident) -- the
+    const int kk = 0;              // timing upper bound of any weight-stationary scheme, results are wrong by construction
+#else
     const int kk = flip_k ? (K - 1 - k) : k;
+#endif
     const float *ap[RBW];
     bool ok[RBW];
 #pragma unroll
