@@ -309,8 +309,12 @@ class ConvProbe:
                 return {}, "profiles/%s was collected with another build of librslo_hip.so (%s, now %s)" % (
                     fname, d.get("lib_sha256"), here)
             return d.get("kernels", {}), None
-        pmc, pmc_note = load_pmc(PMC_TRAFFIC)
-        pmc_busy, busy_note = load_pmc(PMC_BUSY)
+        if getattr(self, "pmc_workload_ok", True):
+            pmc, pmc_note = load_pmc(PMC_TRAFFIC)
+            pmc_busy, busy_note = load_pmc(PMC_BUSY)
+        else:      # the PMC passes were collected on the C3 step: per-launch figures of other workloads are not theirs
+            pmc, pmc_busy = {}, {}
+            pmc_note = busy_note = "PMC summaries under profiles/ are of the C3 workload (scripts/pmc_*.sh)"
 
         def roof_of(gname):
             g = groups[gname]
@@ -593,6 +597,7 @@ def run_encoder(args, world, rank, local_rank, dist_on, dev):
         return bev
 
     probe = ConvProbe(capi)
+    probe.pmc_workload_ok = False
     use_probe = (not args.no_kernel_events) and rank == 0
     if use_probe:
         probe.install()
