@@ -89,6 +89,8 @@ def create(transport="host", group=None):
     except Exception as e:      # agreed below: one rank failing turns the exchange off everywhere
         ok = 0
         err = e
+        if comm is None and handle.value:      # begun but not finished (a peer's handle would not open): give it back
+            lib.rslo_peer_destroy(handle)
     flags = [None] * world
     dist.all_gather_object(flags, ok, group=group)
     if not all(flags):
