@@ -100,6 +100,32 @@ def create(transport="host", group=None):
             raise err          # an explicitly requested transport that cannot be had is an error, not a silent fallback
         return None
     dist.barrier(group=group)   # every rank has the segment mapped before rank 0 may ever unlink it / anyone sends
+    # Self-test before the transport carries statistics: a few exchanges of rank-dependent values with a short timeout,
+    # checked on the host on every rank.  A transport that maps but does not deliver on this machine (peer access, coherence
+    # of the mapping, kernels of the ranks not co-scheduled) is dropped HERE, by agreement, and the next one is tried.
+    good = 1
+    try:
+        comm.set_timeout_ms(3000)
+        tri = world * (world + 1) // 2
+        for n in (3, 513, MAX_N, 129):
+            t = torch.arange(n, dtype=torch.float64, device="cuda") * float(rank + 1) + float(rank)
+            comm.all_reduce_(t)
+            want = torch.arange(n, dtype=torch.float64) * float(tri) + float(tri - world)
+            if not torch.equal(t.cpu(), want):
+                good = 0
+        if comm.status()[0]:
+            good = 0
+        comm.set_timeout_ms(20000)
+    except Exception:
+        good = 0
+    flags = [None] * world
+    dist.all_gather_object(flags, good, group=group)
+    if not all(flags):
+        comm.close()
+        if os.environ.get("RSLO_SYNCBN_EXCHANGE", "auto") in ("host", "device"):
+            raise capi.RsloHipError("peer exchange (%s transport) failed its self-test on ranks %s" % (
+                transport, [r for r, f in enumerate(flags) if not f]))
+        return None
     return comm
 
 
