@@ -692,7 +692,7 @@ RSLO_API int rslo_opt_adam_step(const RsloOptTensor *tensors_dev, const RsloOptC
  *      (and rslo_bn2d_bwd_reduce / _bwd_apply).  Every rank owns a slice (4 slots of {flag, payload}) the others can read;
  *      rslo_peer_allreduce_f64 writes the own payload + flag, waits for every peer's flag of the same exchange number, and
  *      sums the payloads in rank order (identical bits on every rank) into t, in place.  All ranks must issue the same
- *      sequence of exchanges.  A peer that does not arrive within the timeout (default 20 s) poisons t with NaN and is
+ *      sequence of exchanges, and all exchanges of one comm go to ONE stream (slot reuse relies on their order).  A peer that does not arrive within the timeout (default 20 s) poisons t with NaN and is
  *      reported by rslo_peer_status -- the kernel never hangs the GPU.
  *      Transports:  host   = one POSIX shared-memory segment `name` (every rank passes the same name) registered with the
  *                            HIP runtime: any GPUs of one host, also several ranks on one GPU;
@@ -700,6 +700,7 @@ RSLO_API int rslo_opt_adam_step(const RsloOptTensor *tensors_dev, const RsloOptC
  *                            bytes (begin), the handles of ALL ranks in rank order handed back (finish): peers read it
  *                            over xGMI.  world <= 16, max_n <= 1024. */
 RSLO_API int rslo_peer_create_host(const char *name, int rank, int world, int max_n, void **comm_out);
+RSLO_API int rslo_peer_host_unlink(void *comm);   /* after the caller's barrier: drop the segment's name (mappings stay) */
 RSLO_API int rslo_peer_ipc_handle_bytes(void);
 RSLO_API int rslo_peer_create_device_begin(int rank, int world, int max_n, void **comm_out, void *handle_out);
 RSLO_API int rslo_peer_create_device_finish(void *comm, const void *all_handles);

@@ -43,6 +43,7 @@ SIGNATURES = {
     "rslo_spconv_fwd_split": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, C.c_float, _vp, _vp]),
     "rslo_spconv_set_tiling": (None, [_i, _i]),
     "rslo_peer_create_host": (C.c_int, [C.c_char_p, _i, _i, _i, C.POINTER(C.c_void_p)]),
+    "rslo_peer_host_unlink": (C.c_int, [_vp]),
     "rslo_peer_ipc_handle_bytes": (C.c_int, []),
     "rslo_peer_create_device_begin": (C.c_int, [_i, _i, _i, C.POINTER(C.c_void_p), _vp]),
     "rslo_peer_create_device_finish": (C.c_int, [_vp, _vp]),

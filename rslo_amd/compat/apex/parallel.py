@@ -260,6 +260,7 @@ class DistributedDataParallel(nn.Module):
 
     def forward(self, *inputs, **kwargs):
         out = self.module(*inputs, **kwargs)
+        self._queued = False      # (a backward pass that raised before its callback ran must not silence the next one)
         if torch.is_grad_enabled() and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             ts = out.values() if isinstance(out, dict) else (out if isinstance(out, (list, tuple)) else (out,))
             for t in ts:

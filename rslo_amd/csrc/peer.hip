@@ -160,6 +160,18 @@ extern "C" int rslo_peer_create_host(const char *name, int rank, int world, int 
   return RSLO_OK;
 }
 
+// Once every rank has the segment mapped (the caller's barrier), its NAME can go: the mapping stays alive while mapped, and a
+// rank that dies later leaves nothing behind in /dev/shm (which is memory on a box without swap).
+extern "C" int rslo_peer_host_unlink(void *comm) {
+  RsloPeerComm *c = (RsloPeerComm *)comm;
+  RSLO_CHECK_ARG(c && c->transport == 0, "rslo_peer_host_unlink: not a host-transport comm");
+  if (c->shm_name[0]) {
+    shm_unlink(c->shm_name);
+    c->shm_name[0] = 0;
+  }
+  return RSLO_OK;
+}
+
 extern "C" int rslo_peer_ipc_handle_bytes(void) { return (int)sizeof(hipIpcMemHandle_t); }
 
 extern "C" int rslo_peer_create_device_begin(int rank, int world, int max_n, void **comm_out, void *handle_out) {
@@ -241,7 +253,7 @@ extern "C" int rslo_peer_destroy(void *comm) {
   if (c->transport == 0) {
     (void)hipHostUnregister(c->shm_ptr);
     munmap(c->shm_ptr, c->shm_bytes);
-    if (c->rank == 0) shm_unlink(c->shm_name);
+    if (c->rank == 0 && c->shm_name[0]) shm_unlink(c->shm_name);
   } else {
     for (int r = 0; r < c->world; ++r)
       if (c->peer_open[r]) (void)hipIpcCloseMemHandle(c->peer_open[r]);

@@ -100,6 +100,8 @@ def create(transport="host", group=None):
             raise err          # an explicitly requested transport that cannot be had is an error, not a silent fallback
         return None
     dist.barrier(group=group)   # every rank has the segment mapped before rank 0 may ever unlink it / anyone sends
+    if transport == "host" and rank == 0:
+        lib.rslo_peer_host_unlink(handle)      # the name goes now: a rank that dies later leaves nothing in /dev/shm
     # Self-test before the transport carries statistics: a few exchanges of rank-dependent values with a short timeout,
     # checked on the host on every rank.  A transport that maps but does not deliver on this machine (peer access, coherence
     # of the mapping, kernels of the ranks not co-scheduled) is dropped HERE, by agreement, and the next one is tried.
