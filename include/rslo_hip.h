@@ -599,6 +599,20 @@ RSLO_API int rslo_conv2d_fwd(const float *in, const void *Ws, const float *bias,
  *      the same bits as the convolution followed by a separate element-wise add.  res must not alias out. */
 RSLO_API int rslo_conv2d_fwd_add(const float *in, const void *Ws, const float *bias, const float *res, int B, int cin,
                                  int cout, int H, int W, float *out, void *stream);
+/*      Operand planes (round 5).  A dense activation [B,C,H,W] fp32 (C % 8 == 0) stored ONCE, by its producer, in the
+ *      form the convolution's MFMA operands have:  P[b][C/8][3 = hi|mid|lo][H][W][8] bf16 bit patterns, hi + mid + lo ==
+ *      the fp32 value exactly (the split k_conv2d_fwd performs per workgroup while staging).  rslo_opl_bytes: size of P;
+ *      rslo_opl_from_nchw: the stand-alone producer; the BatchNorm apply entry points with a `planes` argument write the
+ *      same layout from their epilogue.  rslo_conv2d_fwd_p = rslo_conv2d_fwd / _fwd_add reading P instead of the fp32
+ *      tensor (Ws with transpose = 1 and the planes of dout: the data gradient): same arithmetic, bit-identical
+ *      results, no operand split and no strided loads in the convolution.  Replaces the same reference calls:
+ *      nn.Conv2d inside rslo/layers/MaskConv.py:30-63 as used by custom_resnet_spc.py:224-298 and
+ *      rslo/models/odom_pred_base.py:155-207. */
+RSLO_API size_t rslo_opl_bytes(int B, int C, int H, int W);
+RSLO_API int rslo_opl_from_nchw(const float *in, int B, int C, int H, int W, void *planes, void *stream);
+RSLO_API int rslo_conv2d_fwd_p_supported(int cin, int cout, int H, int W);
+RSLO_API int rslo_conv2d_fwd_p(const void *planes, const void *Ws, const float *bias, const float *res /* or NULL */,
+                               int B, int cin, int cout, int H, int W, float *out, void *stream);
 /*      The stride-2 layers of the BEV encoder (first 3x3 convolution and 1x1 downsample of every stage,
  *      rslo/models/odom_pred.py:398-426): ksize 3 (padding 1) or 1 (padding 0), no bias (the reference builds them
  *      bias-free in front of a BatchNorm).  in [B,cin,H,W] -> out [B,cout,Ho,Wo], Ho = (H - 1) / 2 + 1.

@@ -160,6 +160,10 @@ SIGNATURES = {
     "rslo_head_masks_bwd": (C.c_int, [_vp, _vp]),
     "rslo_loss_tail_fwd": (C.c_int, [_vp, _vp, _vp]),
     "rslo_loss_tail_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "rslo_opl_bytes": (_sz, [_i, _i, _i, _i]),
+    "rslo_opl_from_nchw": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "rslo_conv2d_fwd_p_supported": (C.c_int, [_i, _i, _i, _i]),
+    "rslo_conv2d_fwd_p": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "rslo_opt_clip_grad_norm": (C.c_int, [_vp, _vp, _i, _f, _vp, _vp, _vp]),
     "rslo_opt_adam_step": (C.c_int, [_vp, _vp, _i, _vp, _f, _vp]),
 }
@@ -1429,6 +1433,36 @@ def conv2d_fwd(x, ws, bias, cout, lp=False, residual=None):
             _stream())
     if rc:
         _chk(rc, "rslo_conv2d_fwd")
+    return out
+
+
+def opl_from_nchw(x):
+    """x [B,C,H,W] contiguous fp32 (C % 8 == 0) -> operand planes [B, C/8, 3, H, W, 8] bf16 bit patterns (int16):
+    the exact hi / mid / lo split, one 16-byte piece per (pixel, channel octet, plane) -- what conv2d_fwd_p stages."""
+    B, Cc, H, W = x.shape
+    pl = torch.empty((B, Cc // 8, 3, H, W, 8), dtype=torch.int16, device=x.device)
+    _chk(lib().rslo_opl_from_nchw(_ptr(x, torch.float32, "x"), B, Cc, H, W, pl.data_ptr(), _stream()), "rslo_opl_from_nchw")
+    return pl
+
+
+def conv2d_fwd_p_supported(cin, cout, H, W):
+    return bool(lib().rslo_conv2d_fwd_p_supported(int(cin), int(cout), int(H), int(W)))
+
+
+def conv2d_fwd_p(planes, ws, bias, cout, residual=None):
+    """planes [B,cin/8,3,H,W,8] (opl_from_nchw or a BatchNorm apply kernel), ws from conv2d_wsplit -> [B,cout,H,W] fp32
+    (3x3, stride 1, padding 1): the same bits as conv2d_fwd on the un-split tensor."""
+    B, no, _, H, W, _ = planes.shape
+    out = torch.empty((B, cout, H, W), dtype=torch.float32, device=planes.device)
+    if residual is not None and (tuple(residual.shape) != tuple(out.shape) or not residual.is_contiguous()):
+        raise ValueError("conv2d_fwd_p: residual must be a contiguous %s tensor" % (tuple(out.shape),))
+    if not planes.is_contiguous() or planes.dtype != torch.int16:
+        raise ValueError("conv2d_fwd_p: planes must be a contiguous int16 tensor")
+    rc = lib().rslo_conv2d_fwd_p(planes.data_ptr(), ws.data_ptr(), _dp(bias),
+                                 _ptr(residual, torch.float32, "residual") if residual is not None else None,
+                                 B, no * 8, cout, H, W, out.data_ptr(), _stream())
+    if rc:
+        _chk(rc, "rslo_conv2d_fwd_p")
     return out
 
 

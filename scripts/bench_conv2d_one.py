@@ -12,13 +12,16 @@ x = torch.randn(B, cin, H, W, device="cuda")
 w = torch.randn(cout, cin, 3, 3, device="cuda") / (3 * cin ** 0.5)
 ws = capi.conv2d_wsplit(w, False)
 ref = torch.nn.functional.conv2d(x, w, None, 1, 1)
-y = capi.conv2d_fwd(x, ws, None, cout)
+PLANES = os.environ.get("PLANES", "0") == "1"       # k_conv2d_fwd_p on pre-split operand planes
+pl = capi.opl_from_nchw(x) if PLANES else None
+run = (lambda: capi.conv2d_fwd_p(pl, ws, None, cout)) if PLANES else (lambda: capi.conv2d_fwd(x, ws, None, cout))
+y = run()
 print("rel err", float((y - ref).abs().max() / ref.abs().max()))
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(N):
-    capi.conv2d_fwd(x, ws, None, cout)
+    run()
 e1.record(); torch.cuda.synchronize()
 gf = 2.0 * B * H * W * cin * cout * 9 / 1e9
 t = e0.elapsed_time(e1) / N * 1e3

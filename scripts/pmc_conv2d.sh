@@ -3,6 +3,7 @@
 OUT=/tmp/pmc_c2; rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 [ -n "$CFG" ] && export RSLO_TUNING="conv2d_fwd_tr=${CFG%%,*},conv2d_fwd_mtw=$(echo $CFG | cut -d, -f2)"
+[ -n "$TUNING" ] && export RSLO_TUNING="$TUNING"      # explicit switch list (scripts/_tuning.py), e.g. conv2d_ablate=1
 run() {
   tag=$1; shift
   timeout -k 5 200 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$tag -o p -- python $GRAFT_REPO_ROOT/scripts/bench_conv2d_one.py > $OUT/$tag.log 2>&1

@@ -1112,6 +1112,39 @@ def test_conv2d_fwd_and_dgrad_match_float64_oracle(hip, B, cin, cout, H, W, cfg)
     assert torch.equal(joined, hip.conv2d_fwd(dev(g), wt, None, cin, lp=True).add_(res))
 
 
+@pytest.mark.parametrize("B,cin,cout,H,W,cfg", [
+    (2, 32, 64, 12, 22, {}), (2, 96, 64, 25, 23, {}),                 # small / odd maps: ragged tiles, borders in every tile
+    (4, 128, 128, 48, 88, {}), (1, 64, 64, 96, 176, {}),              # the one-tap-ahead variant (>= 512 workgroups)
+    (2, 64, 128, 16, 40, {"conv2d_fwd_tr": 8, "conv2d_fwd_mtw": 2}), (2, 64, 128, 16, 40, {"conv2d_fwd_tr": 8}),
+    (2, 64, 128, 16, 40, {"conv2d_fwd_mtw": 2}), (2, 64, 128, 48, 88, {"conv2d_fwd_lean": 0}),
+])
+def test_conv2d_planes_kernel_is_bit_identical_to_the_fp32_staged_kernel(hip, B, cin, cout, H, W, cfg):
+    """rslo_opl_from_nchw + rslo_conv2d_fwd_p (pre-split operand planes, round 5) against rslo_conv2d_fwd on the same
+    tensor: the producer's split is the split the staged kernel performs and the six products are accumulated in the same
+    order, so forward (with bias), data gradient and the residual epilogue are equal BIT FOR BIT; and the planes
+    themselves recompose to the fp32 values exactly (hi + mid + lo)."""
+    rng = np.random.default_rng(21)
+    x = dev(rng.standard_normal((B, cin, H, W)).astype(np.float32))
+    g = dev(rng.standard_normal((B, cout, H, W)).astype(np.float32))
+    w = dev((rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(9 * cin)).astype(np.float32))
+    bias = dev(rng.standard_normal(cout).astype(np.float32))
+    res = dev(rng.standard_normal((B, cin, H, W)).astype(np.float32))
+    wf, wt = hip.conv2d_wsplit(w, False), hip.conv2d_wsplit(w, True)
+    assert hip.conv2d_fwd_p_supported(cin, cout, H, W)
+    px, pg = hip.opl_from_nchw(x), hip.opl_from_nchw(g)
+    # planes [B, C/8, 3, H, W, 8] bf16 bit patterns -> fp32: exact recomposition
+    back = (px.view(torch.bfloat16).float().sum(dim=2)).permute(0, 1, 4, 2, 3).reshape(B, cin, H, W)
+    assert torch.equal(back, x)
+    ref_y = hip.conv2d_fwd(x, wf, bias, cout)
+    ref_dx = hip.conv2d_fwd(g, wt, None, cin, residual=res)
+    with hip.tuning(**cfg):
+        y = hip.conv2d_fwd_p(px, wf, bias, cout)
+        dx = hip.conv2d_fwd_p(pg, wt, None, cin, residual=res)
+    assert torch.equal(y, ref_y) and torch.equal(dx, ref_dx)
+    r = O.conv2d_fwd(x.cpu().numpy(), w.cpu().numpy(), bias.cpu().numpy())
+    assert np.abs(y.cpu().numpy() - r).max() <= 2e-5 * np.abs(r).max()
+
+
 @pytest.mark.parametrize("B,cin,cout,H,W,k", [
     (2, 64, 32, 12, 22, 3), (2, 64, 32, 12, 22, 1),          # small even map
     (1, 32, 64, 13, 21, 3), (1, 32, 64, 13, 21, 1),          # odd sizes: ragged parity classes
