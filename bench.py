@@ -930,8 +930,12 @@ def main():
             ph[name][1] += time.thread_time() - c0
         return time.perf_counter(), time.thread_time()
 
+    ph_hook = [None]
+
     def step():
         w0, c0 = time.perf_counter(), time.thread_time()
+        if ph_hook[0]:
+            ph_hook[0]("optimizer_and_step_start")
         if prefetch is not None:
             tw = time.perf_counter()
             ex = prefetch.get()
@@ -947,6 +951,8 @@ def main():
         if prefetch is not None:
             prefetch.submit(next_clouds())
         w0, c0 = mark("fwd", w0, c0)
+        if ph_hook[0]:
+            ph_hook[0]("forward")
         with amp.scale_loss(ret["loss"].mean(), opt) as scaled_loss:       # train_hdf5.py:663
             scaled_loss.backward()
         if dist_on and not skip_grad_exchange:
@@ -955,6 +961,8 @@ def main():
             else:
                 average_gradients(net, mean=True)
         w0, c0 = mark("bwd", w0, c0)
+        if ph_hook[0]:
+            ph_hook[0]("backward")
         if not args.no_optim:
             hip_optim.clip_grad_norm_(params, 10.0, optimizer=opt)      # train_hdf5.py:671 on the optimizer's tables
             opt.step()
@@ -1056,6 +1064,68 @@ def main():
             "%s %.2f/%.2f" % (k, 1e3 * v[0] / args.steps, 1e3 * v[1] / args.steps) for k, v in ph.items()), file=sys.stderr)
     loss_val = float(ret["loss"].detach().mean().item())
     per_step = np.array([marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)])
+    # Where the training stream's time goes, from HIP events alone (rslo_amd/streamprobe.py): extra steps AFTER the timed
+    # region, every launching library call and every explicit stream join bracketed by events on its stream
+    stream_split = None
+    if world == 1 and not dist_on and not args.no_kernel_events and os.environ.get("RSLO_BENCH_STREAM_SPLIT", "1") != "0":
+        from rslo_amd import streamprobe
+        n_split = 3
+        tstream = torch.cuda.current_stream(dev)
+        step(); torch.cuda.synchronize()
+        capi.probe_streams(True)
+        streamprobe.mark("begin", tstream)
+        for _ in range(n_split):
+            step()
+        streamprobe.mark("end", tstream)
+        stream_split = streamprobe.summarize(tstream, n_split)
+        capi.probe_streams(False)
+        stream_split["plain_step_ms"] = round(float(np.median(per_step)), 3)
+        # how far the issuing threads run ahead of the GPU in the PLAIN step (no probe in the library calls): four points per
+        # step, each an event on the training stream + the host clock, both zeroed at a drained stream.  lag = GPU time of
+        # the point - host time of the point: ~0 means the GPU executed the phase's last launch as soon as it was issued
+        # (the stream had been waiting for the host), a large lag means the host was ahead.
+        lagpts = []
+        hook = {"pts": None}
+
+        def point(name):
+            if hook["pts"] is not None:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record(tstream)
+                hook["pts"].append((name, time.perf_counter(), ev))
+        ph_hook[0] = point
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev0.record(tstream)
+        tstream.synchronize()
+        h0 = time.perf_counter()
+        hook["pts"] = lagpts
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize()
+        ph_hook[0] = None
+        agg = {}
+        for name, h, ev in lagpts:
+            agg.setdefault(name, []).append(ev0.elapsed_time(ev) - 1e3 * (h - h0))
+        stream_split["plain_step_gpu_lag_behind_host_ms"] = {k: round(float(np.median(v)), 3) for k, v in agg.items()}
+        seq = [(n, 1e3 * (h - h0), ev0.elapsed_time(ev)) for n, h, ev in lagpts]
+        dh, dg = {}, {}
+        for (n0, h_a, g_a), (n1, h_b, g_b) in zip(seq[:-1], seq[1:]):
+            dh.setdefault(n1, []).append(h_b - h_a)
+            dg.setdefault(n1, []).append(g_b - g_a)
+        # the same lag at every dense / sparse convolution launch of the training stream (one event each, ~150 per step)
+        capi.probe_streams(True, points_only=("rslo_conv2d_fwd", "rslo_conv2d_fwd_add", "rslo_spconv_fwd", "rslo_spconv_fwd_split",
+                                              "rslo_spconv_dgrad", "rslo_conv2d_fwd_s2", "rslo_conv2d_dgrad_s2_add",
+                                              "rslo_bn2d_fwd_local", "rslo_bn2d_bwd_local"))
+        streamprobe.mark("begin", tstream)
+        for _ in range(5):
+            step()
+        streamprobe.mark("end", tstream)
+        stream_split["plain_step_lag_at_conv_launches"] = streamprobe.lag_profile(tstream)
+        capi.probe_streams(False)
+        stream_split["plain_step_phase_ms"] = {k: {"host_issue": round(float(np.median(dh[k])), 3),
+                                                   "gpu": round(float(np.median(dg[k])), 3)} for k in dh}
     if rank == 0:
         roof = None
         if use_probe and probe.records:
@@ -1099,6 +1169,10 @@ def main():
                        "host_held_back_ms_per_step": round(1e3 * held_back / args.steps, 3),
                        "prefetch_thread_cpu_ms_per_step": (round(1e3 * prefetch.cpu_seconds / max(prefetch.jobs, 1), 3)
                                                            if prefetch is not None and hasattr(prefetch, "jobs") else None),
+                       # the training stream's step split into probed kernel time, explicit stream joins and the rest
+                       # (boundaries between dependent launches + unprobed torch kernels); measured on 3 extra steps
+                       # with events around every library call, so its window is longer than the plain step
+                       "train_stream_split": stream_split,
                        "final_loss": round(loss_val, 4)},
             "roofline": roof,
             "cpu_baseline": None,

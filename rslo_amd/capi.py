@@ -187,7 +187,23 @@ def lib():
             fn.restype = res
             fn.argtypes = args
         _lib = l
-    return _lib
+    return _lib if _proxy is None else _proxy
+
+
+_proxy = None
+
+
+def probe_streams(on, points_only=None):
+    """bench.py: while on, lib() hands out streamprobe.LibProxy -- every launching entry point is bracketed by HIP events on
+    its stream (rslo_amd/streamprobe.py).  Off (the default, and during every timed step): the plain library."""
+    global _proxy
+    from rslo_amd import streamprobe
+    if on:
+        _proxy = streamprobe.LibProxy(lib() if _proxy is None else _proxy._lib, SIGNATURES, points_only)
+        streamprobe.start()
+    else:
+        streamprobe.stop()
+        _proxy = None
 
 
 def tuning_set(name, value):

@@ -104,7 +104,9 @@ class UNOdomPredEncDecSVDTempMaskBase(OdomPredEncDecBase):
         if xs[0].is_cuda and self.training and torch.is_grad_enabled():
             ev = self.__dict__.pop("_presplit_event", None)      # issued at the start of the network forward, on a side stream
             if ev is not None:
-                torch.cuda.current_stream(xs[0].device).wait_event(ev)
+                from rslo_amd import streamprobe
+                cur_ = torch.cuda.current_stream(xs[0].device)
+                streamprobe.wait("head_weight_presplit", cur_, lambda: cur_.wait_event(ev))
             else:
                 hip_conv2d.presplit(self)       # split-bf16 operands of all 3x3 layers for this step, one launch
         if self._cycle_constraint:

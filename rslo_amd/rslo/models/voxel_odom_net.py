@@ -312,7 +312,8 @@ class UnVoxelOdomNetICP3(nn.Module):
                 self.odom_predictor.__dict__.pop("_side_work", None)
                 launch()
             cov = box["cov"]
-            cur.wait_stream(side)
+            from rslo_amd import streamprobe
+            streamprobe.wait("cov_branch_forward", cur, lambda: cur.wait_stream(side))
             cov.record_stream(cur)
             middle_conf_preds = list(cov.split([f.shape[0] for f in voxel_features], dim=0))
         with torch.no_grad():

@@ -30,7 +30,8 @@ def join(device=None):
     """Make the streams that issued leaf work wait for it (no-op when nothing is pending)."""
     for dev, st in _state.items():
         if st["pending"] and (device is None or dev == device):
-            st["cur"].wait_stream(st["side"])
+            from rslo_amd import streamprobe
+            streamprobe.wait("leaf_wgrad_stream", st["cur"], lambda: st["cur"].wait_stream(st["side"]))
             st["pending"] = False
             st["targets"].clear()
             st["keep"].clear()

@@ -204,7 +204,9 @@ class ExamplePrefetcher:
         if self.planner is not None:
             ex = self.planner.finish(ex)        # host wait on an event recorded a step ago, then arena views
         self.plan_wait_seconds += time.perf_counter() - t1   # the plan itself was late / assembling the example
-        torch.cuda.current_stream(self.device).wait_event(ready)
+        from rslo_amd import streamprobe
+        cur = torch.cuda.current_stream(self.device)
+        streamprobe.wait("structure_plan_of_this_batch", cur, lambda: cur.wait_event(ready))
         return ex
 
     def close(self):
