@@ -1049,10 +1049,14 @@ def main():
         if differing and rank == 0:
             print("replicas differ in %d of %d tensors, e.g. %s" % (len(differing), len(digs), differing[:12]), file=sys.stderr)
     syncbn_exchange = None
-    if dist_on and world > 1:
+    if dist_on and (world > 1 or os.environ.get("RSLO_FORCE_SYNCBN_PATH", "0") == "1"):
         from rslo_amd import peer as _peer
+        from apex import parallel as _apx
         _comm = _peer.comm_for(None)
-        syncbn_exchange = _comm.transport + " (same-stream peer kernel)" if _comm is not None else "collective (all_reduce)"
+        syncbn_exchange = ((_comm.transport + (" (per-channel rendezvous inside the BatchNorm kernel: 1 launch per direction; "
+                                                "96x176 maps: statistics -> exchange kernel -> apply)"
+                                                if _apx._fused_peer_comm(None) is not None else " (same-stream peer kernel: statistics -> exchange -> apply)"))
+                           if _comm is not None else "collective (all_reduce)")
         if _comm is not None:
             _comm.check()          # a peer that missed an exchange poisons the statistics with NaN: fail loudly, never report it
     if phases and rank == 0:
@@ -1187,6 +1191,28 @@ def main():
                             "ms_per_step_max": round(1e3 * max(per_rank) / args.steps, 3),
                             # how the 90 SyncBN statistics exchanges per step travelled (rslo_amd/peer.py)
                             "syncbn_exchange": syncbn_exchange, "replicas_identical": replicas_identical}
+        if world == 1 and not dist_on and os.environ.get("RSLO_BENCH_MULTIRANK_CHILD", "1") != "0" and not args.no_kernel_events:
+            # The step a rank of an N > 1 job really runs, measured on this one GPU: a child process with a ONE-rank RCCL
+            # group and the multi-rank code path forced (RSLO_FORCE_SYNCBN_PATH=1: SyncBN statistics meet the "peers" through
+            # a world-size-1 peer comm, gradient buckets go through the overlapped RCCL exchange).  What it cannot show is
+            # the peers' arrival skew and the xGMI hop.
+            try:
+                import subprocess
+                env = dict(os.environ, RSLO_BENCH_FORCE_DIST="1", RSLO_FORCE_SYNCBN_PATH="1", RSLO_BENCH_MULTIRANK_CHILD="0",
+                           RSLO_BENCH_STREAM_SPLIT="0", MASTER_PORT=str(_free_port()))
+                cmd = [sys.executable, os.path.abspath(__file__), "--steps", "40", "--warmup", "10", "--no-cpu-baseline",
+                       "--no-kernel-events", "--batch", str(args.batch), "--rings", str(args.rings), "--dtype", args.dtype]
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+                child = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+                line["config"]["multirank_path_ms_per_step"] = child["ms_per_step"]
+                line["config"]["multirank_path"] = {
+                    "ms_per_step": child["ms_per_step"], "plain_ms_per_step": line["ms_per_step"],
+                    "ratio_to_plain": round(child["ms_per_step"] / line["ms_per_step"], 4),
+                    "syncbn_exchange": (child.get("rccl") or {}).get("syncbn_exchange"),
+                    "what": "one-rank RCCL group, multi-rank SyncBN path forced (RSLO_FORCE_SYNCBN_PATH=1), overlapped "
+                            "gradient exchange on; 40 steps in a child process on the same GPU"}
+            except Exception as e:
+                line["config"]["multirank_path"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 if pinned is not None:

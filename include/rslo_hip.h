@@ -706,7 +706,7 @@ RSLO_API int rslo_opt_adam_step(const RsloOptTensor *tensors_dev, const RsloOptC
  *      (and rslo_bn2d_bwd_reduce / _bwd_apply).  Every rank owns a slice (4 slots of {flag, payload}) the others can read;
  *      rslo_peer_allreduce_f64 writes the own payload + flag, waits for every peer's flag of the same exchange number, and
  *      sums the payloads in rank order (identical bits on every rank) into t, in place.  All ranks must issue the same
- *      sequence of exchanges, and all exchanges of one comm go to ONE stream (slot reuse relies on their order).  A peer that does not arrive within the timeout (default 20 s) poisons t with NaN and is
+ *      sequence of exchanges, and all exchanges of one comm go to ONE stream (slot reuse relies on their order).  A peer that does not arrive within the timeout (default 600 s, rslo_peer_set_timeout_ms) poisons t with NaN and is
  *      reported by rslo_peer_status -- the kernel never hangs the GPU.
  *      Transports:  host   = one POSIX shared-memory segment `name` (every rank passes the same name) registered with the
  *                            HIP runtime: any GPUs of one host, also several ranks on one GPU;
@@ -721,6 +721,23 @@ RSLO_API int rslo_peer_create_device_finish(void *comm, const void *all_handles)
 RSLO_API int rslo_peer_set_timeout_ms(void *comm, int ms);
 RSLO_API int rslo_peer_allreduce_f64(void *comm, double *t, int n, void *stream);
 RSLO_API unsigned long long rslo_peer_status(void *comm, int *peer);
+/*      Round 5: SyncBN of the maps a workgroup holds in registers (N*HW <= 17408 values per channel, C <= 512) in ONE launch
+ *      per direction on any number of ranks.  The workgroup of channel c publishes its sums in the comm's slice, meets the
+ *      workgroups of channel c on the other ranks (per-channel flags; sums in rank order: identical bits everywhere) and
+ *      applies from its registers -- no statistics kernel, no exchange kernel, no second pass over the activation.  Same
+ *      exchange sequence rule as rslo_peer_allreduce_f64 (one sequence number per call, all on one stream); a missing peer
+ *      poisons the outputs with NaN and is reported by rslo_peer_status.  count_out / count_all: the element count over
+ *      all ranks (device double), produced by the forward pass and read by the backward pass.  Replaces apex
+ *      SyncBatchNorm forward / backward (rslo/layers/SparseConv.py:96-132) as rslo_bn2d_fwd_local / _bwd_local do on one rank. */
+RSLO_API int rslo_bn2d_peer_supported(int N, int C, int HW);
+RSLO_API int rslo_bn2d_fwd_peer(void *comm, const float *x, const float *res, const float *gamma, const float *beta, int N,
+                                int C, int HW, float eps, float momentum, float act_slope, float *running_mean,
+                                float *running_var, float *save_mean, float *save_invstd, double *count_out, float *y,
+                                void *stream);
+RSLO_API int rslo_bn2d_bwd_peer(void *comm, const float *dy, const float *y, const float *x, const float *gamma,
+                                const float *save_mean, const float *save_invstd, const double *count_all, int N, int C,
+                                int HW, float act_slope, int has_act, float *dx, float *dres, float *dgamma, float *dbeta,
+                                void *stream);
 RSLO_API int rslo_peer_destroy(void *comm);
 
 #ifdef __cplusplus

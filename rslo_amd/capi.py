@@ -160,6 +160,11 @@ SIGNATURES = {
     "rslo_head_masks_bwd": (C.c_int, [_vp, _vp]),
     "rslo_loss_tail_fwd": (C.c_int, [_vp, _vp, _vp]),
     "rslo_loss_tail_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "rslo_bn2d_peer_supported": (C.c_int, [_i, _i, _i]),
+    "rslo_bn2d_fwd_peer": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, C.c_float, C.c_float, C.c_float, _vp, _vp, _vp, _vp,
+                                     _vp, _vp, _vp]),
+    "rslo_bn2d_bwd_peer": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, C.c_float, _i, _vp, _vp, _vp, _vp,
+                                     _vp]),
     "rslo_opl_bytes": (_sz, [_i, _i, _i, _i]),
     "rslo_opl_from_nchw": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "rslo_conv2d_fwd_p_supported": (C.c_int, [_i, _i, _i, _i]),
@@ -1247,6 +1252,52 @@ def bn2d_bwd_local(dy, y, x, gamma, mean, invstd, slope, has_act, want_res, want
                                    pb, ws.data_ptr(), wsb, _stream())
     if rc:
         _chk(rc, "rslo_bn2d_bwd_local")
+    return dx, dres, dgamma, dbeta
+
+
+_bn_peer_ok = {}
+
+
+def bn2d_peer_supported(N, Cc, HW):
+    key = (N, Cc, HW)
+    v = _bn_peer_ok.get(key)
+    if v is None:
+        v = _bn_peer_ok[key] = bool(lib().rslo_bn2d_peer_supported(N, Cc, HW))
+    return v
+
+
+def bn2d_fwd_peer(comm, x, res, gamma, beta, running_mean, running_var, momentum, eps, slope):
+    """Multi-rank y = act(BN_train(x) + res) in ONE launch: the per-channel sums meet the other ranks' inside the kernel
+    (rslo_bn2d_fwd_peer; comm = rslo_amd.peer.PeerComm).  -> y, save_mean, save_invstd, count_all (device double [1])."""
+    N, Cc, H, W = x.shape
+    dev = x.device
+    y = torch.empty_like(x)
+    stat = torch.empty((2, Cc), dtype=torch.float32, device=dev)
+    cnt = torch.empty((1,), dtype=torch.float64, device=dev)
+    rc = lib().rslo_bn2d_fwd_peer(comm.handle, _ptr(x, torch.float32, "x"), _ptr(res, torch.float32, "res"), _dp(gamma),
+                                  _dp(beta), N, Cc, H * W, eps, momentum, slope, _dp(running_mean), _dp(running_var),
+                                  stat.data_ptr(), stat.data_ptr() + 4 * Cc, cnt.data_ptr(), y.data_ptr(), _stream())
+    if rc:
+        _chk(rc, "rslo_bn2d_fwd_peer")
+    return y, stat[0], stat[1], cnt
+
+
+def bn2d_bwd_peer(comm, dy, y, x, gamma, mean, invstd, count_all, slope, has_act, want_res, want_affine=True):
+    N, Cc, H, W = x.shape
+    dev = x.device
+    dx = torch.empty_like(x)
+    dres = torch.empty_like(x) if want_res else None
+    if want_affine:
+        dgb = torch.empty((2, Cc), dtype=torch.float32, device=dev)
+        dgamma, dbeta = dgb[0], dgb[1]
+        pg, pb = dgb.data_ptr(), dgb.data_ptr() + 4 * Cc
+    else:
+        dgamma = dbeta = pg = pb = None
+    rc = lib().rslo_bn2d_bwd_peer(comm.handle, _ptr(dy, torch.float32, "dy"), _dp(y), x.data_ptr(), _dp(gamma),
+                                  mean.data_ptr(), invstd.data_ptr(), count_all.data_ptr(), N, Cc, H * W, slope,
+                                  1 if has_act else 0, dx.data_ptr(), _dp(dres), pg, pb, _stream())
+    if rc:
+        _chk(rc, "rslo_bn2d_bwd_peer")
     return dx, dres, dgamma, dbeta
 
 

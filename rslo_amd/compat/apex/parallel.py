@@ -90,15 +90,33 @@ def exchange_group(group):
     return _HP_GROUP["group"]
 
 
-def _sum_over_ranks(t, group):
-    """The SyncBN statistics exchange: a same-stream kernel when all ranks share this host (rslo_amd.peer), else the
-    all-reduce on exchange_group(group)."""
+# RSLO_FORCE_SYNCBN_PATH=1: a ONE-rank process group runs the multi-rank code path (statistics that leave the kernel /
+# meet the peers inside it, a world-size-1 peer comm) -- what every rank of an N > 1 job executes per layer, measurable on
+# a one-GPU box (bench.py reports it as config.multirank_path_ms_per_step).  Never on by default.
+FORCE_MULTI = os.environ.get("RSLO_FORCE_SYNCBN_PATH", "0") == "1"
+# "1" (default): the maps a workgroup holds in registers exchange inside ONE kernel per direction (rslo_bn2d_fwd_peer), on
+# either peer transport (two processes on one GPU, 256 channels at 12x22: 16 us against 33 us on the device transport,
+# 22 against 33 on the host segment); "0": statistics kernel -> exchange kernel -> apply kernel everywhere (round 4)
+FUSED_PEER_BN = os.environ.get("RSLO_SYNCBN_FUSED_PEER", "1") != "0"
+
+
+def _fused_peer_comm(group):
+    """The peer comm when this layer's exchange happens inside the BatchNorm kernel, else None."""
+    if not FUSED_PEER_BN:
+        return None
     from rslo_amd import peer
-    c = peer.comm_for(group) if t.is_cuda else None
-    if c is not None:
-        c.all_reduce_(t)
-    else:
-        dist.all_reduce(t, group=exchange_group(group))
+    return peer.comm_for(group)
+
+
+def _multi(world):
+    return world > 1 or (FORCE_MULTI and dist.is_available() and dist.is_initialized())
+
+
+def _sum_over_ranks(t, group):
+    """The SyncBN statistics exchange: a same-stream kernel when all ranks share this host and the tensor fits one
+    exchange (rslo_amd.peer.all_reduce_: float64, <= 1024 elements), else the all-reduce on exchange_group(group)."""
+    from rslo_amd import peer
+    peer.all_reduce_(t, group, fallback_group=exchange_group(group))
 
 
 def fused_bn_forward(bn, x, res, weight, bias, slope, group, world):
@@ -107,7 +125,12 @@ def fused_bn_forward(bn, x, res, weight, bias, slope, group, world):
     from rslo_amd import capi
     track = bn.track_running_stats and bn.running_mean is not None
     mom = bn.momentum          # fusable() leaves momentum=None (cumulative average) to the unfused path
-    if world > 1:
+    if _multi(world):
+        comm = _fused_peer_comm(group)
+        if comm is not None and capi.bn2d_peer_supported(x.shape[0], x.shape[1], x.shape[2] * x.shape[3]):
+            # one launch: the workgroup of a channel meets its peers on the other ranks between its sums and its apply
+            return capi.bn2d_fwd_peer(comm, x, res, weight, bias, bn.running_mean if track else None,
+                                      bn.running_var if track else None, mom, bn.eps, slope)
         stats = capi.bn2d_stats(x)
         _sum_over_ranks(stats, group)
         y, mean, invstd = capi.bn2d_apply(x, res, stats, weight, bias, bn.running_mean if track else None,
@@ -123,8 +146,12 @@ def fused_bn_backward(gy, y, x, weight, mean, invstd, cnt_all, slope, has_res, a
     """-> dx, dres, dgamma, dbeta (dgamma / dbeta are this rank's sums: data parallel averages them afterwards)."""
     from rslo_amd import capi
     has_act = slope != 1.0
-    if world == 1:
+    if cnt_all is None:          # the forward ran the one-rank path
         return capi.bn2d_bwd_local(gy, y, x, weight, mean, invstd, slope, has_act, has_res, want_affine=affine)
+    comm = _fused_peer_comm(group)      # the same condition the forward took: both directions of a layer use one path
+    if comm is not None:
+        if capi.bn2d_peer_supported(x.shape[0], x.shape[1], x.shape[2] * x.shape[3]):
+            return capi.bn2d_bwd_peer(comm, gy, y, x, weight, mean, invstd, cnt_all, slope, has_act, has_res, want_affine=affine)
     red, dgamma, dbeta = capi.bn2d_bwd_reduce(gy, y, x, mean, invstd, slope, has_act, want_affine=affine)
     _sum_over_ranks(red, group)
     # the count all-reduced in the forward pass, read on the device: exact for uneven per-rank batches, no host sync
@@ -251,6 +278,9 @@ class DistributedDataParallel(nn.Module):
             self._exchange.finish()
         else:
             du.average_gradients(self.module, mean=True)
+        pr = sys.modules.get("rslo_amd.peer")
+        if pr is not None:        # a SyncBN exchange that timed out poisoned its statistics with NaN: an error within the
+            pr.check_all()        # step that follows it (pinned-memory read, no synchronisation), never a silent one
 
     def _on_first_grad(self, grad):
         if not self._queued:

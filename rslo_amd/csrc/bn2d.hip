@@ -11,7 +11,7 @@
 // HBM-bound elementwise work: forward reads x twice (+ residual) and writes y; backward reads dy, y, x twice, writes dx.
 #include <stdlib.h>
 
-#include "rslo_common.h"
+#include "peer_comm.h"
 
 #define BN_THREADS 256
 
@@ -496,6 +496,126 @@ __global__ __launch_bounds__(T) void k_bn2d_bwd_small_rc(const float *__restrict
   }
 }
 
+// Multi-rank SyncBN of the register-cached maps in ONE launch per direction (round 5).  The workgroup that owns channel c
+// publishes its sums in this rank's peer slice, meets the workgroups of channel c on the other ranks (peer_chan_exchange,
+// peer_comm.h: per-channel flags, rank-ordered sums = identical bits on every rank) and applies from its registers --
+// instead of statistics kernel -> exchange kernel -> apply kernel with a second pass over the activation.  Same arithmetic
+// as the three-launch path (double sums, the count exchanged with them).
+struct BnPeer {
+  PeerTable tab;
+  int me, world;
+  unsigned long long seq;
+  size_t chan;                  // byte offset of the slot's channel records inside a slice
+  long long timeout_ticks;
+  unsigned long long *status;
+};
+
+template <int T, int E>
+__global__ __launch_bounds__(T) void k_bn2d_fwd_rc_peer(const float *__restrict__ x, const float *__restrict__ res,
+                                                       const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                       int N, int C, int HW, float eps, float momentum, float slope,
+                                                       float *__restrict__ run_mean, float *__restrict__ run_var,
+                                                       float *__restrict__ save_mean, float *__restrict__ save_invstd,
+                                                       double *__restrict__ count_out, float *__restrict__ y, BnPeer pc) {
+  const int c = blockIdx.x, total = N * HW;
+  float v[E], r[E];
+  int64_t off[E];
+#pragma unroll
+  for (int i = 0; i < E; ++i) {
+    const int e = threadIdx.x + i * T;
+    const int n = e / HW, k = e - n * HW;
+    off[i] = e < total ? ((int64_t)n * C + c) * HW + k : -1;
+    v[i] = off[i] >= 0 ? x[off[i]] : 0.f;
+    r[i] = (res && off[i] >= 0) ? res[off[i]] : 0.f;
+  }
+  double s = 0.0, q = 0.0;
+#pragma unroll
+  for (int i = 0; i < E; ++i) {
+    s += v[i];
+    q += (double)v[i] * v[i];
+  }
+  __shared__ double tot[2];
+  __shared__ double sh[4 + 3 * PEER_MAX_WORLD];
+  bn_block_sum2_t<T>(s, q, tot);
+  double ex[3] = {tot[0], tot[1], (double)N * HW};
+  const bool ok = peer_chan_exchange(pc.tab, pc.me, pc.world, pc.seq, pc.chan, c, pc.timeout_ticks, pc.status, ex, sh);
+  const double cnt = ex[2];
+  const double m = ex[0] / cnt;
+  double var = ex[1] / cnt - m * m;
+  var = var > 0.0 ? var : 0.0;
+  float mean = (float)m, invstd = (float)(1.0 / sqrt(var + (double)eps));
+  if (!ok) mean = invstd = __builtin_nanf("");          // a peer never arrived: poison, never hang (status says who)
+  if (threadIdx.x == 0) {
+    save_mean[c] = mean;
+    save_invstd[c] = invstd;
+    if (c == 0) count_out[0] = cnt;
+    if (run_mean) {
+      const double unbiased = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
+      run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mean;
+      run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)unbiased;
+    }
+  }
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  const float a1 = g * invstd, a0 = b - mean * a1;
+#pragma unroll
+  for (int i = 0; i < E; ++i) {
+    if (off[i] < 0) continue;
+    const float o = v[i] * a1 + a0 + r[i];
+    y[off[i]] = o > 0.f ? o : o * slope;
+  }
+}
+
+template <int T, int E>
+__global__ __launch_bounds__(T) void k_bn2d_bwd_rc_peer(const float *__restrict__ dy, const float *__restrict__ y,
+                                                       const float *__restrict__ x, const float *__restrict__ gamma,
+                                                       const float *__restrict__ save_mean,
+                                                       const float *__restrict__ save_invstd,
+                                                       const double *__restrict__ count_all, int N, int C, int HW,
+                                                       float slope, int has_act, float *__restrict__ dx,
+                                                       float *__restrict__ dres, float *__restrict__ dgamma,
+                                                       float *__restrict__ dbeta, BnPeer pc) {
+  const int c = blockIdx.x, total = N * HW;
+  const float mean = save_mean[c], invstd = save_invstd[c];
+  float g[E], xh[E];
+  int64_t off[E];
+#pragma unroll
+  for (int i = 0; i < E; ++i) {
+    const int e = threadIdx.x + i * T;
+    const int n = e / HW, k = e - n * HW;
+    off[i] = e < total ? ((int64_t)n * C + c) * HW + k : -1;
+    const float gv = off[i] >= 0 ? dy[off[i]] : 0.f;
+    const float yv = (has_act && off[i] >= 0) ? y[off[i]] : 1.f;
+    const float xv = off[i] >= 0 ? x[off[i]] : mean;
+    g[i] = yv > 0.f ? gv : gv * slope;
+    xh[i] = (xv - mean) * invstd;
+  }
+  double s = 0.0, q = 0.0;
+#pragma unroll
+  for (int i = 0; i < E; ++i) {
+    s += g[i];
+    q += (double)g[i] * (double)xh[i];
+  }
+  __shared__ double tot[2];
+  __shared__ double sh[4 + 3 * PEER_MAX_WORLD];
+  bn_block_sum2_t<T>(s, q, tot);
+  if (threadIdx.x == 0) {          // the affine gradients are this rank's own sums (data parallel averages them later)
+    if (dbeta) dbeta[c] = (float)tot[0];
+    if (dgamma) dgamma[c] = (float)tot[1];
+  }
+  double ex[3] = {tot[0], tot[1], 0.0};
+  const bool ok = peer_chan_exchange(pc.tab, pc.me, pc.world, pc.seq, pc.chan, c, pc.timeout_ticks, pc.status, ex, sh);
+  const double cnt = *count_all;        // element count over all ranks, as exchanged in the forward pass
+  const float k0 = (gamma ? gamma[c] : 1.f) * invstd;
+  float mg = (float)(ex[0] / cnt), mgx = (float)(ex[1] / cnt);
+  if (!ok) mg = mgx = __builtin_nanf("");
+#pragma unroll
+  for (int i = 0; i < E; ++i) {
+    if (off[i] < 0) continue;
+    dx[off[i]] = k0 * (g[i] - mg - xh[i] * mgx);
+    if (dres) dres[off[i]] = g[i];
+  }
+}
+
 // multi-rank forms of the small maps: the channel's sums go straight into the tensor that is all-reduced (no slice
 // partials, no finish launch)
 template <int T>
@@ -721,5 +841,65 @@ extern "C" int rslo_bn2d_bwd_apply(const float *dy, const float *y, const float 
                      save_invstd, red, count, count_dev, C, HW, act_slope, has_act, dx, dres, (const double *)nullptr, 0,
                      (float *)nullptr, (float *)nullptr);
   RSLO_CHECK_LAUNCH("k_bn2d_bwd_apply");
+  return RSLO_OK;
+}
+
+// ---- multi-rank single-launch entry points (register-cached maps) ---------------------------------------------------------
+// 1 when rslo_bn2d_fwd_peer / _bwd_peer take the shape (else the caller runs statistics -> rslo_peer_allreduce_f64 -> apply)
+extern "C" int rslo_bn2d_peer_supported(int N, int C, int HW) {
+  return rslo_tune(RSLO_TUNE_BN_SMALL_RC) && C >= 1 && C <= PEER_MAX_CH && (int64_t)N * HW <= 1024 * BN_RC_BIG;
+}
+
+static BnPeer bn_peer_args(RsloPeerComm *c, unsigned long long seq) {
+  BnPeer pc;
+  pc.tab = c->tab; pc.me = c->rank; pc.world = c->world; pc.seq = seq;
+  pc.chan = (size_t)(seq % PEER_SLOTS) * c->slot_bytes + peer_chan_off(c->max_n);
+  pc.timeout_ticks = c->timeout_ticks; pc.status = c->status_dev;
+  return pc;
+}
+
+extern "C" int rslo_bn2d_fwd_peer(void *comm, const float *x, const float *res, const float *gamma, const float *beta, int N,
+                                  int C, int HW, float eps, float momentum, float act_slope, float *running_mean,
+                                  float *running_var, float *save_mean, float *save_invstd, double *count_out, float *y,
+                                  void *stream) {
+  RsloPeerComm *c = (RsloPeerComm *)comm;
+  RSLO_CHECK_ARG(c && x && save_mean && save_invstd && count_out && y && rslo_bn2d_peer_supported(N, C, HW),
+                 "rslo_bn2d_fwd_peer: bad arguments / shape outside the single-launch range (N*HW = %lld, C = %d)",
+                 (long long)N * HW, C);
+  const unsigned long long seq = c->seq + 1;
+  const BnPeer pc = bn_peer_args(c, seq);
+  const int64_t per = (int64_t)N * HW;
+  hipStream_t st = (hipStream_t)stream;
+#define BN_GO(T, E) hipLaunchKernelGGL((k_bn2d_fwd_rc_peer<T, E>), dim3(C), dim3(T), 0, st, x, res, gamma, beta, N, C, HW, eps, \
+                                       momentum, act_slope, running_mean, running_var, save_mean, save_invstd, count_out, y, pc)
+  if (per <= 256 * BN_RC) BN_GO(256, BN_RC);
+  else if (per <= 1024 * BN_RC) BN_GO(1024, BN_RC);
+  else BN_GO(1024, BN_RC_BIG);
+#undef BN_GO
+  RSLO_CHECK_LAUNCH("k_bn2d_fwd_rc_peer");
+  c->seq = seq;
+  return RSLO_OK;
+}
+
+extern "C" int rslo_bn2d_bwd_peer(void *comm, const float *dy, const float *y, const float *x, const float *gamma,
+                                  const float *save_mean, const float *save_invstd, const double *count_all, int N, int C,
+                                  int HW, float act_slope, int has_act, float *dx, float *dres, float *dgamma, float *dbeta,
+                                  void *stream) {
+  RsloPeerComm *c = (RsloPeerComm *)comm;
+  RSLO_CHECK_ARG(c && dy && x && save_mean && save_invstd && count_all && dx && rslo_bn2d_peer_supported(N, C, HW),
+                 "rslo_bn2d_bwd_peer: bad arguments / shape outside the single-launch range");
+  RSLO_CHECK_ARG(!has_act || y, "rslo_bn2d_bwd_peer: y is needed for the activation mask");
+  const unsigned long long seq = c->seq + 1;
+  const BnPeer pc = bn_peer_args(c, seq);
+  const int64_t per = (int64_t)N * HW;
+  hipStream_t st = (hipStream_t)stream;
+#define BN_GO(T, E) hipLaunchKernelGGL((k_bn2d_bwd_rc_peer<T, E>), dim3(C), dim3(T), 0, st, dy, y, x, gamma, save_mean, save_invstd, \
+                                       count_all, N, C, HW, act_slope, has_act, dx, dres, dgamma, dbeta, pc)
+  if (per <= 256 * BN_RC) BN_GO(256, BN_RC);
+  else if (per <= 1024 * BN_RC) BN_GO(1024, BN_RC);
+  else BN_GO(1024, BN_RC_BIG);
+#undef BN_GO
+  RSLO_CHECK_LAUNCH("k_bn2d_bwd_rc_peer");
+  c->seq = seq;
   return RSLO_OK;
 }

@@ -22,6 +22,9 @@ import torch.distributed as dist
 from rslo_amd import capi
 
 MAX_N = 1024
+# how long an exchange waits for a peer before it poisons the result with NaN and raises the comm's status word (a rank held
+# up by its data loader, a first-use module load, a debugger ...): the process-group scale, not a kernel scale
+TIMEOUT_MS = int(os.environ.get("RSLO_PEER_TIMEOUT_MS", "600000"))
 _COMMS = {}          # id of the default group object -> PeerComm | False (not eligible)
 
 
@@ -117,7 +120,17 @@ def create(transport="host", group=None):
                 good = 0
         if comm.status()[0]:
             good = 0
-        comm.set_timeout_ms(20000)
+        # the single-launch SyncBN kernels meet their peers per channel (rslo_bn2d_fwd_peer): rank-dependent constants
+        # per channel, whose mean over the ranks is known
+        for Cc, hw in ((8, 16), (64, 1056), (512, 4)):
+            x = (torch.arange(Cc, dtype=torch.float32, device="cuda").view(1, Cc, 1, 1) + float(rank + 1)).expand(2, Cc, hw, 1).contiguous()
+            y, mean, invstd, cnt = capi.bn2d_fwd_peer(comm, x, None, None, None, None, None, 0.1, 1e-5, 1.0)
+            want = torch.arange(Cc, dtype=torch.float32) + float(tri) / world
+            if not torch.allclose(mean.cpu(), want, rtol=0, atol=1e-5) or float(cnt.item()) != 2.0 * hw * world:
+                good = 0
+        if comm.status()[0]:
+            good = 0
+        comm.set_timeout_ms(TIMEOUT_MS)
     except Exception:
         good = 0
     flags = [None] * world
@@ -144,7 +157,7 @@ def comm_for(group):
             old = _COMMS.pop(k)
             if old[1]:
                 old[1].close()
-        if dist.get_world_size() < 2:
+        if dist.get_world_size() < 2 and os.environ.get("RSLO_FORCE_SYNCBN_PATH", "0") != "1":
             c = None
         elif mode in ("host", "device"):
             c = create(mode, None)
@@ -162,6 +175,14 @@ def all_reduce_(t, group=None, fallback_group=None):
     else:
         c.all_reduce_(t)
     return t
+
+
+def check_all():
+    """Raise if any exchange of any live comm timed out (pinned-memory read, no synchronisation): the product path calls this
+    once per step (apex DDP stand-in, bench.py), so a poisoned statistic is an error within a step, never a silent NaN."""
+    for ent in _COMMS.values():
+        if ent[1]:
+            ent[1].check()
 
 
 def shutdown():

@@ -84,6 +84,63 @@ def _worker(rank, world, port, q, transport, mode):
             torch.cuda.synchronize()
             out["us_per_exchange"] = e0.elapsed_time(e1) * 1e3 / 200
             comm.check()
+        elif mode == "fusedbn":
+            # single-launch SyncBN (rslo_bn2d_fwd_peer / _bwd_peer: the channel's workgroup meets its peers inside the
+            # kernel) against statistics kernel -> exchange kernel -> apply kernel, on the three register-cached map sizes
+            # of the head, with one rank lagging; and a late rank in front of every second layer
+            import apex.parallel as AP
+            comm.set_timeout_ms(5000)
+            peer._COMMS[id(dist.group.WORLD)] = (dist.group.WORLD, comm)       # the comm under test is the group's comm
+            outs = {}
+            for name, (Cc, H, W) in {"12x22": (256, 12, 22), "24x44": (128, 24, 44), "48x88": (64, 48, 88)}.items():
+                g = torch.Generator().manual_seed(17)
+                full = torch.randn(4, Cc, H, W, generator=g) * 1.5 + 0.3
+                res_full = torch.randn(4, Cc, H, W, generator=g)
+                gy_full = torch.randn(4, Cc, H, W, generator=g)
+                sl = slice(2 * rank, 2 * rank + 2) if world == 2 else slice(rank, rank + 1)
+                got = []
+                for fused in (True, False):
+                    AP.FUSED_PEER_BN = fused
+                    x = full[sl].cuda().requires_grad_(True)
+                    res = res_full[sl].cuda().requires_grad_(True)
+                    bn = AP.SyncBatchNorm(Cc, eps=1e-3, momentum=0.01).cuda().train()
+                    if rank == 1:
+                        torch.cuda.synchronize()
+                        time.sleep(0.01)
+                    y = bn(x, act_slope=0.0, residual=res)
+                    (y * gy_full[sl].cuda()).sum().backward()
+                    got.append([t.detach().cpu() for t in (y, x.grad, res.grad, bn.weight.grad, bn.bias.grad, bn.running_mean,
+                                                            bn.running_var)])
+                AP.FUSED_PEER_BN = True
+                torch.cuda.synchronize()
+                comm.check()
+                outs[name] = max(float((a - b).abs().max() / (b.abs().max() + 1e-12)) for a, b in zip(got[0], got[1]))
+                # every rank normalises with the same statistics, bit for bit
+                rm = got[0][5].cuda().double()
+                both = [torch.zeros_like(rm) for _ in range(world)]
+                dist.all_gather(both, rm)
+                outs[name + "_same_bits"] = all(torch.equal(both[0], b) for b in both)
+            out["fusedbn"] = outs
+            # latency of one fused layer forward (256 channels at 12x22, both ranks arriving together) against the three launches
+            xs = torch.randn(2, 256, 12, 22, device="cuda")
+            for fused in (True, False):
+                AP.FUSED_PEER_BN = fused
+                bn = AP.SyncBatchNorm(256, eps=1e-3, momentum=0.01).cuda().train()
+                with torch.no_grad():
+                    for _ in range(10):
+                        AP.fused_bn_forward(bn, xs, None, bn.weight, bn.bias, 0.0, None, world)
+                    torch.cuda.synchronize()
+                    dist.barrier()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(100):
+                        AP.fused_bn_forward(bn, xs, None, bn.weight, bn.bias, 0.0, None, world)
+                    e1.record()
+                    torch.cuda.synchronize()
+                out["us_fused" if fused else "us_three_launches"] = e0.elapsed_time(e1) * 1e3 / 100
+            AP.FUSED_PEER_BN = True
+            peer._COMMS.pop(id(dist.group.WORLD), None)
+            comm.check()
         elif mode == "timeout":
             comm.set_timeout_ms(300)
             t = torch.ones(65, dtype=torch.float64, device="cuda")
@@ -140,4 +197,23 @@ def test_missing_peer_times_out_instead_of_hanging_the_gpu():
     res = _run(2, "host", "timeout")
     assert res[0]["poisoned"] is True
     seq, peer_rank = res[0]["status"]
-    assert seq == 5 and peer_rank == 1          # four self-test exchanges at creation, then the one rank 1 never joined
+    assert seq == 8 and peer_rank == 1          # seven self-test exchanges at creation (four plain, three fused SyncBN layers), then the one rank 1 never joined
+
+
+@pytest.mark.parametrize("transport", ["host", "device"])
+def test_single_launch_syncbn_meets_its_peers_inside_the_kernel(transport):
+    """rslo_bn2d_fwd_peer / _bwd_peer (round 5): two ranks on one GPU, each half a batch.  Same results as the three-launch
+    path (statistics -> rslo_peer_allreduce_f64 -> apply) to rounding of the double sums, identical statistics on both
+    ranks, no time-out with a lagging rank; prints what a layer costs either way."""
+    res = _run(2, transport, "fusedbn")
+    if res[0] == "no-comm":
+        assert res[1] == "no-comm"
+        pytest.skip("transport %s not available between two processes on this box" % transport)
+    for r in range(2):
+        for k, v in res[r]["fusedbn"].items():
+            if k.endswith("_same_bits"):
+                assert v is True, (r, k)
+            else:
+                assert v < 2e-6, (r, k, v)
+    print("%s transport, SyncBN forward of 256 ch at 12x22 on 2 ranks: %.1f us in one launch, %.1f us as three launches"
+          % (transport, res[0]["us_fused"], res[0]["us_three_launches"]))
