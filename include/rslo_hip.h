@@ -156,7 +156,7 @@ RSLO_API void rslo_spconv_set_tiling(int rbw, int ks);
  *     calls (process-wide; the defaults are the measured choices).  Names (rslo_tuning_name(i), i = 0 .. until NULL):
  *     conv2d_wgrad_s2_fullres, conv2d_wgrad_nb, conv2d_wgrad_wgs, conv2d_fwd_tr, conv2d_fwd_mtw, conv2d_fwd_occ,
  *     conv2d_fwd_kc, conv2d_fwd_lean, conv2d_fwd_xsc, conv2d_s2_mtw, conv2d_s2_xsc, bn_small_rc, spconv_rbw, spconv_ks,
- *     spconv_v, spconv_wgrad_split, wgrad_xcd, vfe_lds, chamfer, chamfer_segments (meanings: csrc/rslo_common.h RsloTune).  Every setting
+ *     spconv_v, spconv_wgrad_split, wgrad_xcd, vfe_lds, chamfer, chamfer_segments, conv2d_ablate, resid_bwd_ordered (meanings: csrc/rslo_common.h RsloTune).  Every setting
  *     computes the same products; only tiling, summation grouping and launch geometry change.  Unknown name -> RSLO_EINVAL.
  *     (The reference has no counterpart: spconv / cuDNN pick their algorithms internally.) */
 RSLO_API int rslo_tuning_set(const char *name, int value);
@@ -455,7 +455,13 @@ RSLO_API int rslo_cov_residual_bwd(const float *p1, const float *tgt, const floa
                           const int32_t *idx, const float *dist, const float *thr, const float *Rd,
                           const float *gloss /*[B]*/, const float *cnt /*[B]*/, int B, int N, int M,
                           float reg_weight, float *gp1 /*[B,N,3] or NULL*/, float *gtgt /*[B,M,3]*/,
-                          float *gcov1 /*[B,N,7]*/, float *gcov2 /*[B,M,7]*/, void *stream);
+                          float *gcov1 /*[B,N,7]*/, float *gcov2 /*[B,M,7]*/, void *ws, size_t ws_bytes, void *stream);
+/*     The gradients that land on the PARTNER rows (gtgt, gcov2: several sources may share a partner) are added in ascending
+ *     source order: every source leaves its ten values and the key (partner row, source row), the keys are sorted (radix
+ *     sort over B N 64-bit keys) and each partner's run is added by one thread (runs of up to 32 sources) or one wave
+ *     (fixed lane assignment + fixed tree) -- bit-reproducible from run to run, where per-run atomics (rounds 1-4; tuning
+ *     switch resid_bwd_ordered = 0) made every training step unique.  ws: rslo_cov_residual_bwd_ws_bytes(B, N, M). */
+RSLO_API size_t rslo_cov_residual_bwd_ws_bytes(int B, int N, int M);
 RSLO_API size_t rslo_icp_ws_bytes(int B, int N);
 RSLO_API int rslo_icp_step(const float *p1, const float *n1, const float *tgt, const int32_t *idx, const float *dist,
                   const float *thr, int B, int N, int M, void *ws, size_t ws_bytes, float *res_r /*[B,9] in/out*/,

@@ -87,7 +87,8 @@ SIGNATURES = {
     "rslo_chamfer_grad": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "rslo_cov_residual_ws_bytes": (_sz, [_i, _i]),
     "rslo_cov_residual_fwd": (C.c_int, [_vp] * 8 + [_i, _i, _i, _f, _vp, _sz, _vp, _vp, _vp]),
-    "rslo_cov_residual_bwd": (C.c_int, [_vp] * 10 + [_i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
+    "rslo_cov_residual_bwd": (C.c_int, [_vp] * 10 + [_i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "rslo_cov_residual_bwd_ws_bytes": (_sz, [_i, _i, _i]),
     "rslo_icp_ws_bytes": (_sz, [_i, _i]),
     "rslo_icp_step": (C.c_int, [_vp] * 6 + [_i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
     "rslo_transform_points": (C.c_int, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
@@ -865,6 +866,9 @@ def cov_residual_fwd(p1, tgt, cov1, cov2, idx, dist, thr, Rd, reg_weight):
     return loss, cnt
 
 
+_resid_bwd_ws = {}
+
+
 def cov_residual_bwd(p1, tgt, cov1, cov2, idx, dist, thr, Rd, gloss, cnt, reg_weight, need_gp1=False):
     B, N, _ = p1.shape
     M = tgt.shape[1]
@@ -872,12 +876,18 @@ def cov_residual_bwd(p1, tgt, cov1, cov2, idx, dist, thr, Rd, gloss, cnt, reg_we
     gtgt = torch.empty_like(tgt)
     gcov1 = torch.empty_like(cov1)
     gcov2 = torch.empty_like(cov2)
+    key = (B, N, M)
+    wsb = _resid_bwd_ws.get(key)
+    if wsb is None:
+        wsb = _resid_bwd_ws[key] = lib().rslo_cov_residual_bwd_ws_bytes(B, N, M)
+    ws = _ws(wsb, p1.device)
     _chk(lib().rslo_cov_residual_bwd(_ptr(p1, torch.float32, "p1"), _ptr(tgt, torch.float32, "tgt"),
                                      _ptr(cov1, torch.float32, "cov1"), _ptr(cov2, torch.float32, "cov2"),
                                      _ptr(idx, torch.int32, "idx"), _ptr(dist, torch.float32, "dist"),
                                      _ptr(thr, torch.float32, "thr"), _ptr(Rd, torch.float32, "Rd"),
                                      _ptr(gloss, torch.float32, "gloss"), _ptr(cnt, torch.float32, "cnt"), B, N, M,
-                                     float(reg_weight), _ptr(gp1), _ptr(gtgt), _ptr(gcov1), _ptr(gcov2), _stream()),
+                                     float(reg_weight), _ptr(gp1), _ptr(gtgt), _ptr(gcov1), _ptr(gcov2), _ptr(ws), wsb,
+                                     _stream()),
          "rslo_cov_residual_bwd")
     return gp1, gtgt, gcov1, gcov2
 

@@ -10,6 +10,10 @@
 //    thread does the 3x3 Jacobi SVD, the reflection fix and composes the running (R, t) -- no host
 //    round trip for torch.svd / det (rslo/layers/svd.py:36-46).
 // All of it is latency/HBM-bound elementwise work on < 3 MB per pair.
+#include <string.h>
+
+#include <rocprim/rocprim.hpp>
+
 #include "rslo_common.h"
 
 #define LS_THREADS 256
@@ -210,6 +214,9 @@ extern "C" int rslo_cov_residual_fwd(const float *p1, const float *tgt, const fl
 // residual backward: gloss[b] -> gtgt (scatter), gcov1 (direct), gcov2 (scatter)
 // ---------------------------------------------------------------------------------------
 #define RB_THREADS 64
+#define RB_NV 10              // values a source adds to its partner row: 3 (target point) + 7 (covariance parameters)
+#define RB_SRC_BITS 32        // key = partner row (b M + j) << 32 | source row (b N + i): each half is one dword of the key
+#define RB_SHORT 32           // segments up to this length are added by one thread, longer ones by one wave
 __global__ __launch_bounds__(RB_THREADS) void k_resid_bwd(const float *__restrict__ p1, const float *__restrict__ tgt,
                                                           const float *__restrict__ cov1, const float *__restrict__ cov2,
                                                           const int32_t *__restrict__ idx, const float *__restrict__ dist,
@@ -217,7 +224,8 @@ __global__ __launch_bounds__(RB_THREADS) void k_resid_bwd(const float *__restric
                                                           const float *__restrict__ gloss, const float *__restrict__ cnt,
                                                           int N, int M, float reg, float *__restrict__ gp1,
                                                           float *__restrict__ gtgt, float *__restrict__ gcov1,
-                                                          float *__restrict__ gcov2) {
+                                                          float *__restrict__ gcov2, float *__restrict__ contrib,
+                                                          unsigned long long *__restrict__ keys) {
   const int b = blockIdx.y;
   const int i = blockIdx.x * RB_THREADS + threadIdx.x;
   const int lane = threadIdx.x;                      // RB_THREADS == 64: one wave per block
@@ -293,6 +301,18 @@ __global__ __launch_bounds__(RB_THREADS) void k_resid_bwd(const float *__restric
 #pragma unroll
     for (int k = 0; k < 7; ++k) sc[3 + k] = g7[k];
   }
+  if (keys) {
+    // ORDERED mode (default since round 5): nothing is added here.  Every source leaves its ten partner values and the key
+    // (partner row, source row); rslo_cov_residual_bwd sorts the keys and k_resid_gather* add each partner's values in
+    // ascending source order -- the same bits whatever the scheduling (atomics made every training step unique).
+    if (in_range) {
+      float *o = contrib + ((int64_t)b * N + i) * RB_NV;
+#pragma unroll
+      for (int k = 0; k < 10; ++k) o[k] = sc[k];
+      keys[(int64_t)b * N + i] = roi ? ((((unsigned long long)b * M + j) << RB_SRC_BITS) | ((unsigned long long)b * N + i)) : ~0ull;
+    }
+    return;
+  }
   // Source points are in scan order, so the sources of one partner mostly sit in consecutive lanes; when the two
   // clouds overlap badly (early training) thousands of sources share a few partners and per-lane atomics serialise
   // on those rows.  Each run of equal partners inside the wave is summed with a segmented scan and added once.
@@ -321,18 +341,126 @@ __global__ __launch_bounds__(RB_THREADS) void k_resid_bwd(const float *__restric
   }
 }
 
+// one thread per sorted key: the head of a partner's run adds the run's values in key (= source) order
+__global__ __launch_bounds__(256) void k_resid_gather(const unsigned long long *__restrict__ skeys, int64_t n,
+                                                      const float *__restrict__ contrib, float *__restrict__ gtgt,
+                                                      float *__restrict__ gcov2, int *__restrict__ n_long,
+                                                      int64_t *__restrict__ long_list) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= n) return;
+  const unsigned long long k = skeys[p];
+  if (k == ~0ull) return;
+  const unsigned long long row = k >> RB_SRC_BITS;
+  if (p > 0 && (skeys[p - 1] >> RB_SRC_BITS) == row) return;      // not the head of its run
+  int64_t e = p + 1;
+  while (e < n && e - p <= RB_SHORT && (skeys[e] >> RB_SRC_BITS) == row) ++e;
+  if (e - p > RB_SHORT) {                                          // a long run: one wave adds it (k_resid_gather_long)
+    long_list[atomicAdd(n_long, 1)] = p;                           // (the list's order does not matter: disjoint outputs)
+    return;
+  }
+  float acc[RB_NV];
+#pragma unroll
+  for (int q = 0; q < RB_NV; ++q) acc[q] = 0.f;
+  for (int64_t t = p; t < e; ++t) {
+    const float *c = contrib + (int64_t)(unsigned)skeys[t] * RB_NV;      // low dword = source row
+#pragma unroll
+    for (int q = 0; q < RB_NV; ++q) acc[q] += c[q];
+  }
+  float *gt = gtgt + (int64_t)row * 3, *g2 = gcov2 + (int64_t)row * 7;
+  gt[0] = acc[0]; gt[1] = acc[1]; gt[2] = acc[2];
+#pragma unroll
+  for (int q = 0; q < 7; ++q) g2[q] = acc[3 + q];
+}
+
+// one wave per long run: lane l adds elements l, l + 64, ... in order, then the 64 lane sums are added in a fixed tree
+__global__ __launch_bounds__(64) void k_resid_gather_long(const unsigned long long *__restrict__ skeys, int64_t n,
+                                                          const float *__restrict__ contrib, float *__restrict__ gtgt,
+                                                          float *__restrict__ gcov2, const int *__restrict__ n_long,
+                                                          const int64_t *__restrict__ long_list) {
+  const int lane = threadIdx.x;
+  for (int s = blockIdx.x; s < *n_long; s += gridDim.x) {
+    const int64_t p = long_list[s];
+    const unsigned long long row = skeys[p] >> RB_SRC_BITS;
+    float acc[RB_NV];
+#pragma unroll
+    for (int q = 0; q < RB_NV; ++q) acc[q] = 0.f;
+    for (int64_t t = p + lane; t < n && (skeys[t] >> RB_SRC_BITS) == row; t += 64) {
+      const float *c = contrib + (int64_t)(unsigned)skeys[t] * RB_NV;
+#pragma unroll
+      for (int q = 0; q < RB_NV; ++q) acc[q] += c[q];
+    }
+#pragma unroll
+    for (int q = 0; q < RB_NV; ++q)
+      for (int o = 32; o > 0; o >>= 1) acc[q] += __shfl_down(acc[q], o, 64);
+    if (lane == 0) {
+      float *gt = gtgt + (int64_t)row * 3, *g2 = gcov2 + (int64_t)row * 7;
+      gt[0] = acc[0]; gt[1] = acc[1]; gt[2] = acc[2];
+#pragma unroll
+      for (int q = 0; q < 7; ++q) g2[q] = acc[3 + q];
+    }
+  }
+}
+
+static int resid_key_bits(int B, int M) {
+  int bits = 1;
+  while ((1ull << bits) <= (unsigned long long)B * (unsigned long long)M) ++bits;      // all-ones > every partner row
+  return bits + RB_SRC_BITS;
+}
+
+static size_t resid_sort_tmp_bytes(int64_t n, int bits) {
+  size_t tmp = 0;
+  (void)rocprim::radix_sort_keys(nullptr, tmp, (unsigned long long *)nullptr, (unsigned long long *)nullptr, (size_t)n, 0,
+                                 (unsigned)bits, (hipStream_t)0);
+  return (tmp + 255) / 256 * 256;
+}
+
+// workspace of the ordered scatter: contributions [B N][10] f32 | keys [B N] u64 | sorted keys | long-run list [B N / 32 + 1]
+// i64 | counter | the sort's own scratch
+extern "C" size_t rslo_cov_residual_bwd_ws_bytes(int B, int N, int M) {
+  if (B <= 0 || N <= 0 || M <= 0) return 256;
+  const int64_t n = (int64_t)B * N;
+  return (size_t)n * RB_NV * 4 + (size_t)n * 8 * 2 + (size_t)(n / RB_SHORT + 2) * 8 + 256 + resid_sort_tmp_bytes(n, resid_key_bits(B, M)) +
+         8 * 256;      // + alignment of the six sections
+}
+
 extern "C" int rslo_cov_residual_bwd(const float *p1, const float *tgt, const float *cov1, const float *cov2,
                                               const int32_t *idx, const float *dist, const float *thr,
                                               const float *Rd, const float *gloss, const float *cnt, int B, int N,
                                               int M, float reg_weight, float *gp1 /*or NULL*/, float *gtgt,
-                                              float *gcov1, float *gcov2, void *stream) {
+                                              float *gcov1, float *gcov2, void *ws, size_t ws_bytes, void *stream) {
   hipStream_t st = (hipStream_t)stream;
   if (B == 0) return RSLO_OK;
   RSLO_HIP(hipMemsetAsync(gtgt, 0, (size_t)B * M * 3 * sizeof(float), st));
   RSLO_HIP(hipMemsetAsync(gcov2, 0, (size_t)B * M * 7 * sizeof(float), st));
-  hipLaunchKernelGGL(k_resid_bwd, dim3((unsigned)rslo_cdiv(N, RB_THREADS), B), dim3(RB_THREADS), 0, st, p1, tgt, cov1,
-                     cov2, idx, dist, thr, Rd, gloss, cnt, N, M, reg_weight, gp1, gtgt, gcov1, gcov2);
+  if (!rslo_tune(RSLO_TUNE_RESID_BWD_ORDERED)) {      // A/B only: per-run atomics, a different result every run
+    hipLaunchKernelGGL(k_resid_bwd, dim3((unsigned)rslo_cdiv(N, RB_THREADS), B), dim3(RB_THREADS), 0, st, p1, tgt, cov1,
+                       cov2, idx, dist, thr, Rd, gloss, cnt, N, M, reg_weight, gp1, gtgt, gcov1, gcov2, (float *)nullptr,
+                       (unsigned long long *)nullptr);
+    RSLO_CHECK_LAUNCH("cov_residual_bwd");
+    return RSLO_OK;
+  }
+  const int64_t n = (int64_t)B * N;
+  RSLO_CHECK_ARG(n < (1ll << 31) && (int64_t)B * M < (1ll << 31), "cov_residual_bwd: more than 2^31 rows");
+  RSLO_CHECK_ARG(ws && ws_bytes >= rslo_cov_residual_bwd_ws_bytes(B, N, M), "cov_residual_bwd: workspace too small");
+  const int bits = resid_key_bits(B, M);
+  unsigned char *w = (unsigned char *)(((uintptr_t)ws + 255) & ~(uintptr_t)255);      // every section on a 256-byte boundary
+  auto take = [&](size_t bytes) { unsigned char *p = w; w += (bytes + 255) / 256 * 256; return p; };
+  float *contrib = (float *)take((size_t)n * RB_NV * 4);
+  unsigned long long *keys = (unsigned long long *)take((size_t)n * 8);
+  unsigned long long *skeys = (unsigned long long *)take((size_t)n * 8);
+  int64_t *long_list = (int64_t *)take((size_t)(n / RB_SHORT + 2) * 8);
+  int *n_long = (int *)take(256);
+  size_t tmp = resid_sort_tmp_bytes(n, bits);
+  RSLO_HIP(hipMemsetAsync(n_long, 0, sizeof(int), st));
+  hipLaunchKernelGGL(k_resid_bwd, dim3((unsigned)rslo_cdiv(N, RB_THREADS), B), dim3(RB_THREADS), 0, st, p1, tgt, cov1, cov2,
+                     idx, dist, thr, Rd, gloss, cnt, N, M, reg_weight, gp1, gtgt, gcov1, gcov2, contrib, keys);
   RSLO_CHECK_LAUNCH("cov_residual_bwd");
+  RSLO_HIP(rocprim::radix_sort_keys((void *)w, tmp, keys, skeys, (size_t)n, 0, (unsigned)bits, st));
+  hipLaunchKernelGGL(k_resid_gather, dim3((unsigned)rslo_cdiv(n, 256)), dim3(256), 0, st, (const unsigned long long *)skeys, n,
+                     (const float *)contrib, gtgt, gcov2, n_long, long_list);
+  hipLaunchKernelGGL(k_resid_gather_long, dim3(512), dim3(64), 0, st, (const unsigned long long *)skeys, n,
+                     (const float *)contrib, gtgt, gcov2, (const int *)n_long, (const int64_t *)long_list);
+  RSLO_CHECK_LAUNCH("cov_residual_bwd(gather)");
   return RSLO_OK;
 }
 
