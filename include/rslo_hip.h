@@ -416,7 +416,7 @@ RSLO_API int rslo_chamfer_nn_ragged(const float *xyz1, const float *xyz2, int B,
                            void *stream);
 /*     Exact search with spatial pruning (Morton bucket sort of both clouds, 64-point target tiles with bounding
  *     boxes, box lower bound in the distance's own operation order => bit-identical to the exhaustive scan).
- *     rslo_chamfer_nn / _ragged dispatch to it for N >= 1024 and M >= 2048 (RSLO_CHAMFER=brute|grid overrides);
+ *     rslo_chamfer_nn / _ragged dispatch to it for N >= 1024 and M >= 2048 (tuning switch `chamfer`: 1 = exhaustive, 2 = pruned);
  *     rslo_chamfer_ws_bytes covers both. */
 RSLO_API int rslo_chamfer_brute_nn(const float *xyz1, const float *xyz2, int B, int N, int M, const int32_t *ncnt,
                                    const int32_t *mcnt, float *dist, int32_t *idx, void *ws, size_t ws_bytes,

@@ -58,6 +58,7 @@ def build(force=False, verbose=True):
 
 
 HOST_SRC = os.path.join(CSRC, "host", "voxelize_host.c")
+HOST_SRCS = [HOST_SRC, os.path.join(CSRC, "host", "chamfer_host.c")]
 HOST_LIB = os.path.join(HERE, "librslo_host.so")
 HOST_FLAGS = ["-O2", "-fPIC", "-shared", "-ffp-contract=off", "-fvisibility=hidden", "-Wall", "-Wextra"]
 
@@ -65,9 +66,9 @@ HOST_FLAGS = ["-O2", "-fPIC", "-shared", "-ffp-contract=off", "-fvisibility=hidd
 def build_host(force=False, verbose=True):
     """librslo_host.so (include/rslo_host.h): the host-memory face of VoxelGenerator for forked DataLoader workers.
     Plain C through gcc, no HIP."""
-    if not force and os.path.exists(HOST_LIB) and os.path.getmtime(HOST_LIB) >= os.path.getmtime(HOST_SRC):
+    if not force and os.path.exists(HOST_LIB) and os.path.getmtime(HOST_LIB) >= max(os.path.getmtime(f) for f in HOST_SRCS):
         return HOST_LIB
-    cmd = [os.environ.get("CC", "gcc")] + HOST_FLAGS + ["-o", HOST_LIB, HOST_SRC, "-lm"]
+    cmd = [os.environ.get("CC", "gcc")] + HOST_FLAGS + ["-o", HOST_LIB] + HOST_SRCS + ["-lm"]
     if verbose:
         print("[rslo_amd.build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -14,6 +14,10 @@ _lib = None
 
 SIGNATURES = {
     "rslo_host_abi_version": (C.c_int, []),
+    "rslo_host_chamfer_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p]),
+    "rslo_host_chamfer_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_void_p, C.c_void_p]),
     "rslo_host_voxelize": (C.c_int64, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                        C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
@@ -49,3 +53,39 @@ def voxelize(points, pc_range, voxel_size, grid_xyz, max_points, max_voxels):
     if n < 0:
         raise RuntimeError("rslo_host_voxelize failed (%d)" % n)
     return vox[:n], coords[:n], num[:n]
+
+
+def _host_f32(t, name):
+    import torch
+    if t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+        raise ValueError("%s must be a contiguous float32 host tensor" % name)
+    return t.data_ptr()
+
+
+def _host_i32(t, name):
+    import torch
+    if t.is_cuda or t.dtype != torch.int32 or not t.is_contiguous():
+        raise ValueError("%s must be a contiguous int32 host tensor" % name)
+    return t.data_ptr()
+
+
+def chamfer_forward(xyz1, xyz2, dist1, dist2, idx1, idx2):
+    """cd.forward on host tensors (caller-allocated outputs, like the reference's pybind entry point)."""
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    rc = lib().rslo_host_chamfer_forward(_host_f32(xyz1, "xyz1"), _host_f32(xyz2, "xyz2"), b, n, m, _host_f32(dist1, "dist1"),
+                                         _host_f32(dist2, "dist2"), _host_i32(idx1, "idx1"), _host_i32(idx2, "idx2"))
+    if rc:
+        raise RuntimeError("rslo_host_chamfer_forward: bad arguments (empty cloud?)")
+
+
+def chamfer_backward(xyz1, xyz2, gradxyz1, gradxyz2, graddist1, graddist2, idx1, idx2):
+    """cd.backward on host tensors: gradxyz1 / gradxyz2 are overwritten."""
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    rc = lib().rslo_host_chamfer_backward(_host_f32(xyz1, "xyz1"), _host_f32(xyz2, "xyz2"), b, n, m,
+                                          _host_f32(graddist1, "graddist1"), _host_f32(graddist2, "graddist2"),
+                                          _host_i32(idx1, "idx1"), _host_i32(idx2, "idx2"), _host_f32(gradxyz1, "gradxyz1"),
+                                          _host_f32(gradxyz2, "gradxyz2"))
+    if rc:
+        raise RuntimeError("rslo_host_chamfer_backward: bad arguments")

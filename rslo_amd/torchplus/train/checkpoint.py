@@ -108,9 +108,26 @@ def restore(ckpt_path, model, map_func=None, map_location="cpu"):
     # the reference's plain torch.load (checkpoint.py:118-126, torch 1.2): a .tckpt of the OPTIMIZER carries what the
     # schedule wrote into its param groups (numpy scalars from the OneCycle interpolation), which torch >= 2.6's default
     # weights_only unpickler refuses; try the restricted loader first, fall back for the user's own checkpoint files
+    # restricted loader with the numpy scalar types the schedule leaves in the optimizer's param groups allow-listed; only
+    # when THAT still refuses (a type outside the list: pickle.UnpicklingError) the file is unpickled in full like the
+    # reference does -- with a warning, since a full unpickle runs whatever the file says
+    import pickle
+    import warnings
+    import numpy as np
+    safe = [np.dtype, np.ndarray, np.float64, np.float32, np.int64, np.int32, np.bool_]
+    for name in ("core.multiarray.scalar", "_core.multiarray.scalar"):
+        mod, _, attr = ("numpy." + name).rpartition(".")
+        try:
+            safe.append(getattr(__import__(mod, fromlist=[attr]), attr))
+        except (ImportError, AttributeError):
+            pass
+    safe += [type(np.dtype(t)) for t in ("float64", "float32", "int64", "int32", "bool")]
     try:
-        state = torch.load(ckpt_path, map_location=map_location, weights_only=True)
-    except Exception:
+        with torch.serialization.safe_globals(safe):
+            state = torch.load(ckpt_path, map_location=map_location, weights_only=True)
+    except pickle.UnpicklingError as e:
+        warnings.warn("checkpoint %s holds objects outside the weights-only allow-list (%s): unpickling it in full, as the "
+                      "reference's torch.load does -- only do this with files you trust" % (ckpt_path, str(e).splitlines()[0]))
         state = torch.load(ckpt_path, map_location=map_location, weights_only=False)
     if map_func is not None:
         state = map_func(state)

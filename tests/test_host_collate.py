@@ -139,16 +139,18 @@ def test_numpy_voxel_generator_works_in_forked_workers(monkeypatch):
     assert (out["voxels"] == v).all() and (out["coordinates"] == c).all() and (out["num_points_per_voxel"] == m).all()
 
 
-def test_chamfer_host_entry_points_are_refused_with_the_difference_named():
-    """The reference's cd.forward / cd.backward are its HOST implementations (chamfer_distance.cpp:147-234); this package
-    has no CPU compute path for chamfer and must say so instead of aliasing silently."""
+def test_chamfer_one_direction_functions_stay_cuda_only_like_the_reference():
+    """cd.forward / cd.backward take host tensors (librslo_host.so, tests/test_oracle.py); the one-direction functions the
+    loss uses are CUDA-only in the reference (chamfer_distance.py:174-175 raises NotImplementedError) and here: no CPU route
+    into the training path, and a mixed host / device call is an error, never a silent copy."""
     import pytest
     import torch
     import rslo_amd  # noqa: F401
-    from thirdparty.chamfer_distance.chamfer_distance import cd
+    from rslo_amd import capi
+    from thirdparty.chamfer_distance.chamfer_distance import OneDirectionChamferDistanceWithIdx, cd
     a = torch.zeros(1, 4, 3)
+    with pytest.raises((NotImplementedError, capi.RsloHipError)):
+        OneDirectionChamferDistanceWithIdx()(a, a)
     d, i = torch.zeros(1, 4), torch.zeros(1, 4, dtype=torch.int32)
-    with pytest.raises(NotImplementedError, match="HOST"):
-        cd.forward(a, a, d, d.clone(), i, i.clone())
-    with pytest.raises(NotImplementedError, match="HOST"):
-        cd.backward(a, a, a.clone(), a.clone(), d, d.clone(), i, i.clone())
+    cd.forward(a, a, d, d.clone(), i, i.clone())          # host tensors: served on the host, as in the reference
+    assert float(d.abs().max()) == 0.0 and int(i.max()) == 0

@@ -229,6 +229,55 @@ def test_chamfer_golden_vectors_both_directions():
     np.testing.assert_allclose(a2 + b2, g["gradxyz2_both"], rtol=1e-6, atol=1e-6)
 
 
+def test_host_chamfer_entry_points_match_golden_vectors_and_reference_build():
+    """cd.forward / cd.backward on HOST tensors (librslo_host.so: rslo_host_chamfer_forward / _backward, what the mirror's
+    `cd` serves for CPU tensors like the reference's chamfer_distance.cpp:147-234): dist / idx of both directions bit-exact
+    against the reference-generated vectors, both-direction gradients to rounding, and -- where oracle/_ref is built --
+    against the reference's own functions on fresh inputs incl. ties; the two-direction autograd module on CPU tensors."""
+    import rslo_amd  # noqa: F401
+    from thirdparty.chamfer_distance.chamfer_distance import ChamferDistance, cd
+    g = np.load(os.path.join(GOLD, "chamfer_ref.npz"))
+    a, c = torch.from_numpy(g["xyz1"]), torch.from_numpy(g["xyz2"])
+    b, n, m = a.shape[0], a.shape[1], c.shape[1]
+    d1, d2 = torch.zeros(b, n), torch.zeros(b, m)
+    i1, i2 = torch.zeros(b, n, dtype=torch.int32), torch.zeros(b, m, dtype=torch.int32)
+    cd.forward(a, c, d1, d2, i1, i2)
+    assert (i1.numpy() == g["idx1"]).all() and (d1.numpy() == g["dist1"]).all()
+    assert (i2.numpy() == g["idx2"]).all() and (d2.numpy() == g["dist2"]).all()
+    g1, g2 = torch.full((b, n, 3), 7.0), torch.full((b, m, 3), 7.0)      # overwritten, not accumulated into
+    cd.backward(a, c, g1, g2, torch.from_numpy(g["graddist1"]), torch.from_numpy(g["graddist2"]), i1, i2)
+    np.testing.assert_allclose(g1.numpy(), g["gradxyz1_both"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(g2.numpy(), g["gradxyz2_both"], rtol=1e-6, atol=1e-6)
+    ref = _ref_module()
+    if ref is not None:
+        rng = np.random.default_rng(15)
+        for (bb, nn, mm) in [(2, 333, 1025), (1, 1, 1), (1, 64, 3)]:
+            x = torch.from_numpy(rng.normal(size=(bb, nn, 3)).astype(np.float32) * 10)
+            y = torch.from_numpy(rng.normal(size=(bb, mm, 3)).astype(np.float32) * 10)
+            y[:, : min(mm, 5)] = x[:, : min(mm, 5)][:, : min(mm, nn)] if nn >= min(mm, 5) else y[:, : min(mm, 5)]
+            outs = []
+            for fwd, bwd in ((ref.forward, ref.backward), (cd.forward, cd.backward)):
+                e1, e2 = torch.zeros(bb, nn), torch.zeros(bb, mm)
+                j1, j2 = torch.zeros(bb, nn, dtype=torch.int32), torch.zeros(bb, mm, dtype=torch.int32)
+                fwd(x, y, e1, e2, j1, j2)
+                gd1 = torch.from_numpy(np.random.default_rng(3).normal(size=(bb, nn)).astype(np.float32))
+                gd2 = torch.from_numpy(np.random.default_rng(4).normal(size=(bb, mm)).astype(np.float32))
+                h1, h2 = torch.zeros(bb, nn, 3), torch.zeros(bb, mm, 3)
+                bwd(x, y, h1, h2, gd1, gd2, j1, j2)
+                outs.append((e1, e2, j1, j2, h1, h2))
+            for r_, o_ in zip(outs[0], outs[1]):
+                assert torch.equal(r_, o_)          # the same loops in the same order: identical bits
+    # the module on CPU tensors (chamfer_distance.py:34,61): autograd through the host entry points
+    x = a[:, :200].clone().requires_grad_(True)
+    y = c[:, :150].clone().requires_grad_(True)
+    e1, e2 = ChamferDistance()(x, y)
+    (e1.sum() + 2 * e2.sum()).backward()
+    xd, yd = x.detach().double(), y.detach().double()
+    dd = ((xd[:, :, None] - yd[:, None]) ** 2).sum(-1)
+    np.testing.assert_allclose(e1.detach().numpy(), dd.min(2).values.numpy(), rtol=1e-5, atol=1e-6)
+    assert x.grad is not None and y.grad is not None and float(x.grad.abs().sum()) > 0
+
+
 def test_chamfer_vs_cdist_and_tie_break():
     rng = np.random.default_rng(6)
     a = rng.normal(size=(1, 400, 3)).astype(np.float32)
