@@ -828,6 +828,12 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", str(rank))
         os.environ.setdefault("WORLD_SIZE", str(world))
+        if world > 1 and not one_gpu:
+            # the first real N > 1 run must be diagnosable in one shot: RCCL's INIT / GRAPH lines (rings, trees, transports
+            # per channel, xGMI vs PCIe) go to a per-rank file whose relevant lines rank 0 quotes in `rccl.topology_lines`
+            os.environ.setdefault("NCCL_DEBUG", "INFO")
+            os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,GRAPH")
+            os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/rslo_rccl_%d_rank%%p.log" % os.getppid())
         if one_gpu:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -931,6 +937,7 @@ def main():
         return time.perf_counter(), time.thread_time()
 
     ph_hook = [None]
+    gx_events = []       # (before, after) grad_exchange.finish() on the training stream: what of the gradient exchange is NOT hidden
 
     def step():
         w0, c0 = time.perf_counter(), time.thread_time()
@@ -956,10 +963,15 @@ def main():
         with amp.scale_loss(ret["loss"].mean(), opt) as scaled_loss:       # train_hdf5.py:663
             scaled_loss.backward()
         if dist_on and not skip_grad_exchange:
+            gx0 = torch.cuda.Event(enable_timing=True)
+            gx1 = torch.cuda.Event(enable_timing=True)
+            gx0.record()
             if grad_exchange is not None:
                 grad_exchange.finish()
             else:
                 average_gradients(net, mean=True)
+            gx1.record()
+            gx_events.append((gx0, gx1))
         w0, c0 = mark("bwd", w0, c0)
         if ph_hook[0]:
             ph_hook[0]("backward")
@@ -994,6 +1006,7 @@ def main():
     barrier()
     # per-launch HIP events on the last PROBE_STEPS timed steps only (the events themselves cost host time)
     probe_steps = min(3, args.steps)
+    del gx_events[:]
     wait[0] = 0.0
     if prefetch is not None:
         prefetch.plan_wait_seconds = 0.0
@@ -1059,6 +1072,33 @@ def main():
                            if _comm is not None else "collective (all_reduce)")
         if _comm is not None:
             _comm.check()          # a peer that missed an exchange poisons the statistics with NaN: fail loudly, never report it
+    # N > 1 diagnostics, gathered on every rank (collective calls), reported by rank 0
+    gx_exposed = peer_waits = transports = topo = None
+    if dist_on:
+        torch.cuda.synchronize()
+        n_gx = min(len(gx_events), args.steps)
+        if n_gx:
+            gx_exposed = round(sum(a.elapsed_time(b) for a, b in gx_events[-n_gx:]) / n_gx, 3)
+        from rslo_amd import peer as _peer2
+        _c2 = _peer2.comm_for(None) if (world > 1 or os.environ.get("RSLO_FORCE_SYNCBN_PATH", "0") == "1") else None
+        mine = {"transport": _c2.transport if _c2 is not None else "rccl", "wait": _c2.wait_stats() if _c2 is not None else None}
+        allr = [None] * world
+        dist.all_gather_object(allr, mine)
+        transports = [a["transport"] for a in allr]
+        peer_waits = [a["wait"] for a in allr]
+        dbg = os.environ.get("NCCL_DEBUG_FILE", "")
+        if rank == 0 and dbg:
+            import glob as _glob
+            topo = []
+            for f in sorted(_glob.glob(dbg.replace("%p", "*").replace("%h", "*")))[:2]:
+                try:
+                    with open(f, errors="replace") as fh:
+                        keep = [ln.strip()[-200:] for ln in fh if any(k in ln for k in ("Ring", "Tree", "Channel", " via ", "XGMI", "xGMI",
+                                                                                         "P2P", "NET/", "nranks", "comm 0x"))]
+                    topo += keep[:12]
+                except OSError:
+                    pass
+            topo = topo[:24] or None
     if phases and rank == 0:
         st = torch.cuda.memory_stats(dev)
         print("allocator: %d hipMalloc calls during the %d timed steps, %d MB reserved, %d MB peak allocated, live %d -> %d MB" % (
@@ -1190,7 +1230,12 @@ def main():
                             "ms_per_step_min": round(1e3 * min(per_rank) / args.steps, 3),
                             "ms_per_step_max": round(1e3 * max(per_rank) / args.steps, 3),
                             # how the 90 SyncBN statistics exchanges per step travelled (rslo_amd/peer.py)
-                            "syncbn_exchange": syncbn_exchange, "replicas_identical": replicas_identical}
+                            "syncbn_exchange": syncbn_exchange, "replicas_identical": replicas_identical,
+                            # diagnostics for the first real N > 1 run (verdict r4 #6): the part of the gradient exchange
+                            # the training stream waits for, per-rank peer transport and per-exchange waits, RCCL's own
+                            # topology lines
+                            "grad_exchange_exposed_ms_per_step": gx_exposed, "syncbn_wait_us": peer_waits,
+                            "syncbn_transport_per_rank": transports, "topology_lines": topo}
         if world == 1 and not dist_on and os.environ.get("RSLO_BENCH_MULTIRANK_CHILD", "1") != "0" and not args.no_kernel_events:
             # The step a rank of an N > 1 job really runs, measured on this one GPU: a child process with a ONE-rank RCCL
             # group and the multi-rank code path forced (RSLO_FORCE_SYNCBN_PATH=1: SyncBN statistics meet the "peers" through

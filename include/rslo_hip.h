@@ -727,6 +727,9 @@ RSLO_API int rslo_peer_create_device_finish(void *comm, const void *all_handles)
 RSLO_API int rslo_peer_set_timeout_ms(void *comm, int ms);
 RSLO_API int rslo_peer_allreduce_f64(void *comm, double *t, int n, void *stream);
 RSLO_API unsigned long long rslo_peer_status(void *comm, int *peer);
+/*      Diagnostics for the first real N > 1 run: microseconds each of the most recent exchanges (<= 4096) spent spinning for its
+ *      slowest peer, oldest first (arrival skew + transport latency); returns the sample count. */
+RSLO_API int rslo_peer_wait_samples(void *comm, float *out_us, int max_out);
 /*      Round 5: SyncBN of the maps a workgroup holds in registers (N*HW <= 17408 values per channel, C <= 512) in ONE launch
  *      per direction on any number of ranks.  The workgroup of channel c publishes its sums in the comm's slice, meets the
  *      workgroups of channel c on the other ranks (per-channel flags; sums in rank order: identical bits everywhere) and

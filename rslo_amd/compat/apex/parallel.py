@@ -105,7 +105,13 @@ def _fused_peer_comm(group):
     if not FUSED_PEER_BN:
         return None
     from rslo_amd import peer
-    return peer.comm_for(group)
+    comm = peer.comm_for(group)
+    if comm is not None and comm.shared_device and not FORCE_FUSED_ON_SHARED_DEVICE:
+        return None          # ranks sharing one GPU: see PeerComm.shared_device
+    return comm
+
+
+FORCE_FUSED_ON_SHARED_DEVICE = False      # tests/test_peer_exchange.py sets it for its small layers
 
 
 def _multi(world):

@@ -508,6 +508,7 @@ struct BnPeer {
   size_t chan;                  // byte offset of the slot's channel records inside a slice
   long long timeout_ticks;
   unsigned long long *status;
+  unsigned *wait_ring;
 };
 
 template <int T, int E>
@@ -535,10 +536,10 @@ __global__ __launch_bounds__(T) void k_bn2d_fwd_rc_peer(const float *__restrict_
     q += (double)v[i] * v[i];
   }
   __shared__ double tot[2];
-  __shared__ double sh[4 + 3 * PEER_MAX_WORLD];
+  __shared__ double sh[4 + 4 * PEER_MAX_WORLD];
   bn_block_sum2_t<T>(s, q, tot);
   double ex[3] = {tot[0], tot[1], (double)N * HW};
-  const bool ok = peer_chan_exchange(pc.tab, pc.me, pc.world, pc.seq, pc.chan, c, pc.timeout_ticks, pc.status, ex, sh);
+  const bool ok = peer_chan_exchange(pc.tab, pc.me, pc.world, pc.seq, pc.chan, c, pc.timeout_ticks, pc.status, ex, sh, pc.wait_ring);
   const double cnt = ex[2];
   const double m = ex[0] / cnt;
   double var = ex[1] / cnt - m * m;
@@ -596,14 +597,14 @@ __global__ __launch_bounds__(T) void k_bn2d_bwd_rc_peer(const float *__restrict_
     q += (double)g[i] * (double)xh[i];
   }
   __shared__ double tot[2];
-  __shared__ double sh[4 + 3 * PEER_MAX_WORLD];
+  __shared__ double sh[4 + 4 * PEER_MAX_WORLD];
   bn_block_sum2_t<T>(s, q, tot);
   if (threadIdx.x == 0) {          // the affine gradients are this rank's own sums (data parallel averages them later)
     if (dbeta) dbeta[c] = (float)tot[0];
     if (dgamma) dgamma[c] = (float)tot[1];
   }
   double ex[3] = {tot[0], tot[1], 0.0};
-  const bool ok = peer_chan_exchange(pc.tab, pc.me, pc.world, pc.seq, pc.chan, c, pc.timeout_ticks, pc.status, ex, sh);
+  const bool ok = peer_chan_exchange(pc.tab, pc.me, pc.world, pc.seq, pc.chan, c, pc.timeout_ticks, pc.status, ex, sh, pc.wait_ring);
   const double cnt = *count_all;        // element count over all ranks, as exchanged in the forward pass
   const float k0 = (gamma ? gamma[c] : 1.f) * invstd;
   float mg = (float)(ex[0] / cnt), mgx = (float)(ex[1] / cnt);
@@ -855,6 +856,8 @@ static BnPeer bn_peer_args(RsloPeerComm *c, unsigned long long seq) {
   pc.tab = c->tab; pc.me = c->rank; pc.world = c->world; pc.seq = seq;
   pc.chan = (size_t)(seq % PEER_SLOTS) * c->slot_bytes + peer_chan_off(c->max_n);
   pc.timeout_ticks = c->timeout_ticks; pc.status = c->status_dev;
+  pc.wait_ring = c->wait_ring_dev;
+  c->wait_ring_host[seq % PEER_WAIT_RING] = 0;      // (host write to pinned memory, ordered before the launch that follows)
   return pc;
 }
 

@@ -37,7 +37,7 @@
 // convolution that left it dirty).
 __global__ void __launch_bounds__(1024) k_peer_allreduce(double *__restrict__ t, int n, PeerTable tab, int me, int world,
                                                          unsigned long long seq, size_t slot_off, long long timeout_ticks,
-                                                         unsigned long long *__restrict__ status) {
+                                                         unsigned long long *__restrict__ status, unsigned *__restrict__ wait_ring) {
   const int tid = threadIdx.x;
   const unsigned tag = (unsigned)seq;
   __shared__ int s_bad;
@@ -49,6 +49,7 @@ __global__ void __launch_bounds__(1024) k_peer_allreduce(double *__restrict__ t,
     __hip_atomic_store(g, ((unsigned long long)tag << 32) | (unsigned)bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(g + 1, ((unsigned long long)tag << 32) | (unsigned)(bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
+  unsigned waited = 0;
   for (int i = tid; i < n; i += blockDim.x) {
     double s = 0.0;
     for (int r = 0; r < world; ++r) {                      // rank order: the same bits on every rank
@@ -65,10 +66,12 @@ __global__ void __launch_bounds__(1024) k_peer_allreduce(double *__restrict__ t,
           break;
         }
       }
+      if (r != me) waited = max(waited, (unsigned)(wall_clock64() - t0));
       s += __longlong_as_double((long long)((w1 << 32) | (unsigned)w0));
     }
     t[i] = s;
   }
+  if (tid == 0) __hip_atomic_store(wait_ring + (seq % PEER_WAIT_RING), waited, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   __syncthreads();
   if (s_bad) {       // a peer never arrived: poison the result and report; never hang the GPU
     if (tid == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0) {
@@ -85,7 +88,7 @@ __global__ void __launch_bounds__(1024) k_peer_allreduce(double *__restrict__ t,
 // does not use this form.
 __global__ void __launch_bounds__(1024) k_peer_allreduce_flag(double *__restrict__ t, int n, PeerTable tab, int me, int world,
                                                               unsigned long long seq, size_t slot_off, long long timeout_ticks,
-                                                              unsigned long long *__restrict__ status) {
+                                                              unsigned long long *__restrict__ status, unsigned *__restrict__ wait_ring) {
   const int tid = threadIdx.x;
   unsigned char *mine = tab.base[me] + slot_off;
   unsigned long long *my_flag = (unsigned long long *)mine;
@@ -99,7 +102,8 @@ __global__ void __launch_bounds__(1024) k_peer_allreduce_flag(double *__restrict
     __hip_atomic_store(my_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   __shared__ int s_bad;
-  if (tid == 0) s_bad = 0;
+  __shared__ unsigned s_wait;
+  if (tid == 0) { s_bad = 0; s_wait = 0; }
   __syncthreads();
   if (tid < world && tid != me) {
     const unsigned long long *f = (const unsigned long long *)(tab.base[tid] + slot_off);
@@ -111,8 +115,10 @@ __global__ void __launch_bounds__(1024) k_peer_allreduce_flag(double *__restrict
         break;
       }
     }
+    atomicMax(&s_wait, (unsigned)(wall_clock64() - t0));
   }
   __syncthreads();
+  if (tid == 0) __hip_atomic_store(wait_ring + (seq % PEER_WAIT_RING), s_wait, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // system scope
   if (s_bad) {       // a peer never arrived: poison the result and report; never hang the GPU
     if (tid == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0) {
@@ -141,6 +147,9 @@ static int peer_common_init(RsloPeerComm *c, int rank, int world, int max_n) {
   RSLO_HIP(hipHostMalloc((void **)&c->status_host, 64, hipHostMallocMapped));
   memset(c->status_host, 0, 64);
   RSLO_HIP(hipHostGetDevicePointer((void **)&c->status_dev, c->status_host, 0));
+  RSLO_HIP(hipHostMalloc((void **)&c->wait_ring_host, PEER_WAIT_RING * sizeof(unsigned), hipHostMallocMapped));
+  memset(c->wait_ring_host, 0, PEER_WAIT_RING * sizeof(unsigned));
+  RSLO_HIP(hipHostGetDevicePointer((void **)&c->wait_ring_dev, c->wait_ring_host, 0));
   return RSLO_OK;
 }
 
@@ -256,12 +265,13 @@ extern "C" int rslo_peer_allreduce_f64(void *comm, double *t, int n, void *strea
   const unsigned long long seq = c->seq + 1;      // committed only once the launch is in the stream
   const size_t slot_off = (size_t)(seq % PEER_SLOTS) * c->slot_bytes;
   const int threads = n >= 512 ? 1024 : (n >= 192 ? 512 : 256);
+  c->wait_ring_host[seq % PEER_WAIT_RING] = 0;
   if (c->transport == 0)
     hipLaunchKernelGGL(k_peer_allreduce_flag, dim3(1), dim3(threads), 0, (hipStream_t)stream, t, n, c->tab, c->rank, c->world,
-                       seq, slot_off, c->timeout_ticks, c->status_dev);
+                       seq, slot_off, c->timeout_ticks, c->status_dev, c->wait_ring_dev);
   else
     hipLaunchKernelGGL(k_peer_allreduce, dim3(1), dim3(threads), 0, (hipStream_t)stream, t, n, c->tab, c->rank, c->world, seq,
-                       slot_off, c->timeout_ticks, c->status_dev);
+                       slot_off, c->timeout_ticks, c->status_dev, c->wait_ring_dev);
   RSLO_CHECK_LAUNCH("k_peer_allreduce");
   c->seq = seq;
   return RSLO_OK;
@@ -275,6 +285,21 @@ extern "C" unsigned long long rslo_peer_status(void *comm, int *peer) {
   const unsigned long long s = ((volatile unsigned long long *)c->status_host)[0];
   if (peer) *peer = s ? (int)((volatile unsigned long long *)c->status_host)[1] : -1;
   return s;
+}
+
+// Diagnostics: the waits (microseconds) of the most recent exchanges, oldest first -- how long each spent spinning for its
+// slowest peer (arrival skew + transport latency; 0 for a one-rank comm).  Reads pinned memory: synchronise the stream first for
+// a consistent picture.  Returns the number of samples written (<= max_out, <= PEER_WAIT_RING, <= exchanges issued).
+extern "C" int rslo_peer_wait_samples(void *comm, float *out_us, int max_out) {
+  RsloPeerComm *c = (RsloPeerComm *)comm;
+  if (!c || !out_us || max_out <= 0) return 0;
+  unsigned long long n = c->seq < PEER_WAIT_RING ? c->seq : PEER_WAIT_RING;
+  if (n > (unsigned long long)max_out) n = (unsigned long long)max_out;
+  for (unsigned long long k = 0; k < n; ++k) {
+    const unsigned long long q = c->seq - n + 1 + k;
+    out_us[k] = (float)((volatile unsigned *)c->wait_ring_host)[q % PEER_WAIT_RING] * 0.01f;      // 100 MHz ticks
+  }
+  return (int)n;
 }
 
 extern "C" int rslo_peer_destroy(void *comm) {
@@ -291,6 +316,7 @@ extern "C" int rslo_peer_destroy(void *comm) {
     if (c->own_slice) (void)hipFree(c->own_slice);
   }
   (void)hipHostFree(c->status_host);
+  (void)hipHostFree(c->wait_ring_host);
   delete c;
   return RSLO_OK;
 }

@@ -6,6 +6,7 @@
 #define PEER_SLOTS 4
 #define PEER_MAX_WORLD 16
 #define PEER_MAX_N 1024
+#define PEER_WAIT_RING 4096              // per-exchange wait samples kept for the diagnostics (rslo_peer_wait_samples)
 #define PEER_MAX_CH 512                 // channels of a fused SyncBN exchange (per-channel flags)
 #define PEER_CH_BYTES 64                // six 8-byte granules {32-bit half | 32-bit tag} per channel (3 doubles), padded
 
@@ -21,6 +22,7 @@ struct RsloPeerComm {
   unsigned long long *status_host;          // pinned: [0] = first sequence number that timed out (0 = none), [1] = peer
   unsigned long long *status_dev;
   long long timeout_ticks;                  // wall_clock64() ticks (100 MHz)
+  unsigned *wait_ring_host, *wait_ring_dev; // pinned [PEER_WAIT_RING]: ticks exchange q spent waiting for its peers, at q mod ring
   // host transport
   void *shm_ptr;
   size_t shm_bytes;
@@ -48,7 +50,7 @@ static inline size_t peer_slot_bytes(int max_n) { return peer_chan_off(max_n) + 
 // local BatchNorm (profiles/NOTES.md round 5).
 __device__ __forceinline__ bool peer_chan_exchange(const PeerTable &tab, int me, int world, unsigned long long seq, size_t chan,
                                                    int c, long long timeout_ticks, unsigned long long *status, double (&v)[3],
-                                                   double *sh /* [4 + 3 * PEER_MAX_WORLD] shared */) {
+                                                   double *sh /* [4 + 4 * PEER_MAX_WORLD] shared */, unsigned *wait_ring = nullptr) {
   const int tid = threadIdx.x;
   const unsigned tag = (unsigned)seq;
   unsigned *halves = (unsigned *)(sh + 4);                 // [world][6]
@@ -76,8 +78,15 @@ __device__ __forceinline__ bool peer_chan_exchange(const PeerTable &tab, int me,
       }
     }
     halves[r * 6 + k] = (unsigned)w;
+    if (k == 0) halves[6 * world + r] = r != me ? (unsigned)(wall_clock64() - t0) : 0u;
   }
   __syncthreads();
+  // diagnostics: how long channel 0's workgroup waited for the slowest OTHER rank (one sample per exchange, plain store)
+  if (wait_ring && c == 0 && tid == 0) {
+    unsigned mx = 0;
+    for (int r = 0; r < world; ++r) mx = halves[6 * world + r] > mx ? halves[6 * world + r] : mx;
+    __hip_atomic_store(wait_ring + (seq % PEER_WAIT_RING), mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   const int bad = (int)sh[3];
   if (bad) {
     if (tid == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0) {

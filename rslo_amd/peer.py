@@ -29,8 +29,13 @@ _COMMS = {}          # id of the default group object -> PeerComm | False (not e
 
 
 class PeerComm:
-    def __init__(self, handle, rank, world, transport):
+    def __init__(self, handle, rank, world, transport, shared_device=False):
         self.handle, self.rank, self.world, self.transport = handle, rank, world, transport
+        # two ranks of the comm live on ONE GPU (development boxes): kernels whose every workgroup spins for its peer
+        # (rslo_bn2d_fwd_peer) then need both processes' grids resident side by side, which nothing guarantees -- a full
+        # GPU of waiting workgroups starves the peer's kernel until the timeout.  The single-workgroup exchange kernel is
+        # fine there; the fused SyncBN path is only taken when every rank has its own device.
+        self.shared_device = shared_device
 
     def all_reduce_(self, t):
         assert t.is_cuda and t.dtype == torch.float64 and t.is_contiguous() and t.numel() <= MAX_N
@@ -50,6 +55,17 @@ class PeerComm:
         if s:
             raise capi.RsloHipError("peer exchange %d timed out waiting for rank %d (results were poisoned with NaN)" % (s, peer))
 
+    def wait_stats(self):
+        """p50 / p99 / max microseconds the recent exchanges (<= 4096) spent waiting for their slowest peer, and how many
+        samples that is over; call after a synchronisation."""
+        buf = (C.c_float * 4096)()
+        n = capi.lib().rslo_peer_wait_samples(self.handle, buf, 4096)
+        if n <= 0:
+            return {"samples": 0}
+        v = sorted(buf[:n])
+        return {"samples": n, "p50_us": round(v[n // 2], 2), "p99_us": round(v[min(n - 1, (99 * n) // 100)], 2),
+                "max_us": round(v[-1], 2)}
+
     def set_timeout_ms(self, ms):
         capi._chk(capi.lib().rslo_peer_set_timeout_ms(self.handle, int(ms)), "rslo_peer_set_timeout_ms")
 
@@ -66,8 +82,13 @@ def create(transport="host", group=None):
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     hosts = [None] * world
-    dist.all_gather_object(hosts, socket.gethostname(), group=group)
-    if len(set(hosts)) != 1 or world > 16:
+    pr = torch.cuda.get_device_properties(torch.cuda.current_device())
+    dev_id = tuple(getattr(pr, k, None) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
+    if dev_id == (None, None, None):
+        dev_id = ("index", torch.cuda.current_device())
+    dist.all_gather_object(hosts, (socket.gethostname(), dev_id), group=group)
+    shared_device = len({h[1] for h in hosts}) < world
+    if len({h[0] for h in hosts}) != 1 or world > 16:
         return None
     lib = capi.lib()
     handle = C.c_void_p()
@@ -88,7 +109,7 @@ def create(transport="host", group=None):
             capi._chk(lib.rslo_peer_create_device_finish(handle, b"".join(allh)), "rslo_peer_create_device_finish")
         else:
             raise ValueError("unknown peer transport %r" % (transport,))
-        comm = PeerComm(handle, rank, world, transport)
+        comm = PeerComm(handle, rank, world, transport, shared_device)
     except Exception as e:      # agreed below: one rank failing turns the exchange off everywhere
         ok = 0
         err = e
@@ -122,7 +143,7 @@ def create(transport="host", group=None):
             good = 0
         # the single-launch SyncBN kernels meet their peers per channel (rslo_bn2d_fwd_peer): rank-dependent constants
         # per channel, whose mean over the ranks is known
-        for Cc, hw in ((8, 16), (64, 1056), (512, 4)):
+        for Cc, hw in (((8, 16), (64, 1056), (512, 4)) if not shared_device else ((8, 16),)):
             x = (torch.arange(Cc, dtype=torch.float32, device="cuda").view(1, Cc, 1, 1) + float(rank + 1)).expand(2, Cc, hw, 1).contiguous()
             y, mean, invstd, cnt = capi.bn2d_fwd_peer(comm, x, None, None, None, None, None, 0.1, 1e-5, 1.0)
             want = torch.arange(Cc, dtype=torch.float32) + float(tri) / world

@@ -60,8 +60,9 @@ def test_bench_gpus_2_runs_the_full_two_rank_step(hip):
     functional, not a performance mode."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env["RSLO_BENCH_ONE_GPU"] = "1"
+    env["RSLO_PEER_TIMEOUT_MS"] = "20000"          # a peer that does not show up fails the test in seconds, not minutes
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
-                          "--batch", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=1200, cwd=ROOT, env=env)
+                          "--batch", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=400, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     line = _last_json(out.stdout)
     assert line["n_gpus"] == 2 and line["value"] > 0
@@ -69,6 +70,12 @@ def test_bench_gpus_2_runs_the_full_two_rank_step(hip):
     # SyncBN statistics travelled through the same-stream peer kernel, and after the steps both ranks hold the same bits
     assert "peer kernel" in line["rccl"]["syncbn_exchange"], line["rccl"]
     assert line["rccl"]["replicas_identical"] is True, line["rccl"]
+    # diagnostics of an N > 1 run: the exposed part of the gradient exchange, per-rank transport and per-exchange waits
+    r = line["rccl"]
+    assert r["grad_exchange_exposed_ms_per_step"] is not None and r["grad_exchange_exposed_ms_per_step"] >= 0
+    assert len(r["syncbn_transport_per_rank"]) == 2 and len(set(r["syncbn_transport_per_rank"])) == 1
+    assert all(w["samples"] > 0 and w["p50_us"] <= w["p99_us"] <= w["max_us"] for w in r["syncbn_wait_us"]), r["syncbn_wait_us"]
+    assert "topology_lines" in r          # RCCL's own INIT / GRAPH lines at N > 1 over RCCL (None in the gloo one-GPU mode)
 
 
 @pytest.mark.gpu

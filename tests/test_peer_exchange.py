@@ -89,6 +89,7 @@ def _worker(rank, world, port, q, transport, mode):
             # kernel) against statistics kernel -> exchange kernel -> apply kernel, on the three register-cached map sizes
             # of the head, with one rank lagging; and a late rank in front of every second layer
             import apex.parallel as AP
+            AP.FORCE_FUSED_ON_SHARED_DEVICE = True        # two ranks on ONE GPU here: small layers, both grids fit side by side
             comm.set_timeout_ms(5000)
             peer._COMMS[id(dist.group.WORLD)] = (dist.group.WORLD, comm)       # the comm under test is the group's comm
             outs = {}
@@ -197,7 +198,7 @@ def test_missing_peer_times_out_instead_of_hanging_the_gpu():
     res = _run(2, "host", "timeout")
     assert res[0]["poisoned"] is True
     seq, peer_rank = res[0]["status"]
-    assert seq == 8 and peer_rank == 1          # seven self-test exchanges at creation (four plain, three fused SyncBN layers), then the one rank 1 never joined
+    assert seq == 6 and peer_rank == 1          # five self-test exchanges at creation (four plain, one fused SyncBN layer: the ranks share a GPU), then the one rank 1 never joined
 
 
 @pytest.mark.parametrize("transport", ["host", "device"])
