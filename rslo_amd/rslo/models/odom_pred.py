@@ -135,6 +135,10 @@ class UNOdomPredEncDecSVDTempMaskBase(OdomPredEncDecBase):
         ups = []
         side_work = self.__dict__.pop("_side_work", None)      # (mark, launch) of work for a second stream, see
         for i, (blk, skip) in enumerate(zip(self.blocks, self.skip_blocks)):   # voxel_odom_net.network_forward
+            if i == 1 and x[0].is_cuda:      # where the small-map stages begin on this stream (a gate other streams may wait on)
+                g_ = torch.cuda.Event()
+                g_.record(torch.cuda.current_stream(x[0].device))
+                self.__dict__["_small_maps_gate_event"] = g_
             if i == 1 and side_work is not None:
                 side_work[0]()      # the half- / quarter-resolution stages start here: launches of ~1 workgroup per CU
             x = blk(x)

@@ -373,6 +373,10 @@ class UnVoxelOdomNetICP3(nn.Module):
             preds_dict = self.network_forward(voxels, num_points, coors, batch_size_dev, example=example)
 
         if self.training:
+            if voxels[0].is_cuda:       # where the loss begins on this stream: the structure plan of a coming batch may be
+                g = torch.cuda.Event()  # gated here (rslo_amd/workload.py RSLO_PLAN_GATE=loss)
+                g.record(torch.cuda.current_stream(voxels[0].device))
+                self.__dict__["_loss_gate_event"] = g
             ret = self.loss(example, preds_dict)
             if throttle:
                 ev = torch.cuda.Event(blocking=True)

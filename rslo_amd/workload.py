@@ -110,6 +110,10 @@ class ExamplePrefetcher:
         self._keep = {}             # seq -> example, until the training stream is done with it
         self._next_submit = self._next_get = 0
         self._done_ring = []
+        # where on the training stream's timeline a plan job may START (it then runs at low priority beside whatever follows):
+        # "none" = at once (round 3), "loss" (default, round 5: 11.50-11.60 vs 11.77-11.79 ms per step) = where the current
+        # step's loss begins, "head" = where the head's small-map stages begin, "fwd_end" = behind the current step's loss
+        self._gate = os.environ.get("RSLO_PLAN_GATE", "loss")
         self.lead_wait_seconds = self.plan_wait_seconds = 0.0
         self.cpu_seconds, self.jobs = 0.0, 0
         # Several Python threads issue GPU work here.  With the interpreter's default 5 ms switch interval a helper can
@@ -183,7 +187,16 @@ class ExamplePrefetcher:
             # (Waiting on the event of THIS submit holds every job back until the current forward has drained on the GPU.)
             self._done_ring.append(done)
             lag = self.planner.n_arenas - 1 - self.depth
-            done = self._done_ring[-1 - lag] if len(self._done_ring) > lag else None
+            gate = self._gate
+            if gate == "fwd_end":         # start when the forward + loss of the step that just issued them have drained
+                pass                      # `done` IS that event
+            elif gate == "loss" and self.net.__dict__.get("_loss_gate_event") is not None:
+                done = self.net.__dict__["_loss_gate_event"]          # start where this step's loss begins on the GPU
+            elif gate == "head" and getattr(self.net, "odom_predictor", None) is not None and \
+                    self.net.odom_predictor.__dict__.get("_small_maps_gate_event") is not None:
+                done = self.net.odom_predictor.__dict__["_small_maps_gate_event"]      # the head's small-map stages (forward)
+            else:
+                done = self._done_ring[-1 - lag] if len(self._done_ring) > lag else None
             del self._done_ring[:-(lag + 1)]
         self._in.put((self._next_submit, clouds, done))
         self._next_submit += 1
