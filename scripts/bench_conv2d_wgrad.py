@@ -5,6 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import rslo_amd  # noqa: F401
 from rslo_amd import capi
+import _tuning; _tuning.apply_from_env()
 
 LAYERS = [  # (count per step, cin, cout, H, W, stride)
     (5, 128, 128, 48, 88, 1), (1, 192, 64, 96, 176, 1), (3, 64, 64, 96, 176, 1), (9, 128, 128, 24, 44, 1),
