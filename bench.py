@@ -163,6 +163,7 @@ class ConvProbe:
         self.records = []
         self.enabled = False
         self.keep_tables = False
+        self.orders = {}          # table -> tile order of the launch (k_spconv_v6 walks 32-row tiles of the ORDERED rows)
         self._orig = {}
 
     @staticmethod
@@ -209,6 +210,8 @@ class ConvProbe:
                     probe.kernel_name(cin, cout, nbr.shape[0], False))
 
         def split_meta(x, Ws, bias, nbr, cin, cout, flip_k=False, act_slope=1.0, order=None):
+            if probe.keep_tables and order is not None:
+                probe.orders[(nbr.data_ptr(), tuple(nbr.shape))] = order
             return ("fwd", cin, cout, nbr.shape[1], nbr.shape[0], nbr if probe.keep_tables else None,
                     probe.kernel_name(cin, cout, nbr.shape[0], False, split=True))
 
@@ -270,6 +273,23 @@ class ConvProbe:
             if k not in counted:
                 counted[k] = int((t >= 0).sum().item())
             return counted[k]
+        issued_cache = {}
+
+        def issued_pairs(t, rows_per_tile=32):
+            """Row-offset products the tiled kernel ISSUES for this table: every offset that is active for any row of a
+            32-row tile is computed for all 32 rows (padding = the part of the offset union a row does not have)."""
+            k = (t.data_ptr(), tuple(t.shape))
+            if k not in issued_cache:
+                a = t >= 0
+                o = self.orders.get(k)
+                if o is not None:
+                    a = a[o.long()]
+                n, K = a.shape
+                pad = (-n) % rows_per_tile
+                if pad:
+                    a = torch.cat([a, torch.zeros((pad, K), dtype=torch.bool, device=a.device)], 0)
+                issued_cache[k] = int(a.view(-1, rows_per_tile, K).any(dim=1).sum().item()) * rows_per_tile
+            return issued_cache[k]
         groups = {}
         for i, (m, e0, e1) in enumerate(self.records):
             if m[0] == "dense":
@@ -280,8 +300,11 @@ class ConvProbe:
                 sz = 2 if kind == "bf16" else 4          # bytes per feature / weight element
                 byts = P * cin * sz + n_out * cout * sz + 8 * P + K * cin * cout * sz
                 flops = 2 * P * cin * cout
-            g = groups.setdefault(name, {"launches": 0, "ms": 0.0, "bytes": 0, "flops": 0,
+            g = groups.setdefault(name, {"launches": 0, "ms": 0.0, "bytes": 0, "flops": 0, "pairs": 0, "issued_pairs": 0,
                                          "big": {"launches": 0, "ms": 0.0, "flops": 0}})
+            if m[0] != "dense" and "k_spconv_v6" in name:
+                g["pairs"] += P
+                g["issued_pairs"] += issued_pairs(table)
             dt = e0.elapsed_time(e1)
             g["launches"] += 1
             g["ms"] += dt
@@ -339,6 +362,9 @@ class ConvProbe:
             else:
                 r = {"bound": "hbm", "kernel": name, "achieved": round(g["GBps"], 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(g["GBps"] / HBM_PEAK_GBS, 4), "traffic": None}
+            if g.get("issued_pairs"):
+                # useful / issued MFMA work of the tiled gather: a tile computes its offset UNION for all of its 32 rows
+                r["mfma_useful_frac"] = round(g["pairs"] / g["issued_pairs"], 4)
             if lowp:
                 r["matrix_core_path"] = "bf16 operands (round to nearest), fp32 accumulation: 1 x v_mfma_f32_16x16x32_bf16"
             elif "k_spconv_v6" in name or "k_conv2d" in name:
@@ -385,9 +411,9 @@ class ConvProbe:
         merged = {}
         for gname, g in groups.items():
             k = gname.split(" [")[0]
-            m = merged.setdefault(k, {"launches": 0, "ms": 0.0, "bytes": 0, "flops": 0, "big": None})
-            for f in ("launches", "ms", "bytes", "flops"):
-                m[f] += g[f]
+            m = merged.setdefault(k, {"launches": 0, "ms": 0.0, "bytes": 0, "flops": 0, "pairs": 0, "issued_pairs": 0, "big": None})
+            for f in ("launches", "ms", "bytes", "flops", "pairs", "issued_pairs"):
+                m[f] += g.get(f, 0)
             if gname == k:
                 m["big"] = g.get("big")
         for k, m in merged.items():
