@@ -282,8 +282,8 @@ class ConvProbe:
             if k not in issued_cache:
                 a = t >= 0
                 o = self.orders.get(k)
-                if o is not None:
-                    a = a[o.long()]
+                if o is not None and o.numel() == a.shape[0]:
+                    a = a[o.long().clamp_(0, a.shape[0] - 1)]      # (a recycled arena could hold anything: never fault)
                 n, K = a.shape
                 pad = (-n) % rows_per_tile
                 if pad:
@@ -1134,6 +1134,13 @@ def main():
             "%s %.2f/%.2f" % (k, 1e3 * v[0] / args.steps, 1e3 * v[1] / args.steps) for k, v in ph.items()), file=sys.stderr)
     loss_val = float(ret["loss"].detach().mean().item())
     per_step = np.array([marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)])
+    # the launch probe's tables are views of the structure plan's arenas, which later steps recycle: count pairs NOW, before
+    # the extra measurement steps below run
+    probe_groups = probe_roof = None
+    if rank == 0 and use_probe and probe.records:
+        probe_groups, probe_roof = probe.summarize(probe_steps)
+        probe.uninstall()
+        probe.records = []
     # Where the training stream's time goes, from HIP events alone (rslo_amd/streamprobe.py): extra steps AFTER the timed
     # region, every launching library call and every explicit stream join bracketed by events on its stream
     stream_split = None
@@ -1197,14 +1204,11 @@ def main():
         stream_split["plain_step_phase_ms"] = {k: {"host_issue": round(float(np.median(dh[k])), 3),
                                                    "gpu": round(float(np.median(dg[k])), 3)} for k in dh}
     if rank == 0:
-        roof = None
-        if use_probe and probe.records:
-            groups, roof = probe.summarize(probe_steps)
-            if args.kernel_report:
-                with open(args.kernel_report, "w") as f:
-                    json.dump({k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()}
-                               for k, v in groups.items()}, f, indent=1)
-            probe.uninstall()
+        roof = probe_roof
+        if probe_groups is not None and args.kernel_report:
+            with open(args.kernel_report, "w") as f:
+                json.dump({k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()}
+                           for k, v in probe_groups.items()}, f, indent=1)
         n_points = int(np.mean([c.shape[0] for cs in cloud_sets for pair in cs for c in pair]))
         line = {
             "metric": "frame-pairs/sec fwd+bwd (synthetic KITTI-shaped ~%dk-pt scans)" % (n_points // 1000),
