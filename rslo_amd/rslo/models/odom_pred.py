@@ -5,6 +5,7 @@ xs = [bev_0, bev_1(, bev_2)] each [B,128,96,176] -> all (i<j) pairs -> encoder-d
 local (t, q) map -> local->global transform -> confidence-weighted mean = the pair's pose.
 """
 import contextlib
+import weakref
 
 import apex
 import apex.amp as amp
@@ -17,6 +18,8 @@ import numpy as np
 from rslo.data.dataset import _grid_geometry, from_pointwise_local_transformation_tch
 from rslo.layers.confidence import ConfidenceModule, masked_spatial_softmax
 from rslo.layers import hip_conv2d
+
+SMALL_MAPS_GATE = weakref.WeakKeyDictionary()      # head -> event where its latest forward reached the half-resolution stages
 from rslo.layers.hip_conv2d import Conv2d
 from rslo.layers.MaskConv import MaskConv
 from rslo.models.odom_pred_base import OdomPredEncDecBase, conf_trunk
@@ -138,7 +141,7 @@ class UNOdomPredEncDecSVDTempMaskBase(OdomPredEncDecBase):
             if i == 1 and x[0].is_cuda:      # where the small-map stages begin on this stream (a gate other streams may wait on)
                 g_ = torch.cuda.Event()
                 g_.record(torch.cuda.current_stream(x[0].device))
-                self.__dict__["_small_maps_gate_event"] = g_
+                SMALL_MAPS_GATE[self] = g_       # outside the module: events neither deep-copy nor pickle
             if i == 1 and side_work is not None:
                 side_work[0]()      # the half- / quarter-resolution stages start here: launches of ~1 workgroup per CU
             x = blk(x)

@@ -33,6 +33,7 @@ from rslo.models import middle, odom_pred, voxel_encoder
 
 _SIDE_STREAMS = {}
 _HOST_LEAD = int(os.environ.get("RSLO_HOST_LEAD", "1"))
+GATE_EVENTS = weakref.WeakKeyDictionary()      # network -> event where its latest training forward reached the loss
 _LEAD_EVENTS = weakref.WeakKeyDictionary()   # network -> events recorded behind its recent training forwards
 _LEAD_WAIT = [0.0, 0.0]  # wall seconds the issuing thread was held back, CPU seconds it spent in that wait (bench.py)
 
@@ -376,7 +377,7 @@ class UnVoxelOdomNetICP3(nn.Module):
             if voxels[0].is_cuda:       # where the loss begins on this stream: the structure plan of a coming batch may be
                 g = torch.cuda.Event()  # gated here (rslo_amd/workload.py RSLO_PLAN_GATE=loss)
                 g.record(torch.cuda.current_stream(voxels[0].device))
-                self.__dict__["_loss_gate_event"] = g
+                GATE_EVENTS[self] = g        # outside the module: events neither deep-copy nor pickle
             ret = self.loss(example, preds_dict)
             if throttle:
                 ev = torch.cuda.Event(blocking=True)

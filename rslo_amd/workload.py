@@ -176,6 +176,16 @@ class ExamplePrefetcher:
                 self.jobs += 1
                 self._cv.notify_all()
 
+    def _gate_event(self, which):
+        try:
+            if which == "loss":
+                from rslo.models.voxel_odom_net import GATE_EVENTS
+                return GATE_EVENTS.get(self.net)
+            from rslo.models.odom_pred import SMALL_MAPS_GATE
+            return SMALL_MAPS_GATE.get(getattr(self.net, "odom_predictor", None))
+        except (ImportError, TypeError):
+            return None
+
     def submit(self, clouds):
         done = torch.cuda.Event()
         done.record(torch.cuda.current_stream(self.device))
@@ -190,11 +200,10 @@ class ExamplePrefetcher:
             gate = self._gate
             if gate == "fwd_end":         # start when the forward + loss of the step that just issued them have drained
                 pass                      # `done` IS that event
-            elif gate == "loss" and self.net.__dict__.get("_loss_gate_event") is not None:
-                done = self.net.__dict__["_loss_gate_event"]          # start where this step's loss begins on the GPU
-            elif gate == "head" and getattr(self.net, "odom_predictor", None) is not None and \
-                    self.net.odom_predictor.__dict__.get("_small_maps_gate_event") is not None:
-                done = self.net.odom_predictor.__dict__["_small_maps_gate_event"]      # the head's small-map stages (forward)
+            elif gate == "loss" and self._gate_event("loss") is not None:
+                done = self._gate_event("loss")          # start where this step's loss begins on the GPU
+            elif gate == "head" and self._gate_event("head") is not None:
+                done = self._gate_event("head")          # the head's small-map stages (forward)
             else:
                 done = self._done_ring[-1 - lag] if len(self._done_ring) > lag else None
             del self._done_ring[:-(lag + 1)]
