@@ -597,6 +597,20 @@ def run_encoder(args, world, rank, local_rank, dist_on, dev):
                 prefetch = None
         except Exception:
             prefetch = None
+    # C2 is an INFERENCE pass (evaluate.py:363-408): eval-mode encoder, one scan per step, replayed from one hipGraph per plan
+    # arena (rslo_amd/inference.py) with the structure work of the coming scans on the runner's side stream.
+    # RSLO_C2_GRAPH=0 / --no-prefetch: the eager pass of round 4.
+    runner = None
+    if cfg == "c2" and not args.no_prefetch and os.environ.get("RSLO_C2_GRAPH", "1") != "0":
+        from rslo_amd import inference
+        enc.eval()
+
+        class _EvalEncoder:
+            middle_feature_extractor, voxel_generator, training = enc, gen, False
+        runner = inference.EncoderGraphRunner(_EvalEncoder(), max_vox, dev)
+        if prefetch is not None:
+            prefetch.close()
+            prefetch = None
     T_frames = 1 if cfg == "c2" else 2
     dev_clouds = [torch.from_numpy(c).to(dev) for c in clouds]
     per_sample = [[dev_clouds[b * T_frames + t] for t in range(T_frames)] for b in range(frames // T_frames)]
@@ -604,7 +618,17 @@ def run_encoder(args, world, rank, local_rank, dist_on, dev):
         for _ in range(prefetch.depth):
             prefetch.submit(per_sample)
 
+    jobs = []
+    if runner is not None:
+        for _ in range(int(os.environ.get("RSLO_C2_DEPTH", "3"))):
+            jobs.append(runner.submit(dev_clouds[0]))
+    eager_pass = [False]
+
     def step():
+        if runner is not None:
+            job = jobs.pop(0)
+            jobs.append(runner.submit(dev_clouds[0]))
+            return runner.run(job, graph=not eager_pass[0])[0]
         if prefetch is not None:
             ex = prefetch.get()
             prefetch.submit(per_sample)
@@ -638,11 +662,30 @@ def run_encoder(args, world, rank, local_rank, dist_on, dev):
     probe_steps = min(3, args.steps)
     t0 = time.perf_counter()
     for i in range(args.steps):
-        if use_probe and i == args.steps - probe_steps:
+        if use_probe and runner is None and i == args.steps - probe_steps:
             probe.enabled = probe.keep_tables = True
         step()
     barrier()
     elapsed = time.perf_counter() - t0
+    graph_extras = {}
+    if runner is not None:
+        # the same scans through the same modules issued EAGERLY (what the graph replays): the launch probe's per-kernel numbers
+        # come from these passes, and their time is what the graph is compared with
+        eager_pass[0] = True
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        n_eager = max(10, min(50, args.steps))
+        for i in range(n_eager):
+            if use_probe and i == n_eager - probe_steps:
+                probe.enabled = probe.keep_tables = True
+            step()
+        torch.cuda.synchronize()
+        graph_extras = {"ms_per_pass_same_pipeline_eager": round(1e3 * (time.perf_counter() - t1) / n_eager, 4),
+                        "inference_path": "eval-mode encoder, one hipGraph per plan arena (%d captured), capacity-laid-out plan "
+                                          "with padding rows, structure work of the coming scans on a side stream" % len(runner._graphs)}
+        eager_pass[0] = False
     probe.enabled = False
     per_rank = [elapsed]
     if dist_on:
@@ -716,8 +759,10 @@ def run_encoder(args, world, rank, local_rank, dist_on, dev):
                 "workload": ("C2: forward-only GU encoder + covariance branch, 1 x 64-ring scan (%d points -> %d voxels), bs 1, "
                              "fp32; a step = %s + 20 sparse convs + dense() (= half a frame pair)" % (
                                  clouds[0].shape[0], feats.shape[0],
-                                 "voxelization + rulebook chain of the next frame on a side stream (rslo_plan_encoder) + VFE"
-                                 if prefetch is not None else "rulebook chain on a resident voxelized frame")) if cfg == "c2" else
+                                 "voxelization + rulebook chain of the coming scans on a side stream (rslo_plan_encoder) + VFE, the pass "
+                                 "replayed from one hipGraph per plan arena (eval mode: rslo_amd/inference.py)" if runner is not None else
+                                 ("voxelization + rulebook chain of the next frame on a side stream (rslo_plan_encoder) + VFE"
+                                  if prefetch is not None else "rulebook chain on a resident voxelized frame"))) if cfg == "c2" else
                             ("C5: GU encoder + covariance branch fwd+bwd, %d x 128-ring scans (%d points/frame, %d voxels in all), "
                              "0.1 m voxels, sparse shape %s, bs %d frame pairs/GPU, fp32, dp%d; the 256-channel BEV map does "
                              "not fit the head (SURVEY 8d): encoder only; %s" % (
@@ -725,12 +770,12 @@ def run_encoder(args, world, rank, local_rank, dist_on, dev):
                                  "voxelization + rulebooks of the next step on a side stream (rslo_plan_encoder)"
                                  if prefetch is not None else "resident voxelized inputs, rulebooks built inline")),
                 "frames_per_step_per_gpu": frames, "voxels": int(feats.shape[0]), "sparse_convs": len(convs),
-                "voxelize_and_plan_on_side_stream": prefetch is not None,
+                "voxelize_and_plan_on_side_stream": prefetch is not None or runner is not None,
                 "lib_sha256": lib_hash(),
                 "algorithmic_GB_per_step": round(mult * byts / 1e9, 3), "algorithmic_GFLOP_per_step": round(mult * fl / 1e9, 2),
                 "whole_pass_algorithmic_GBps": round(mult * byts / ms / 1e6, 1),
                 "whole_pass_hbm_roofline_frac": round(mult * byts / ms / 1e6 / HBM_PEAK_GBS, 4),
-                "ideal_ms_at_8TBps": round(mult * byts / 8e9, 4)}, **extras),
+                "ideal_ms_at_8TBps": round(mult * byts / 8e9, 4)}, **extras, **graph_extras),
             "roofline": roof, "cpu_baseline": None}
         if dist_on:
             try:

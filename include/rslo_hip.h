@@ -339,6 +339,14 @@ RSLO_API int rslo_plan_encoder(const RsloEncoderSpec *h_spec, const RsloPlanLayo
                                const int64_t *h_n_points, void *arena, size_t arena_bytes,
                                int32_t *h_counts /*pinned, [RSLO_PLAN_CNT_WORDS] or NULL*/, void *stream);
 
+/*     rslo_plan_encoder_pad_tails (round 5): behind rslo_plan_encoder on the same stream, turns the rows of every table past
+ *     its level's device-side count -- up to the level's CAPACITY -- into padding rows: coordinates -1 (rslo_dense_scatter
+ *     skips them), neighbour entries -1 (a padding output row gathers nothing), tile orders continued as the identity.  The
+ *     encoder's kernels can then be launched for capacity-sized tensors whose shapes do not depend on the scan: what an
+ *     inference loop needs to replay ONE hipGraph per arena (evaluate.py:363-408 runs the same forward frame after frame). */
+RSLO_API int rslo_plan_encoder_pad_tails(const RsloEncoderSpec *h_spec, const RsloPlanLayout *h_layout, void *arena,
+                                         void *stream);
+
 /* wgrad over pair lists: dW[k] = sum_{p in [koff[k],koff[k+1])} in[pairs_in[p]]^T dout[pairs_out[p]];
  * dbias = column sums of dout (all n_out rows).  Deterministic (fixed-order two-stage reduction). */
 RSLO_API size_t rslo_spconv_wgrad_pairs_ws_bytes(int64_t n_out, int K, int cin, int cout);

@@ -152,6 +152,7 @@ SIGNATURES = {
     "rslo_pyramid_l2_fwd": (C.c_int, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp]),
     "rslo_pyramid_l2_bwd": (C.c_int, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "rslo_plan_encoder_layout": (C.c_int, [_vp, _i, _vp, _vp]),
+    "rslo_plan_encoder_pad_tails": (C.c_int, [_vp, _vp, _vp, _vp]),
     "rslo_plan_encoder": (C.c_int, [_vp, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp, _vp]),
     "rslo_tq_normalize_fwd": (C.c_int, [_vp, _i, _i64, _vp, _vp]),
     "rslo_tq_normalize_bwd": (C.c_int, [_vp, _vp, _i, _i64, _vp, _vp]),
@@ -386,6 +387,11 @@ def plan_encoder(spec, lay, clouds, clouds_per_frame, arena, h_counts):
     cnts = (C.c_int64 * n)(*[int(c.shape[0]) for c in clouds])
     _chk(lib().rslo_plan_encoder(C.byref(spec), C.byref(lay), n, int(clouds_per_frame), ptrs, cnts, _ptr(arena),
                                  arena.numel(), C.c_void_p(h_counts.data_ptr()), _stream()), "rslo_plan_encoder")
+
+
+def plan_encoder_pad_tails(spec, lay, arena):
+    """Behind plan_encoder on the current stream: rows past every level's count become padding rows (capacity-sized plan)."""
+    _chk(lib().rslo_plan_encoder_pad_tails(C.byref(spec), C.byref(lay), _ptr(arena), _stream()), "rslo_plan_encoder_pad_tails")
 
 
 def rulebook_subm(index, ks):

@@ -740,6 +740,7 @@ __global__ void k_dense(float *__restrict__ feat, const int32_t *__restrict__ co
   const int64_t r = t % M;
   const int ch = (int)(t / M);
   int4 c = reinterpret_cast<const int4 *>(coords)[r];
+  if (c.x < 0) return;      // padding row of a capacity-sized plan (rslo_plan_encoder_pad_tails): no site
   if (frames > 1) c.x = (c.x % B) * frames + c.x / B;
   const int64_t vol = (int64_t)s.d * s.h * s.w;
   const int64_t off = ((int64_t)c.x * C + ch) * vol + ((int64_t)c.y * s.h + c.z) * s.w + c.w;
@@ -1598,5 +1599,60 @@ extern "C" int rslo_plan_encoder(const RsloEncoderSpec *spec, const RsloPlanLayo
   if (int rc = pairs_run_batch(pbatch, n_ptab, st)) return rc;      // the pair lists of all rulebooks: three launches
   if (h_counts)
     RSLO_HIP(hipMemcpyAsync(h_counts, cnt, RSLO_PLAN_CNT_WORDS * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  return RSLO_OK;
+}
+
+
+// ---- static (capacity-sized) view of a plan: rslo_plan_encoder_pad_tails ----------------------------------------------
+// An inference loop replays ONE hipGraph per arena: every kernel of the encoder is launched for the CAPACITY of its level
+// and the tables' rows past the level's device-side count must then be harmless.  This pass (same stream, behind
+// rslo_plan_encoder) turns them into padding rows: coordinates -1 (rslo_dense_scatter skips them), every neighbour entry -1
+// (a padding output row gathers nothing: its value is the bias, which nobody reads), tile orders continued as the identity.
+// (Tried: orders that mark the padding rows as absent, -1, for EVERY table so that a padding tile neither gathers nor stores --
+// 0.62 vs 0.60 ms per replayed pass: the order indirection costs what the skipped stores save.)
+struct PadEntry {
+  int32_t *base;
+  const int32_t *d_n;
+  int32_t cap, width, identity;
+};
+struct PadTable {
+  PadEntry e[6 * RSLO_PLAN_MAX_LEVELS + 1];
+};
+
+__global__ void kp_pad_tails(PadTable T) {
+  const PadEntry e = T.e[blockIdx.y];
+  const int64_t n0 = (int64_t)(*e.d_n < e.cap ? *e.d_n : e.cap) * e.width, n1 = (int64_t)e.cap * e.width;
+  for (int64_t i = n0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n1; i += (int64_t)gridDim.x * blockDim.x)
+    e.base[i] = e.identity ? (int32_t)i : -1;
+}
+
+extern "C" int rslo_plan_encoder_pad_tails(const RsloEncoderSpec *spec, const RsloPlanLayout *lay, void *arena, void *stream) {
+  RSLO_CHECK_ARG(spec && lay && arena, "plan_encoder_pad_tails: null argument");
+  char *A = (char *)arena;
+  const int L = spec->n_levels;
+  const int32_t *cnt = (const int32_t *)(A + lay->counts_off);
+  PadTable T;
+  int n = 0;
+  int64_t widest = 1;
+  auto add = [&](uint64_t off, int level_rows, int width, int identity) {
+    T.e[n++] = PadEntry{(int32_t *)(A + off), cnt + RSLO_PLAN_CNT_ROWS + level_rows, (int32_t)lay->cap_rows[level_rows], width, identity};
+    if ((int64_t)lay->cap_rows[level_rows] * width > widest) widest = (int64_t)lay->cap_rows[level_rows] * width;
+  };
+  for (int l = 0; l < L; ++l) {
+    add(lay->coords_off[l], l, 4, 0);
+    const int Ks = spec->subm_ks[l][0] * spec->subm_ks[l][1] * spec->subm_ks[l][2];
+    if (Ks > 0) add(lay->subm_nbr_off[l], l, Ks, 0);
+    if (l + 1 < L) {
+      const int K = spec->conv_ks[l][0] * spec->conv_ks[l][1] * spec->conv_ks[l][2];
+      add(lay->conv_nbr_off[l], l + 1, K, 0);
+      add(lay->conv_nbrT_off[l], l, K, 0);
+      if (spec->want_orders) add(lay->conv_order_off[l], l, 1, 1);
+    }
+  }
+  add(lay->coords_frame_off, 0, 4, 0);
+  int64_t bx = rslo_cdiv(widest, 256 * 8);
+  if (bx > 1024) bx = 1024;
+  hipLaunchKernelGGL(kp_pad_tails, dim3((unsigned)bx, (unsigned)n), dim3(256), 0, (hipStream_t)stream, T);
+  RSLO_CHECK_LAUNCH("kp_pad_tails");
   return RSLO_OK;
 }

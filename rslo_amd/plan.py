@@ -81,7 +81,7 @@ def encoder_levels(middle):
 
 
 class _Job:
-    __slots__ = ("arena", "counts", "lay", "ready", "B", "T", "n_clouds", "with_pairs", "clouds")
+    __slots__ = ("arena", "counts", "lay", "ready", "B", "T", "n_clouds", "with_pairs", "clouds", "slot")
 
 
 class EncoderPlanner:
@@ -99,6 +99,8 @@ class EncoderPlanner:
         self._arenas = []         # [(uint8 CUDA tensor, pinned int32 counts)], handed out round-robin
         self._next = 0
         self._lock = threading.Lock()
+        self.static_level_fractions = [1.0, 0.75, 0.5, 0.25, 0.15, 0.15, 0.15, 0.15]      # capacities of a static plan's levels
+        self._static = {}         # (features, pairs, point capacity, clouds) -> (spec, layout) of the capacity-laid-out arena
         self.fallbacks = 0
 
     def _spec(self, n_features, with_pairs):
@@ -142,9 +144,13 @@ class EncoderPlanner:
                 ent[0] = torch.empty((nbytes,), dtype=torch.uint8, device=device)
             return ent
 
-    def submit(self, clouds_per_sample, with_pairs=None, slot=None):
+    def submit(self, clouds_per_sample, with_pairs=None, slot=None, point_capacity=None):
         """clouds_per_sample: list (batch) of lists (frames) of CUDA fp32 [P,F] tensors.  Enqueues everything on the
-        current stream and records the `ready` event; no host read."""
+        current stream and records the `ready` event; no host read.
+        point_capacity = P: the arena is laid out for clouds of P points whatever their actual sizes (<= P) and the rows
+        past every level's count are turned into padding rows (rslo_plan_encoder_pad_tails): the layout -- every pointer a
+        kernel of the encoder receives -- is then the same for every scan, which is what finish_static() / a replayed
+        hipGraph need (rslo_amd/inference.py)."""
         B, T = len(clouds_per_sample), len(clouds_per_sample[0])
         flat = [clouds_per_sample[b][t] for t in range(T) for b in range(B)]
         for p in flat:
@@ -152,18 +158,85 @@ class EncoderPlanner:
                 raise capi.RsloHipError("EncoderPlanner.submit: clouds must be contiguous fp32 CUDA tensors")
         if with_pairs is None:
             with_pairs = self.net.training
-        spec = self._spec(flat[0].shape[1], with_pairs)
-        lay = capi.plan_encoder_layout(spec, [p.shape[0] for p in flat])
+        if point_capacity is not None:
+            if any(p.shape[0] > point_capacity for p in flat):
+                raise capi.RsloHipError("EncoderPlanner.submit: a cloud exceeds point_capacity = %d" % point_capacity)
+            key = (flat[0].shape[1], bool(with_pairs), int(point_capacity), len(flat))
+            ent = self._static.get(key)
+            if ent is None:
+                sp = self._spec(flat[0].shape[1], with_pairs)
+                # every kernel of a replayed pass runs for its level's CAPACITY: the deeper levels get capacities that follow how
+                # LiDAR surfaces thin out under stride 2 (measured on the synthetic scans: 0.57 / 0.36 / 0.14 / 0.08 of level 0)
+                # with a wide margin, instead of level 0's capacity everywhere; an overflow is flagged in the counts block and
+                # the caller falls back to the exact-size plan (rslo_amd/inference.py)
+                c0 = min(len(flat) * self.max_voxels, len(flat) * int(point_capacity))
+                for l, frac in enumerate(self.static_level_fractions[:len(self.levels)]):
+                    if l > 0:
+                        sp.cap_rows[l] = max(256, int(c0 * frac))
+                ent = self._static[key] = (sp, capi.plan_encoder_layout(sp, [int(point_capacity)] * len(flat)))
+            spec, lay = ent
+        else:
+            spec = self._spec(flat[0].shape[1], with_pairs)
+            lay = capi.plan_encoder_layout(spec, [p.shape[0] for p in flat])
         arena, counts = self._arena(int(lay.total_bytes), flat[0].device, slot)
         capi.plan_encoder(spec, lay, flat, B, arena, counts)
+        if point_capacity is not None:
+            capi.plan_encoder_pad_tails(spec, lay, arena)
         job = _Job()
         job.arena, job.counts, job.lay, job.B, job.T, job.n_clouds = arena, counts, lay, B, T, len(flat)
         job.with_pairs, job.clouds = bool(with_pairs), clouds_per_sample
+        job.slot = slot
         job.ready = torch.cuda.Event()
         job.ready.record(torch.cuda.current_stream(flat[0].device))
         return job
 
     # ------------------------------------------------------------------------------------------------------------
+    def finish_static(self, job):
+        """The CAPACITY-sized view of a job submitted with point_capacity: (voxels [cap0, T, F], num_points [cap0], plan,
+        rows_dev) without any host read -- every tensor spans its level's capacity, rows past the level's count are
+        padding rows, rows_dev[l] is the device word holding the count of level l.  The views depend on the arena only
+        (the layout is the same for every scan), so a hipGraph captured over them replays for any later job in that arena."""
+        import spconv
+        lay, A, n = job.lay, job.arena, job.n_clouds
+        L = len(self.levels)
+        rows = [int(lay.cap_rows[l]) for l in range(L)]
+        Tp, F = self.vg._max_num_points, job.clouds[0][0].shape[1]
+
+        def i32(off, count, shape=None):
+            t = A[int(off):int(off) + 4 * int(count)].view(torch.int32)
+            return t if shape is None else t.view(shape)
+
+        voxels = A[int(lay.voxels_off):int(lay.voxels_off) + 4 * rows[0] * Tp * F].view(torch.float32).view(rows[0], Tp, F)
+        num = i32(lay.num_points_off, rows[0])
+        rows_dev = [i32(lay.counts_off + 4 * (capi.PLAN_CNT_ROWS + l), 1) for l in range(L)]
+        idx = []
+        for l in range(L):
+            coords = i32(lay.coords_off[l], rows[l] * 4, (rows[l], 4))
+            hc = int(lay.hash_cap[l])
+            si = capi.SiteIndex.from_parts(coords, n, list(lay.dims[l]), i32(lay.keys_off[l], hc), i32(lay.vals_off[l], hc), hc)
+            si.subm_cache = {}
+            si.batch_offs = None
+            si.batch_offs_dev = i32(lay.counts_off + 4 * (capi.PLAN_CNT_BOFF + l * (capi.PLAN_MAX_CLOUDS + 1)), n + 1)
+            idx.append(si)
+        x = spconv.SparseConvTensor(None, idx[0].coords, self.middle.sparse_shape, n, index=idx[0])
+        rbs_conv = {}
+        for l, lv in enumerate(self.levels):
+            if lv["subm"] is not None:
+                ks = lv["subm"]
+                K = ks[0] * ks[1] * ks[2]
+                idx[l].subm_cache[tuple(ks)] = spconv.Rulebook("subm", i32(lay.subm_nbr_off[l], rows[l] * K, (rows[l], K)),
+                                                              None, None, None, ks, [1, 1, 1], None)
+            if lv["conv"] is not None:
+                ks, stv, pd = lv["conv"]
+                K = ks[0] * ks[1] * ks[2]
+                rb = spconv.Rulebook("conv", i32(lay.conv_nbr_off[l], rows[l + 1] * K, (rows[l + 1], K)),
+                                     i32(lay.conv_nbrT_off[l], rows[l] * K, (rows[l], K)), idx[l], idx[l + 1], ks, stv, pd)
+                rb._orders["nbrT"] = i32(lay.conv_order_off[l], rows[l]) if capi.ROW_ORDER else None
+                rbs_conv[l] = rb
+        for key, (kind, l) in self.keys.items():
+            x.indice_dict[key] = rbs_conv[l] if kind == "conv" else idx[l].subm_cache[tuple(self.levels[l]["subm"])]
+        return voxels, num, x, rows_dev
+
     def finish(self, job):
         """Wait for the job's event (host side: it was recorded a step ago), read the counts and wrap the arena:
         returns the example dict with "sparse_plan" attached.  A capacity overflow (a strided level with more sites

@@ -25,6 +25,7 @@ SWITCHES = {
     "RSLO_NATIVE_PLAN": ("1", "mode", "0: Python-issued voxelization + rulebook plan instead of rslo_plan_encoder"),
     "RSLO_PRESPLIT_EARLY": ("1", "mode", "0: head weight operands split in front of the head instead of beside the encoder"),
     "RSLO_PLAN_GATE": ("loss", "mode", "where a structure-plan job of a coming batch may start on the GPU: 'loss' where the current step's loss begins, 'head' at the head's small-map stages, 'fwd_end' behind the loss, 'none' at once"),
+    "RSLO_INFER_PLAN_STREAMS": ("1", "mode", "side streams the inference runner (rslo_amd/inference.py) issues the coming scans' structure plans on, round-robin"),
     "RSLO_PREFETCH_PRIORITY": ("", "mode", "HIP stream priority of the structure-plan stream (default: lowest)"),
     "RSLO_SWITCH_INTERVAL": ("0.0002", "mode", "interpreter switch interval while helper threads issue GPU work"),
     "RSLO_SPCONV_SPLIT": ("1", "path", "0: 32/64-channel sparse layers on the fp32-MFMA kernels instead of the split-bf16 ones"),

@@ -1151,3 +1151,43 @@ def test_head_with_registry_variants_steps_on_the_gpu_and_equals_the_cpu_run(hip
         assert cos > 0.999, (name, cos)
         n += 1
     assert n > 40
+
+
+def test_encoder_graph_runner_replays_any_scan_bit_equal_to_the_eager_pass(hip):
+    """rslo_amd.inference.EncoderGraphRunner (verdict r4 #7): the eval-mode GU encoder of one scan replayed from ONE hipGraph
+    per plan arena -- capacity-laid-out plan, rows past each level's device-side count as padding rows
+    (rslo_plan_encoder_pad_tails), no host read.  Five DIFFERENT scans through four arenas (so the fifth replays a graph
+    captured on another scan): BEV map and the covariance rows of the valid sites equal the eager pass (exact-size plan,
+    same modules) bit for bit; the valid-row count on the device equals the eager plan's."""
+    import spconv
+    from rslo.models import middle
+    from rslo_amd import inference, synthetic as S
+    from rslo_amd.plan import EncoderPlanner
+    gen = spconv.utils.VoxelGenerator(list(S.VOXEL_SIZE), list(S.PC_RANGE), S.MAX_POINTS_PER_VOXEL, S.MAX_VOXELS)
+    torch.manual_seed(7)
+    enc = middle.get_middle_class("SpMiddleFHDWithCov2_3")(
+        [1] + gen.grid_size[::-1].tolist() + [7], bn_type="None", use_leakyReLU=True, num_input_features=7,
+        num_filters_down1=[], num_filters_down2=[]).cuda().eval()
+    for m in enc.modules():                 # non-trivial running statistics in the covariance branch's BatchNorm1d layers
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+
+    class _Net:
+        middle_feature_extractor, voxel_generator, training = enc, gen, False
+    runner = inference.EncoderGraphRunner(_Net(), S.MAX_VOXELS)
+    eager = EncoderPlanner(_Net(), S.MAX_VOXELS)
+    clouds = [torch.from_numpy(S.scan(n_el=64 if i != 2 else 32, scan_seed=40 + i)).cuda() for i in range(5)]
+    for i, c in enumerate(clouds):
+        job = runner.submit(c)
+        bev, cov, n_dev = runner.run(job)
+        ex = eager.finish(eager.submit([[c]], with_pairs=False))
+        vox, num = ex["_frame_major"]
+        with torch.no_grad():
+            rb, rc = enc(hip.vfe_mean(vox, num), ex["sparse_plan"].indices, 1, plan=ex["sparse_plan"])
+        n = int(n_dev.item())
+        assert n == rc.shape[0] == vox.shape[0], (i, n, rc.shape)
+        assert torch.equal(bev, rb), i
+        assert torch.equal(cov[:n], rc), i
+    assert len(runner._graphs) == 4         # one capture per arena, the fifth scan replayed the first arena's graph
+    runner.close()
