@@ -496,6 +496,127 @@ __global__ __launch_bounds__(T) void k_bn2d_bwd_small_rc(const float *__restrict
   }
 }
 
+// Vectorised register-cached forms (round 5): HW % 4 == 0 (every map of the head), 16-byte loads and stores -- element group
+// q = tid + i T covers the channel's values 4q .. 4q+3 (one (n, c) row: a group never straddles rows).  A thread keeps E4 groups:
+// 5 x 16-byte loads in flight per tensor instead of 17 x 4-byte ones, and a quarter of the index arithmetic.
+template <int T, int E4>
+__global__ __launch_bounds__(T) void k_bn2d_fwd_small_rc4(const float *__restrict__ x, const float *__restrict__ res,
+                                                         const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                         int N, int C, int HW, float eps, float momentum, float slope,
+                                                         float *__restrict__ run_mean, float *__restrict__ run_var,
+                                                         float *__restrict__ save_mean, float *__restrict__ save_invstd,
+                                                         float *__restrict__ y) {
+  const int c = blockIdx.x, groups = (N * HW) >> 2;
+  float4 v[E4], r[E4];
+  int off[E4];
+#pragma unroll
+  for (int i = 0; i < E4; ++i) {
+    const int q = threadIdx.x + i * T;
+    const int e = q << 2;
+    const int n = e / HW, k = e - n * HW;
+    off[i] = q < groups ? (n * C + c) * HW + k : -1;
+    v[i] = off[i] >= 0 ? *reinterpret_cast<const float4 *>(x + off[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    r[i] = (res && off[i] >= 0) ? *reinterpret_cast<const float4 *>(res + off[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  double s = 0.0, q2 = 0.0;
+#pragma unroll
+  for (int i = 0; i < E4; ++i) {
+    s += ((double)v[i].x + v[i].y) + ((double)v[i].z + v[i].w);
+    q2 += ((double)v[i].x * v[i].x + (double)v[i].y * v[i].y) + ((double)v[i].z * v[i].z + (double)v[i].w * v[i].w);
+  }
+  __shared__ double tot[2];
+  bn_block_sum2_t<T>(s, q2, tot);
+  const double cnt = (double)N * HW;
+  const double m = tot[0] / cnt;
+  double var = tot[1] / cnt - m * m;
+  var = var > 0.0 ? var : 0.0;
+  const float mean = (float)m, invstd = (float)(1.0 / sqrt(var + (double)eps));
+  if (threadIdx.x == 0) {
+    save_mean[c] = mean;
+    save_invstd[c] = invstd;
+    if (run_mean) {
+      const double unbiased = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
+      run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mean;
+      run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)unbiased;
+    }
+  }
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  const float a1 = g * invstd, a0 = b - mean * a1;
+#pragma unroll
+  for (int i = 0; i < E4; ++i) {
+    if (off[i] < 0) continue;
+    float4 o;
+    o.x = v[i].x * a1 + a0 + r[i].x;
+    o.y = v[i].y * a1 + a0 + r[i].y;
+    o.z = v[i].z * a1 + a0 + r[i].z;
+    o.w = v[i].w * a1 + a0 + r[i].w;
+    o.x = o.x > 0.f ? o.x : o.x * slope;
+    o.y = o.y > 0.f ? o.y : o.y * slope;
+    o.z = o.z > 0.f ? o.z : o.z * slope;
+    o.w = o.w > 0.f ? o.w : o.w * slope;
+    *reinterpret_cast<float4 *>(y + off[i]) = o;
+  }
+}
+
+template <int T, int E4>
+__global__ __launch_bounds__(T) void k_bn2d_bwd_small_rc4(const float *__restrict__ dy, const float *__restrict__ y,
+                                                         const float *__restrict__ x, const float *__restrict__ gamma,
+                                                         const float *__restrict__ save_mean,
+                                                         const float *__restrict__ save_invstd, int N, int C, int HW,
+                                                         float slope, int has_act, float *__restrict__ dx,
+                                                         float *__restrict__ dres, float *__restrict__ dgamma,
+                                                         float *__restrict__ dbeta) {
+  const int c = blockIdx.x, groups = (N * HW) >> 2;
+  const float mean = save_mean[c], invstd = save_invstd[c];
+  float4 g[E4], xh[E4];
+  int off[E4];
+#pragma unroll
+  for (int i = 0; i < E4; ++i) {
+    const int q = threadIdx.x + i * T;
+    const int e = q << 2;
+    const int n = e / HW, k = e - n * HW;
+    off[i] = q < groups ? (n * C + c) * HW + k : -1;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 gv = off[i] >= 0 ? *reinterpret_cast<const float4 *>(dy + off[i]) : z;
+    const float4 yv = (has_act && off[i] >= 0) ? *reinterpret_cast<const float4 *>(y + off[i]) : make_float4(1.f, 1.f, 1.f, 1.f);
+    const float4 xv = off[i] >= 0 ? *reinterpret_cast<const float4 *>(x + off[i]) : make_float4(mean, mean, mean, mean);
+    g[i].x = yv.x > 0.f ? gv.x : gv.x * slope;
+    g[i].y = yv.y > 0.f ? gv.y : gv.y * slope;
+    g[i].z = yv.z > 0.f ? gv.z : gv.z * slope;
+    g[i].w = yv.w > 0.f ? gv.w : gv.w * slope;
+    xh[i].x = (xv.x - mean) * invstd;
+    xh[i].y = (xv.y - mean) * invstd;
+    xh[i].z = (xv.z - mean) * invstd;
+    xh[i].w = (xv.w - mean) * invstd;
+  }
+  double s = 0.0, q2 = 0.0;
+#pragma unroll
+  for (int i = 0; i < E4; ++i) {
+    s += ((double)g[i].x + g[i].y) + ((double)g[i].z + g[i].w);
+    q2 += ((double)g[i].x * xh[i].x + (double)g[i].y * xh[i].y) + ((double)g[i].z * xh[i].z + (double)g[i].w * xh[i].w);
+  }
+  __shared__ double tot[2];
+  bn_block_sum2_t<T>(s, q2, tot);
+  if (threadIdx.x == 0) {
+    if (dbeta) dbeta[c] = (float)tot[0];
+    if (dgamma) dgamma[c] = (float)tot[1];
+  }
+  const double cnt = (double)N * HW;
+  const float k0 = (gamma ? gamma[c] : 1.f) * invstd;
+  const float mg = (float)(tot[0] / cnt), mgx = (float)(tot[1] / cnt);
+#pragma unroll
+  for (int i = 0; i < E4; ++i) {
+    if (off[i] < 0) continue;
+    float4 o;
+    o.x = k0 * (g[i].x - mg - xh[i].x * mgx);
+    o.y = k0 * (g[i].y - mg - xh[i].y * mgx);
+    o.z = k0 * (g[i].z - mg - xh[i].z * mgx);
+    o.w = k0 * (g[i].w - mg - xh[i].w * mgx);
+    *reinterpret_cast<float4 *>(dx + off[i]) = o;
+    if (dres) *reinterpret_cast<float4 *>(dres + off[i]) = g[i];
+  }
+}
+
 // Multi-rank SyncBN of the register-cached maps in ONE launch per direction (round 5).  The workgroup that owns channel c
 // publishes its sums in this rank's peer slice, meets the workgroups of channel c on the other ranks (peer_chan_exchange,
 // peer_comm.h: per-channel flags, rank-ordered sums = identical bits on every rank) and applies from its registers --
@@ -729,8 +850,20 @@ extern "C" int rslo_bn2d_fwd_local(const float *x, const float *res, const float
   RSLO_CHECK_ARG(x && ws && save_mean && save_invstd && y && N >= 1 && C >= 1 && HW >= 1, "rslo_bn2d_fwd_local: bad arguments");
   RSLO_CHECK_ARG(ws_bytes >= rslo_bn2d_ws_bytes(N, C, HW), "rslo_bn2d_fwd_local: workspace too small");
   if ((int64_t)N * HW <= BN_SMALL_MAX) {
-    const int rc = rslo_tune(RSLO_TUNE_BN_SMALL_RC);      // 0: the two-pass loops
-    if (rc && (int64_t)N * HW <= 256 * BN_RC)
+    const int rc = rslo_tune(RSLO_TUNE_BN_SMALL_RC);      // 0: the two-pass loops; 2: the scalar register-cached forms (round 4)
+    const int64_t groups = ((int64_t)N * HW) >> 2;
+    const bool vec = rc == 1 && (HW & 3) == 0 && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)res) & 15) == 0 &&
+                     (int64_t)N * C * HW < ((int64_t)1 << 31);
+    if (vec && groups <= 256 * 2)
+      hipLaunchKernelGGL((k_bn2d_fwd_small_rc4<256, 2>), dim3(C), dim3(256), 0, (hipStream_t)stream, x, res, gamma, beta, N, C,
+                         HW, eps, momentum, act_slope, running_mean, running_var, save_mean, save_invstd, y);
+    else if (vec && groups <= 1024 * 2)
+      hipLaunchKernelGGL((k_bn2d_fwd_small_rc4<1024, 2>), dim3(C), dim3(1024), 0, (hipStream_t)stream, x, res, gamma, beta, N, C,
+                         HW, eps, momentum, act_slope, running_mean, running_var, save_mean, save_invstd, y);
+    else if (vec && groups <= 1024 * 5)
+      hipLaunchKernelGGL((k_bn2d_fwd_small_rc4<1024, 5>), dim3(C), dim3(1024), 0, (hipStream_t)stream, x, res, gamma, beta, N, C,
+                         HW, eps, momentum, act_slope, running_mean, running_var, save_mean, save_invstd, y);
+    else if (rc && (int64_t)N * HW <= 256 * BN_RC)
       hipLaunchKernelGGL((k_bn2d_fwd_small_rc<256>), dim3(C), dim3(256), 0, (hipStream_t)stream, x, res, gamma, beta, N, C,
                          HW, eps, momentum, act_slope, running_mean, running_var, save_mean, save_invstd, y);
     else if (rc && (int64_t)N * HW <= 1024 * BN_RC)
@@ -770,7 +903,19 @@ extern "C" int rslo_bn2d_bwd_local(const float *dy, const float *y, const float 
   RSLO_CHECK_ARG(ws_bytes >= rslo_bn2d_ws_bytes(N, C, HW), "rslo_bn2d_bwd_local: workspace too small");
   if ((int64_t)N * HW <= BN_SMALL_MAX) {
     const int rc = rslo_tune(RSLO_TUNE_BN_SMALL_RC);
-    if (rc && (int64_t)N * HW <= 256 * BN_RC)
+    const int64_t groups = ((int64_t)N * HW) >> 2;
+    const bool vec = rc == 1 && (HW & 3) == 0 && (int64_t)N * C * HW < ((int64_t)1 << 31) &&
+                     (((uintptr_t)dy | (uintptr_t)y | (uintptr_t)x | (uintptr_t)dx | (uintptr_t)dres) & 15) == 0;
+    if (vec && groups <= 256 * 2)
+      hipLaunchKernelGGL((k_bn2d_bwd_small_rc4<256, 2>), dim3(C), dim3(256), 0, (hipStream_t)stream, dy, y, x, gamma, save_mean,
+                         save_invstd, N, C, HW, act_slope, has_act, dx, dres, dgamma, dbeta);
+    else if (vec && groups <= 1024 * 2)
+      hipLaunchKernelGGL((k_bn2d_bwd_small_rc4<1024, 2>), dim3(C), dim3(1024), 0, (hipStream_t)stream, dy, y, x, gamma, save_mean,
+                         save_invstd, N, C, HW, act_slope, has_act, dx, dres, dgamma, dbeta);
+    else if (vec && groups <= 1024 * 5)
+      hipLaunchKernelGGL((k_bn2d_bwd_small_rc4<1024, 5>), dim3(C), dim3(1024), 0, (hipStream_t)stream, dy, y, x, gamma, save_mean,
+                         save_invstd, N, C, HW, act_slope, has_act, dx, dres, dgamma, dbeta);
+    else if (rc && (int64_t)N * HW <= 256 * BN_RC)
       hipLaunchKernelGGL((k_bn2d_bwd_small_rc<256>), dim3(C), dim3(256), 0, (hipStream_t)stream, dy, y, x, gamma, save_mean,
                          save_invstd, N, C, HW, act_slope, has_act, dx, dres, dgamma, dbeta);
     else if (rc && (int64_t)N * HW <= 1024 * BN_RC)
