@@ -496,16 +496,27 @@ __global__ __launch_bounds__(T) void k_bn2d_bwd_small_rc(const float *__restrict
   }
 }
 
+struct BnPeer {
+  PeerTable tab;
+  int me, world;
+  unsigned long long seq;
+  size_t chan;                  // byte offset of the slot's channel records inside a slice
+  long long timeout_ticks;
+  unsigned long long *status;
+  unsigned *wait_ring;
+};
+
 // Vectorised register-cached forms (round 5): HW % 4 == 0 (every map of the head), 16-byte loads and stores -- element group
 // q = tid + i T covers the channel's values 4q .. 4q+3 (one (n, c) row: a group never straddles rows).  A thread keeps E4 groups:
 // 5 x 16-byte loads in flight per tensor instead of 17 x 4-byte ones, and a quarter of the index arithmetic.
-template <int T, int E4>
+// PEER: the multi-rank form -- the channel's sums meet the other ranks' between the block sum and the apply (peer_chan_exchange)
+template <int T, int E4, bool PEER = false>
 __global__ __launch_bounds__(T) void k_bn2d_fwd_small_rc4(const float *__restrict__ x, const float *__restrict__ res,
                                                          const float *__restrict__ gamma, const float *__restrict__ beta,
                                                          int N, int C, int HW, float eps, float momentum, float slope,
                                                          float *__restrict__ run_mean, float *__restrict__ run_var,
                                                          float *__restrict__ save_mean, float *__restrict__ save_invstd,
-                                                         float *__restrict__ y) {
+                                                         float *__restrict__ y, double *__restrict__ count_out, BnPeer pc) {
   const int c = blockIdx.x, groups = (N * HW) >> 2;
   float4 v[E4], r[E4];
   int off[E4];
@@ -526,14 +537,22 @@ __global__ __launch_bounds__(T) void k_bn2d_fwd_small_rc4(const float *__restric
   }
   __shared__ double tot[2];
   bn_block_sum2_t<T>(s, q2, tot);
-  const double cnt = (double)N * HW;
-  const double m = tot[0] / cnt;
-  double var = tot[1] / cnt - m * m;
+  double ex[3] = {tot[0], tot[1], (double)N * HW};
+  bool ok = true;
+  if constexpr (PEER) {
+    __shared__ double sh[4 + 4 * PEER_MAX_WORLD];
+    ok = peer_chan_exchange(pc.tab, pc.me, pc.world, pc.seq, pc.chan, c, pc.timeout_ticks, pc.status, ex, sh, pc.wait_ring);
+  }
+  const double cnt = ex[2];
+  const double m = ex[0] / cnt;
+  double var = ex[1] / cnt - m * m;
   var = var > 0.0 ? var : 0.0;
-  const float mean = (float)m, invstd = (float)(1.0 / sqrt(var + (double)eps));
+  float mean = (float)m, invstd = (float)(1.0 / sqrt(var + (double)eps));
+  if (!ok) mean = invstd = __builtin_nanf("");          // a peer never arrived: poison, never hang (status says who)
   if (threadIdx.x == 0) {
     save_mean[c] = mean;
     save_invstd[c] = invstd;
+    if (PEER && c == 0) count_out[0] = cnt;
     if (run_mean) {
       const double unbiased = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
       run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mean;
@@ -558,14 +577,15 @@ __global__ __launch_bounds__(T) void k_bn2d_fwd_small_rc4(const float *__restric
   }
 }
 
-template <int T, int E4>
+template <int T, int E4, bool PEER = false>
 __global__ __launch_bounds__(T) void k_bn2d_bwd_small_rc4(const float *__restrict__ dy, const float *__restrict__ y,
                                                          const float *__restrict__ x, const float *__restrict__ gamma,
                                                          const float *__restrict__ save_mean,
                                                          const float *__restrict__ save_invstd, int N, int C, int HW,
                                                          float slope, int has_act, float *__restrict__ dx,
                                                          float *__restrict__ dres, float *__restrict__ dgamma,
-                                                         float *__restrict__ dbeta) {
+                                                         float *__restrict__ dbeta, const double *__restrict__ count_all,
+                                                         BnPeer pc) {
   const int c = blockIdx.x, groups = (N * HW) >> 2;
   const float mean = save_mean[c], invstd = save_invstd[c];
   float4 g[E4], xh[E4];
@@ -597,13 +617,20 @@ __global__ __launch_bounds__(T) void k_bn2d_bwd_small_rc4(const float *__restric
   }
   __shared__ double tot[2];
   bn_block_sum2_t<T>(s, q2, tot);
-  if (threadIdx.x == 0) {
+  if (threadIdx.x == 0) {          // the affine gradients are this rank's own sums (data parallel averages them later)
     if (dbeta) dbeta[c] = (float)tot[0];
     if (dgamma) dgamma[c] = (float)tot[1];
   }
-  const double cnt = (double)N * HW;
+  double ex[3] = {tot[0], tot[1], 0.0};
+  bool ok = true;
+  if constexpr (PEER) {
+    __shared__ double sh[4 + 4 * PEER_MAX_WORLD];
+    ok = peer_chan_exchange(pc.tab, pc.me, pc.world, pc.seq, pc.chan, c, pc.timeout_ticks, pc.status, ex, sh, pc.wait_ring);
+  }
+  const double cnt = PEER ? *count_all : (double)N * HW;      // element count over all ranks, as exchanged in the forward pass
   const float k0 = (gamma ? gamma[c] : 1.f) * invstd;
-  const float mg = (float)(tot[0] / cnt), mgx = (float)(tot[1] / cnt);
+  float mg = (float)(ex[0] / cnt), mgx = (float)(ex[1] / cnt);
+  if (!ok) mg = mgx = __builtin_nanf("");
 #pragma unroll
   for (int i = 0; i < E4; ++i) {
     if (off[i] < 0) continue;
@@ -622,15 +649,6 @@ __global__ __launch_bounds__(T) void k_bn2d_bwd_small_rc4(const float *__restric
 // peer_comm.h: per-channel flags, rank-ordered sums = identical bits on every rank) and applies from its registers --
 // instead of statistics kernel -> exchange kernel -> apply kernel with a second pass over the activation.  Same arithmetic
 // as the three-launch path (double sums, the count exchanged with them).
-struct BnPeer {
-  PeerTable tab;
-  int me, world;
-  unsigned long long seq;
-  size_t chan;                  // byte offset of the slot's channel records inside a slice
-  long long timeout_ticks;
-  unsigned long long *status;
-  unsigned *wait_ring;
-};
 
 template <int T, int E>
 __global__ __launch_bounds__(T) void k_bn2d_fwd_rc_peer(const float *__restrict__ x, const float *__restrict__ res,
@@ -856,13 +874,13 @@ extern "C" int rslo_bn2d_fwd_local(const float *x, const float *res, const float
                      (int64_t)N * C * HW < ((int64_t)1 << 31);
     if (vec && groups <= 256 * 2)
       hipLaunchKernelGGL((k_bn2d_fwd_small_rc4<256, 2>), dim3(C), dim3(256), 0, (hipStream_t)stream, x, res, gamma, beta, N, C,
-                         HW, eps, momentum, act_slope, running_mean, running_var, save_mean, save_invstd, y);
+                         HW, eps, momentum, act_slope, running_mean, running_var, save_mean, save_invstd, y, (double *)nullptr, BnPeer{});
     else if (vec && groups <= 1024 * 2)
       hipLaunchKernelGGL((k_bn2d_fwd_small_rc4<1024, 2>), dim3(C), dim3(1024), 0, (hipStream_t)stream, x, res, gamma, beta, N, C,
-                         HW, eps, momentum, act_slope, running_mean, running_var, save_mean, save_invstd, y);
+                         HW, eps, momentum, act_slope, running_mean, running_var, save_mean, save_invstd, y, (double *)nullptr, BnPeer{});
     else if (vec && groups <= 1024 * 5)
       hipLaunchKernelGGL((k_bn2d_fwd_small_rc4<1024, 5>), dim3(C), dim3(1024), 0, (hipStream_t)stream, x, res, gamma, beta, N, C,
-                         HW, eps, momentum, act_slope, running_mean, running_var, save_mean, save_invstd, y);
+                         HW, eps, momentum, act_slope, running_mean, running_var, save_mean, save_invstd, y, (double *)nullptr, BnPeer{});
     else if (rc && (int64_t)N * HW <= 256 * BN_RC)
       hipLaunchKernelGGL((k_bn2d_fwd_small_rc<256>), dim3(C), dim3(256), 0, (hipStream_t)stream, x, res, gamma, beta, N, C,
                          HW, eps, momentum, act_slope, running_mean, running_var, save_mean, save_invstd, y);
@@ -908,13 +926,13 @@ extern "C" int rslo_bn2d_bwd_local(const float *dy, const float *y, const float 
                      (((uintptr_t)dy | (uintptr_t)y | (uintptr_t)x | (uintptr_t)dx | (uintptr_t)dres) & 15) == 0;
     if (vec && groups <= 256 * 2)
       hipLaunchKernelGGL((k_bn2d_bwd_small_rc4<256, 2>), dim3(C), dim3(256), 0, (hipStream_t)stream, dy, y, x, gamma, save_mean,
-                         save_invstd, N, C, HW, act_slope, has_act, dx, dres, dgamma, dbeta);
+                         save_invstd, N, C, HW, act_slope, has_act, dx, dres, dgamma, dbeta, (const double *)nullptr, BnPeer{});
     else if (vec && groups <= 1024 * 2)
       hipLaunchKernelGGL((k_bn2d_bwd_small_rc4<1024, 2>), dim3(C), dim3(1024), 0, (hipStream_t)stream, dy, y, x, gamma, save_mean,
-                         save_invstd, N, C, HW, act_slope, has_act, dx, dres, dgamma, dbeta);
+                         save_invstd, N, C, HW, act_slope, has_act, dx, dres, dgamma, dbeta, (const double *)nullptr, BnPeer{});
     else if (vec && groups <= 1024 * 5)
       hipLaunchKernelGGL((k_bn2d_bwd_small_rc4<1024, 5>), dim3(C), dim3(1024), 0, (hipStream_t)stream, dy, y, x, gamma, save_mean,
-                         save_invstd, N, C, HW, act_slope, has_act, dx, dres, dgamma, dbeta);
+                         save_invstd, N, C, HW, act_slope, has_act, dx, dres, dgamma, dbeta, (const double *)nullptr, BnPeer{});
     else if (rc && (int64_t)N * HW <= 256 * BN_RC)
       hipLaunchKernelGGL((k_bn2d_bwd_small_rc<256>), dim3(C), dim3(256), 0, (hipStream_t)stream, dy, y, x, gamma, save_mean,
                          save_invstd, N, C, HW, act_slope, has_act, dx, dres, dgamma, dbeta);
@@ -1020,10 +1038,19 @@ extern "C" int rslo_bn2d_fwd_peer(void *comm, const float *x, const float *res, 
   hipStream_t st = (hipStream_t)stream;
 #define BN_GO(T, E) hipLaunchKernelGGL((k_bn2d_fwd_rc_peer<T, E>), dim3(C), dim3(T), 0, st, x, res, gamma, beta, N, C, HW, eps, \
                                        momentum, act_slope, running_mean, running_var, save_mean, save_invstd, count_out, y, pc)
-  if (per <= 256 * BN_RC) BN_GO(256, BN_RC);
+#define BN_GO4(T, E) hipLaunchKernelGGL((k_bn2d_fwd_small_rc4<T, E, true>), dim3(C), dim3(T), 0, st, x, res, gamma, beta, N, C, HW, \
+                                        eps, momentum, act_slope, running_mean, running_var, save_mean, save_invstd, y, count_out, pc)
+  const int64_t groups = per >> 2;
+  const bool vec = rslo_tune(RSLO_TUNE_BN_SMALL_RC) == 1 && (HW & 3) == 0 && (int64_t)N * C * HW < ((int64_t)1 << 31) &&
+                   (((uintptr_t)x | (uintptr_t)y | (uintptr_t)res) & 15) == 0;
+  if (vec && groups <= 256 * 2) BN_GO4(256, 2);
+  else if (vec && groups <= 1024 * 2) BN_GO4(1024, 2);
+  else if (vec && groups <= 1024 * 5) BN_GO4(1024, 5);
+  else if (per <= 256 * BN_RC) BN_GO(256, BN_RC);
   else if (per <= 1024 * BN_RC) BN_GO(1024, BN_RC);
   else BN_GO(1024, BN_RC_BIG);
 #undef BN_GO
+#undef BN_GO4
   RSLO_CHECK_LAUNCH("k_bn2d_fwd_rc_peer");
   c->seq = seq;
   return RSLO_OK;
@@ -1043,10 +1070,19 @@ extern "C" int rslo_bn2d_bwd_peer(void *comm, const float *dy, const float *y, c
   hipStream_t st = (hipStream_t)stream;
 #define BN_GO(T, E) hipLaunchKernelGGL((k_bn2d_bwd_rc_peer<T, E>), dim3(C), dim3(T), 0, st, dy, y, x, gamma, save_mean, save_invstd, \
                                        count_all, N, C, HW, act_slope, has_act, dx, dres, dgamma, dbeta, pc)
-  if (per <= 256 * BN_RC) BN_GO(256, BN_RC);
+#define BN_GO4(T, E) hipLaunchKernelGGL((k_bn2d_bwd_small_rc4<T, E, true>), dim3(C), dim3(T), 0, st, dy, y, x, gamma, save_mean, \
+                                        save_invstd, N, C, HW, act_slope, has_act, dx, dres, dgamma, dbeta, count_all, pc)
+  const int64_t groups = per >> 2;
+  const bool vec = rslo_tune(RSLO_TUNE_BN_SMALL_RC) == 1 && (HW & 3) == 0 && (int64_t)N * C * HW < ((int64_t)1 << 31) &&
+                   (((uintptr_t)dy | (uintptr_t)y | (uintptr_t)x | (uintptr_t)dx | (uintptr_t)dres) & 15) == 0;
+  if (vec && groups <= 256 * 2) BN_GO4(256, 2);
+  else if (vec && groups <= 1024 * 2) BN_GO4(1024, 2);
+  else if (vec && groups <= 1024 * 5) BN_GO4(1024, 5);
+  else if (per <= 256 * BN_RC) BN_GO(256, BN_RC);
   else if (per <= 1024 * BN_RC) BN_GO(1024, BN_RC);
   else BN_GO(1024, BN_RC_BIG);
 #undef BN_GO
+#undef BN_GO4
   RSLO_CHECK_LAUNCH("k_bn2d_bwd_rc_peer");
   c->seq = seq;
   return RSLO_OK;
