@@ -41,6 +41,22 @@ class defer_batch_counts:
         return False
 
 
+class isolated_batch_counts:
+    """Inside this context a defer_batch_counts() block is an OUTERMOST one whatever encloses the caller: its increments are
+    applied at ITS exit.  rslo_amd/headgraph.py captures the head's forward into a hipGraph while the network's own
+    defer_batch_counts() is open; the increments have to be launches of the capture, not of the enclosing context."""
+
+    def __enter__(self):
+        global _pending_counts
+        self.prev, _pending_counts = _pending_counts, None
+        return self
+
+    def __exit__(self, *exc):
+        global _pending_counts
+        _pending_counts = self.prev
+        return False
+
+
 def count_batch(bn):
     """`bn.num_batches_tracked += 1`, deferred when inside defer_batch_counts()."""
     if bn.num_batches_tracked is None:

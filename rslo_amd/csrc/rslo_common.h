@@ -64,6 +64,7 @@ enum RsloTune {
   RSLO_TUNE_CHAMFER_SEGMENTS,          // pruned search: target segments per query wave (0 = choose; 1..8)
   RSLO_TUNE_CONV2D_ABLATE,             // experiments only (wrong results): bit 0 every weight fetch reads chunk 0 / tap 0, bit 1 every chunk stages chunk 0
   RSLO_TUNE_RESID_BWD_ORDERED,         // 1 (default): partner gradients of the covariance residual added in source order (bit-reproducible); 0: atomics
+  RSLO_TUNE_DENSE_TILED,               // 1 (default): dense() scatter / gather through 64 x 64 LDS tiles; 0: one thread per element
   RSLO_TUNE_COUNT
 };
 extern int g_rslo_tune[RSLO_TUNE_COUNT];

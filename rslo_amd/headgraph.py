@@ -1,0 +1,231 @@
+"""The BEV head's training pass as TWO hipGraphs (forward, backward) instead of ~350 launches issued one by one.
+
+The head (reference: rslo/models/odom_pred.py:136-300, UNOdomPredEncDecSVDTempMask) works on maps of a fixed size: its 13
+residual blocks, 3 deblocks, pyramid / confidence branches and the element-wise tail are the same ~170 launches forward and
+~180 backward in every step, most of them on 24x44 / 12x22 maps where a kernel lasts 5-10 us -- less than the interpreter
+needs to issue it.  The issuing threads (forward: main thread, backward: the autograd thread) are then what the training
+stream waits for (profiles/NOTES.md round 5: host 9.3-11 ms against an 11.6 ms GPU step, idle training stream 1.1 ms).
+
+Here the head's forward over a STATIC input map is captured once (torch.cuda.graph around the same modules: every capi
+launch goes to the capturing stream) and its backward right after it (torch.autograd.grad over the captured forward's graph,
+weight gradients on the leaf stream exactly as in the eager pass: the fork and the end-of-pass join are part of the capture).
+A step then is: copy the encoder's BEV map into the static input, replay; in backward copy the loss's gradients into the
+static output gradients, replay, hand the static parameter gradients to `p.grad` and the static input gradient to autograd.
+Same kernels, same order per stream, same bits as the eager pass (tests/test_gpu_model.py).
+
+Not captured: the sparse encoder and the losses (row counts change with every scan), the optimizer (already 3 launches), the
+weight-operand split (runs beside the encoder, rslo/layers/hip_conv2d.py presplit_early) and the covariance branch.
+The eager pass stays the path for eval / no-grad calls, other dtypes, multi-rank SyncBatchNorm (its exchange number is a
+launch argument) and the first WARM_CALLS calls of a shape (lazy initialisation must not be captured).
+
+OFF by default (RSLO_HEAD_GRAPH=1 turns it on).  Measured, round 5 (profiles/NOTES.md): the issuing threads' time per step
+drops from 10.4 to 4 ms and the step does not get shorter -- 11.9 ms with the backward as one linear graph against 11.45 ms
+eager; 13.5 ms with the leaf-stream fork inside the graph (hipGraphLaunch of a multi-branch graph: 0.8 ms on the host, and the
+branches run behind cross-queue barriers).  The GPU's own time is the bound of the step, not the host.  Kept for hosts that are
+busy with something else (a real data loader beside 8 ranks).
+"""
+import os
+import warnings
+import weakref
+
+import torch
+
+ENABLED = os.environ.get("RSLO_HEAD_GRAPH", "0") == "1"
+WARM_CALLS = 2
+_STATE = weakref.WeakKeyDictionary()      # head module -> _State (graphs neither deep-copy nor pickle: kept off the module)
+
+
+def _flatten(obj, out):
+    if torch.is_tensor(obj):
+        out.append(obj)
+        return ("t", len(out) - 1)
+    if isinstance(obj, dict):
+        return ("d", [(k, _flatten(v, out)) for k, v in obj.items()])
+    if isinstance(obj, (list, tuple)):
+        return ("l" if isinstance(obj, list) else "u", [_flatten(v, out) for v in obj])
+    return ("c", obj)
+
+
+def _unflatten(spec, ts):
+    kind, val = spec
+    if kind == "t":
+        return ts[val]
+    if kind == "d":
+        return {k: _unflatten(v, ts) for k, v in val}
+    if kind == "l":
+        return [_unflatten(v, ts) for v in val]
+    if kind == "u":
+        return tuple(_unflatten(v, ts) for v in val)
+    return val
+
+
+class _State:
+    def __init__(self):
+        self.key, self.calls, self.graph, self.failed = None, 0, None, False
+
+
+class _HeadGraphFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, hg, base):
+        ctx.hg = hg
+        hg.static_in.detach().copy_(base)
+        hg.replay(hg.g_fwd, "head_graph_forward")
+        return tuple(hg.flat[i].detach() for i in hg.req)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        hg = ctx.hg
+        for k, g in enumerate(gouts):
+            if g is None:
+                if not hg.gout_zero[k]:
+                    hg.gouts[k].zero_()
+                    hg.gout_zero[k] = True
+            else:
+                hg.gouts[k].copy_(g)
+                hg.gout_zero[k] = False
+        # a caller that did not reset the gradients expects a SUM: the replay overwrites the static buffers, so a static
+        # buffer still installed as p.grad is copied out first (the shipped loop resets to None every step: no copy)
+        for p, sg in hg.pgrads:
+            if p.grad is sg:
+                p.grad = sg.clone()
+        hg.replay(hg.g_bwd, "head_graph_backward")
+        for p, sg in hg.pgrads:
+            if p.grad is None:
+                p.grad = sg
+            else:
+                p.grad = p.grad + sg
+        return None, hg.grad_in
+
+
+class HeadGraph:
+    def __init__(self, head, base, T):
+        from apex import parallel as apex_parallel
+        self.T = T
+        dev = base.device
+        named = [(n, p) for n, p in head.named_parameters() if p.requires_grad]
+        params = [p for _, p in named]
+        # The capture runs over ALIASES of the parameters (same storage, fresh leaves): a parameter's AccumulateGrad node may be
+        # alive from an earlier step and belongs to the stream of that step -- the engine would then order the capturing stream
+        # against it inside the capture (on the legacy default stream that ends the capture with a fault).  An alias gets its node
+        # here, on the capturing stream; it also has no gradient yet, which is what the leaf stream (rslo_amd/streams.py) wants to
+        # see before it takes a weight gradient.  The split operands the layers look up on the parameter object ride along.
+        alias = {}
+        for n, p in named:
+            a = p.detach().requires_grad_(True)
+            if hasattr(p, "_hip_split"):
+                a._hip_split = p._hip_split
+            alias[n] = a
+        aliases = [alias[n] for n, _ in named]
+        self.static_in = torch.empty_like(base).requires_grad_(True)
+        self.static_in.detach().copy_(base)
+        pool = torch.cuda.graph_pool_handle()
+        self.g_fwd, self.g_bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        isolate = getattr(apex_parallel, "isolated_batch_counts", None)
+        head.__dict__["_in_graph_capture"] = True
+        try:
+            with (isolate() if isolate is not None else _null()):
+                with torch.cuda.graph(self.g_fwd, pool=pool, capture_error_mode="thread_local"):
+                    frames = list(self.static_in.split(base.shape[1] // T, dim=1))
+                    for f in frames:
+                        f._pair_base = self.static_in
+                    with torch.enable_grad():
+                        out = torch.func.functional_call(head, alias, (frames,))
+            self.flat = []
+            self.spec = _flatten(out, self.flat)
+            self.req = [i for i, t in enumerate(self.flat) if t.requires_grad]
+            self.gouts = [torch.zeros_like(self.flat[i]) for i in self.req]
+            self.gout_zero = [True] * len(self.req)
+            with torch.cuda.graph(self.g_bwd, pool=pool, capture_error_mode="thread_local"):
+                grads = torch.autograd.grad([self.flat[i] for i in self.req], [self.static_in] + aliases, self.gouts,
+                                            allow_unused=True)
+        finally:
+            head.__dict__.pop("_in_graph_capture", None)
+        self.grad_in = grads[0]
+        self.pgrads = [(p, g) for p, g in zip(params, grads[1:]) if g is not None]
+        self.flat = [t.detach() for t in self.flat]
+        self.device = dev
+
+    @staticmethod
+    def replay(g, name):
+        from rslo_amd import streamprobe
+        if streamprobe.enabled():
+            with streamprobe.span("op", name):
+                g.replay()
+        else:
+            g.replay()
+
+    def forward(self, base):
+        outs = _HeadGraphFn.apply(self, base)
+        ts = list(self.flat)
+        for i, o in zip(self.req, outs):
+            ts[i] = o
+        return _unflatten(self.spec, ts)
+
+
+class _null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+def _multi_rank():
+    import torch.distributed as dist
+    if os.environ.get("RSLO_FORCE_SYNCBN_PATH", "0") == "1":
+        return True
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def wanted(head, base, T):
+    """True when this call of the head goes through run(): a training pass over one fp32 CUDA pair map by a head that has the
+    hook points, on one rank.  (The first WARM_CALLS calls of a shape still come back from run() as None = eager.)"""
+    if not ENABLED or base is None or not (head.training and torch.is_grad_enabled()):
+        return False
+    if not (base.is_cuda and base.dtype == torch.float32 and base.requires_grad and base.dim() == 4 and T == 2):
+        return False
+    if not getattr(head, "graph_capturable", False):      # (T == 2: the cycle-constraint pairing is the identity)
+        return False
+    if getattr(head, "use_svd", False) or getattr(head, "track_masks", False):      # a library SVD reads back to the host
+        return False
+    from rslo_amd import precision
+    if precision.low_precision() is not None or _multi_rank():
+        return False
+    st = _STATE.get(head)
+    return st is None or not st.failed
+
+
+def run(head, base, T):
+    """The head's training forward over `base` ([B, T*C, H, W], the frames of a pair side by side) -> its prediction dict, or
+    None: the caller runs the eager pass (warm-up calls of a shape, or a capture that failed -- warned once)."""
+    st = _STATE.get(head)
+    if st is None:
+        st = _STATE[head] = _State()
+    # the graphs hold the addresses of the parameters (and of everything else they touch): a head whose storage moved is a new one
+    key = (tuple(base.shape), base.device, T, tuple(p.data_ptr() for p in head.parameters() if p.requires_grad))
+    if st.key != key:
+        st.key, st.calls, st.graph = key, 0, None
+    if st.graph is None and st.calls < WARM_CALLS:
+        st.calls += 1
+        return None
+    # the split weight operands of this step (hip_conv2d.presplit_early, beside the encoder): waited for / made OUTSIDE the
+    # graphs, which only read them
+    from rslo.layers import hip_conv2d
+    ev = head.__dict__.pop("_presplit_event", None)
+    if ev is not None:
+        from rslo_amd import streamprobe
+        cur = torch.cuda.current_stream(base.device)
+        streamprobe.wait("head_weight_presplit", cur, lambda: cur.wait_event(ev))
+    else:
+        hip_conv2d.presplit(head)
+    if st.graph is None:
+        try:
+            st.graph = HeadGraph(head, base, T)
+        except Exception as e:      # the eager pass runs the same kernels: slower issue, same results
+            st.failed = True
+            from rslo_amd import streams
+            streams.join()
+            warnings.warn("rslo_amd.headgraph: capture of the BEV head failed (%s: %s); the head stays on the eager pass"
+                          % (type(e).__name__, e))
+            return None
+    return st.graph.forward(base)

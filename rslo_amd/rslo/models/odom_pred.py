@@ -69,6 +69,7 @@ def _maxpool_321(m):
 
 class UNOdomPredEncDecSVDTempMaskBase(OdomPredEncDecBase):
     consumes_presplit_event = True      # _forward waits for hip_conv2d.presplit_early's event instead of splitting itself
+    graph_capturable = True             # fixed map size, no host read: rslo_amd/headgraph.py may replay the training pass
 
     def __init__(self, use_svd=True, *args, **kwargs):
         super().__init__(*args, **kwargs)
@@ -104,7 +105,8 @@ class UNOdomPredEncDecSVDTempMaskBase(OdomPredEncDecBase):
     def _forward(self, xs):
         if not isinstance(xs, list):
             xs = [xs]
-        if xs[0].is_cuda and self.training and torch.is_grad_enabled():
+        capturing = self.__dict__.get("_in_graph_capture", False)      # rslo_amd/headgraph.py: the operands are split and
+        if xs[0].is_cuda and self.training and torch.is_grad_enabled() and not capturing:      # waited for outside the graph
             ev = self.__dict__.pop("_presplit_event", None)      # issued at the start of the network forward, on a side stream
             if ev is not None:
                 from rslo_amd import streamprobe
@@ -138,7 +140,7 @@ class UNOdomPredEncDecSVDTempMaskBase(OdomPredEncDecBase):
         ups = []
         side_work = self.__dict__.pop("_side_work", None)      # (mark, launch) of work for a second stream, see
         for i, (blk, skip) in enumerate(zip(self.blocks, self.skip_blocks)):   # voxel_odom_net.network_forward
-            if i == 1 and x[0].is_cuda:      # where the small-map stages begin on this stream (a gate other streams may wait on)
+            if i == 1 and x[0].is_cuda and not capturing:      # where the small-map stages begin on this stream (a gate other streams may wait on)
                 g_ = torch.cuda.Event()
                 g_.record(torch.cuda.current_stream(x[0].device))
                 SMALL_MAPS_GATE[self] = g_       # outside the module: events neither deep-copy nor pickle

@@ -33,6 +33,7 @@ from rslo.models import middle, odom_pred, voxel_encoder
 
 _SIDE_STREAMS = {}
 _HOST_LEAD = int(os.environ.get("RSLO_HOST_LEAD", "1"))
+_GRAPH_COV = os.environ.get("RSLO_HEAD_GRAPH_COV", "before")      # covariance branch: "before" / "after" the replayed head
 GATE_EVENTS = weakref.WeakKeyDictionary()      # network -> event where its latest training forward reached the loss
 _LEAD_EVENTS = weakref.WeakKeyDictionary()   # network -> events recorded behind its recent training forwards
 _LEAD_WAIT = [0.0, 0.0]  # wall seconds the issuing thread was held back, CPU seconds it spent in that wait (bench.py)
@@ -307,7 +308,19 @@ class UnVoxelOdomNetICP3(nn.Module):
                     box["cov"] = cov_fn()
             if os.environ.get("RSLO_COV_STREAM", "1") != "2":      # "2": issued behind the whole head, no gate (A/B runs)
                 self.odom_predictor.__dict__["_side_work"] = (mark, launch)
-        preds_dict = self.odom_predictor(spatial_features, tq_map_gt=example.get("tq_maps", [None])[0])
+        # the head's training pass as two replayed hipGraphs (rslo_amd/headgraph.py) once its shape has been seen twice
+        from rslo_amd import headgraph
+        preds_dict = None
+        if pair_bev and headgraph.wanted(self.odom_predictor, bev, T):
+            side_work = self.odom_predictor.__dict__.pop("_side_work", None)
+            if side_work is not None and _GRAPH_COV == "before":       # no hook points inside a graph: the branch starts beside
+                side_work[0]()                                          # the head's first stage
+                side_work[1]()
+            preds_dict = headgraph.run(self.odom_predictor, bev, T)
+            if preds_dict is None and side_work is not None and "cov" not in box:
+                self.odom_predictor.__dict__["_side_work"] = side_work
+        if preds_dict is None:
+            preds_dict = self.odom_predictor(spatial_features, tq_map_gt=example.get("tq_maps", [None])[0])
         if cov_fn is not None:
             if "cov" not in box:        # a head without the hook points (registry variant): run the branch now
                 self.odom_predictor.__dict__.pop("_side_work", None)

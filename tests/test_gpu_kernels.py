@@ -328,15 +328,25 @@ def test_conv_linearity_at_full_size(hip):
     np.testing.assert_allclose(hip.spconv_fwd(x1, W, None, nbr).cpu().numpy(), yo, **CONV_TOL)
 
 
-def test_dense_scatter_gather(hip):
+@pytest.mark.parametrize("tiled", [1, 0])
+@pytest.mark.parametrize("Cc,n", [(64, 200), (64, 1), (16, 67), (48, 129), (8, 200)])
+def test_dense_scatter_gather(hip, tiled, Cc, n):
+    """dense() and its backward gather against the oracle: the 64-row x 64-channel LDS-tiled kernel (dense_tiled = 1, C >= 16)
+    and the thread-per-element one, ragged last tiles, and the pair layout (frames = 2) the two must agree on bit for bit."""
     rng = np.random.default_rng(5)
-    dims, B, Cc = [2, 12, 10], 3, 64
-    coords = rand_sites(rng, B, dims, 200)
+    dims, B = [2, 12, 10], 4
+    coords = rand_sites(rng, B, dims, n)
     f = rng.normal(size=(len(coords), Cc)).astype(np.float32)
-    d = hip.dense_scatter(dev(f), dev(coords), B, dims)
-    assert (d.cpu().numpy() == O.dense(f, coords, B, dims)).all()
-    back = hip.dense_gather(d, dev(coords), Cc, B, dims)
-    assert (back.cpu().numpy() == f).all()
+    with hip.tuning(dense_tiled=tiled):
+        d = hip.dense_scatter(dev(f), dev(coords), B, dims)
+        assert (d.cpu().numpy() == O.dense(f, coords, B, dims)).all()
+        back = hip.dense_gather(d, dev(coords), Cc, B, dims)
+        assert (back.cpu().numpy() == f).all()
+        d2 = hip.dense_scatter(dev(f), dev(coords), B, dims, frames=2)
+        back2 = hip.dense_gather(d2, dev(coords), Cc, B, dims, frames=2)
+    assert (back2.cpu().numpy() == f).all()
+    with hip.tuning(dense_tiled=1 - tiled):
+        assert torch.equal(hip.dense_scatter(dev(f), dev(coords), B, dims, frames=2), d2)
 
 
 @pytest.mark.parametrize("B,T,Cg,H,W", [(4, 2, 128, 96, 176), (1, 2, 48, 7, 5), (3, 1, 100, 33, 17)])

@@ -498,6 +498,45 @@ def test_training_steps_are_bit_reproducible(hip):
     print("30 steps twice: identical (%s); with atomic partner gradients: %s" % (h1[:12], "identical too" if h3 == h1 else "different"))
 
 
+def test_replayed_head_graphs_train_bit_identically_to_the_eager_pass(hip, monkeypatch):
+    """rslo_amd/headgraph.py: 12 optimizer steps with the BEV head's forward / backward replayed from two hipGraphs (captured on
+    the third step) end in the SAME weights, BatchNorm statistics (incl. num_batches_tracked) and per-step losses as 12 steps
+    issued launch by launch -- same kernels, same order per stream.  Also: gradients that are not reset between two backward
+    passes add up (the static gradient buffers are copied out before a replay overwrites them)."""
+    import hashlib
+    from rslo_amd import headgraph
+    pool = [list(reduced_pair(i)[:2]) for i in range(6)]
+
+    def run(graphs):
+        monkeypatch.setattr(headgraph, "ENABLED", graphs)
+        torch.manual_seed(7)
+        net, _ = workload.build_network()
+        net.train()
+        losses = real_training_steps(net, 12, lambda i: [pool[(2 * i) % 6], pool[(2 * i + 1) % 6]])
+        torch.cuda.synchronize()
+        state = torch.cat([t.detach().double().reshape(-1) for t in list(net.parameters()) + list(net.buffers())])
+        st = headgraph._STATE.get(net.odom_predictor)
+        return hashlib.sha256(state.cpu().numpy().tobytes()).hexdigest(), losses, st, net
+    h0, l0, st0, _ = run(False)
+    h1, l1, st1, net = run(True)
+    assert st0 is None and st1 is not None and st1.graph is not None and not st1.failed
+    assert l0 == l1, [(i, a, b) for i, (a, b) in enumerate(zip(l0, l1)) if a != b][:3]
+    assert h0 == h1
+    # two backward passes without a reset in between: the head's gradients are the sum of the two passes'
+    ex = [workload.make_example(net, [pool[0], pool[1]]), workload.make_example(net, [pool[2], pool[3]])]
+    w = next(net.odom_predictor.blocks[1][2].parameters())
+    net.zero_grad(set_to_none=True)
+    singles = []
+    for e in ex:
+        net.zero_grad(set_to_none=True)
+        net(e)["loss"].mean().backward()
+        singles.append(w.grad.clone())
+    net.zero_grad(set_to_none=True)
+    for e in ex:
+        net(e)["loss"].mean().backward()
+    assert torch.equal(w.grad, singles[0] + singles[1])
+
+
 def test_basic_blocks_are_exact_on_the_inputs_they_see_in_the_network(hip):
     """The BEV encoder's BasicBlocks, each evaluated STAND-ALONE on the input and output gradient it receives inside the
     network (default init, sparse reduced-ring BEV map, warm-up regime -- the state in which whole-network gradient
