@@ -1141,6 +1141,205 @@ __global__ __launch_bounds__(256, 2) void k_conv2d_str(const float *__restrict__
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same four passes with the tap list known at COMPILE time (round 5).  k_conv2d_str above walks run-time class / tap
+// loops: its weight operands are requested right in front of the MFMAs that consume them (18 exposed L2 round trips per
+// 32-channel chunk with MTW = 2), its barriers are __syncthreads() (vmcnt(0): the next chunk's values land before anyone
+// passes, so the prefetch overlaps nothing) and the stride-2 taps of the forward read the 208-byte pixel rows at a lane stride
+// of 416 bytes (4 lanes per LDS slot).  Here, per MODE (0 forward 3x3, 1 forward 1x1, 2 data gradient 3x3, 3 data gradient
+// 1x1), the taps are a constexpr table: weight and pixel operands of tap t + 1 are in flight during the MFMAs of tap t (the
+// next chunk's first tap during the last), barriers order LDS traffic only, the halo is as large as the mode needs, and the
+// forward 3x3 stores its staged columns de-interleaved by parity (even columns, then odd ones: a tap reads 16 CONSECUTIVE
+// 224-byte slots, conflict-free like the stride-1 kernel).  Same products in the same order: same bits as k_conv2d_str.
+// ---------------------------------------------------------------------------------------------------------------------
+struct StrTap {
+  int cls, oy, ox, wt;
+};
+template <int MODE>
+__device__ constexpr StrTap str_tap(int t) {
+  if (MODE == 0) return StrTap{0, t / 3, t % 3, t};
+  if (MODE == 2) {      // classes (py, px) = (0,0) (0,1) (1,0) (1,1) with 1, 2, 2, 4 taps; taps iy-major, as the class descriptors
+    const int c = t == 0 ? 0 : (t < 3 ? 1 : (t < 5 ? 2 : 3));
+    const int py = c >> 1, px = c & 1;
+    const int k = t - (c == 0 ? 0 : (c == 1 ? 1 : (c == 2 ? 3 : 5)));
+    const int nx = px ? 2 : 1;
+    const int iy = k / nx, ix = k % nx;
+    const int ky = py ? (iy == 0 ? 0 : 2) : 1, dy = py ? (iy == 0 ? 1 : 0) : 0;
+    const int kx = px ? (ix == 0 ? 0 : 2) : 1, dx = px ? (ix == 0 ? 1 : 0) : 0;
+    return StrTap{c, dy, dx, 8 - (3 * ky + kx)};
+  }
+  return StrTap{0, 0, 0, 0};
+}
+
+template <int MODE, int MTW, int OCC, bool FULLA = (MTW == 1)>
+__global__ __launch_bounds__(256, OCC) void k_conv2d_str2(const float *__restrict__ in, const unsigned short *__restrict__ Ws,
+                                                          Conv2dStrGeom gm, float *__restrict__ out) {
+  constexpr int TR = 4, NTW = TR / 2;
+  constexpr int S_IN = MODE == 0 ? 2 : 1, NCLS = MODE >= 2 ? 4 : 1, NT = (MODE == 0 || MODE == 2) ? 9 : 1;
+  constexpr int EXT = MODE == 0 ? 3 : (MODE == 2 ? 2 : 1);          // halo extent past the last sampled pixel
+  constexpr int HR = S_IN * (TR - 1) + EXT, HC = S_IN * 15 + EXT, NPX = HR * HC;
+  constexpr int HC0 = (HC + 1) / 2;                                  // MODE 0: even columns first (HC0 of them), then the odd ones
+  __shared__ __attribute__((aligned(16))) unsigned char lds[NPX * C2F_PXB1];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int wm = wid & 1, wn = wid >> 1;
+  int bx, by;
+  if (!conv2d_xcd_tile(gm.xsc, gm.npix, gm.ny, bx, by)) return;
+  const int tx = bx % gm.tiles_x; bx /= gm.tiles_x;
+  const int ty = bx % gm.tiles_y;
+  const int b = bx / gm.tiles_y;
+  const int c0 = tx * 16, r0 = ty * TR;
+  const int64_t HWi = (int64_t)gm.Hi * gm.Wi, HWo = (int64_t)gm.Ho * gm.Wo;
+  const int n_mt = gm.cout / 16;
+  const int mt0 = (by * 2 + wm) * MTW;
+
+  f32x4 acc[NCLS][MTW][NTW];
+#pragma unroll
+  for (int c = 0; c < NCLS; ++c)
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) acc[c][mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  constexpr int NTASK = (NPX * 4 + 255) / 256;
+  int tsrc[NTASK], tdst[NTASK];
+  const glb_u8 *const in_b = (const glb_u8 *)in;
+#pragma unroll
+  for (int r = 0; r < NTASK; ++r) {
+    const int task = tid + r * 256;
+    const int o = task / NPX, q = task - o * NPX;
+    const int qy = q / HC, qx = q - qy * HC;
+    const int y = gm.src_stride * (S_IN * r0 + gm.by + qy), x = gm.src_stride * (S_IN * c0 + gm.bx + qx);
+    const bool ok = task < NPX * 4 && y >= 0 && y < gm.Hi && x >= 0 && x < gm.Wi;
+    tsrc[r] = ok ? (int)((((int64_t)b * gm.cin + 8 * o) * HWi + (int64_t)y * gm.Wi + x) * 4) : -1;
+    const int pidx = MODE == 0 ? qy * HC + (qx & 1) * HC0 + (qx >> 1) : q;
+    tdst[r] = task < NPX * 4 ? pidx * C2F_PXB1 + o * 16 : -1;
+  }
+#define C2S_RAW(CH, J, OFF) (*(const glb_f32 *)(c2f_uniform(in_b + ((int64_t)(CH) * 32 + (J)) * HWi * 4) + (unsigned)(OFF)))
+  float raw[NTASK][8];
+  const int n_chunks = gm.cin / 32;
+#pragma unroll
+  for (int r = 0; r < NTASK; ++r)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) raw[r][j] = tsrc[r] >= 0 ? C2S_RAW(0, j, tsrc[r]) : 0.f;
+  const unsigned short *wbase = Ws + (int64_t)mt0 * 3 * 512 + lane * 8;
+  // FULLA (one 16-channel block per wave): the operands of ALL taps of a chunk are held in registers and each tap's set is
+  // refilled for the NEXT chunk right after its MFMAs -- a prefetch distance of a whole chunk.  One tap ahead (12 MFMAs =
+  // 192 cycles) does not cover an L2 round trip at the 2-3 waves per SIMD these kernels run with (forward 256 -> 128 at
+  // 96x176: 144 -> 96 us).  Two blocks per wave keep one tap ahead (216 operand registers otherwise), and so does the
+  // four-class data gradient of a launch that fills the chip more than once (3 waves per SIMD at 160 registers: 77 vs 93 us).
+  constexpr int NA = FULLA ? NT : 1;
+  u32x4 ah[NA][MTW], am[NA][MTW], al[NA][MTW], nh[MTW], nm[MTW], nl[MTW];
+#define C2S_LOAD_A(CH, WT, H_, M_, L_)                                                                   \
+  _Pragma("unroll") for (int mt = 0; mt < MTW; ++mt) {                                                    \
+    const unsigned short *wp = wbase + ((((int64_t)(CH) * NT + (WT)) * n_mt + mt) * 3) * 512;            \
+    H_[mt] = *(const u32x4 *)(wp);                                                                        \
+    M_[mt] = *(const u32x4 *)(wp + 512);                                                                  \
+    L_[mt] = *(const u32x4 *)(wp + 1024);                                                                 \
+  }
+  if (FULLA) {
+#pragma unroll
+    for (int t = 0; t < NA; ++t) { C2S_LOAD_A(0, str_tap<MODE>(t).wt, ah[t], am[t], al[t]) }
+  } else {
+    C2S_LOAD_A(0, str_tap<MODE>(0).wt, ah[0], am[0], al[0])
+  }
+  // pixel operand of tap (oy, ox), tile row nt: MODE 0 reads column 2 li + ox = parity ox & 1, entry li + (ox >> 1)
+  const lds_u8 *bbase = (const lds_u8 *)lds + (S_IN * wn * NTW * HC + li) * C2F_PXB1 + g * 16;
+#define C2S_LOAD_B(OY, OX, H_, M_, L_)                                                                   \
+  _Pragma("unroll") for (int nt = 0; nt < NTW; ++nt) {                                                    \
+    const lds_u8 *bp = bbase + ((S_IN * nt + (OY)) * HC + (MODE == 0 ? ((OX) & 1) * HC0 + ((OX) >> 1) : (OX))) * C2F_PXB1; \
+    H_[nt] = *(const lds_u32x4 *)(bp);                                                                    \
+    M_[nt] = *(const lds_u32x4 *)(bp + 64);                                                               \
+    L_[nt] = *(const lds_u32x4 *)(bp + 128);                                                              \
+  }
+  for (int chunk = 0; chunk < n_chunks; ++chunk) {
+#pragma unroll
+    for (int r = 0; r < NTASK; ++r) {
+      if (tdst[r] >= 0) {
+        const Split3 s = split_masked(raw[r], 0xffu);
+        unsigned char *dst = lds + tdst[r];
+        *(u32x4 *)(dst) = s.h;
+        *(u32x4 *)(dst + 64) = s.m;
+        *(u32x4 *)(dst + 128) = s.l;
+      }
+    }
+    if (chunk + 1 < n_chunks) {
+#pragma unroll
+      for (int r = 0; r < NTASK; ++r)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) raw[r][j] = tsrc[r] >= 0 ? C2S_RAW(chunk + 1, j, tsrc[r]) : 0.f;
+    }
+    C2F_LDS_BARRIER();
+    u32x4 pbh[NTW], pbm[NTW], pbl[NTW];
+    C2S_LOAD_B(str_tap<MODE>(0).oy, str_tap<MODE>(0).ox, pbh, pbm, pbl)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const StrTap tp = str_tap<MODE>(t);
+      const int ia = FULLA ? t : 0;
+      if (!FULLA) {
+        if (t + 1 < NT) {
+          C2S_LOAD_A(chunk, str_tap<MODE>(t + 1 < NT ? t + 1 : 0).wt, nh, nm, nl)
+        } else if (chunk + 1 < n_chunks) {
+          C2S_LOAD_A(chunk + 1, str_tap<MODE>(0).wt, nh, nm, nl)
+        }
+      }
+      u32x4 bh[NTW], bm[NTW], bl[NTW];
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) { bh[nt] = pbh[nt]; bm[nt] = pbm[nt]; bl[nt] = pbl[nt]; }
+      if (t + 1 < NT) {
+        C2S_LOAD_B(str_tap<MODE>(t + 1 < NT ? t + 1 : 0).oy, str_tap<MODE>(t + 1 < NT ? t + 1 : 0).ox, pbh, pbm, pbl)
+      }
+      const int c = tp.cls;
+#pragma unroll
+      for (int mt = 0; mt < MTW; ++mt) {
+        // six products per block, smallest first (the order of k_conv2d_str)
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) acc[c][mt][nt] = MFMA_BF16(al[ia][mt], bh[nt], acc[c][mt][nt]);
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) acc[c][mt][nt] = MFMA_BF16(am[ia][mt], bm[nt], acc[c][mt][nt]);
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) acc[c][mt][nt] = MFMA_BF16(ah[ia][mt], bl[nt], acc[c][mt][nt]);
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) acc[c][mt][nt] = MFMA_BF16(am[ia][mt], bh[nt], acc[c][mt][nt]);
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) acc[c][mt][nt] = MFMA_BF16(ah[ia][mt], bm[nt], acc[c][mt][nt]);
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) acc[c][mt][nt] = MFMA_BF16(ah[ia][mt], bh[nt], acc[c][mt][nt]);
+      }
+      if (FULLA) {
+        if (chunk + 1 < n_chunks) { C2S_LOAD_A(chunk + 1, tp.wt, ah[ia], am[ia], al[ia]) }
+      } else {
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) { ah[0][mt] = nh[mt]; am[0][mt] = nm[mt]; al[0][mt] = nl[mt]; }
+      }
+    }
+    C2F_LDS_BARRIER();
+  }
+#undef C2S_RAW
+#undef C2S_LOAD_A
+#undef C2S_LOAD_B
+
+#pragma unroll
+  for (int c = 0; c < NCLS; ++c) {
+    const Conv2dStrClass &cl = gm.cls[c];
+    const int col = c0 + li;
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int m = (mt0 + mt) * 16 + 4 * g + j;
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+          const int r = r0 + wn * NTW + nt;
+          if (col < cl.cols && r < cl.rows) {
+            const int64_t o = ((int64_t)b * gm.cout + m) * HWo + (int64_t)(gm.s_out * r + cl.py) * gm.Wo + gm.s_out * col + cl.px;
+            out[o] = gm.res ? acc[c][mt][nt][j] + gm.res[o] : acc[c][mt][nt][j];
+          }
+        }
+      }
+  }
+}
+
 // ksize 3 (padding 1) or 1 (padding 0), stride 2
 extern "C" int rslo_conv2d_s2_supported(int cin, int cout, int ksize) {
   return (ksize == 1 || ksize == 3) && cin > 0 && cout > 0 && cin % 32 == 0 && cout % 32 == 0;
@@ -1162,8 +1361,10 @@ extern "C" int rslo_conv2d_fwd_s2(const float *in, const void *Ws, int B, int ci
   // halo and its operand split are shared by twice the MFMAs (256 -> 128 at 96x176: 237 -> 218 us, its 1x1: 41 -> 31 us;
   // the smaller stages lose, 44 -> 62 us, and keep 32 channels)
   const int mtw_env = rslo_tune(RSLO_TUNE_CONV2D_S2_MTW);
+  const bool piped = rslo_tune(RSLO_TUNE_CONV2D_S2_PIPED) != 0;      // compile-time tap lists + operand prefetch (k_conv2d_str2)
   const int64_t wgs32 = (int64_t)B * gm.tiles_x * gm.tiles_y * (cout / 32);
-  const int mtw = (cout % 64 == 0 && (mtw_env ? mtw_env == 2 : wgs32 >= 1024)) ? 2 : 1;
+  // (k_conv2d_str2 holds a chunk's weight operands in registers with ONE block per wave: 96 vs 161 us on that layer)
+  const int mtw = (cout % 64 == 0 && (mtw_env ? mtw_env == 2 : (!piped && wgs32 >= 1024))) ? 2 : 1;
   gm.npix = B * gm.tiles_x * gm.tiles_y;
   gm.ny = cout / (32 * mtw);
   gm.xsc = conv2d_xcd_split(RSLO_TUNE_CONV2D_S2_XSC, gm.ny, 6.0 * ksize * ksize * cin * cout, 4.0 * B * cin * H * W * (ksize == 3 ? 1.5 : 0.25));
@@ -1174,11 +1375,15 @@ extern "C" int rslo_conv2d_fwd_s2(const float *in, const void *Ws, int B, int ci
     gm.src_stride = 1; gm.by = gm.bx = -1; c.ny = c.nx = 3;
     for (int i = 0; i < 3; ++i) c.oy[i] = c.ox[i] = i;
     for (int i = 0; i < 9; ++i) c.wt[i] = i;
-    if (mtw == 2) hipLaunchKernelGGL((k_conv2d_str<4, 2, 1, 2>), grid, dim3(256), 0, st, in, ws, gm, out);
+    if (piped && mtw == 2) hipLaunchKernelGGL((k_conv2d_str2<0, 2, 2>), grid, dim3(256), 0, st, in, ws, gm, out);
+    else if (piped) hipLaunchKernelGGL((k_conv2d_str2<0, 1, 2>), grid, dim3(256), 0, st, in, ws, gm, out);
+    else if (mtw == 2) hipLaunchKernelGGL((k_conv2d_str<4, 2, 1, 2>), grid, dim3(256), 0, st, in, ws, gm, out);
     else hipLaunchKernelGGL((k_conv2d_str<4, 2, 1, 1>), grid, dim3(256), 0, st, in, ws, gm, out);
   } else {        // out[y][x] = W in[2y][2x]: stage only the sampled pixels
     gm.src_stride = 2; c.ny = c.nx = 1;
-    if (mtw == 2) hipLaunchKernelGGL((k_conv2d_str<4, 1, 1, 2>), grid, dim3(256), 0, st, in, ws, gm, out);
+    if (piped && mtw == 2) hipLaunchKernelGGL((k_conv2d_str2<1, 2, 4>), grid, dim3(256), 0, st, in, ws, gm, out);
+    else if (piped) hipLaunchKernelGGL((k_conv2d_str2<1, 1, 4>), grid, dim3(256), 0, st, in, ws, gm, out);
+    else if (mtw == 2) hipLaunchKernelGGL((k_conv2d_str<4, 1, 1, 2>), grid, dim3(256), 0, st, in, ws, gm, out);
     else hipLaunchKernelGGL((k_conv2d_str<4, 1, 1, 1>), grid, dim3(256), 0, st, in, ws, gm, out);
   }
   RSLO_CHECK_LAUNCH("k_conv2d_str(fwd)");
@@ -1229,17 +1434,23 @@ extern "C" int rslo_conv2d_dgrad_s2_add(const float *dout, const void *Ws, const
   // all four classes of a tile from one staged halo of dout (9 tap products in total for 3x3)
   const int mtw_env = rslo_tune(RSLO_TUNE_CONV2D_S2_MTW);
   const int64_t wgs32 = (int64_t)B * gm.tiles_x * gm.tiles_y * (cin / 32);
-  (void)wgs32;      // measured: 64 channels per workgroup loses on the four-class data gradient (138 vs 100 us on the
+  // measured: 64 channels per workgroup loses on the four-class data gradient (138 vs 100 us on the
                     // largest layer: 4 x 2 x 2 accumulator tiles per wave), so it is opt-in here
   const int mtw = (cin % 64 == 0 && mtw_env == 2) ? 2 : 1;
   gm.npix = B * gm.tiles_x * gm.tiles_y;
   gm.ny = cin / (32 * mtw);
   gm.xsc = conv2d_xcd_split(RSLO_TUNE_CONV2D_S2_XSC, gm.ny, 6.0 * ksize * ksize * cin * cout, 4.0 * B * cout * gm.Hi * gm.Wi * 1.5);
   const dim3 grid = conv2d_xcd_grid(gm.xsc, gm.npix, gm.ny);
-  if (mtw == 2)
-    hipLaunchKernelGGL((k_conv2d_str<4, 1, 4, 2>), grid, dim3(256), 0, (hipStream_t)stream, dout, (const unsigned short *)Ws, gm, din);
-  else
-    hipLaunchKernelGGL((k_conv2d_str<4, 1, 4, 1>), grid, dim3(256), 0, (hipStream_t)stream, dout, (const unsigned short *)Ws, gm, din);
+  const bool piped = rslo_tune(RSLO_TUNE_CONV2D_S2_PIPED) != 0;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned short *ws = (const unsigned short *)Ws;
+  if (piped && ksize == 3 && mtw == 2) hipLaunchKernelGGL((k_conv2d_str2<2, 2, 2>), grid, dim3(256), 0, st, dout, ws, gm, din);
+  else if (piped && ksize == 3 && wgs32 > 512) hipLaunchKernelGGL((k_conv2d_str2<2, 1, 3, false>), grid, dim3(256), 0, st, dout, ws, gm, din);
+  else if (piped && ksize == 3) hipLaunchKernelGGL((k_conv2d_str2<2, 1, 2, true>), grid, dim3(256), 0, st, dout, ws, gm, din);
+  else if (piped && mtw == 2) hipLaunchKernelGGL((k_conv2d_str2<3, 2, 2>), grid, dim3(256), 0, st, dout, ws, gm, din);
+  else if (piped) hipLaunchKernelGGL((k_conv2d_str2<3, 1, 3>), grid, dim3(256), 0, st, dout, ws, gm, din);
+  else if (mtw == 2) hipLaunchKernelGGL((k_conv2d_str<4, 1, 4, 2>), grid, dim3(256), 0, st, dout, ws, gm, din);
+  else hipLaunchKernelGGL((k_conv2d_str<4, 1, 4, 1>), grid, dim3(256), 0, st, dout, ws, gm, din);
   RSLO_CHECK_LAUNCH("k_conv2d_str(dgrad)");
   return RSLO_OK;
 }

@@ -1431,6 +1431,33 @@ def test_conv2d_stride2_xcd_orders_keep_the_bits(hip, B, cin, cout, H, W, k):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,cin,cout,H,W,k", [(4, 128, 128, 48, 88, 3), (2, 64, 128, 21, 37, 3), (4, 128, 256, 24, 44, 1),
+                                               (1, 256, 128, 96, 176, 3), (1, 32, 64, 13, 21, 1), (2, 64, 64, 5, 3, 3)])
+def test_conv2d_stride2_pipelined_kernels_keep_the_bits(hip, B, cin, cout, H, W, k):
+    """k_conv2d_str2 (compile-time tap lists, operands one tap ahead, parity-ordered halo columns; switch conv2d_s2_piped)
+    forms the same products in the same order as k_conv2d_str: forward and data gradient (with and without the joined
+    residual), one and two 16-channel blocks per wave, ragged maps."""
+    torch.manual_seed(8)
+    x = torch.randn(B, cin, H, W, device="cuda")
+    g = torch.randn(B, cout, (H - 1) // 2 + 1, (W - 1) // 2 + 1, device="cuda")
+    res = torch.randn(B, cin, H, W, device="cuda")
+    w = torch.randn(cout, cin, k, k, device="cuda") / (k * cin ** 0.5)
+    ws, wst = hip.conv2d_wsplit_k(w, False), hip.conv2d_wsplit_k(w, True)
+
+    def run():
+        return [hip.conv2d_fwd_s2(x, ws, cout, k).clone(), hip.conv2d_dgrad_s2(g, wst, cin, H, W, k).clone(),
+                hip.conv2d_dgrad_s2(g, wst, cin, H, W, k, residual=res).clone()]
+    for mtw in (1, 2):
+        if mtw == 2 and (cin % 64 or cout % 64):
+            continue
+        with hip.tuning(conv2d_s2_mtw=mtw, conv2d_s2_piped=0):
+            ref = run()
+        with hip.tuning(conv2d_s2_mtw=mtw, conv2d_s2_piped=1):
+            for a, b in zip(ref, run()):
+                assert torch.equal(a, b), mtw
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("M", [1, 63, 64, 65, 300, 4097])
 def test_vfe_mean_wave_tail_sizes_match_oracle(hip, M):
     """k_vfe_mean_lds stages the rows of 64 voxels per wave through LDS: voxel counts around the wave / block boundaries
