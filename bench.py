@@ -41,12 +41,12 @@ MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md; the 5 P
 
 
 def lib_hash():
-    """First 16 hex digits of the sha256 of librslo_hip.so: the PMC summaries under profiles/ carry the hash of the
-    library they were collected with; counter fields are only quoted when it matches the library being benchmarked."""
-    import hashlib
+    """rslo_amd.build.source_hash(): first 16 hex digits of the sha256 over the sources and flags librslo_hip.so is built from.
+    The PMC summaries under profiles/ carry the hash of the library they were collected with; counter fields are only quoted
+    when it matches the library being benchmarked."""
     try:
-        with open(os.path.join(ROOT, "rslo_amd", "librslo_hip.so"), "rb") as f:
-            return hashlib.sha256(f.read()).hexdigest()[:16]
+        import runpy
+        return runpy.run_path(os.path.join(ROOT, "rslo_amd", "build.py"))["source_hash"]()
     except OSError:
         return None
 
@@ -149,8 +149,8 @@ def _flush_c_stdio():
         pass
 
 
-PMC_TRAFFIC = "r04_pmc_traffic_bench.json"
-PMC_BUSY = "r04_pmc_mfma_busy.json"
+PMC_TRAFFIC = "r05_pmc_traffic_bench.json"
+PMC_BUSY = "r05_pmc_mfma_busy.json"
 
 
 # --------------------------------------------------------------------------------------------- kernel events

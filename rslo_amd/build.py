@@ -22,6 +22,19 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
+def source_hash():
+    """First 16 hex digits of the sha256 over what librslo_hip.so is built FROM: every csrc/*.hip and csrc/*.h, include/rslo_hip.h
+    and the compiler flags.  The PMC summaries under profiles/ are stamped with it and bench.py quotes them only for the same
+    sources (the hash of the binary differs between two builds of identical sources on different boxes)."""
+    import hashlib
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for f in sources() + sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(HERE, "..", "include", "rslo_hip.h")]:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def stale():
     if not os.path.exists(LIB):
         return True

@@ -17,7 +17,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for k, v in agg.items():
         res[k][c] = sum(v) / len(v); res[k]["launches"] = len(v)
 import hashlib
-out = {"lib_sha256": hashlib.sha256(open(sys.argv[3], "rb").read()).hexdigest()[:16],
+out = {"lib_sha256": __import__("runpy").run_path(__import__("os").path.join(__import__("os").path.dirname(sys.argv[3]), "build.py"))["source_hash"](),
        "note": "per-launch averages over a 5-step bench.py run; FETCH_SIZE/WRITE_SIZE are reported in KB; "
                "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE counts 128-B requests as 64 B)",
        "kernels": {}}

@@ -15,7 +15,7 @@ for d in csv.DictReader(open(f)):
     if any(k in n for k in ("k_spconv", "k_wgrad", "k_conv2d_fwd", "k_conv2d_wgrad_s1", "k_conv2d_wgrad<", "k_conv2d_str", "miopenSp3", "igemm")):
         per[re.sub(r"^void ", "", n.split("(")[0])[:60]][d["Counter_Name"]].append(float(d["Counter_Value"]))
 import hashlib
-out = {"lib_sha256": hashlib.sha256(open(sys.argv[3], "rb").read()).hexdigest()[:16],
+out = {"lib_sha256": __import__("runpy").run_path(__import__("os").path.join(__import__("os").path.dirname(sys.argv[3]), "build.py"))["source_hash"](),
        "note": "per-launch averages over a 5-step bench.py run; mfma_busy_pct = 100 * SQ_VALU_MFMA_BUSY_CYCLES / "
                "(GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs); shader_clock_cycles = GRBM_GUI_ACTIVE / 8", "kernels": {}}
 for k, v in sorted(per.items()):

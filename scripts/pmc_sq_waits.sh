@@ -22,6 +22,6 @@ for k, v in sorted(per.items()):
     out["kernels"][k] = row
     print("%-30s" % k, row)
 import hashlib, os
-out["lib_sha256"] = hashlib.sha256(open(os.path.join(os.environ["GRAFT_REPO_ROOT"], "rslo_amd/librslo_hip.so"), "rb").read()).hexdigest()[:16]
+out["lib_sha256"] = __import__("runpy").run_path(os.path.join(os.environ["GRAFT_REPO_ROOT"], "rslo_amd/build.py"))["source_hash"]()
 json.dump(out, open(sys.argv[2], "w"), indent=1)
 PY
