@@ -639,8 +639,9 @@ RSLO_API int rslo_conv2d_fwd_s2(const float *in, const void *Ws, int B, int cin,
                                 float *out, void *stream);
 RSLO_API int rslo_conv2d_dgrad_s2(const float *dout, const void *Ws, int B, int cin, int cout, int H, int W, int ksize,
                                   float *din, void *stream);
-/*      din = data gradient + res (res [B,cin,H,W], must not alias din): the input gradients of the two branches of a
- *      stride-2 BasicBlock (custom_resnet_spc.py:74-96) joined in the second branch's epilogue, same bits as the add. */
+/*      din = data gradient + res (res [B,cin,H,W]): the input gradients of the two branches of a stride-2 BasicBlock
+ *      (custom_resnet_spc.py:74-96) joined in the second branch's epilogue, same bits as the add.  ksize 1 only: res may
+ *      BE din (in place) -- the 1x1 gradient lands on the pixels (2y, 2x), the other three quarters of din are not touched. */
 RSLO_API int rslo_conv2d_dgrad_s2_add(const float *dout, const void *Ws, const float *res, int B, int cin, int cout, int H,
                                       int W, int ksize, float *din, void *stream);
 /*      C4 (bf16 operands, fp32 accumulation and storage): the same kernels issuing only the product of the

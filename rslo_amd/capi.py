@@ -1483,13 +1483,17 @@ def conv2d_fwd_s2(x, ws, cout, ksize):
     return out
 
 
-def conv2d_dgrad_s2(dy, ws_t, cin, H, W, ksize, residual=None):
+def conv2d_dgrad_s2(dy, ws_t, cin, H, W, ksize, residual=None, inplace=False):
     """dy [B,cout,Ho,Wo] -> dx [B,cin,H,W] of the stride-2 layer; ws_t = the transpose=True operand.
-    residual [B,cin,H,W]: added in the epilogue (rslo_conv2d_dgrad_s2_add)."""
+    residual [B,cin,H,W]: added in the epilogue (rslo_conv2d_dgrad_s2_add); inplace (ksize 1): the gradient is added INTO
+    residual, which is returned -- only the pixels (2y, 2x) are read and written."""
     B, cout = dy.shape[0], dy.shape[1]
-    dx = torch.empty((B, cin, H, W), dtype=torch.float32, device=dy.device)
-    if residual is not None and (tuple(residual.shape) != tuple(dx.shape) or not residual.is_contiguous()):
-        raise ValueError("conv2d_dgrad_s2: residual must be a contiguous %s tensor" % (tuple(dx.shape),))
+    shape = (B, cin, H, W)
+    if residual is not None and (tuple(residual.shape) != shape or not residual.is_contiguous()):
+        raise ValueError("conv2d_dgrad_s2: residual must be a contiguous %s tensor" % (shape,))
+    if inplace and (residual is None or ksize != 1):
+        raise ValueError("conv2d_dgrad_s2: inplace needs a residual and ksize 1")
+    dx = residual if inplace else torch.empty(shape, dtype=torch.float32, device=dy.device)
     rc = lib().rslo_conv2d_dgrad_s2_add(_ptr(dy, torch.float32, "dy"), ws_t.data_ptr(),
                                         _ptr(residual, torch.float32, "residual") if residual is not None else None,
                                         B, cin, cout, H, W, ksize, dx.data_ptr(), _stream())

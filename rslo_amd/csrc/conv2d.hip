@@ -1012,6 +1012,7 @@ struct Conv2dStrGeom {
   int by, bx;             // halo origin offset
   int s_out, ntap_w;      // output stride of class pixels; taps per chunk in the weight operand (9 or 1)
   int n_class;            // classes computed by every workgroup from ONE staged halo (1 forward, 4 data gradient)
+  int cls_out;            // classes WRITTEN (= n_class; 1 for the in-place 1x1 data gradient: the other classes keep res)
   int tiles_x, tiles_y;
   int xsc, npix, ny;      // XCD-aware workgroup order, as in Conv2dFwdGeom
   const float *res;       // optional [B][cout][Ho][Wo] added in the epilogue (NULL: none)
@@ -1122,6 +1123,7 @@ __global__ __launch_bounds__(256, 2) void k_conv2d_str(const float *__restrict__
 
 #pragma unroll
   for (int c = 0; c < NCLS; ++c) {
+    if (c >= gm.cls_out) break;
     const Conv2dStrClass &cl = gm.cls[c];
     const int col = c0 + li;
 #pragma unroll
@@ -1321,6 +1323,7 @@ __global__ __launch_bounds__(256, OCC) void k_conv2d_str2(const float *__restric
 
 #pragma unroll
   for (int c = 0; c < NCLS; ++c) {
+    if (c >= gm.cls_out) break;
     const Conv2dStrClass &cl = gm.cls[c];
     const int col = c0 + li;
 #pragma unroll
@@ -1353,7 +1356,7 @@ extern "C" int rslo_conv2d_fwd_s2(const float *in, const void *Ws, int B, int ci
   Conv2dStrGeom gm = {};
   gm.B = B; gm.cin = cin; gm.cout = cout; gm.Hi = H; gm.Wi = W;
   gm.Ho = (H - 1) / 2 + 1; gm.Wo = (W - 1) / 2 + 1;
-  gm.s_out = 1; gm.ntap_w = ksize * ksize; gm.n_class = 1;
+  gm.s_out = 1; gm.ntap_w = ksize * ksize; gm.n_class = gm.cls_out = 1;
   gm.tiles_x = (int)rslo_cdiv(gm.Wo, 16); gm.tiles_y = (int)rslo_cdiv(gm.Ho, 4);
   Conv2dStrClass &c = gm.cls[0];
   c.rows = gm.Ho; c.cols = gm.Wo;
@@ -1409,6 +1412,10 @@ extern "C" int rslo_conv2d_dgrad_s2_add(const float *dout, const void *Ws, const
   gm.Hi = (H - 1) / 2 + 1; gm.Wi = (W - 1) / 2 + 1; gm.Ho = H; gm.Wo = W;
   gm.s_out = 2; gm.ntap_w = ksize * ksize; gm.n_class = 4; gm.src_stride = 1;
   gm.res = res;
+  // 1x1 in place (res == din): the gradient lands on the pixels (2y, 2x) only, every other element of din keeps the value it
+  // has -- a quarter of the elements is read and written instead of a full read of res and a full write of din
+  RSLO_CHECK_ARG(res != din || ksize == 1, "rslo_conv2d_dgrad_s2_add: res may alias din for ksize 1 only");
+  gm.cls_out = (res == din && res != nullptr) ? 1 : 4;
   const int rmax = (H + 1) / 2, cmax = (W + 1) / 2;
   gm.tiles_x = (int)rslo_cdiv(cmax, 16); gm.tiles_y = (int)rslo_cdiv(rmax, 4);
   for (int py = 0; py < 2; ++py)

@@ -122,8 +122,9 @@ class _BasicBlockFn(torch.autograd.Function):
         if wd is not None:
             from rslo_amd import streams
             d_od, _, dgd, dbd = fused_bn_backward(d_res, None, od, gd, md, idd, nd, 1.0, False, True, group, world)
-            # the downsample branch's input gradient lands on every other pixel: joined with the 3x3 branch's in its epilogue
-            dx = capi.conv2d_dgrad_s2(d_od, wdt, wd.shape[1], x.shape[2], x.shape[3], 1, residual=dx)
+            # the downsample branch's input gradient lands on every other pixel of every other row: added INTO the 3x3
+            # branch's gradient (this node's own buffer), a quarter of the map touched instead of a full read + write
+            dx = capi.conv2d_dgrad_s2(d_od, wdt, wd.shape[1], x.shape[2], x.shape[3], 1, residual=dx, inplace=True)
             dwd = hip_conv2d.conv1x1s2_wgrad_leaf(x, d_od, wd.shape, params=(wd,))
         elif not res_joined:
             dx.add_(d_res)

@@ -1190,6 +1190,13 @@ def test_conv2d_stride2_fwd_and_dgrad_match_float64_oracle(hip, B, cin, cout, H,
     res = dev(rng.standard_normal((B, cin, H, W)).astype(np.float32))
     joined = hip.conv2d_dgrad_s2(dev(g), hip.conv2d_wsplit_k(dev(w), True), cin, H, W, k, residual=res)
     assert torch.equal(joined, res.clone().add_(dx))
+    if k == 1:      # in place: only the pixels (2y, 2x) of the residual are read and written, same bits
+        buf = res.clone()
+        for piped in (1, 0):
+            with hip.tuning(conv2d_s2_piped=piped):
+                out = hip.conv2d_dgrad_s2(dev(g), hip.conv2d_wsplit_k(dev(w), True), cin, H, W, k, residual=buf, inplace=True)
+            assert out.data_ptr() == buf.data_ptr() and torch.equal(out, joined)
+            buf = res.clone()
 
 
 def test_hip_conv2d_stride2_layers_match_library_through_autograd(hip):
