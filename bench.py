@@ -887,6 +887,9 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # a bench run is minutes long: a peer that never shows up fails the run after 2 minutes, not after the 10-minute
+        # production default (rslo_amd/peer.py reads the variable at import, below)
+        os.environ.setdefault("RSLO_PEER_TIMEOUT_MS", "120000")
         # RSLO_BENCH_ONE_GPU=1: all ranks share GPU 0 and talk through gloo -- a functional check of the multi-rank
         # code path (SyncBN statistics exchange, gradient all-reduce) on a single-GPU box; not a performance mode
         one_gpu = os.environ.get("RSLO_BENCH_ONE_GPU", "0") == "1"
