@@ -849,12 +849,17 @@ static int conv2d_fwd_plan(int B, int cin, int cout, int H, int W, int *tr, int 
   // chunk's weight operands prefetched 9 taps ahead win on every map size of the head (45 vs 67 us on 48x88, 23 vs 54 us
   // on 12x22 against the 8-row / one-tap-ahead configurations, which stay selectable for experiments)
   int t = 4, m = 1;
-  if (cfg_tr == 4 || cfg_tr == 8) t = cfg_tr;
+  if (cfg_tr == 4 || cfg_tr == 6 || cfg_tr == 8) t = cfg_tr;
   if ((cfg_mtw == 1 || cfg_mtw == 2) && cout % (32 * cfg_mtw) == 0) m = cfg_mtw;
   // few input channels feeding many output channels on a full-resolution map (the data gradient of the decoder's
   // 192 -> 64 layer: 64 -> 192 at 96x176): two channel blocks per wave halve the staging per product; measured round 4
   // (scripts/sweep_conv2d_fwd.py, B = 4): 92.2 -> 83.3 us.  Every other head shape is slower that way.
   else if (cfg_mtw == 0 && cfg_tr == 0 && cin <= 64 && cout >= 192 && cout % 64 == 0 && (int64_t)H * W >= 96 * 176) m = 2;
+  // 6-row tiles (conv2d_fwd_tr = 6, round 5): a wave covers 16 channels x 48 pixels -- 2/3 of the weight-operand bytes per
+  // MFMA -- and 128 -> 128 at 48x88 becomes 768 workgroups = exactly 3 per CU.  Back-to-back launches win 5-12 % on the
+  // 48x88 / 96x176 maps (scripts/sweep_conv2d_fwd.py: 36.9 -> 33.1, 66.1 -> 57.9, 34.2 -> 32.6, 91.1 -> 83.4 us), the training
+  // step does not (10.84-10.99 ms either way in six alternating runs: at 3 waves per SIMD the kernel is the one that yields
+  // to the leaf / covariance streams' kernels), so the default stays 4 rows.  Same bits.
   *tr = t; *mtw = m;
   return 1;
 }
@@ -972,7 +977,10 @@ static int conv2d_fwd_launch(const float *in, const void *Ws, const float *bias,
     else C2F_OCC(2, 3);
 #undef C2F_OCC
   } else
-  if (tr == 8 && mtw == 2) hipLaunchKernelGGL((k_conv2d_fwd<8, 2, false>), grid, dim3(256), 0, st, in, ws, bias, gm, out);
+  if (tr == 6 && g_c2f_occ == 4) hipLaunchKernelGGL((k_conv2d_fwd<6, 1, false, false, 1, 4>), grid, dim3(256), 0, st, in, ws, bias, gm, out);
+  else if (tr == 6 && g_c2f_occ == 2) hipLaunchKernelGGL((k_conv2d_fwd<6, 1, true, false, 1, 2>), grid, dim3(256), 0, st, in, ws, bias, gm, out);
+  else if (tr == 6) hipLaunchKernelGGL((k_conv2d_fwd<6, 1, false, false, 1, 3>), grid, dim3(256), 0, st, in, ws, bias, gm, out);
+  else if (tr == 8 && mtw == 2) hipLaunchKernelGGL((k_conv2d_fwd<8, 2, false>), grid, dim3(256), 0, st, in, ws, bias, gm, out);
   else if (tr == 8) hipLaunchKernelGGL((k_conv2d_fwd<8, 1, false>), grid, dim3(256), 0, st, in, ws, bias, gm, out);
   else if (mtw == 2) hipLaunchKernelGGL((k_conv2d_fwd<4, 2, false>), grid, dim3(256), 0, st, in, ws, bias, gm, out);
   else if (kc2) hipLaunchKernelGGL((k_conv2d_fwd<4, 1, true, false, 2>), grid, dim3(512), 0, st, in, ws, bias, gm, out);

@@ -13,7 +13,10 @@ CFGS = [("default", {}), ("lean0", dict(conv2d_fwd_lean=0)), ("4,2", dict(conv2d
         ("4,2,occ4", dict(conv2d_fwd_tr=4, conv2d_fwd_mtw=2, conv2d_fwd_occ=4)),
         ("4,2,occ3", dict(conv2d_fwd_tr=4, conv2d_fwd_mtw=2, conv2d_fwd_occ=3)),
         ("4,1,occ4", dict(conv2d_fwd_tr=4, conv2d_fwd_mtw=1, conv2d_fwd_occ=4)),
-        ("8,1", dict(conv2d_fwd_tr=8, conv2d_fwd_mtw=1)), ("8,2", dict(conv2d_fwd_tr=8, conv2d_fwd_mtw=2))]
+        ("8,1", dict(conv2d_fwd_tr=8, conv2d_fwd_mtw=1)), ("8,2", dict(conv2d_fwd_tr=8, conv2d_fwd_mtw=2)),
+        ("6,1,occ3", dict(conv2d_fwd_tr=6)), ("6,1,occ4", dict(conv2d_fwd_tr=6, conv2d_fwd_occ=4)), ("6,1,fulla", dict(conv2d_fwd_tr=6, conv2d_fwd_occ=2))]
+if os.environ.get("TR6") == "1":
+    CFGS = [c for c in CFGS if c[0] in ("default", "8,1") or c[0].startswith("6,")]
 CFGS += [(k, v) for k, v in (("cw4", dict(conv2d_fwd_cw=4)), ("cw4,tr2", dict(conv2d_fwd_cw=4, conv2d_fwd_tr=2)))
          if os.environ.get("CW", "0") == "1"]
 B = 4

@@ -1075,6 +1075,7 @@ def test_leaf_stream_weight_gradients_accumulate_and_share_safely(hip):
     (2, 96, 64, 25, 23, None),       # odd sizes: ragged tiles in both directions
     (1, 64, 64, 96, 176, None),      # full-resolution BEV map
     (2, 64, 128, 16, 40, "8,2"), (2, 64, 128, 16, 40, "8,1"), (2, 64, 128, 16, 40, "4,2"), (2, 64, 128, 16, 40, "4,1"),
+    (2, 64, 128, 16, 40, "6,1"),     # 6-row tiles on a map they do not divide
     (1, 256, 256, 12, 22, None),     # the library's own choice here: two wave sets per workgroup (forward and gradient)
     (2, 96, 64, 25, 23, "kc=2"),     # two wave sets forced on an ODD number of channel chunks and ragged tiles
     (1, 64, 32, 9, 17, "kc=2"),      # ... and on one chunk per set
@@ -1414,6 +1415,26 @@ def test_conv2d_fwd_xcd_orders_keep_the_bits(hip, B, cin, cout, H, W):
                 assert torch.equal(a, b), xsc
     lib = torch.nn.functional.conv2d(x, w, bias, 1, 1)
     assert float((ref[0] - lib).abs().max()) <= 2e-4 * float(lib.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,cin,cout,H,W", [(4, 128, 128, 48, 88), (1, 64, 64, 96, 176), (2, 96, 64, 25, 23), (4, 256, 128, 48, 88)])
+def test_conv2d_fwd_tile_heights_keep_the_bits(hip, B, cin, cout, H, W):
+    """4-, 6- and 8-row tiles (switch conv2d_fwd_tr) accumulate every output element over the same (channel chunk, tap, product) sequence: forward with bias and the
+    residual epilogue are equal bit for bit."""
+    torch.manual_seed(9)
+    x = torch.randn(B, cin, H, W, device="cuda")
+    w = torch.randn(cout, cin, 3, 3, device="cuda") / (3 * cin ** 0.5)
+    bias = torch.randn(cout, device="cuda")
+    res = torch.randn(B, cout, H, W, device="cuda")
+    ws = hip.conv2d_wsplit(w, False)
+    with hip.tuning(conv2d_fwd_tr=4):
+        ref = [hip.conv2d_fwd(x, ws, bias, cout).clone(), hip.conv2d_fwd(x, ws, None, cout, residual=res).clone()]
+    for tr in (0, 6, 8):
+        with hip.tuning(conv2d_fwd_tr=tr):
+            got = [hip.conv2d_fwd(x, ws, bias, cout), hip.conv2d_fwd(x, ws, None, cout, residual=res)]
+        for a, b in zip(ref, got):
+            assert torch.equal(a, b), tr
 
 
 @pytest.mark.gpu
