@@ -30,7 +30,10 @@ import weakref
 
 import torch
 
-ENABLED = os.environ.get("RSLO_HEAD_GRAPH", "0") == "1"
+# "0" (default) | "fwd": the forward replayed, the backward issued launch by launch over the retained autograd graph of the capture
+# | "1" / "full": forward and backward replayed
+MODE = {"1": "full", "full": "full", "fwd": "fwd"}.get(os.environ.get("RSLO_HEAD_GRAPH", "0"))
+ENABLED = MODE is not None
 WARM_CALLS = 2
 _STATE = weakref.WeakKeyDictionary()      # head module -> _State (graphs neither deep-copy nor pickle: kept off the module)
 
@@ -64,17 +67,45 @@ class _State:
         self.key, self.calls, self.graph, self.failed = None, 0, None, False
 
 
+def _storage_alias(t):
+    """A tensor over the same memory as `t` with its OWN autograd version counter (detach() shares the counter): writes through
+    it, and the optimizer's in-place updates of the parameter it aliases, are invisible to the version checks of a retained
+    autograd graph that saved the other tensor -- the retained graph reads whatever the memory holds when it runs, which is
+    exactly what a replayed forward needs."""
+    return torch.empty(0, dtype=t.dtype, device=t.device).set_(t.untyped_storage(), t.storage_offset(), t.shape, t.stride())
+
+
 class _HeadGraphFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, hg, base):
         ctx.hg = hg
-        hg.static_in.detach().copy_(base)
+        if base.data_ptr() != hg.static_in.data_ptr():
+            hg.input_writer.copy_(base)
         hg.replay(hg.g_fwd, "head_graph_forward")
         return tuple(hg.flat[i].detach() for i in hg.req)
 
     @staticmethod
     def backward(ctx, *gouts):
         hg = ctx.hg
+        if hg.g_bwd is None:
+            # mode "fwd": the backward pass is issued launch by launch (weight gradients on the leaf stream, as ever) over
+            # the autograd graph the captured forward built -- retained, its saved tensors are the static buffers the replay
+            # has just refilled
+            from rslo_amd import streams
+            gs = [g if g is not None else hg.zero_gout(k) for k, g in enumerate(gouts)]
+            if hg.on_callers_stream:
+                with streams.join_in_enclosing_pass():
+                    grads = torch.autograd.grad(hg.raw_req, [hg.static_in] + hg.aliases, gs, retain_graph=True, allow_unused=True)
+            else:       # captured on a side stream (the caller sits on the legacy default stream): the nodes run there and the
+                prev, streams.ENABLED = streams.ENABLED, False      # engine orders that stream against the caller's at the end of
+                try:                                                # the nested pass -- which only covers work issued ON it
+                    grads = torch.autograd.grad(hg.raw_req, [hg.static_in] + hg.aliases, gs, retain_graph=True, allow_unused=True)
+                finally:
+                    streams.ENABLED = prev
+            for p, g in zip(hg.params, grads[1:]):
+                if g is not None:
+                    p.grad = g if p.grad is None else p.grad + g
+            return None, grads[0]
         for k, g in enumerate(gouts):
             if g is None:
                 if not hg.gout_zero[k]:
@@ -98,12 +129,12 @@ class _HeadGraphFn(torch.autograd.Function):
 
 
 class HeadGraph:
-    def __init__(self, head, base, T):
+    def __init__(self, head, base, T, mode):
         from apex import parallel as apex_parallel
-        self.T = T
+        self.T, self.mode = T, mode
         dev = base.device
         named = [(n, p) for n, p in head.named_parameters() if p.requires_grad]
-        params = [p for _, p in named]
+        self.params = params = [p for _, p in named]
         # The capture runs over ALIASES of the parameters (same storage, fresh leaves): a parameter's AccumulateGrad node may be
         # alive from an earlier step and belongs to the stream of that step -- the engine would then order the capturing stream
         # against it inside the capture (on the legacy default stream that ends the capture with a fault).  An alias gets its node
@@ -111,20 +142,28 @@ class HeadGraph:
         # see before it takes a weight gradient.  The split operands the layers look up on the parameter object ride along.
         alias = {}
         for n, p in named:
-            a = p.detach().requires_grad_(True)
-            if hasattr(p, "_hip_split"):
-                a._hip_split = p._hip_split
+            a = _storage_alias(p).requires_grad_(True)
+            sp = getattr(p, "_hip_split", None)
+            if sp is not None:
+                a._hip_split = (sp[0], sp[1], a._version, a.data_ptr()) if (sp[2] == p._version and sp[3] == p.data_ptr()) else None
             alias[n] = a
-        aliases = [alias[n] for n, _ in named]
+        self.aliases = [alias[n] for n, _ in named]
         self.static_in = torch.empty_like(base).requires_grad_(True)
-        self.static_in.detach().copy_(base)
+        self.input_writer = _storage_alias(self.static_in)
+        self.input_writer.copy_(base)
         pool = torch.cuda.graph_pool_handle()
-        self.g_fwd, self.g_bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        self.g_fwd = torch.cuda.CUDAGraph()
+        self.g_bwd = torch.cuda.CUDAGraph() if mode == "full" else None
         isolate = getattr(apex_parallel, "isolated_batch_counts", None)
+        # mode "fwd": the backward nodes run on the stream their forward was captured on -- capture on the caller's stream
+        # (the training stream with its priority) whenever that is not the legacy default stream
+        cur = torch.cuda.current_stream(dev)
+        on = {"stream": cur} if (mode == "fwd" and cur.cuda_stream != 0) else {}
+        self.on_callers_stream = bool(on)
         head.__dict__["_in_graph_capture"] = True
         try:
             with (isolate() if isolate is not None else _null()):
-                with torch.cuda.graph(self.g_fwd, pool=pool, capture_error_mode="thread_local"):
+                with torch.cuda.graph(self.g_fwd, pool=pool, capture_error_mode="thread_local", **on):
                     frames = list(self.static_in.split(base.shape[1] // T, dim=1))
                     for f in frames:
                         f._pair_base = self.static_in
@@ -133,17 +172,26 @@ class HeadGraph:
             self.flat = []
             self.spec = _flatten(out, self.flat)
             self.req = [i for i, t in enumerate(self.flat) if t.requires_grad]
-            self.gouts = [torch.zeros_like(self.flat[i]) for i in self.req]
-            self.gout_zero = [True] * len(self.req)
-            with torch.cuda.graph(self.g_bwd, pool=pool, capture_error_mode="thread_local"):
-                grads = torch.autograd.grad([self.flat[i] for i in self.req], [self.static_in] + aliases, self.gouts,
-                                            allow_unused=True)
+            self.raw_req = [self.flat[i] for i in self.req]
+            self._zero_gouts = {}
+            if mode == "full":
+                self.gouts = [torch.zeros_like(self.flat[i]) for i in self.req]
+                self.gout_zero = [True] * len(self.req)
+                with torch.cuda.graph(self.g_bwd, pool=pool, capture_error_mode="thread_local"):
+                    grads = torch.autograd.grad(self.raw_req, [self.static_in] + self.aliases, self.gouts, allow_unused=True)
+                self.grad_in = grads[0]
+                self.pgrads = [(p, g) for p, g in zip(params, grads[1:]) if g is not None]
+                self.raw_req = None
         finally:
             head.__dict__.pop("_in_graph_capture", None)
-        self.grad_in = grads[0]
-        self.pgrads = [(p, g) for p, g in zip(params, grads[1:]) if g is not None]
         self.flat = [t.detach() for t in self.flat]
         self.device = dev
+
+    def zero_gout(self, k):
+        z = self._zero_gouts.get(k)
+        if z is None:
+            z = self._zero_gouts[k] = torch.zeros_like(self.flat[self.req[k]])
+        return z
 
     @staticmethod
     def replay(g, name):
@@ -220,7 +268,7 @@ def run(head, base, T):
         hip_conv2d.presplit(head)
     if st.graph is None:
         try:
-            st.graph = HeadGraph(head, base, T)
+            st.graph = HeadGraph(head, base, T, MODE or "full")
         except Exception as e:      # the eager pass runs the same kernels: slower issue, same results
             st.failed = True
             from rslo_amd import streams

@@ -62,6 +62,8 @@ def create_cycle_constraint_data(xs, cat_dim=1):
         for j in range(i + 1, len(xs)):
             x1.append(xs[i])
             x2.append(xs[j])
+    if len(x1) == 1:      # two frames: the stack + reshape of one element is the tensor itself (no copy launches)
+        return [x1[0].reshape(-1, *shape[1:]), x2[0].reshape(-1, *shape[1:])]
     return [torch.stack(x1, dim=cat_dim).reshape(-1, *shape[1:]), torch.stack(x2, dim=cat_dim).reshape(-1, *shape[1:])]
 
 

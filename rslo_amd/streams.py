@@ -24,6 +24,26 @@ import torch
 
 ENABLED = os.environ.get("RSLO_WGRAD_STREAM", "1") != "0"
 _state = {}          # device -> {"side", "cur": stream of the backward nodes, "pending", "targets": ids, "keep": inputs}
+_hold = [0]          # > 0: inside join_in_enclosing_pass()
+
+
+class join_in_enclosing_pass:
+    """A backward pass run from INSIDE a node of another one (rslo_amd/headgraph.py: torch.autograd.grad over a retained graph):
+    leaf work issued in it is joined at the end of the ENCLOSING pass, not of the nested one -- the trailing weight gradients
+    keep running beside whatever the enclosing pass issues next.  The callback is queued at exit, in the enclosing pass."""
+
+    def __enter__(self):
+        _hold[0] += 1
+        return self
+
+    def __exit__(self, *exc):
+        _hold[0] -= 1
+        if _hold[0] == 0:
+            for dev, st in _state.items():
+                if st["pending"] and not st.get("queued"):
+                    st["queued"] = True
+                    torch.autograd.Variable._execution_engine.queue_callback(lambda d=dev: join(d))
+        return False
 
 
 def join(device=None):
@@ -33,6 +53,7 @@ def join(device=None):
             from rslo_amd import streamprobe
             streamprobe.wait("leaf_wgrad_stream", st["cur"], lambda: st["cur"].wait_stream(st["side"]))
             st["pending"] = False
+            st["queued"] = False
             st["targets"].clear()
             st["keep"].clear()
 
@@ -67,5 +88,7 @@ def leaf(fn, inputs, params=None):
     st["targets"].update(id(p) for p in params)
     if not st["pending"]:
         st["pending"], st["cur"] = True, cur
-        torch.autograd.Variable._execution_engine.queue_callback(lambda d=dev: join(d))
+        if _hold[0] == 0:
+            st["queued"] = True
+            torch.autograd.Variable._execution_engine.queue_callback(lambda d=dev: join(d))
     return out

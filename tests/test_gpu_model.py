@@ -508,7 +508,8 @@ def test_replayed_head_graphs_train_bit_identically_to_the_eager_pass(hip, monke
     pool = [list(reduced_pair(i)[:2]) for i in range(6)]
 
     def run(graphs):
-        monkeypatch.setattr(headgraph, "ENABLED", graphs)
+        monkeypatch.setattr(headgraph, "ENABLED", bool(graphs))
+        monkeypatch.setattr(headgraph, "MODE", graphs or None)
         torch.manual_seed(7)
         net, _ = workload.build_network()
         net.train()
@@ -518,10 +519,20 @@ def test_replayed_head_graphs_train_bit_identically_to_the_eager_pass(hip, monke
         st = headgraph._STATE.get(net.odom_predictor)
         return hashlib.sha256(state.cpu().numpy().tobytes()).hexdigest(), losses, st, net
     h0, l0, st0, _ = run(False)
-    h1, l1, st1, net = run(True)
-    assert st0 is None and st1 is not None and st1.graph is not None and not st1.failed
-    assert l0 == l1, [(i, a, b) for i, (a, b) in enumerate(zip(l0, l1)) if a != b][:3]
-    assert h0 == h1
+    assert st0 is None
+    for mode in ("fwd", "full"):      # forward replayed + backward issued over the retained autograd graph / both replayed
+        h1, l1, st1, net = run(mode)
+        assert st1 is not None and st1.graph is not None and st1.graph.mode == mode and not st1.failed
+        assert l0 == l1, (mode, [(i, a, b) for i, (a, b) in enumerate(zip(l0, l1)) if a != b][:3])
+        assert h0 == h1, mode
+    # ... and on a non-default stream, where the "fwd" capture sits on the caller's stream and the leaf stream is in use
+    s_ = torch.cuda.Stream()
+    s_.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s_):
+        h2, l2, st2, _ = run("fwd")
+    torch.cuda.current_stream().wait_stream(s_)
+    assert st2.graph.on_callers_stream and l2 == l0 and h2 == h0
+    monkeypatch.setattr(headgraph, "MODE", "full")
     # two backward passes without a reset in between: the head's gradients are the sum of the two passes'
     ex = [workload.make_example(net, [pool[0], pool[1]]), workload.make_example(net, [pool[2], pool[3]])]
     w = next(net.odom_predictor.blocks[1][2].parameters())
