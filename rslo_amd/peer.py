@@ -207,6 +207,17 @@ def check_all():
 
 
 def shutdown():
+    """Close every live comm.  A collective call: no rank may free or unmap its slice while a peer's exchange kernel can still
+    be polling it, so each rank first drains its own device and the ranks meet at a barrier (skipped if the process group is
+    already gone: the caller then vouches that every rank is past its last exchange)."""
+    if any(ent[1] for ent in _COMMS.values()):
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            try:
+                dist.barrier()
+            except Exception:
+                pass
     for k in list(_COMMS):
         ent = _COMMS.pop(k)
         if ent[1]:
