@@ -230,3 +230,35 @@ def test_hip_clip_and_adam_match_torch(hip):
         assert torch.allclose(a, b, rtol=2e-6, atol=1e-7)
         if a.grad is not None:
             assert float(oa.state[a]["step"]) == float(ob.state[b]["step"])      # 7; 4 (late tensor); 6 (skipped once)
+
+
+def test_head_graph_host_logic_without_a_gpu():
+    """rslo_amd/headgraph.py: the prediction dict survives flatten / unflatten (nested lists, Nones, constants); a CPU call
+    is never routed to the graphs (the eager pass is the path there); streams.join_in_enclosing_pass nests and queues nothing
+    when no leaf work is pending."""
+    import torch
+    from rslo_amd import headgraph, streams
+    a, b, c = torch.zeros(2), torch.ones(3), torch.full((1,), 2.0)
+    tree = {"t": [a], "pyr": [[b, c], [c, None]], "k": 3, "tuple": (a, "x")}
+    flat = []
+    spec = headgraph._flatten(tree, flat)
+    assert len(flat) == 5 and all(torch.is_tensor(t) for t in flat)
+    back = headgraph._unflatten(spec, [t + 1 for t in flat])
+    assert back["k"] == 3 and back["pyr"][1][1] is None and back["tuple"][1] == "x"
+    assert torch.equal(back["pyr"][0][1], c + 1) and torch.equal(back["t"][0], a + 1)
+
+    class _Head(torch.nn.Module):
+        graph_capturable = True
+    h = _Head().train()
+    x = torch.zeros(1, 4, 2, 2, requires_grad=True)
+    assert not headgraph.wanted(h, x, 2)            # off by default, and never for a CPU tensor
+    old = headgraph.ENABLED
+    headgraph.ENABLED = True
+    try:
+        assert not headgraph.wanted(h, x, 2) and not headgraph.wanted(h, None, 2)
+    finally:
+        headgraph.ENABLED = old
+    with streams.join_in_enclosing_pass():
+        with streams.join_in_enclosing_pass():
+            assert streams._hold[0] == 2
+    assert streams._hold[0] == 0
