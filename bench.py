@@ -51,6 +51,12 @@ def lib_hash():
         return None
 
 
+def _head_graph_mode(net):
+    from rslo_amd import headgraph
+    st = headgraph._STATE.get(getattr(net, "odom_predictor", None))
+    return st.graph.mode if (st is not None and st.graph is not None) else None
+
+
 def cpu_model():
     try:
         with open("/proc/cpuinfo") as f:
@@ -193,7 +199,7 @@ class ConvProbe:
 
         def timed(fn, name_fn):
             def wrapper(*a, **k):
-                if not probe.enabled:
+                if not probe.enabled or torch.cuda.is_current_stream_capturing():      # (rslo_amd/headgraph.py capturing the head)
                     return fn(*a, **k)
                 e0 = torch.cuda.Event(enable_timing=True)
                 e1 = torch.cuda.Event(enable_timing=True)
@@ -1295,6 +1301,9 @@ def main():
                        # (boundaries between dependent launches + unprobed torch kernels); measured on 3 extra steps
                        # with events around every library call, so its window is longer than the plain step
                        "train_stream_split": stream_split,
+                       # rslo_amd/headgraph.py: "fwd" = the head's forward replayed from a hipGraph (its launches are then not
+                       # among the probed ones: the dense groups of `roofline` are the backward's), None = issued launch by launch
+                       "head_graph": _head_graph_mode(net),
                        "final_loss": round(loss_val, 4)},
             "roofline": roof,
             "cpu_baseline": None,

@@ -1,28 +1,33 @@
-"""The BEV head's training pass as TWO hipGraphs (forward, backward) instead of ~350 launches issued one by one.
+"""The BEV head's training pass with its FORWARD replayed from a hipGraph (default), optionally its backward as well.
 
 The head (reference: rslo/models/odom_pred.py:136-300, UNOdomPredEncDecSVDTempMask) works on maps of a fixed size: its 13
 residual blocks, 3 deblocks, pyramid / confidence branches and the element-wise tail are the same ~170 launches forward and
 ~180 backward in every step, most of them on 24x44 / 12x22 maps where a kernel lasts 5-10 us -- less than the interpreter
-needs to issue it.  The issuing threads (forward: main thread, backward: the autograd thread) are then what the training
-stream waits for (profiles/NOTES.md round 5: host 9.3-11 ms against an 11.6 ms GPU step, idle training stream 1.1 ms).
+needs to issue it.  Issuing one step costs the two host threads 9.3-11 ms (forward 4-5 on the main thread, backward 5-6 on the
+autograd thread), the GPU needs ~11 ms: on the fast hosts of the pool the GPU is the bound, on the slower ones the host is.
 
-Here the head's forward over a STATIC input map is captured once (torch.cuda.graph around the same modules: every capi
-launch goes to the capturing stream) and its backward right after it (torch.autograd.grad over the captured forward's graph,
-weight gradients on the leaf stream exactly as in the eager pass: the fork and the end-of-pass join are part of the capture).
-A step then is: copy the encoder's BEV map into the static input, replay; in backward copy the loss's gradients into the
-static output gradients, replay, hand the static parameter gradients to `p.grad` and the static input gradient to autograd.
-Same kernels, same order per stream, same bits as the eager pass (tests/test_gpu_model.py).
+Mode "fwd" (default): the head's forward over a STATIC input map is captured once (torch.cuda.graph around the same modules:
+every capi launch goes to the capturing stream -- the caller's own stream whenever that is not the legacy default one).  The
+capture also builds the forward's autograd graph over static buffers; it is RETAINED, and every later step is: copy the
+encoder's BEV map into the static input, replay (one launch instead of ~170), and in backward run torch.autograd.grad over the
+retained graph -- the backward kernels issued launch by launch as ever, weight gradients on the leaf stream (rslo_amd/
+streams.py, joined at the end of the ENCLOSING pass).  Parameters and the static input enter the capture as storage aliases
+with their own version counters, so the optimizer's in-place updates and the per-step input copy do not trip the retained
+graph's version checks.  Mode "full" (RSLO_HEAD_GRAPH=1): the backward is captured too (torch.autograd.grad inside a second
+capture) and replayed; static parameter gradients are handed to `p.grad`.
+Same kernels, same order per stream, same bits as the eager pass in both modes (tests/test_gpu_model.py).
+
+Measured, round 5 (profiles/NOTES.md), ms per step eager | fwd | full: C3 (fp32) on a fast host 11.12 | 11.20 | 13.5 (11.9 with
+a linear backward graph), on a slower host 11.55-11.91 | 10.98-11.21; C4 (bf16 operands, less GPU work) 10.9-13.0 | 9.2-9.4.
+"fwd" never loses more than the noise and wins wherever the host is the bound; "full" loses on ROCm 7.2 (a multi-branch
+hipGraph runs behind cross-queue barriers and takes 0.8 ms to launch) and stays an option.
 
 Not captured: the sparse encoder and the losses (row counts change with every scan), the optimizer (already 3 launches), the
 weight-operand split (runs beside the encoder, rslo/layers/hip_conv2d.py presplit_early) and the covariance branch.
 The eager pass stays the path for eval / no-grad calls, other dtypes, multi-rank SyncBatchNorm (its exchange number is a
-launch argument) and the first WARM_CALLS calls of a shape (lazy initialisation must not be captured).
-
-OFF by default (RSLO_HEAD_GRAPH=1 turns it on).  Measured, round 5 (profiles/NOTES.md): the issuing threads' time per step
-drops from 10.4 to 4 ms and the step does not get shorter -- 11.9 ms with the backward as one linear graph against 11.45 ms
-eager; 13.5 ms with the leaf-stream fork inside the graph (hipGraphLaunch of a multi-branch graph: 0.8 ms on the host, and the
-branches run behind cross-queue barriers).  The GPU's own time is the bound of the step, not the host.  Kept for hosts that are
-busy with something else (a real data loader beside 8 ranks).
+launch argument), the first WARM_CALLS calls of a shape (lazy initialisation must not be captured), a second training forward
+issued while the first one's backward is still outstanding (the static activations belong to the first), and any head whose
+capture fails (warned once).  RSLO_HEAD_GRAPH=0 turns the graphs off.
 """
 import os
 import warnings
@@ -32,9 +37,9 @@ import torch
 
 # "0" (default) | "fwd": the forward replayed, the backward issued launch by launch over the retained autograd graph of the capture
 # | "1" / "full": forward and backward replayed
-MODE = {"1": "full", "full": "full", "fwd": "fwd"}.get(os.environ.get("RSLO_HEAD_GRAPH", "0"))
+MODE = {"1": "full", "full": "full", "fwd": "fwd"}.get(os.environ.get("RSLO_HEAD_GRAPH", "fwd"))
 ENABLED = MODE is not None
-WARM_CALLS = 2
+WARM_CALLS = 1      # the first call of a shape runs eagerly (lazy initialisation: workspaces, operand plans, fused-BN state)
 _STATE = weakref.WeakKeyDictionary()      # head module -> _State (graphs neither deep-copy nor pickle: kept off the module)
 
 
@@ -64,7 +69,7 @@ def _unflatten(spec, ts):
 
 class _State:
     def __init__(self):
-        self.key, self.calls, self.graph, self.failed = None, 0, None, False
+        self.key, self.calls, self.graph, self.failed, self.mods = None, 0, None, False, None
 
 
 def _storage_alias(t):
@@ -87,6 +92,7 @@ class _HeadGraphFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *gouts):
         hg = ctx.hg
+        hg.awaiting = False
         if hg.g_bwd is None:
             # mode "fwd": the backward pass is issued launch by launch (weight gradients on the leaf stream, as ever) over
             # the autograd graph the captured forward built -- retained, its saved tensors are the static buffers the replay
@@ -186,6 +192,7 @@ class HeadGraph:
             head.__dict__.pop("_in_graph_capture", None)
         self.flat = [t.detach() for t in self.flat]
         self.device = dev
+        self.awaiting, self._node = False, None
 
     def zero_gout(self, k):
         z = self._zero_gouts.get(k)
@@ -202,8 +209,15 @@ class HeadGraph:
         else:
             g.replay()
 
+    def busy(self):
+        """True while the outputs of the latest replayed forward can still be back-propagated (their node is alive and no
+        backward has run): a second forward would overwrite the static activations that backward needs."""
+        return self.awaiting and self._node is not None and self._node() is not None
+
     def forward(self, base):
         outs = _HeadGraphFn.apply(self, base)
+        self.awaiting = True
+        self._node = weakref.ref(outs[0].grad_fn) if outs and outs[0].grad_fn is not None else None
         ts = list(self.flat)
         for i, o in zip(self.req, outs):
             ts[i] = o
@@ -236,8 +250,7 @@ def wanted(head, base, T):
         return False
     if getattr(head, "use_svd", False) or getattr(head, "track_masks", False):      # a library SVD reads back to the host
         return False
-    from rslo_amd import precision
-    if precision.low_precision() is not None or _multi_rank():
+    if _multi_rank():
         return False
     st = _STATE.get(head)
     return st is None or not st.failed
@@ -250,11 +263,24 @@ def run(head, base, T):
     if st is None:
         st = _STATE[head] = _State()
     # the graphs hold the addresses of the parameters (and of everything else they touch): a head whose storage moved is a new one
-    key = (tuple(base.shape), base.device, T, tuple(p.data_ptr() for p in head.parameters() if p.requires_grad))
+    from rslo_amd import precision
+    if st.mods is None:
+        st.mods = list(head.modules())
+    key = (tuple(base.shape), base.device, T, MODE, precision.low_precision(),
+           tuple(p.data_ptr() for p in head.parameters() if p.requires_grad))
     if st.key != key:
         st.key, st.calls, st.graph = key, 0, None
+    # a replay runs the captured kernels, not the modules: hooks on a submodule and instance-level `forward` overrides (tests,
+    # debugging) would silently not run -- such a head takes the eager pass
+    for m in st.mods:
+        if m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or m._backward_pre_hooks or "forward" in m.__dict__:
+            return None
     if st.graph is None and st.calls < WARM_CALLS:
         st.calls += 1
+        return None
+    if st.graph is not None and st.graph.busy():
+        # two training forwards before a backward (losses of several batches summed): the static activations of the first
+        # are still needed -- this call takes the eager pass, whose activations are its own
         return None
     # the split weight operands of this step (hip_conv2d.presplit_early, beside the encoder): waited for / made OUTSIDE the
     # graphs, which only read them

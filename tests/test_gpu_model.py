@@ -546,6 +546,14 @@ def test_replayed_head_graphs_train_bit_identically_to_the_eager_pass(hip, monke
     for e in ex:
         net(e)["loss"].mean().backward()
     assert torch.equal(w.grad, singles[0] + singles[1])
+    # two forwards BEFORE one backward of the summed losses: the second forward must not overwrite the static activations the
+    # first one's backward needs (it takes the eager pass)
+    monkeypatch.setattr(headgraph, "MODE", "fwd")
+    net.zero_grad(set_to_none=True)
+    l1 = net(ex[0])["loss"].mean()
+    l2 = net(ex[1])["loss"].mean()
+    (l1 + l2).backward()
+    assert torch.equal(w.grad, singles[0] + singles[1])
 
 
 def test_basic_blocks_are_exact_on_the_inputs_they_see_in_the_network(hip):

@@ -251,7 +251,7 @@ def test_head_graph_host_logic_without_a_gpu():
         graph_capturable = True
     h = _Head().train()
     x = torch.zeros(1, 4, 2, 2, requires_grad=True)
-    assert not headgraph.wanted(h, x, 2)            # off by default, and never for a CPU tensor
+    assert not headgraph.wanted(h, x, 2)            # never for a CPU tensor
     old = headgraph.ENABLED
     headgraph.ENABLED = True
     try:
