@@ -248,12 +248,17 @@ def _chk(rc, name):
         raise RsloHipError("%s failed (%d): %s" % (name, rc, lib().rslo_last_error().decode()))
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream():
-    # raw hipStream_t of torch's current stream (fast path; falls back to the public API)
-    try:
-        return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
-    except AttributeError:
-        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # raw hipStream_t of torch's current stream: two C calls (torch.cuda.current_device() re-checks the lazy initialisation in
+    # Python on every call: 1.5 us x ~270 launches per step); falls back to the public API
+    # (a plain int is what a c_void_p parameter wants: no wrapper object per launch)
+    if _raw_stream is not None and _raw_device is not None:
+        return _raw_stream(_raw_device())
+    return torch.cuda.current_stream().cuda_stream
 
 
 def _ptr(t, dtype=None, name="tensor"):
@@ -265,7 +270,7 @@ def _ptr(t, dtype=None, name="tensor"):
         raise RsloHipError("%s must be %s, got %s" % (name, dtype, t.dtype))
     if not t.is_contiguous():
         raise RsloHipError("%s must be contiguous" % name)
-    return C.c_void_p(t.data_ptr())
+    return t.data_ptr()
 
 
 def _dp(t):
@@ -383,7 +388,7 @@ def plan_encoder(spec, lay, clouds, clouds_per_frame, arena, h_counts):
     stream: ONE foreign call, no host read.  arena: uint8 CUDA tensor of >= lay.total_bytes; h_counts: pinned int32
     tensor [PLAN_CNT_WORDS] that receives the counts block (valid once an event recorded after this call has passed)."""
     n = len(clouds)
-    ptrs = (C.c_void_p * n)(*[_ptr(c, torch.float32, "cloud").value if c.shape[0] else None for c in clouds])
+    ptrs = (C.c_void_p * n)(*[_ptr(c, torch.float32, "cloud") if c.shape[0] else None for c in clouds])
     cnts = (C.c_int64 * n)(*[int(c.shape[0]) for c in clouds])
     _chk(lib().rslo_plan_encoder(C.byref(spec), C.byref(lay), n, int(clouds_per_frame), ptrs, cnts, _ptr(arena),
                                  arena.numel(), C.c_void_p(h_counts.data_ptr()), _stream()), "rslo_plan_encoder")
@@ -463,7 +468,7 @@ def weight_split_many(weights):
         f, t = pool[off:off + n], pool[off + n:off + 2 * n]
         off += 2 * n
         views.append((f, t))
-        arr[i] = WeightSplitDesc(_ptr(w, torch.float32, "w").value, f.data_ptr(), t.data_ptr(), *w.shape)
+        arr[i] = WeightSplitDesc(_ptr(w, torch.float32, "w"), f.data_ptr(), t.data_ptr(), *w.shape)
     table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
     return {"table": table, "n": len(weights), "max": max(int(w.numel()) for w in weights), "pool": pool,
             "ptrs": [w.data_ptr() for w in weights]}, views
@@ -937,9 +942,9 @@ def _pyramid_levels(preds, masks, dpreds=None):
     for l, (p, m) in enumerate(zip(preds, masks)):
         if p.dim() != 4 or p.shape[1] != 7 or m.shape[0] != B or p.shape[0] != B or m.shape[2:] != p.shape[2:]:
             raise RsloHipError("pyramid_l2: level %d pred %s / mask %s" % (l, tuple(p.shape), tuple(m.shape)))
-        arr[l].pred = _ptr(p, torch.float32, "pred").value
-        arr[l].mask = _ptr(m, torch.float32, "mask").value
-        arr[l].dpred = _ptr(dpreds[l], torch.float32, "dpred").value if dpreds is not None else None
+        arr[l].pred = _ptr(p, torch.float32, "pred")
+        arr[l].mask = _ptr(m, torch.float32, "mask")
+        arr[l].dpred = _ptr(dpreds[l], torch.float32, "dpred") if dpreds is not None else None
         arr[l].h, arr[l].w, arr[l].mask_channels = p.shape[2], p.shape[3], m.shape[1]
     return arr, B
 
@@ -1028,8 +1033,8 @@ def head_masks_fwd(mask, conf, tq, tq_g, preds):
     dev = mask.device
     L = 1 + len(preds)
     a = HeadMasks()
-    a.mask, a.conf, a.tq, a.tq_g = _ptr(mask, torch.float32, "mask").value, _ptr(conf, torch.float32, "conf").value, \
-        _ptr(tq, torch.float32, "tq").value, _ptr(tq_g, torch.float32, "tq_g").value
+    a.mask, a.conf, a.tq, a.tq_g = _ptr(mask, torch.float32, "mask"), _ptr(conf, torch.float32, "conf"), \
+        _ptr(tq, torch.float32, "tq"), _ptr(tq_g, torch.float32, "tq_g")
     w, occ, mp = [], [mask], []
     for k in range(L):
         wk = torch.empty((B, 2, H >> k, W >> k), dtype=torch.float32, device=dev)
@@ -1039,7 +1044,7 @@ def head_masks_fwd(mask, conf, tq, tq_g, preds):
             ok = torch.empty((B, 1, H >> k, W >> k), dtype=torch.float32, device=dev)
             occ.append(ok)
             a.occ[k] = ok.data_ptr()
-            a.pred[k - 1] = _ptr(preds[k - 1], torch.float32, "pred").value
+            a.pred[k - 1] = _ptr(preds[k - 1], torch.float32, "pred")
             m = torch.empty_like(preds[k - 1])
             mp.append(m)
             a.mpred[k - 1] = m.data_ptr()
@@ -1446,7 +1451,7 @@ def conv2d_wsplit_many(weights):
         f, t = pool[off:off + n], pool[off + n:off + 2 * n]
         off += 2 * n
         views.append((f, t))
-        arr[i] = Conv2dSplitDesc(_ptr(w, torch.float32, "w").value, f.data_ptr(), t.data_ptr(), w.shape[1], w.shape[0],
+        arr[i] = Conv2dSplitDesc(_ptr(w, torch.float32, "w"), f.data_ptr(), t.data_ptr(), w.shape[1], w.shape[0],
                                  w.shape[2] * w.shape[3], 0)
     host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
     table = host.to(dev)

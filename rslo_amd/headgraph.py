@@ -69,7 +69,7 @@ def _unflatten(spec, ts):
 
 class _State:
     def __init__(self):
-        self.key, self.calls, self.graph, self.failed, self.mods = None, 0, None, False, None
+        self.key, self.calls, self.graph, self.failed, self.mods, self.hooks, self.params = None, 0, None, False, None, None, None
 
 
 def _storage_alias(t):
@@ -264,17 +264,18 @@ def run(head, base, T):
         st = _STATE[head] = _State()
     # the graphs hold the addresses of the parameters (and of everything else they touch): a head whose storage moved is a new one
     from rslo_amd import precision
-    if st.mods is None:
-        st.mods = list(head.modules())
-    key = (tuple(base.shape), base.device, T, MODE, precision.low_precision(),
-           tuple(p.data_ptr() for p in head.parameters() if p.requires_grad))
+    if st.mods is None:      # walked once per head (Module.parameters() / .modules() cost ~1 ms per call on this head)
+        mods = list(head.modules())
+        st.mods = [m.__dict__ for m in mods]
+        st.hooks = [d for m in mods for d in (m._forward_hooks, m._forward_pre_hooks, m._backward_hooks, m._backward_pre_hooks)]
+        st.params = [p for p in head.parameters() if p.requires_grad]
+    key = (tuple(base.shape), base.device, T, MODE, precision.low_precision(), tuple([p.data_ptr() for p in st.params]))
     if st.key != key:
         st.key, st.calls, st.graph = key, 0, None
     # a replay runs the captured kernels, not the modules: hooks on a submodule and instance-level `forward` overrides (tests,
     # debugging) would silently not run -- such a head takes the eager pass
-    for m in st.mods:
-        if m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or m._backward_pre_hooks or "forward" in m.__dict__:
-            return None
+    if any(st.hooks) or any("forward" in d for d in st.mods):
+        return None
     if st.graph is None and st.calls < WARM_CALLS:
         st.calls += 1
         return None
