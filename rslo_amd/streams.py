@@ -73,14 +73,24 @@ def leaf(fn, inputs, params=None):
         join(dev)              # everything issued so far is ordered in front of the accumulation that follows
         return fn()
     side = st["side"]
-    ev = torch.cuda.Event()
+    # one event per device, recorded anew for every call (a wait takes the state of the event at the time of the call); inside a
+    # stream capture every fork gets its own
+    ev = st.get("event")
+    if ev is None or torch.cuda.is_current_stream_capturing():
+        ev = torch.cuda.Event()
+        if not torch.cuda.is_current_stream_capturing():
+            st["event"] = ev
     ev.record(cur)
     side.wait_event(ev)
-    with torch.cuda.stream(side):
+    torch.cuda.set_stream(side)
+    try:
         out = fn()
+    finally:
+        torch.cuda.set_stream(cur)
+    # the inputs stay referenced until the join, after which the issuing stream is ordered behind every read of the side
+    # stream: no block of theirs can be handed out again before that (no record_stream needed for them)
     for t in inputs:
         if t is not None:
-            t.record_stream(side)
             st["keep"].append(t)
     for t in (out if isinstance(out, (tuple, list)) else (out,)):
         if t is not None:
