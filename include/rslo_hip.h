@@ -156,7 +156,7 @@ RSLO_API void rslo_spconv_set_tiling(int rbw, int ks);
  *     calls (process-wide; the defaults are the measured choices).  Names (rslo_tuning_name(i), i = 0 .. until NULL):
  *     conv2d_wgrad_s2_fullres, conv2d_wgrad_nb, conv2d_wgrad_wgs, conv2d_fwd_tr, conv2d_fwd_mtw, conv2d_fwd_occ,
  *     conv2d_fwd_kc, conv2d_fwd_lean, conv2d_fwd_xsc, conv2d_s2_mtw, conv2d_s2_xsc, bn_small_rc, spconv_rbw, spconv_ks,
- *     spconv_v, spconv_wgrad_split, wgrad_xcd, vfe_lds, chamfer, chamfer_segments, conv2d_ablate, resid_bwd_ordered, dense_tiled, conv2d_s2_piped (meanings: csrc/rslo_common.h RsloTune).  Every setting
+ *     spconv_v, spconv_wgrad_split, wgrad_xcd, vfe_lds, chamfer, chamfer_segments, conv2d_ablate, resid_bwd_ordered, dense_tiled, conv2d_s2_piped, conv1x1_split (meanings: csrc/rslo_common.h RsloTune).  Every setting
  *     computes the same products; only tiling, summation grouping and launch geometry change.  Unknown name -> RSLO_EINVAL.
  *     (The reference has no counterpart: spconv / cuDNN pick their algorithms internally.) */
 RSLO_API int rslo_tuning_set(const char *name, int value);

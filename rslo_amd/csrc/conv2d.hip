@@ -1538,6 +1538,73 @@ __global__ __launch_bounds__(256) void k_conv1x1_dgrad(const float *__restrict__
   }
 }
 
+// The same two passes with the CHANNELS of a pixel dealt to the four waves of a workgroup (cin <= 64; round 5).  One thread
+// per pixel is 1056 waves on the 96x176 maps -- one per SIMD -- and its inner loops were latency chains: the weights sat in LDS
+// behind a run-time `co < cout` test, so every product waited for its own ds_read (0.3 us per channel: 20 us even on a 24x44
+// map).  Here COUT is a template parameter and the weights are read straight from global memory at wave-uniform addresses
+// (scalar loads into SGPRs, no LDS); a workgroup takes 64 pixels, wave w loads channels [w G, (w + 1) G) of them at once
+// (G = ceil(cin / 4) <= 16 loads in flight per lane), and the waves add their products onto the running sums one after the
+// other through LDS: the additions of a pixel happen in channel order exactly as in k_conv1x1_fwd -- same bits.
+template <int COUT>
+__global__ __launch_bounds__(256) void k_conv1x1_fwd4(const float *__restrict__ x, const float *__restrict__ W,
+                                                      const float *__restrict__ bias, int B, int cin, int HW,
+                                                      float *__restrict__ out) {
+  __shared__ float run[COUT][64];
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+  const bool valid = i < (int64_t)B * HW;
+  const int b = valid ? (int)(i / HW) : 0, p = valid ? (int)(i - (int64_t)b * HW) : 0;
+  const int G = (cin + 3) >> 2, c0 = wid * G, c1 = (c0 + G < cin) ? c0 + G : cin;
+  const float *xp = x + (int64_t)b * cin * HW + p;
+  float xv[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) xv[u] = (valid && c0 + u < c1) ? xp[(int64_t)(c0 + u) * HW] : 0.f;
+  float acc[COUT];
+  for (int step = 0; step < 4; ++step) {
+    if (wid == step) {
+#pragma unroll
+      for (int co = 0; co < COUT; ++co) acc[co] = step == 0 ? (bias ? bias[co] : 0.f) : run[co][lane];
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        if (c0 + u < c1) {
+#pragma unroll
+          for (int co = 0; co < COUT; ++co) acc[co] += W[co * cin + c0 + u] * xv[u];
+        }
+      if (step < 3) {
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) run[co][lane] = acc[co];
+      } else if (valid) {
+        float *op = out + (int64_t)b * COUT * HW + p;
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) op[(int64_t)co * HW] = acc[co];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// dx channels [w G, (w + 1) G) of 64 pixels per wave: every channel's sum is formed as in k_conv1x1_dgrad (same bits)
+template <int COUT>
+__global__ __launch_bounds__(256) void k_conv1x1_dgrad4(const float *__restrict__ dy, const float *__restrict__ W, int B,
+                                                        int cin, int HW, float *__restrict__ dx) {
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+  if (i >= (int64_t)B * HW) return;
+  const int b = (int)(i / HW), p = (int)(i - (int64_t)b * HW);
+  float g[COUT];
+  const float *gp = dy + (int64_t)b * COUT * HW + p;
+#pragma unroll
+  for (int co = 0; co < COUT; ++co) g[co] = gp[(int64_t)co * HW];
+  const int G = (cin + 3) >> 2, c0 = wid * G, c1 = (c0 + G < cin) ? c0 + G : cin;
+  float *dp = dx + (int64_t)b * cin * HW + p;
+  for (int ci = c0; ci < c1; ++ci) {
+    float s = 0.f;
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) s += W[co * cin + ci] * g[co];
+    dp[(int64_t)ci * HW] = s;
+  }
+}
+
 // grid (cin + 1, S): block (ci, slab) sums dy[b][co][p] * x[b][ci][p] over its pixel slab (ci == cin: x = 1, the bias
 // gradient); part [S][cin + 1][C11_MAXCO]
 __global__ __launch_bounds__(256) void k_conv1x1_wgrad(const float *__restrict__ x, const float *__restrict__ dy, int B,
@@ -1602,8 +1669,14 @@ extern "C" size_t rslo_conv1x1_wgrad_ws_bytes(int B, int cin, int cout, int HW) 
 extern "C" int rslo_conv1x1_fwd(const float *x, const float *W, const float *bias, int B, int cin, int cout, int HW,
                                 float *out, void *stream) {
   RSLO_CHECK_ARG(x && W && out && rslo_conv1x1_supported(cin, cout) && B >= 1 && HW >= 1, "rslo_conv1x1_fwd: bad arguments");
-  hipLaunchKernelGGL(k_conv1x1_fwd, dim3((unsigned)rslo_cdiv((int64_t)B * HW, 256)), dim3(256), 0, (hipStream_t)stream, x,
-                     W, bias, B, cin, cout, HW, out);
+  if (cin <= 64 && rslo_tune(RSLO_TUNE_CONV1X1_SPLIT)) {       // channels dealt to the four waves of a workgroup
+    const dim3 grid4((unsigned)rslo_cdiv((int64_t)B * HW, 64));
+#define C11_F4(N) case N: hipLaunchKernelGGL((k_conv1x1_fwd4<N>), grid4, dim3(256), 0, (hipStream_t)stream, x, W, bias, B, cin, HW, out); break;
+    switch (cout) { C11_F4(1) C11_F4(2) C11_F4(3) C11_F4(4) C11_F4(5) C11_F4(6) C11_F4(7) C11_F4(8) }
+#undef C11_F4
+  } else
+    hipLaunchKernelGGL(k_conv1x1_fwd, dim3((unsigned)rslo_cdiv((int64_t)B * HW, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       W, bias, B, cin, cout, HW, out);
   RSLO_CHECK_LAUNCH("k_conv1x1_fwd");
   return RSLO_OK;
 }
@@ -1611,8 +1684,14 @@ extern "C" int rslo_conv1x1_fwd(const float *x, const float *W, const float *bia
 extern "C" int rslo_conv1x1_dgrad(const float *dy, const float *W, int B, int cin, int cout, int HW, float *dx,
                                   void *stream) {
   RSLO_CHECK_ARG(dy && W && dx && rslo_conv1x1_supported(cin, cout) && B >= 1 && HW >= 1, "rslo_conv1x1_dgrad: bad arguments");
-  hipLaunchKernelGGL(k_conv1x1_dgrad, dim3((unsigned)rslo_cdiv((int64_t)B * HW, 256)), dim3(256), 0, (hipStream_t)stream,
-                     dy, W, B, cin, cout, HW, dx);
+  if (cin <= 64 && rslo_tune(RSLO_TUNE_CONV1X1_SPLIT)) {
+    const dim3 grid4((unsigned)rslo_cdiv((int64_t)B * HW, 64));
+#define C11_D4(N) case N: hipLaunchKernelGGL((k_conv1x1_dgrad4<N>), grid4, dim3(256), 0, (hipStream_t)stream, dy, W, B, cin, HW, dx); break;
+    switch (cout) { C11_D4(1) C11_D4(2) C11_D4(3) C11_D4(4) C11_D4(5) C11_D4(6) C11_D4(7) C11_D4(8) }
+#undef C11_D4
+  } else
+    hipLaunchKernelGGL(k_conv1x1_dgrad, dim3((unsigned)rslo_cdiv((int64_t)B * HW, 256)), dim3(256), 0, (hipStream_t)stream,
+                       dy, W, B, cin, cout, HW, dx);
   RSLO_CHECK_LAUNCH("k_conv1x1_dgrad");
   return RSLO_OK;
 }

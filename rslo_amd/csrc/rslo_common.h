@@ -66,6 +66,7 @@ enum RsloTune {
   RSLO_TUNE_RESID_BWD_ORDERED,         // 1 (default): partner gradients of the covariance residual added in source order (bit-reproducible); 0: atomics
   RSLO_TUNE_DENSE_TILED,               // 1 (default): dense() scatter / gather through 64 x 64 LDS tiles; 0: one thread per element
   RSLO_TUNE_CONV2D_S2_PIPED,           // 1 (default): stride-2 kernels with compile-time tap lists and operands one tap ahead (k_conv2d_str2); 0: k_conv2d_str
+  RSLO_TUNE_CONV1X1_SPLIT,             // 1 (default): 1x1 output convolutions (cin <= 64) with a pixel's channels dealt to four waves; 0: one thread per pixel
   RSLO_TUNE_COUNT
 };
 extern int g_rslo_tune[RSLO_TUNE_COUNT];

@@ -1284,6 +1284,25 @@ def test_conv1x1_kernels_match_oracle_and_autograd(hip, B, cin, cout, H, W):
     assert torch.equal(dW1, dW2)
 
 
+@pytest.mark.parametrize("B,cin,cout,H,W", [(4, 64, 7, 96, 176), (2, 32, 1, 96, 176), (3, 32, 7, 7, 9), (1, 50, 8, 5, 13),
+                                            (2, 3, 2, 4, 4)])
+def test_conv1x1_channel_split_kernels_keep_the_bits(hip, B, cin, cout, H, W):
+    """k_conv1x1_fwd4 / _dgrad4 (a pixel's channels dealt to the four waves of a workgroup, switch conv1x1_split) add a
+    pixel's products in channel order like the one-thread-per-pixel kernels: forward (with and without bias) and data
+    gradient are equal bit for bit, ragged channel groups and pixel counts included."""
+    torch.manual_seed(5)
+    x = torch.randn(B, cin, H, W, device="cuda")
+    w = torch.randn(cout, cin, 1, 1, device="cuda")
+    bias = torch.randn(cout, device="cuda")
+    gy = torch.randn(B, cout, H, W, device="cuda")
+    with hip.tuning(conv1x1_split=0):
+        ref = [hip.conv1x1_fwd(x, w, bias), hip.conv1x1_fwd(x, w, None), hip.conv1x1_dgrad(gy, w)]
+    with hip.tuning(conv1x1_split=1):
+        got = [hip.conv1x1_fwd(x, w, bias), hip.conv1x1_fwd(x, w, None), hip.conv1x1_dgrad(gy, w)]
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("stride", [1, 2])
 def test_basic_block_as_one_autograd_node_gives_the_same_bits(hip, stride, monkeypatch):
     """custom_resnet_spc._BasicBlockFn (one autograd node per BasicBlock) against the layer-by-layer nodes
