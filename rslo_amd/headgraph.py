@@ -70,6 +70,7 @@ def _unflatten(spec, ts):
 class _State:
     def __init__(self):
         self.key, self.calls, self.graph, self.failed, self.mods, self.hooks, self.params = None, 0, None, False, None, None, None
+        self.parked = None          # (key, graphs) of the shape used before the current one
 
 
 def _storage_alias(t):
@@ -271,7 +272,15 @@ def run(head, base, T):
         st.params = [p for p in head.parameters() if p.requires_grad]
     key = (tuple(base.shape), base.device, T, MODE, precision.low_precision(), tuple([p.data_ptr() for p in st.params]))
     if st.key != key:
-        st.key, st.calls, st.graph = key, 0, None
+        # a second shape (the short last batch of an epoch) gets its own graphs; the previous one is parked and comes back
+        # without a new capture -- two shapes are kept, an older one is dropped with its memory pool
+        prev = (st.key, st.graph) if st.graph is not None else None
+        if st.parked is not None and st.parked[0] == key:
+            st.key, st.calls, st.graph, st.parked = key, WARM_CALLS, st.parked[1], prev
+        else:
+            st.key, st.calls, st.graph = key, 0, None
+            if prev is not None:
+                st.parked = prev
     # a replay runs the captured kernels, not the modules: hooks on a submodule and instance-level `forward` overrides (tests,
     # debugging) would silently not run -- such a head takes the eager pass
     if any(st.hooks) or any("forward" in d for d in st.mods):

@@ -546,6 +546,17 @@ def test_replayed_head_graphs_train_bit_identically_to_the_eager_pass(hip, monke
     for e in ex:
         net(e)["loss"].mean().backward()
     assert torch.equal(w.grad, singles[0] + singles[1])
+    # a second batch size gets its own graphs and the first one's come back without a new capture
+    st = headgraph._STATE[net.odom_predictor]
+    g_two = st.graph
+    one = workload.make_example(net, [pool[4]])
+    for _ in range(3):
+        net.zero_grad(set_to_none=True)
+        net(one)["loss"].mean().backward()
+    assert st.graph is not None and st.graph is not g_two and st.parked is not None and st.parked[1] is g_two
+    net.zero_grad(set_to_none=True)
+    net(ex[0])["loss"].mean().backward()
+    assert st.graph is g_two and torch.equal(w.grad, singles[0])
     # two forwards BEFORE one backward of the summed losses: the second forward must not overwrite the static activations the
     # first one's backward needs (it takes the eager pass)
     monkeypatch.setattr(headgraph, "MODE", "fwd")
