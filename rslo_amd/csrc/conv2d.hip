@@ -917,11 +917,20 @@ extern "C" int rslo_conv2d_fwd_add_bf16(const float *in, const void *Ws, const f
   return conv2d_fwd_launch(in, Ws, bias, B, cin, cout, H, W, out, stream, true, res);
 }
 
+// conv2d_wl.hip: the same convolution with the weight operands shared through LDS (bit-identical results)
+int conv2d_wl_wanted(int B, int cin, int cout, int H, int W);
+int conv2d_wl_launch(const float *in, const void *Ws, const float *bias, const float *res, int B, int cin, int cout, int H,
+                     int W, float *out, void *stream);
+
 static int conv2d_fwd_launch(const float *in, const void *Ws, const float *bias, int B, int cin, int cout, int H, int W,
                              float *out, void *stream, bool lp, const float *res) {
   int tr, mtw;
   RSLO_CHECK_ARG(conv2d_fwd_plan(B, cin, cout, H, W, &tr, &mtw), "rslo_conv2d_fwd: unsupported shape cin=%d cout=%d H=%d W=%d",
                  cin, cout, H, W);
+  // explicit tile settings (experiments, the tiling tests) keep k_conv2d_fwd
+  if (!lp && !rslo_tune(RSLO_TUNE_CONV2D_FWD_TR) && !rslo_tune(RSLO_TUNE_CONV2D_FWD_MTW) && !g_c2f_occ &&
+      !rslo_tune(RSLO_TUNE_CONV2D_FWD_KC) && rslo_tune(RSLO_TUNE_CONV2D_FWD_LEAN) < 0 && conv2d_wl_wanted(B, cin, cout, H, W))
+    return conv2d_wl_launch(in, Ws, bias, res, B, cin, cout, H, W, out, stream);
   Conv2dFwdGeom gm;
   gm.B = B; gm.cin = cin; gm.cout = cout; gm.H = H; gm.W = W;
   gm.res = res;

@@ -67,6 +67,7 @@ enum RsloTune {
   RSLO_TUNE_DENSE_TILED,               // 1 (default): dense() scatter / gather through 64 x 64 LDS tiles; 0: one thread per element
   RSLO_TUNE_CONV2D_S2_PIPED,           // 1 (default): stride-2 kernels with compile-time tap lists and operands one tap ahead (k_conv2d_str2); 0: k_conv2d_str
   RSLO_TUNE_CONV1X1_SPLIT,             // 1 (default): 1x1 output convolutions (cin <= 64) with a pixel's channels dealt to four waves; 0: one thread per pixel
+  RSLO_TUNE_CONV2D_FWD_WL,             // dense 3x3 stride-1 forward / data gradient with the weight operands through LDS (k_conv2d_wl, measured slower): 0 (default) never; 1: 8-row tiles; 3: 6-row tiles
   RSLO_TUNE_COUNT
 };
 extern int g_rslo_tune[RSLO_TUNE_COUNT];

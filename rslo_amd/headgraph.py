@@ -109,6 +109,11 @@ class _HeadGraphFn(torch.autograd.Function):
                     grads = torch.autograd.grad(hg.raw_req, [hg.static_in] + hg.aliases, gs, retain_graph=True, allow_unused=True)
                 finally:
                     streams.ENABLED = prev
+            # The alias leaves never carry a gradient, so streams.leaf() always took the side stream for them; an ADD into a
+            # gradient that is already there (accumulation over several backward() calls, zero_grad(set_to_none=False)) reads
+            # `g` on the issuing stream: the leaf stream is joined first, exactly as streams.leaf() does on the eager pass
+            if any(g is not None and p.grad is not None for p, g in zip(hg.params, grads[1:])):
+                streams.join(hg.device)
             for p, g in zip(hg.params, grads[1:]):
                 if g is not None:
                     p.grad = g if p.grad is None else p.grad + g

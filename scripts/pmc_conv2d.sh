@@ -12,7 +12,7 @@ run() {
 import csv, sys, collections
 agg = collections.defaultdict(float); cnt = collections.Counter()
 for d in csv.DictReader(open(sys.argv[1])):
-    if "k_conv2d_fwd" not in d["Kernel_Name"] and "k_conv2d_g2" not in d["Kernel_Name"]: continue
+    if not any(k in d["Kernel_Name"] for k in ("k_conv2d_fwd", "k_conv2d_g2", "k_conv2d_wl")): continue
     agg[d["Counter_Name"]] += float(d["Counter_Value"]); cnt[d["Counter_Name"]] += 1
 print({a: round(b / max(cnt[a], 1)) for a, b in agg.items()})
 PY

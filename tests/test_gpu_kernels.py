@@ -1457,6 +1457,36 @@ def test_conv2d_fwd_tile_heights_keep_the_bits(hip, B, cin, cout, H, W):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,cin,cout,H,W", [(4, 128, 128, 48, 88), (1, 64, 64, 96, 176), (2, 96, 64, 25, 23), (4, 256, 128, 48, 88),
+                                            (1, 32, 32, 7, 9), (3, 64, 192, 12, 22), (1, 512, 128, 24, 44)])
+def test_conv2d_lds_weight_kernel_keeps_the_bits(hip, B, cin, cout, H, W):
+    """k_conv2d_wl (csrc/conv2d_wl.hip: a workgroup's weight operands copied once into LDS by LDS-DMA, kernel-row stages in a
+    two-deep ring, a wave = both 16-channel blocks x 2 rows) accumulates every output element over the same (channel chunk, tap,
+    product) sequence as k_conv2d_fwd: forward with bias, the data gradient (transposed operand) and the residual epilogue are
+    equal bit for bit -- 8-row and 6-row tiles, ragged edges in both directions, maps smaller than one tile, 1 to 16 chunks."""
+    torch.manual_seed(11)
+    x = torch.randn(B, cin, H, W, device="cuda")
+    g = torch.randn(B, cout, H, W, device="cuda")
+    w = torch.randn(cout, cin, 3, 3, device="cuda") / (3 * cin ** 0.5)
+    bias = torch.randn(cout, device="cuda")
+    res = torch.randn(B, cout, H, W, device="cuda")
+    ws, wst = hip.conv2d_wsplit(w, False), hip.conv2d_wsplit(w, True)
+
+    def run():
+        return [hip.conv2d_fwd(x, ws, bias, cout).clone(), hip.conv2d_fwd(x, ws, None, cout, residual=res).clone(),
+                hip.conv2d_fwd(g, wst, None, cin).clone()]
+    with hip.tuning(conv2d_fwd_wl=0, conv2d_fwd_kc=1):      # (two wave sets add their halves of the chunks: another order)
+        ref = run()
+    for mode in (1, 3):
+        with hip.tuning(conv2d_fwd_wl=mode):
+            for i in range(3):      # repeated launches: a stale weight stage or halo would show as a difference between runs
+                for a, b in zip(ref, run()):
+                    assert torch.equal(a, b), (mode, i)
+    lib = torch.nn.functional.conv2d(x, w, bias, 1, 1)
+    assert float((ref[0] - lib).abs().max()) <= 2e-4 * float(lib.abs().max())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B,cin,cout,H,W,k", [(4, 128, 128, 48, 88, 3), (2, 64, 128, 21, 37, 3), (4, 128, 256, 24, 44, 1),
                                                (1, 256, 128, 96, 176, 3)])
 def test_conv2d_stride2_xcd_orders_keep_the_bits(hip, B, cin, cout, H, W, k):

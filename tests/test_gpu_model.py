@@ -565,6 +565,23 @@ def test_replayed_head_graphs_train_bit_identically_to_the_eager_pass(hip, monke
     l2 = net(ex[1])["loss"].mean()
     (l1 + l2).backward()
     assert torch.equal(w.grad, singles[0] + singles[1])
+    # mode "fwd" on a non-default stream (capture on the caller's stream, weight gradients on the leaf stream): two backward
+    # passes WITHOUT a reset -- the add into the gradient that is already there must wait for the leaf stream (the alias
+    # leaves never carry a gradient, so streams.leaf() cannot see the accumulation by itself)
+    torch.cuda.synchronize()
+    headgraph._STATE.pop(net.odom_predictor, None)      # the graphs captured from the legacy default stream above
+    s_.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s_):
+        for _ in range(2):      # the stream's own capture of this shape (first call warm-up, second captures)
+            net.zero_grad(set_to_none=True)
+            net(ex[0])["loss"].mean().backward()
+        assert headgraph._STATE[net.odom_predictor].graph.on_callers_stream
+        for rep in range(3):
+            net.zero_grad(set_to_none=True)
+            for e in ex:
+                net(e)["loss"].mean().backward()
+            assert torch.equal(w.grad, singles[0] + singles[1]), rep
+    torch.cuda.current_stream().wait_stream(s_)
 
 
 def test_basic_blocks_are_exact_on_the_inputs_they_see_in_the_network(hip):
