@@ -806,6 +806,37 @@ def run_encoder(args, world, rank, local_rank, dist_on, dev):
         print(json.dumps(line), flush=True)
 
 
+# --------------------------------------------------------------------------------------------- the step of a rank of an N > 1 job
+def multirank_child(args, cores=None, sibling_blocks=None):
+    """This script's C3 step in a child process with a ONE-rank RCCL group and the multi-rank code path forced
+    (RSLO_FORCE_SYNCBN_PATH=1: SyncBN statistics meet the "peers" through a world-size-1 peer comm, gradient buckets go through
+    the overlapped RCCL exchange) -> the child's JSON line.  cores: confine the child to these CPUs (and turn its own pinning
+    off); sibling_blocks: CPU lists that are kept busy by interpreter loops for the duration (one process per CPU)."""
+    import subprocess
+    env = dict(os.environ, RSLO_BENCH_FORCE_DIST="1", RSLO_FORCE_SYNCBN_PATH="1", RSLO_BENCH_MULTIRANK_CHILD="0",
+               RSLO_BENCH_OTHER_CONFIGS="0", RSLO_BENCH_STREAM_SPLIT="0", MASTER_PORT=str(_free_port()))
+    pre = None
+    if cores is not None:
+        env["RSLO_BENCH_PIN"] = "0"
+        pre = (lambda cs=set(cores): os.sched_setaffinity(0, cs))
+    sibs = []
+    try:
+        for blk in (sibling_blocks or []):
+            for c in blk:
+                sibs.append(subprocess.Popen(
+                    [sys.executable, "-c", "import os\nos.sched_setaffinity(0, {%d})\nx = list(range(4096))\nwhile True:\n    s = sum(x); x = x[1:] + x[:1]" % c],
+                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL))
+        cmd = [sys.executable, os.path.abspath(__file__), "--steps", "40", "--warmup", "10", "--no-cpu-baseline",
+               "--no-kernel-events", "--batch", str(args.batch), "--rings", str(args.rings), "--dtype", args.dtype]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, preexec_fn=pre)
+        return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    finally:
+        for p_ in sibs:          # exactly the processes started here
+            p_.kill()
+        for p_ in sibs:
+            p_.wait()
+
+
 # --------------------------------------------------------------------------------------------- the other BASELINE configs
 def other_configs(args):
     """BASELINE.json configs[1] (C2), configs[3] (C4, its per-GPU part) and configs[4] (C5, its per-GPU part) from the default
@@ -1367,22 +1398,34 @@ def main():
             # a world-size-1 peer comm, gradient buckets go through the overlapped RCCL exchange).  What it cannot show is
             # the peers' arrival skew and the xGMI hop.
             try:
-                import subprocess
-                env = dict(os.environ, RSLO_BENCH_FORCE_DIST="1", RSLO_FORCE_SYNCBN_PATH="1", RSLO_BENCH_MULTIRANK_CHILD="0",
-                           RSLO_BENCH_STREAM_SPLIT="0", MASTER_PORT=str(_free_port()))
-                cmd = [sys.executable, os.path.abspath(__file__), "--steps", "40", "--warmup", "10", "--no-cpu-baseline",
-                       "--no-kernel-events", "--batch", str(args.batch), "--rings", str(args.rings), "--dtype", args.dtype]
-                r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
-                child = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+                child = multirank_child(args)
                 line["config"]["multirank_path_ms_per_step"] = child["ms_per_step"]
                 line["config"]["multirank_path"] = {
                     "ms_per_step": child["ms_per_step"], "plain_ms_per_step": line["ms_per_step"],
                     "ratio_to_plain": round(child["ms_per_step"] / line["ms_per_step"], 4),
+                    # round 6: the head's forward is replayed from its hipGraph on this path too (the SyncBN exchanges inside the
+                    # capture carry numbers relative to a device word, rslo_amd/headgraph.py)
+                    "head_graph": child["config"].get("head_graph"),
+                    "host_issue_ms_per_step": child["config"].get("host_issue_ms_per_step"),
                     "syncbn_exchange": (child.get("rccl") or {}).get("syncbn_exchange"),
                     "what": "one-rank RCCL group, multi-rank SyncBN path forced (RSLO_FORCE_SYNCBN_PATH=1), overlapped "
                             "gradient exchange on; 40 steps in a child process on the same GPU"}
+                # what the HOST costs a rank of an 8-rank job: the same child confined to 2 cores, alone and beside 7 sibling
+                # processes that keep the neighbouring 2-core blocks busy with interpreter work (CPU-only contention: caches,
+                # memory, the socket's power budget; the GPU is this child's alone)
+                if pinned is not None and os.environ.get("RSLO_BENCH_HOST_PRICE", "1") != "0":
+                    allowed = sorted(orig_affinity)
+                    blk = [c for c in range(pinned[0], pinned[0] + 16) if c in allowed]
+                    if len(blk) == 16:
+                        two = multirank_child(args, cores=blk[:2])
+                        sib = multirank_child(args, cores=blk[:2], sibling_blocks=[blk[2 * k:2 * k + 2] for k in range(1, 8)])
+                        line["config"]["multirank_path"]["two_cores_per_rank"] = {
+                            "ms_per_step": two["ms_per_step"], "host_issue_ms_per_step": two["config"].get("host_issue_ms_per_step"),
+                            "with_7_busy_siblings": {"ms_per_step": sib["ms_per_step"],
+                                                     "host_issue_ms_per_step": sib["config"].get("host_issue_ms_per_step")},
+                            "cores": blk[:2]}
             except Exception as e:
-                line["config"]["multirank_path"] = {"error": repr(e)}
+                line["config"]["multirank_path"] = dict(line["config"].get("multirank_path") or {}, error=repr(e))
         if (world == 1 and not dist_on and args.config == "c3" and args.batch == 4 and args.rings == 64
                 and os.environ.get("RSLO_BENCH_OTHER_CONFIGS", "1") != "0"):
             # BASELINE.json configs[1], [3] (per-GPU part) and [4] measured by the SAME invocation the driver runs, each in a

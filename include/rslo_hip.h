@@ -756,6 +756,16 @@ RSLO_API int rslo_bn2d_bwd_peer(void *comm, const float *dy, const float *y, con
                                 const float *save_mean, const float *save_invstd, const double *count_all, int N, int C,
                                 int HW, float act_slope, int has_act, float *dx, float *dres, float *dgamma, float *dbeta,
                                 void *stream);
+/*      Round 6: exchanges inside a REPLAYED stream capture (the BEV head's forward as one hipGraph, rslo_amd/headgraph.py --
+ *      the reference runs the same 45 SyncBatchNorm layers per step under apex DDP, train_hdf5.py:463).  Between
+ *      rslo_peer_capture_begin and _end every exchange launched on the comm (rslo_peer_allreduce_f64, rslo_bn2d_fwd_peer /
+ *      _bwd_peer) carries its number RELATIVE to a device word: its launch arguments are replay-invariant.  _end returns how
+ *      many exchanges the capture holds.  In front of EVERY replay the caller issues rslo_peer_replay_prepare(comm, n, stream)
+ *      on the replaying stream: it writes the word (= exchanges issued so far) in stream order and advances the comm's counter
+ *      past the replay's n exchanges.  Every rank must capture the same exchanges in the same order (they run the same model). */
+RSLO_API int rslo_peer_capture_begin(void *comm);
+RSLO_API int rslo_peer_capture_end(void *comm, int *n_exchanges);
+RSLO_API int rslo_peer_replay_prepare(void *comm, int n_exchanges, void *stream);
 RSLO_API int rslo_peer_destroy(void *comm);
 
 #ifdef __cplusplus

@@ -163,6 +163,9 @@ SIGNATURES = {
     "rslo_loss_tail_fwd": (C.c_int, [_vp, _vp, _vp]),
     "rslo_loss_tail_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rslo_peer_wait_samples": (C.c_int, [_vp, _vp, _i]),
+    "rslo_peer_capture_begin": (C.c_int, [_vp]),
+    "rslo_peer_capture_end": (C.c_int, [_vp, _vp]),
+    "rslo_peer_replay_prepare": (C.c_int, [_vp, _i, _vp]),
     "rslo_bn2d_peer_supported": (C.c_int, [_i, _i, _i]),
     "rslo_bn2d_fwd_peer": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, C.c_float, C.c_float, C.c_float, _vp, _vp, _vp, _vp,
                                      _vp, _vp, _vp]),

@@ -116,6 +116,19 @@ FORCE_MULTI = os.environ.get("RSLO_FORCE_SYNCBN_PATH", "0") == "1"
 FUSED_PEER_BN = os.environ.get("RSLO_SYNCBN_FUSED_PEER", "1") != "0"
 
 
+# The single-launch / three-launch choice of a layer must come out THE SAME on every rank (a rank on the other path would wait
+# in another slot region until the timeout).  It depends on the per-rank batch through N * HW <= 17408: with equal per-rank
+# batches -- what the reference's DistributedSampler + drop-less DataLoader deliver, train_hdf5.py:300-330 -- every rank decides
+# alike from its own shape.  Where per-rank batch sizes CAN differ (a short last batch on some ranks), set
+# RSLO_SYNCBN_MAX_BATCH to the largest per-rank batch: the choice is then made for that size on every rank, whatever it holds.
+MAX_BATCH = int(os.environ.get("RSLO_SYNCBN_MAX_BATCH", "0"))
+
+
+def _peer_shape_ok(x):
+    from rslo_amd import capi
+    return capi.bn2d_peer_supported(max(int(x.shape[0]), MAX_BATCH), x.shape[1], x.shape[2] * x.shape[3])
+
+
 def _fused_peer_comm(group):
     """The peer comm when this layer's exchange happens inside the BatchNorm kernel, else None."""
     if not FUSED_PEER_BN:
@@ -149,7 +162,7 @@ def fused_bn_forward(bn, x, res, weight, bias, slope, group, world):
     mom = bn.momentum          # fusable() leaves momentum=None (cumulative average) to the unfused path
     if _multi(world):
         comm = _fused_peer_comm(group)
-        if comm is not None and capi.bn2d_peer_supported(x.shape[0], x.shape[1], x.shape[2] * x.shape[3]):
+        if comm is not None and _peer_shape_ok(x):
             # one launch: the workgroup of a channel meets its peers on the other ranks between its sums and its apply
             return capi.bn2d_fwd_peer(comm, x, res, weight, bias, bn.running_mean if track else None,
                                       bn.running_var if track else None, mom, bn.eps, slope)
@@ -172,7 +185,7 @@ def fused_bn_backward(gy, y, x, weight, mean, invstd, cnt_all, slope, has_res, a
         return capi.bn2d_bwd_local(gy, y, x, weight, mean, invstd, slope, has_act, has_res, want_affine=affine)
     comm = _fused_peer_comm(group)      # the same condition the forward took: both directions of a layer use one path
     if comm is not None:
-        if capi.bn2d_peer_supported(x.shape[0], x.shape[1], x.shape[2] * x.shape[3]):
+        if _peer_shape_ok(x):
             return capi.bn2d_bwd_peer(comm, gy, y, x, weight, mean, invstd, cnt_all, slope, has_act, has_res, want_affine=affine)
     red, dgamma, dbeta = capi.bn2d_bwd_reduce(gy, y, x, mean, invstd, slope, has_act, want_affine=affine)
     _sum_over_ranks(red, group)

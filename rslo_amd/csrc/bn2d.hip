@@ -499,12 +499,17 @@ __global__ __launch_bounds__(T) void k_bn2d_bwd_small_rc(const float *__restrict
 struct BnPeer {
   PeerTable tab;
   int me, world;
-  unsigned long long seq;
-  size_t chan;                  // byte offset of the slot's channel records inside a slice
+  PeerSeq sq;                   // exchange number: absolute, or relative to the device word of a replayed capture (peer_comm.h)
+  size_t chan_off;              // byte offset of the channel records inside a slot
   long long timeout_ticks;
   unsigned long long *status;
   unsigned *wait_ring;
 };
+
+__device__ __forceinline__ unsigned long long bn_peer_seq(const BnPeer &pc) { return peer_seq_value(pc.sq); }
+__device__ __forceinline__ size_t bn_peer_chan(const BnPeer &pc) {
+  return (size_t)(peer_seq_value(pc.sq) % PEER_SLOTS) * pc.sq.slot_bytes + pc.chan_off;
+}
 
 // Vectorised register-cached forms (round 5): HW % 4 == 0 (every map of the head), 16-byte loads and stores -- element group
 // q = tid + i T covers the channel's values 4q .. 4q+3 (one (n, c) row: a group never straddles rows).  A thread keeps E4 groups:
@@ -541,7 +546,7 @@ __global__ __launch_bounds__(T) void k_bn2d_fwd_small_rc4(const float *__restric
   bool ok = true;
   if constexpr (PEER) {
     __shared__ double sh[4 + 4 * PEER_MAX_WORLD];
-    ok = peer_chan_exchange(pc.tab, pc.me, pc.world, pc.seq, pc.chan, c, pc.timeout_ticks, pc.status, ex, sh, pc.wait_ring);
+    ok = peer_chan_exchange(pc.tab, pc.me, pc.world, bn_peer_seq(pc), bn_peer_chan(pc), c, pc.timeout_ticks, pc.status, ex, sh, pc.wait_ring);
   }
   const double cnt = ex[2];
   const double m = ex[0] / cnt;
@@ -625,7 +630,7 @@ __global__ __launch_bounds__(T) void k_bn2d_bwd_small_rc4(const float *__restric
   bool ok = true;
   if constexpr (PEER) {
     __shared__ double sh[4 + 4 * PEER_MAX_WORLD];
-    ok = peer_chan_exchange(pc.tab, pc.me, pc.world, pc.seq, pc.chan, c, pc.timeout_ticks, pc.status, ex, sh, pc.wait_ring);
+    ok = peer_chan_exchange(pc.tab, pc.me, pc.world, bn_peer_seq(pc), bn_peer_chan(pc), c, pc.timeout_ticks, pc.status, ex, sh, pc.wait_ring);
   }
   const double cnt = PEER ? *count_all : (double)N * HW;      // element count over all ranks, as exchanged in the forward pass
   const float k0 = (gamma ? gamma[c] : 1.f) * invstd;
@@ -678,7 +683,7 @@ __global__ __launch_bounds__(T) void k_bn2d_fwd_rc_peer(const float *__restrict_
   __shared__ double sh[4 + 4 * PEER_MAX_WORLD];
   bn_block_sum2_t<T>(s, q, tot);
   double ex[3] = {tot[0], tot[1], (double)N * HW};
-  const bool ok = peer_chan_exchange(pc.tab, pc.me, pc.world, pc.seq, pc.chan, c, pc.timeout_ticks, pc.status, ex, sh, pc.wait_ring);
+  const bool ok = peer_chan_exchange(pc.tab, pc.me, pc.world, bn_peer_seq(pc), bn_peer_chan(pc), c, pc.timeout_ticks, pc.status, ex, sh, pc.wait_ring);
   const double cnt = ex[2];
   const double m = ex[0] / cnt;
   double var = ex[1] / cnt - m * m;
@@ -743,7 +748,7 @@ __global__ __launch_bounds__(T) void k_bn2d_bwd_rc_peer(const float *__restrict_
     if (dgamma) dgamma[c] = (float)tot[1];
   }
   double ex[3] = {tot[0], tot[1], 0.0};
-  const bool ok = peer_chan_exchange(pc.tab, pc.me, pc.world, pc.seq, pc.chan, c, pc.timeout_ticks, pc.status, ex, sh, pc.wait_ring);
+  const bool ok = peer_chan_exchange(pc.tab, pc.me, pc.world, bn_peer_seq(pc), bn_peer_chan(pc), c, pc.timeout_ticks, pc.status, ex, sh, pc.wait_ring);
   const double cnt = *count_all;        // element count over all ranks, as exchanged in the forward pass
   const float k0 = (gamma ? gamma[c] : 1.f) * invstd;
   float mg = (float)(ex[0] / cnt), mgx = (float)(ex[1] / cnt);
@@ -1014,13 +1019,15 @@ extern "C" int rslo_bn2d_peer_supported(int N, int C, int HW) {
   return rslo_tune(RSLO_TUNE_BN_SMALL_RC) && C >= 1 && C <= PEER_MAX_CH && (int64_t)N * HW <= 1024 * BN_RC_BIG;
 }
 
-static BnPeer bn_peer_args(RsloPeerComm *c, unsigned long long seq) {
+static BnPeer bn_peer_args(RsloPeerComm *c) {
   BnPeer pc;
-  pc.tab = c->tab; pc.me = c->rank; pc.world = c->world; pc.seq = seq;
-  pc.chan = (size_t)(seq % PEER_SLOTS) * c->slot_bytes + peer_chan_off(c->max_n);
+  pc.tab = c->tab; pc.me = c->rank; pc.world = c->world;
+  pc.sq = peer_next_seq(c);
+  pc.chan_off = peer_chan_off(c->max_n);
   pc.timeout_ticks = c->timeout_ticks; pc.status = c->status_dev;
   pc.wait_ring = c->wait_ring_dev;
-  c->wait_ring_host[seq % PEER_WAIT_RING] = 0;      // (host write to pinned memory, ordered before the launch that follows)
+  // (host write to pinned memory, ordered before the launch that follows; a captured launch: rslo_peer_replay_prepare)
+  if (!c->capturing) c->wait_ring_host[pc.sq.seq % PEER_WAIT_RING] = 0;
   return pc;
 }
 
@@ -1032,8 +1039,7 @@ extern "C" int rslo_bn2d_fwd_peer(void *comm, const float *x, const float *res, 
   RSLO_CHECK_ARG(c && x && save_mean && save_invstd && count_out && y && rslo_bn2d_peer_supported(N, C, HW),
                  "rslo_bn2d_fwd_peer: bad arguments / shape outside the single-launch range (N*HW = %lld, C = %d)",
                  (long long)N * HW, C);
-  const unsigned long long seq = c->seq + 1;
-  const BnPeer pc = bn_peer_args(c, seq);
+  const BnPeer pc = bn_peer_args(c);
   const int64_t per = (int64_t)N * HW;
   hipStream_t st = (hipStream_t)stream;
 #define BN_GO(T, E) hipLaunchKernelGGL((k_bn2d_fwd_rc_peer<T, E>), dim3(C), dim3(T), 0, st, x, res, gamma, beta, N, C, HW, eps, \
@@ -1052,7 +1058,7 @@ extern "C" int rslo_bn2d_fwd_peer(void *comm, const float *x, const float *res, 
 #undef BN_GO
 #undef BN_GO4
   RSLO_CHECK_LAUNCH("k_bn2d_fwd_rc_peer");
-  c->seq = seq;
+  peer_commit_seq(c);
   return RSLO_OK;
 }
 
@@ -1064,8 +1070,7 @@ extern "C" int rslo_bn2d_bwd_peer(void *comm, const float *dy, const float *y, c
   RSLO_CHECK_ARG(c && dy && x && save_mean && save_invstd && count_all && dx && rslo_bn2d_peer_supported(N, C, HW),
                  "rslo_bn2d_bwd_peer: bad arguments / shape outside the single-launch range");
   RSLO_CHECK_ARG(!has_act || y, "rslo_bn2d_bwd_peer: y is needed for the activation mask");
-  const unsigned long long seq = c->seq + 1;
-  const BnPeer pc = bn_peer_args(c, seq);
+  const BnPeer pc = bn_peer_args(c);
   const int64_t per = (int64_t)N * HW;
   hipStream_t st = (hipStream_t)stream;
 #define BN_GO(T, E) hipLaunchKernelGGL((k_bn2d_bwd_rc_peer<T, E>), dim3(C), dim3(T), 0, st, dy, y, x, gamma, save_mean, save_invstd, \
@@ -1084,6 +1089,6 @@ extern "C" int rslo_bn2d_bwd_peer(void *comm, const float *dy, const float *y, c
 #undef BN_GO
 #undef BN_GO4
   RSLO_CHECK_LAUNCH("k_bn2d_bwd_rc_peer");
-  c->seq = seq;
+  peer_commit_seq(c);
   return RSLO_OK;
 }

@@ -36,9 +36,11 @@
 // release / acquire fences of the flag protocol wrote back / invalidated the XCD's L2 once per exchange, right behind a
 // convolution that left it dirty).
 __global__ void __launch_bounds__(1024) k_peer_allreduce(double *__restrict__ t, int n, PeerTable tab, int me, int world,
-                                                         unsigned long long seq, size_t slot_off, long long timeout_ticks,
+                                                         PeerSeq sq, long long timeout_ticks,
                                                          unsigned long long *__restrict__ status, unsigned *__restrict__ wait_ring) {
   const int tid = threadIdx.x;
+  const unsigned long long seq = peer_seq_value(sq);
+  const size_t slot_off = (size_t)(seq % PEER_SLOTS) * sq.slot_bytes;
   const unsigned tag = (unsigned)seq;
   __shared__ int s_bad;
   if (tid == 0) s_bad = 0;
@@ -87,9 +89,11 @@ __global__ void __launch_bounds__(1024) k_peer_allreduce(double *__restrict__ t,
 // the granule form there.  The system-scope fences write back / invalidate the XCD's L2, which is why the device transport
 // does not use this form.
 __global__ void __launch_bounds__(1024) k_peer_allreduce_flag(double *__restrict__ t, int n, PeerTable tab, int me, int world,
-                                                              unsigned long long seq, size_t slot_off, long long timeout_ticks,
+                                                              PeerSeq sq, long long timeout_ticks,
                                                               unsigned long long *__restrict__ status, unsigned *__restrict__ wait_ring) {
   const int tid = threadIdx.x;
+  const unsigned long long seq = peer_seq_value(sq);
+  const size_t slot_off = (size_t)(seq % PEER_SLOTS) * sq.slot_bytes;
   unsigned char *mine = tab.base[me] + slot_off;
   unsigned long long *my_flag = (unsigned long long *)mine;
   double *my_pay = (double *)(mine + 64);
@@ -150,6 +154,10 @@ static int peer_common_init(RsloPeerComm *c, int rank, int world, int max_n) {
   RSLO_HIP(hipHostMalloc((void **)&c->wait_ring_host, PEER_WAIT_RING * sizeof(unsigned), hipHostMallocMapped));
   memset(c->wait_ring_host, 0, PEER_WAIT_RING * sizeof(unsigned));
   RSLO_HIP(hipHostGetDevicePointer((void **)&c->wait_ring_dev, c->wait_ring_host, 0));
+  RSLO_HIP(hipMalloc((void **)&c->seq_word_dev, 64));
+  RSLO_HIP(hipMemset(c->seq_word_dev, 0, 64));
+  c->capturing = 0;
+  c->cap_count = 0;
   return RSLO_OK;
 }
 
@@ -262,18 +270,53 @@ extern "C" int rslo_peer_set_timeout_ms(void *comm, int ms) {
 extern "C" int rslo_peer_allreduce_f64(void *comm, double *t, int n, void *stream) {
   RsloPeerComm *c = (RsloPeerComm *)comm;
   RSLO_CHECK_ARG(c && t && n >= 1 && n <= c->max_n, "rslo_peer_allreduce_f64: n = %d outside 1..%d", n, c ? c->max_n : 0);
-  const unsigned long long seq = c->seq + 1;      // committed only once the launch is in the stream
-  const size_t slot_off = (size_t)(seq % PEER_SLOTS) * c->slot_bytes;
+  const PeerSeq sq = peer_next_seq(c);      // committed only once the launch is in the stream
   const int threads = n >= 512 ? 1024 : (n >= 192 ? 512 : 256);
-  c->wait_ring_host[seq % PEER_WAIT_RING] = 0;
+  if (!c->capturing) c->wait_ring_host[sq.seq % PEER_WAIT_RING] = 0;
   if (c->transport == 0)
     hipLaunchKernelGGL(k_peer_allreduce_flag, dim3(1), dim3(threads), 0, (hipStream_t)stream, t, n, c->tab, c->rank, c->world,
-                       seq, slot_off, c->timeout_ticks, c->status_dev, c->wait_ring_dev);
+                       sq, c->timeout_ticks, c->status_dev, c->wait_ring_dev);
   else
-    hipLaunchKernelGGL(k_peer_allreduce, dim3(1), dim3(threads), 0, (hipStream_t)stream, t, n, c->tab, c->rank, c->world, seq,
-                       slot_off, c->timeout_ticks, c->status_dev, c->wait_ring_dev);
+    hipLaunchKernelGGL(k_peer_allreduce, dim3(1), dim3(threads), 0, (hipStream_t)stream, t, n, c->tab, c->rank, c->world, sq,
+                       c->timeout_ticks, c->status_dev, c->wait_ring_dev);
   RSLO_CHECK_LAUNCH("k_peer_allreduce");
-  c->seq = seq;
+  peer_commit_seq(c);
+  return RSLO_OK;
+}
+
+// ---- exchanges inside a replayed stream capture (rslo_amd/headgraph.py: the BEV head's forward as one hipGraph) ---------------
+// Every rank captures the same layers in the same order, so exchange k of a replay is number base + k on every rank, base = the
+// number of exchanges the rank had issued when the replay was launched.  The kernels of the capture read base from a device
+// word; rslo_peer_replay_prepare writes it in stream order (a one-thread kernel whose argument is the host's counter) and
+// advances the host's counter past the replay's exchanges -- launches issued eagerly before and after a replay (the backward
+// pass) keep their absolute numbers, and the order of all exchanges on the stream is the order of their numbers, as ever.
+__global__ void k_peer_set_word(unsigned long long *word, unsigned long long value) { *word = value; }
+
+extern "C" int rslo_peer_capture_begin(void *comm) {
+  RsloPeerComm *c = (RsloPeerComm *)comm;
+  RSLO_CHECK_ARG(c && !c->capturing, "rslo_peer_capture_begin: no comm, or a capture is already open");
+  c->capturing = 1;
+  c->cap_count = 0;
+  return RSLO_OK;
+}
+
+extern "C" int rslo_peer_capture_end(void *comm, int *n_exchanges) {
+  RsloPeerComm *c = (RsloPeerComm *)comm;
+  RSLO_CHECK_ARG(c && c->capturing, "rslo_peer_capture_end: no capture is open");
+  c->capturing = 0;
+  if (n_exchanges) *n_exchanges = (int)c->cap_count;
+  return RSLO_OK;
+}
+
+extern "C" int rslo_peer_replay_prepare(void *comm, int n_exchanges, void *stream) {
+  RsloPeerComm *c = (RsloPeerComm *)comm;
+  RSLO_CHECK_ARG(c && !c->capturing && n_exchanges >= 0 && n_exchanges <= PEER_WAIT_RING,
+                 "rslo_peer_replay_prepare: bad arguments (or a capture is open)");
+  if (n_exchanges == 0) return RSLO_OK;
+  hipLaunchKernelGGL(k_peer_set_word, dim3(1), dim3(1), 0, (hipStream_t)stream, c->seq_word_dev, c->seq);
+  RSLO_CHECK_LAUNCH("k_peer_set_word");
+  for (int k = 1; k <= n_exchanges; ++k) c->wait_ring_host[(c->seq + k) % PEER_WAIT_RING] = 0;
+  c->seq += (unsigned long long)n_exchanges;
   return RSLO_OK;
 }
 
@@ -317,6 +360,7 @@ extern "C" int rslo_peer_destroy(void *comm) {
   }
   (void)hipHostFree(c->status_host);
   (void)hipHostFree(c->wait_ring_host);
+  if (c->seq_word_dev) (void)hipFree(c->seq_word_dev);
   delete c;
   return RSLO_OK;
 }

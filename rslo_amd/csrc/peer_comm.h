@@ -18,6 +18,12 @@ struct RsloPeerComm {
   int rank, world, max_n, transport;        // 0 host shm, 1 device ipc
   size_t slice_bytes, slot_bytes;
   unsigned long long seq;                   // exchanges issued so far
+  // Exchanges launched inside a stream capture (rslo_peer_capture_begin .. _end) carry their number RELATIVE to a device word
+  // the host sets in stream order in front of every replay (rslo_peer_replay_prepare): number = *seq_word + k, k = 1, 2, ... in
+  // capture order.  Their launch arguments are then replay-invariant.
+  unsigned long long *seq_word_dev;
+  int capturing;
+  unsigned long long cap_count;             // exchanges launched since rslo_peer_capture_begin
   PeerTable tab;
   unsigned long long *status_host;          // pinned: [0] = first sequence number that timed out (0 = none), [1] = peer
   unsigned long long *status_dev;
@@ -36,6 +42,26 @@ struct RsloPeerComm {
 // a slot = { 64 bytes unused | payload [max_n] x 2 granules { half u32 | tag u32 } | per-channel records [PEER_MAX_CH] x 6 granules { half u32 | tag u32 } }
 static inline size_t peer_chan_off(int max_n) { return 64 + (size_t)max_n * 2 * sizeof(unsigned long long); }
 static inline size_t peer_slot_bytes(int max_n) { return peer_chan_off(max_n) + (size_t)PEER_MAX_CH * PEER_CH_BYTES; }
+
+// The exchange number as a kernel sees it: absolute (word == NULL) or relative to the device word of a replayed capture.
+struct PeerSeq {
+  unsigned long long seq;
+  const unsigned long long *word;
+  size_t slot_bytes;
+};
+__device__ __forceinline__ unsigned long long peer_seq_value(const PeerSeq &q) { return q.seq + (q.word ? *q.word : 0ULL); }
+// (host) the number the next launch carries, and its commit once the launch is in the stream
+static inline PeerSeq peer_next_seq(const RsloPeerComm *c) {
+  PeerSeq q;
+  q.seq = c->capturing ? c->cap_count + 1 : c->seq + 1;
+  q.word = c->capturing ? c->seq_word_dev : nullptr;
+  q.slot_bytes = c->slot_bytes;
+  return q;
+}
+static inline void peer_commit_seq(RsloPeerComm *c) {
+  if (c->capturing) ++c->cap_count;
+  else ++c->seq;
+}
 
 // Per-channel rendezvous of ONE workgroup with the workgroups of the same channel on the other ranks (fused SyncBN,
 // bn2d.hip).  v[3] in: this rank's values of channel c (valid in thread 0); out: their sums over the ranks IN RANK ORDER,

@@ -24,8 +24,11 @@ hipGraph runs behind cross-queue barriers and takes 0.8 ms to launch) and stays 
 
 Not captured: the sparse encoder and the losses (row counts change with every scan), the optimizer (already 3 launches), the
 weight-operand split (runs beside the encoder, rslo/layers/hip_conv2d.py presplit_early) and the covariance branch.
-The eager pass stays the path for eval / no-grad calls, other dtypes, multi-rank SyncBatchNorm (its exchange number is a
-launch argument), the first WARM_CALLS calls of a shape (lazy initialisation must not be captured), a second training forward
+Multi-rank SyncBatchNorm (round 6): the statistics exchanges of the node's peer comm are launched inside the capture with
+numbers relative to a device word that is set in front of every replay (rslo_amd/peer.py capture_begin / replay_prepare), so a
+rank of an N > 1 job replays the same graph the one-rank step does; exchanges that are RCCL collectives (several hosts,
+RSLO_SYNCBN_EXCHANGE=rccl) keep the head eager.
+The eager pass stays the path for eval / no-grad calls, other dtypes, the first WARM_CALLS calls of a shape (lazy initialisation must not be captured), a second training forward
 issued while the first one's backward is still outstanding (the static activations belong to the first), and any head whose
 capture fails (warned once).  RSLO_HEAD_GRAPH=0 turns the graphs off.
 """
@@ -87,6 +90,8 @@ class _HeadGraphFn(torch.autograd.Function):
         ctx.hg = hg
         if base.data_ptr() != hg.static_in.data_ptr():
             hg.input_writer.copy_(base)
+        if hg.n_fwd_exchanges:       # multi-rank SyncBN inside the capture: this replay's exchange numbers (rslo_amd/peer.py)
+            hg.comm.replay_prepare(hg.n_fwd_exchanges)
         hg.replay(hg.g_fwd, "head_graph_forward")
         return tuple(hg.flat[i].detach() for i in hg.req)
 
@@ -131,6 +136,8 @@ class _HeadGraphFn(torch.autograd.Function):
         for p, sg in hg.pgrads:
             if p.grad is sg:
                 p.grad = sg.clone()
+        if hg.n_bwd_exchanges:
+            hg.comm.replay_prepare(hg.n_bwd_exchanges)
         hg.replay(hg.g_bwd, "head_graph_backward")
         for p, sg in hg.pgrads:
             if p.grad is None:
@@ -172,15 +179,26 @@ class HeadGraph:
         cur = torch.cuda.current_stream(dev)
         on = {"stream": cur} if (mode == "fwd" and cur.cuda_stream != 0) else {}
         self.on_callers_stream = bool(on)
+        # Multi-rank SyncBatchNorm inside the capture: the layers' statistics exchanges (same-stream kernels of the node's peer
+        # comm) are launched with numbers RELATIVE to a device word that replay_prepare() sets in front of every replay, so
+        # their launch arguments do not change from replay to replay (csrc/peer.hip rslo_peer_capture_begin).
+        self.comm = _peer_comm() if _multi_rank() else None
+        self.n_fwd_exchanges = self.n_bwd_exchanges = 0
         head.__dict__["_in_graph_capture"] = True
         try:
             with (isolate() if isolate is not None else _null()):
-                with torch.cuda.graph(self.g_fwd, pool=pool, capture_error_mode="thread_local", **on):
-                    frames = list(self.static_in.split(base.shape[1] // T, dim=1))
-                    for f in frames:
-                        f._pair_base = self.static_in
-                    with torch.enable_grad():
-                        out = torch.func.functional_call(head, alias, (frames,))
+                if self.comm is not None:
+                    self.comm.capture_begin()
+                try:
+                    with torch.cuda.graph(self.g_fwd, pool=pool, capture_error_mode="thread_local", **on):
+                        frames = list(self.static_in.split(base.shape[1] // T, dim=1))
+                        for f in frames:
+                            f._pair_base = self.static_in
+                        with torch.enable_grad():
+                            out = torch.func.functional_call(head, alias, (frames,))
+                finally:
+                    if self.comm is not None:
+                        self.n_fwd_exchanges = self.comm.capture_end()
             self.flat = []
             self.spec = _flatten(out, self.flat)
             self.req = [i for i, t in enumerate(self.flat) if t.requires_grad]
@@ -189,8 +207,14 @@ class HeadGraph:
             if mode == "full":
                 self.gouts = [torch.zeros_like(self.flat[i]) for i in self.req]
                 self.gout_zero = [True] * len(self.req)
-                with torch.cuda.graph(self.g_bwd, pool=pool, capture_error_mode="thread_local"):
-                    grads = torch.autograd.grad(self.raw_req, [self.static_in] + self.aliases, self.gouts, allow_unused=True)
+                if self.comm is not None:
+                    self.comm.capture_begin()
+                try:
+                    with torch.cuda.graph(self.g_bwd, pool=pool, capture_error_mode="thread_local"):
+                        grads = torch.autograd.grad(self.raw_req, [self.static_in] + self.aliases, self.gouts, allow_unused=True)
+                finally:
+                    if self.comm is not None:
+                        self.n_bwd_exchanges = self.comm.capture_end()
                 self.grad_in = grads[0]
                 self.pgrads = [(p, g) for p, g in zip(params, grads[1:]) if g is not None]
                 self.raw_req = None
@@ -241,8 +265,23 @@ class _null:
 def _multi_rank():
     import torch.distributed as dist
     if os.environ.get("RSLO_FORCE_SYNCBN_PATH", "0") == "1":
-        return True
+        return dist.is_available() and dist.is_initialized()
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def _peer_comm():
+    """The node's peer comm if it EXISTS already (created by the first eager forward: a collective call, never made here), else
+    None.  With it every SyncBN exchange of the head is a same-stream kernel that can go into the capture; without it (several
+    hosts, RSLO_SYNCBN_EXCHANGE=rccl, an explicit process group) the exchanges are RCCL collectives and the head stays eager."""
+    import sys
+    import torch.distributed as dist
+    pr = sys.modules.get("rslo_amd.peer")
+    if pr is None:
+        return None
+    ent = pr._COMMS.get(id(dist.group.WORLD))
+    if ent is None or ent[0] is not dist.group.WORLD or not ent[1]:
+        return None
+    return ent[1]
 
 
 def wanted(head, base, T):
@@ -256,8 +295,8 @@ def wanted(head, base, T):
         return False
     if getattr(head, "use_svd", False) or getattr(head, "track_masks", False):      # a library SVD reads back to the host
         return False
-    if _multi_rank():
-        return False
+    if _multi_rank() and _STATE.get(head) is not None and _STATE[head].calls >= WARM_CALLS and _peer_comm() is None:
+        return False      # (the warm-up call of a shape is eager anyway and is what creates the comm)
     st = _STATE.get(head)
     return st is None or not st.failed
 

@@ -66,6 +66,21 @@ class PeerComm:
         return {"samples": n, "p50_us": round(v[n // 2], 2), "p99_us": round(v[min(n - 1, (99 * n) // 100)], 2),
                 "max_us": round(v[-1], 2)}
 
+    # ---- exchanges inside a replayed stream capture (rslo_amd/headgraph.py) -------------------------------------------------
+    def capture_begin(self):
+        """Exchanges launched from here to capture_end() carry numbers relative to a device word (replay-invariant launches)."""
+        capi._chk(capi.lib().rslo_peer_capture_begin(self.handle), "rslo_peer_capture_begin")
+
+    def capture_end(self):
+        """-> how many exchanges the capture holds."""
+        n = C.c_int(0)
+        capi._chk(capi.lib().rslo_peer_capture_end(self.handle, C.byref(n)), "rslo_peer_capture_end")
+        return int(n.value)
+
+    def replay_prepare(self, n):
+        """In front of every replay of a capture with n exchanges, on the replaying (current) stream."""
+        capi._chk(capi.lib().rslo_peer_replay_prepare(self.handle, int(n), capi._stream()), "rslo_peer_replay_prepare")
+
     def set_timeout_ms(self, ms):
         capi._chk(capi.lib().rslo_peer_set_timeout_ms(self.handle, int(ms)), "rslo_peer_set_timeout_ms")
 
@@ -143,7 +158,10 @@ def create(transport="host", group=None):
             good = 0
         # the single-launch SyncBN kernels meet their peers per channel (rslo_bn2d_fwd_peer): rank-dependent constants
         # per channel, whose mean over the ranks is known
+        fused_on = os.environ.get("RSLO_SYNCBN_FUSED_PEER", "1") != "0"
         for Cc, hw in (((8, 16), (64, 1056), (512, 4)) if not shared_device else ((8, 16),)):
+            if not (fused_on and capi.bn2d_peer_supported(2, Cc, hw)):
+                continue          # the fused kernels are switched off / do not take the shape: nothing of theirs to test
             x = (torch.arange(Cc, dtype=torch.float32, device="cuda").view(1, Cc, 1, 1) + float(rank + 1)).expand(2, Cc, hw, 1).contiguous()
             y, mean, invstd, cnt = capi.bn2d_fwd_peer(comm, x, None, None, None, None, None, 0.1, 1e-5, 1.0)
             want = torch.arange(Cc, dtype=torch.float32) + float(tri) / world
@@ -192,6 +210,9 @@ def all_reduce_(t, group=None, fallback_group=None):
     """Sum of t (float64 CUDA, <= 1024 elements) over the ranks, in place, on the current stream."""
     c = comm_for(group) if (t.is_cuda and t.dtype == torch.float64 and t.numel() <= MAX_N) else None
     if c is None:
+        if t.is_cuda and torch.cuda.is_current_stream_capturing():
+            # (rslo_amd/headgraph.py then keeps the head on the eager pass)
+            raise capi.RsloHipError("a SyncBN statistics exchange that needs an RCCL collective cannot go into a stream capture")
         dist.all_reduce(t, group=fallback_group if fallback_group is not None else group)
     else:
         c.all_reduce_(t)

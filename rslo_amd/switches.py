@@ -16,6 +16,7 @@ SWITCHES = {
     "RSLO_SYNCBN_EXCHANGE": ("auto", "mode", "SyncBN statistics exchange: auto | device | host | rccl (rslo_amd/peer.py)"),
     "RSLO_SYNCBN_FUSED_PEER": ("1", "mode", "0: multi-rank SyncBN as statistics kernel -> exchange kernel -> apply kernel on every map, instead of ONE kernel per direction that meets its peers per channel (rslo_bn2d_fwd_peer) on the register-cached maps"),
     "RSLO_FORCE_SYNCBN_PATH": ("0", "mode", "1: a one-rank process group runs the multi-rank SyncBN path (world-size-1 peer comm): what a rank of an N > 1 job executes, measurable on one GPU (bench.py multirank_path)"),
+    "RSLO_SYNCBN_MAX_BATCH": ("0", "mode", "largest per-rank batch of a job whose ranks may hold different batch sizes: the single-launch / three-launch choice of every SyncBN layer is then made for that size on every rank (0: each rank's own batch, equal on all ranks)"),
     "RSLO_PEER_TIMEOUT_MS": ("600000", "mode", "how long a SyncBN exchange waits for a peer before it poisons the statistics with NaN and raises the comm's status (polled once per step)"),
     "RSLO_SYNCBN_HP_GROUP": ("0", "mode", "1: a dedicated high-priority RCCL group for the SyncBN collectives (only when they are collectives)"),
     "RSLO_OVERLAP_GRADS": ("1", "mode", "0: one gradient bucket after backward instead of the overlapped head bucket"),

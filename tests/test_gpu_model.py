@@ -584,6 +584,53 @@ def test_replayed_head_graphs_train_bit_identically_to_the_eager_pass(hip, monke
     torch.cuda.current_stream().wait_stream(s_)
 
 
+def test_head_graph_replays_the_multi_rank_syncbn_path_bit_identically(hip, monkeypatch):
+    """Round 6: the step a rank of an N > 1 job runs.  A one-rank process group with the multi-rank SyncBatchNorm path forced
+    (RSLO_FORCE_SYNCBN_PATH=1: every layer's statistics go through the node's peer comm -- inside the BatchNorm kernel on the
+    register-cached maps, statistics -> exchange kernel -> apply on the 96x176 maps).  With the head's forward replayed from a
+    hipGraph (the exchanges carry numbers relative to a device word that is set in front of every replay) ten optimizer steps end
+    in the same weights, statistics and losses as the same ten steps issued launch by launch."""
+    import hashlib
+    import socket
+    import torch.distributed as dist
+    import apex.parallel as AP
+    from rslo_amd import headgraph, peer
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    monkeypatch.setenv("RSLO_FORCE_SYNCBN_PATH", "1")
+    monkeypatch.setattr(AP, "FORCE_MULTI", True)
+    dist.init_process_group("gloo", rank=0, world_size=1, init_method="tcp://127.0.0.1:%d" % port)
+    pool = [list(reduced_pair(i)[:2]) for i in range(6)]
+    try:
+        def run(mode):
+            monkeypatch.setattr(headgraph, "ENABLED", bool(mode))
+            monkeypatch.setattr(headgraph, "MODE", mode)
+            torch.manual_seed(7)
+            net, _ = workload.build_network()
+            net.train()
+            losses = real_training_steps(net, 10, lambda i: [pool[(2 * i) % 6], pool[(2 * i + 1) % 6]])
+            torch.cuda.synchronize()
+            peer.check_all()
+            state = torch.cat([t.detach().double().reshape(-1) for t in list(net.parameters()) + list(net.buffers())])
+            return hashlib.sha256(state.cpu().numpy().tobytes()).hexdigest(), losses, headgraph._STATE.get(net.odom_predictor)
+        h0, l0, st0 = run(None)
+        assert st0 is None
+        comm = peer.comm_for(None)
+        assert comm is not None and comm.world == 1            # the multi-rank path really ran (a world-size-1 peer comm)
+        for mode in ("fwd", "full"):
+            h1, l1, st1 = run(mode)
+            assert st1 is not None and st1.graph is not None and not st1.failed, mode
+            assert st1.graph.comm is comm and st1.graph.n_fwd_exchanges >= 45, (mode, st1.graph.n_fwd_exchanges)
+            if mode == "full":
+                assert st1.graph.n_bwd_exchanges >= 45
+            assert l0 == l1 and h0 == h1, mode
+    finally:
+        peer.shutdown()
+        dist.destroy_process_group()
+
+
 def test_basic_blocks_are_exact_on_the_inputs_they_see_in_the_network(hip):
     """The BEV encoder's BasicBlocks, each evaluated STAND-ALONE on the input and output gradient it receives inside the
     network (default init, sparse reduced-ring BEV map, warm-up regime -- the state in which whole-network gradient

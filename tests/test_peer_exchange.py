@@ -142,6 +142,62 @@ def _worker(rank, world, port, q, transport, mode):
             AP.FUSED_PEER_BN = True
             peer._COMMS.pop(id(dist.group.WORLD), None)
             comm.check()
+        elif mode == "captured":
+            # exchanges inside a REPLAYED stream capture (rslo_peer_capture_begin / _end / _replay_prepare: numbers relative to a
+            # device word): two plain exchanges + one single-launch SyncBN layer captured once, replayed 8 times with fresh
+            # inputs, eager exchanges in between, one rank lagging -- every result is the rank-ordered sum / the full-batch mean
+            from rslo_amd import capi
+            import apex.parallel as AP
+            AP.FORCE_FUSED_ON_SHARED_DEVICE = True
+            comm.set_timeout_ms(5000)
+            ta = torch.zeros(65, dtype=torch.float64, device="cuda")
+            tb = torch.zeros(513, dtype=torch.float64, device="cuda")
+            xs = torch.zeros(2, 8, 4, 4, device="cuda")
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            ok, details = True, []
+            with torch.cuda.stream(side):
+                for _ in range(2):           # (eager first: lazy state of the launch code)
+                    comm.all_reduce_(ta.clone())
+                    capi.bn2d_fwd_peer(comm, xs, None, None, None, None, None, 0.1, 1e-5, 1.0)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                comm.capture_begin()
+                try:
+                    with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+                        comm.all_reduce_(ta)
+                        comm.all_reduce_(tb)
+                        y, mean, invstd, cnt = capi.bn2d_fwd_peer(comm, xs, None, None, None, None, None, 0.1, 1e-5, 1.0)
+                finally:
+                    n = comm.capture_end()
+                out["n_captured"] = n
+
+                def vals(k, r, m):
+                    return torch.from_numpy(np.random.default_rng(977 * k + 13 * r + m).standard_normal(m))
+                for k in range(8):
+                    ta.copy_(vals(k, rank, 65))
+                    tb.copy_(vals(k, rank, 513))
+                    xs.copy_(vals(k, rank, 256).float().view(2, 8, 4, 4))
+                    if (k + rank) % 3 == 0:
+                        torch.cuda.synchronize()
+                        time.sleep(0.02)
+                    comm.replay_prepare(n)
+                    g.replay()
+                    e = vals(k, rank, 129).cuda()
+                    comm.all_reduce_(e)                                   # an eager exchange between two replays
+                    torch.cuda.synchronize()
+                    wa = sum(vals(k, r, 65) for r in range(world))
+                    wb = sum(vals(k, r, 513) for r in range(world))
+                    we = sum(vals(k, r, 129) for r in range(world))
+                    full = torch.cat([vals(k, r, 256).float().view(2, 8, 4, 4) for r in range(world)], 0)
+                    wm = full.double().mean(dim=(0, 2, 3)).float()
+                    good = (torch.equal(ta.cpu(), wa) and torch.equal(tb.cpu(), wb) and torch.equal(e.cpu(), we)
+                            and torch.allclose(mean.cpu(), wm, rtol=0, atol=1e-6) and float(cnt.item()) == 32.0 * world)
+                    ok = ok and good
+                    details.append(good)
+            torch.cuda.current_stream().wait_stream(side)
+            comm.check()
+            out["captured_ok"], out["details"] = ok, details
         elif mode == "timeout":
             comm.set_timeout_ms(300)
             t = torch.ones(65, dtype=torch.float64, device="cuda")
@@ -199,6 +255,20 @@ def test_missing_peer_times_out_instead_of_hanging_the_gpu():
     assert res[0]["poisoned"] is True
     seq, peer_rank = res[0]["status"]
     assert seq == 6 and peer_rank == 1          # five self-test exchanges at creation (four plain, one fused SyncBN layer: the ranks share a GPU), then the one rank 1 never joined
+
+
+@pytest.mark.parametrize("transport", ["host", "device"])
+def test_exchanges_inside_a_replayed_capture_keep_their_numbers(transport):
+    """Round 6 (capturable SyncBN): exchanges launched between capture_begin() and capture_end() read their number as
+    device word + k; replay_prepare() sets the word in front of every replay.  Eight replays of one hipGraph holding two
+    plain exchanges and one single-launch SyncBN layer, eager exchanges in between, a lagging rank: all sums exact."""
+    res = _run(2, transport, "captured")
+    if res[0] == "no-comm":
+        assert res[1] == "no-comm"
+        pytest.skip("transport %s not available between two processes on this box" % transport)
+    for r in range(2):
+        assert res[r]["n_captured"] == 3, res
+        assert res[r]["captured_ok"] is True, res
 
 
 @pytest.mark.parametrize("transport", ["host", "device"])
