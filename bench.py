@@ -838,7 +838,7 @@ def multirank_child(args, cores=None, sibling_blocks=None):
 
 
 # --------------------------------------------------------------------------------------------- the other BASELINE configs
-def other_configs(args):
+def other_configs(args, affinity=None):
     """BASELINE.json configs[1] (C2), configs[3] (C4, its per-GPU part) and configs[4] (C5, its per-GPU part) from the default
     invocation: one child process of this script per config (`--config ...`, the child's own step counts -- C2 / C5 steps are
     0.7-5 ms, C4's is the C3 step with bf16 operands), each child's line condensed to what the headline line carries for C3.
@@ -853,7 +853,10 @@ def other_configs(args):
         try:
             env = dict(os.environ, RSLO_BENCH_OTHER_CONFIGS="0", RSLO_BENCH_MULTIRANK_CHILD="0", RSLO_BENCH_STREAM_SPLIT="0")
             cmd = [sys.executable, os.path.abspath(__file__), "--config", cfg] + extra
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+            # (the parent is pinned to 8 cores; a child starts from the host's whole mask -- it pins its own GPU run, and its
+            # CPU baseline uses every core, like the headline line's)
+            pre = (lambda a=set(affinity): os.sched_setaffinity(0, a)) if affinity else None
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, preexec_fn=pre)
             child = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
             roof = child.get("roofline") or {}
             cpu = child.get("cpu_baseline") or {}
@@ -1431,7 +1434,7 @@ def main():
             # BASELINE.json configs[1], [3] (per-GPU part) and [4] measured by the SAME invocation the driver runs, each in a
             # child process of this script (`--config c2 | c4 | c5`: its own timing protocol, roofline and CPU baseline), and
             # carried under config.other_configs of the one final line.  The C3 headline above is already measured.
-            line["config"]["other_configs"] = other_configs(args)
+            line["config"]["other_configs"] = other_configs(args, orig_affinity)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 if pinned is not None:

@@ -715,6 +715,28 @@ RSLO_API int rslo_opt_clip_grad_norm(const RsloOptTensor *tensors_dev, const Rsl
 RSLO_API int rslo_opt_adam_step(const RsloOptTensor *tensors_dev, const RsloOptChunk *chunks_dev, int n_chunks,
                                 const RsloOptHyper *hyper, float step, void *stream);
 
+/* ---- a6 / a10 second stage (round 6): all weight-gradient reduces of a backward pass in ONE launch.
+ *      Every weight-gradient entry point (rslo_conv2d_wgrad[_bf16], rslo_conv1x1s2_wgrad, rslo_spconv_wgrad_pairs[_bf16]) is a
+ *      kernel that leaves slab / chunk partials in the caller's workspace + a small kernel that adds them in a fixed order.  While
+ *      a sink is installed (rslo_wgrad_reduce_defer(sink, capacity, &count)) they append a descriptor of that second kernel to
+ *      the caller's array instead of launching it (count is advanced; a full sink: launched at once, as without one);
+ *      rslo_wgrad_reduce_defer(NULL, 0, NULL) removes the sink.  rslo_wgrad_reduce_many(reduces, n, stream) then runs the n
+ *      reduces as one grid -- the same block bodies, the same bits.  The caller keeps every workspace / bias-partial buffer a
+ *      descriptor points to alive and unmodified until that launch, and orders it behind the kernels that wrote them (same
+ *      stream or an event).  Nothing of the reference reads a gradient before the pass is over (train_hdf5.py:663-672). */
+typedef struct RsloWgradReduce {
+  int32_t kind;               /* 0: dense slab partials (conv2d.hip); 2: sparse pair-chunk partials (spconv.hip) */
+  int32_t n_blocks;           /* workgroups of 256 threads */
+  const void *ws;
+  void *dW;
+  const void *aux;            /* bias-gradient partial rows */
+  void *dbias;
+  const void *koff;           /* sparse: pair offsets per kernel offset */
+  int32_t p[8];               /* shape parameters, written by the launch code */
+} RsloWgradReduce;
+RSLO_API int rslo_wgrad_reduce_defer(RsloWgradReduce *sink, int capacity, int *count);
+RSLO_API int rslo_wgrad_reduce_many(const RsloWgradReduce *reduces, int n, void *stream);
+
 /* ---- a22 (SyncBN statistics): sum of a few hundred doubles over the ranks of ONE node, as a kernel on the caller's stream
  *      Replaces the per-layer all-reduce of apex SyncBatchNorm (rslo/layers/SparseConv.py:96-132 -> apex
  *      sync_batchnorm: 45 layers x 2 directions per step, train_hdf5.py:463) between rslo_bn2d_stats and rslo_bn2d_apply

@@ -163,6 +163,8 @@ SIGNATURES = {
     "rslo_loss_tail_fwd": (C.c_int, [_vp, _vp, _vp]),
     "rslo_loss_tail_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rslo_peer_wait_samples": (C.c_int, [_vp, _vp, _i]),
+    "rslo_wgrad_reduce_defer": (C.c_int, [_vp, _i, _vp]),
+    "rslo_wgrad_reduce_many": (C.c_int, [_vp, _i, _vp]),
     "rslo_peer_capture_begin": (C.c_int, [_vp]),
     "rslo_peer_capture_end": (C.c_int, [_vp, _vp]),
     "rslo_peer_replay_prepare": (C.c_int, [_vp, _i, _vp]),
@@ -287,6 +289,71 @@ def _i3(x):
 
 def _ws(nbytes, device):
     return torch.empty((max(int(nbytes), 16),), dtype=torch.uint8, device=device)
+
+
+# --------------------------------------------------------------------------------------
+# deferred weight-gradient reduces (csrc/wgrad_reduce.hip)
+# --------------------------------------------------------------------------------------
+class RsloWgradReduce(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("n_blocks", C.c_int32), ("ws", C.c_void_p), ("dW", C.c_void_p), ("aux", C.c_void_p),
+                ("dbias", C.c_void_p), ("koff", C.c_void_p), ("p", C.c_int32 * 8)]
+
+
+_active_sink = None
+
+
+class ReduceSink:
+    """Collects the second stage (partials -> gradient) of the weight-gradient entry points called inside `with
+    sink.collect():` instead of launching it per layer; `flush()` runs everything collected as ONE launch on the current
+    stream (rslo_wgrad_reduce_many: same block bodies, same bits).  The workspaces / bias partials the descriptors point to are
+    kept referenced until the flush.  The caller (rslo_amd/streams.py) flushes before anything can read a gradient."""
+    CAP = 256
+
+    def __init__(self):
+        self.arr = (RsloWgradReduce * self.CAP)()
+        self.count = C.c_int(0)
+        self.keep = []
+
+    class _Collect:
+        def __init__(self, sink):
+            self.sink = sink
+
+        def __enter__(self):
+            global _active_sink
+            self.prev, _active_sink = _active_sink, self.sink
+            _chk(lib().rslo_wgrad_reduce_defer(self.sink.arr, ReduceSink.CAP, C.byref(self.sink.count)), "rslo_wgrad_reduce_defer")
+            return self.sink
+
+        def __exit__(self, *exc):
+            global _active_sink
+            _active_sink = self.prev
+            if self.prev is not None:
+                lib().rslo_wgrad_reduce_defer(self.prev.arr, ReduceSink.CAP, C.byref(self.prev.count))
+            else:
+                lib().rslo_wgrad_reduce_defer(None, 0, None)
+            return False
+
+    def collect(self):
+        return ReduceSink._Collect(self)
+
+    def pending(self):
+        return self.count.value
+
+    def flush(self):
+        n = self.count.value
+        if n:
+            rc = lib().rslo_wgrad_reduce_many(self.arr, n, _stream())
+            self.count.value = 0
+            self.keep.clear()
+            _chk(rc, "rslo_wgrad_reduce_many")
+        else:
+            self.keep.clear()
+
+
+def _keep_for_reduce(*tensors):
+    """Inside ReduceSink.collect(): the buffers a deferred reduce will read stay referenced until its flush."""
+    if _active_sink is not None:
+        _active_sink.keep.extend(t for t in tensors if t is not None)
 
 
 # --------------------------------------------------------------------------------------
@@ -651,6 +718,7 @@ def spconv_wgrad_pairs(x, dout, pairs, n_out, K, cin, cout, with_bias=True, bias
                                        _ptr(bias_partial if with_bias else None),
                                        0 if bias_partial is None else bias_partial.shape[0], _stream()),
          "rslo_spconv_wgrad_pairs")
+    _keep_for_reduce(ws, bias_partial, koff)
     return dW, db
 
 
@@ -698,6 +766,7 @@ def spconv_wgrad_pairs_bf16(x, dout, pairs, n_out, K, cin, cout, bias_partial=No
                                             _ptr(koff, torch.int32, "koff"), n_out, K, _ptr(ws), wsb, _ptr(dW), _ptr(db),
                                             _ptr(bias_partial), 0 if bias_partial is None else bias_partial.shape[0],
                                             _stream()), "rslo_spconv_wgrad_pairs_bf16")
+    _keep_for_reduce(ws, bias_partial, koff)
     return dW, db
 
 
@@ -1401,6 +1470,7 @@ def conv2d_wgrad(x, dout, stride=1, want_bias=False, lp=False):
             stride, dW.data_ptr(), _dp(db), ws.data_ptr(), wsb, _stream())
     if rc:
         _chk(rc, "rslo_conv2d_wgrad")
+    _keep_for_reduce(ws)
     return (dW, db) if want_bias else dW
 
 
@@ -1421,6 +1491,7 @@ def conv1x1s2_wgrad(x, dout):
                                     dW.data_ptr(), ws.data_ptr(), wsb, _stream())
     if rc:
         _chk(rc, "rslo_conv1x1s2_wgrad")
+    _keep_for_reduce(ws)
     return dW
 
 

@@ -309,6 +309,7 @@ class DistributedDataParallel(nn.Module):
         st = sys.modules.get("rslo_amd.streams")
         if st is not None:        # weight gradients still on the leaf stream (its own end-of-pass callback was queued after
             st.join()             # this one): the buckets are built on the issuing stream, behind them
+            st.flush_deferred()   # ... and the collected sparse weight-gradient reduces of the issuing stream
         if self._exchange is not None:
             self._exchange.finish()
         else:

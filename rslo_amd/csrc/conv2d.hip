@@ -18,6 +18,7 @@
 #include <stdlib.h>
 
 #include "conv2d_tile.h"
+#include "wgrad_reduce.h"
 
 
 // 8 consecutive floats at base[idx .. idx+7]; lanes whose window leaves [0, total) read element-wise under the mask
@@ -357,54 +358,15 @@ __global__ __launch_bounds__(C2_THREADS, NB == 2 ? 3 : 2) void k_conv2d_wgrad_s1
   }
 }
 
-// 32 (tile, tap, ci, co) elements x 8 slab groups per block: group sg adds slabs sg, sg+8, ... in order, the 8 group sums
-// are added in group order (fixed summation order); writes dW in OIHW
+// the slab partials added in slab order (fixed summation order), dW in OIHW: block body in wgrad_reduce.h (shared with the
+// one-launch form over many layers, rslo_wgrad_reduce_many)
 __global__ __launch_bounds__(256) void k_conv2d_wgrad_reduce(const float *__restrict__ ws, int n_slabs, int n_tiles,
                                                              int n_cout_tiles, int co_t, int cin, int cout,
                                                              float *__restrict__ dW, int n_main_blocks,
                                                              const float *__restrict__ bws, float *__restrict__ dbias,
                                                              int ntap) {
   __shared__ float part[8][32];
-  const int per_tile = ntap * 16 * co_t;
-  const int64_t n = (int64_t)n_tiles * per_tile;
-  const int se = threadIdx.x & 31, sg = threadIdx.x >> 5;
-  if ((int)blockIdx.x >= n_main_blocks) {          // bias gradient: 32 channels per block, same 8-group slab order
-    const int c = ((int)blockIdx.x - n_main_blocks) * 32 + se;
-    float t = 0.f;
-    if (c < cout)
-      for (int sl = sg; sl < n_slabs; sl += 8) t += bws[(int64_t)sl * cout + c];
-    part[sg][se] = t;
-    __syncthreads();
-    if (sg == 0 && c < cout) {
-      float t8 = part[0][se];
-#pragma unroll
-      for (int q = 1; q < 8; ++q) t8 += part[q][se];
-      dbias[c] = t8;
-    }
-    return;
-  }
-  const int64_t e = (int64_t)blockIdx.x * 32 + se;
-  float s = 0.f;
-  if (e < n) {
-    int sl = sg;
-    for (; sl + 24 < n_slabs; sl += 32) {
-      const float a0 = ws[(int64_t)(sl + 0) * n + e], a1 = ws[(int64_t)(sl + 8) * n + e];
-      const float a2 = ws[(int64_t)(sl + 16) * n + e], a3 = ws[(int64_t)(sl + 24) * n + e];
-      s += a0; s += a1; s += a2; s += a3;
-    }
-    for (; sl < n_slabs; sl += 8) s += ws[(int64_t)sl * n + e];
-  }
-  part[sg][se] = s;
-  __syncthreads();
-  if (sg != 0 || e >= n) return;
-  float t8 = part[0][se];
-#pragma unroll
-  for (int q = 1; q < 8; ++q) t8 += part[q][se];
-  const int tile = (int)(e / per_tile), r = (int)(e - (int64_t)tile * per_tile);
-  const int t = r / (16 * co_t), r2 = r - t * 16 * co_t;
-  const int ci = r2 / co_t, co = r2 - ci * co_t;
-  const int ct = tile / n_cout_tiles, ot = tile - ct * n_cout_tiles;
-  dW[((int64_t)(ot * co_t + co) * cin + ct * 16 + ci) * ntap + t] = t8;
+  wr_dense_block((int)blockIdx.x, ws, n_slabs, n_tiles, n_cout_tiles, co_t, cin, cout, dW, n_main_blocks, bws, dbias, ntap, part);
 }
 
 static int conv2d_plan(int B, int cin, int cout, int H, int W, int stride, Conv2dGeom *gm, int *nb, int *n_slabs) {
@@ -496,6 +458,7 @@ static int conv2d_wgrad_launch(const float *in, const float *dout, int B, int ci
   RSLO_CHECK_LAUNCH("k_conv2d_wgrad");
   const int64_t n = (int64_t)tiles * 9 * 16 * 16 * nb;
   const int n_main = (int)rslo_cdiv(n, 32);
+  if (wr_defer(wr_dense_desc(ws, ns, tiles, gm.n_cout_tiles, 16 * nb, cin, cout, dW, n_main, bws, dbias, 9))) return RSLO_OK;
   hipLaunchKernelGGL(k_conv2d_wgrad_reduce, dim3((unsigned)(n_main + (dbias ? (int)rslo_cdiv(cout, 32) : 0))), dim3(256), 0,
                      st, (const float *)ws, ns, tiles, gm.n_cout_tiles, 16 * nb, cin, cout, dW, n_main,
                      (const float *)bws, dbias, 9);
@@ -548,6 +511,7 @@ extern "C" int rslo_conv1x1s2_wgrad(const float *in, const float *dout, int B, i
   RSLO_CHECK_LAUNCH("k_conv2d_wgrad(1x1)");
   const int64_t n = (int64_t)tiles * 16 * 16 * nb;
   const int n_main = (int)rslo_cdiv(n, 32);
+  if (wr_defer(wr_dense_desc(ws, ns, tiles, gm.n_cout_tiles, 16 * nb, cin, cout, dW, n_main, nullptr, nullptr, 1))) return RSLO_OK;
   hipLaunchKernelGGL(k_conv2d_wgrad_reduce, dim3((unsigned)n_main), dim3(256), 0, st, (const float *)ws, ns, tiles,
                      gm.n_cout_tiles, 16 * nb, cin, cout, dW, n_main, (const float *)nullptr, (float *)nullptr, 1);
   RSLO_CHECK_LAUNCH("k_conv2d_wgrad_reduce(1x1)");

@@ -16,6 +16,7 @@
 #include <stdlib.h>
 
 #include "rslo_common.h"
+#include "wgrad_reduce.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -1693,63 +1694,13 @@ __global__ __launch_bounds__(SPC_THREADS) void k_wgrad3_bf16(const unsigned shor
   for (int e = tid; e < CIN_T * COUT_T; e += SPC_THREADS) dst[e] = red[e];
 }
 
-// grid (ceil(cc / 256), K [+ 1]): row k < K adds the chunk partials of offset k in chunk order; the optional row K adds
-// the bias-gradient partial rows bpart [n_bpart][cout] in row order (8 independent loads in flight, ordered adds).
+// grid (ceil(cc / 32), K [+ 1]): the chunk partials added in chunk order (+ the bias-gradient rows); block body in
+// wgrad_reduce.h (shared with the one-launch form over many layers, rslo_wgrad_reduce_many)
 __global__ void k_wgrad2_reduce(const float *__restrict__ ws, const int32_t *__restrict__ koff, int K, int chunk, int cc,
                                 float *__restrict__ dW, const float *__restrict__ bpart, int n_bpart, int cout,
                                 float *__restrict__ dbias) {
-  const int k = blockIdx.y;
-  if (k == K) {
-    if (blockIdx.x != 0) return;
-    __shared__ float red[256];
-    const int cp = cout <= 16 ? 16 : (cout <= 32 ? 32 : 64);
-    const int c = threadIdx.x % cp, part = threadIdx.x / cp, nparts = 256 / cp;
-    float s = 0.f;
-    if (c < cout) {
-      for (int b = part; b < n_bpart; b += 8 * nparts) {
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int bb = b + u * nparts;
-          v[u] = bb < n_bpart ? bpart[(int64_t)bb * cout + c] : 0.f;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) s += v[u];
-      }
-    }
-    red[threadIdx.x] = s;
-    __syncthreads();
-    if (part == 0 && c < cout) {
-      float t = 0.f;
-      for (int q = 0; q < nparts; ++q) t += red[q * cp + c];
-      dbias[c] = t;
-    }
-    return;
-  }
-  // 32 elements x 8 chunk groups per block: group sg adds chunks sg, sg + 8, ... in order, the 8 group sums are added
-  // in group order (a serial loop over ~100 chunk partials per thread was a 16 us latency chain)
-  __shared__ float part[8][32];
-  const int se = threadIdx.x & 31, sg = threadIdx.x >> 5;
-  const int e = blockIdx.x * 32 + se;
-  const int n = koff[k + 1] - koff[k];
-  const int nch = (n + chunk - 1) / chunk;
-  float s = 0.f;
-  if (e < cc) {
-    int c = sg;
-    for (; c + 24 < nch; c += 32) {
-      const float a0 = ws[((int64_t)(c + 0) * K + k) * cc + e], a1 = ws[((int64_t)(c + 8) * K + k) * cc + e];
-      const float a2 = ws[((int64_t)(c + 16) * K + k) * cc + e], a3 = ws[((int64_t)(c + 24) * K + k) * cc + e];
-      s += a0; s += a1; s += a2; s += a3;
-    }
-    for (; c < nch; c += 8) s += ws[((int64_t)c * K + k) * cc + e];
-  }
-  part[sg][se] = s;
-  __syncthreads();
-  if (sg != 0 || e >= cc) return;
-  float t = part[0][se];
-#pragma unroll
-  for (int q = 1; q < 8; ++q) t += part[q][se];
-  dW[(int64_t)k * cc + e] = t;
+  __shared__ float red[256];
+  wr_sparse_block((int)blockIdx.x, (int)blockIdx.y, ws, koff, K, chunk, cc, dW, bpart, n_bpart, cout, dbias, red);
 }
 
 // Bias gradient = column sums of the (activation-masked) output gradient, in two deterministic stages without fences:
@@ -1851,6 +1802,7 @@ extern "C" int rslo_spconv_wgrad_pairs(const float *in, int cin, const float *do
       bpart = wsb;
     }
   }
+  if (wr_defer(wr_sparse_desc(ws, koff, K, chunk, cc, dW, bpart, n_bpart, cout, dbias))) return RSLO_OK;
   hipLaunchKernelGGL(k_wgrad2_reduce, dim3((unsigned)rslo_cdiv(cc, 32), (unsigned)(K + (dbias ? 1 : 0))), dim3(256), 0, st,
                      (const float *)ws, koff, K, chunk, cc, dW, bpart, n_bpart, cout, dbias);
   RSLO_CHECK_LAUNCH("wgrad_pairs");
@@ -1887,6 +1839,7 @@ extern "C" int rslo_spconv_wgrad_pairs_bf16(const void *in, int cin, const void 
   WG3B_CASE(32, 32) WG3B_CASE(32, 64) WG3B_CASE(64, 32) WG3B_CASE(64, 64)
 #undef WG3B_CASE
   const int cc = cin * cout;
+  if (wr_defer(wr_sparse_desc(ws, koff, K, WG3_CHUNK, cc, dW, bias_partial, dbias ? n_bias_partial : 0, cout, dbias))) return RSLO_OK;
   hipLaunchKernelGGL(k_wgrad2_reduce, dim3((unsigned)rslo_cdiv(cc, 32), (unsigned)(K + (dbias ? 1 : 0))), dim3(256), 0, st,
                      (const float *)ws, koff, K, WG3_CHUNK, cc, dW, bias_partial, dbias ? n_bias_partial : 0, cout, dbias);
   RSLO_CHECK_LAUNCH("wgrad_pairs_bf16");

@@ -205,6 +205,10 @@ class OverlappedGradientExchange:
 
     def finish(self):
         """The rest of average_gradients(model, mean=self.mean)."""
+        import sys
+        st = sys.modules.get("rslo_amd.streams")
+        if st is not None:              # called from inside a backward pass (apex DDP stand-in): the collected weight-gradient
+            st.flush_deferred()         # reduces of the issuing stream must be in front of the buckets
         if not _active():
             return
         params = [p for p in self.model.parameters() if p.requires_grad]

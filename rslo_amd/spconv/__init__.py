@@ -206,6 +206,7 @@ class _SparseConvFn(torch.autograd.Function):
                             order=None if rb is None else rb.order(fwd_key))
         ctx.save_for_backward(x, weight, y if slope != 1.0 else None, nbr, nbrT)
         ctx.meta = (subm, slope, bias is not None)
+        ctx.params = (weight,) if bias is None else (weight, bias)      # (the objects whose .grad the results become)
         return y
 
     @staticmethod
@@ -233,8 +234,17 @@ class _SparseConvFn(torch.autograd.Function):
                 pin, pout, koff = ctx.rb.pairs()
                 # an inverse conv runs over the same pairs with the roles of the two sides swapped
                 pairs = (pout, pin, koff) if ctx.inverse else (pin, pout, koff)
-                gw, gb = capi.spconv_wgrad_pairs(x, g, pairs, g.shape[0], K, cin, cout, with_bias=has_bias,
-                                                 bias_partial=bias_partial)
+                # the chunk partials -> gradient stage is left to ONE launch at the end of the pass where nothing can read the
+                # gradient earlier (rslo_amd/streams.py deferred_reduce)
+                from rslo_amd import streams
+                defer = streams.deferred_reduce(ctx.params) if all(isinstance(p, nn.Parameter) for p in ctx.params) else None
+                if defer is not None:
+                    with defer:
+                        gw, gb = capi.spconv_wgrad_pairs(x, g, pairs, g.shape[0], K, cin, cout, with_bias=has_bias,
+                                                         bias_partial=bias_partial)
+                else:
+                    gw, gb = capi.spconv_wgrad_pairs(x, g, pairs, g.shape[0], K, cin, cout, with_bias=has_bias,
+                                                     bias_partial=bias_partial)
             else:
                 gw, gb = capi.spconv_wgrad(x, g, nbr, cin, cout, with_bias=has_bias)
             gw = gw.reshape(weight.shape)

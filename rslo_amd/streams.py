@@ -23,7 +23,13 @@ import os
 import torch
 
 ENABLED = os.environ.get("RSLO_WGRAD_STREAM", "1") != "0"
-_state = {}          # device -> {"side", "cur": stream of the backward nodes, "pending", "targets": ids, "keep": inputs}
+# "1" (default): the second stage of every weight gradient of a backward pass (slab / chunk partials -> gradient, a 2-10 us
+# launch per layer: 45 dense 3x3, 5 dense 1x1, 20 sparse) is collected and run as ONE launch per stream at the end of the pass
+# (rslo_amd.capi.ReduceSink, csrc/wgrad_reduce.hip): the dense ones on the leaf stream in front of its join, the sparse ones on
+# the issuing stream in an end-of-pass callback.  Same block bodies, same bits.  "0": a reduce launch per layer, as before.
+DEFER_REDUCES = os.environ.get("RSLO_DEFER_WGRAD_REDUCE", "1") != "0"
+_DEFER_WHICH = os.environ.get("RSLO_DEFER_WGRAD_REDUCE", "1")      # (debugging: "dense" / "sparse" = only that family)
+_state = {}          # device -> {"side", "cur": stream of the backward nodes, "pending", "targets": {pass -> ids}, "keep": inputs}
 _hold = [0]          # > 0: inside join_in_enclosing_pass()
 
 
@@ -42,20 +48,58 @@ class join_in_enclosing_pass:
             for dev, st in _state.items():
                 if st["pending"] and not st.get("queued"):
                     st["queued"] = True
-                    torch.autograd.Variable._execution_engine.queue_callback(lambda d=dev: join(d))
+                    torch.autograd.Variable._execution_engine.queue_callback(lambda d=dev, p=_pass_id(): join(d, p))
         return False
 
 
-def join(device=None):
-    """Make the streams that issued leaf work wait for it (no-op when nothing is pending)."""
+def _flush_leaf_sink(st):
+    sink = st.get("sink")
+    if sink is not None and (sink.pending() or sink.keep):
+        cur = torch.cuda.current_stream(st["side"].device)
+        torch.cuda.set_stream(st["side"])
+        try:
+            sink.flush()
+        finally:
+            torch.cuda.set_stream(cur)
+
+
+def _pass_id():
+    """The running backward pass (graph task), -1 outside one."""
+    try:
+        return torch._C._current_graph_task_id()
+    except AttributeError:
+        return -1
+
+
+def _targets(st):
+    """The parameters that already got a result in THIS backward pass.  Kept until the pass is over -- not until the next join: the
+    engine adds a parameter's second contribution to the buffered first one as soon as it arrives (InputBuffer::add), whatever
+    joins happened in between."""
+    by_pass = st["targets"]
+    pid = _pass_id()
+    t = by_pass.get(pid)
+    if t is None:
+        if len(by_pass) > 8:          # passes whose end-of-pass callback never ran (an exception inside backward)
+            by_pass.clear()
+        t = by_pass[pid] = set()
+    return t
+
+
+def join(device=None, done_pass=None):
+    """Make the streams that issued leaf work wait for it (no-op when nothing is pending).  The collected weight-gradient
+    reduces of the leaf stream are launched in front of the wait.  done_pass: the backward pass that is over (its end-of-pass
+    callback)."""
     for dev, st in _state.items():
-        if st["pending"] and (device is None or dev == device):
-            from rslo_amd import streamprobe
-            streamprobe.wait("leaf_wgrad_stream", st["cur"], lambda: st["cur"].wait_stream(st["side"]))
-            st["pending"] = False
-            st["queued"] = False
-            st["targets"].clear()
-            st["keep"].clear()
+        if device is None or dev == device:
+            if st["pending"]:
+                _flush_leaf_sink(st)
+                from rslo_amd import streamprobe
+                streamprobe.wait("leaf_wgrad_stream", st["cur"], lambda: st["cur"].wait_stream(st["side"]))
+                st["pending"] = False
+                st["queued"] = False
+                st["keep"].clear()
+            if done_pass is not None:
+                st["targets"].pop(done_pass, None)
 
 
 def leaf(fn, inputs, params=None):
@@ -67,9 +111,11 @@ def leaf(fn, inputs, params=None):
     cur = torch.cuda.current_stream(dev)
     st = _state.get(dev)
     if st is None:
-        st = _state[dev] = {"side": torch.cuda.Stream(dev), "cur": cur, "pending": False, "targets": set(), "keep": []}
+        st = _state[dev] = {"side": torch.cuda.Stream(dev), "cur": cur, "pending": False, "targets": {}, "keep": []}
     # (a non-leaf "parameter", e.g. a cast copy, hands the result to another backward node on the issuing stream)
-    if any((not p.is_leaf) or p.grad is not None or id(p) in st["targets"] for p in params):
+    targets = _targets(st)
+    if any((not p.is_leaf) or p.grad is not None or id(p) in targets for p in params):
+        targets.update(id(p) for p in params)
         join(dev)              # everything issued so far is ordered in front of the accumulation that follows
         return fn()
     side = st["side"]
@@ -84,7 +130,15 @@ def leaf(fn, inputs, params=None):
     side.wait_event(ev)
     torch.cuda.set_stream(side)
     try:
-        out = fn()
+        if DEFER_REDUCES and _DEFER_WHICH != "sparse":
+            sink = st.get("sink")
+            if sink is None:
+                from rslo_amd import capi
+                sink = st["sink"] = capi.ReduceSink()
+            with sink.collect():
+                out = fn()
+        else:
+            out = fn()
     finally:
         torch.cuda.set_stream(cur)
     # the inputs stay referenced until the join, after which the issuing stream is ordered behind every read of the side
@@ -95,10 +149,60 @@ def leaf(fn, inputs, params=None):
     for t in (out if isinstance(out, (tuple, list)) else (out,)):
         if t is not None:
             t.record_stream(cur)
-    st["targets"].update(id(p) for p in params)
+    targets.update(id(p) for p in params)
     if not st["pending"]:
         st["pending"], st["cur"] = True, cur
         if _hold[0] == 0:
             st["queued"] = True
-            torch.autograd.Variable._execution_engine.queue_callback(lambda d=dev: join(d))
+            torch.autograd.Variable._execution_engine.queue_callback(lambda d=dev, p=_pass_id(): join(d, p))
     return out
+
+
+# ---- weight-gradient reduces of work that stays on the ISSUING stream (the sparse encoder's layers) ------------------------------
+_train = {}          # device -> {"sink", "queued": passes with a callback, "targets": {pass -> data_ptrs of the parameters with a result}}
+
+
+def in_backward_pass():
+    return _pass_id() != -1
+
+
+def deferred_reduce(params):
+    """-> a context (capi.ReduceSink.collect()) inside which a weight-gradient entry point leaves its second stage to ONE launch
+    at the end of the running backward pass, or None when the results may be READ before that: not inside a pass, a parameter
+    that already holds a gradient (accumulation: AccumulateGrad adds at once) or got one earlier in this pass (shared
+    weight), a non-leaf "parameter", a stream capture.  params: the parameters the results become gradients of."""
+    if not DEFER_REDUCES or _DEFER_WHICH == "dense" or not params or params[0].device.type != "cuda" or not in_backward_pass():
+        return None
+    if torch.cuda.is_current_stream_capturing():
+        return None
+    dev = params[0].device
+    st = _train.get(dev)
+    if st is None:
+        from rslo_amd import capi
+        st = _train[dev] = {"sink": capi.ReduceSink(), "queued": set(), "targets": {}}
+    pid = _pass_id()
+    targets = _targets(st)
+    seen = any((not p.is_leaf) or p.grad is not None or p.data_ptr() in targets for p in params)
+    targets.update(p.data_ptr() for p in params)
+    if pid not in st["queued"]:
+        st["queued"].add(pid)
+        torch.autograd.Variable._execution_engine.queue_callback(lambda d=dev, p=pid: flush_deferred(d, p))
+    if seen:
+        # a second contribution to a gradient in one pass (two forwards before one backward, a shared weight), or an
+        # accumulation: the engine ADDS at once -- everything collected so far is made real, this result is computed in place
+        flush_deferred(dev)
+        return None
+    return st["sink"].collect()
+
+
+def flush_deferred(device=None, done_pass=None):
+    """Launch the collected reduces of the issuing stream now (on the current stream).  Called at the end of the pass (done_pass:
+    that pass), and by anything that reads gradients inside it (the gradient exchange of the apex DDP stand-in)."""
+    for dev, st in _train.items():
+        if device is None or dev == device:
+            if done_pass is not None:
+                st["queued"].discard(done_pass)
+                st["targets"].pop(done_pass, None)
+            if st["sink"].pending() or st["sink"].keep:
+                with torch.cuda.device(dev):
+                    st["sink"].flush()

@@ -584,6 +584,46 @@ def test_replayed_head_graphs_train_bit_identically_to_the_eager_pass(hip, monke
     torch.cuda.current_stream().wait_stream(s_)
 
 
+def test_deferred_weight_gradient_reduces_keep_the_bits(hip, monkeypatch):
+    """Round 6: the partials -> gradient stage of all 70 weight gradients of a step runs as ONE launch per stream at the end of
+    the backward pass (rslo_amd/streams.py DEFER_REDUCES, csrc/wgrad_reduce.hip) instead of a launch per layer.  Six optimizer
+    steps end in the same weights / statistics / losses either way; gradient accumulation over two backward passes without a
+    reset (the case where a gradient IS read inside the pass) gives the sum of the two passes' gradients."""
+    import hashlib
+    from rslo_amd import headgraph, streams
+    pool = [list(reduced_pair(i)[:2]) for i in range(6)]
+
+    def run(defer, graph):
+        monkeypatch.setattr(streams, "DEFER_REDUCES", defer)
+        monkeypatch.setattr(headgraph, "ENABLED", bool(graph))
+        monkeypatch.setattr(headgraph, "MODE", graph)
+        torch.manual_seed(7)
+        net, _ = workload.build_network()
+        net.train()
+        losses = real_training_steps(net, 6, lambda i: [pool[(2 * i) % 6], pool[(2 * i + 1) % 6]])
+        torch.cuda.synchronize()
+        state = torch.cat([t.detach().double().reshape(-1) for t in list(net.parameters()) + list(net.buffers())])
+        return hashlib.sha256(state.cpu().numpy().tobytes()).hexdigest(), losses, net
+    h0, l0, _ = run(False, None)
+    for graph in (None, "fwd"):
+        h1, l1, net = run(True, graph)
+        assert l0 == l1 and h0 == h1, graph
+    # accumulation: the second pass must not defer (AccumulateGrad adds into the gradient that is already there)
+    ex = [workload.make_example(net, [pool[0], pool[1]]), workload.make_example(net, [pool[2], pool[3]])]
+    probes = [next(net.odom_predictor.blocks[1][2].parameters()), net.middle_feature_extractor.middle_conv[3].weight,
+              net.middle_feature_extractor.middle_conv_tail[0].weight]
+    singles = []
+    for e in ex:
+        net.zero_grad(set_to_none=True)
+        net(e)["loss"].mean().backward()
+        singles.append([p.grad.clone() for p in probes])
+    net.zero_grad(set_to_none=True)
+    for e in ex:
+        net(e)["loss"].mean().backward()
+    for p, a, b in zip(probes, singles[0], singles[1]):
+        assert torch.equal(p.grad, a + b)
+
+
 def test_head_graph_replays_the_multi_rank_syncbn_path_bit_identically(hip, monkeypatch):
     """Round 6: the step a rank of an N > 1 job runs.  A one-rank process group with the multi-rank SyncBatchNorm path forced
     (RSLO_FORCE_SYNCBN_PATH=1: every layer's statistics go through the node's peer comm -- inside the BatchNorm kernel on the
