@@ -557,7 +557,11 @@ __device__ __forceinline__ Split8 split8(const float4 a, const float4 b, bool ok
 // 3 or 4 waves from start to end, the kernel's time is the gather latency chain of the SIMDs that got 4, and nothing
 // else is in flight to hide it.  Half-length chains in twice as many waves put 6.2 waves on a SIMD (quantisation 6.2 vs
 // 7 instead of 3.1 vs 4) at the same weight and row traffic per product.
-template <int CIN_T, int COUT_T, int RBW, int KS = 1>
+// SKIPB (round 6 experiment, switch spconv_skip): a 16-row block none of whose rows has the offset is skipped -- no gather, no
+// split, no MFMAs for it (the tile's offset union is what the loop walks; 30 % of the issued products are such padding on C3,
+// 42 % on C5).  A lone live block interleaves the accumulators of two column blocks instead of two row blocks.  A row's sum
+// keeps its order (offsets ascending, the same six products): same bits.
+template <int CIN_T, int COUT_T, int RBW, int KS = 1, bool SKIPB = false>
 __global__ __launch_bounds__(SPC_THREADS) void k_spconv_v6(const float *__restrict__ in,
                                                            const unsigned short *__restrict__ Ws,
                                                            const float *__restrict__ bias,
@@ -627,6 +631,33 @@ __global__ __launch_bounds__(SPC_THREADS) void k_spconv_v6(const float *__restri
       const int32_t r = nbl[tw][(rb * 16 + li) * K + k];
       ok[rb] = r >= 0;
       ap[rb] = in + (int64_t)(ok[rb] ? r : 0) * CIN_T + 8 * g;
+    }
+    if constexpr (SKIPB && RBW == 2) {
+      const bool l0 = __ballot(ok[0]) != 0ull, l1 = __ballot(ok[1]) != 0ull;
+      if (!(l0 && l1)) {
+        // exactly one live row block (the offset is in the mask: at least one is)
+#define SPC6_ONE(R)                                                                                              \
+  _Pragma("unroll") for (int sk = 0; sk < NS; ++sk) {                                                            \
+    const unsigned short *wb = Ws + ((((int64_t)kk * NS + sk) * 4 + g) * COUT_T + li) * 8;                       \
+    const float4 x0 = *reinterpret_cast<const float4 *>(ap[R] + 32 * sk);                                        \
+    const float4 x1 = *reinterpret_cast<const float4 *>(ap[R] + 32 * sk + 4);                                    \
+    const Split8 a1 = split8(x0, x1, ok[R]);                                                                     \
+    _Pragma("unroll") for (int nb = 0; nb < NB; nb += 2) {                                                       \
+      const u32x4 bh0 = SPC_WLOAD(wb + nb * 16 * 8), bh1 = SPC_WLOAD(wb + (nb + 1) * 16 * 8);                    \
+      const u32x4 bm0 = SPC_WLOAD(wb + plane + nb * 16 * 8), bm1 = SPC_WLOAD(wb + plane + (nb + 1) * 16 * 8);    \
+      const u32x4 bl0 = SPC_WLOAD(wb + 2 * plane + nb * 16 * 8), bl1 = SPC_WLOAD(wb + 2 * plane + (nb + 1) * 16 * 8); \
+      acc[R][nb] = MFMA_BF16(a1.l, bh0, acc[R][nb]); acc[R][nb + 1] = MFMA_BF16(a1.l, bh1, acc[R][nb + 1]);      \
+      acc[R][nb] = MFMA_BF16(a1.m, bm0, acc[R][nb]); acc[R][nb + 1] = MFMA_BF16(a1.m, bm1, acc[R][nb + 1]);      \
+      acc[R][nb] = MFMA_BF16(a1.h, bl0, acc[R][nb]); acc[R][nb + 1] = MFMA_BF16(a1.h, bl1, acc[R][nb + 1]);      \
+      acc[R][nb] = MFMA_BF16(a1.m, bh0, acc[R][nb]); acc[R][nb + 1] = MFMA_BF16(a1.m, bh1, acc[R][nb + 1]);      \
+      acc[R][nb] = MFMA_BF16(a1.h, bm0, acc[R][nb]); acc[R][nb + 1] = MFMA_BF16(a1.h, bm1, acc[R][nb + 1]);      \
+      acc[R][nb] = MFMA_BF16(a1.h, bh0, acc[R][nb]); acc[R][nb + 1] = MFMA_BF16(a1.h, bh1, acc[R][nb + 1]);      \
+    }                                                                                                            \
+  }
+        if (l0) { SPC6_ONE(0) } else { SPC6_ONE(1) }
+#undef SPC6_ONE
+        continue;
+      }
     }
 #pragma unroll
     for (int sk = 0; sk < NS; ++sk) {
@@ -1031,11 +1062,21 @@ extern "C" int rslo_spconv_fwd_split(const float *in, int cin, const void *Ws, c
 #define SPC6_LAUNCH(CI, CO, RB, KSv)                                                                        \
   hipLaunchKernelGGL((k_spconv_v6<CI, CO, RB, KSv>), dim3(xcd_grid(rslo_cdiv(rslo_cdiv(n_out, 16 * RB), 4 / KSv))), \
                      dim3(SPC_THREADS), 0, st, in, ws, bias, nbr, row_order, n_out, K, flip_k, act_slope, out)
+#define SPC6_LAUNCH_SKIP(CI, CO, KSv)                                                                       \
+  hipLaunchKernelGGL((k_spconv_v6<CI, CO, 2, KSv, true>), dim3(xcd_grid(rslo_cdiv(rslo_cdiv(n_out, 32), 4 / KSv))), \
+                     dim3(SPC_THREADS), 0, st, in, ws, bias, nbr, row_order, n_out, K, flip_k, act_slope, out)
+  // measured (profiles/r06_spconv_skip.txt, 8 frames, us without | with): 64 -> 64 level 2 159.0 | 158.8, level 3 71.7 | 69.6,
+  // strided 64 -> 64 73.1 | 67.1, inverse 64 -> 64 92.9 | 86.4, inverse 64 -> 32 95.1 | 93.7; 32 -> 32 72.7 | 77.8, strided
+  // 32 -> 64 66.5 | 73.3: on for 64 input channels (-1 = that choice), where a block's products are worth the branch
+  const int skip_mode = rslo_tune(RSLO_TUNE_SPCONV_SKIP);
+  const bool skipb = skip_mode < 0 ? cin == 64 : skip_mode != 0;
 #define SPC6_CASE(CI, CO)                                                                                    \
   if (cin == CI && cout == CO) {                                                                             \
     if (rbw == 4) SPC6_LAUNCH(CI, CO, 4, 1);                                                                 \
     else if (rbw == 2 && ks == 4) SPC6_LAUNCH(CI, CO, 2, 4);                                                 \
+    else if (rbw == 2 && ks == 2 && skipb) SPC6_LAUNCH_SKIP(CI, CO, 2);                                      \
     else if (rbw == 2 && ks == 2) SPC6_LAUNCH(CI, CO, 2, 2);                                                 \
+    else if (rbw == 2 && skipb) SPC6_LAUNCH_SKIP(CI, CO, 1);                                                 \
     else if (rbw == 2) SPC6_LAUNCH(CI, CO, 2, 1);                                                            \
     else if (ks == 4) SPC6_LAUNCH(CI, CO, 1, 4);                                                             \
     else if (ks == 2) SPC6_LAUNCH(CI, CO, 1, 2);                                                             \
@@ -1044,6 +1085,7 @@ extern "C" int rslo_spconv_fwd_split(const float *in, int cin, const void *Ws, c
   SPC6_CASE(32, 32) SPC6_CASE(32, 64) SPC6_CASE(64, 32) SPC6_CASE(64, 64)
 #undef SPC6_CASE
 #undef SPC6_LAUNCH
+#undef SPC6_LAUNCH_SKIP
   RSLO_CHECK_LAUNCH("spconv_v6");
   return RSLO_OK;
 }

@@ -1457,6 +1457,32 @@ def test_conv2d_fwd_tile_heights_keep_the_bits(hip, B, cin, cout, H, W):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout", [(32, 32), (64, 64), (32, 64), (64, 32)])
+def test_spconv_dead_row_block_skip_keeps_the_bits(hip, cin, cout):
+    """Switch spconv_skip (round 6): k_spconv_v6 on 32-row tiles skips a 16-row block none of whose rows has the offset.  A
+    row's sum keeps its order: forward (bias + LeakyReLU) and the data gradient through the transposed operand are equal bit
+    for bit with the kernel that always computes both blocks -- on a table with whole missing blocks, isolated rows, a
+    ragged last tile, one and two waves per tile."""
+    g = torch.Generator().manual_seed(5)
+    n_in, n_out, K = 5000, 4133, 27
+    nbr = torch.randint(0, n_in, (n_out, K), generator=g, dtype=torch.int32)
+    keep = torch.rand((n_out, K), generator=g) < 0.45
+    blk = torch.arange(n_out) // 16
+    keep &= ~(((blk[:, None] * 7 + torch.arange(K)[None]) % 3) == 0)        # a third of the (block, offset) pairs are empty
+    keep[torch.arange(0, n_out, 97)] = False                                  # rows without any neighbour
+    nbr = torch.where(keep, nbr, torch.full_like(nbr, -1)).cuda().contiguous()
+    x = torch.randn(n_in, cin, generator=g).cuda()
+    W = (torch.randn(K, cin, cout, generator=g) * 0.1).cuda()
+    bias = torch.randn(cout, generator=g).cuda()
+    for ks in (1, 2):
+        with hip.tuning(spconv_rbw=2, spconv_ks=ks, spconv_skip=0):
+            ref = hip.spconv_fwd(x, W, bias, nbr, act_slope=0.01).clone()
+        with hip.tuning(spconv_rbw=2, spconv_ks=ks, spconv_skip=1):
+            got = hip.spconv_fwd(x, W, bias, nbr, act_slope=0.01)
+        assert torch.equal(ref, got), ks
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B,cin,cout,H,W", [(4, 128, 128, 48, 88), (1, 64, 64, 96, 176), (2, 96, 64, 25, 23), (4, 256, 128, 48, 88),
                                             (1, 32, 32, 7, 9), (3, 64, 192, 12, 22), (1, 512, 128, 24, 44)])
 def test_conv2d_lds_weight_kernel_keeps_the_bits(hip, B, cin, cout, H, W):
