@@ -68,7 +68,7 @@ enum RsloTune {
   RSLO_TUNE_CONV2D_S2_PIPED,           // 1 (default): stride-2 kernels with compile-time tap lists and operands one tap ahead (k_conv2d_str2); 0: k_conv2d_str
   RSLO_TUNE_CONV1X1_SPLIT,             // 1 (default): 1x1 output convolutions (cin <= 64) with a pixel's channels dealt to four waves; 0: one thread per pixel
   RSLO_TUNE_CONV2D_FWD_WL,             // dense 3x3 stride-1 forward / data gradient with the weight operands through LDS (k_conv2d_wl, measured slower): 0 (default) never; 1: 8-row tiles; 3: 6-row tiles
-  RSLO_TUNE_SPCONV_SKIP,               // k_spconv_v6 (32-row tiles): a 16-row block none of whose rows has the offset is skipped (same bits): -1 (default) with 64 input channels, 1 always, 0 never
+  RSLO_TUNE_SPCONV_SKIP,               // k_spconv_v6 (32-row tiles): a 16-row block none of whose rows has the offset is skipped (same bits): 1 (default) on, 0 off
   RSLO_TUNE_COUNT
 };
 extern int g_rslo_tune[RSLO_TUNE_COUNT];

@@ -562,7 +562,7 @@ __device__ __forceinline__ Split8 split8(const float4 a, const float4 b, bool ok
 // 42 % on C5).  A lone live block interleaves the accumulators of two column blocks instead of two row blocks.  A row's sum
 // keeps its order (offsets ascending, the same six products): same bits.
 template <int CIN_T, int COUT_T, int RBW, int KS = 1, bool SKIPB = false>
-__global__ __launch_bounds__(SPC_THREADS) void k_spconv_v6(const float *__restrict__ in,
+__global__ __launch_bounds__(SPC_THREADS, (SKIPB ? 4 : 1)) void k_spconv_v6(const float *__restrict__ in,
                                                            const unsigned short *__restrict__ Ws,
                                                            const float *__restrict__ bias,
                                                            const int32_t *__restrict__ nbr,
@@ -1065,11 +1065,10 @@ extern "C" int rslo_spconv_fwd_split(const float *in, int cin, const void *Ws, c
 #define SPC6_LAUNCH_SKIP(CI, CO, KSv)                                                                       \
   hipLaunchKernelGGL((k_spconv_v6<CI, CO, 2, KSv, true>), dim3(xcd_grid(rslo_cdiv(rslo_cdiv(n_out, 32), 4 / KSv))), \
                      dim3(SPC_THREADS), 0, st, in, ws, bias, nbr, row_order, n_out, K, flip_k, act_slope, out)
-  // measured (profiles/r06_spconv_skip.txt, 8 frames, us without | with): 64 -> 64 level 2 159.0 | 158.8, level 3 71.7 | 69.6,
-  // strided 64 -> 64 73.1 | 67.1, inverse 64 -> 64 92.9 | 86.4, inverse 64 -> 32 95.1 | 93.7; 32 -> 32 72.7 | 77.8, strided
-  // 32 -> 64 66.5 | 73.3: on for 64 input channels (-1 = that choice), where a block's products are worth the branch
-  const int skip_mode = rslo_tune(RSLO_TUNE_SPCONV_SKIP);
-  const bool skipb = skip_mode < 0 ? cin == 64 : skip_mode != 0;
+  // measured (profiles/r06_spconv_skip.txt, 8 frames, us without | with, the skipping kernel compiled for 4 waves per SIMD like the
+  // other one): 64 -> 64 level 2 155.3 | 152.6, level 3 70.7 | 67.5, strided 64 -> 64 72.4 | 66.5, inverse 64 -> 64 94.2 | 84.3,
+  // inverse 64 -> 32 96.0 | 93.3, 32 -> 32 71.2 | 68.4, strided 32 -> 64 66.7 | 62.0: on by default (-1 / 1), 0 = off
+  const bool skipb = rslo_tune(RSLO_TUNE_SPCONV_SKIP) != 0;
 #define SPC6_CASE(CI, CO)                                                                                    \
   if (cin == CI && cout == CO) {                                                                             \
     if (rbw == 4) SPC6_LAUNCH(CI, CO, 4, 1);                                                                 \
