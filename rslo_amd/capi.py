@@ -803,12 +803,27 @@ def segbn_bwd(x, y, gy, seg_off, S, max_len, gamma, mean, invstd, act_slope):
     return gx, dgamma, dbeta
 
 
-def dense_scatter(feat, coords, batch, dims, frames=1):
+def dense_scatter(feat, coords, batch, dims, frames=1, out=None):
     """[M,C] rows -> [batch, C, D, H, W]; frames > 1: [batch / frames, frames, C, D, H, W] (rows of frame t of sample b
-    carry the batch index t * (batch / frames) + b)."""
+    carry the batch index t * (batch / frames) + b).  out: a contiguous fp32 buffer of that many elements to write into
+    (the static input of a replayed head graph: rslo_amd/headgraph.py) -- returned viewed to the shape above."""
     M, Cc = feat.shape
     shape = (batch, Cc, dims[0], dims[1], dims[2]) if frames == 1 else (batch // frames, frames, Cc, dims[0], dims[1], dims[2])
-    out = torch.empty(shape, dtype=torch.float32, device=feat.device)
+    if out is not None:
+        n = 1
+        for v in shape:
+            n *= int(v)
+        if not (out.is_contiguous() and out.dtype == torch.float32 and out.device == feat.device and out.numel() == n):
+            raise RsloHipError("dense_scatter: `out` must be a contiguous fp32 buffer of %d elements on %s" % (n, feat.device))
+        # a tensor of its own over the same memory (not a view of `out`: the result is an autograd output)
+        strides, acc = [], 1
+        for v in reversed(shape):
+            strides.append(acc)
+            acc *= int(v)
+        out = torch.empty(0, dtype=torch.float32, device=feat.device).set_(out.untyped_storage(), out.storage_offset(), shape,
+                                                                          tuple(reversed(strides)))
+    else:
+        out = torch.empty(shape, dtype=torch.float32, device=feat.device)
     _chk(lib().rslo_dense_scatter_frames(_ptr(feat, torch.float32, "feat"), _ptr(coords, torch.int32, "coords"), M, Cc,
                                          int(batch), int(frames), _i3(dims), _ptr(out), _stream()), "rslo_dense_scatter")
     return out

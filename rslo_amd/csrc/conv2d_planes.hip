@@ -273,20 +273,8 @@ extern "C" int rslo_conv2d_fwd_p(const void *planes, const void *Ws, const float
   if (tr == 8 && mtw == 2) C2P_GO(8, 2, 1, 2);
   else if (tr == 8) C2P_GO(8, 1, 1, 2);
   else if (mtw == 2) C2P_GO(4, 2, 1, 2);
-  else if (lean) {
-    switch (rslo_tune(RSLO_TUNE_CONV2D_ABLATE)) {
-      case 1: hipLaunchKernelGGL((k_conv2d_fwd_p<4, 1, 1, 4, 1>), grid, dim3(256), 0, st, pl, ws, bias, gm, out); break;
-      case 2: hipLaunchKernelGGL((k_conv2d_fwd_p<4, 1, 1, 4, 2>), grid, dim3(256), 0, st, pl, ws, bias, gm, out); break;
-      case 3: hipLaunchKernelGGL((k_conv2d_fwd_p<4, 1, 1, 4, 3>), grid, dim3(256), 0, st, pl, ws, bias, gm, out); break;
-      case 4: hipLaunchKernelGGL((k_conv2d_fwd_p<4, 1, 1, 4, 4>), grid, dim3(256), 0, st, pl, ws, bias, gm, out); break;
-      case 7: hipLaunchKernelGGL((k_conv2d_fwd_p<4, 1, 1, 4, 7>), grid, dim3(256), 0, st, pl, ws, bias, gm, out); break;
-      case 8: hipLaunchKernelGGL((k_conv2d_fwd_p<4, 1, 1, 4, 8>), grid, dim3(256), 0, st, pl, ws, bias, gm, out); break;
-      case 103: C2P_GO(4, 1, 3, 3); break;
-      case 104: C2P_GO(4, 1, 3, 4); break;
-      case 109: C2P_GO(4, 1, 9, 2); break;
-      default: C2P_GO(4, 1, 1, 4);
-    }
-  }
+  // (the ablations of profiles/NOTES.md round 5 were k_conv2d_fwd_p<4, 1, 1, 4, ABL> and the NAHEAD = 3 / 9 forms, behind conv2d_ablate)
+  else if (lean) C2P_GO(4, 1, 1, 4);
   else C2P_GO(4, 1, 9, 2);
 #undef C2P_GO
   RSLO_CHECK_LAUNCH("k_conv2d_fwd_p");

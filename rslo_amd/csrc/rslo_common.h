@@ -54,9 +54,9 @@ enum RsloTune {
   RSLO_TUNE_CONV2D_S2_MTW,             // stride-2 kernels: 16-channel blocks per wave (0 = choose; 1 | 2)
   RSLO_TUNE_CONV2D_S2_XSC,             //   XCD channel classes, as above
   RSLO_TUNE_BN_SMALL_RC,               // 1: register-cached single-launch BatchNorm on small maps; 0: two-pass loops
-  RSLO_TUNE_SPCONV_RBW,                // k_spconv_v6: 16-row blocks per tile (0 = choose; 1 | 2 | 4)
+  RSLO_TUNE_SPCONV_RBW,                // k_spconv_v6: 16-row blocks per tile (0 = choose; 1 | 2)
   RSLO_TUNE_SPCONV_KS,                 //   waves per tile (0 = choose; 1 | 2 | 4)
-  RSLO_TUNE_SPCONV_V,                  // fp32-MFMA sparse forward: 0 = choose, 100 + RBW forces v3's row blocking, else k_spconv
+  RSLO_TUNE_SPCONV_V,                  // fp32-MFMA sparse forward: 0 = choose, 100 + RBW forces v3's row blocking, 1..99 k_spconv
   RSLO_TUNE_SPCONV_WGRAD_SPLIT,        // 1: split-bf16 sparse weight gradient (k_wgrad3) on 32/64 channels; 0: fp32 MFMA
   RSLO_TUNE_WGRAD_XCD,                 // 1: XCD-ordered grid of the sparse weight gradients; 0: (chunk, offset) grid
   RSLO_TUNE_VFE_LDS,                   // 1: LDS-staged VFE mean; 0: one thread per voxel from memory

@@ -174,126 +174,6 @@ __global__ __launch_bounds__(SPC_THREADS) void k_spconv(const float *__restrict_
 
 
 // ---------------------------------------------------------------------------------------
-// v2: barrier-free, wave-granular variant.  A wave owns 16*RBW output rows x 16*NBW output channels and
-// walks the K offsets on its own: the tile's neighbour rows sit in a wave-private LDS slab, the A fragments
-// are gathered with 16-byte loads as above, and the B fragments (W_k[:, 16*NBW columns]) come straight from
-// global memory (the weight tensor is <= 442 KB and lives in L2/L1) -- no W staging, no __syncthreads in the
-// offset loop, no lock-step between waves; offsets are skipped per 16-row block.  The NB/NBW waves that share
-// a row tile sit in the same workgroup, so their identical gathers hit the CU's L1.
-// ---------------------------------------------------------------------------------------
-template <int CIN_T, int COUT_T, int RBW, int NBW, bool TRANS>
-__global__ __launch_bounds__(SPC_THREADS) void k_spconv_v2(const float *__restrict__ in, int cin,
-                                                           const float *__restrict__ W,
-                                                           const float *__restrict__ bias,
-                                                           const int32_t *__restrict__ nbr, int64_t n_out,
-                                                           int K, int cout, int flip_k, float slope,
-                                                           float *__restrict__ out) {
-  constexpr int NSLAB = CIN_T / 4;
-  constexpr int NB = COUT_T / 16;
-  constexpr int CG = NB / NBW;            // column groups (waves) per row tile
-  constexpr int ROWS = 16 * RBW;
-  __shared__ int32_t nbl[SPC_WAVES][ROWS * SPC_MAXK];
-
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int li = lane & 15, g = lane >> 4;
-  const int64_t n_blocks = (((n_out + ROWS - 1) / ROWS) * CG + SPC_WAVES - 1) / SPC_WAVES;
-  const int64_t vb = xcd_tile(n_blocks);
-  const int64_t task = (vb < n_blocks ? vb : (int64_t)1 << 40) * SPC_WAVES + wid;
-  const int64_t tile = task / CG;
-  const int cg = (int)(task - tile * CG);
-  const int64_t row0 = tile * ROWS;
-  const bool active = row0 < n_out;
-
-  if (active) {
-    const int64_t lim = (n_out - row0) * K;
-    for (int e = lane; e < ROWS * K; e += 64) nbl[wid][e] = (e < lim) ? nbr[row0 * K + e] : -1;
-  }
-  __syncthreads();
-  if (!active) return;
-
-  f32x4 acc[RBW][NBW];
-#pragma unroll
-  for (int rb = 0; rb < RBW; ++rb)
-#pragma unroll
-    for (int nb = 0; nb < NBW; ++nb) acc[rb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  for (int k = 0; k < K; ++k) {
-    int32_t r[RBW];
-    bool on[RBW];
-    bool any = false;
-#pragma unroll
-    for (int rb = 0; rb < RBW; ++rb) {
-      r[rb] = nbl[wid][(rb * 16 + li) * K + k];
-      on[rb] = (__ballot(r[rb] >= 0) != 0ull);
-      any |= on[rb];
-    }
-    if (!any) continue;
-    const int kk = flip_k ? (K - 1 - k) : k;
-    const float *wk = W + (int64_t)kk * cin * cout;
-    float b[NSLAB][NBW];
-    if constexpr (TRANS && CIN_T >= 16) {
-      // B[ci][co] = wk[co * cin + ci]: contiguous along ci -> one float4 per (j, nb) covers slabs 4j..4j+3
-#pragma unroll
-      for (int nb = 0; nb < NBW; ++nb) {
-        const int co = (cg * NBW + nb) * 16 + li;
-#pragma unroll
-        for (int j = 0; j < CIN_T / 16; ++j) {
-          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (co < cout) v = *reinterpret_cast<const float4 *>(wk + (int64_t)co * cin + 16 * j + 4 * g);
-          b[4 * j + 0][nb] = v.x;
-          b[4 * j + 1][nb] = v.y;
-          b[4 * j + 2][nb] = v.z;
-          b[4 * j + 3][nb] = v.w;
-        }
-      }
-    } else {
-#pragma unroll
-      for (int s = 0; s < NSLAB; ++s) {
-        const int ch = slab_channel<CIN_T>(s, g);
-#pragma unroll
-        for (int nb = 0; nb < NBW; ++nb) {
-          const int co = (cg * NBW + nb) * 16 + li;
-          float v = 0.f;
-          if (ch < cin && co < cout) v = TRANS ? wk[(int64_t)co * cin + ch] : wk[(int64_t)ch * cout + co];
-          b[s][nb] = v;
-        }
-      }
-    }
-#pragma unroll
-    for (int rb = 0; rb < RBW; ++rb) {
-      if (!on[rb]) continue;
-      AFrag<CIN_T> a;
-      load_a<CIN_T>(in, r[rb], cin, g, a);
-#pragma unroll
-      for (int s = 0; s < NSLAB; ++s)
-#pragma unroll
-        for (int nb = 0; nb < NBW; ++nb)
-          acc[rb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[s], b[s][nb], acc[rb][nb], 0, 0, 0);
-    }
-  }
-
-#pragma unroll
-  for (int rb = 0; rb < RBW; ++rb) {
-#pragma unroll
-    for (int nb = 0; nb < NBW; ++nb) {
-      const int col = (cg * NBW + nb) * 16 + li;
-      if (col >= cout) continue;
-      const float bv = bias ? bias[col] : 0.f;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int64_t row = row0 + rb * 16 + 4 * g + j;
-        if (row < n_out) {
-          float v = acc[rb][nb][j] + bv;
-          v = v > 0.f ? v : v * slope;
-          out[row * cout + col] = v;
-        }
-      }
-    }
-  }
-}
-
-
-// ---------------------------------------------------------------------------------------
 // v3: the production kernel for channel counts that are multiples of 16.
 //   * wave-granular: a wave owns 16*RBW output rows x all COUT_T channels and walks ONLY its active kernel
 //     offsets (a 27-bit mask built once from the wave-private LDS copy of its neighbour rows), so the offset
@@ -1069,17 +949,19 @@ extern "C" int rslo_spconv_fwd_split(const float *in, int cin, const void *Ws, c
   // other one): 64 -> 64 level 2 155.3 | 152.6, level 3 70.7 | 67.5, strided 64 -> 64 72.4 | 66.5, inverse 64 -> 64 94.2 | 84.3,
   // inverse 64 -> 32 96.0 | 93.3, 32 -> 32 71.2 | 68.4, strided 32 -> 64 66.7 | 62.0: on by default (-1 / 1), 0 = off
   const bool skipb = rslo_tune(RSLO_TUNE_SPCONV_SKIP) != 0;
+  // tilings kept: 32-row tiles by two waves or one, 16-row tiles by four waves (the small-problem tiling).  The other
+  // combinations of (row blocks, waves) were measured and closed in rounds 2-5 (profiles/NOTES.md): (4,1) / (4,2) / (4,4)
+  // register-bound, (2,4) / (1,2) / (1,1) never ahead; a forced value outside the kept set takes the nearest kept one.
+  if (rbw == 4) rbw = 2;
+  if (rbw == 2 && ks == 4) ks = 2;
+  if (rbw == 1) ks = 4;
 #define SPC6_CASE(CI, CO)                                                                                    \
   if (cin == CI && cout == CO) {                                                                             \
-    if (rbw == 4) SPC6_LAUNCH(CI, CO, 4, 1);                                                                 \
-    else if (rbw == 2 && ks == 4) SPC6_LAUNCH(CI, CO, 2, 4);                                                 \
-    else if (rbw == 2 && ks == 2 && skipb) SPC6_LAUNCH_SKIP(CI, CO, 2);                                      \
+    if (rbw == 2 && ks == 2 && skipb) SPC6_LAUNCH_SKIP(CI, CO, 2);                                           \
     else if (rbw == 2 && ks == 2) SPC6_LAUNCH(CI, CO, 2, 2);                                                 \
     else if (rbw == 2 && skipb) SPC6_LAUNCH_SKIP(CI, CO, 1);                                                 \
     else if (rbw == 2) SPC6_LAUNCH(CI, CO, 2, 1);                                                            \
-    else if (ks == 4) SPC6_LAUNCH(CI, CO, 1, 4);                                                             \
-    else if (ks == 2) SPC6_LAUNCH(CI, CO, 1, 2);                                                             \
-    else SPC6_LAUNCH(CI, CO, 1, 1);                                                                          \
+    else SPC6_LAUNCH(CI, CO, 1, 4);                                                                          \
   }
   SPC6_CASE(32, 32) SPC6_CASE(32, 64) SPC6_CASE(64, 32) SPC6_CASE(64, 64)
 #undef SPC6_CASE
@@ -1120,39 +1002,6 @@ static int launch_spconv(const float *in, int cin, const float *W, const float *
     SPC3_CASE(64, 16) SPC3_CASE(64, 32) SPC3_CASE(64, 64)
 #undef SPC3_CASE
     RSLO_CHECK_LAUNCH("spconv_v3");
-    return RSLO_OK;
-  }
-  if (variant >= 1 && variant < 100) {
-    // v2: variant digits = RBW*10 + NBW (e.g. 41 = 4 row blocks x 1 col block per wave)
-    const int rbw = variant / 10, nbw = variant % 10;
-#define SPC2_LAUNCH(CI, CO, RBW, NBW)                                                                     \
-    {                                                                                                   \
-      constexpr int CG = (CO / 16) / NBW;                                                               \
-      const int64_t tasks = rslo_cdiv(n_out, 16 * RBW) * CG;                                            \
-      hipLaunchKernelGGL((k_spconv_v2<CI, CO, RBW, NBW, TRANS>), dim3(xcd_grid(rslo_cdiv(tasks, 4))),   \
-                         dim3(SPC_THREADS), 0, st, in, cin, W, bias, nbr, n_out, K, cout, flip_k, slope, \
-                         out);                                                                          \
-    }
-#define SPC2_CASE(CI, CO)                                                                               \
-    if (ci == CI && co == CO) {                                                                         \
-      constexpr int NBALL = CO / 16;                                                                    \
-      const int nb_eff = nbw > NBALL ? NBALL : nbw;                                                     \
-      if (rbw == 4 && nb_eff == 1) SPC2_LAUNCH(CI, CO, 4, 1)                                            \
-      else if (rbw == 2 && nb_eff == 1) SPC2_LAUNCH(CI, CO, 2, 1)                                       \
-      else if (rbw == 2 && nb_eff == 2) SPC2_LAUNCH(CI, CO, 2, (NBALL >= 2 ? 2 : 1))                    \
-      else if (rbw == 4 && nb_eff == 2) SPC2_LAUNCH(CI, CO, 4, (NBALL >= 2 ? 2 : 1))                    \
-      else if (rbw == 1 && nb_eff == 2) SPC2_LAUNCH(CI, CO, 1, (NBALL >= 2 ? 2 : 1))                    \
-      else if (rbw == 1 && nb_eff >= 4) SPC2_LAUNCH(CI, CO, 1, NBALL)                                   \
-      else if (rbw == 2 && nb_eff >= 4) SPC2_LAUNCH(CI, CO, 2, NBALL)                                   \
-      else SPC2_LAUNCH(CI, CO, 1, 1)                                                                    \
-    }
-    SPC2_CASE(8, 16) SPC2_CASE(8, 32) SPC2_CASE(8, 64)
-    SPC2_CASE(16, 16) SPC2_CASE(16, 32) SPC2_CASE(16, 64)
-    SPC2_CASE(32, 16) SPC2_CASE(32, 32) SPC2_CASE(32, 64)
-    SPC2_CASE(64, 16) SPC2_CASE(64, 32) SPC2_CASE(64, 64)
-#undef SPC2_CASE
-#undef SPC2_LAUNCH
-    RSLO_CHECK_LAUNCH("spconv_v2");
     return RSLO_OK;
   }
   // one 16-row block per wave while the launch would not fill the chip, two otherwise

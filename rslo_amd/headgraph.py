@@ -42,6 +42,7 @@ import torch
 # | "1" / "full": forward and backward replayed
 MODE = {"1": "full", "full": "full", "fwd": "fwd"}.get(os.environ.get("RSLO_HEAD_GRAPH", "fwd"))
 ENABLED = MODE is not None
+DIRECT_INPUT = os.environ.get("RSLO_HEAD_GRAPH_INPUT", "direct") != "copy"      # static_input(): dense() writes into the graph's input
 WARM_CALLS = 1      # the first call of a shape runs eagerly (lazy initialisation: workspaces, operand plans, fused-BN state)
 _STATE = weakref.WeakKeyDictionary()      # head module -> _State (graphs neither deep-copy nor pickle: kept off the module)
 
@@ -299,6 +300,26 @@ def wanted(head, base, T):
         return False      # (the warm-up call of a shape is eager anyway and is what creates the comm)
     st = _STATE.get(head)
     return st is None or not st.failed
+
+
+def static_input(head, T, batch):
+    """The buffer the NEXT training forward of `head` would copy its input map into -- the static input of the current graph --
+    or None: no graph yet, graphs off, eval / no-grad, a forward still waiting for its backward (its static activations are
+    in use).  The encoder's dense() writes the BEV map there directly (70 MB less copied per step); run() sees the same address
+    and skips its copy.  A caller that ends up with a map of another shape simply does not use the buffer."""
+    if not ENABLED or not DIRECT_INPUT or not (head.training and torch.is_grad_enabled()) or T != 2:
+        return None
+    st = _STATE.get(head)
+    if st is None or st.graph is None or st.failed or st.graph.busy() or st.key is None or st.key[3] != MODE:
+        return None
+    if st.key[0][0] != batch or st.key[2] != T:
+        return None
+    if any(st.hooks) or any("forward" in d for d in st.mods):
+        return None
+    from rslo_amd import precision
+    if st.key[4] != precision.low_precision() or st.key[5] != tuple([p.data_ptr() for p in st.params]):
+        return None
+    return st.graph.input_writer
 
 
 def run(head, base, T):

@@ -109,14 +109,15 @@ class SpMiddleFHDWithCov2_3(nn.Module):
                 rb.pairs()
         return x
 
-    def forward(self, voxel_features, coors, batch_size, plan=None, defer_cov=False, bev_frames=1):
+    def forward(self, voxel_features, coors, batch_size, plan=None, defer_cov=False, bev_frames=1, bev_out=None):
         """defer_cov=True: returns (bev, cov_fn); cov_fn() runs the covariance branch.  The caller can then issue it on
         a second stream behind the BEV head (voxel_odom_net.network_forward): the branch only meets the rest of the
         network again in the loss, so its six level-1 / level-0 layers -- launches that fill the GPU -- run beside the
         head's 12 x 22 / 24 x 44 layers, which leave most CUs idle, forward AND backward (autograd replays every node
         on the stream of its forward).  Same kernels on the same inputs: identical results.
         bev_frames = T > 1: batch_size = T * B frames in frame-major order; the BEV map comes back as [B, T * C * D, H, W]
-        (frame t of a sample in channels [t * C * D, (t + 1) * C * D)) instead of [T * B, C * D, H, W]."""
+        (frame t of a sample in channels [t * C * D, (t + 1) * C * D)) instead of [T * B, C * D, H, W].
+        bev_out: a buffer the BEV map is written into (the static input of the head's replayed graph: no 70 MB copy)."""
         # all rulebooks first (they depend on coordinates only): the host reads of output-site counts happen
         # before any convolution is queued, then the ~20 conv launches run without a sync in between
         if plan is None:
@@ -141,7 +142,7 @@ class SpMiddleFHDWithCov2_3(nn.Module):
 
         ret = self.middle_conv_tail(ret0)
         if bev_frames > 1:      # [B, frames * C * D, H, W]: the frames of a sample side by side (what the head concatenates)
-            dense = ret.dense(frames=bev_frames)
+            dense = ret.dense(frames=bev_frames, out=bev_out)
             N, Fr, Cc, D, H, W = dense.shape
             bev = dense.view(N, Fr * Cc * D, H, W)
         else:

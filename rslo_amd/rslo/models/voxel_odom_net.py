@@ -269,8 +269,16 @@ class UnVoxelOdomNetICP3(nn.Module):
         # two frames per sample on the GPU: the encoder writes its BEV map with a sample's frames side by side, which IS the
         # tensor the head would build with torch.cat (70 MB per step and the same again for the gradient's split)
         pair_bev = T == 2 and feats_all.is_cuda and os.environ.get("RSLO_PAIR_BEV", "1") != "0"
+        # a head whose forward is replayed from a hipGraph reads a STATIC input map: the encoder writes its BEV map there
+        bev_out = None
+        if pair_bev:
+            from rslo_amd import headgraph as _hg
+            bev_out = _hg.static_input(self.odom_predictor, T, batch_size)
         bev, cov = self.middle_feature_extractor(feats_all, plan.indices, T * batch_size, plan=plan,
-                                                 defer_cov=two_streams, bev_frames=T if pair_bev else 1)
+                                                 defer_cov=two_streams, bev_frames=T if pair_bev else 1,
+                                                 **({} if bev_out is None else {"bev_out": bev_out}))
+        if bev_out is not None and bev.shape != bev_out.shape:      # (another batch size than the graph's: a fresh map after all)
+            bev_out = None
         cov_fn = cov if two_streams else None
         exchange = self.__dict__.get("_grad_exchange")      # data parallel: the head's gradient bucket leaves when the
         if exchange is not None:                            # gradient of the BEV map is complete (distributed_utils)

@@ -124,11 +124,14 @@ class SparseConvTensor:
             index.batch_offs = offs
         return offs
 
-    def dense(self, channels_first=True, frames=1):
+    def dense(self, channels_first=True, frames=1, out=None):
         """frames > 1 (not part of spconv's API): the batch holds frame t of sample b at index t * (batch / frames) + b and
-        the result is [batch / frames, frames, C, D, H, W] -- the frames of a sample side by side (rslo_dense_scatter_frames)."""
+        the result is [batch / frames, frames, C, D, H, W] -- the frames of a sample side by side (rslo_dense_scatter_frames).
+        out (not part of spconv's API): a buffer to write the dense tensor into (capi.dense_scatter)."""
         feats = self.features.float() if self.features.dtype == torch.bfloat16 else self.features   # bf16 trunk (C4)
-        out = _DenseFn.apply(feats, self.site_index().coords, self.batch_size, tuple(self.spatial_shape), int(frames))
+        # (the buffer travels in a list: it is a destination, not an autograd input)
+        out = _DenseFn.apply(feats, self.site_index().coords, self.batch_size, tuple(self.spatial_shape), int(frames),
+                             None if out is None else [out])
         if not channels_first:
             assert frames == 1
             out = out.permute(0, 2, 3, 4, 1).contiguous()
@@ -144,20 +147,21 @@ class SparseConvTensor:
 
 class _DenseFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, feat, coords, batch, dims, frames=1):
+    def forward(ctx, feat, coords, batch, dims, frames=1, out=None):
         ctx.save_for_backward(coords)
         ctx.meta = (feat.shape[1], batch, dims, frames)
+        kw = {} if out is None else {"out": out[0]}
         if frames == 1:
-            return capi.dense_scatter(feat.contiguous(), coords, batch, dims)
-        return capi.dense_scatter(feat.contiguous(), coords, batch, dims, frames)
+            return capi.dense_scatter(feat.contiguous(), coords, batch, dims, **kw)
+        return capi.dense_scatter(feat.contiguous(), coords, batch, dims, frames, **kw)
 
     @staticmethod
     def backward(ctx, g):
         (coords,) = ctx.saved_tensors
         C_, batch, dims, frames = ctx.meta
         if frames == 1:
-            return capi.dense_gather(g.contiguous(), coords, C_, batch, dims), None, None, None, None
-        return capi.dense_gather(g.contiguous(), coords, C_, batch, dims, frames), None, None, None, None
+            return capi.dense_gather(g.contiguous(), coords, C_, batch, dims), None, None, None, None, None
+        return capi.dense_gather(g.contiguous(), coords, C_, batch, dims, frames), None, None, None, None, None
 
 
 def _w3(weight, K, cin, cout):

@@ -46,6 +46,8 @@ class join_in_enclosing_pass:
         _hold[0] -= 1
         if _hold[0] == 0:
             for dev, st in _state.items():
+                for pid in st.pop("nested", ()):          # the nested passes are over: nothing of theirs can arrive any more
+                    st["targets"].pop(pid, None)
                 if st["pending"] and not st.get("queued"):
                     st["queued"] = True
                     torch.autograd.Variable._execution_engine.queue_callback(lambda d=dev, p=_pass_id(): join(d, p))
@@ -100,6 +102,7 @@ def join(device=None, done_pass=None):
                 st["keep"].clear()
             if done_pass is not None:
                 st["targets"].pop(done_pass, None)
+                st.get("cleanup", set()).discard(done_pass)
 
 
 def leaf(fn, inputs, params=None):
@@ -114,6 +117,12 @@ def leaf(fn, inputs, params=None):
         st = _state[dev] = {"side": torch.cuda.Stream(dev), "cur": cur, "pending": False, "targets": {}, "keep": []}
     # (a non-leaf "parameter", e.g. a cast copy, hands the result to another backward node on the issuing stream)
     targets = _targets(st)
+    pid = _pass_id()
+    if _hold[0] > 0:
+        st.setdefault("nested", set()).add(pid)
+    elif pid not in st.setdefault("cleanup", set()):      # the pass's entry goes when the pass is over, joined or not
+        st["cleanup"].add(pid)
+        torch.autograd.Variable._execution_engine.queue_callback(lambda d=dev, p=pid: join(d, p))
     if any((not p.is_leaf) or p.grad is not None or id(p) in targets for p in params):
         targets.update(id(p) for p in params)
         join(dev)              # everything issued so far is ordered in front of the accumulation that follows
@@ -153,8 +162,7 @@ def leaf(fn, inputs, params=None):
     if not st["pending"]:
         st["pending"], st["cur"] = True, cur
         if _hold[0] == 0:
-            st["queued"] = True
-            torch.autograd.Variable._execution_engine.queue_callback(lambda d=dev, p=_pass_id(): join(d, p))
+            st["queued"] = True      # (the pass's clean-up callback, queued above, is the join)
     return out
 
 

@@ -28,6 +28,7 @@ SWITCHES = {
     "RSLO_PRESPLIT_EARLY": ("1", "mode", "0: head weight operands split in front of the head instead of beside the encoder"),
     "RSLO_PLAN_GATE": ("loss", "mode", "where a structure-plan job of a coming batch may start on the GPU: 'loss' where the current step's loss begins, 'head' at the head's small-map stages, 'fwd_end' behind the loss, 'none' at once"),
     "RSLO_HEAD_GRAPH": ("fwd", "mode", "0: the head issued launch by launch; fwd: the BEV head's training forward replayed from one hipGraph, its backward issued launch by launch over the capture's retained autograd graph; 1 / full: backward replayed as well (rslo_amd/headgraph.py; same bits as the eager pass)"),
+    "RSLO_HEAD_GRAPH_INPUT": ("direct", "mode", "direct: the encoder's dense() writes the BEV map into the static input of the head's replayed graph; copy: into a fresh tensor that is then copied there (70 MB per step; A/B runs)"),
     "RSLO_HEAD_GRAPH_COV": ("before", "mode", "where the covariance branch's forward is issued when the head is a replayed graph: 'before' or 'after' the head"),
     "RSLO_INFER_PLAN_STREAMS": ("1", "mode", "side streams the inference runner (rslo_amd/inference.py) issues the coming scans' structure plans on, round-robin"),
     "RSLO_PREFETCH_PRIORITY": ("", "mode", "HIP stream priority of the structure-plan stream (default: lowest)"),
