@@ -210,12 +210,12 @@ class ConvProbe:
                 return out
             return wrapper
 
-        def fwd_meta(x, W, bias, nbr, flip_k=False, act_slope=1.0, order=None):
+        def fwd_meta(x, W, bias, nbr, flip_k=False, act_slope=1.0, order=None, n_live=None):
             K, cin, cout = W.shape
             return ("fwd", cin, cout, K, nbr.shape[0], nbr if probe.keep_tables else None,
                     probe.kernel_name(cin, cout, nbr.shape[0], False))
 
-        def split_meta(x, Ws, bias, nbr, cin, cout, flip_k=False, act_slope=1.0, order=None):
+        def split_meta(x, Ws, bias, nbr, cin, cout, flip_k=False, act_slope=1.0, order=None, n_live=None):
             if probe.keep_tables and order is not None:
                 probe.orders[(nbr.data_ptr(), tuple(nbr.shape))] = order
             return ("fwd", cin, cout, nbr.shape[1], nbr.shape[0], nbr if probe.keep_tables else None,
@@ -666,6 +666,9 @@ def run_encoder(args, world, rank, local_rank, dist_on, dev):
         torch.cuda.synchronize()
     barrier()
     probe_steps = min(3, args.steps)
+    if runner is not None:
+        for k_ in runner.stats:
+            runner.stats[k_] = 0
     t0 = time.perf_counter()
     for i in range(args.steps):
         if use_probe and runner is None and i == args.steps - probe_steps:
@@ -673,6 +676,7 @@ def run_encoder(args, world, rank, local_rank, dist_on, dev):
         step()
     barrier()
     elapsed = time.perf_counter() - t0
+    st_ = dict(runner.stats) if runner is not None else None
     graph_extras = {}
     if runner is not None:
         # the same scans through the same modules issued EAGERLY (what the graph replays): the launch probe's per-kernel numbers
@@ -688,7 +692,10 @@ def run_encoder(args, world, rank, local_rank, dist_on, dev):
                 probe.enabled = probe.keep_tables = True
             step()
         torch.cuda.synchronize()
-        graph_extras = {"ms_per_pass_same_pipeline_eager": round(1e3 * (time.perf_counter() - t1) / n_eager, 4),
+        graph_extras = {"runner_host_split": {"helper_thread_ms_per_plan": round(1e3 * st_["helper_s"] / max(st_["plans"], 1), 4),
+                                              "ready_wait_ms_per_run": round(1e3 * st_["ready_wait_s"] / max(st_["runs"], 1), 4),
+                                              "handshake_wait_included": "issued.wait() is outside"},
+                        "ms_per_pass_same_pipeline_eager": round(1e3 * (time.perf_counter() - t1) / n_eager, 4),
                         "inference_path": "eval-mode encoder, one hipGraph per plan arena (%d captured), capacity-laid-out plan "
                                           "with padding rows, structure work of the coming scans on a side stream" % len(runner._graphs)}
         eager_pass[0] = False

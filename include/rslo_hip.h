@@ -151,6 +151,12 @@ RSLO_API int rslo_spconv_fwd_split(const float *in, int cin, const void *Ws, con
  *     (a fixed summation order, results within fp32 rounding of the one-wave form).  0 = the library chooses per layer
  *     shape (default: 32 rows and two waves except for 32 -> 32 channels).  Same as the switches spconv_rbw / spconv_ks. */
 RSLO_API void rslo_spconv_set_tiling(int rbw, int ks);
+/*     Round 6, the replayed inference pass (evaluate.py:363-408 -> rslo/models/middle.py:219-245 per frame; rslo_amd/inference.py):
+ *     a capacity-laid-out rulebook has more rows than the scan has sites, the rows past the level's count being padding rows
+ *     (rslo_plan_encoder_pad_tails), and the count lives in a device word.  rslo_spconv_set_live_rows(p) hands that word to the
+ *     NEXT rslo_spconv_fwd / rslo_spconv_fwd_split launch (and only that one): workgroups whose rows all lie at or past *p
+ *     return at once -- their output rows are left unwritten; nothing reads a padding row.  Ignored with a row order. */
+RSLO_API void rslo_spconv_set_live_rows(const int32_t *n_live_dev);
 /*     Tuning switches of the launch code.  The library reads NO environment variable: tile shapes and kernel variants that
  *     exist for A/B measurements and for the parity tests that pin every tiling against the oracle are set through these
  *     calls (process-wide; the defaults are the measured choices).  Names (rslo_tuning_name(i), i = 0 .. until NULL):
@@ -309,7 +315,7 @@ typedef struct {
   int32_t dims0[3];                              /* sparse_shape (z, y, x) of level 0 */
   int32_t subm_ks[RSLO_PLAN_MAX_LEVELS][3];      /* 0,0,0: no SubM table on this level */
   int32_t conv_ks[RSLO_PLAN_MAX_LEVELS][3], conv_stride[RSLO_PLAN_MAX_LEVELS][3], conv_pad[RSLO_PLAN_MAX_LEVELS][3];
-  int32_t want_pairs, want_orders;
+  int32_t want_pairs, want_orders;               /* want_orders: bit l = a mask-sorted row order for the transposed table of level l's strided conv */
   float range6[6], vsize3[3];                    /* voxelizer geometry (rslo_voxelize) */
   int32_t grid_xyz[3], max_points, max_voxels, n_features;
   int64_t cap_rows[RSLO_PLAN_MAX_LEVELS];        /* 0 = default capacity */
@@ -373,6 +379,12 @@ RSLO_API int rslo_segbn_fwd(const float *x, int C, const int32_t *seg_off, int S
                    const float *gamma, const float *beta, float *running_mean /*or NULL*/,
                    float *running_var /*or NULL*/, float momentum, float eps, float act_slope, void *ws,
                    size_t ws_bytes, float *y, float *save_mean, float *save_invstd, void *stream);
+/*     Eval mode (evaluate.py:363-408; the nn.BatchNorm1d layers of rslo/models/middle.py:181-213 with their running statistics):
+ *     y = act((x - running_mean) / sqrt(running_var + eps) * gamma + beta) over [n, C] rows in one launch; act_slope 1 = no
+ *     activation; gamma / beta may be NULL; n_live_dev (or NULL): device count of the live rows (rows past it stay unwritten). */
+RSLO_API int rslo_bn1d_eval_act(const float *x, int64_t n, int C, const float *running_mean, const float *running_var,
+                                const float *gamma, const float *beta, float eps, float act_slope, const int32_t *n_live_dev,
+                                float *y, void *stream);
 /* ws_bytes >= rslo_segbn_ws_bytes(...) + 2*S*C*4 */
 RSLO_API int rslo_segbn_bwd(const float *x, const float *y, const float *gy, int C, const int32_t *seg_off, int S,
                    int64_t max_seg_len, const float *gamma, const float *save_mean, const float *save_invstd,

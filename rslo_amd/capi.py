@@ -42,6 +42,7 @@ SIGNATURES = {
     "rslo_weight_split_many": (C.c_int, [_vp, _i, _i64, _vp]),
     "rslo_spconv_fwd_split": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, C.c_float, _vp, _vp]),
     "rslo_spconv_set_tiling": (None, [_i, _i]),
+    "rslo_spconv_set_live_rows": (None, [_vp]),
     "rslo_peer_create_host": (C.c_int, [C.c_char_p, _i, _i, _i, C.POINTER(C.c_void_p)]),
     "rslo_peer_host_unlink": (C.c_int, [_vp]),
     "rslo_peer_ipc_handle_bytes": (C.c_int, []),
@@ -163,6 +164,7 @@ SIGNATURES = {
     "rslo_loss_tail_fwd": (C.c_int, [_vp, _vp, _vp]),
     "rslo_loss_tail_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rslo_peer_wait_samples": (C.c_int, [_vp, _vp, _i]),
+    "rslo_bn1d_eval_act": (C.c_int, [_vp, _i64, _i, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp]),
     "rslo_wgrad_reduce_defer": (C.c_int, [_vp, _i, _vp]),
     "rslo_wgrad_reduce_many": (C.c_int, [_vp, _i, _vp]),
     "rslo_peer_capture_begin": (C.c_int, [_vp]),
@@ -577,11 +579,13 @@ def rulebook_row_order(nbr, flip_k=False):
     return order
 
 
-def spconv_fwd_split(x, Ws, bias, nbr, cin, cout, flip_k=False, act_slope=1.0, order=None):
+def spconv_fwd_split(x, Ws, bias, nbr, cin, cout, flip_k=False, act_slope=1.0, order=None, n_live=None):
     n_out, K = nbr.shape
     if x.shape[1] != cin:
         raise RsloHipError("spconv_fwd_split: shape mismatch")
     out = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
+    if n_live is not None and order is None:       # consumed by the launch that follows
+        lib().rslo_spconv_set_live_rows(_ptr(n_live, torch.int32, "n_live"))
     _chk(lib().rslo_spconv_fwd_split(_ptr(x, torch.float32, "x"), cin, _ptr(Ws), _ptr(bias, torch.float32, "bias"),
                                      _ptr(nbr, torch.int32, "nbr"), _ptr(order, torch.int32, "order"), n_out, K, cout,
                                      int(flip_k), float(act_slope), _ptr(out), _stream()), "rslo_spconv_fwd_split")
@@ -618,22 +622,26 @@ def _splittable(cin, cout):
     return SPLIT_BF16 and cin in (32, 64) and cout in (32, 64)
 
 
-def spconv_fwd(x, W, bias, nbr, flip_k=False, act_slope=1.0, order=None):
-    """x [Nin,Cin], W [K,Cin,Cout], nbr [Nout,K] -> [Nout,Cout].  order: optional rulebook_row_order(nbr)."""
+def spconv_fwd(x, W, bias, nbr, flip_k=False, act_slope=1.0, order=None, n_live=None):
+    """x [Nin,Cin], W [K,Cin,Cout], nbr [Nout,K] -> [Nout,Cout].  order: optional rulebook_row_order(nbr).
+    n_live: device int32 word = how many leading rows of a capacity-laid-out table are real (rslo_spconv_set_live_rows);
+    rows past it are left unwritten."""
     n_out, K = nbr.shape
     Kw, cin, cout = W.shape
     if Kw != K or x.shape[1] != cin:
         raise RsloHipError("spconv_fwd: shape mismatch x%s W%s nbr%s" % (tuple(x.shape), tuple(W.shape), tuple(nbr.shape)))
     if _splittable(cin, cout):
-        return spconv_fwd_split(x, weight_split(W), bias, nbr, cin, cout, flip_k, act_slope, order)
-    return spconv_fwd_direct(x, W, bias, nbr, flip_k, act_slope, order)
+        return spconv_fwd_split(x, weight_split(W), bias, nbr, cin, cout, flip_k, act_slope, order, n_live)
+    return spconv_fwd_direct(x, W, bias, nbr, flip_k, act_slope, order, n_live)
 
 
-def spconv_fwd_direct(x, W, bias, nbr, flip_k=False, act_slope=1.0, order=None):
+def spconv_fwd_direct(x, W, bias, nbr, flip_k=False, act_slope=1.0, order=None, n_live=None):
     """rslo_spconv_fwd itself (fp32 MFMA kernels)."""
     n_out, K = nbr.shape
     Kw, cin, cout = W.shape
     out = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
+    if n_live is not None and order is None:       # consumed by the launch that follows
+        lib().rslo_spconv_set_live_rows(_ptr(n_live, torch.int32, "n_live"))
     _chk(lib().rslo_spconv_fwd(_ptr(x, torch.float32, "x"), cin, _ptr(W, torch.float32, "W"),
                                _ptr(bias, torch.float32, "bias"), _ptr(nbr, torch.int32, "nbr"),
                                _ptr(order, torch.int32, "order"), n_out, K, cout,
@@ -786,6 +794,17 @@ def segbn_fwd(x, seg_off, S, max_len, gamma, beta, running_mean, running_var, mo
                               float(act_slope), _ptr(ws), wsb, _ptr(y), _ptr(mean), _ptr(invstd), _stream()),
          "rslo_segbn_fwd")
     return y, mean, invstd
+
+
+def bn1d_eval_act(x, running_mean, running_var, gamma, beta, eps, act_slope=1.0, n_live=None):
+    """Eval-mode BatchNorm1d + (Leaky)ReLU over [n, C] fp32 rows in one launch (rslo_bn1d_eval_act)."""
+    n, Cc = x.shape
+    y = torch.empty_like(x)
+    _chk(lib().rslo_bn1d_eval_act(_ptr(x, torch.float32, "x"), n, Cc, _ptr(running_mean, torch.float32, "running_mean"),
+                                  _ptr(running_var, torch.float32, "running_var"), _ptr(gamma, torch.float32, "gamma"),
+                                  _ptr(beta, torch.float32, "beta"), float(eps), float(act_slope),
+                                  _ptr(n_live, torch.int32, "n_live"), _ptr(y), _stream()), "rslo_bn1d_eval_act")
+    return y
 
 
 def segbn_bwd(x, y, gy, seg_off, S, max_len, gamma, mean, invstd, act_slope):

@@ -1439,7 +1439,7 @@ extern "C" int rslo_plan_encoder_layout(const RsloEncoderSpec *spec, int n_cloud
       const int64_t capo = lay->cap_rows[l + 1];
       lay->conv_nbr_off[l] = plan_take(off, (size_t)capo * K * 4);
       lay->conv_nbrT_off[l] = plan_take(off, (size_t)cap * K * 4);
-      if (spec->want_orders) lay->conv_order_off[l] = plan_take(off, (size_t)cap * 4);
+      if ((spec->want_orders >> l) & 1) lay->conv_order_off[l] = plan_take(off, (size_t)cap * 4);
       if (spec->want_pairs) {
         lay->conv_pin_off[l] = plan_take(off, (size_t)capo * K * 4);
         lay->conv_pout_off[l] = plan_take(off, (size_t)capo * K * 4);
@@ -1646,7 +1646,7 @@ extern "C" int rslo_plan_encoder(const RsloEncoderSpec *spec, const RsloPlanLayo
     else PLAN_CONVT(false, false);
 #undef PLAN_CONVT
     RSLO_CHECK_LAUNCH("plan rulebook_conv");
-    if (spec->want_orders) {
+    if ((spec->want_orders >> l) & 1) {
       hipLaunchKernelGGL(k_row_order, dim3((unsigned)rslo_cdiv(cap, RO_WINDOW)), dim3(RO_THREADS), 0, st,
                          (const int32_t *)nbrT, (int64_t)0, d_n, K, 0, (int32_t *)(A + lay->conv_order_off[l]));
       RSLO_CHECK_LAUNCH("plan row_order");
@@ -1704,7 +1704,7 @@ extern "C" int rslo_plan_encoder_pad_tails(const RsloEncoderSpec *spec, const Rs
       const int K = spec->conv_ks[l][0] * spec->conv_ks[l][1] * spec->conv_ks[l][2];
       add(lay->conv_nbr_off[l], l + 1, K, 0);
       add(lay->conv_nbrT_off[l], l, K, 0);
-      if (spec->want_orders) add(lay->conv_order_off[l], l, 1, 1);
+      if ((spec->want_orders >> l) & 1) add(lay->conv_order_off[l], l, 1, 1);
     }
   }
   add(lay->coords_frame_off, 0, 4, 0);

@@ -262,3 +262,42 @@ extern "C" int rslo_segbn_bwd(const float *x, const float *y, const float *gy, i
   RSLO_CHECK_LAUNCH("segbn_bwd");
   return RSLO_OK;
 }
+
+
+// ---- eval mode (evaluate.py:363-408 runs the network in eval(): rslo/models/middle.py:181-213's nn.BatchNorm1d layers then
+// normalise with their running statistics) -- y = act((x - mean) / sqrt(var + eps) * gamma + beta), one launch instead of the
+// library's statistics-to-invstd kernel + transform kernel + a separate activation kernel.  n_live: optional device count of
+// the live rows of a capacity-laid-out tensor (rows past it are padding: left unwritten).
+__global__ __launch_bounds__(256) void k_bn1d_eval_act(const float *__restrict__ x, int64_t n, int C, const float *__restrict__ mean,
+                                                       const float *__restrict__ var, const float *__restrict__ gamma,
+                                                       const float *__restrict__ beta, float eps, float slope,
+                                                       const int32_t *__restrict__ n_live, float *__restrict__ y) {
+  const int64_t rows = n_live ? (int64_t)*n_live : n;
+  const int64_t total = (rows < n ? rows : n) * C;
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < total; i += (int64_t)gridDim.x * 1024) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int64_t j = i + e;
+      if (j < total) {
+        const int c = (int)(j % C);
+        const float inv = 1.0f / sqrtf(var[c] + eps);
+        float v = (x[j] - mean[c]) * inv;
+        v = v * (gamma ? gamma[c] : 1.f) + (beta ? beta[c] : 0.f);
+        y[j] = v > 0.f ? v : v * slope;
+      }
+    }
+  }
+}
+
+extern "C" int rslo_bn1d_eval_act(const float *x, int64_t n, int C, const float *running_mean, const float *running_var,
+                                  const float *gamma, const float *beta, float eps, float act_slope, const int32_t *n_live_dev,
+                                  float *y, void *stream) {
+  RSLO_CHECK_ARG(x && y && running_mean && running_var && n >= 0 && C >= 1, "rslo_bn1d_eval_act: bad arguments");
+  if (n == 0) return RSLO_OK;
+  int64_t blocks = rslo_cdiv(n * C, 1024);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(k_bn1d_eval_act, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, n, C, running_mean,
+                     running_var, gamma, beta, eps, act_slope, n_live_dev, y);
+  RSLO_CHECK_LAUNCH("k_bn1d_eval_act");
+  return RSLO_OK;
+}

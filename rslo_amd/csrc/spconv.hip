@@ -34,6 +34,17 @@ __device__ __forceinline__ int64_t xcd_tile(int64_t n_tiles) {
   return (int64_t)(blockIdx.x % NX) * chunk + blockIdx.x / NX;
 }
 static inline unsigned xcd_grid(int64_t n_tiles) { return (unsigned)(8 * ((n_tiles + 7) / 8)); }
+// The same order over the first n_live of the launch's tiles (capacity-laid-out tables: the tiles past the live rows are
+// padding): every XCD gets a contiguous eighth of the LIVE tiles, the surplus workgroups (-1) return at once.  Mapping the
+// capacity instead leaves the XCDs that own the tail with nothing but padding (measured: 20 000 live rows of 40 000 took
+// 89 us against 92).
+__device__ __forceinline__ int64_t xcd_tile_live(int64_t n_live) {
+  static const int NX = 8;
+  const int64_t chunk = (n_live + NX - 1) / NX, j = blockIdx.x / NX;
+  if (j >= chunk) return -1;
+  const int64_t t = (int64_t)(blockIdx.x % NX) * chunk + j;
+  return t < n_live ? t : -1;
+}
 
 template <int CIN_T>
 struct AFrag {
@@ -79,7 +90,7 @@ __global__ __launch_bounds__(SPC_THREADS) void k_spconv(const float *__restrict_
                                                         const float *__restrict__ bias,
                                                         const int32_t *__restrict__ nbr, int64_t n_out,
                                                         int K, int cout, int flip_k, float slope,
-                                                        float *__restrict__ out) {
+                                                        float *__restrict__ out, const int32_t *__restrict__ n_live) {
   constexpr int LDW = COUT_T + 4;
   constexpr int NSLAB = CIN_T / 4;
   constexpr int NB = COUT_T / 16;
@@ -90,8 +101,9 @@ __global__ __launch_bounds__(SPC_THREADS) void k_spconv(const float *__restrict_
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int li = lane & 15, g = lane >> 4;
   const int64_t n_tiles = (n_out + TILE - 1) / TILE;
-  const int64_t tile_id = xcd_tile(n_tiles);
-  if (tile_id >= n_tiles) return;
+  // (n_live: only the tiles that hold live rows of a capacity-laid-out table, rslo_spconv_set_live_rows)
+  const int64_t tile_id = n_live ? xcd_tile_live(((int64_t)*n_live + TILE - 1) / TILE) : xcd_tile(n_tiles);
+  if (tile_id < 0 || tile_id >= n_tiles) return;
   const int64_t row0 = tile_id * TILE;
 
   // neighbour rows of the tile: one contiguous slab of the table
@@ -241,7 +253,7 @@ __global__ __launch_bounds__(SPC_THREADS) void k_spconv_v3(const float *__restri
                                                            const int32_t *__restrict__ nbr,
                                                            const int32_t *__restrict__ order, int64_t n_out,
                                                            int K, int flip_k, float slope,
-                                                           float *__restrict__ out) {
+                                                           float *__restrict__ out, const int32_t *__restrict__ n_live) {
   constexpr int NJ = CIN_T / 16;
   constexpr int NB = COUT_T / 16;
   constexpr int ROWS = 16 * RBW;
@@ -252,7 +264,10 @@ __global__ __launch_bounds__(SPC_THREADS) void k_spconv_v3(const float *__restri
   const int li = lane & 15, g = lane >> 4;
   const int64_t n_tiles = (n_out + ROWS - 1) / ROWS;
   const int64_t n_blocks = (n_tiles + SPC_WAVES - 1) / SPC_WAVES;
-  const int64_t vb = xcd_tile(n_blocks);
+  // (n_live: only the workgroups that hold live rows of a capacity-laid-out table, rslo_spconv_set_live_rows)
+  const bool use_live = n_live != nullptr && order == nullptr;
+  const int64_t vb = use_live ? xcd_tile_live(((int64_t)*n_live + SPC_WAVES * ROWS - 1) / (SPC_WAVES * ROWS)) : xcd_tile(n_blocks);
+  if (vb < 0) return;
   const int64_t tile = vb * SPC_WAVES + wid;
   const bool active = vb < n_blocks && tile < n_tiles;
   const int64_t row0 = tile * ROWS;
@@ -448,7 +463,7 @@ __global__ __launch_bounds__(SPC_THREADS, (SKIPB ? 4 : 1)) void k_spconv_v6(cons
                                                            const int32_t *__restrict__ nbr,
                                                            const int32_t *__restrict__ order, int64_t n_out,
                                                            int K, int flip_k, float slope,
-                                                           float *__restrict__ out) {
+                                                           float *__restrict__ out, const int32_t *__restrict__ n_live) {
   constexpr int NS = CIN_T / 32;       // K-steps of 32 input channels
   constexpr int NB = COUT_T / 16;      // 16-column blocks: column li of block nb = output channel NB li + nb
   constexpr int ROWS = 16 * RBW;
@@ -462,7 +477,12 @@ __global__ __launch_bounds__(SPC_THREADS, (SKIPB ? 4 : 1)) void k_spconv_v6(cons
   const int tw = wid / KS, half = wid % KS;
   const int64_t n_tiles = (n_out + ROWS - 1) / ROWS;
   const int64_t n_blocks = (n_tiles + TPB - 1) / TPB;
-  const int64_t vb = xcd_tile(n_blocks);
+  // n_live (rslo_spconv_set_live_rows: a capacity-laid-out table whose live-row count stays on the device): only the
+  // workgroups that hold live rows run, spread over the XCDs like a launch of that size; a workgroup of padding rows has
+  // nothing to compute and nothing anyone reads to write
+  const bool use_live = n_live != nullptr && order == nullptr;
+  const int64_t vb = use_live ? xcd_tile_live(((int64_t)*n_live + TPB * ROWS - 1) / (TPB * ROWS)) : xcd_tile(n_blocks);
+  if (vb < 0) return;
   const int64_t tile = vb * TPB + tw;
   const bool active = vb < n_blocks && tile < n_tiles;
   const int64_t row0 = tile * ROWS;
@@ -911,6 +931,15 @@ extern "C" int rslo_weight_split_many(const RsloWeightSplitDesc *desc_dev, int n
   return RSLO_OK;
 }
 
+// Live-row count of the NEXT forward launch (rslo_spconv_fwd / rslo_spconv_fwd_split), consumed by it: see include/rslo_hip.h
+static const int32_t *g_spc_live_rows = nullptr;
+extern "C" void rslo_spconv_set_live_rows(const int32_t *n_live_dev) { g_spc_live_rows = n_live_dev; }
+static inline const int32_t *spc_take_live() {
+  const int32_t *p = g_spc_live_rows;
+  g_spc_live_rows = nullptr;
+  return p;
+}
+
 extern "C" void rslo_spconv_set_tiling(int rbw, int ks) {
   g_rslo_tune[RSLO_TUNE_SPCONV_RBW] = (rbw == 1 || rbw == 2 || rbw == 4) ? rbw : 0;
   g_rslo_tune[RSLO_TUNE_SPCONV_KS] = (ks == 1 || ks == 2 || ks == 4) ? ks : 0;
@@ -920,6 +949,7 @@ extern "C" int rslo_spconv_fwd_split(const float *in, int cin, const void *Ws, c
                                      const int32_t *row_order, int64_t n_out, int K, int cout, int flip_k,
                                      float act_slope, float *out, void *stream) {
   hipStream_t st = (hipStream_t)stream;
+  const int32_t *live = spc_take_live();
   RSLO_CHECK_ARG((cin == 32 || cin == 64) && (cout == 32 || cout == 64), "spconv_fwd_split: channels must be 32 or 64");
   RSLO_CHECK_ARG(K >= 1 && K <= SPC_MAXK, "spconv_fwd_split: K must be in 1..27");
   if (n_out == 0) return RSLO_OK;
@@ -941,10 +971,10 @@ extern "C" int rslo_spconv_fwd_split(const float *in, int cin, const void *Ws, c
   }
 #define SPC6_LAUNCH(CI, CO, RB, KSv)                                                                        \
   hipLaunchKernelGGL((k_spconv_v6<CI, CO, RB, KSv>), dim3(xcd_grid(rslo_cdiv(rslo_cdiv(n_out, 16 * RB), 4 / KSv))), \
-                     dim3(SPC_THREADS), 0, st, in, ws, bias, nbr, row_order, n_out, K, flip_k, act_slope, out)
+                     dim3(SPC_THREADS), 0, st, in, ws, bias, nbr, row_order, n_out, K, flip_k, act_slope, out, live)
 #define SPC6_LAUNCH_SKIP(CI, CO, KSv)                                                                       \
   hipLaunchKernelGGL((k_spconv_v6<CI, CO, 2, KSv, true>), dim3(xcd_grid(rslo_cdiv(rslo_cdiv(n_out, 32), 4 / KSv))), \
-                     dim3(SPC_THREADS), 0, st, in, ws, bias, nbr, row_order, n_out, K, flip_k, act_slope, out)
+                     dim3(SPC_THREADS), 0, st, in, ws, bias, nbr, row_order, n_out, K, flip_k, act_slope, out, live)
   // measured (profiles/r06_spconv_skip.txt, 8 frames, us without | with, the skipping kernel compiled for 4 waves per SIMD like the
   // other one): 64 -> 64 level 2 155.3 | 152.6, level 3 70.7 | 67.5, strided 64 -> 64 72.4 | 66.5, inverse 64 -> 64 94.2 | 84.3,
   // inverse 64 -> 32 96.0 | 93.3, 32 -> 32 71.2 | 68.4, strided 32 -> 64 66.7 | 62.0: on by default (-1 / 1), 0 = off
@@ -978,6 +1008,7 @@ template <bool TRANS>
 static int launch_spconv(const float *in, int cin, const float *W, const float *bias, const int32_t *nbr,
                          const int32_t *order, int64_t n_out, int K, int cout, int flip_k, float slope, float *out,
                          hipStream_t st) {
+  const int32_t *live = spc_take_live();
   RSLO_CHECK_ARG(cin >= 1 && cin <= 64 && cout >= 1 && cout <= 64, "spconv: channels must be in 1..64");
   RSLO_CHECK_ARG(K >= 1 && K <= SPC_MAXK, "spconv: K must be in 1..27");
   RSLO_CHECK_ARG(cin <= 8 || cin % 4 == 0, "spconv: cin > 8 must be a multiple of 4");
@@ -992,10 +1023,10 @@ static int launch_spconv(const float *in, int cin, const float *W, const float *
     if (ci == CI && co == CO) {                                                                            \
       if (rbw == 2)                                                                                        \
         hipLaunchKernelGGL((k_spconv_v3<CI, CO, 2, TRANS>), dim3(xcd_grid(rslo_cdiv(rslo_cdiv(n_out, 32), 4))), \
-                           dim3(SPC_THREADS), 0, st, in, W, bias, nbr, order, n_out, K, flip_k, slope, out); \
+                           dim3(SPC_THREADS), 0, st, in, W, bias, nbr, order, n_out, K, flip_k, slope, out, live); \
       else                                                                                                 \
         hipLaunchKernelGGL((k_spconv_v3<CI, CO, 1, TRANS>), dim3(xcd_grid(rslo_cdiv(rslo_cdiv(n_out, 16), 4))), \
-                           dim3(SPC_THREADS), 0, st, in, W, bias, nbr, order, n_out, K, flip_k, slope, out); \
+                           dim3(SPC_THREADS), 0, st, in, W, bias, nbr, order, n_out, K, flip_k, slope, out, live); \
     }
     SPC3_CASE(16, 16) SPC3_CASE(16, 32) SPC3_CASE(16, 64)
     SPC3_CASE(32, 16) SPC3_CASE(32, 32) SPC3_CASE(32, 64)
@@ -1011,11 +1042,11 @@ static int launch_spconv(const float *in, int cin, const float *W, const float *
     if (rb2)                                                                                         \
       hipLaunchKernelGGL((k_spconv<CI, CO, 2, TRANS>), dim3(xcd_grid(rslo_cdiv(n_out, 128))),        \
                          dim3(SPC_THREADS), 0, st, in, cin, W, bias, nbr, n_out, K, cout, flip_k,    \
-                         slope, out);                                                                \
+                         slope, out, live);                                                          \
     else                                                                                             \
       hipLaunchKernelGGL((k_spconv<CI, CO, 1, TRANS>), dim3(xcd_grid(rslo_cdiv(n_out, 64))),         \
                          dim3(SPC_THREADS), 0, st, in, cin, W, bias, nbr, n_out, K, cout, flip_k,    \
-                         slope, out);                                                                \
+                         slope, out, live);                                                          \
   }
   SPC_CASE(8, 16) SPC_CASE(8, 32) SPC_CASE(8, 64)
   SPC_CASE(16, 16) SPC_CASE(16, 32) SPC_CASE(16, 64)

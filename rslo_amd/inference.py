@@ -52,15 +52,19 @@ class EncoderGraphRunner:
         # structure stream(s), used round-robin.  One is the measured choice: a plan alone takes 0.43 ms per scan on one stream and
         # 0.26 on two alternating ones, but beside the replayed pass two or three streams change nothing (0.75-0.77 ms per scan)
         import os
-        self.sides = [torch.cuda.Stream(self.device) for _ in range(int(os.environ.get("RSLO_INFER_PLAN_STREAMS", "1")))]
+        prio = os.environ.get("RSLO_INFER_PLAN_PRIORITY", "")
+        self.sides = [torch.cuda.Stream(self.device, **({"priority": int(prio)} if prio else {}))
+                      for _ in range(int(os.environ.get("RSLO_INFER_PLAN_STREAMS", "1")))]
         self._exact_planner = EncoderPlanner(net_like, max_voxels, arenas=2)
         self.fallbacks = 0
         self._seq = 0
         self._queue = queue.Queue()
         self._thread = threading.Thread(target=self._work, daemon=True)
         self._thread.start()
+        self.stats = {"plans": 0, "helper_s": 0.0, "ready_wait_s": 0.0, "runs": 0}      # host-side time split (bench.py c2)
         self._graphs = {}          # arena slot -> (graph, bev, cov, rows_dev0, arena data_ptr)
         self._last_use = {}        # arena slot -> event recorded behind the last replay that read the arena
+        self._pending = {}         # arena slot -> scan submitted into it and not yet run()
 
     def submit(self, clouds):
         """clouds: one CUDA fp32 [P,F] tensor (or a list of `frames_per_job` of them).  Returns a handle for run().  The
@@ -69,9 +73,15 @@ class EncoderGraphRunner:
         if torch.is_tensor(clouds):
             clouds = [clouds]
         slot = self._seq
+        a = slot % self.planner.n_arenas
+        if a in self._pending:
+            # the plan of this scan would overwrite tables the pending replay of handle `self._pending[a]` still has to read
+            raise capi.RsloHipError("EncoderGraphRunner.submit: arena %d still holds scan %d, which has not been run(); keep fewer "
+                                    "than %d handles outstanding" % (a, self._pending[a], self.planner.n_arenas))
         self._seq += 1
+        self._pending[a] = slot
         h = _Handle(slot)
-        prev = self._last_use.get(slot % self.planner.n_arenas)
+        prev = self._last_use.get(a)
         self._queue.put((h, clouds, prev))
         return h
 
@@ -82,6 +92,8 @@ class EncoderGraphRunner:
             if item is None:
                 return
             h, clouds, prev = item
+            import time as _t
+            t0 = _t.perf_counter()
             try:
                 side = self.sides[h.slot % len(self.sides)]
                 with torch.cuda.stream(side):
@@ -91,6 +103,8 @@ class EncoderGraphRunner:
                                                 point_capacity=self.point_capacity)
             except Exception as e:      # surfaces in run()
                 h.error = e
+            self.stats["plans"] += 1
+            self.stats["helper_s"] += _t.perf_counter() - t0
             h.issued.set()
 
     def close(self):
@@ -134,11 +148,17 @@ class EncoderGraphRunner:
         if handle.error is not None:
             raise handle.error
         job = handle.job
+        if self._pending.get(handle.slot % self.planner.n_arenas) == handle.slot:
+            del self._pending[handle.slot % self.planner.n_arenas]
         cur = torch.cuda.current_stream(self.device)
         # the counts block of the job reached pinned memory behind job.ready; it was submitted `depth` scans ago, so the event has
         # normally passed and this is a read of host memory, not a wait.  A level that outgrew its capacity (not a LiDAR-shaped
         # scan) cannot be replayed: that scan takes the exact-size eager pass.
+        import time as _t
+        t0 = _t.perf_counter()
         job.ready.synchronize()
+        self.stats["ready_wait_s"] += _t.perf_counter() - t0
+        self.stats["runs"] += 1
         if int(job.counts[capi.PLAN_CNT_OVERFLOW]) != 0:
             self.fallbacks += 1
             return self._exact(job)

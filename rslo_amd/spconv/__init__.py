@@ -206,8 +206,13 @@ class _SparseConvFn(torch.autograd.Function):
         # table walked forward / backward: (nbr, nbrT) of the rulebook, swapped for an inverse conv
         fwd_key, bwd_key = ("nbrT", "nbr") if inverse else ("nbr", "nbr_flip" if subm else "nbrT")
         ctx.bwd_key = bwd_key
-        y = capi.spconv_fwd(x, W3, bias, nbr, flip_k=False, act_slope=slope,
-                            order=None if rb is None else rb.order(fwd_key))
+        live = getattr(rb, "n_live", None) if rb is not None else None      # capacity-laid-out plan (rslo_amd/inference.py)
+        if live is not None and live.get(fwd_key) is not None and not torch.is_grad_enabled():
+            y = capi.spconv_fwd(x, W3, bias, nbr, flip_k=False, act_slope=slope, order=rb.order(fwd_key),
+                                n_live=live[fwd_key])
+        else:
+            y = capi.spconv_fwd(x, W3, bias, nbr, flip_k=False, act_slope=slope,
+                                order=None if rb is None else rb.order(fwd_key))
         ctx.save_for_backward(x, weight, y if slope != 1.0 else None, nbr, nbrT)
         ctx.meta = (subm, slope, bias is not None)
         ctx.params = (weight,) if bias is None else (weight, bias)      # (the objects whose .grad the results become)
@@ -548,6 +553,16 @@ class SparseSequential(SparseModule):
                     j = i + 1
                     slope = _act_slope(mods[j]) if j < len(mods) else None
                     x = _segmented_bn_act(x, m, 1.0 if slope is None else slope)
+                    i = j + 1 if slope is not None else j
+                    continue
+                if (type(m) is nn.BatchNorm1d and not m.training and m.track_running_stats and x.features.is_cuda
+                        and x.features.dtype == torch.float32 and x.features.shape[0] > 0 and not torch.is_grad_enabled()):
+                    # eval / no-grad (evaluate.py): running statistics + the activation that follows in ONE launch
+                    j = i + 1
+                    slope = _act_slope(mods[j]) if j < len(mods) else None
+                    live = getattr(x.site_index(), "n_live", None) if x._index is not None else None
+                    x = x._like(capi.bn1d_eval_act(x.features.contiguous(), m.running_mean, m.running_var, m.weight, m.bias,
+                                                   m.eps, 1.0 if slope is None else slope, n_live=live))
                     i = j + 1 if slope is not None else j
                     continue
                 if isinstance(m, nn.modules.batchnorm._BatchNorm) and m.training and x.batch_size > 1:

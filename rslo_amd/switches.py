@@ -31,6 +31,7 @@ SWITCHES = {
     "RSLO_HEAD_GRAPH_INPUT": ("direct", "mode", "direct: the encoder's dense() writes the BEV map into the static input of the head's replayed graph; copy: into a fresh tensor that is then copied there (70 MB per step; A/B runs)"),
     "RSLO_HEAD_GRAPH_COV": ("before", "mode", "where the covariance branch's forward is issued when the head is a replayed graph: 'before' or 'after' the head"),
     "RSLO_INFER_PLAN_STREAMS": ("1", "mode", "side streams the inference runner (rslo_amd/inference.py) issues the coming scans' structure plans on, round-robin"),
+    "RSLO_INFER_PLAN_PRIORITY": ("", "mode", "HIP stream priority of the inference runner's structure-plan stream(s) (default: the runtime's default; measured without effect on C2)"),
     "RSLO_PREFETCH_PRIORITY": ("", "mode", "HIP stream priority of the structure-plan stream (default: lowest)"),
     "RSLO_SWITCH_INTERVAL": ("0.0002", "mode", "interpreter switch interval while helper threads issue GPU work"),
     "RSLO_SPCONV_SPLIT": ("1", "path", "0: 32/64-channel sparse layers on the fp32-MFMA kernels instead of the split-bf16 ones"),

@@ -1457,6 +1457,28 @@ def test_conv2d_fwd_tile_heights_keep_the_bits(hip, B, cin, cout, H, W):
 
 
 @pytest.mark.gpu
+def test_eval_batchnorm1d_with_activation_in_one_launch(hip):
+    """rslo_bn1d_eval_act (round 6): eval-mode nn.BatchNorm1d + LeakyReLU of the covariance branch (rslo/models/middle.py:181-213
+    under evaluate.py's net.eval()) against torch's F.batch_norm(training=False) + leaky_relu in float64; with a device-side
+    live-row count the rows past it stay untouched."""
+    import torch.nn.functional as F
+    torch.manual_seed(3)
+    for n, C in ((31495, 16), (1777, 32), (5, 7)):
+        x = torch.randn(n, C, device="cuda") * 2 + 0.5
+        rm, rv = torch.randn(C, device="cuda"), torch.rand(C, device="cuda") + 0.3
+        g, b = torch.randn(C, device="cuda"), torch.randn(C, device="cuda")
+        for slope in (0.01, 0.0, 1.0):
+            y = hip.bn1d_eval_act(x, rm, rv, g, b, 1e-3, slope)
+            ref = F.batch_norm(x.double(), rm.double(), rv.double(), g.double(), b.double(), False, 0.0, 1e-3)
+            ref = F.leaky_relu(ref, slope) if slope != 1.0 else ref
+            assert float((y.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+        live = torch.tensor([n // 2], dtype=torch.int32, device="cuda")
+        y2 = hip.bn1d_eval_act(x, rm, rv, g, b, 1e-3, 0.01, n_live=live)
+        y = hip.bn1d_eval_act(x, rm, rv, g, b, 1e-3, 0.01)
+        assert torch.equal(y2[:n // 2], y[:n // 2])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("cin,cout", [(32, 32), (64, 64), (32, 64), (64, 32)])
 def test_spconv_dead_row_block_skip_keeps_the_bits(hip, cin, cout):
     """Switch spconv_skip (round 6): k_spconv_v6 on 32-row tiles skips a 16-row block none of whose rows has the offset.  A

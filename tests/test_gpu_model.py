@@ -1363,4 +1363,11 @@ def test_encoder_graph_runner_replays_any_scan_bit_equal_to_the_eager_pass(hip):
         assert torch.equal(bev, rb), i
         assert torch.equal(cov[:n], rc), i
     assert len(runner._graphs) == 4         # one capture per arena, the fifth scan replayed the first arena's graph
+    # as many handles outstanding as there are arenas: the next plan would overwrite tables a pending replay still reads
+    hs = [runner.submit(clouds[0]) for _ in range(4)]
+    with pytest.raises(hip.RsloHipError):
+        runner.submit(clouds[0])
+    for h in hs:
+        runner.run(h)
+    runner.run(runner.submit(clouds[1]))
     runner.close()
