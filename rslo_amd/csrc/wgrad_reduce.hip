@@ -23,8 +23,12 @@ struct WrBatch {
 __global__ __launch_bounds__(256) void k_wgrad_reduce_many(WrBatch b) {
   __shared__ float red[256];
   const int bid = (int)blockIdx.x;
-  int l = 0;
-  while (l + 1 < b.n && bid >= b.start[l + 1]) ++l;      // (uniform: scalar loop over the kernel arguments)
+  int l = 0, hi = b.n;       // (uniform: a scalar binary search over the kernel arguments -- the last l with start[l] <= bid)
+  while (hi - l > 1) {
+    const int mid = (l + hi) >> 1;
+    if (bid >= b.start[mid]) l = mid;
+    else hi = mid;
+  }
   const RsloWgradReduce &d = b.d[l];
   const int lb = bid - b.start[l];
   if (d.kind == 0)

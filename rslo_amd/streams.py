@@ -27,8 +27,11 @@ ENABLED = os.environ.get("RSLO_WGRAD_STREAM", "1") != "0"
 # launch per layer: 45 dense 3x3, 5 dense 1x1, 20 sparse) is collected and run as ONE launch per stream at the end of the pass
 # (rslo_amd.capi.ReduceSink, csrc/wgrad_reduce.hip): the dense ones on the leaf stream in front of its join, the sparse ones on
 # the issuing stream in an end-of-pass callback.  Same block bodies, same bits.  "0": a reduce launch per layer, as before.
-DEFER_REDUCES = os.environ.get("RSLO_DEFER_WGRAD_REDUCE", "1") != "0"
-_DEFER_WHICH = os.environ.get("RSLO_DEFER_WGRAD_REDUCE", "1")      # (debugging: "dense" / "sparse" = only that family)
+DEFER_REDUCES = os.environ.get("RSLO_DEFER_WGRAD_REDUCE", "8") != "0"
+_DEFER_WHICH = os.environ.get("RSLO_DEFER_WGRAD_REDUCE", "8")      # (debugging: "dense" / "sparse" = only that family)
+# a sink is flushed when it holds this many layers (and at the end of the pass): the partials of ~8 layers (~100 MB) are still in
+# the 256 MB Infinity Cache when their reduce reads them, the partials of a whole pass (~900 MB) are not ("1": only at the end)
+FLUSH_EVERY = int(_DEFER_WHICH) if _DEFER_WHICH.isdigit() and int(_DEFER_WHICH) >= 2 else (1 << 30)
 _state = {}          # device -> {"side", "cur": stream of the backward nodes, "pending", "targets": {pass -> ids}, "keep": inputs}
 _hold = [0]          # > 0: inside join_in_enclosing_pass()
 
@@ -146,6 +149,8 @@ def leaf(fn, inputs, params=None):
                 sink = st["sink"] = capi.ReduceSink()
             with sink.collect():
                 out = fn()
+            if sink.pending() >= FLUSH_EVERY:          # (on the side stream, behind the kernels that wrote the partials)
+                sink.flush()
         else:
             out = fn()
     finally:
@@ -195,6 +200,8 @@ def deferred_reduce(params):
     if pid not in st["queued"]:
         st["queued"].add(pid)
         torch.autograd.Variable._execution_engine.queue_callback(lambda d=dev, p=pid: flush_deferred(d, p))
+    if st["sink"].pending() >= FLUSH_EVERY:      # the layers collected so far, while their partials are cache-resident
+        st["sink"].flush()
     if seen:
         # a second contribution to a gradient in one pass (two forwards before one backward, a shared weight), or an
         # accumulation: the engine ADDS at once -- everything collected so far is made real, this result is computed in place

@@ -147,8 +147,9 @@ class ExamplePrefetcher:
             try:
                 if self.planner is not None:
                     with torch.cuda.stream(stream):
-                        if prev_done is not None:     # arena reuse: ordered behind the training stream on the GPU
-                            stream.wait_event(prev_done)
+                        for ev_ in (prev_done if isinstance(prev_done, tuple) else (prev_done,)):
+                            if ev_ is not None:       # arena reuse (+ the start gate): ordered behind the training stream on the GPU
+                                stream.wait_event(ev_)
                         cl = [[c if torch.is_tensor(c) else torch.from_numpy(c) for c in s] for s in clouds]
                         cl = [[c.to(self.device, torch.float32).contiguous() for c in s] for s in cl]
                         ex = self.planner.submit(cl, slot=seq)          # a job: becomes the example in get()
@@ -198,14 +199,18 @@ class ExamplePrefetcher:
             self._done_ring.append(done)
             lag = self.planner.n_arenas - 1 - self.depth
             gate = self._gate
+            # the arena-reuse event is ALWAYS waited for (it is old: the wait costs nothing); a gate event only moves the start
+            # later -- it may be stale (recorded in an earlier step: the head's gate is not re-recorded while the head is
+            # replayed from its hipGraph, the loss gate not in eval loops), and a stale event alone orders nothing
+            ring_ev = self._done_ring[-1 - lag] if len(self._done_ring) > lag else None
             if gate == "fwd_end":         # start when the forward + loss of the step that just issued them have drained
-                pass                      # `done` IS that event
+                done = (ring_ev, done)
             elif gate == "loss" and self._gate_event("loss") is not None:
-                done = self._gate_event("loss")          # start where this step's loss begins on the GPU
+                done = (ring_ev, self._gate_event("loss"))          # start where this step's loss begins on the GPU
             elif gate == "head" and self._gate_event("head") is not None:
-                done = self._gate_event("head")          # the head's small-map stages (forward)
+                done = (ring_ev, self._gate_event("head"))          # the head's small-map stages (forward)
             else:
-                done = self._done_ring[-1 - lag] if len(self._done_ring) > lag else None
+                done = (ring_ev,)
             del self._done_ring[:-(lag + 1)]
         self._in.put((self._next_submit, clouds, done))
         self._next_submit += 1
