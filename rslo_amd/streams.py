@@ -172,18 +172,36 @@ def leaf(fn, inputs, params=None):
 
 
 # ---- weight-gradient reduces of work that stays on the ISSUING stream (the sparse encoder's layers) ------------------------------
-_train = {}          # device -> {"sink", "queued": passes with a callback, "targets": {pass -> data_ptrs of the parameters with a result}}
+_train = {}          # device -> {"sinks": {stream id -> (stream, sink)}, "queued": passes with a callback, "targets": {pass -> data_ptrs}}
 
 
 def in_backward_pass():
     return _pass_id() != -1
 
 
+def _flush_sink_on(stream, sink):
+    """A sink's reduces run on the stream that wrote its partials (autograd runs a layer's backward on the stream of its forward:
+    the covariance branch has its own); the calling stream then waits for it -- whoever flushes is about to read gradients."""
+    if not (sink.pending() or sink.keep):
+        return
+    cur = torch.cuda.current_stream(stream.device)
+    if cur.cuda_stream == stream.cuda_stream:
+        sink.flush()
+        return
+    torch.cuda.set_stream(stream)
+    try:
+        sink.flush()
+    finally:
+        torch.cuda.set_stream(cur)
+    cur.wait_stream(stream)
+
+
 def deferred_reduce(params):
     """-> a context (capi.ReduceSink.collect()) inside which a weight-gradient entry point leaves its second stage to ONE launch
-    at the end of the running backward pass, or None when the results may be READ before that: not inside a pass, a parameter
-    that already holds a gradient (accumulation: AccumulateGrad adds at once) or got one earlier in this pass (shared
-    weight), a non-leaf "parameter", a stream capture.  params: the parameters the results become gradients of."""
+    per ~8 layers / at the end of the running backward pass, or None when the results may be READ before that: not inside a
+    pass, a parameter that already holds a gradient (accumulation: AccumulateGrad adds at once) or got one earlier in this pass
+    (shared weight), a non-leaf "parameter", a stream capture.  params: the parameters the results become gradients of.
+    One sink per STREAM: the reduce of a layer has to run behind the kernel that wrote its partials."""
     if not DEFER_REDUCES or _DEFER_WHICH == "dense" or not params or params[0].device.type != "cuda" or not in_backward_pass():
         return None
     if torch.cuda.is_current_stream_capturing():
@@ -191,8 +209,13 @@ def deferred_reduce(params):
     dev = params[0].device
     st = _train.get(dev)
     if st is None:
+        st = _train[dev] = {"sinks": {}, "queued": set(), "targets": {}}
+    cur = torch.cuda.current_stream(dev)
+    ent = st["sinks"].get(cur.cuda_stream)
+    if ent is None:
         from rslo_amd import capi
-        st = _train[dev] = {"sink": capi.ReduceSink(), "queued": set(), "targets": {}}
+        ent = st["sinks"][cur.cuda_stream] = (cur, capi.ReduceSink())
+    sink = ent[1]
     pid = _pass_id()
     targets = _targets(st)
     seen = any((not p.is_leaf) or p.grad is not None or p.data_ptr() in targets for p in params)
@@ -200,24 +223,25 @@ def deferred_reduce(params):
     if pid not in st["queued"]:
         st["queued"].add(pid)
         torch.autograd.Variable._execution_engine.queue_callback(lambda d=dev, p=pid: flush_deferred(d, p))
-    if st["sink"].pending() >= FLUSH_EVERY:      # the layers collected so far, while their partials are cache-resident
-        st["sink"].flush()
+    if sink.pending() >= FLUSH_EVERY:      # the layers collected so far on this stream, while their partials are cache-resident
+        sink.flush()
     if seen:
         # a second contribution to a gradient in one pass (two forwards before one backward, a shared weight), or an
         # accumulation: the engine ADDS at once -- everything collected so far is made real, this result is computed in place
         flush_deferred(dev)
         return None
-    return st["sink"].collect()
+    return sink.collect()
 
 
 def flush_deferred(device=None, done_pass=None):
-    """Launch the collected reduces of the issuing stream now (on the current stream).  Called at the end of the pass (done_pass:
-    that pass), and by anything that reads gradients inside it (the gradient exchange of the apex DDP stand-in)."""
+    """Launch the collected reduces now, each sink on its own stream, the current stream waiting for the others.  Called at the
+    end of the pass (done_pass: that pass), and by anything that reads gradients inside it (the gradient exchange of the apex
+    DDP stand-in)."""
     for dev, st in _train.items():
         if device is None or dev == device:
             if done_pass is not None:
                 st["queued"].discard(done_pass)
                 st["targets"].pop(done_pass, None)
-            if st["sink"].pending() or st["sink"].keep:
-                with torch.cuda.device(dev):
-                    st["sink"].flush()
+            with torch.cuda.device(dev):
+                for stream, sink in list(st["sinks"].values()):
+                    _flush_sink_on(stream, sink)
