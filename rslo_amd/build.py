@@ -15,7 +15,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -fno-slp-vectorize: the SLP pass pairs independent fp32 operations into v_pk_*_f32, which issue at half rate on
 # gfx950 and need their operands in adjacent registers (extra v_mov): measured 80 -> 128 us on k_wgrad3<64,64>
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-fno-slp-vectorize",
-         "-Wno-unused-result"]
+         "-Wno-unused-result"] + os.environ.get("RSLO_HIPCC_EXTRA", "").split()      # (experiments: -DSPC_PREW_ALL=1 ...)
 
 
 def sources():

@@ -443,6 +443,9 @@ __device__ __forceinline__ Split8 split8(const float4 a, const float4 b, bool ok
   return o;
 }
 
+#ifndef SPC_PREW_ALL
+#define SPC_PREW_ALL 0
+#endif
 #define SPC_WLOAD(p) (*reinterpret_cast<const u32x4 *>(p))
 #define MFMA_BF16(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), C, 0, 0, 0)
 
@@ -566,7 +569,7 @@ __global__ __launch_bounds__(SPC_THREADS, (SKIPB ? 4 : 1)) void k_spconv_v6(cons
       // one-row-block tiles (the small-problem tiling: a launch of a few waves per SIMD, nothing to hide latency behind):
       // ALL weight operands of the step are requested before the gathered rows are waited for -- one memory round trip
       // per step instead of one for the rows plus one per column block (C2: 26 -> ... us per 64 -> 64 layer)
-      constexpr bool PREW = RBW == 1;
+      constexpr bool PREW = RBW == 1 || SPC_PREW_ALL;
       u32x4 pw[PREW ? NB : 1][3];
       if constexpr (PREW) {
 #pragma unroll
