@@ -155,8 +155,8 @@ def _flush_c_stdio():
         pass
 
 
-PMC_TRAFFIC = "r05_pmc_traffic_bench.json"
-PMC_BUSY = "r05_pmc_mfma_busy.json"
+PMC_TRAFFIC = "r06_pmc_traffic_bench.json"
+PMC_BUSY = "r06_pmc_mfma_busy.json"
 
 
 # --------------------------------------------------------------------------------------------- kernel events
@@ -173,15 +173,29 @@ class ConvProbe:
         self._orig = {}
 
     @staticmethod
+    def _tune(name, default):
+        try:
+            from rslo_amd import capi
+            return capi.tuning_get(name)
+        except Exception:
+            return default
+
+    @staticmethod
     def kernel_name(cin_op, cout_op, n_out, trans, split=False, bf16=False):
         """The template instantiation the entry point dispatches to (rslo_amd/csrc/spconv.hip)."""
         t = "true" if trans else "false"
         rbw = 2 if n_out >= 256 * 32 * 8 else 1
         if bf16:
             return "k_spconv_bf16<%d, %d, %d, %d>" % (cin_op, cout_op, rbw, 1 if (cin_op == 32 and cout_op == 32) else 2)
-        if split:      # rslo_spconv_fwd_split: two waves per 32-row tile except for 32 -> 32
-            ks = 1 if (cin_op == 32 and cout_op == 32) else 2
-            return "k_spconv_v6<%d, %d, %d, %d>" % (cin_op, cout_op, 2 if ks == 2 else rbw, ks)
+        if split:      # rslo_spconv_fwd_split: two waves per 32-row tile except for 32 -> 32; dead 16-row blocks skipped
+            ks = 1 if (cin_op == 32 and cout_op == 32) else 2      # (switch spconv_skip, on by default: round 6)
+            if n_out < 20000:                                      # the small-problem tiling: 16-row tiles, four waves
+                return "k_spconv_v6<%d, %d, 1, 4, false>" % (cin_op, cout_op)
+            rb = 2 if ks == 2 else rbw
+            if rb == 1:
+                return "k_spconv_v6<%d, %d, 1, 4, false>" % (cin_op, cout_op)
+            skip = ConvProbe._tune("spconv_skip", 1) != 0
+            return "k_spconv_v6<%d, %d, 2, %d, %s>" % (cin_op, cout_op, ks, "true" if skip else "false")
         if cin_op % 16 == 0 and cout_op % 16 == 0:
             return "k_spconv_v3<%d, %d, %d, %s>" % (cin_op, cout_op, rbw, t)
         ci = 8 if cin_op <= 8 else (16 if cin_op <= 16 else (32 if cin_op <= 32 else 64))
@@ -285,7 +299,8 @@ class ConvProbe:
             """Row-offset products the tiled kernel ISSUES for this table: every offset that is active for any row of a
             32-row tile is computed for all 32 rows (padding = the part of the offset union a row does not have)."""
             k = (t.data_ptr(), tuple(t.shape))
-            if k not in issued_cache:
+            ck = k + (rows_per_tile,)
+            if ck not in issued_cache:
                 a = t >= 0
                 o = self.orders.get(k)
                 if o is not None and o.numel() == a.shape[0]:
@@ -294,8 +309,8 @@ class ConvProbe:
                 pad = (-n) % rows_per_tile
                 if pad:
                     a = torch.cat([a, torch.zeros((pad, K), dtype=torch.bool, device=a.device)], 0)
-                issued_cache[k] = int(a.view(-1, rows_per_tile, K).any(dim=1).sum().item()) * rows_per_tile
-            return issued_cache[k]
+                issued_cache[ck] = int(a.view(-1, rows_per_tile, K).any(dim=1).sum().item()) * rows_per_tile
+            return issued_cache[ck]
         groups = {}
         for i, (m, e0, e1) in enumerate(self.records):
             if m[0] == "dense":
@@ -310,7 +325,8 @@ class ConvProbe:
                                          "big": {"launches": 0, "ms": 0.0, "flops": 0}})
             if m[0] != "dense" and "k_spconv_v6" in name:
                 g["pairs"] += P
-                g["issued_pairs"] += issued_pairs(table)
+                # the skipping kernels (k_spconv_v6<.., true>) issue products per live 16-row BLOCK of a (tile, offset)
+                g["issued_pairs"] += issued_pairs(table, 16 if name.endswith("true>") else 32)
             dt = e0.elapsed_time(e1)
             g["launches"] += 1
             g["ms"] += dt
@@ -1437,6 +1453,7 @@ def main():
             except Exception as e:
                 line["config"]["multirank_path"] = dict(line["config"].get("multirank_path") or {}, error=repr(e))
         if (world == 1 and not dist_on and args.config == "c3" and args.batch == 4 and args.rings == 64
+                and not args.no_cpu_baseline and not args.no_kernel_events      # (the plain default invocation only)
                 and os.environ.get("RSLO_BENCH_OTHER_CONFIGS", "1") != "0"):
             # BASELINE.json configs[1], [3] (per-GPU part) and [4] measured by the SAME invocation the driver runs, each in a
             # child process of this script (`--config c2 | c4 | c5`: its own timing protocol, roofline and CPU baseline), and

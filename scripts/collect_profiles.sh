@@ -14,6 +14,7 @@ print("bench line: %.1f frame-pairs/s, %.3f ms per step (runs: %s)" % (runs[1]["
 PY
 for c in c2 c4 c5; do [ -f $G/bench_${R}_$c.json ] && cp $G/bench_${R}_$c.json $P/${R}_bench_line_$c.json; done
 cp $G/bench_${R}_with_cpu.json $P/${R}_bench_line_with_cpu_baseline.json
+[ -f $G/bench_${R}_driver_invocation.json ] && cp $G/bench_${R}_driver_invocation.json $P/${R}_bench_line_driver_invocation.json
 cp $G/${R}_kernel_stats.csv $P/${R}_kernel_stats.csv
 cp $G/prof_${R}_last_step.txt $P/${R}_step_breakdown.txt
 cp $G/prof_${R}fix_last_step.txt $P/${R}_step_breakdown_fixed_plan.txt

@@ -17,6 +17,8 @@ unset RSLO_BENCH_FIXED_PLAN BENCH_ARGS
 python scripts/timeline_gaps.py $(find /tmp/prof_$R -name "*kernel_trace.csv" | head -1) > gpurun_out/${R}_timeline_gaps.txt 2>&1
 timeout 900 python bench.py 2>/dev/null | tail -1 > gpurun_out/bench_${R}_with_cpu.json; cut -c100-230 gpurun_out/bench_${R}_with_cpu.json
 for c in c2 c4 c5; do timeout 600 python bench.py --config $c 2>/dev/null | tail -1 > gpurun_out/bench_${R}_$c.json; cut -c1-200 gpurun_out/bench_${R}_$c.json; done
+# the driver's own invocation (C3 headline + multirank child + host pricing + C2 / C4 / C5 under config.other_configs)
+timeout 1500 python bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > gpurun_out/bench_${R}_driver_invocation.json; cut -c100-230 gpurun_out/bench_${R}_driver_invocation.json
 # the two-rank step on ONE GPU (functional mode): peer SyncBN exchange + overlapped gradient exchange over gloo, replicas compared
 RSLO_PEER_TIMEOUT_MS=20000 RSLO_BENCH_ONE_GPU=1 timeout 600 python bench.py --gpus 2 --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/${R}_two_rank_one_gpu.log 2>&1; tail -1 gpurun_out/${R}_two_rank_one_gpu.log | cut -c100-230
 RSLO_BENCH_FORCE_DIST=1 timeout 300 python bench.py --no-cpu-baseline > gpurun_out/${R}_nccl_n1.log 2>&1; tail -1 gpurun_out/${R}_nccl_n1.log | cut -c100-230
