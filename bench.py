@@ -829,6 +829,17 @@ def run_encoder(args, world, rank, local_rank, dist_on, dev):
         print(json.dumps(line), flush=True)
 
 
+def _child_line(r):
+    """The JSON line of a child bench.py from its captured stdout (the collectives library writes its banner through C stdio:
+    the line may follow it without a newline of its own)."""
+    out = r.stdout or ""
+    i = out.rfind('{"metric"')
+    if i < 0:
+        raise RuntimeError("child bench.py printed no result line (rc %s); stderr tail: %s" % (
+            r.returncode, (r.stderr or "")[-400:].replace("\n", " | ")))
+    return json.loads(out[i:].splitlines()[0])
+
+
 # --------------------------------------------------------------------------------------------- the step of a rank of an N > 1 job
 def multirank_child(args, cores=None, sibling_blocks=None):
     """This script's C3 step in a child process with a ONE-rank RCCL group and the multi-rank code path forced
@@ -852,7 +863,7 @@ def multirank_child(args, cores=None, sibling_blocks=None):
         cmd = [sys.executable, os.path.abspath(__file__), "--steps", "40", "--warmup", "10", "--no-cpu-baseline",
                "--no-kernel-events", "--batch", str(args.batch), "--rings", str(args.rings), "--dtype", args.dtype]
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, preexec_fn=pre)
-        return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        return _child_line(r)
     finally:
         for p_ in sibs:          # exactly the processes started here
             p_.kill()
@@ -880,7 +891,7 @@ def other_configs(args, affinity=None):
             # CPU baseline uses every core, like the headline line's)
             pre = (lambda a=set(affinity): os.sched_setaffinity(0, a)) if affinity else None
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, preexec_fn=pre)
-            child = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+            child = _child_line(r)
             roof = child.get("roofline") or {}
             cpu = child.get("cpu_baseline") or {}
             out[cfg] = {
@@ -1443,13 +1454,17 @@ def main():
                     allowed = sorted(orig_affinity)
                     blk = [c for c in range(pinned[0], pinned[0] + 16) if c in allowed]
                     if len(blk) == 16:
-                        two = multirank_child(args, cores=blk[:2])
-                        sib = multirank_child(args, cores=blk[:2], sibling_blocks=[blk[2 * k:2 * k + 2] for k in range(1, 8)])
-                        line["config"]["multirank_path"]["two_cores_per_rank"] = {
-                            "ms_per_step": two["ms_per_step"], "host_issue_ms_per_step": two["config"].get("host_issue_ms_per_step"),
-                            "with_7_busy_siblings": {"ms_per_step": sib["ms_per_step"],
-                                                     "host_issue_ms_per_step": sib["config"].get("host_issue_ms_per_step")},
-                            "cores": blk[:2]}
+                        try:
+                            two = multirank_child(args, cores=blk[:2])
+                            sib = multirank_child(args, cores=blk[:2], sibling_blocks=[blk[2 * k:2 * k + 2] for k in range(1, 8)])
+                            line["config"]["multirank_path"]["two_cores_per_rank"] = {
+                                "ms_per_step": two["ms_per_step"],
+                                "host_issue_ms_per_step": two["config"].get("host_issue_ms_per_step"),
+                                "with_7_busy_siblings": {"ms_per_step": sib["ms_per_step"],
+                                                         "host_issue_ms_per_step": sib["config"].get("host_issue_ms_per_step")},
+                                "cores": blk[:2]}
+                        except Exception as e:
+                            line["config"]["multirank_path"]["two_cores_per_rank"] = {"error": repr(e)[:400]}
             except Exception as e:
                 line["config"]["multirank_path"] = dict(line["config"].get("multirank_path") or {}, error=repr(e))
         if (world == 1 and not dist_on and args.config == "c3" and args.batch == 4 and args.rings == 64
