@@ -155,7 +155,8 @@ RSLO_API void rslo_spconv_set_tiling(int rbw, int ks);
  *     a capacity-laid-out rulebook has more rows than the scan has sites, the rows past the level's count being padding rows
  *     (rslo_plan_encoder_pad_tails), and the count lives in a device word.  rslo_spconv_set_live_rows(p) hands that word to the
  *     NEXT rslo_spconv_fwd / rslo_spconv_fwd_split launch (and only that one): workgroups whose rows all lie at or past *p
- *     return at once -- their output rows are left unwritten; nothing reads a padding row.  Ignored with a row order. */
+ *     return at once -- their output rows are left unwritten; nothing reads a padding row.  Ignored with a row order.
+ *     Per calling thread. */
 RSLO_API void rslo_spconv_set_live_rows(const int32_t *n_live_dev);
 /*     Tuning switches of the launch code.  The library reads NO environment variable: tile shapes and kernel variants that
  *     exist for A/B measurements and for the parity tests that pin every tiling against the oracle are set through these
@@ -732,7 +733,7 @@ RSLO_API int rslo_opt_adam_step(const RsloOptTensor *tensors_dev, const RsloOptC
  *      kernel that leaves slab / chunk partials in the caller's workspace + a small kernel that adds them in a fixed order.  While
  *      a sink is installed (rslo_wgrad_reduce_defer(sink, capacity, &count)) they append a descriptor of that second kernel to
  *      the caller's array instead of launching it (count is advanced; a full sink: launched at once, as without one);
- *      rslo_wgrad_reduce_defer(NULL, 0, NULL) removes the sink.  rslo_wgrad_reduce_many(reduces, n, stream) then runs the n
+ *      rslo_wgrad_reduce_defer(NULL, 0, NULL) removes the sink (the sink is per calling THREAD).  rslo_wgrad_reduce_many(reduces, n, stream) then runs the n
  *      reduces as one grid -- the same block bodies, the same bits.  The caller keeps every workspace / bias-partial buffer a
  *      descriptor points to alive and unmodified until that launch, and orders it behind the kernels that wrote them (same
  *      stream or an event).  Nothing of the reference reads a gradient before the pass is over (train_hdf5.py:663-672). */

@@ -301,7 +301,8 @@ class RsloWgradReduce(C.Structure):
                 ("dbias", C.c_void_p), ("koff", C.c_void_p), ("p", C.c_int32 * 8)]
 
 
-_active_sink = None
+import threading as _threading
+_tls = _threading.local()      # .sink: the ReduceSink installed by THIS thread (the C library's sink is per thread as well)
 
 
 class ReduceSink:
@@ -321,14 +322,13 @@ class ReduceSink:
             self.sink = sink
 
         def __enter__(self):
-            global _active_sink
-            self.prev, _active_sink = _active_sink, self.sink
+            self.prev = getattr(_tls, "sink", None)
+            _tls.sink = self.sink
             _chk(lib().rslo_wgrad_reduce_defer(self.sink.arr, ReduceSink.CAP, C.byref(self.sink.count)), "rslo_wgrad_reduce_defer")
             return self.sink
 
         def __exit__(self, *exc):
-            global _active_sink
-            _active_sink = self.prev
+            _tls.sink = self.prev
             if self.prev is not None:
                 lib().rslo_wgrad_reduce_defer(self.prev.arr, ReduceSink.CAP, C.byref(self.prev.count))
             else:
@@ -354,8 +354,9 @@ class ReduceSink:
 
 def _keep_for_reduce(*tensors):
     """Inside ReduceSink.collect(): the buffers a deferred reduce will read stay referenced until its flush."""
-    if _active_sink is not None:
-        _active_sink.keep.extend(t for t in tensors if t is not None)
+    sink = getattr(_tls, "sink", None)
+    if sink is not None:
+        sink.keep.extend(t for t in tensors if t is not None)
 
 
 # --------------------------------------------------------------------------------------

@@ -935,7 +935,7 @@ extern "C" int rslo_weight_split_many(const RsloWeightSplitDesc *desc_dev, int n
 }
 
 // Live-row count of the NEXT forward launch (rslo_spconv_fwd / rslo_spconv_fwd_split), consumed by it: see include/rslo_hip.h
-static const int32_t *g_spc_live_rows = nullptr;
+static thread_local const int32_t *g_spc_live_rows = nullptr;      // per thread: set and consumed by the same caller
 extern "C" void rslo_spconv_set_live_rows(const int32_t *n_live_dev) { g_spc_live_rows = n_live_dev; }
 static inline const int32_t *spc_take_live() {
   const int32_t *p = g_spc_live_rows;

@@ -113,9 +113,9 @@ __device__ __forceinline__ void wr_sparse_block(int bx, int k, const float *__re
 }
 
 // ---- deferral: the launch code hands a layer's reduce to the caller's sink instead of launching it (rslo_wgrad_reduce_defer) -----
-extern RsloWgradReduce *g_wr_sink;
-extern int g_wr_cap;
-extern int *g_wr_count;
+extern thread_local RsloWgradReduce *g_wr_sink;
+extern thread_local int g_wr_cap;
+extern thread_local int *g_wr_count;
 static inline bool wr_defer(const RsloWgradReduce &d) {
   if (!g_wr_sink || !g_wr_count || *g_wr_count >= g_wr_cap) return false;
   g_wr_sink[(*g_wr_count)++] = d;

@@ -9,9 +9,11 @@
 // blocks find their layer through a prefix table in the kernel arguments.  Same block bodies (wgrad_reduce.h), same bits.
 #include "wgrad_reduce.h"
 
-RsloWgradReduce *g_wr_sink = nullptr;
-int g_wr_cap = 0;
-int *g_wr_count = nullptr;
+// per thread: a sink is installed, fed and removed by ONE caller (the thread that runs the backward pass); launches of other
+// threads of the process are not its business
+thread_local RsloWgradReduce *g_wr_sink = nullptr;
+thread_local int g_wr_cap = 0;
+thread_local int *g_wr_count = nullptr;
 
 #define WR_MAX 40          // descriptors per launch: 40 x 88 B + 41 x 4 B of kernel arguments (< 4 KB)
 struct WrBatch {

@@ -11,6 +11,7 @@ Three kinds:
 
 SWITCHES = {
     # name: (default, kind, meaning)
+    "RSLO_HIPCC_EXTRA": ("", "location", "extra hipcc flags of rslo_amd/build.py (experiments: -DSPC_PREW_ALL=1); part of the source hash"),
     "RSLO_HIP_LIB": ("", "location", "path of librslo_hip.so (default: next to the package)"),
     "RSLO_REFERENCE_ROOT": ("", "location", "a reference checkout whose non-hot-path modules (protos, logging, ...) are forwarded to"),
     "RSLO_SYNCBN_EXCHANGE": ("auto", "mode", "SyncBN statistics exchange: auto | device | host | rccl (rslo_amd/peer.py)"),
