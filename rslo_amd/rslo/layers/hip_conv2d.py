@@ -152,6 +152,7 @@ class _Conv1x1Fn(torch.autograd.Function):
         x = x.contiguous()
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
+        ctx.leaf_params = (w,) if bias is None else (w, bias)
         return capi.conv1x1_fwd(x, w, bias)
 
     @staticmethod
@@ -163,7 +164,9 @@ class _Conv1x1Fn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = capi.conv1x1_dgrad(dy, w)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            dw, db = capi.conv1x1_wgrad(x, dy, want_bias=ctx.has_bias)
+            # leaf work like the 3x3 layers' weight gradients (round 6: five launch pairs per step off the training stream)
+            from rslo_amd import streams
+            dw, db = streams.leaf(lambda: capi.conv1x1_wgrad(x, dy, want_bias=ctx.has_bias), (x, dy), ctx.leaf_params)
         return dx, dw, db
 
 
