@@ -263,6 +263,7 @@ RSLO_API int rslo_pose_tail_bwd(const float *odom, const float *g_t, const float
  *      out5 = (total, T, R, pyramid, C).  Pointers are device pointers; alpha_* point at the modules' log-variance
  *      parameters (they may alias: the shipped configuration uses the SAME modules for pose and pyramid terms). */
 #define RSLO_LOSS_TAIL_MAX_LEVELS 8
+#define RSLO_LOSS_TAIL_ALPHA_STRIDE 4
 typedef struct {
   const float *t_pred, *t_tgt;        /* [B,3] */
   const float *q_pred, *q_tgt;        /* [B,4] (w,x,y,z) */
@@ -279,7 +280,11 @@ typedef struct {
 RSLO_API int rslo_loss_tail_fwd(const RsloLossTail *h_p, float *out5, void *stream);
 RSLO_API int rslo_loss_tail_bwd(const RsloLossTail *h_p, const float *grad_out /*[1]*/, float *d_t /*[B,3]*/,
                                 float *d_q /*[B,4]*/, float *d_pyr /*[L,B,2]*/, float *d_pair /*[n_pairs]*/,
-                                float *d_alpha5 /*(T, R, pT, pR, C)*/, void *stream);
+                                float *d_alpha5 /*(T, R, pT, pR, C): 5 x RSLO_LOSS_TAIL_ALPHA_STRIDE floats*/, void *stream);
+/*     d_alpha5: entry i is written to d_alpha5[i * RSLO_LOSS_TAIL_ALPHA_STRIDE] -- 16-byte slots, so that each one can be
+ *     handed on as a parameter's gradient tensor (the optimizer's tables take 16-byte aligned gradients).  A module that
+ *     serves several terms (the same alpha pointer more than once): its FIRST entry holds the sum of all of them, added in
+ *     entry order. */
 
 /* ------------------------------------------------------------------------------------
  * a1 + a2 + a5 in ONE call: voxelization of all clouds of a step (frames x samples) and the complete rulebook chain
@@ -488,6 +493,12 @@ RSLO_API int rslo_icp_step(const float *p1, const float *n1, const float *tgt, c
                   const float *thr, int B, int N, int M, void *ws, size_t ws_bytes, float *res_r /*[B,9] in/out*/,
                   float *res_t /*[B,3] in/out*/, float *step_R /*[B,9] or NULL*/, float *step_t /*[B,3] or NULL*/,
                   void *stream);
+/*     _first: the first refinement of a pair -- res_r / res_t are outputs only (the running motion starts as the identity,
+ *     losses.py:452-453), the caller does not fill them. */
+RSLO_API int rslo_icp_step_first(const float *p1, const float *n1, const float *tgt, const int32_t *idx, const float *dist,
+                  const float *thr, int B, int N, int M, void *ws, size_t ws_bytes, float *res_r /*[B,9] out*/,
+                  float *res_t /*[B,3] out*/, float *step_R /*[B,9] or NULL*/, float *step_t /*[B,3] or NULL*/,
+                  void *stream);
 /* a18  ROI threshold (rslo/core/losses.py:326-334): thr[b] = max(k-th smallest of dist[b][0..counts[b]), 1) with
  *      k = 1 + int(counts[b] * ratio); counts NULL = N everywhere.  Exact (radix select), no sort. */
 RSLO_API int rslo_roi_threshold(const float *dist, int B, int N, const int32_t *counts, double ratio, float *thr,
@@ -535,6 +546,12 @@ RSLO_API int rslo_pad_rows_fwd(const float *src, int64_t N, int C, const int32_t
                                int Lmax, float *out, void *stream);
 RSLO_API int rslo_pad_rows_bwd(const float *dout, int64_t N, int C, const int32_t *off, const int32_t *len, int B,
                                int Lmax, float *dsrc, void *stream);
+/*      rslo_pair_rows_fwd: the three operands of one frame in one launch (voxel_odom_net.py:630-660 selects the xyz and
+ *      normal columns of the voxel features, joins them with the covariance head's rows and pads): feats [N,F] (F = 7:
+ *      xyz, intensity, normal -- or F = 6: xyz, normal), conf [N,Cc] -> xyz [B,Lmax,3], nrm [B,Lmax,3], cov [B,Lmax,Cc],
+ *      zero padded as above.  Only conf carries a gradient: rslo_pad_rows_bwd with C = Cc is its backward. */
+RSLO_API int rslo_pair_rows_fwd(const float *feats, int64_t N, int F, const float *conf, int Cc, const int32_t *off,
+                                const int32_t *len, int B, int Lmax, float *xyz, float *nrm, float *cov, void *stream);
 
 /* a10-a12  training-mode (Sync)BatchNorm2d of the dense head fused with activation and residual add, NCHW fp32
  *      (apex.parallel.SyncBatchNorm via rslo/layers/SparseConv.py:96-113; rslo/models/custom_resnet_spc.py:224-298).
@@ -694,6 +711,9 @@ RSLO_API int rslo_quat_to_rot(const float *q_wxyz, int B, float *R, void *stream
 RSLO_API int rslo_quat_to_rot_bwd(const float *q_wxyz, const float *gR, int B, float *gq, void *stream);
 RSLO_API int rslo_pose_targets(const float *res_r, const float *res_t, const float *R_pred, const float *T_pred, int B,
                                float *rot_targets_wxyz, float *trans_targets, void *stream);
+/*      _tq: additionally the rows (t*, q*) [B,7] the pyramid supervision reads (voxel_odom_net.py:747), NULL = skip. */
+RSLO_API int rslo_pose_targets_tq(const float *res_r, const float *res_t, const float *R_pred, const float *T_pred, int B,
+                                  float *rot_targets_wxyz, float *trans_targets, float *tq, void *stream);
 
 /* f1   optimizer step of the training driver: global gradient-norm clipping (train_hdf5.py:671,
  *      torch.nn.utils.clip_grad_norm_) and torch.optim.Adam under the fastai OptimWrapper's decoupled weight decay

@@ -92,6 +92,7 @@ SIGNATURES = {
     "rslo_cov_residual_bwd_ws_bytes": (_sz, [_i, _i, _i]),
     "rslo_icp_ws_bytes": (_sz, [_i, _i]),
     "rslo_icp_step": (C.c_int, [_vp] * 6 + [_i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
+    "rslo_icp_step_first": (C.c_int, [_vp] * 6 + [_i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
     "rslo_transform_points": (C.c_int, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
     "rslo_transform_rows": (C.c_int, [_vp, _i, _vp, _vp, _i, _i, _vp, _vp]),
     "rslo_transform_rows_bwd_ws_bytes": (_sz, [_i, _i]),
@@ -147,6 +148,8 @@ SIGNATURES = {
     "rslo_quat_to_rot": (C.c_int, [_vp, _i, _vp, _vp]),
     "rslo_quat_to_rot_bwd": (C.c_int, [_vp, _vp, _i, _vp, _vp]),
     "rslo_pose_targets": (C.c_int, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    "rslo_pose_targets_tq": (C.c_int, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "rslo_pair_rows_fwd": (C.c_int, [_vp, _i64, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "rslo_pad_rows_fwd": (C.c_int, [_vp, _i64, _i, _vp, _vp, _i, _i, _vp, _vp]),
     "rslo_pad_rows_bwd": (C.c_int, [_vp, _i64, _i, _vp, _vp, _i, _i, _vp, _vp]),
     "rslo_pyramid_l2_ws_bytes": (_sz, [_vp, _i, _i]),
@@ -1011,17 +1014,19 @@ def cov_residual_bwd(p1, tgt, cov1, cov2, idx, dist, thr, Rd, gloss, cnt, reg_we
     return gp1, gtgt, gcov1, gcov2
 
 
-def icp_step(p1, n1, tgt, idx, dist, thr, res_r, res_t):
-    """One Kabsch refinement over the ROI; composes res_r [B,3,3] / res_t [B,3] IN PLACE."""
+def icp_step(p1, n1, tgt, idx, dist, thr, res_r, res_t, first=False):
+    """One Kabsch refinement over the ROI; composes res_r [B,3,3] / res_t [B,3] IN PLACE.
+    first: the running motion is the identity -- res_r / res_t are written without being read (no fill by the caller)."""
     B, N, _ = p1.shape
     M = tgt.shape[1]
     wsb = lib().rslo_icp_ws_bytes(B, N)
     ws = _ws(wsb, p1.device)
-    _chk(lib().rslo_icp_step(_ptr(p1, torch.float32, "p1"), _ptr(n1, torch.float32, "n1"),
-                             _ptr(tgt, torch.float32, "tgt"), _ptr(idx, torch.int32, "idx"),
-                             _ptr(dist, torch.float32, "dist"), _ptr(thr, torch.float32, "thr"), B, N, M, _ptr(ws), wsb,
-                             _ptr(res_r, torch.float32, "res_r"), _ptr(res_t, torch.float32, "res_t"), None, None,
-                             _stream()), "rslo_icp_step")
+    entry = "rslo_icp_step_first" if first else "rslo_icp_step"
+    _chk(getattr(lib(), entry)(_ptr(p1, torch.float32, "p1"), _ptr(n1, torch.float32, "n1"),
+                               _ptr(tgt, torch.float32, "tgt"), _ptr(idx, torch.int32, "idx"),
+                               _ptr(dist, torch.float32, "dist"), _ptr(thr, torch.float32, "thr"), B, N, M, _ptr(ws), wsb,
+                               _ptr(res_r, torch.float32, "res_r"), _ptr(res_t, torch.float32, "res_t"), None, None,
+                               _stream()), entry)
 
 
 def transform_points(x, R, t):
@@ -1203,10 +1208,10 @@ def loss_tail_bwd(desc, grad_out, B, L, n_pairs):
     d_q = torch.empty((B, 4), dtype=torch.float32, device=dev)
     d_pyr = torch.empty((L, B, 2), dtype=torch.float32, device=dev) if L else None
     d_pair = torch.empty((n_pairs,), dtype=torch.float32, device=dev) if n_pairs else None
-    d_alpha = torch.empty((5,), dtype=torch.float32, device=dev)
+    d_alpha = torch.empty((5, 4), dtype=torch.float32, device=dev)      # 16-byte slots (include/rslo_hip.h: stride 4)
     _chk(lib().rslo_loss_tail_bwd(C.byref(desc), _ptr(grad_out, torch.float32, "grad"), _ptr(d_t), _ptr(d_q), _ptr(d_pyr),
                                   _ptr(d_pair), _ptr(d_alpha), _stream()), "rslo_loss_tail_bwd")
-    return d_t, d_q, d_pyr, d_pair, d_alpha
+    return d_t, d_q, d_pyr, d_pair, d_alpha[:, 0]
 
 
 def pad_rows_fwd(src, off, length, Lmax):
@@ -1217,6 +1222,22 @@ def pad_rows_fwd(src, off, length, Lmax):
     _chk(lib().rslo_pad_rows_fwd(_ptr(src, torch.float32, "src"), N, Cc, _ptr(off, torch.int32, "off"),
                                  _ptr(length, torch.int32, "len"), B, int(Lmax), _ptr(out), _stream()), "rslo_pad_rows_fwd")
     return out
+
+
+def pair_rows_fwd(feats, conf, off, length, Lmax):
+    """feats [N,F] (F = 7: xyz, intensity, normal | 6: xyz, normal), conf [N,Cc] -> xyz [B,Lmax,3], nrm [B,Lmax,3],
+    cov [B,Lmax,Cc]: rows off[b] .. off[b]+len[b] of both, zero padded, in one launch."""
+    N, F = feats.shape
+    Cc = conf.shape[1]
+    B = off.shape[0]
+    dev = feats.device
+    xyz = torch.empty((B, Lmax, 3), dtype=torch.float32, device=dev)
+    nrm = torch.empty((B, Lmax, 3), dtype=torch.float32, device=dev)
+    cov = torch.empty((B, Lmax, Cc), dtype=torch.float32, device=dev)
+    _chk(lib().rslo_pair_rows_fwd(_ptr(feats, torch.float32, "feats"), N, F, _ptr(conf, torch.float32, "conf"), Cc,
+                                  _ptr(off, torch.int32, "off"), _ptr(length, torch.int32, "len"), B, int(Lmax),
+                                  _ptr(xyz), _ptr(nrm), _ptr(cov), _stream()), "rslo_pair_rows_fwd")
+    return xyz, nrm, cov
 
 
 def pad_rows_bwd(dout, off, length, N):
@@ -1728,11 +1749,13 @@ def quat_to_rot_bwd(q, gR):
     return gq
 
 
-def pose_targets(res_r, res_t, R_pred, T_pred):
+def pose_targets(res_r, res_t, R_pred, T_pred, with_tq=False):
+    """-> (q* [B,4] wxyz, t* [B,3]); with_tq: also the rows (t*, q*) [B,7] from the same launch."""
     B = res_r.shape[0]
     rot = torch.empty((B, 4), dtype=torch.float32, device=res_r.device)
     trans = torch.empty((B, 3), dtype=torch.float32, device=res_r.device)
-    _chk(lib().rslo_pose_targets(_ptr(res_r, torch.float32, "res_r"), _ptr(res_t, torch.float32, "res_t"),
-                                 _ptr(R_pred, torch.float32, "R_pred"), _ptr(T_pred, torch.float32, "T_pred"), B,
-                                 _ptr(rot), _ptr(trans), _stream()), "rslo_pose_targets")
-    return rot, trans
+    tq = torch.empty((B, 7), dtype=torch.float32, device=res_r.device) if with_tq else None
+    _chk(lib().rslo_pose_targets_tq(_ptr(res_r, torch.float32, "res_r"), _ptr(res_t, torch.float32, "res_t"),
+                                    _ptr(R_pred, torch.float32, "R_pred"), _ptr(T_pred, torch.float32, "T_pred"), B,
+                                    _ptr(rot), _ptr(trans), _ptr(tq), _stream()), "rslo_pose_targets_tq")
+    return (rot, trans, tq) if with_tq else (rot, trans)

@@ -176,13 +176,22 @@ __global__ __launch_bounds__(LS_THREADS) void k_resid_fwd(const float *__restric
 
 __global__ void k_resid_finish(const double *__restrict__ partial, int nblk, float reg, float *__restrict__ loss,
                                float *__restrict__ cnt_out) {
+  // the block partials come in through LDS, all loads of a chunk in flight together; thread 0 then adds them in block
+  // order as before (one thread walking nblk x 3 dependent global loads was 19 us of a serial stretch of the step)
+  __shared__ double sh[64 * 3];
   const int b = blockIdx.x;
-  if (threadIdx.x != 0) return;
   double s0 = 0, s1 = 0, s2 = 0;
-  for (int k = 0; k < nblk; ++k) {
-    const double *o = partial + ((int64_t)b * nblk + k) * 3;
-    s0 += o[0]; s1 += o[1]; s2 += o[2];
+  for (int k0 = 0; k0 < nblk; k0 += 64) {
+    const int nk = nblk - k0 < 64 ? nblk - k0 : 64;
+    for (int i = threadIdx.x; i < nk * 3; i += blockDim.x) sh[i] = partial[((int64_t)b * nblk + k0) * 3 + i];
+    __syncthreads();
+    if (threadIdx.x == 0)
+      for (int k = 0; k < nk; ++k) {
+        s0 += sh[k * 3 + 0]; s1 += sh[k * 3 + 1]; s2 += sh[k * 3 + 2];
+      }
+    __syncthreads();
   }
+  if (threadIdx.x != 0) return;
   loss[b] = (float)(s0 / s2 + (double)reg * (s1 / s2));
   cnt_out[b] = (float)s2;
 }
@@ -409,8 +418,8 @@ static int resid_key_bits(int B, int M) {
 
 static size_t resid_sort_tmp_bytes(int64_t n, int bits) {
   size_t tmp = 0;
-  (void)rocprim::radix_sort_keys(nullptr, tmp, (unsigned long long *)nullptr, (unsigned long long *)nullptr, (size_t)n, 0,
-                                 (unsigned)bits, (hipStream_t)0);
+  (void)rocprim::radix_sort_keys(nullptr, tmp, (unsigned long long *)nullptr, (unsigned long long *)nullptr, (size_t)n,
+                                 (unsigned)RB_SRC_BITS, (unsigned)bits, (hipStream_t)0);
   return (tmp + 255) / 256 * 256;
 }
 
@@ -455,7 +464,10 @@ extern "C" int rslo_cov_residual_bwd(const float *p1, const float *tgt, const fl
   hipLaunchKernelGGL(k_resid_bwd, dim3((unsigned)rslo_cdiv(N, RB_THREADS), B), dim3(RB_THREADS), 0, st, p1, tgt, cov1, cov2,
                      idx, dist, thr, Rd, gloss, cnt, N, M, reg_weight, gp1, gtgt, gcov1, gcov2, contrib, keys);
   RSLO_CHECK_LAUNCH("cov_residual_bwd");
-  RSLO_HIP(rocprim::radix_sort_keys((void *)w, tmp, keys, skeys, (size_t)n, 0, (unsigned)bits, st));
+  // The keys are written in source order (key p belongs to source row p), and the radix sort is stable: sorting on the
+  // partner half alone leaves every partner's run in ascending source order -- the order the full 49-bit sort gives, in 3
+  // digit passes instead of 7.
+  RSLO_HIP(rocprim::radix_sort_keys((void *)w, tmp, keys, skeys, (size_t)n, (unsigned)RB_SRC_BITS, (unsigned)bits, st));
   hipLaunchKernelGGL(k_resid_gather, dim3((unsigned)rslo_cdiv(n, 256)), dim3(256), 0, st, (const unsigned long long *)skeys, n,
                      (const float *)contrib, gtgt, gcov2, n_long, long_list);
   hipLaunchKernelGGL(k_resid_gather_long, dim3(512), dim3(64), 0, st, (const unsigned long long *)skeys, n,
@@ -567,7 +579,8 @@ __device__ double det3(const double M[9]) {
 
 // One thread per pair: reduce partials, Kabsch, compose res_r/res_t in place.
 __global__ void k_icp_solve(const double *__restrict__ partial, int nblk, float *__restrict__ res_r,
-                            float *__restrict__ res_t, float *__restrict__ step_R, float *__restrict__ step_t) {
+                            float *__restrict__ res_t, float *__restrict__ step_R, float *__restrict__ step_t,
+                            int first) {
   const int b = blockIdx.x;
   __shared__ double mo[ICP_NM];
   // one wave per moment (4 waves take the moments round-robin), lanes stride over the block partials: a single thread
@@ -610,9 +623,11 @@ __global__ void k_icp_solve(const double *__restrict__ partial, int nblk, float 
   if (step_t)
     for (int a = 0; a < 3; ++a) step_t[b * 3 + a] = (float)ti[a];
   // res_r = Ri res_r ; res_t = Ri res_t + ti
+  // first: the running motion is the identity and res_r / res_t are written without being read (same bits as a
+  // caller-side eye / zeros fill: the products with 0 and 1 are exact)
   double rr[9], rt[3];
-  for (int k = 0; k < 9; ++k) rr[k] = res_r[b * 9 + k];
-  for (int a = 0; a < 3; ++a) rt[a] = res_t[b * 3 + a];
+  for (int k = 0; k < 9; ++k) rr[k] = first ? (k % 4 == 0 ? 1.0 : 0.0) : (double)res_r[b * 9 + k];
+  for (int a = 0; a < 3; ++a) rt[a] = first ? 0.0 : (double)res_t[b * 3 + a];
   for (int a = 0; a < 3; ++a) {
     for (int c = 0; c < 3; ++c)
       res_r[b * 9 + a * 3 + c] = (float)(Ri[a * 3 + 0] * rr[0 * 3 + c] + Ri[a * 3 + 1] * rr[1 * 3 + c] + Ri[a * 3 + 2] * rr[2 * 3 + c]);
@@ -624,10 +639,9 @@ extern "C" size_t rslo_icp_ws_bytes(int B, int N) {
   return (size_t)(B > 0 ? B : 1) * (size_t)rslo_cdiv(N > 0 ? N : 1, LS_THREADS) * ICP_NM * sizeof(double);
 }
 
-extern "C" int rslo_icp_step(const float *p1, const float *n1, const float *tgt, const int32_t *idx,
-                                      const float *dist, const float *thr, int B, int N, int M, void *ws,
-                                      size_t ws_bytes, float *res_r /*[B,9] in/out*/, float *res_t /*[B,3] in/out*/,
-                                      float *step_R /*[B,9] or NULL*/, float *step_t /*[B,3] or NULL*/, void *stream) {
+static int icp_step_launch(const float *p1, const float *n1, const float *tgt, const int32_t *idx, const float *dist,
+                           const float *thr, int B, int N, int M, void *ws, size_t ws_bytes, float *res_r, float *res_t,
+                           float *step_R, float *step_t, int first, void *stream) {
   hipStream_t st = (hipStream_t)stream;
   if (B == 0) return RSLO_OK;
   RSLO_CHECK_ARG(N >= 1 && M >= 1, "icp_step: empty clouds");
@@ -638,9 +652,24 @@ extern "C" int rslo_icp_step(const float *p1, const float *n1, const float *tgt,
   const int nblk = (int)rslo_cdiv(N, LS_THREADS);
   hipLaunchKernelGGL(k_icp_moments, dim3(nblk, B), dim3(LS_THREADS), 0, st, p1, n1, tgt, idx, dist, thr, N, M,
                      (double *)ws);
-  hipLaunchKernelGGL(k_icp_solve, dim3(B), dim3(256), 0, st, (const double *)ws, nblk, res_r, res_t, step_R, step_t);
+  hipLaunchKernelGGL(k_icp_solve, dim3(B), dim3(256), 0, st, (const double *)ws, nblk, res_r, res_t, step_R, step_t,
+                     first);
   RSLO_CHECK_LAUNCH("icp_step");
   return RSLO_OK;
+}
+
+extern "C" int rslo_icp_step(const float *p1, const float *n1, const float *tgt, const int32_t *idx,
+                                      const float *dist, const float *thr, int B, int N, int M, void *ws,
+                                      size_t ws_bytes, float *res_r /*[B,9] in/out*/, float *res_t /*[B,3] in/out*/,
+                                      float *step_R /*[B,9] or NULL*/, float *step_t /*[B,3] or NULL*/, void *stream) {
+  return icp_step_launch(p1, n1, tgt, idx, dist, thr, B, N, M, ws, ws_bytes, res_r, res_t, step_R, step_t, 0, stream);
+}
+
+extern "C" int rslo_icp_step_first(const float *p1, const float *n1, const float *tgt, const int32_t *idx,
+                                   const float *dist, const float *thr, int B, int N, int M, void *ws, size_t ws_bytes,
+                                   float *res_r /*[B,9] out*/, float *res_t /*[B,3] out*/, float *step_R, float *step_t,
+                                   void *stream) {
+  return icp_step_launch(p1, n1, tgt, idx, dist, thr, B, N, M, ws, ws_bytes, res_r, res_t, step_R, step_t, 1, stream);
 }
 
 // out[b][j] = R[b] x[b][j] + t[b]
@@ -917,6 +946,37 @@ __global__ void k_pad_rows_bwd(const float *__restrict__ dout, int C, const int3
   dsrc[i] = v;
 }
 
+// The consistency loss's operands of one frame in one launch: xyz / normal columns of the voxel features and the
+// covariance head's rows, each as its own zero-padded [B,Lmax,.] block (voxel_odom_net.py:630-660 slices, concatenates and
+// pads them with a dozen tensor ops).  One thread per output row.
+__global__ void k_pair_rows_fwd(const float *__restrict__ feats, int F, int ncol, const float *__restrict__ conf, int Cc,
+                                const int32_t *__restrict__ off, const int32_t *__restrict__ len, int Lmax,
+                                float *__restrict__ xyz, float *__restrict__ nrm, float *__restrict__ cov, int64_t rows) {
+  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= rows) return;
+  const int r = (int)(row % Lmax), b = (int)(row / Lmax);
+  const bool live = r < len[b];
+  const int64_t s = (int64_t)off[b] + r;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    xyz[row * 3 + c] = live ? feats[s * F + c] : 0.0f;
+    nrm[row * 3 + c] = live ? feats[s * F + ncol + c] : 0.0f;
+  }
+  for (int c = 0; c < Cc; ++c) cov[row * Cc + c] = live ? conf[s * Cc + c] : 0.0f;
+}
+
+extern "C" int rslo_pair_rows_fwd(const float *feats, int64_t N, int F, const float *conf, int Cc, const int32_t *off,
+                                  const int32_t *len, int B, int Lmax, float *xyz, float *nrm, float *cov, void *stream) {
+  RSLO_CHECK_ARG(feats && conf && off && len && xyz && nrm && cov && F >= 6 && Cc > 0 && B > 0 && Lmax >= 0 && N >= 0,
+                 "rslo_pair_rows_fwd: bad arguments");
+  const int64_t rows = (int64_t)B * Lmax;
+  if (rows == 0) return RSLO_OK;
+  hipLaunchKernelGGL(k_pair_rows_fwd, dim3((unsigned)rslo_cdiv(rows, 256)), dim3(256), 0, (hipStream_t)stream, feats, F,
+                     F > 6 ? 4 : 3, conf, Cc, off, len, Lmax, xyz, nrm, cov, rows);
+  RSLO_CHECK_LAUNCH("k_pair_rows_fwd");
+  return RSLO_OK;
+}
+
 extern "C" int rslo_pad_rows_fwd(const float *src, int64_t N, int C, const int32_t *off, const int32_t *len, int B,
                                  int Lmax, float *out, void *stream) {
   RSLO_CHECK_ARG(src && off && len && out && C > 0 && B > 0 && Lmax >= 0 && N >= 0, "rslo_pad_rows_fwd: bad arguments");
@@ -950,7 +1010,30 @@ extern "C" int rslo_pad_rows_bwd(const float *dout, int64_t N, int C, const int3
 //   consist.: C   = c_scale (exp(-a_C) mean_b lb_b + a_C)            (focal_gamma = 0 everywhere: the shipped configuration)
 // out[0] = T + R + P + C, out[1..4] = T, R, P, C.
 // ---------------------------------------------------------------------------------------
+// The operands (a few dozen floats) come in through LDS, all loads in flight together, and thread 0 then walks them in the
+// torch formulation's order: read straight from global memory the walk was a chain of ~60 dependent loads -- 28 us for the
+// backward kernel, in the stretch of the step where nothing else runs.  Larger batches than LT_MAXB read global memory.
+#define LT_MAXB 64
+struct LtStage {
+  float tp[LT_MAXB * 3], tt[LT_MAXB * 3], qp[LT_MAXB * 4], qt[LT_MAXB * 4];
+  float pyr[RSLO_LOSS_TAIL_MAX_LEVELS * LT_MAXB * 2], pair[LT_MAXB];
+};
+
+__device__ __forceinline__ void lt_stage(RsloLossTail &p, LtStage &S) {
+  if (p.B > LT_MAXB || p.n_pairs > LT_MAXB) return;      // block-uniform
+  for (int i = threadIdx.x; i < p.B * 3; i += blockDim.x) { S.tp[i] = p.t_pred[i]; S.tt[i] = p.t_tgt[i]; }
+  for (int i = threadIdx.x; i < p.B * 4; i += blockDim.x) { S.qp[i] = p.q_pred[i]; S.qt[i] = p.q_tgt[i]; }
+  for (int i = threadIdx.x; i < p.L * p.B * 2; i += blockDim.x) S.pyr[i] = p.pyr_loss_b[i];
+  for (int i = threadIdx.x; i < p.n_pairs; i += blockDim.x) S.pair[i] = p.pair_loss[i];
+  __syncthreads();
+  p.t_pred = S.tp; p.t_tgt = S.tt; p.q_pred = S.qp; p.q_tgt = S.qt;
+  if (p.L > 0) p.pyr_loss_b = S.pyr;
+  if (p.n_pairs > 0) p.pair_loss = S.pair;
+}
+
 __global__ void k_loss_tail_fwd(RsloLossTail p, float *__restrict__ out) {
+  __shared__ LtStage S;
+  lt_stage(p, S);
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const float inv_b = 1.0f / ((float)p.B + 1e-12f);
   float st = 0.f, sr = 0.f;
@@ -995,14 +1078,18 @@ __global__ void k_loss_tail_fwd(RsloLossTail p, float *__restrict__ out) {
   out[4] = Cl;
 }
 
-// gradients of out[0] scaled by *g: d_t [B,3], d_q [B,4], d_pyr [L,B,2], d_pair [n_pairs], d_alpha[5] = (T, R, pT, pR, C)
-// (a module used for both the pose and the pyramid terms gets the SUM of its two entries from the caller)
+// gradients of out[0] scaled by *g: d_t [B,3], d_q [B,4], d_pyr [L,B,2], d_pair [n_pairs], d_alpha = (T, R, pT, pR, C), entry i at d_alpha[4 i]
+// A module used for more than one term (the same alpha pointer twice): the FIRST of its entries holds the sum of all of
+// them, added in entry order -- what the autograd engine's accumulation of the separate entries gives, without its launches.
 __global__ void k_loss_tail_bwd(RsloLossTail p, const float *__restrict__ g, float *__restrict__ d_t,
                                 float *__restrict__ d_q, float *__restrict__ d_pyr, float *__restrict__ d_pair,
                                 float *__restrict__ d_alpha) {
+  __shared__ LtStage S;
   const float go = *g, inv_b = 1.0f / ((float)p.B + 1e-12f);
   const float aT = *p.alpha_T, aR = *p.alpha_R;
   const float eT = expf(-aT), eR = expf(-aR);
+  const float *const alpha_ptr[5] = {p.alpha_T, p.alpha_R, p.alpha_pT, p.alpha_pR, p.alpha_C};
+  lt_stage(p, S);
   const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
   const float kt = go * p.w_T * eT * inv_b * 2.0f / (3.0f + 1e-12f), kq = go * p.w_R * eR * inv_b * 2.0f / (4.0f + 1e-12f);
   for (int i = tid; i < p.B * 3; i += nth) d_t[i] = kt * (p.t_pred[i] - p.t_tgt[i]);
@@ -1033,8 +1120,8 @@ __global__ void k_loss_tail_bwd(RsloLossTail p, const float *__restrict__ g, flo
       st += a / (3.0f + 1e-12f);
       sr += c / (4.0f + 1e-12f);
     }
-    d_alpha[0] = go * p.w_T * (1.0f - eT * st * inv_b);
-    d_alpha[1] = go * p.w_R * (1.0f - eR * sr * inv_b);
+    const float dT = go * p.w_T * (1.0f - eT * st * inv_b);
+    const float dR = go * p.w_R * (1.0f - eR * sr * inv_b);
     float dpT = 0.f, dpR = 0.f;
     if (p.L > 0) {
       const float epT = expf(-*p.alpha_pT), epR = expf(-*p.alpha_pR);
@@ -1048,15 +1135,20 @@ __global__ void k_loss_tail_bwd(RsloLossTail p, const float *__restrict__ g, flo
         dpR += p.level_w[l] * p.w_pR * (1.0f - epR * s1 * inv_b);
       }
     }
-    d_alpha[2] = go * dpT;
-    d_alpha[3] = go * dpR;
     float dc = 0.f;
     if (p.n_pairs > 0) {
       float s = 0.f;
       for (int b = 0; b < p.n_pairs; ++b) s += p.pair_loss[b];
       dc = go * p.c_scale * (1.0f - expf(-*p.alpha_C) * (s / (float)p.n_pairs));
     }
-    d_alpha[4] = dc;
+    float da[5] = {dT, dR, go * dpT, go * dpR, dc};
+    for (int i = 1; i < 5; ++i)
+      for (int j = 0; j < i; ++j)
+        if (alpha_ptr[i] && alpha_ptr[i] == alpha_ptr[j]) {
+          da[j] += da[i];
+          break;
+        }
+    for (int i = 0; i < 5; ++i) d_alpha[i * RSLO_LOSS_TAIL_ALPHA_STRIDE] = da[i];
   }
 }
 

@@ -53,7 +53,7 @@ __device__ __forceinline__ float pose_safe_div(float num, float den) {
 
 __global__ void k_pose_targets(const float *__restrict__ res_r, const float *__restrict__ res_t,
                                const float *__restrict__ R_pred, const float *__restrict__ T_pred, int B,
-                               float *__restrict__ rot_t, float *__restrict__ trans_t) {
+                               float *__restrict__ rot_t, float *__restrict__ trans_t, float *__restrict__ tq) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   const float *a = res_r + b * 9, *r = R_pred + b * 9, *t = T_pred + b * 3;
@@ -63,7 +63,11 @@ __global__ void k_pose_targets(const float *__restrict__ res_r, const float *__r
 #pragma unroll
     for (int j = 0; j < 3; ++j) m[i * 3 + j] = a[i * 3 + 0] * r[0 * 3 + j] + a[i * 3 + 1] * r[1 * 3 + j] + a[i * 3 + 2] * r[2 * 3 + j];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) trans_t[b * 3 + i] = a[i * 3 + 0] * t[0] + a[i * 3 + 1] * t[1] + a[i * 3 + 2] * t[2] + res_t[b * 3 + i];
+  for (int i = 0; i < 3; ++i) {
+    const float v = a[i * 3 + 0] * t[0] + a[i * 3 + 1] * t[1] + a[i * 3 + 2] * t[2] + res_t[b * 3 + i];
+    trans_t[b * 3 + i] = v;
+    if (tq) tq[b * 7 + i] = v;
+  }
   const float eps = 1e-8f;
   const float m00 = m[0], m01 = m[1], m02 = m[2], m10 = m[3], m11 = m[4], m12 = m[5], m20 = m[6], m21 = m[7], m22 = m[8];
   const float trace = m00 + m11 + m22;
@@ -87,6 +91,12 @@ __global__ void k_pose_targets(const float *__restrict__ res_r, const float *__r
   rot_t[b * 4 + 1] = qx * s;
   rot_t[b * 4 + 2] = qy * s;
   rot_t[b * 4 + 3] = qz * s;
+  if (tq) {      // the [B,7] (t, q) rows the pyramid supervision reads (voxel_odom_net.py:747): no concatenation launch
+    tq[b * 7 + 3] = qw * s;
+    tq[b * 7 + 4] = qx * s;
+    tq[b * 7 + 5] = qy * s;
+    tq[b * 7 + 6] = qz * s;
+  }
 }
 
 extern "C" int rslo_quat_to_rot(const float *q_wxyz, int B, float *R, void *stream) {
@@ -106,13 +116,19 @@ extern "C" int rslo_quat_to_rot_bwd(const float *q_wxyz, const float *gR, int B,
   return RSLO_OK;
 }
 
-extern "C" int rslo_pose_targets(const float *res_r, const float *res_t, const float *R_pred, const float *T_pred, int B,
-                                 float *rot_targets_wxyz, float *trans_targets, void *stream) {
+extern "C" int rslo_pose_targets_tq(const float *res_r, const float *res_t, const float *R_pred, const float *T_pred,
+                                    int B, float *rot_targets_wxyz, float *trans_targets, float *tq /*[B,7] or NULL*/,
+                                    void *stream) {
   RSLO_CHECK_ARG(res_r && res_t && R_pred && T_pred && rot_targets_wxyz && trans_targets && B >= 0,
                  "rslo_pose_targets: bad arguments");
   if (B == 0) return RSLO_OK;
   hipLaunchKernelGGL(k_pose_targets, dim3((unsigned)rslo_cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, res_r, res_t,
-                     R_pred, T_pred, B, rot_targets_wxyz, trans_targets);
+                     R_pred, T_pred, B, rot_targets_wxyz, trans_targets, tq);
   RSLO_CHECK_LAUNCH("k_pose_targets");
   return RSLO_OK;
+}
+
+extern "C" int rslo_pose_targets(const float *res_r, const float *res_t, const float *R_pred, const float *T_pred, int B,
+                                 float *rot_targets_wxyz, float *trans_targets, void *stream) {
+  return rslo_pose_targets_tq(res_r, res_t, R_pred, T_pred, B, rot_targets_wxyz, trans_targets, nullptr, stream);
 }

@@ -148,10 +148,10 @@ class AdamStepper:
             if g is None:
                 continue
             if g.dtype != torch.float32 or not g.is_contiguous() or not g.is_cuda:
-                return False
+                return self._torch_step("a gradient that is not a contiguous fp32 CUDA tensor")
             ptrs[i] = g.data_ptr()
         if (ptrs % 16).any():
-            return False
+            return self._torch_step("a gradient tensor that is not 16-byte aligned")
         late = (ptrs != 0) & ~self.has_state
         if late.any():      # first gradient of a tensor: torch starts ITS count at 1 whatever the others have reached
             for i in np.nonzero(late)[0]:
@@ -171,6 +171,15 @@ class AdamStepper:
             self.tensors_dev.copy_(pin, non_blocking=True)
             self.grad_ptrs = ptrs
         return bool(ptrs.any())
+
+    def _torch_step(self, why):
+        """This step goes through torch.optim (same update, ~30 launches instead of 2): said once, because it is slow."""
+        if not self.__dict__.get("_warned"):
+            import warnings
+            warnings.warn("rslo_amd.optim: the fused clip + Adam kernels are skipped for this step (%s); torch's own "
+                          "optimizer path runs instead" % why)
+            self._warned = True
+        return False
 
     # ------------------------------------------------------------------ the two operations
     def clip_grad_norm_(self, max_norm):

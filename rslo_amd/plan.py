@@ -102,6 +102,7 @@ class EncoderPlanner:
         self.static_level_fractions = [1.0, 0.75, 0.5, 0.25, 0.15, 0.15, 0.15, 0.15]      # capacities of a static plan's levels
         self._static = {}         # (features, pairs, point capacity, clouds) -> (spec, layout) of the capacity-laid-out arena
         self.fallbacks = 0
+        self._zero_inputs = {}
 
     def _spec(self, n_features, with_pairs):
         sp = capi.EncoderSpec()
@@ -292,8 +293,14 @@ class EncoderPlanner:
             ex["num_voxels"].append(torch.tensor(nvox[t * B:(t + 1) * B], dtype=torch.int64).reshape(B, 1))
         npairs = T * (T - 1) // 2
         dev = A.device
-        ex["icp_odometry"] = torch.zeros(B * npairs, 7, device=dev)
-        ex["tq_maps"] = [torch.zeros(B * npairs, 7, 96, 176, device=dev)]
+        # placeholders of the ground-truth inputs no synthetic cloud has (read-only downstream): filled once, not per step
+        zk = (B * npairs, str(dev))
+        zs = self._zero_inputs.get(zk)
+        if zs is None:
+            zs = self._zero_inputs[zk] = (torch.zeros(B * npairs, 7, device=dev),
+                                          torch.zeros(B * npairs, 7, 96, 176, device=dev))
+        ex["icp_odometry"] = zs[0]
+        ex["tq_maps"] = [zs[1]]
         ex["_frame_major"] = (voxels, num)          # all frames in one block: one VFE launch, no concatenation
 
         # ---- the plan: site indices, rulebooks, orders, pair lists as arena views

@@ -123,7 +123,10 @@ class _LossTailFn(torch.autograd.Function):
         desc = _LossTailFn._desc(t_pred, q_pred, pyr, pair, (aT, aR, apT, apR, aC), ctx.meta)
         d_t, d_q, d_pyr, d_pair, d_a = capi.loss_tail_bwd(desc, g[0:1].contiguous(), desc.B, desc.L, desc.n_pairs)
         need = ctx.needs_input_grad
-        da = [d_a[i:i + 1] if need[4 + i] else None for i in range(5)]
+        # a module used for several terms: the kernel has added its entries into the first one (in entry order, as the
+        # engine would); the later ones return nothing, so no accumulation launches follow
+        ptrs = [a.data_ptr() for a in (aT, aR, apT, apR, aC)]
+        da = [d_a[i:i + 1] if need[4 + i] and ptrs[i] not in ptrs[:i] else None for i in range(5)]      # (16-byte slots)
         return d_t, d_q, d_pyr, d_pair, da[0], da[1], da[2], da[3], da[4], None
 
 
@@ -148,6 +151,31 @@ class _PadRowsFn(torch.autograd.Function):
     def backward(ctx, g):
         off, length = ctx.saved_tensors
         return capi.pad_rows_bwd(g.contiguous(), off, length, ctx.n), None, None, None
+
+
+class _PairRowsFn(torch.autograd.Function):
+    """One frame's consistency-loss operands (rslo_pair_rows_fwd): xyz / normal columns of the voxel features (network
+    inputs, no gradient) and the covariance rows, each a contiguous zero-padded [B,Lmax,.] block."""
+
+    @staticmethod
+    def forward(ctx, feats, conf, off, length, Lmax):
+        ctx.save_for_backward(off, length)
+        ctx.n = conf.shape[0]
+        xyz, nrm, cov = capi.pair_rows_fwd(feats.contiguous(), conf.contiguous(), off, length, Lmax)
+        ctx.mark_non_differentiable(xyz, nrm)
+        return xyz, nrm, cov
+
+    @staticmethod
+    def backward(ctx, _gx, _gn, g):
+        off, length = ctx.saved_tensors
+        return None, capi.pad_rows_bwd(g.contiguous(), off, length, ctx.n), None, None, None
+
+
+def pair_rows(feats, conf, off, length, Lmax):
+    """feats [N,7 | 6], conf [N,Cc], off/length int32 [B] (device) -> xyz [B,Lmax,3], normals [B,Lmax,3], cov [B,Lmax,Cc]:
+    what pad_rows(cat([feats[:, xyz + normal columns], conf], 1)) and the column slices of its result hold, as three
+    contiguous tensors from one launch."""
+    return _PairRowsFn.apply(feats.detach(), conf, off, length, Lmax)
 
 
 def pad_rows(src, off, length, Lmax):
@@ -207,11 +235,14 @@ def quat_wxyz_to_rot(q):
     return kornia.quaternion_to_rotation_matrix(torchplus.roll(q, shift=-1, dim=-1))
 
 
-def icp_pose_targets(res_r, res_t, R_pred, T_pred):
-    """Pseudo-targets from the ICP refinement (voxel_odom_net.py:709-735), no gradient: (q* wxyz with w >= 0, t*)."""
+def icp_pose_targets(res_r, res_t, R_pred, T_pred, with_tq=False):
+    """Pseudo-targets from the ICP refinement (voxel_odom_net.py:709-735), no gradient: (q* wxyz with w >= 0, t*).
+    with_tq (cuda): also the [B,7] rows (t*, q*) of the pyramid supervision, written by the same launch."""
     R_pred, T_pred = R_pred.detach(), T_pred.detach()
     if res_r.is_cuda:
-        return capi.pose_targets(res_r.contiguous(), res_t.contiguous(), R_pred.contiguous(), T_pred.contiguous())
+        return capi.pose_targets(res_r.contiguous(), res_t.contiguous(), R_pred.contiguous(), T_pred.contiguous(),
+                                 with_tq=with_tq)
+    assert not with_tq
     import torchplus
     rot = kornia.rotation_matrix_to_quaternion((res_r @ R_pred).contiguous())
     rot = torchplus.roll(rot, 1, dim=-1)
@@ -462,11 +493,15 @@ class Aleat5_1ChamferL2NormalWeightedALLSVDLoss(Loss):
         loss_b = _CovResidualFn.apply(xyz_pred, xyz_target, cov_pred, cov_target, idx, dist, thr,
                                       R_pred.detach(), float(self.reg_weight))
         B = p1.shape[0]
-        res_r = torch.eye(3, device=p1.device, dtype=torch.float32).repeat(B, 1, 1)
-        res_t = torch.zeros(B, 3, device=p1.device, dtype=torch.float32)
+        if icp_iter > 0:       # the first refinement writes them (identity start inside the kernel): no fill launches
+            res_r = torch.empty(B, 3, 3, device=p1.device, dtype=torch.float32)
+            res_t = torch.empty(B, 3, device=p1.device, dtype=torch.float32)
+        else:
+            res_r = torch.eye(3, device=p1.device, dtype=torch.float32).repeat(B, 1, 1)
+            res_t = torch.zeros(B, 3, device=p1.device, dtype=torch.float32)
         cur = tgt0
         for it in range(icp_iter):
-            capi.icp_step(p1, n1, cur, idx, dist, thr, res_r, res_t)
+            capi.icp_step(p1, n1, cur, idx, dist, thr, res_r, res_t, first=(it == 0))
             if it < icp_iter - 1:
                 cur = capi.transform_points(tgt0, res_r, res_t)
                 dist, idx = capi.chamfer_nn(p1, cur, ncnt=counts, mcnt=counts)

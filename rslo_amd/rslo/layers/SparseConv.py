@@ -144,9 +144,10 @@ class _ConvBNActFn(torch.autograd.Function):
     replaces (rslo_conv2d_fwd, rslo_bn2d_*, rslo_conv2d_wgrad with the bias gradient from the same pass): bit-identical."""
 
     @staticmethod
-    def forward(ctx, x, w, cb, g, b, conv, bn, slope):
+    def forward(ctx, x, w, cb, g, b, conv, bn, slope, fork=False):
         from rslo_amd import capi, precision
         from apex.parallel import _world, count_batch, fused_bn_forward
+        x_in = x
         x = x.contiguous()
         lp = precision.low_precision() is not None
         ws = getattr(w, "_hip_split", None)
@@ -162,23 +163,31 @@ class _ConvBNActFn(torch.autograd.Function):
         ctx.save_for_backward(x, w, g, o, y if slope != 1.0 else None, mean, invstd, cnt)
         ctx.meta = (wt, slope, lp, cb is not None, group, world)
         ctx.leaf_params = (w,) if cb is None else (w, cb)
+        if fork:      # the input again, as an output of THIS node: what its other consumers read (see forward_fork)
+            ctx.set_materialize_grads(False)
+            return y, x_in
         return y
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, g_other=None):
         from rslo_amd import capi
         from rslo.layers import hip_conv2d
         from apex.parallel import fused_bn_backward
         x, w, g, o, y, mean, invstd, cnt = ctx.saved_tensors
         wt, slope, lp, has_bias, group, world = ctx.meta
+        if gy is None:      # only the forked input was used downstream
+            return g_other, None, None, None, None, None, None, None, None
         d_o, _, dg, db = fused_bn_backward(gy.contiguous(), y, o, g, mean, invstd, cnt, slope, False, True, group, world)
-        dx = capi.conv2d_fwd(d_o, wt, None, w.shape[1], lp=lp) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:      # the other consumers' gradient joins in the data gradient's epilogue
+            dx = capi.conv2d_fwd(d_o, wt, None, w.shape[1], lp=lp,
+                                 residual=None if g_other is None else g_other.contiguous())
         dcb = None
         if has_bias:
             dw, dcb = hip_conv2d.conv2d_wgrad_leaf(x, d_o, 1, want_bias=True, lp=lp, params=ctx.leaf_params)
         else:
             dw = hip_conv2d.conv2d_wgrad_leaf(x, d_o, 1, lp=lp, params=ctx.leaf_params)
-        return dx, dw, dcb, dg, db, None, None, None
+        return dx, dw, dcb, dg, db, None, None, None, None
 
 
 def _conv_bn_fusable(conv, bn, x):
@@ -247,11 +256,30 @@ class FusedSequential(nn.Sequential):
     def forward(self, x):
         return self.forward_from(x, 0)
 
+    def forward_fork(self, x):
+        """-> (self(x), x'), x' holding x's values for the OTHER consumers of x.  When the first children are a fused
+        conv -> BN -> activation node, x' is an output of that node and the gradient its consumers send back arrives as
+        an operand of the node's backward, where the data-gradient kernel adds it in its epilogue -- instead of the
+        autograd engine summing the two contributions to x with a launch of its own (seven full-map additions per step in
+        the BEV head: every encoder stage feeds a skip branch, every decoder stage a prediction branch).  Otherwise
+        x' is x."""
+        steps = self._steps()
+        if steps and isinstance(steps[0][0], tuple) and isinstance(x, torch.Tensor) and x.requires_grad:
+            conv, bn = steps[0][0]
+            if _conv_bn_fusable(conv, bn, x):
+                y, x_other = _ConvBNActFn.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, conv, bn, steps[0][1], True)
+                return self._run(y, steps[1:], 0), x_other
+        return self.forward_from(x, 0), x
+
     def forward_from(self, x, first_child):
         """The children from index `first_child` on (a caller that has already applied the leading ones, e.g. the
         head's fused concatenation + nn.Upsample in front of a deblock)."""
+        return self._run(x, self._steps(), first_child)
+
+    @staticmethod
+    def _run(x, steps, first_child):
         skip = first_child
-        for m, slope in self._steps():
+        for m, slope in steps:
             if skip > 0:      # steps are whole children or (conv, BN, act) / (BN, act) groups: only leading singles are skipped
                 if isinstance(m, tuple) or slope is not None:
                     raise ValueError("forward_from: child %d is inside a fused group" % first_child)

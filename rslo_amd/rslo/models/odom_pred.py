@@ -147,7 +147,11 @@ class UNOdomPredEncDecSVDTempMaskBase(OdomPredEncDecBase):
             if i == 1 and side_work is not None:
                 side_work[0]()      # the half- / quarter-resolution stages start here: launches of ~1 workgroup per CU
             x = blk(x)
-            ups.append(skip(x[0]))
+            # the stage's map feeds its skip branch AND the next stage (the last one: the first deblock): the skip branch
+            # hands it on, so the two gradients meet inside its data-gradient kernel (FusedSequential.forward_fork)
+            u, x0 = _fork(skip, x[0])
+            ups.append(u)
+            x = [x0, x[1]]
         x = x[0]
         if side_work is not None:
             side_work[1]()          # created HERE in the graph: in backward it is issued right before the stages above
@@ -165,7 +169,7 @@ class UNOdomPredEncDecSVDTempMaskBase(OdomPredEncDecBase):
         for i, deblock in enumerate(self.deblocks):
             x = _deblock(deblock, x, ups[-(i + 1)])
             if self.pred_pyramid_motion and i < len(self.deblocks) - 1:
-                p = self.pyramid_motion_blocks[i](x)
+                p, x = _fork(self.pyramid_motion_blocks[i], x)
                 if fused_tail:
                     py_raw.append(p)
                 else:
@@ -174,7 +178,7 @@ class UNOdomPredEncDecSVDTempMaskBase(OdomPredEncDecBase):
 
         if not self.dense_predict:
             raise NotImplementedError("the fc (non-dense) head is outside the RSLO hot path")
-        tq_map = self.tq_map_conv(x)
+        tq_map, x_tail = _fork(self.tq_map_conv, x)      # three consumers of the full-resolution map: a chain of forks
         # The reference evaluates both confidence heads twice on the same features (T = 1 with gradient, T = 20 on
         # x.detach(), odom_pred.py:242-243,257-258).  The logits of the second pass are identical, so they are reused;
         # its only other effect -- a second running-statistics update of the trunk's BatchNorms with the same batch
@@ -184,8 +188,8 @@ class UNOdomPredEncDecSVDTempMaskBase(OdomPredEncDecBase):
             # the element-wise tail on csrc/headtail.hip: quaternion normalisation, the four masked softmaxes, the mask /
             # weight pyramid and the masked maps -- 3 launches forward, 3 backward instead of ~45 each way
             tq_map = _TqNormFn.apply(tq_map)
-            t_conf, r_conf, temp_tq_conf = _ConfPairFn.apply(self.t_map_conf.conf_model(x_tail),
-                                                              self.q_map_conf.conf_model(x_tail), outside, 20.0)
+            t_logit, x_tail = _fork(self.t_map_conf.conf_model, x_tail)
+            t_conf, r_conf, temp_tq_conf = _ConfPairFn.apply(t_logit, self.q_map_conf.conf_model(x_tail), outside, 20.0)
         else:
             t_part, q_part = tq_map.split([3, 4], dim=1)      # one split: its backward is one cat, not 3 x (zeros + copy)
             tq_map = torch.cat([t_part, q_part / torch.norm(q_part, dim=1, keepdim=True)], dim=1)
@@ -349,6 +353,13 @@ class _CatUpsampleFn(torch.autograd.Function):
         ca, cb, scale = ctx.meta
         da, db = capi.cat_upsample_bwd(g.contiguous(), ca, cb, scale, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         return da, db, None
+
+
+def _fork(seq, x):
+    """(seq(x), x for the other consumers of x) -- see FusedSequential.forward_fork."""
+    if hasattr(seq, "forward_fork"):
+        return seq.forward_fork(x)
+    return seq(x), x
 
 
 def _deblock(deblock, x, skip):

@@ -67,6 +67,16 @@ def create_cycle_constraint_data(xs, cat_dim=1):
     return [torch.stack(x1, dim=cat_dim).reshape(-1, *shape[1:]), torch.stack(x2, dim=cat_dim).reshape(-1, *shape[1:])]
 
 
+def pair_rows_meta(counts):
+    """counts[t][b] = voxels of sample b in frame t (the frames hold their samples back to back) -> int32 [T + 1, B]:
+    row t = first row of each sample inside frame t, row T = the rows every frame of the sample is truncated to (the
+    shortest frame's, reference voxel_odom_net.py:646-651).  The operand of losses.pair_rows / pad_rows."""
+    T_, B = len(counts), len(counts[0])
+    offs = [[sum(counts[t][:b]) for b in range(B)] for t in range(T_)]
+    lens = [min(counts[t][b] for t in range(T_)) for b in range(B)]
+    return torch.tensor(offs + [lens], dtype=torch.int32)
+
+
 def _detach_tree(x):
     if isinstance(x, torch.Tensor):
         return x.detach()
@@ -516,7 +526,6 @@ class UnVoxelOdomNetICP3(nn.Module):
         else:
             warm_weight = 0
 
-        C_loss = torch.zeros([1], dtype=dtype, device=device)
         res_r = res_t = None
         raw_pair = None
         AW = losses.AdaptiveWeightedL2Loss
@@ -529,6 +538,7 @@ class UnVoxelOdomNetICP3(nn.Module):
                     for m in (pyramid_translation_loss, pyramid_rotation_loss))
             and (pyramid_translation_loss is None) == (pyramid_rotation_loss is None)
             and (consistency_loss is None or getattr(consistency_loss, "focal_gamma", 0) == 0))
+        C_loss = None if raw_tail else torch.zeros([1], dtype=dtype, device=device)      # the fused tail has its own
         if consistency_loss is not None:
             if len(preds_dict["middle_conf_preds"]) == 0:
                 # the reference has no working behaviour here: it keeps point_confs = None (voxel_odom_net.py:628) and
@@ -536,12 +546,16 @@ class UnVoxelOdomNetICP3(nn.Module):
                 raise NotImplementedError("hier_points supervision without a covariance head (SURVEY.md 8f-4): the "
                                           "reference itself fails in this branch (point_confs is None)")
             feats = preds_dict["voxel_features"]
+            B = example["num_voxels"][0].shape[0]
+            # GPU, more than one sample: one launch per frame selects the columns, joins the covariance rows and pads
+            one_launch = device.type == "cuda" and B > 1 and all(f.dtype == torch.float32 for f in feats)
             # xyz + normal columns (intensity dropped); slices, not an index list (no host->device index upload)
-            if feats[0].shape[1] > 6:
+            if one_launch:
+                pass
+            elif feats[0].shape[1] > 6:
                 feats = [torch.cat([f[:, 0:3], f[:, 4:7]], 1) for f in feats]
             else:
                 feats = [f[:, 0:6] for f in feats]
-            B = example["num_voxels"][0].shape[0]
             # rows of sample b inside frame t (frames hold the samples back to back)
             if B == 1:
                 counts = [[f.shape[0]] for f in feats]
@@ -559,15 +573,18 @@ class UnVoxelOdomNetICP3(nn.Module):
                 # all samples as ONE zero-padded batch [B, Lmax, .] per frame: a single row gather per frame
                 # (row offsets / lengths go up as one small pinned upload -- no per-sample slicing and padding ops)
                 Lmax = max(lens)
-                offs = [[sum(counts[t][:b]) for b in range(B)] for t in range(T_)]
-                meta = torch.tensor(offs + [lens], dtype=torch.int32)
+                meta = pair_rows_meta(counts)
                 if device.type == "cuda":      # pinned + async: a pageable upload would drain the stream
                     meta = meta.pin_memory().to(device, non_blocking=True)
-                points, confs = [], []
+                points, confs, normals = [], [], []
                 for t in range(T_):
-                    both = losses.pad_rows(torch.cat([feats[t], confs_all[t]], 1), meta[t], meta[T_], Lmax)
-                    nf = feats[t].shape[1]            # one split: its backward is one cat, not 2 x (zeros + copy) + add
-                    pt, cf = both.split([nf, both.shape[-1] - nf], dim=-1)
+                    if one_launch:
+                        pt, nr, cf = losses.pair_rows(feats[t], confs_all[t], meta[t], meta[T_], Lmax)
+                        normals.append(nr)
+                    else:
+                        both = losses.pad_rows(torch.cat([feats[t], confs_all[t]], 1), meta[t], meta[T_], Lmax)
+                        nf = feats[t].shape[1]        # one split: its backward is one cat, not 2 x (zeros + copy) + add
+                        pt, cf = both.split([nf, both.shape[-1] - nf], dim=-1)
                     points.append(pt)
                     confs.append(cf)
                 npairs_ = T_ * (T_ - 1) // 2
@@ -577,6 +594,11 @@ class UnVoxelOdomNetICP3(nn.Module):
                     cnt_dev = cnt_dev.repeat_interleave(npairs_)
             pts1, pts2 = create_cycle_constraint_data(points, 1)      # [B * npairs, L, 6], sample-major
             cov1, cov2 = create_cycle_constraint_data(confs, 1)
+            if one_launch:      # xyz and normals arrived as separate contiguous tensors
+                xyz1, xyz2 = pts1, pts2
+                nrm1, nrm2 = create_cycle_constraint_data(normals, 1)
+            else:
+                xyz1, nrm1, xyz2, nrm2 = pts1[:, :, :3], pts1[:, :, 3:], pts2[:, :, :3], pts2[:, :, 3:]
 
             weights = [0.01, 0.01, 0.05, 0.1, 1]
             for R_pred, T_pred, weight in zip(rotation_preds, translation_preds, weights[-len(translation_preds):]):
@@ -589,11 +611,11 @@ class UnVoxelOdomNetICP3(nn.Module):
                     T_pred = torch.zeros_like(T_pred)
                 icp_iter = self.icp_iter if step > 1500 else 5
                 # the points/normals are network inputs: only the pose receives a gradient through the move
-                p2_moved = losses.rigid_move(pts2[:, :, :3], R_pred, T_pred)
-                n2_moved = losses.rigid_move(pts2[:, :, 3:], R_pred.detach())
+                p2_moved = losses.rigid_move(xyz2, R_pred, T_pred)
+                n2_moved = losses.rigid_move(nrm2, R_pred.detach())
                 lb, res_r, res_t = consistency_loss.pair_losses(
-                    pts1[:, :, :3], p2_moved, cov_pred=cov1, cov_target=cov2, R_pred=R_pred, t_pred=T_pred,
-                    normal_pred=pts1[:, :, 3:].detach(), normal_target=n2_moved.detach(), icp_iter=icp_iter,
+                    xyz1, p2_moved, cov_pred=cov1, cov_target=cov2, R_pred=R_pred, t_pred=T_pred,
+                    normal_pred=nrm1.detach(), normal_target=n2_moved.detach(), icp_iter=icp_iter,
                     counts=cnt_dev, counts_host=cnt_host)
                 if raw_tail:
                     raw_pair = (lb, (1 - warm_weight) * weight * consistency_loss._loss_weight)
@@ -601,8 +623,13 @@ class UnVoxelOdomNetICP3(nn.Module):
                 l = consistency_loss._loss_weight * consistency_loss.reduce(lb)
                 C_loss = C_loss + (1 - warm_weight) * weight * l
 
+        tq_targets = None
         if res_r is not None and res_t is not None:
-            rotation_targets, translation_targets = losses.icp_pose_targets(res_r, res_t, R_pred, T_pred)
+            if raw_tail:       # the (t*, q*) rows of the pyramid supervision come out of the same launch
+                rotation_targets, translation_targets, tq_targets = losses.icp_pose_targets(res_r, res_t, R_pred, T_pred,
+                                                                                            with_tq=True)
+            else:
+                rotation_targets, translation_targets = losses.icp_pose_targets(res_r, res_t, R_pred, T_pred)
 
         if raw_tail:
             raw = {"t_pred": translation_preds[0], "q_pred": rotation_preds[0], "t_tgt": translation_targets,
@@ -617,7 +644,8 @@ class UnVoxelOdomNetICP3(nn.Module):
                          pyramid_rotation_loss._loss_weight if pyramid_rotation_loss is not None else 0.0,
                          raw_pair[1] if raw_pair is not None else 0.0]}
             levels = [(pp[0], pp[1]) if isinstance(pp, (tuple, list)) else (pp, None) for pp in pyramid_preds]
-            tq_targets = torch.cat([translation_targets, rotation_targets], dim=-1).reshape(-1, 7)
+            if tq_targets is None:
+                tq_targets = torch.cat([translation_targets, rotation_targets], dim=-1).reshape(-1, 7)
             example["tq_targets"] = tq_targets
             if pyramid_translation_loss is not None and len(levels) > 0:
                 if not all(m is not None and p.dim() == 4 for p, m in levels):

@@ -1,6 +1,8 @@
-"""Which Python lines still launch torch-native GPU kernels (at::native / rocclr copies / library GEMMs) in one C3 step.
+"""Which Python lines still launch torch-native GPU kernels (at::native / rocclr copies / library GEMMs) in one C3 step --
+the step bench.py times: examples from the ExamplePrefetcher (native planner on the side stream), head graph as configured.
 Forward launches are attributed to the innermost frame under rslo_amd/ (with_stack); backward launches to the autograd
-node that issued them."""
+node that issued them.  RSLO_SITES_INLINE=1: voxelize + plan inline through workload.make_example instead (the
+Python planner the native one is tested against)."""
 import os, sys, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, rslo_amd
@@ -16,16 +18,22 @@ train_cfg = config_text.shipped_config().train_config
 opt = optimizer_builder.build(train_cfg.optimizer, net)
 sched = lr_scheduler_builder.build(train_cfg.optimizer, opt, train_cfg.steps)
 clouds = [[torch.from_numpy(c).cuda() for c in pair] for pair in workload.kitti_pairs(4)]
+inline = os.environ.get("RSLO_SITES_INLINE") == "1"
+prefetch = None
+if not inline:
+    prefetch = workload.ExamplePrefetcher(net, device="cuda", depth=2, workers=1)
+    for _ in range(2): prefetch.submit(clouds)
 def step():
-    ex = workload.make_example(net, clouds)
+    ex = workload.make_example(net, clouds) if inline else prefetch.get()
     sched.step(net.get_global_step())
     opt.zero_grad()
     ret = net(ex)
+    if prefetch is not None: prefetch.submit(clouds)
     ret["loss"].mean().backward()
     hip_optim.clip_grad_norm_(params, 10.0, optimizer=opt)
     opt.step()
     net.update_global_step()
-for _ in range(4): step()
+for _ in range(6): step()
 torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True,
              experimental_config=torch._C._profiler._ExperimentalConfig(verbose=True)) as prof:
@@ -56,3 +64,4 @@ for e in prof.events():
 print("torch-native launches in one step:", total)
 for site, (n, us, ops) in sorted(sites.items(), key=lambda kv: -kv[1][0]):
     print("%4d %8.1f us  %-80s %s" % (n, us, site[:80], dict(ops.most_common(4))))
+if prefetch is not None: prefetch.close()

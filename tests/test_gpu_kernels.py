@@ -605,6 +605,31 @@ def test_pad_rows_fwd_bwd(hip):
     assert torch.equal(out.cpu(), ref) and torch.equal(dev_in.grad.cpu(), ref_in.grad)
 
 
+@pytest.mark.parametrize("F", [7, 6])
+def test_pair_rows_equals_the_slice_cat_pad_formulation(hip, F):
+    """rslo_pair_rows_fwd (one launch per frame) == column selection + concatenation with the covariance rows + pad_rows +
+    the column slices of the result (voxel_odom_net.py:630-660), values and the covariance gradient, exactly."""
+    import torch
+    from rslo.core import losses
+    g = torch.Generator().manual_seed(3)
+    feats = torch.randn(1000, F, generator=g)
+    conf = torch.randn(1000, 7, generator=g)
+    off = torch.tensor([0, 300, 450, 900], dtype=torch.int32)
+    length = torch.tensor([250, 150, 400, 100], dtype=torch.int32)
+    cols = torch.cat([feats[:, 0:3], feats[:, 4:7]], 1) if F > 6 else feats[:, 0:6]
+    cref = conf.clone().requires_grad_(True)
+    both = losses.pad_rows(torch.cat([cols, cref], 1), off, length, 401)      # CPU formulation
+    w = torch.randn(4, 401, 7, generator=g)
+    (both[:, :, 6:] * w).sum().backward()
+    cdev = conf.cuda().requires_grad_(True)
+    xyz, nrm, cov = losses.pair_rows(feats.cuda(), cdev, off.cuda(), length.cuda(), 401)
+    (cov * w.cuda()).sum().backward()
+    assert xyz.is_contiguous() and nrm.is_contiguous() and cov.is_contiguous()
+    assert torch.equal(xyz.cpu(), both[:, :, 0:3]) and torch.equal(nrm.cpu(), both[:, :, 3:6])
+    assert torch.equal(cov.cpu(), both[:, :, 6:].detach()) and torch.equal(cdev.grad.cpu(), cref.grad)
+    assert not xyz.requires_grad and not nrm.requires_grad
+
+
 def test_rigid_move_fwd_bwd(hip):
     """rslo_transform_rows / _bwd on a column slice of a wider tensor == x @ R^T + t and its pose gradients."""
     from rslo.core import losses
@@ -945,6 +970,9 @@ def test_pose_algebra_kernels_match_kornia_restatement(hip):
     rd, td = losses.icp_pose_targets(res_r.cuda(), res_t.cuda(), Rp.cuda(), Tp.cuda())
     assert float((td.cpu() - tc).abs().max()) < 1e-5
     assert float((rd.cpu() - rc).abs().max()) < 2e-5
+    # the [B,7] (t*, q*) rows from the same launch hold the same bits
+    rd2, td2, tq = losses.icp_pose_targets(res_r.cuda(), res_t.cuda(), Rp.cuda(), Tp.cuda(), with_tq=True)
+    assert torch.equal(rd2, rd) and torch.equal(td2, td) and torch.equal(tq, torch.cat([td, rd], 1))
 
 
 # ------------------------------------------------------------------------------- dense conv2d weight gradient (BEV head)
@@ -1380,6 +1408,58 @@ def test_conv_bn_act_as_one_autograd_node_gives_the_same_bits(hip, monkeypatch):
         assert torch.equal(p.grad, q.grad), n
     for (n, p), (_, q) in zip(seq.named_buffers(), ref.named_buffers()):
         assert torch.equal(p, q), n
+
+
+def test_forked_input_gradient_joins_in_the_data_gradient_kernel(hip):
+    """FusedSequential.forward_fork: the map a branch reads is handed on to its other consumers as an output of the branch's
+    first node, and their gradient is added in that node's data-gradient epilogue.  Same outputs, input gradient, parameter
+    gradients and statistics as the plain form, where the autograd engine adds the two contributions with a launch of its
+    own -- also with a chain of two forks (three consumers) and when only the handed-on map is used."""
+    import copy
+    from rslo.layers import hip_conv2d
+    from rslo.layers.SparseConv import FusedSequential, SPC_ReLU, SPC_SyncBN2d
+    torch.manual_seed(9)
+
+    def trunk():
+        return FusedSequential(hip_conv2d.Conv2d(64, 32, kernel_size=3, padding=1), SPC_SyncBN2d(32), SPC_ReLU(),
+                               hip_conv2d.Conv2d(32, 7, 1)).cuda().train()
+    a, b = trunk(), trunk()
+    ra, rb = copy.deepcopy(a), copy.deepcopy(b)
+    x = torch.randn(2, 64, 24, 44, device="cuda")
+    w = torch.randn(2, 64, 24, 44, device="cuda")
+    g = torch.randn(2, 7, 24, 44, device="cuda")
+
+    def run(ma, mb, fork):
+        for m in (ma, mb):
+            hip_conv2d.presplit(m)
+        xi = x.clone().requires_grad_(True)
+        h = xi * 1.0                                  # a non-leaf map, as in the head
+        if fork:
+            ya, h1 = ma.forward_fork(h)
+            yb, h2 = mb.forward_fork(h1)
+            assert h1 is not h and h1.data_ptr() == h.data_ptr() and h2.data_ptr() == h.data_ptr()
+        else:
+            ya, yb, h2 = ma(h), mb(h), h
+        ((ya * g).sum() + (yb * g).sum() * 0.5 + (h2 * w).sum()).backward()
+        return ya.detach(), yb.detach(), xi.grad
+    out_f = run(a, b, True)
+    out_p = run(ra, rb, False)
+    for u, v in zip(out_f, out_p):
+        assert torch.equal(u, v)
+    for m, r in ((a, ra), (b, rb)):
+        for (n, p), (_, q) in zip(m.named_parameters(), r.named_parameters()):
+            assert torch.equal(p.grad, q.grad), n
+        for (n, p), (_, q) in zip(m.named_buffers(), r.named_buffers()):
+            assert torch.equal(p, q), n
+    # only the handed-on map reaches the loss: the branch's own output is dropped
+    xi = x.clone().requires_grad_(True)
+    _, h1 = a.forward_fork(xi * 1.0)
+    (h1 * w).sum().backward()
+    assert torch.equal(xi.grad, w)
+    # without autograd (evaluation) nothing is forked
+    with torch.no_grad():
+        y, h = a.forward_fork(x)
+    assert h is x and y.shape == (2, 7, 24, 44)
 
 
 @pytest.mark.gpu

@@ -69,6 +69,11 @@ def test_icp_step_recovers_known_motion(hip):
     assert float((res_t + (R.transpose(1, 2) @ t[..., None]).squeeze(-1)).abs().max()) < 1e-4
     moved = hip.transform_points(tgt, res_r, res_t)
     assert float((moved - p).abs().max()) < 1e-3
+    # first=True: the kernel starts from the identity itself -- same bits as the filled start, whatever the buffers held
+    fr = torch.full((2, 3, 3), float("nan"), device="cuda")
+    ft = torch.full((2, 3), float("nan"), device="cuda")
+    hip.icp_step(p.contiguous(), n.contiguous(), tgt, idx, dist, thr, fr, ft, first=True)
+    assert torch.equal(fr, res_r) and torch.equal(ft, res_t)
 
 
 def test_bev_head_gpu_matches_reference(hip):
