@@ -234,11 +234,22 @@ __global__ __launch_bounds__(RB_THREADS) void k_resid_bwd(const float *__restric
                                                           int N, int M, float reg, float *__restrict__ gp1,
                                                           float *__restrict__ gtgt, float *__restrict__ gcov1,
                                                           float *__restrict__ gcov2, float *__restrict__ contrib,
-                                                          unsigned long long *__restrict__ keys) {
+                                                          unsigned long long *__restrict__ keys, int *__restrict__ n_long) {
   const int b = blockIdx.y;
   const int i = blockIdx.x * RB_THREADS + threadIdx.x;
   const int lane = threadIdx.x;                      // RB_THREADS == 64: one wave per block
   const bool in_range = i < N;
+  if (keys) {
+    // ORDERED mode: the partner rows no source reaches stay zero and the long-run counter starts at zero -- written here (the
+    // grid covers max(N, M) rows), not by three fill launches in front of this kernel; the gather kernels run behind it
+    if (i < M) {
+      float *gt = gtgt + ((int64_t)b * M + i) * 3, *g2 = gcov2 + ((int64_t)b * M + i) * 7;
+      gt[0] = gt[1] = gt[2] = 0.f;
+#pragma unroll
+      for (int k = 0; k < 7; ++k) g2[k] = 0.f;
+    }
+    if (b == 0 && i == 0) *n_long = 0;
+  }
   const bool roi = in_range && (dist[(int64_t)b * N + i] < thr[b]);
   // values this lane scatter-adds to its partner row j: 3 (target point) + 7 (target covariance parameters)
   float sc[10];
@@ -381,7 +392,9 @@ __global__ __launch_bounds__(256) void k_resid_gather(const unsigned long long *
   for (int q = 0; q < 7; ++q) g2[q] = acc[3 + q];
 }
 
-// one wave per long run: lane l adds elements l, l + 64, ... in order, then the 64 lane sums are added in a fixed tree
+// one wave per long run: lane l adds elements l, l + 64, ... in order, then the 64 lane sums are added in a fixed tree.
+// (Four waves per run measured 34 -> ~15 us on the bench's random-init state, where a few partners collect thousands of
+// sources -- not kept: another summation order is another weight trajectory, and the parity tests pin this one.)
 __global__ __launch_bounds__(64) void k_resid_gather_long(const unsigned long long *__restrict__ skeys, int64_t n,
                                                           const float *__restrict__ contrib, float *__restrict__ gtgt,
                                                           float *__restrict__ gcov2, const int *__restrict__ n_long,
@@ -439,12 +452,12 @@ extern "C" int rslo_cov_residual_bwd(const float *p1, const float *tgt, const fl
                                               float *gcov1, float *gcov2, void *ws, size_t ws_bytes, void *stream) {
   hipStream_t st = (hipStream_t)stream;
   if (B == 0) return RSLO_OK;
-  RSLO_HIP(hipMemsetAsync(gtgt, 0, (size_t)B * M * 3 * sizeof(float), st));
-  RSLO_HIP(hipMemsetAsync(gcov2, 0, (size_t)B * M * 7 * sizeof(float), st));
   if (!rslo_tune(RSLO_TUNE_RESID_BWD_ORDERED)) {      // A/B only: per-run atomics, a different result every run
+    RSLO_HIP(hipMemsetAsync(gtgt, 0, (size_t)B * M * 3 * sizeof(float), st));
+    RSLO_HIP(hipMemsetAsync(gcov2, 0, (size_t)B * M * 7 * sizeof(float), st));
     hipLaunchKernelGGL(k_resid_bwd, dim3((unsigned)rslo_cdiv(N, RB_THREADS), B), dim3(RB_THREADS), 0, st, p1, tgt, cov1,
                        cov2, idx, dist, thr, Rd, gloss, cnt, N, M, reg_weight, gp1, gtgt, gcov1, gcov2, (float *)nullptr,
-                       (unsigned long long *)nullptr);
+                       (unsigned long long *)nullptr, (int *)nullptr);
     RSLO_CHECK_LAUNCH("cov_residual_bwd");
     return RSLO_OK;
   }
@@ -460,9 +473,9 @@ extern "C" int rslo_cov_residual_bwd(const float *p1, const float *tgt, const fl
   int64_t *long_list = (int64_t *)take((size_t)(n / RB_SHORT + 2) * 8);
   int *n_long = (int *)take(256);
   size_t tmp = resid_sort_tmp_bytes(n, bits);
-  RSLO_HIP(hipMemsetAsync(n_long, 0, sizeof(int), st));
-  hipLaunchKernelGGL(k_resid_bwd, dim3((unsigned)rslo_cdiv(N, RB_THREADS), B), dim3(RB_THREADS), 0, st, p1, tgt, cov1, cov2,
-                     idx, dist, thr, Rd, gloss, cnt, N, M, reg_weight, gp1, gtgt, gcov1, gcov2, contrib, keys);
+  hipLaunchKernelGGL(k_resid_bwd, dim3((unsigned)rslo_cdiv(N > M ? N : M, RB_THREADS), B), dim3(RB_THREADS), 0, st, p1, tgt,
+                     cov1, cov2, idx, dist, thr, Rd, gloss, cnt, N, M, reg_weight, gp1, gtgt, gcov1, gcov2, contrib, keys,
+                     n_long);
   RSLO_CHECK_LAUNCH("cov_residual_bwd");
   // The keys are written in source order (key p belongs to source row p), and the radix sort is stable: sorting on the
   // partner half alone leaves every partner's run in ascending source order -- the order the full 49-bit sort gives, in 3
@@ -866,10 +879,14 @@ __global__ __launch_bounds__(TR_THREADS) void k_transform_rows_bwd(const float *
 
 __global__ void k_transform_rows_bwd_finish(const double *__restrict__ part, int nblk, float *__restrict__ dR,
                                             float *__restrict__ dt) {
+  // (the partials come in through LDS with all loads in flight; the sums keep their block order: deterministic)
+  __shared__ double sh[TR_MAXBLK * 12];
   const int b = blockIdx.x, k = threadIdx.x;
+  for (int e = threadIdx.x; e < nblk * 12; e += blockDim.x) sh[e] = part[(int64_t)b * nblk * 12 + e];
+  __syncthreads();
   if (k >= 12) return;
   double v = 0.0;
-  for (int i = 0; i < nblk; ++i) v += part[((int64_t)b * nblk + i) * 12 + k];      // block order: deterministic
+  for (int i = 0; i < nblk; ++i) v += sh[i * 12 + k];
   if (k < 9)
     dR[b * 9 + k] = (float)v;
   else

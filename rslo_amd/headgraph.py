@@ -89,6 +89,7 @@ class _HeadGraphFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, hg, base):
         ctx.hg = hg
+        ctx.set_materialize_grads(False)     # outputs the loss does not differentiate arrive as None, not as zero-filled maps
         if base.data_ptr() != hg.static_in.data_ptr():
             hg.input_writer.copy_(base)
         if hg.n_fwd_exchanges:       # multi-rank SyncBN inside the capture: this replay's exchange numbers (rslo_amd/peer.py)
@@ -105,14 +106,19 @@ class _HeadGraphFn(torch.autograd.Function):
             # the autograd graph the captured forward built -- retained, its saved tensors are the static buffers the replay
             # has just refilled
             from rslo_amd import streams
-            gs = [g if g is not None else hg.zero_gout(k) for k, g in enumerate(gouts)]
+            # only the outputs the loss differentiates are roots of the nested pass: a zero stand-in for an unused one (the
+            # confidence maps returned for logging) is ADDED to the real gradient of the same tensor by the engine
+            live = [k for k, g in enumerate(gouts) if g is not None]
+            if not live:
+                return None, None
+            roots, gs = [hg.raw_req[k] for k in live], [gouts[k] for k in live]
             if hg.on_callers_stream:
                 with streams.join_in_enclosing_pass():
-                    grads = torch.autograd.grad(hg.raw_req, [hg.static_in] + hg.aliases, gs, retain_graph=True, allow_unused=True)
+                    grads = torch.autograd.grad(roots, [hg.static_in] + hg.aliases, gs, retain_graph=True, allow_unused=True)
             else:       # captured on a side stream (the caller sits on the legacy default stream): the nodes run there and the
                 prev, streams.ENABLED = streams.ENABLED, False      # engine orders that stream against the caller's at the end of
                 try:                                                # the nested pass -- which only covers work issued ON it
-                    grads = torch.autograd.grad(hg.raw_req, [hg.static_in] + hg.aliases, gs, retain_graph=True, allow_unused=True)
+                    grads = torch.autograd.grad(roots, [hg.static_in] + hg.aliases, gs, retain_graph=True, allow_unused=True)
                 finally:
                     streams.ENABLED = prev
             # The alias leaves never carry a gradient, so streams.leaf() always took the side stream for them; an ADD into a
@@ -204,7 +210,6 @@ class HeadGraph:
             self.spec = _flatten(out, self.flat)
             self.req = [i for i, t in enumerate(self.flat) if t.requires_grad]
             self.raw_req = [self.flat[i] for i in self.req]
-            self._zero_gouts = {}
             if mode == "full":
                 self.gouts = [torch.zeros_like(self.flat[i]) for i in self.req]
                 self.gout_zero = [True] * len(self.req)
@@ -224,12 +229,6 @@ class HeadGraph:
         self.flat = [t.detach() for t in self.flat]
         self.device = dev
         self.awaiting, self._node = False, None
-
-    def zero_gout(self, k):
-        z = self._zero_gouts.get(k)
-        if z is None:
-            z = self._zero_gouts[k] = torch.zeros_like(self.flat[self.req[k]])
-        return z
 
     @staticmethod
     def replay(g, name):

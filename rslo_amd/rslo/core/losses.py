@@ -115,13 +115,19 @@ class _LossTailFn(torch.autograd.Function):
         out = capi.loss_tail_fwd(_LossTailFn._desc(t_pred, q_pred, pyr, pair, alphas, meta), t_pred.device)
         ctx.save_for_backward(t_pred, q_pred, pyr, pair, *alphas, meta["t_tgt"], meta["q_tgt"])
         ctx.meta = meta
-        return out
+        # the total as an output of its own ([1], over out's first element): its gradient arrives as it is -- sliced out of
+        # `out` by the caller, the slice's backward is a zero fill of [5] plus a copy in front of this node's backward
+        ctx.mark_non_differentiable(out)
+        ctx.set_materialize_grads(False)
+        return out[0:1], out
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, _g_terms):
         t_pred, q_pred, pyr, pair, aT, aR, apT, apR, aC, _, _ = ctx.saved_tensors
+        if g is None:
+            return (None,) * 10
         desc = _LossTailFn._desc(t_pred, q_pred, pyr, pair, (aT, aR, apT, apR, aC), ctx.meta)
-        d_t, d_q, d_pyr, d_pair, d_a = capi.loss_tail_bwd(desc, g[0:1].contiguous(), desc.B, desc.L, desc.n_pairs)
+        d_t, d_q, d_pyr, d_pair, d_a = capi.loss_tail_bwd(desc, g.reshape(1).contiguous(), desc.B, desc.L, desc.n_pairs)
         need = ctx.needs_input_grad
         # a module used for several terms: the kernel has added its entries into the first one (in entry order, as the
         # engine would); the later ones return nothing, so no accumulation launches follow
@@ -131,7 +137,8 @@ class _LossTailFn(torch.autograd.Function):
 
 
 def loss_tail(raw, level_w):
-    """raw: the ingredients create_loss(..., raw_tail=True) returns -> the [5] tensor (total, T, R, pyramid, C)."""
+    """raw: the ingredients create_loss(..., raw_tail=True) returns -> (total [1], differentiable; the [5] tensor
+    (total, T, R, pyramid, C), values only)."""
     meta = {"t_tgt": raw["t_tgt"].detach().contiguous().float(), "q_tgt": raw["q_tgt"].detach().contiguous().float(),
             "w": tuple(float(v) for v in raw["w"]), "level_w": [float(v) for v in level_w]}
     return _LossTailFn.apply(raw["t_pred"], raw["q_pred"], raw["pyr_loss_b"], raw["pair_loss"], *raw["alphas"], meta)
@@ -163,11 +170,14 @@ class _PairRowsFn(torch.autograd.Function):
         ctx.n = conf.shape[0]
         xyz, nrm, cov = capi.pair_rows_fwd(feats.contiguous(), conf.contiguous(), off, length, Lmax)
         ctx.mark_non_differentiable(xyz, nrm)
+        ctx.set_materialize_grads(False)      # no zero-filled stand-ins for the two outputs nobody differentiates
         return xyz, nrm, cov
 
     @staticmethod
     def backward(ctx, _gx, _gn, g):
         off, length = ctx.saved_tensors
+        if g is None:
+            return None, None, None, None, None
         return None, capi.pad_rows_bwd(g.contiguous(), off, length, ctx.n), None, None, None
 
 

@@ -478,10 +478,9 @@ class UnVoxelOdomNetICP3(nn.Module):
             raw_tail=self.fused_loss_tail)
         if isinstance(res, dict):       # the partial losses: reductions, loss weights and the total in ONE launch
             n = res["pyr_loss_b"].shape[0] if res["pyr_loss_b"] is not None else 0
-            out = losses.loss_tail(res, [self._pyloss_exp_w_base ** (n - i) for i in range(n)])
+            total, terms = losses.loss_tail(res, [self._pyloss_exp_w_base ** (n - i) for i in range(n)])
             self.end_timer("create_loss forward")
-            terms = out.detach()
-            return {"loss": out[0:1], "translation_loss": terms[1:2], "rotation_loss": terms[2:3],
+            return {"loss": total, "translation_loss": terms[1:2], "rotation_loss": terms[2:3],
                     "pyramid_loss": terms[3:4], "C_loss": terms[4:5],
                     "translation_preds": T_preds[0].detach(), "rotation_preds": R_preds[0].detach()}
         t_loss, r_loss, py_T, py_R, C_loss = res

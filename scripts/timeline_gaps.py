@@ -60,3 +60,22 @@ for s, e, n, q, g in sel:
         a[0] += 1; a[1] += (e - s) / 1e3; a[2] = max(a[2], g)
 for n, (c, t, g) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     print("   %3d x %7.1f us avg (<= %3d wg)  %s" % (c, t / c, g, n))
+
+# SEG_FROM / SEG_TO (kernel-name prefixes): every launch of the training queue between the first SEG_FROM and the first
+# SEG_TO after it -- start offset, duration, gap to the previous launch (the serial stretch between the head's forward and the
+# backward pass is SEG_FROM=k_pair_rows_fwd SEG_TO=k_head_masks_bwd)
+import os
+if os.environ.get("SEG_FROM"):
+    fr, to = os.environ["SEG_FROM"], os.environ.get("SEG_TO", "")
+    mainq = max(byq.items(), key=lambda kv: len(kv[1]))[0]
+    rs = byq[mainq]
+    i0 = next((i for i, r in enumerate(rs) if r[2].startswith(fr)), None)
+    if i0 is not None:
+        i1 = next((i for i in range(i0 + 1, len(rs)) if to and rs[i][2].startswith(to)), len(rs) - 1)
+        base, busy, prev_end = rs[i0][0], 0, rs[i0][0]
+        print("== training queue from %s to %s: %d launches" % (fr, to, i1 - i0 + 1))
+        for s, e, n, _, g in rs[i0:i1 + 1]:
+            print("   +%8.1f us  %7.1f us  gap %6.1f  wg %6d  %s" % ((s - base) / 1e3, (e - s) / 1e3, (s - prev_end) / 1e3, g, n[:70]))
+            busy += e - s
+            prev_end = e
+        print("   span %.1f us, busy %.1f us" % ((rs[i1][1] - base) / 1e3, busy / 1e3))

@@ -35,7 +35,8 @@ def step():
     net.update_global_step()
 for _ in range(6): step()
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True,
+shapes = os.environ.get("RSLO_SITES_SHAPES") == "1"      # also print the operand shapes of every launch
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=shapes,
              experimental_config=torch._C._profiler._ExperimentalConfig(verbose=True)) as prof:
     step(); torch.cuda.synchronize()
 NATIVE = ("at::native", "__amd_rocclr", "Cijk_", "igemm", "batched_transpose", "void at::")
@@ -59,9 +60,9 @@ for e in prof.events():
         while q.cpu_parent is not None: q = q.cpu_parent
         site = "<bwd> " + q.name
     s = sites[site]
-    s[0] += len(ks); s[1] += sum(k.duration for k in ks); s[2][e.name] += len(ks)
+    s[0] += len(ks); s[1] += sum(k.duration for k in ks); s[2][e.name + (" " + str(e.input_shapes) if shapes else "")] += len(ks)
     total += len(ks)
 print("torch-native launches in one step:", total)
 for site, (n, us, ops) in sorted(sites.items(), key=lambda kv: -kv[1][0]):
-    print("%4d %8.1f us  %-80s %s" % (n, us, site[:80], dict(ops.most_common(4))))
+    print("%4d %8.1f us  %-80s %s" % (n, us, site[:80], dict(ops.most_common(12 if shapes else 4))))
 if prefetch is not None: prefetch.close()
