@@ -173,14 +173,6 @@ class ConvProbe:
         self._orig = {}
 
     @staticmethod
-    def _tune(name, default):
-        try:
-            from rslo_amd import capi
-            return capi.tuning_get(name)
-        except Exception:
-            return default
-
-    @staticmethod
     def kernel_name(cin_op, cout_op, n_out, trans, split=False, bf16=False):
         """The template instantiation the entry point dispatches to (rslo_amd/csrc/spconv.hip)."""
         t = "true" if trans else "false"
@@ -188,14 +180,13 @@ class ConvProbe:
         if bf16:
             return "k_spconv_bf16<%d, %d, %d, %d>" % (cin_op, cout_op, rbw, 1 if (cin_op == 32 and cout_op == 32) else 2)
         if split:      # rslo_spconv_fwd_split: two waves per 32-row tile except for 32 -> 32; dead 16-row blocks skipped
-            ks = 1 if (cin_op == 32 and cout_op == 32) else 2      # (switch spconv_skip, on by default: round 6)
+            ks = 1 if (cin_op == 32 and cout_op == 32) else 2
             if n_out < 20000:                                      # the small-problem tiling: 16-row tiles, four waves
                 return "k_spconv_v6<%d, %d, 1, 4, false>" % (cin_op, cout_op)
             rb = 2 if ks == 2 else rbw
             if rb == 1:
                 return "k_spconv_v6<%d, %d, 1, 4, false>" % (cin_op, cout_op)
-            skip = ConvProbe._tune("spconv_skip", 1) != 0
-            return "k_spconv_v6<%d, %d, 2, %d, %s>" % (cin_op, cout_op, ks, "true" if skip else "false")
+            return "k_spconv_v6<%d, %d, 2, %d, true>" % (cin_op, cout_op, ks)
         if cin_op % 16 == 0 and cout_op % 16 == 0:
             return "k_spconv_v3<%d, %d, %d, %s>" % (cin_op, cout_op, rbw, t)
         ci = 8 if cin_op <= 8 else (16 if cin_op <= 16 else (32 if cin_op <= 32 else 64))

@@ -163,7 +163,8 @@ RSLO_API void rslo_spconv_set_live_rows(const int32_t *n_live_dev);
  *     calls (process-wide; the defaults are the measured choices).  Names (rslo_tuning_name(i), i = 0 .. until NULL):
  *     conv2d_wgrad_s2_fullres, conv2d_wgrad_nb, conv2d_wgrad_wgs, conv2d_fwd_tr, conv2d_fwd_mtw, conv2d_fwd_occ,
  *     conv2d_fwd_kc, conv2d_fwd_lean, conv2d_fwd_xsc, conv2d_s2_mtw, conv2d_s2_xsc, bn_small_rc, spconv_rbw, spconv_ks,
- *     spconv_v, spconv_wgrad_split, wgrad_xcd, vfe_lds, chamfer, chamfer_segments, conv2d_ablate, resid_bwd_ordered, dense_tiled, conv2d_s2_piped, conv1x1_split (meanings: csrc/rslo_common.h RsloTune).  Every setting
+ *     spconv_v, spconv_wgrad_split, wgrad_xcd, vfe_lds, chamfer, chamfer_segments, dense_tiled, conv1x1_split, conv2d_fwd_wl
+ *     (meanings: csrc/rslo_common.h RsloTune).  Every setting
  *     computes the same products; only tiling, summation grouping and launch geometry change.  Unknown name -> RSLO_EINVAL.
  *     (The reference has no counterpart: spconv / cuDNN pick their algorithms internally.) */
 RSLO_API int rslo_tuning_set(const char *name, int value);
@@ -485,8 +486,8 @@ RSLO_API int rslo_cov_residual_bwd(const float *p1, const float *tgt, const floa
 /*     The gradients that land on the PARTNER rows (gtgt, gcov2: several sources may share a partner) are added in ascending
  *     source order: every source leaves its ten values and the key (partner row, source row), the keys are sorted (radix
  *     sort over B N 64-bit keys) and each partner's run is added by one thread (runs of up to 32 sources) or one wave
- *     (fixed lane assignment + fixed tree) -- bit-reproducible from run to run, where per-run atomics (rounds 1-4; tuning
- *     switch resid_bwd_ordered = 0) made every training step unique.  ws: rslo_cov_residual_bwd_ws_bytes(B, N, M). */
+ *     (fixed lane assignment + fixed tree) -- bit-reproducible from run to run, where per-run atomics (rounds 1-4, deleted in
+ *     round 6) made every training step unique.  ws: rslo_cov_residual_bwd_ws_bytes(B, N, M). */
 RSLO_API size_t rslo_cov_residual_bwd_ws_bytes(int B, int N, int M);
 RSLO_API size_t rslo_icp_ws_bytes(int B, int N);
 RSLO_API int rslo_icp_step(const float *p1, const float *n1, const float *tgt, const int32_t *idx, const float *dist,

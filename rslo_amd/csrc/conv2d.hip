@@ -1000,133 +1000,9 @@ struct Conv2dStrGeom {
   Conv2dStrClass cls[4];
 };
 
-template <int TR, int S_IN, int NCLS, int MTW>
-__global__ __launch_bounds__(256, 2) void k_conv2d_str(const float *__restrict__ in, const unsigned short *__restrict__ Ws,
-                                                       Conv2dStrGeom gm, float *__restrict__ out) {
-  constexpr int NTW = TR / 2, HR = S_IN * (TR - 1) + 3, HC = S_IN * 15 + 3, NPX = HR * HC;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[NPX * C2F_PXB];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int li = lane & 15, g = lane >> 4;
-  const int wm = wid & 1, wn = wid >> 1;
-  int bx, by;
-  if (!conv2d_xcd_tile(gm.xsc, gm.npix, gm.ny, bx, by)) return;
-  const int tx = bx % gm.tiles_x; bx /= gm.tiles_x;
-  const int ty = bx % gm.tiles_y;
-  const int b = bx / gm.tiles_y;
-  const int c0 = tx * 16, r0 = ty * TR;
-  const int64_t HWi = (int64_t)gm.Hi * gm.Wi, HWo = (int64_t)gm.Ho * gm.Wo;
-  const int n_mt = gm.cout / 16;
-  const int mt0 = (by * 2 + wm) * MTW;          // this wave's first 16-channel output block (MTW of them)
-
-  f32x4 acc[NCLS][MTW][NTW];
-#pragma unroll
-  for (int c = 0; c < NCLS; ++c)
-#pragma unroll
-    for (int mt = 0; mt < MTW; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < NTW; ++nt) acc[c][mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  constexpr int NTASK = (NPX * 4 + 255) / 256;
-  const float *tsrc[NTASK];
-  int tdst[NTASK];
-#pragma unroll
-  for (int r = 0; r < NTASK; ++r) {
-    const int task = tid + r * 256;
-    const int o = task / NPX, q = task - o * NPX;
-    const int qy = q / HC, qx = q - qy * HC;
-    const int y = gm.src_stride * (S_IN * r0 + gm.by + qy), x = gm.src_stride * (S_IN * c0 + gm.bx + qx);
-    const bool ok = task < NPX * 4 && y >= 0 && y < gm.Hi && x >= 0 && x < gm.Wi;
-    tsrc[r] = ok ? in + ((int64_t)b * gm.cin + 8 * o) * HWi + (int64_t)y * gm.Wi + x : nullptr;
-    tdst[r] = task < NPX * 4 ? q * C2F_PXB + o * 16 : -1;
-  }
-  float raw[NTASK][8];
-  const int n_chunks = gm.cin / 32;
-#pragma unroll
-  for (int r = 0; r < NTASK; ++r)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) raw[r][j] = tsrc[r] ? tsrc[r][j * HWi] : 0.f;
-  const unsigned short *wbase = Ws + (int64_t)mt0 * 3 * 512 + lane * 8;
-  for (int chunk = 0; chunk < n_chunks; ++chunk) {
-#pragma unroll
-    for (int r = 0; r < NTASK; ++r) {
-      if (tdst[r] >= 0) {
-        const Split3 s = split_masked(raw[r], 0xffu);
-        unsigned char *dst = lds + tdst[r];
-        *(u32x4 *)(dst) = s.h;
-        *(u32x4 *)(dst + 64) = s.m;
-        *(u32x4 *)(dst + 128) = s.l;
-      }
-    }
-    if (chunk + 1 < n_chunks) {
-#pragma unroll
-      for (int r = 0; r < NTASK; ++r)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) raw[r][j] = tsrc[r] ? tsrc[r][((int64_t)(chunk + 1) * 32 + j) * HWi] : 0.f;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < NCLS; ++c) {
-      const Conv2dStrClass &cl = gm.cls[c];
-      for (int iy = 0; iy < cl.ny; ++iy) {
-        for (int ix = 0; ix < cl.nx; ++ix) {
-          u32x4 bh[NTW], bm[NTW], bl[NTW];
-#pragma unroll
-          for (int nt = 0; nt < NTW; ++nt) {
-            const unsigned char *bp = lds + ((S_IN * (wn * NTW + nt) + cl.oy[iy]) * HC + S_IN * li + cl.ox[ix]) * C2F_PXB +
-                                      g * 16;
-            bh[nt] = *(const u32x4 *)(bp);
-            bm[nt] = *(const u32x4 *)(bp + 64);
-            bl[nt] = *(const u32x4 *)(bp + 128);
-          }
-#pragma unroll
-          for (int mt = 0; mt < MTW; ++mt) {
-            const unsigned short *wp = wbase + ((((int64_t)chunk * gm.ntap_w + cl.wt[iy * 3 + ix]) * n_mt + mt) * 3) * 512;
-            const u32x4 ah = *(const u32x4 *)(wp), am = *(const u32x4 *)(wp + 512), al = *(const u32x4 *)(wp + 1024);
-            // six products per block, smallest first
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) acc[c][mt][nt] = MFMA_BF16(al, bh[nt], acc[c][mt][nt]);
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) acc[c][mt][nt] = MFMA_BF16(am, bm[nt], acc[c][mt][nt]);
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) acc[c][mt][nt] = MFMA_BF16(ah, bl[nt], acc[c][mt][nt]);
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) acc[c][mt][nt] = MFMA_BF16(am, bh[nt], acc[c][mt][nt]);
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) acc[c][mt][nt] = MFMA_BF16(ah, bm[nt], acc[c][mt][nt]);
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) acc[c][mt][nt] = MFMA_BF16(ah, bh[nt], acc[c][mt][nt]);
-          }
-        }
-      }
-    }
-    __syncthreads();
-  }
-
-#pragma unroll
-  for (int c = 0; c < NCLS; ++c) {
-    if (c >= gm.cls_out) break;
-    const Conv2dStrClass &cl = gm.cls[c];
-    const int col = c0 + li;
-#pragma unroll
-    for (int mt = 0; mt < MTW; ++mt)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int m = (mt0 + mt) * 16 + 4 * g + j;
-#pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) {
-          const int r = r0 + wn * NTW + nt;
-          if (col < cl.cols && r < cl.rows) {
-            const int64_t o = ((int64_t)b * gm.cout + m) * HWo + (int64_t)(gm.s_out * r + cl.py) * gm.Wo + gm.s_out * col + cl.px;
-            out[o] = gm.res ? acc[c][mt][nt][j] + gm.res[o] : acc[c][mt][nt][j];
-          }
-        }
-      }
-  }
-}
-
 // ---------------------------------------------------------------------------------------------------------------------
-// The same four passes with the tap list known at COMPILE time (round 5).  k_conv2d_str above walks run-time class / tap
-// loops: its weight operands are requested right in front of the MFMAs that consume them (18 exposed L2 round trips per
+// The four passes with the tap list known at COMPILE time (round 5).  The first form of this kernel (k_conv2d_str, rounds 3-5,
+// deleted in round 6: its bits are in tests/golden/kernel_bits.json) walked run-time class / tap loops: its weight operands are requested right in front of the MFMAs that consume them (18 exposed L2 round trips per
 // 32-channel chunk with MTW = 2), its barriers are __syncthreads() (vmcnt(0): the next chunk's values land before anyone
 // passes, so the prefetch overlaps nothing) and the stride-2 taps of the forward read the 208-byte pixel rows at a lane stride
 // of 416 bytes (4 lanes per LDS slot).  Here, per MODE (0 forward 3x3, 1 forward 1x1, 2 data gradient 3x3, 3 data gradient
@@ -1275,7 +1151,7 @@ __global__ __launch_bounds__(256, OCC) void k_conv2d_str2(const float *__restric
       const int c = tp.cls;
 #pragma unroll
       for (int mt = 0; mt < MTW; ++mt) {
-        // six products per block, smallest first (the order of k_conv2d_str)
+        // six products per block, smallest first
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) acc[c][mt][nt] = MFMA_BF16(al[ia][mt], bh[nt], acc[c][mt][nt]);
 #pragma unroll
@@ -1345,10 +1221,8 @@ extern "C" int rslo_conv2d_fwd_s2(const float *in, const void *Ws, int B, int ci
   // halo and its operand split are shared by twice the MFMAs (256 -> 128 at 96x176: 237 -> 218 us, its 1x1: 41 -> 31 us;
   // the smaller stages lose, 44 -> 62 us, and keep 32 channels)
   const int mtw_env = rslo_tune(RSLO_TUNE_CONV2D_S2_MTW);
-  const bool piped = rslo_tune(RSLO_TUNE_CONV2D_S2_PIPED) != 0;      // compile-time tap lists + operand prefetch (k_conv2d_str2)
-  const int64_t wgs32 = (int64_t)B * gm.tiles_x * gm.tiles_y * (cout / 32);
-  // (k_conv2d_str2 holds a chunk's weight operands in registers with ONE block per wave: 96 vs 161 us on that layer)
-  const int mtw = (cout % 64 == 0 && (mtw_env ? mtw_env == 2 : (!piped && wgs32 >= 1024))) ? 2 : 1;
+  // (k_conv2d_str2 holds a chunk's weight operands in registers with ONE block per wave: 96 vs 161 us on that layer; two are opt-in)
+  const int mtw = (cout % 64 == 0 && mtw_env == 2) ? 2 : 1;
   gm.npix = B * gm.tiles_x * gm.tiles_y;
   gm.ny = cout / (32 * mtw);
   gm.xsc = conv2d_xcd_split(RSLO_TUNE_CONV2D_S2_XSC, gm.ny, 6.0 * ksize * ksize * cin * cout, 4.0 * B * cin * H * W * (ksize == 3 ? 1.5 : 0.25));
@@ -1359,18 +1233,14 @@ extern "C" int rslo_conv2d_fwd_s2(const float *in, const void *Ws, int B, int ci
     gm.src_stride = 1; gm.by = gm.bx = -1; c.ny = c.nx = 3;
     for (int i = 0; i < 3; ++i) c.oy[i] = c.ox[i] = i;
     for (int i = 0; i < 9; ++i) c.wt[i] = i;
-    if (piped && mtw == 2) hipLaunchKernelGGL((k_conv2d_str2<0, 2, 2>), grid, dim3(256), 0, st, in, ws, gm, out);
-    else if (piped) hipLaunchKernelGGL((k_conv2d_str2<0, 1, 2>), grid, dim3(256), 0, st, in, ws, gm, out);
-    else if (mtw == 2) hipLaunchKernelGGL((k_conv2d_str<4, 2, 1, 2>), grid, dim3(256), 0, st, in, ws, gm, out);
-    else hipLaunchKernelGGL((k_conv2d_str<4, 2, 1, 1>), grid, dim3(256), 0, st, in, ws, gm, out);
+    if (mtw == 2) hipLaunchKernelGGL((k_conv2d_str2<0, 2, 2>), grid, dim3(256), 0, st, in, ws, gm, out);
+    else hipLaunchKernelGGL((k_conv2d_str2<0, 1, 2>), grid, dim3(256), 0, st, in, ws, gm, out);
   } else {        // out[y][x] = W in[2y][2x]: stage only the sampled pixels
     gm.src_stride = 2; c.ny = c.nx = 1;
-    if (piped && mtw == 2) hipLaunchKernelGGL((k_conv2d_str2<1, 2, 4>), grid, dim3(256), 0, st, in, ws, gm, out);
-    else if (piped) hipLaunchKernelGGL((k_conv2d_str2<1, 1, 4>), grid, dim3(256), 0, st, in, ws, gm, out);
-    else if (mtw == 2) hipLaunchKernelGGL((k_conv2d_str<4, 1, 1, 2>), grid, dim3(256), 0, st, in, ws, gm, out);
-    else hipLaunchKernelGGL((k_conv2d_str<4, 1, 1, 1>), grid, dim3(256), 0, st, in, ws, gm, out);
+    if (mtw == 2) hipLaunchKernelGGL((k_conv2d_str2<1, 2, 4>), grid, dim3(256), 0, st, in, ws, gm, out);
+    else hipLaunchKernelGGL((k_conv2d_str2<1, 1, 4>), grid, dim3(256), 0, st, in, ws, gm, out);
   }
-  RSLO_CHECK_LAUNCH("k_conv2d_str(fwd)");
+  RSLO_CHECK_LAUNCH("k_conv2d_str2(fwd)");
   return RSLO_OK;
 }
 
@@ -1429,17 +1299,14 @@ extern "C" int rslo_conv2d_dgrad_s2_add(const float *dout, const void *Ws, const
   gm.ny = cin / (32 * mtw);
   gm.xsc = conv2d_xcd_split(RSLO_TUNE_CONV2D_S2_XSC, gm.ny, 6.0 * ksize * ksize * cin * cout, 4.0 * B * cout * gm.Hi * gm.Wi * 1.5);
   const dim3 grid = conv2d_xcd_grid(gm.xsc, gm.npix, gm.ny);
-  const bool piped = rslo_tune(RSLO_TUNE_CONV2D_S2_PIPED) != 0;
   hipStream_t st = (hipStream_t)stream;
   const unsigned short *ws = (const unsigned short *)Ws;
-  if (piped && ksize == 3 && mtw == 2) hipLaunchKernelGGL((k_conv2d_str2<2, 2, 2>), grid, dim3(256), 0, st, dout, ws, gm, din);
-  else if (piped && ksize == 3 && wgs32 > 512) hipLaunchKernelGGL((k_conv2d_str2<2, 1, 3, false>), grid, dim3(256), 0, st, dout, ws, gm, din);
-  else if (piped && ksize == 3) hipLaunchKernelGGL((k_conv2d_str2<2, 1, 2, true>), grid, dim3(256), 0, st, dout, ws, gm, din);
-  else if (piped && mtw == 2) hipLaunchKernelGGL((k_conv2d_str2<3, 2, 2>), grid, dim3(256), 0, st, dout, ws, gm, din);
-  else if (piped) hipLaunchKernelGGL((k_conv2d_str2<3, 1, 3>), grid, dim3(256), 0, st, dout, ws, gm, din);
-  else if (mtw == 2) hipLaunchKernelGGL((k_conv2d_str<4, 1, 4, 2>), grid, dim3(256), 0, st, dout, ws, gm, din);
-  else hipLaunchKernelGGL((k_conv2d_str<4, 1, 4, 1>), grid, dim3(256), 0, st, dout, ws, gm, din);
-  RSLO_CHECK_LAUNCH("k_conv2d_str(dgrad)");
+  if (ksize == 3 && mtw == 2) hipLaunchKernelGGL((k_conv2d_str2<2, 2, 2>), grid, dim3(256), 0, st, dout, ws, gm, din);
+  else if (ksize == 3 && wgs32 > 512) hipLaunchKernelGGL((k_conv2d_str2<2, 1, 3, false>), grid, dim3(256), 0, st, dout, ws, gm, din);
+  else if (ksize == 3) hipLaunchKernelGGL((k_conv2d_str2<2, 1, 2, true>), grid, dim3(256), 0, st, dout, ws, gm, din);
+  else if (mtw == 2) hipLaunchKernelGGL((k_conv2d_str2<3, 2, 2>), grid, dim3(256), 0, st, dout, ws, gm, din);
+  else hipLaunchKernelGGL((k_conv2d_str2<3, 1, 3>), grid, dim3(256), 0, st, dout, ws, gm, din);
+  RSLO_CHECK_LAUNCH("k_conv2d_str2(dgrad)");
   return RSLO_OK;
 }
 

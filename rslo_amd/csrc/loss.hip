@@ -239,17 +239,15 @@ __global__ __launch_bounds__(RB_THREADS) void k_resid_bwd(const float *__restric
   const int i = blockIdx.x * RB_THREADS + threadIdx.x;
   const int lane = threadIdx.x;                      // RB_THREADS == 64: one wave per block
   const bool in_range = i < N;
-  if (keys) {
-    // ORDERED mode: the partner rows no source reaches stay zero and the long-run counter starts at zero -- written here (the
-    // grid covers max(N, M) rows), not by three fill launches in front of this kernel; the gather kernels run behind it
-    if (i < M) {
-      float *gt = gtgt + ((int64_t)b * M + i) * 3, *g2 = gcov2 + ((int64_t)b * M + i) * 7;
-      gt[0] = gt[1] = gt[2] = 0.f;
+  // the partner rows no source reaches stay zero and the long-run counter starts at zero -- written here (the grid covers
+  // max(N, M) rows), not by three fill launches in front of this kernel; the gather kernels run behind it
+  if (i < M) {
+    float *gt = gtgt + ((int64_t)b * M + i) * 3, *g2 = gcov2 + ((int64_t)b * M + i) * 7;
+    gt[0] = gt[1] = gt[2] = 0.f;
 #pragma unroll
-      for (int k = 0; k < 7; ++k) g2[k] = 0.f;
-    }
-    if (b == 0 && i == 0) *n_long = 0;
+    for (int k = 0; k < 7; ++k) g2[k] = 0.f;
   }
+  if (b == 0 && i == 0) *n_long = 0;
   const bool roi = in_range && (dist[(int64_t)b * N + i] < thr[b]);
   // values this lane scatter-adds to its partner row j: 3 (target point) + 7 (target covariance parameters)
   float sc[10];
@@ -321,43 +319,14 @@ __global__ __launch_bounds__(RB_THREADS) void k_resid_bwd(const float *__restric
 #pragma unroll
     for (int k = 0; k < 7; ++k) sc[3 + k] = g7[k];
   }
-  if (keys) {
-    // ORDERED mode (default since round 5): nothing is added here.  Every source leaves its ten partner values and the key
-    // (partner row, source row); rslo_cov_residual_bwd sorts the keys and k_resid_gather* add each partner's values in
-    // ascending source order -- the same bits whatever the scheduling (atomics made every training step unique).
-    if (in_range) {
-      float *o = contrib + ((int64_t)b * N + i) * RB_NV;
+  // Nothing is added here.  Every source leaves its ten partner values and the key (partner row, source row);
+  // rslo_cov_residual_bwd sorts the keys and k_resid_gather* add each partner's values in ascending source order -- the same
+  // bits whatever the scheduling (per-run atomics, rounds 1-4, made every training step unique; that path is deleted).
+  if (in_range) {
+    float *o = contrib + ((int64_t)b * N + i) * RB_NV;
 #pragma unroll
-      for (int k = 0; k < 10; ++k) o[k] = sc[k];
-      keys[(int64_t)b * N + i] = roi ? ((((unsigned long long)b * M + j) << RB_SRC_BITS) | ((unsigned long long)b * N + i)) : ~0ull;
-    }
-    return;
-  }
-  // Source points are in scan order, so the sources of one partner mostly sit in consecutive lanes; when the two
-  // clouds overlap badly (early training) thousands of sources share a few partners and per-lane atomics serialise
-  // on those rows.  Each run of equal partners inside the wave is summed with a segmented scan and added once.
-  const int jp = __shfl_up(j, 1, 64);
-  const bool head = lane == 0 || jp != j;
-  const unsigned long long heads = __ballot(head);
-  const int start = 63 - __builtin_clzll(heads & ((2ull << lane) - 1ull));
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-#pragma unroll
-    for (int k = 0; k < 10; ++k) {
-      const float t = __shfl_up(sc[k], d, 64);
-      if (lane - d >= start) sc[k] += t;
-    }
-  }
-  const int jn = __shfl_down(j, 1, 64);
-  const bool tail = lane == 63 || jn != j;
-  if (tail && j >= 0) {
-    float *gt = gtgt + ((int64_t)b * M + j) * 3;
-    atomicAdd(gt + 0, sc[0]);
-    atomicAdd(gt + 1, sc[1]);
-    atomicAdd(gt + 2, sc[2]);
-    float *g2 = gcov2 + ((int64_t)b * M + j) * 7;
-#pragma unroll
-    for (int k = 0; k < 7; ++k) atomicAdd(g2 + k, sc[3 + k]);
+    for (int k = 0; k < 10; ++k) o[k] = sc[k];
+    keys[(int64_t)b * N + i] = roi ? ((((unsigned long long)b * M + j) << RB_SRC_BITS) | ((unsigned long long)b * N + i)) : ~0ull;
   }
 }
 
@@ -452,15 +421,6 @@ extern "C" int rslo_cov_residual_bwd(const float *p1, const float *tgt, const fl
                                               float *gcov1, float *gcov2, void *ws, size_t ws_bytes, void *stream) {
   hipStream_t st = (hipStream_t)stream;
   if (B == 0) return RSLO_OK;
-  if (!rslo_tune(RSLO_TUNE_RESID_BWD_ORDERED)) {      // A/B only: per-run atomics, a different result every run
-    RSLO_HIP(hipMemsetAsync(gtgt, 0, (size_t)B * M * 3 * sizeof(float), st));
-    RSLO_HIP(hipMemsetAsync(gcov2, 0, (size_t)B * M * 7 * sizeof(float), st));
-    hipLaunchKernelGGL(k_resid_bwd, dim3((unsigned)rslo_cdiv(N, RB_THREADS), B), dim3(RB_THREADS), 0, st, p1, tgt, cov1,
-                       cov2, idx, dist, thr, Rd, gloss, cnt, N, M, reg_weight, gp1, gtgt, gcov1, gcov2, (float *)nullptr,
-                       (unsigned long long *)nullptr, (int *)nullptr);
-    RSLO_CHECK_LAUNCH("cov_residual_bwd");
-    return RSLO_OK;
-  }
   const int64_t n = (int64_t)B * N;
   RSLO_CHECK_ARG(n < (1ll << 31) && (int64_t)B * M < (1ll << 31), "cov_residual_bwd: more than 2^31 rows");
   RSLO_CHECK_ARG(ws && ws_bytes >= rslo_cov_residual_bwd_ws_bytes(B, N, M), "cov_residual_bwd: workspace too small");

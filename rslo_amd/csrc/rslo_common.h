@@ -62,13 +62,9 @@ enum RsloTune {
   RSLO_TUNE_VFE_LDS,                   // 1: LDS-staged VFE mean; 0: one thread per voxel from memory
   RSLO_TUNE_CHAMFER,                   // 0: choose by size; 1: exhaustive; 2: pruned grid search
   RSLO_TUNE_CHAMFER_SEGMENTS,          // pruned search: target segments per query wave (0 = choose; 1..8)
-  RSLO_TUNE_CONV2D_ABLATE,             // experiments only (wrong results): bit 0 every weight fetch reads chunk 0 / tap 0, bit 1 every chunk stages chunk 0
-  RSLO_TUNE_RESID_BWD_ORDERED,         // 1 (default): partner gradients of the covariance residual added in source order (bit-reproducible); 0: atomics
   RSLO_TUNE_DENSE_TILED,               // 1 (default): dense() scatter / gather through 64 x 64 LDS tiles; 0: one thread per element
-  RSLO_TUNE_CONV2D_S2_PIPED,           // 1 (default): stride-2 kernels with compile-time tap lists and operands one tap ahead (k_conv2d_str2); 0: k_conv2d_str
   RSLO_TUNE_CONV1X1_SPLIT,             // 1 (default): 1x1 output convolutions (cin <= 64) with a pixel's channels dealt to four waves; 0: one thread per pixel
   RSLO_TUNE_CONV2D_FWD_WL,             // dense 3x3 stride-1 forward / data gradient with the weight operands through LDS (k_conv2d_wl, measured slower): 0 (default) never; 1: 8-row tiles; 3: 6-row tiles
-  RSLO_TUNE_SPCONV_SKIP,               // k_spconv_v6 (32-row tiles): a 16-row block none of whose rows has the offset is skipped (same bits): 1 (default) on, 0 off
   RSLO_TUNE_COUNT
 };
 extern int g_rslo_tune[RSLO_TUNE_COUNT];

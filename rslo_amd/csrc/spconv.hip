@@ -455,7 +455,7 @@ __device__ __forceinline__ Split8 split8(const float4 a, const float4 b, bool ok
 // 3 or 4 waves from start to end, the kernel's time is the gather latency chain of the SIMDs that got 4, and nothing
 // else is in flight to hide it.  Half-length chains in twice as many waves put 6.2 waves on a SIMD (quantisation 6.2 vs
 // 7 instead of 3.1 vs 4) at the same weight and row traffic per product.
-// SKIPB (round 6 experiment, switch spconv_skip): a 16-row block none of whose rows has the offset is skipped -- no gather, no
+// SKIPB (round 6; always on for 32-row tiles): a 16-row block none of whose rows has the offset is skipped -- no gather, no
 // split, no MFMAs for it (the tile's offset union is what the loop walks; 30 % of the issued products are such padding on C3,
 // 42 % on C5).  A lone live block interleaves the accumulators of two column blocks instead of two row blocks.  A row's sum
 // keeps its order (offsets ascending, the same six products): same bits.
@@ -980,8 +980,8 @@ extern "C" int rslo_spconv_fwd_split(const float *in, int cin, const void *Ws, c
                      dim3(SPC_THREADS), 0, st, in, ws, bias, nbr, row_order, n_out, K, flip_k, act_slope, out, live)
   // measured (profiles/r06_spconv_skip.txt, 8 frames, us without | with, the skipping kernel compiled for 4 waves per SIMD like the
   // other one): 64 -> 64 level 2 155.3 | 152.6, level 3 70.7 | 67.5, strided 64 -> 64 72.4 | 66.5, inverse 64 -> 64 94.2 | 84.3,
-  // inverse 64 -> 32 96.0 | 93.3, 32 -> 32 71.2 | 68.4, strided 32 -> 64 66.7 | 62.0: on by default (-1 / 1), 0 = off
-  const bool skipb = rslo_tune(RSLO_TUNE_SPCONV_SKIP) != 0;
+  // inverse 64 -> 32 96.0 | 93.3, 32 -> 32 71.2 | 68.4, strided 32 -> 64 66.7 | 62.0.  The 32-row kernels without the skip are
+  // deleted (their bits: tests/golden/kernel_bits.json).
   // tilings kept: 32-row tiles by two waves or one, 16-row tiles by four waves (the small-problem tiling).  The other
   // combinations of (row blocks, waves) were measured and closed in rounds 2-5 (profiles/NOTES.md): (4,1) / (4,2) / (4,4)
   // register-bound, (2,4) / (1,2) / (1,1) never ahead; a forced value outside the kept set takes the nearest kept one.
@@ -990,10 +990,8 @@ extern "C" int rslo_spconv_fwd_split(const float *in, int cin, const void *Ws, c
   if (rbw == 1) ks = 4;
 #define SPC6_CASE(CI, CO)                                                                                    \
   if (cin == CI && cout == CO) {                                                                             \
-    if (rbw == 2 && ks == 2 && skipb) SPC6_LAUNCH_SKIP(CI, CO, 2);                                           \
-    else if (rbw == 2 && ks == 2) SPC6_LAUNCH(CI, CO, 2, 2);                                                 \
-    else if (rbw == 2 && skipb) SPC6_LAUNCH_SKIP(CI, CO, 1);                                                 \
-    else if (rbw == 2) SPC6_LAUNCH(CI, CO, 2, 1);                                                            \
+    if (rbw == 2 && ks == 2) SPC6_LAUNCH_SKIP(CI, CO, 2);                                                    \
+    else if (rbw == 2) SPC6_LAUNCH_SKIP(CI, CO, 1);                                                          \
     else SPC6_LAUNCH(CI, CO, 1, 4);                                                                          \
   }
   SPC6_CASE(32, 32) SPC6_CASE(32, 64) SPC6_CASE(64, 32) SPC6_CASE(64, 64)

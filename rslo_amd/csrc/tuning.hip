@@ -8,12 +8,14 @@ int g_rslo_tune[RSLO_TUNE_COUNT] = {
     /* conv2d_fwd_tr */ 0, /* conv2d_fwd_mtw */ 0, /* conv2d_fwd_occ */ 0, /* conv2d_fwd_kc */ 0, /* conv2d_fwd_lean */ -1,
     /* conv2d_fwd_xsc */ 0, /* conv2d_s2_mtw */ 0, /* conv2d_s2_xsc */ 0, /* bn_small_rc */ 1,
     /* spconv_rbw */ 0, /* spconv_ks */ 0, /* spconv_v */ 0, /* spconv_wgrad_split */ 1, /* wgrad_xcd */ 1,
-    /* vfe_lds */ 1, /* chamfer */ 0, /* chamfer_segments */ 0, /* conv2d_ablate */ 0, /* resid_bwd_ordered */ 1, /* dense_tiled */ 1, /* conv2d_s2_piped */ 1, /* conv1x1_split */ 1, /* conv2d_fwd_wl */ 0, /* spconv_skip */ 1};
+    /* vfe_lds */ 1, /* chamfer */ 0, /* chamfer_segments */ 0, /* dense_tiled */ 1,
+    /* conv1x1_split */ 1, /* conv2d_fwd_wl */ 0};
 
 static const char *const k_tune_names[RSLO_TUNE_COUNT] = {
     "conv2d_wgrad_s2_fullres", "conv2d_wgrad_nb", "conv2d_wgrad_wgs", "conv2d_fwd_tr", "conv2d_fwd_mtw", "conv2d_fwd_occ",
     "conv2d_fwd_kc", "conv2d_fwd_lean", "conv2d_fwd_xsc", "conv2d_s2_mtw", "conv2d_s2_xsc", "bn_small_rc",
-    "spconv_rbw", "spconv_ks", "spconv_v", "spconv_wgrad_split", "wgrad_xcd", "vfe_lds", "chamfer", "chamfer_segments", "conv2d_ablate", "resid_bwd_ordered", "dense_tiled", "conv2d_s2_piped", "conv1x1_split", "conv2d_fwd_wl", "spconv_skip"};
+    "spconv_rbw", "spconv_ks", "spconv_v", "spconv_wgrad_split", "wgrad_xcd", "vfe_lds", "chamfer", "chamfer_segments", "dense_tiled",
+    "conv1x1_split", "conv2d_fwd_wl"};
 
 static int tune_index(const char *name) {
   if (name)

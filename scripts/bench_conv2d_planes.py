@@ -31,7 +31,6 @@ tun = {}
 if "tr" in cfg: tun["conv2d_fwd_tr"] = int(cfg["tr"])
 if "mtw" in cfg: tun["conv2d_fwd_mtw"] = int(cfg["mtw"])
 if "lean" in cfg: tun["conv2d_fwd_lean"] = int(cfg["lean"])
-if "ablate" in cfg: tun["conv2d_ablate"] = int(cfg["ablate"])
 tot = [0.0, 0.0, 0.0]
 for cnt, cin, cout, H, W in LAYERS:
     x = torch.randn(B, cin, H, W, device="cuda")

@@ -1,5 +1,6 @@
-"""Stride-2 layers of the BEV stages: forward / data gradient of rslo_conv2d_fwd_s2 / _dgrad_s2, k_conv2d_str2 (switch
-conv2d_s2_piped = 1) against k_conv2d_str (0): us per launch back to back (HIP events), B = 4."""
+"""Stride-2 layers of the BEV stages: forward / data gradient of rslo_conv2d_fwd_s2 / _dgrad_s2 (k_conv2d_str2), one and two
+16-channel blocks per wave: us per launch back to back (HIP events), B = 4.  (Round 5 ran it against the run-time-loop kernel
+k_conv2d_str as well -- profiles/r05_*; that kernel is deleted.)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, rslo_amd
@@ -27,10 +28,9 @@ for cin, cout, H, W in [(256, 128, 96, 176), (128, 128, 48, 88), (128, 256, 24, 
         wf, wt = capi.conv2d_wsplit_k(w, False), capi.conv2d_wsplit_k(w, True)
         g = torch.randn(B, cout, (H - 1) // 2 + 1, (W - 1) // 2 + 1, device="cuda")
         row = []
-        for piped in (0, 1):
-            for mtw in (0, 1, 2):
-                with capi.tuning(conv2d_s2_piped=piped, conv2d_s2_mtw=mtw):
-                    row.append("piped=%d mtw=%d: fwd %6.1f dgrad %6.1f" % (
-                        piped, mtw, t(lambda: capi.conv2d_fwd_s2(x, wf, cout, k)), t(lambda: capi.conv2d_dgrad_s2(g, wt, cin, H, W, k))))
+        for mtw in (0, 1, 2):
+            with capi.tuning(conv2d_s2_mtw=mtw):
+                row.append("mtw=%d: fwd %6.1f dgrad %6.1f" % (
+                    mtw, t(lambda: capi.conv2d_fwd_s2(x, wf, cout, k)), t(lambda: capi.conv2d_dgrad_s2(g, wt, cin, H, W, k))))
         gf = 2.0 * B * g.shape[2] * g.shape[3] * cin * cout * k * k * 1e-9
         print("%d->%d @%dx%d k=%d (%.2f GFLOP, six-product floor %.1f us): " % (cin, cout, H, W, k, gf, gf * 6 / 2.5e3) + " | ".join(row))

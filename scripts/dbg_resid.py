@@ -1,4 +1,5 @@
-"""rslo_cov_residual_bwd: ordered (sorted keys, fixed-order sums) twice -> identical bits; vs the atomic form -> rounding only."""
+"""rslo_cov_residual_bwd (sorted keys, fixed-order sums) twice -> identical bits, and its time per call.  (The atomic form it was
+compared with in round 5 is deleted.)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, rslo_amd
@@ -13,8 +14,8 @@ dist = torch.rand(B, N, device="cuda"); thr = torch.full((B,), 0.9, device="cuda
 Rd = torch.eye(3, device="cuda").reshape(1, 9).repeat(B, 1).contiguous()
 gloss = torch.ones(B, device="cuda"); cnt = torch.full((B,), 1000.0, device="cuda")
 outs = []
-for ordered in (1, 1, 0):
-    with capi.tuning(resid_bwd_ordered=ordered):
+for ordered in (1, 1):
+    if True:
         o = capi.cov_residual_bwd(p1, tgt, cov1, cov2, idx, dist, thr, Rd, gloss, cnt, 0.005, need_gp1=True)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -25,5 +26,5 @@ for ordered in (1, 1, 0):
         print("ordered=%d: %.1f us per call" % (ordered, e0.elapsed_time(e1) / 20 * 1e3))
         outs.append(o)
 for k, name in enumerate(("gp1", "gtgt", "gcov1", "gcov2")):
-    a, b, c = outs[0][k], outs[1][k], outs[2][k]
-    print(name, "ordered twice identical:", torch.equal(a, b), " vs atomic: max diff %.2e of %.2e" % (float((a - c).abs().max()), float(c.abs().max())))
+    a, b = outs[0][k], outs[1][k]
+    print(name, "twice identical:", torch.equal(a, b))

@@ -1221,11 +1221,8 @@ def test_conv2d_stride2_fwd_and_dgrad_match_float64_oracle(hip, B, cin, cout, H,
     assert torch.equal(joined, res.clone().add_(dx))
     if k == 1:      # in place: only the pixels (2y, 2x) of the residual are read and written, same bits
         buf = res.clone()
-        for piped in (1, 0):
-            with hip.tuning(conv2d_s2_piped=piped):
-                out = hip.conv2d_dgrad_s2(dev(g), hip.conv2d_wsplit_k(dev(w), True), cin, H, W, k, residual=buf, inplace=True)
-            assert out.data_ptr() == buf.data_ptr() and torch.equal(out, joined)
-            buf = res.clone()
+        out = hip.conv2d_dgrad_s2(dev(g), hip.conv2d_wsplit_k(dev(w), True), cin, H, W, k, residual=buf, inplace=True)
+        assert out.data_ptr() == buf.data_ptr() and torch.equal(out, joined)
 
 
 def test_hip_conv2d_stride2_layers_match_library_through_autograd(hip):
@@ -1558,13 +1555,12 @@ def test_eval_batchnorm1d_with_activation_in_one_launch(hip):
         assert torch.equal(y2[:n // 2], y[:n // 2])
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("cin,cout", [(32, 32), (64, 64), (32, 64), (64, 32)])
-def test_spconv_dead_row_block_skip_keeps_the_bits(hip, cin, cout):
-    """Switch spconv_skip (round 6): k_spconv_v6 on 32-row tiles skips a 16-row block none of whose rows has the offset.  A
-    row's sum keeps its order: forward (bias + LeakyReLU) and the data gradient through the transposed operand are equal bit
-    for bit with the kernel that always computes both blocks -- on a table with whole missing blocks, isolated rows, a
-    ragged last tile, one and two waves per tile."""
+SPCONV_SKIP_CASES = [(32, 32), (64, 64), (32, 64), (64, 32)]
+
+
+def spconv_skip_case(hip, cin, cout, ks):
+    """k_spconv_v6 forward (bias + LeakyReLU) on 32-row tiles, `ks` waves per tile, over a seeded table with whole missing
+    16-row blocks, isolated rows and a ragged last tile."""
     g = torch.Generator().manual_seed(5)
     n_in, n_out, K = 5000, 4133, 27
     nbr = torch.randint(0, n_in, (n_out, K), generator=g, dtype=torch.int32)
@@ -1576,12 +1572,21 @@ def test_spconv_dead_row_block_skip_keeps_the_bits(hip, cin, cout):
     x = torch.randn(n_in, cin, generator=g).cuda()
     W = (torch.randn(K, cin, cout, generator=g) * 0.1).cuda()
     bias = torch.randn(cout, generator=g).cuda()
+    with hip.tuning(spconv_rbw=2, spconv_ks=ks):
+        return hip.spconv_fwd(x, W, bias, nbr, act_slope=0.01).clone()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout", SPCONV_SKIP_CASES)
+def test_spconv_dead_row_block_skip_keeps_the_recorded_bits(hip, cin, cout):
+    """k_spconv_v6 on 32-row tiles skips a 16-row block none of whose rows has the offset (round 6).  A row's sum keeps its
+    order: the result equals, bit for bit, what the kernel that always computed both blocks gave -- on a table with whole missing
+    blocks, isolated rows, a ragged last tile, one and two waves per tile.  That kernel is deleted; its bits are in
+    tests/golden/kernel_bits.json (written by tests/golden/make_golden_kernel_bits.py while both forms existed and agreed)."""
+    gold = kernel_bits()
     for ks in (1, 2):
-        with hip.tuning(spconv_rbw=2, spconv_ks=ks, spconv_skip=0):
-            ref = hip.spconv_fwd(x, W, bias, nbr, act_slope=0.01).clone()
-        with hip.tuning(spconv_rbw=2, spconv_ks=ks, spconv_skip=1):
-            got = hip.spconv_fwd(x, W, bias, nbr, act_slope=0.01)
-        assert torch.equal(ref, got), ks
+        key = "spconv_skip/%d_%d/ks%d" % (cin, cout, ks)
+        assert tensor_bits(spconv_skip_case(hip, cin, cout, ks)) == gold[key], key
 
 
 @pytest.mark.gpu
@@ -1635,31 +1640,53 @@ def test_conv2d_stride2_xcd_orders_keep_the_bits(hip, B, cin, cout, H, W, k):
                 assert torch.equal(a, b), xsc
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("B,cin,cout,H,W,k", [(4, 128, 128, 48, 88, 3), (2, 64, 128, 21, 37, 3), (4, 128, 256, 24, 44, 1),
-                                               (1, 256, 128, 96, 176, 3), (1, 32, 64, 13, 21, 1), (2, 64, 64, 5, 3, 3)])
-def test_conv2d_stride2_pipelined_kernels_keep_the_bits(hip, B, cin, cout, H, W, k):
-    """k_conv2d_str2 (compile-time tap lists, operands one tap ahead, parity-ordered halo columns; switch conv2d_s2_piped)
-    forms the same products in the same order as k_conv2d_str: forward and data gradient (with and without the joined
-    residual), one and two 16-channel blocks per wave, ragged maps."""
+def tensor_bits(*tensors):
+    """sha256 over the bytes of the tensors: what tests/golden/kernel_bits.json records."""
+    import hashlib
+    h = hashlib.sha256()
+    for t in tensors:
+        h.update(t.detach().cpu().contiguous().numpy().tobytes())
+    return h.hexdigest()
+
+
+def kernel_bits():
+    import json
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kernel_bits.json")) as f:
+        return json.load(f)
+
+
+CONV2D_S2_CASES = [(4, 128, 128, 48, 88, 3), (2, 64, 128, 21, 37, 3), (4, 128, 256, 24, 44, 1),
+                   (1, 256, 128, 96, 176, 3), (1, 32, 64, 13, 21, 1), (2, 64, 64, 5, 3, 3)]
+
+
+def conv2d_s2_case(hip, B, cin, cout, H, W, k, mtw):
+    """Forward, data gradient and data gradient with the joined residual of one stride-2 layer on seeded operands, `mtw`
+    16-channel blocks per wave -> the three tensors."""
     torch.manual_seed(8)
     x = torch.randn(B, cin, H, W, device="cuda")
     g = torch.randn(B, cout, (H - 1) // 2 + 1, (W - 1) // 2 + 1, device="cuda")
     res = torch.randn(B, cin, H, W, device="cuda")
     w = torch.randn(cout, cin, k, k, device="cuda") / (k * cin ** 0.5)
     ws, wst = hip.conv2d_wsplit_k(w, False), hip.conv2d_wsplit_k(w, True)
-
-    def run():
+    with hip.tuning(conv2d_s2_mtw=mtw):
         return [hip.conv2d_fwd_s2(x, ws, cout, k).clone(), hip.conv2d_dgrad_s2(g, wst, cin, H, W, k).clone(),
                 hip.conv2d_dgrad_s2(g, wst, cin, H, W, k, residual=res).clone()]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,cin,cout,H,W,k", CONV2D_S2_CASES)
+def test_conv2d_stride2_kernels_keep_the_recorded_bits(hip, B, cin, cout, H, W, k):
+    """k_conv2d_str2 (compile-time tap lists, operands one tap ahead, parity-ordered halo columns) forms the same products in the
+    same order as its run-time-loop predecessor k_conv2d_str did: forward and data gradient (with and without the joined
+    residual), one and two 16-channel blocks per wave, ragged maps.  Until round 6 this test ran both kernels; k_conv2d_str is
+    deleted, its bits are in tests/golden/kernel_bits.json (written by tests/golden/make_golden_kernel_bits.py while both
+    kernels existed and agreed)."""
+    gold = kernel_bits()
     for mtw in (1, 2):
         if mtw == 2 and (cin % 64 or cout % 64):
             continue
-        with hip.tuning(conv2d_s2_mtw=mtw, conv2d_s2_piped=0):
-            ref = run()
-        with hip.tuning(conv2d_s2_mtw=mtw, conv2d_s2_piped=1):
-            for a, b in zip(ref, run()):
-                assert torch.equal(a, b), mtw
+        key = "conv2d_s2/%d_%d_%d_%d_%d_k%d/mtw%d" % (B, cin, cout, H, W, k, mtw)
+        assert tensor_bits(*conv2d_s2_case(hip, B, cin, cout, H, W, k, mtw)) == gold[key], key
 
 
 @pytest.mark.gpu
