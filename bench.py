@@ -1401,7 +1401,12 @@ def main():
                        # rslo_amd/headgraph.py: "fwd" = the head's forward replayed from a hipGraph (its launches are then not
                        # among the probed ones: the dense groups of `roofline` are the backward's), None = issued launch by launch
                        "head_graph": _head_graph_mode(net),
-                       "final_loss": round(loss_val, 4)},
+                       # random-init weights, W + K optimizer steps: the head still votes a pose metres off, so the two chamfer
+                       # searches of the consistency loss scan 2-3 x the tiles they scan on a trained head (0.36 + 0.15 ms per
+                       # step here against 0.12-0.19 each, profiles/r06_tail_segment.txt): the timed step is not an easy one
+                       "final_loss": round(loss_val, 4),
+                       "final_loss_note": "random-init weights after warmup + steps optimizer steps; the pose is still metres "
+                                          "off, which makes the loss's two chamfer searches 2-3 x slower than on a trained head"},
             "roofline": roof,
             "cpu_baseline": None,
         }
