@@ -313,7 +313,9 @@ class UnVoxelOdomNetICP3(nn.Module):
             cur = torch.cuda.current_stream(feats_all.device)
             side = _SIDE_STREAMS.get(feats_all.device)       # per device, outside the module: deepcopy / pickle of a
             if side is None:                                 # network must not meet a stream object
-                side = _SIDE_STREAMS[feats_all.device] = torch.cuda.Stream(feats_all.device)
+                from rslo_amd import streams as _streams      # (with several ranks: the stream the leaf work uses too)
+                side = _SIDE_STREAMS[feats_all.device] = (_streams.side_stream(feats_all.device) if _streams.sharing()
+                                                          else torch.cuda.Stream(feats_all.device))
             box = {}
             gate = torch.cuda.Event()
 
@@ -400,7 +402,8 @@ class UnVoxelOdomNetICP3(nn.Module):
             dev_ = voxels[0].device
             side_ = _SIDE_STREAMS.get(dev_)          # the covariance branch's stream (idle until the head starts)
             if side_ is None:
-                side_ = _SIDE_STREAMS[dev_] = torch.cuda.Stream(dev_)
+                from rslo_amd import streams as _streams
+                side_ = _SIDE_STREAMS[dev_] = _streams.side_stream(dev_) if _streams.sharing() else torch.cuda.Stream(dev_)
             hip_conv2d.presplit_early(self.odom_predictor, dev_, side_)
         # one multi-tensor add for the num_batches_tracked buffers of every normalisation layer (ROCm apex stand-in only)
         with getattr(_apex_parallel, "defer_batch_counts", contextlib.nullcontext)():

@@ -23,6 +23,28 @@ import os
 import torch
 
 ENABLED = os.environ.get("RSLO_WGRAD_STREAM", "1") != "0"
+# "1" (default): the dense weight gradients are issued on the covariance branch's stream; "0": on a stream of their own.
+# The step tolerates FOUR streams with work on them (training, structure plan, covariance branch, leaf work): a fifth one -- a
+# single tiny kernel per step on any further stream, which is what RCCL's own stream is in a data-parallel job -- ran the C3
+# step at HALF speed (21.3 vs 10.6 ms, profiles/r06_fifth_stream.txt; not the hardware-queue count, not a priority matter; it
+# does not happen without the leaf stream).  Sharing one side stream costs nothing at one rank (10.54-10.59 vs 10.58-10.62 ms)
+# and leaves the fourth slot to the collective library: with the extra stream active the step stays at 10.48-10.52 ms.
+SHARE_SIDE = os.environ.get("RSLO_SHARE_SIDE_STREAM", "1")
+_shared_side = {}
+
+
+def sharing():
+    return SHARE_SIDE != "0"
+
+
+def side_stream(dev):
+    """The one side stream of `dev` that the covariance branch and the leaf work share when sharing() is on."""
+    dev = torch.device(dev)
+    s = _shared_side.get(dev)
+    if s is None:
+        s = _shared_side[dev] = torch.cuda.Stream(dev)
+    return s
+
 # "1" (default): the second stage of every weight gradient of a backward pass (slab / chunk partials -> gradient, a 2-10 us
 # launch per layer: 45 dense 3x3, 5 dense 1x1, 20 sparse) is collected and run as ONE launch per stream at the end of the pass
 # (rslo_amd.capi.ReduceSink, csrc/wgrad_reduce.hip): the dense ones on the leaf stream in front of its join, the sparse ones on
@@ -117,7 +139,7 @@ def leaf(fn, inputs, params=None):
     cur = torch.cuda.current_stream(dev)
     st = _state.get(dev)
     if st is None:
-        st = _state[dev] = {"side": torch.cuda.Stream(dev), "cur": cur, "pending": False, "targets": {}, "keep": []}
+        st = _state[dev] = {"side": side_stream(dev) if sharing() else torch.cuda.Stream(dev), "cur": cur, "pending": False, "targets": {}, "keep": []}
     # (a non-leaf "parameter", e.g. a cast copy, hands the result to another backward node on the issuing stream)
     targets = _targets(st)
     pid = _pass_id()
