@@ -23,18 +23,24 @@ import os
 import torch
 
 ENABLED = os.environ.get("RSLO_WGRAD_STREAM", "1") != "0"
-# "1" (default): the dense weight gradients are issued on the covariance branch's stream; "0": on a stream of their own.
 # The step tolerates FOUR streams with work on them (training, structure plan, covariance branch, leaf work): a fifth one -- a
 # single tiny kernel per step on any further stream, which is what RCCL's own stream is in a data-parallel job -- ran the C3
 # step at HALF speed (21.3 vs 10.6 ms, profiles/r06_fifth_stream.txt; not the hardware-queue count, not a priority matter; it
-# does not happen without the leaf stream).  Sharing one side stream costs nothing at one rank (10.54-10.59 vs 10.58-10.62 ms)
-# and leaves the fourth slot to the collective library: with the extra stream active the step stays at 10.48-10.52 ms.
-SHARE_SIDE = os.environ.get("RSLO_SHARE_SIDE_STREAM", "1")
+# does not happen without the leaf stream; two further streams break the shared form as well: 23.4 ms).
+# "auto" (default): in a process with an initialised process group the dense weight gradients are issued on the covariance
+# branch's stream -- three streams of ours, the fourth slot left to the collective library; "1": always; "0": never.  Sharing
+# costs the step nothing at one rank (10.52-10.59 vs 10.54-10.62 ms) but the side work then reaches further into the encoder's
+# backward: the sparse kernels of the training stream measure 98 instead of 91 us per launch inside the step, which is why a
+# single process keeps the two streams apart.
+SHARE_SIDE = os.environ.get("RSLO_SHARE_SIDE_STREAM", "auto")
 _shared_side = {}
 
 
 def sharing():
-    return SHARE_SIDE != "0"
+    if SHARE_SIDE in ("0", "1"):
+        return SHARE_SIDE == "1"
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized()
 
 
 def side_stream(dev):

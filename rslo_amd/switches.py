@@ -23,7 +23,7 @@ SWITCHES = {
     "RSLO_OVERLAP_GRADS": ("1", "mode", "0: one gradient bucket after backward instead of the overlapped head bucket"),
     "RSLO_WGRAD_STREAM": ("1", "mode", "0: dense weight gradients on the issuing stream instead of the leaf stream (rslo_amd/streams.py)"),
     "RSLO_DEFER_WGRAD_REDUCE": ("8", "mode", "the partials -> gradient stage of the weight gradients: n >= 2: one launch per n layers and stream (rslo_amd/streams.py, csrc/wgrad_reduce.hip; same bits), 1: one launch per stream at the end of the backward pass, 0: one launch per layer"),
-    "RSLO_SHARE_SIDE_STREAM": ("1", "mode", "1: dense weight gradients on the covariance branch's stream (three streams of ours, the fourth slot left to the collective library's: a fifth active stream halves the step's speed, profiles/r06_fifth_stream.txt); 0: a stream of their own (rounds 3-6)"),
+    "RSLO_SHARE_SIDE_STREAM": ("auto", "mode", "dense weight gradients on the covariance branch's stream (three streams of ours, the fourth slot left to the collective library's: a fifth active stream halves the step's speed, profiles/r06_fifth_stream.txt): auto = in a process with an initialised process group, 1 = always, 0 = never"),
     "RSLO_COV_STREAM": ("1", "mode", "0: covariance branch on the training stream; 2: issued behind the whole head (A/B)"),
     "RSLO_HOST_LEAD": ("1", "mode", "forward passes the issuing thread may run ahead of the GPU (0: unbounded)"),
     "RSLO_NATIVE_PLAN": ("1", "mode", "0: Python-issued voxelization + rulebook plan instead of rslo_plan_encoder"),
