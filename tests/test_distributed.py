@@ -38,7 +38,12 @@ def head_loss(head, xs):
 def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    from rslo_amd import streams
+    assert streams.SHARE_SIDE == "auto" and not streams.sharing()      # a single process keeps its two side streams apart
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    # a rank of a data-parallel job issues the dense weight gradients on the covariance branch's stream: the step tolerates four
+    # active streams and the collective library's is one of them (rslo_amd/streams.py, profiles/r06_fifth_stream.txt)
+    assert streams.sharing()
     from rslo.utils.distributed_utils import (DistributedGivenIterationSamplerEpoch, average_gradients,
                                               broadcast_params)
     torch.manual_seed(rank)              # different init per rank on purpose
